@@ -1,0 +1,303 @@
+"""Generate tests/golden/*.npz by running the reference's OWN modules (verbatim, under stubs).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Every array stored here is an input fed to, or an output produced by, unmodified reference
+code loaded by oracle/ref_loader.py.  The fixtures travel to the GPU box, where
+/root/reference does not exist.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_loader as R  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: _np(v) for k, v in arrs.items()})
+    print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def peaked_heatmaps(g, b, k, h, w, sharp=1.0):
+    """Head-like heatmaps: spatial softmax of smooth blobs + noise (sum to one per map)."""
+    ys = torch.arange(h).view(1, 1, h, 1).float()
+    xs = torch.arange(w).view(1, 1, 1, w).float()
+    cx = torch.rand(b, k, 1, 1, generator=g) * (w - 1)
+    cy = torch.rand(b, k, 1, 1, generator=g) * (h - 1)
+    logit = -((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * 1.5 ** 2) * sharp * 8 + 0.3 * torch.randn(b, k, h, w, generator=g)
+    return torch.softmax(logit.reshape(b, k, -1), -1).reshape(b, k, h, w)
+
+
+def gen_decode():
+    hm = R.load("models.heads.heatmap")
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for tag, (b, k, h, w) in {"a": (3, 5, 16, 16), "b": (2, 17, 24, 32), "c": (2, 3, 64, 64)}.items():
+        x = peaked_heatmaps(g, b, k, h, w)
+        out[f"{tag}_in"] = x
+        for ds in (1, 2, 3):
+            if ds == 3 and h > 32:
+                continue
+            kp, conf = hm.run_subpixelmaxima(x.clone(), ds, torch.tensor(1000.0))
+            out[f"{tag}_kp_ds{ds}"] = kp
+            out[f"{tag}_conf_ds{ds}"] = conf
+    # flat / low-contrast maps (random-init network regime) and a border peak
+    x = torch.softmax(0.01 * torch.randn(2, 4, 16 * 16, generator=g), -1).reshape(2, 4, 16, 16)
+    out["flat_in"] = x
+    kp, conf = hm.run_subpixelmaxima(x.clone(), 2, torch.tensor(1000.0))
+    out["flat_kp_ds2"], out["flat_conf_ds2"] = kp, conf
+    x = torch.zeros(1, 4, 12, 12)
+    x[0, 0, 0, 0] = 1.0
+    x[0, 1, 11, 11] = 1.0
+    x[0, 2, 0, 7] = 1.0
+    x[0, 3, 5, 11] = 1.0
+    out["edge_in"] = x
+    kp, conf = hm.run_subpixelmaxima(x.clone(), 2, torch.tensor(1000.0))
+    out["edge_kp_ds2"], out["edge_conf_ds2"] = kp, conf
+    # upsample alone
+    u_in = torch.randn(2, 3, 10, 14, generator=g)
+    out["up_in"] = u_in
+    out["up_out"] = hm.upsample(u_in.clone())
+    save("decode", **out)
+
+
+def gen_heatmaps():
+    H = R.load("data.heatmaps")
+    g = torch.Generator().manual_seed(1)
+    kp = torch.rand(4, 6, 2, generator=g) * 128
+    kp[0, 0] = float("nan")
+    kp[1, 2, 0] = -20.0           # far out of bounds
+    kp[2, 3] = torch.tensor([129.5, 64.0])  # inside the +-1 heatmap-pixel margin (x*32/128 = 32.4)
+    kp[3, 4] = torch.tensor([140.0, 64.0])  # outside margin
+    kp[3, 5] = torch.tensor([-3.0, -3.9])   # -0.75,-0.97 on the grid: inside margin
+    vis = torch.tensor([[0, 2, 2, 1, 2, 2], [2, 2, 2, 2, 1, 0], [2, 1, 0, 2, 2, 2], [2, 2, 2, 2, 2, 2]])
+    out = {"kp": kp, "vis": vis}
+    out["hm_novis"] = H.generate_heatmaps(kp.clone(), 128, 128, (32, 32))
+    out["hm_vis"] = H.generate_heatmaps(kp.clone(), 128, 128, (32, 32), visibility=vis)
+    out["hm_rect"] = H.generate_heatmaps(kp.clone(), 128, 160, (32, 40), sigma=2.0)
+    # confidence window
+    p = torch.rand(2, 3, 20, 24, generator=g)
+    p = p / p.sum(dim=(2, 3), keepdim=True)
+    locs = torch.rand(2, 3, 2, generator=g) * torch.tensor([23.0, 19.0])
+    locs[0, 0] = torch.tensor([0.2, 0.7])
+    locs[1, 2] = torch.tensor([23.0, 19.0])
+    out["cw_p"], out["cw_locs"] = p, locs
+    out["cw_out"] = H.evaluate_heatmaps_at_location(p, locs)
+    save("heatmaps", **out)
+
+
+def gen_geometry():
+    U = R.load("data.utils")
+    B = R.load("data.bboxes")
+    g = torch.Generator().manual_seed(2)
+    kp = torch.rand(6, 8, generator=g) * 100
+    th = 0.3
+    A = torch.tensor([[1.1 * np.cos(th), -1.1 * np.sin(th), 5.0], [0.9 * np.sin(th), 0.9 * np.cos(th), -3.0]], dtype=torch.float32)
+    out = {"kp": kp, "A": A}
+    out["undo_single"] = U.undo_affine_transform_batch(kp.clone(), A, False)
+    As = A.unsqueeze(0).repeat(6, 1, 1) + 0.05 * torch.randn(6, 2, 3, generator=g)
+    out["As"] = As
+    out["undo_perframe"] = U.undo_affine_transform_batch(kp.clone(), As, False)
+    Av = As[:2]
+    out["undo_multiview"] = U.undo_affine_transform_batch(kp.clone(), Av, True)
+    out["undo_sentinel"] = U.undo_affine_transform_batch(kp.clone(), torch.tensor([-1.0]), False)
+    bbox = torch.tensor([[10.0, 20.0, 200.0, 300.0]]).repeat(6, 1) + torch.rand(6, 4, generator=g)
+    out["bbox"] = bbox
+    batch = {"frames": torch.zeros(6, 3, 128, 160), "bbox": bbox, "is_multiview": False}
+    out["m2f_single"] = B.model_to_frame_batch(batch, kp.clone())
+    bbox2 = torch.cat([bbox, bbox * 0.5 + 1.0], dim=1)
+    out["bbox2"] = bbox2
+    batch = {"frames": torch.zeros(6, 2, 3, 128, 160), "bbox": bbox2, "is_multiview": True}
+    out["m2f_multiview"] = B.model_to_frame_batch(batch, kp.clone())
+    batch = {"images": torch.zeros(6, 3, 128, 160), "bbox": bbox}
+    out["m2f_labeled"] = B.model_to_frame_batch(batch, kp.clone())
+    save("geometry", **out)
+
+
+def gen_losses():
+    L = R.load("losses.losses")
+    Fa = R.load("losses.factory")
+    H = R.load("data.heatmaps")
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    # heatmap losses
+    kp = torch.rand(5, 4, 2, generator=g) * 64
+    kp[0, 1] = float("nan")
+    kp[3, 3] = float("nan")
+    targ = H.generate_heatmaps(kp, 64, 64, (16, 16))
+    pred = peaked_heatmaps(g, 5, 4, 16, 16, sharp=0.5)
+    out["hm_targ"], out["hm_pred"] = targ, pred
+    out["heatmap_mse"] = L.HeatmapMSELoss()(targ, pred, stage="train")[0]
+    out["heatmap_kl"] = L.HeatmapKLLoss()(targ, pred, stage="train")[0]
+    out["heatmap_js"] = L.HeatmapJSLoss()(targ, pred, stage="train")[0]
+    # temporal
+    kps = torch.cumsum(torch.randn(9, 10, generator=g) * 6, dim=0) + 50
+    conf = torch.rand(9, 5, generator=g)
+    out["t_kp"], out["t_conf"] = kps, conf
+    out["temporal_plain"] = L.TemporalLoss()(kps)[0]
+    out["temporal_eps"] = L.TemporalLoss(epsilon=5.0)(kps)[0]
+    out["temporal_conf"] = L.TemporalLoss(epsilon=3.0, prob_threshold=0.3)(kps, conf)[0]
+    eps_list = [1.0, 2.0, 3.0, 4.0, 5.0]
+    out["t_eps_list"] = torch.tensor(eps_list)
+    out["temporal_epslist"] = L.TemporalLoss(epsilon=eps_list, prob_threshold=0.3)(kps, conf)[0]
+    # rmse
+    kt = torch.rand(6, 8, generator=g) * 100
+    kt[1, 2:4] = float("nan")
+    kt[4, 0:2] = float("nan")
+    kpred = kt + torch.randn(6, 8, generator=g)
+    kpred = torch.nan_to_num(kpred, nan=7.0)
+    out["r_targ"], out["r_pred"] = kt, kpred
+    out["rmse"] = L.RegressionRMSELoss()(kt, kpred)[0]
+    # pca singleview: low-rank data + noise, NaNs in the fit data
+    n, kk = 200, 7
+    basis = torch.randn(3, 2 * kk, generator=g)
+    data = torch.randn(n, 3, generator=g) @ basis * 10 + 100 + 0.5 * torch.randn(n, 2 * kk, generator=g)
+    data_nan = data.clone()
+    data_nan[5, 0:2] = float("nan")
+    data_nan[17, 6:8] = float("nan")
+    cols = [0, 1, 2, 4, 5, 6]
+    for tag, ctk in (("sv99", 0.99), ("sv3", 3)):
+        kpca = R.fit_keypoint_pca("pca_singleview", data_nan, components_to_keep=ctk,
+                                  columns_for_singleview_pca=cols)
+        out[f"pca_{tag}_mean"] = kpca.parameters["mean"]
+        out[f"pca_{tag}_kept"] = kpca.parameters["kept_eigenvectors"]
+        out[f"pca_{tag}_eps"] = kpca.parameters["epsilon"]
+        test = data[:16] + 3.0 * torch.randn(16, 2 * kk, generator=g)
+        out[f"pca_{tag}_test"] = test
+        loss = L.PCALoss.__new__(L.PCALoss)
+        L.Loss.__init__(loss, log_weight=0.0)
+        loss.device, loss.loss_name, loss.pca = "cpu", "pca_singleview", kpca
+        loss.epsilon = kpca.parameters["epsilon"]
+        out[f"pca_{tag}_loss"] = loss(test, stage="train")[0]
+        out[f"pca_{tag}_err"] = kpca.compute_reprojection_error(kpca._format_data(test))
+    out["pca_fit_data"] = data_nan
+    out["pca_cols"] = np.array(cols)
+    # pca multiview: 2 views x 4 keypoints (8 keypoints total), mirrored matches per view
+    mcm = [[0, 1, 2], [4, 5, 6]]
+    xyz = torch.randn(150, 3, 3, generator=g) * 20
+    P = torch.randn(2, 2, 3, generator=g)
+    mv = torch.full((150, 8, 2), 50.0) + 3 * torch.randn(150, 8, 2, generator=g)
+    for v in range(2):
+        for j in range(3):
+            mv[:, mcm[v][j]] = xyz[:, j] @ P[v].T + 0.3 * torch.randn(150, 2, generator=g)
+    mv = mv.reshape(150, 16)
+    kpca = R.fit_keypoint_pca("pca_multiview", mv, components_to_keep=3, mirrored_column_matches=mcm)
+    out["pca_mv_fit_data"] = mv
+    out["pca_mv_mcm"] = np.array(mcm)
+    out["pca_mv_mean"] = kpca.parameters["mean"]
+    out["pca_mv_kept"] = kpca.parameters["kept_eigenvectors"]
+    out["pca_mv_eps"] = kpca.parameters["epsilon"]
+    test = mv[:10] + 2.0 * torch.randn(10, 16, generator=g)
+    out["pca_mv_test"] = test
+    loss = L.PCALoss.__new__(L.PCALoss)
+    L.Loss.__init__(loss, log_weight=0.0)
+    loss.device, loss.loss_name, loss.pca = "cpu", "pca_multiview", kpca
+    loss.epsilon = kpca.parameters["epsilon"]
+    out["pca_mv_loss"] = loss(test, stage="train")[0]
+    # loss factory: weights + anneal
+    fac = Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    for aw in (None, 0.0, 0.5):
+        tot, logs = fac(stage="train", anneal_weight=aw, heatmaps_targ=targ, heatmaps_pred=pred)
+        out[f"fac_sup_aw{aw}"] = tot
+    fac = Fa.LossFactory({"temporal": {"log_weight": 5.0, "epsilon": 3.0, "prob_threshold": 0.3}}, None)
+    for aw in (None, 0.0, 0.5, 1.0):
+        tot, logs = fac(stage="train", anneal_weight=aw, keypoints_pred=kps, confidences=conf)
+        out[f"fac_unsup_aw{aw}"] = tot
+    out["fac_log_names"] = np.array([d["name"] for d in logs])
+    save("losses", **out)
+
+
+def gen_callbacks():
+    C = R.load("callbacks")
+
+    class M:
+        current_epoch = 0
+        global_step = 0
+
+    m = M()
+    cb = C.AnnealWeight(attr_name="total_unsupervised_importance", init_val=0.0, increase_factor=0.01,
+                        final_val=1.0, freeze_until_epoch=3)
+    cb.on_train_start(None, m)
+    vals = []
+    for e in range(120):
+        m.current_epoch = e
+        cb.on_train_epoch_start(None, m)
+        vals.append(float(m.total_unsupervised_importance))
+    ub = C.UnfreezeBackbone(unfreeze_epoch=5, initial_ratio=0.1, warm_up_ratio=1.5)
+    lrs = []
+    head_lr = 1e-3
+    for e in range(20):
+        if e == 12:
+            head_lr *= 0.5  # scheduler milestone during warm-up
+        lrs.append(0.0 if ub._warmed_up and False else (ub._get_backbone_lr(None, e, head_lr) if not ub._warmed_up else -1.0))
+    save("callbacks", anneal=np.array(vals), unfreeze_lr=np.array(lrs))
+
+
+def gen_tracker_step():
+    """One semi-supervised training step of the reference's own SemiSupervisedHeatmapTracker (ResNet-50,
+    random init, torch_seed=7) at 64x64, K=3: logged scalars + a few gradient checksums."""
+    T = R.load("models.heatmap_tracker")
+    Fa = R.load("losses.factory")
+    H = R.load("data.heatmaps")
+    g = torch.Generator().manual_seed(4)
+    K, S, Bl, HW = 3, 5, 4, 64
+    sup = Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    unsup = Fa.LossFactory({"temporal": {"log_weight": 2.0, "epsilon": 1.0, "prob_threshold": 0.0}}, None)
+    model = T.SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup,
+                                           backbone="resnet50", pretrained=False, torch_seed=7, image_size=HW)
+    model.total_unsupervised_importance = torch.tensor(0.5)
+    images = torch.randn(Bl, 3, HW, HW, generator=g)
+    kp = torch.rand(Bl, 2 * K, generator=g) * HW
+    kp[1, 2:4] = float("nan")
+    hm = H.generate_heatmaps(kp.reshape(Bl, K, 2), HW, HW, (HW // 4, HW // 4))
+    bbox_l = torch.tensor([[3.0, 5.0, 128.0, 96.0]]).repeat(Bl, 1)
+    frames = torch.randn(S, 3, HW, HW, generator=g)
+    th = 0.1
+    A = torch.tensor([[np.cos(th), -np.sin(th), 2.0], [np.sin(th), np.cos(th), -1.0]], dtype=torch.float32)
+    bbox_u = torch.tensor([[0.0, 0.0, 64.0, 64.0]]).repeat(S, 1)
+    batch = {
+        "labeled": {"images": images, "keypoints": kp.clone(), "heatmaps": hm, "bbox": bbox_l,
+                    "idxs": torch.arange(Bl)},
+        "unlabeled": {"frames": frames, "transforms": A, "bbox": bbox_u, "is_multiview": False},
+    }
+    model.train()
+    out = model.training_step(batch, 0)
+    out["loss"].backward()
+    logged = {k: float(v) for k, v in model.logged.items()}
+    with torch.no_grad():
+        heat = model.forward(images)
+    arrs = dict(images=images, keypoints=kp, heatmaps=hm, bbox_l=bbox_l, frames=frames, A=A, bbox_u=bbox_u,
+                log_names=np.array(list(logged.keys())), log_values=np.array(list(logged.values())),
+                loss=out["loss"],
+                g_head_last_w=model.head.upsampling_layers[2].weight.grad,
+                g_head_first_b=model.head.upsampling_layers[1].bias.grad,
+                g_conv1_norm=model.backbone[0].weight.grad.norm(),
+                g_l4_last_norm=model.backbone[7][2].conv3.weight.grad.norm(),
+                w_conv1_sum=model.backbone[0].weight.detach().double().sum(),
+                w_head1_sum=model.head.upsampling_layers[1].weight.detach().double().sum(),
+                heat_after_step_train_mode=heat)
+    save("tracker_step", **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_decode()
+    gen_heatmaps()
+    gen_geometry()
+    gen_losses()
+    gen_callbacks()
+    gen_tracker_step()
