@@ -1,0 +1,129 @@
+/* lp_hip.h - C ABI of liblp_hip.so: the MI355X (gfx950) kernels behind the Lightning Pose heatmap-tracker
+ * training step.
+ *
+ * The reference (paninski-lab/lightning-pose v2.4.0) is pure Python; the functions below replace the third-party
+ * native ops its hot path invokes.  Each entry point cites the reference interface
+ * it stands in for (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned, contiguous memory (torch tensor .data_ptr());
+ *     the library never allocates, frees or retains pointers; structs are passed by host pointer and only read
+ *     during the call
+ *   - `stream` is the hipStream_t the kernels are enqueued on (torch.cuda.current_stream().cuda_stream);
+ *     calls only enqueue - no device synchronisation, no host read-back
+ *   - return value: 0 = LP_OK, < 0 = argument / shape error (nothing was launched), > 0 = hipError_t
+ *   - re-entrant and thread-safe (no mutable globals)
+ *   - heat-maps are fp32 NCHW (B, K, h, w); keypoints are fp32 (B, K, 2) = the reference's (B, 2K) row layout;
+ *     backbone activations are bf16 NHWC; weights fp32 masters + bf16 GEMM copies
+ */
+#ifndef LP_HIP_H
+#define LP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lp_stream_t; /* hipStream_t */
+
+enum {
+    LP_OK = 0,
+    LP_ERR_ARGUMENT = -1,    /* null pointer / non-positive dimension  -> ValueError on the Python side */
+    LP_ERR_UNSUPPORTED = -2, /* shape outside the instantiated kernels -> NotImplementedError          */
+};
+
+enum { LP_TF_NONE = 0, LP_TF_SINGLE = 1, LP_TF_PER_FRAME = 2, LP_TF_PER_VIEW = 3 };
+
+int lp_version(void);
+const char* lp_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Decode: heat-map -> sub-pixel keypoints + confidence   (models/heads/heatmap.py:103-144 run_subpixelmaxima,
+ * :86-100 upsample, data/heatmaps.py:90-142 evaluate_heatmaps_at_location, data/utils.py:191-234
+ * undo_affine_transform_batch, data/bboxes.py:222-288 model_to_frame_batch)
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* Banded tap tables of the composite `downsample_factor` x (bicubic x2, 5x5 binomial) operator along each axis,
+ * built on the host in fp64 (lightning_pose_amd.ops.decode_tables).  ty = lp_decode_window(ds, h). */
+typedef struct lp_decode_tables {
+    const int* row_base;     /* [h]           first heat-map row of output-row group j's window                */
+    const float* row_taps;   /* [h][R][ty]    taps of output row j*R+rr relative to row_base[j], R = 2^ds        */
+    const int* col_start;    /* [w*R]         first heat-map column feeding output column c                    */
+    const float* col_taps;   /* [w*R][12]     zero padded                                                      */
+    const int* colT_start;   /* [w]           first output column fed by heat-map column q   (backward only)   */
+    const float* colT_taps;  /* [w][tc]                                                                        */
+    int ty, tx, tc;
+} lp_decode_tables;
+
+/* keypoint epilogue: undo the augmentation affine, then model px -> frame px */
+typedef struct lp_frame_map {
+    const float* transforms; /* LP_TF_SINGLE (2,3) | LP_TF_PER_FRAME (B,2,3) | LP_TF_PER_VIEW (V,2,3) | NULL     */
+    int tf_mode;
+    const float* bbox;       /* (B, 4*V) rows [x, y, h, w] per view, or NULL for identity                       */
+    int bbox_stride;         /* 4*V */
+    int kp_per_view;         /* K / V */
+    float model_h, model_w;  /* network input size */
+} lp_frame_map;
+
+int lp_decode_window(int downsample_factor, int n);
+
+/* heat (B,K,h,w) -> kp_aug (B,K,2) model px, kp_frame (B,K,2) frame px, conf (B,K), stats (B,K,4)={max,sumexp,ex,ey} */
+int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
+                  const lp_decode_tables* tables, const lp_frame_map* frame_map, float* kp_aug, float* kp_frame, float* conf,
+                  float* stats, lp_stream_t stream);
+
+/* g_heat (B,K,h,w) (+)= d loss / d heat given d loss / d kp_aug and/or d loss / d kp_frame (either may be NULL) */
+int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
+                  const lp_decode_tables* tables, const lp_frame_map* frame_map, const float* stats, const float* g_kp_aug,
+                  const float* g_kp_frame, float* g_heat, int accumulate, lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Heat-map targets and heat-map losses
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* data/heatmaps.py:11-87 generate_heatmaps.  keypoints (B,K,2) image px; visibility int32 (B,K) or NULL. */
+int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w, float sigma,
+                   float* out, lp_stream_t stream);
+
+/* losses/losses.py:229-290,314-335 HeatmapMSELoss (remove_nans -> mse*h*w -> mean).  workspace persists to bwd. */
+size_t lp_heatmap_mse_workspace_bytes(int B, int K);
+int lp_heatmap_mse_fwd(const float* targ, const float* pred, int B, int K, int h, int w, float* loss, void* workspace,
+                       lp_stream_t stream);
+int lp_heatmap_mse_bwd(const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace, const float* gout,
+                       float* gpred, int accumulate, lp_stream_t stream);
+
+/* "unimodal_mse" (not in the reference snapshot; defined by oracle/restated.py unimodal_mse_loss,
+ * structurally losses/losses.py:1129-1260).  Same workspace size as lp_heatmap_mse. */
+int lp_unimodal_mse_fwd(const float* kp_aug, const float* pred, const float* conf, int S, int K, int img_h, int img_w, int h, int w,
+                        float sigma, float prob_threshold, float* loss, void* workspace, lp_stream_t stream);
+int lp_unimodal_mse_bwd(const float* kp_aug, const float* pred, int S, int K, int img_h, int img_w, int h, int w, float sigma,
+                        const void* workspace, const float* gout, float* gpred, int accumulate, lp_stream_t stream);
+
+/* models/heads/heatmap.py:209-211 spatial_softmax2d(T=1).  Input element (b,k,i) at in[b*sb + i*si + k*sk]. */
+int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, long stride_k, int B, int K, int n, float* out,
+                     lp_stream_t stream);
+int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, float* gin, long stride_b, long stride_i,
+                     long stride_k, lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Keypoint-space losses (loss scalar + gradient for unit upstream, one launch each)
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* losses/losses.py:576-703 TemporalLoss.  kp (S,K,2), conf (S,K) or NULL, eps_per_kp (K). */
+int lp_temporal_fwd_bwd(const float* kp, const float* conf, int S, int K, const float* eps_per_kp, float prob_threshold,
+                        float* loss, float* grad_unit, lp_stream_t stream);
+
+/* losses/losses.py:528-573 PCALoss + utils/pca.py:97-190,266-309.  index (rows, points) int32 keypoint ids. */
+int lp_pca_fwd_bwd(const float* kp, int S, int K, const int* index, int rows, int points, const float* mean,
+                   const float* kept_eigenvectors, int ncomp, float epsilon, float* loss, float* grad_unit, lp_stream_t stream);
+
+/* losses/losses.py:880-996 RegressionRMSELoss (always-on diagnostic, models/base.py:528). */
+int lp_rmse_fwd(const float* kp_targ, const float* kp_pred, int n_points, float* loss, lp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LP_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of liblp_hip.so (include/lp_hip.h).  Fails loudly when the library is absent."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblp_hip.so")
+
+
+class LpHipUnavailable(RuntimeError):
+    """liblp_hip.so could not be loaded, or an op was given a non-ROCm tensor.  There is no fallback path."""
+
+
+class LpHipError(RuntimeError):
+    pass
+
+
+class DecodeTables(C.Structure):
+    _fields_ = [("row_base", C.c_void_p), ("row_taps", C.c_void_p), ("col_start", C.c_void_p),
+                ("col_taps", C.c_void_p), ("colT_start", C.c_void_p), ("colT_taps", C.c_void_p),
+                ("ty", C.c_int), ("tx", C.c_int), ("tc", C.c_int)]
+
+
+class FrameMap(C.Structure):
+    _fields_ = [("transforms", C.c_void_p), ("tf_mode", C.c_int), ("bbox", C.c_void_p), ("bbox_stride", C.c_int),
+                ("kp_per_view", C.c_int), ("model_h", C.c_float), ("model_w", C.c_float)]
+
+
+TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
+
+_P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/lp_hip.h one to one
+PROTOTYPES = {
+    "lp_version": (_I, []),
+    "lp_strerror": (C.c_char_p, [_I]),
+    "lp_decode_window": (_I, [_I, _I]),
+    "lp_decode_fwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _P]),
+    "lp_decode_bwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _I, _P]),
+    "lp_heatmap_gen": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "lp_heatmap_mse_workspace_bytes": (_Z, [_I, _I]),
+    "lp_heatmap_mse_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_heatmap_mse_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "lp_unimodal_mse_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "lp_unimodal_mse_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
+    "lp_softmax2d_fwd": (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P]),
+    "lp_softmax2d_bwd": (_I, [_P, _P, _I, _I, _I, _P, _L, _L, _L, _P]),
+    "lp_temporal_fwd_bwd": (_I, [_P, _P, _I, _I, _P, _F, _P, _P, _P]),
+    "lp_pca_fwd_bwd": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
+    "lp_rmse_fwd": (_I, [_P, _P, _I, _P, _P]),
+}
+
+
+def declare(lib: C.CDLL) -> C.CDLL:
+    """Attach the lp_hip.h prototypes to an opened library (every symbol must exist)."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded liblp_hip.so; raises LpHipUnavailable (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LpHipUnavailable(
+                f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(lightning-pose_amd/csrc/build.sh).  lightning_pose_amd has no CPU fallback.")
+        try:
+            _lib = declare(C.CDLL(LIB_PATH))
+        except OSError as e:  # e.g. no ROCm runtime on this host
+            raise LpHipUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    """Map C-ABI return codes to the reference's exception conventions."""
+    if code == 0:
+        return
+    msg = lib().lp_strerror(code).decode()
+    if code == -1:
+        raise ValueError(f"{what}: {msg}")
+    if code == -2:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise LpHipError(f"{what}: HIP error {code}: {msg}")

@@ -1,0 +1,12 @@
+// Library-level entry points of liblp_hip.so.
+#include "lp_common.h"
+
+extern "C" int lp_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char* lp_strerror(int code) {
+    if (code == LP_OK) return "ok";
+    if (code == LP_ERR_ARGUMENT) return "invalid argument (null pointer or non-positive dimension)";
+    if (code == LP_ERR_UNSUPPORTED) return "shape not covered by the instantiated kernels";
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown lp_hip error";
+}

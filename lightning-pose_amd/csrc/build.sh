@@ -1,0 +1,39 @@
+#!/usr/bin/env bash
+# Build liblp_hip.so (gfx950) in-tree.  Usage: build.sh [emu]
+#   (no arg)  hipcc --offload-arch=gfx950 -> ../liblp_hip.so      (the product library)
+#   emu       host clang++ against tests/hipemu -> ../../tests/hipemu/liblp_emu.so  (CPU logic tests only)
+set -euo pipefail
+cd "$(dirname "$0")"
+ROCM=${ROCM_PATH:-/opt/rocm}
+SRCS=(api.hip decode.hip heatmap.hip kploss.hip conv.hip bn.hip optim.hip)
+mode=${1:-hip}
+if [ "$mode" = emu ]; then
+  out=../../tests/hipemu
+  mkdir -p "$out/obj"
+  objs=()
+  for s in "${SRCS[@]}"; do
+    [ -f "$s" ] || continue
+    o="$out/obj/${s%.hip}.o"
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || [ ../../include/lp_hip.h -nt "$o" ] || [ "$out/hip/hip_runtime.h" -nt "$o" ]; then
+      "$ROCM/lib/llvm/bin/clang++" -x c++ -std=c++17 -O2 -fPIC -Wno-psabi -Wno-unused-value -I"$out" -c "$s" -o "$o" &
+    fi
+    objs+=("$o")
+  done
+  wait
+  "$ROCM/lib/llvm/bin/clang++" -shared -o "$out/liblp_emu.so" "${objs[@]}" -lpthread
+  echo "built $out/liblp_emu.so"
+else
+  mkdir -p obj
+  objs=()
+  for s in "${SRCS[@]}"; do
+    [ -f "$s" ] || continue
+    o="obj/${s%.hip}.o"
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || [ ../../include/lp_hip.h -nt "$o" ]; then
+      "$ROCM/bin/hipcc" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+    fi
+    objs+=("$o")
+  done
+  wait
+  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC -o ../liblp_hip.so "${objs[@]}"
+  echo "built $(cd .. && pwd)/liblp_hip.so"
+fi

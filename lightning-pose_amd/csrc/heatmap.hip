@@ -1,0 +1,289 @@
+// Heat-map side of the step: Gaussian target generation, masked heat-map MSE (targets supplied or generated
+// on the fly for the unimodal loss) and the head's spatial softmax, forward + backward.  gfx950, fp32.
+//
+// Reference arithmetic (paths relative to the reference tree):
+//   data/heatmaps.py:11-87                  generate_heatmaps
+//   losses/losses.py:229-290,314-335        HeatmapLoss.remove_nans / HeatmapMSELoss.compute_loss
+//   losses/losses.py:1129-1260              ReprojectionHeatmapLoss (template for unimodal_mse)
+//   models/heads/heatmap.py:209-211         spatial_softmax2d(T=1) at the end of HeatmapHead.forward
+//
+// All of these are HBM-bound streaming kernels: one workgroup per (frame, keypoint) map, float4 accesses,
+// wave-shuffle reductions, no host synchronisation (the masked-mean denominator stays on the device).
+#include "lp_common.h"
+
+namespace lp {
+
+struct GaussSpec {
+    float sx, sy;        // heat-map px per image px  (w / width, h / height)
+    float inv_two_var;   // 1 / (2 sigma^2)
+    int h, w;
+};
+
+// Centre of the Gaussian on the heat-map grid and the reference's validity rule.
+__device__ __forceinline__ bool gauss_centre(float kx, float ky, const GaussSpec& g, float& cx, float& cy) {
+    const float x = kx * g.sx, y = ky * g.sy;
+    const bool bad = (x != x) || (x < -1.f) || (x > (float)g.w + 1.f) || (y < -1.f) || (y > (float)g.h + 1.f);
+    cx = fminf(fmaxf(x, -1.f), (float)g.w + 1.f);
+    cy = fminf(fmaxf(y, -1.f), (float)g.h + 1.f);
+    return !bad;
+}
+
+__device__ __forceinline__ float gauss_at(int i, float cx, float cy, const GaussSpec& g) {
+    const int r = i / g.w, c = i - r * g.w;
+    const float dx = (float)c - cx, dy = (float)r - cy;
+    return expf(-(dx * dx + dy * dy) * g.inv_two_var);
+}
+
+// ---- generate_heatmaps -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heatmap_gen_kernel(const float* __restrict__ kp, const int* __restrict__ vis, GaussSpec g,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4];
+    const int bk = blockIdx.x, n = g.h * g.w;
+    float cx, cy;
+    const bool ok = gauss_centre(kp[bk * 2], kp[bk * 2 + 1], g, cx, cy);
+    int mode = ok ? 2 : 0;  // 2 gaussian, 1 uniform, 0 zeros
+    if (vis != nullptr) {
+        const int v = vis[bk];
+        if (v == 0) mode = 0;
+        else if (v == 1) mode = 1;
+        // v == 2: gaussian unless out of bounds / NaN
+    }
+    float* dst = out + (size_t)bk * n;
+    if (mode != 2) {
+        const float val = mode == 1 ? 1.f / (float)n : 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) dst[i] = val;
+        return;
+    }
+    float part = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) part += gauss_at(i, cx, cy, g);
+    const float total = block_sum<4>(part, red);
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = gauss_at(i, cx, cy, g) / total;
+}
+
+// ---- masked heat-map MSE -----------------------------------------------------------------------------
+// pass 1: per map, sum (t-p)^2 and a validity flag.  FROM_KP: the target is the Gaussian at kp (unimodal loss).
+template <bool FROM_KP>
+__global__ __launch_bounds__(256) void hm_rowsq_kernel(const float* __restrict__ targ, const float* __restrict__ pred,
+                                                       const float* __restrict__ kp, const float* __restrict__ conf,
+                                                       float prob_threshold, GaussSpec g, float* __restrict__ rowsum,
+                                                       int* __restrict__ valid) {
+    __shared__ float red[4];
+    const int bk = blockIdx.x, n = g.h * g.w;
+    const float* p = pred + (size_t)bk * n;
+    float part = 0.f;
+    bool ok;
+    if (FROM_KP) {
+        float cx, cy;
+        ok = gauss_centre(kp[bk * 2], kp[bk * 2 + 1], g, cx, cy) && (conf[bk] >= prob_threshold);
+        if (ok) {  // block-uniform
+            float gs = 0.f;
+            for (int i = threadIdx.x; i < n; i += 256) gs += gauss_at(i, cx, cy, g);
+            const float inv = 1.f / block_sum<4>(gs, red);
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const float d = gauss_at(i, cx, cy, g) * inv - p[i];
+                part = fmaf(d, d, part);
+            }
+        }
+    } else {
+        const float* t = targ + (size_t)bk * n;
+        float nz = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float tv = t[i];
+            const float d = tv - p[i];
+            part = fmaf(d, d, part);
+            nz += (tv != 0.f) ? 1.f : 0.f;
+        }
+        ok = block_sum<4>(nz, red) > 0.f;
+    }
+    const float total = block_sum<4>(part, red);
+    if (threadIdx.x == 0) {
+        rowsum[bk] = ok ? total : 0.f;
+        valid[bk] = ok ? 1 : 0;
+    }
+}
+
+// pass 2 (one workgroup): loss = sum(rowsum over valid) / n_valid ; mean of an empty set is NaN as in torch,
+// except for the unimodal loss, which is defined as 0 when nothing is kept.
+__global__ __launch_bounds__(256) void hm_finish_kernel(const float* __restrict__ rowsum, const int* __restrict__ valid, int rows,
+                                                        int zero_if_empty, float* __restrict__ loss, float* __restrict__ nvalid_out) {
+    __shared__ float red[4];
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        s += rowsum[i];
+        c += (float)valid[i];
+    }
+    s = block_sum<4>(s, red);
+    c = block_sum<4>(c, red);
+    if (threadIdx.x == 0) {
+        loss[0] = (c == 0.f && zero_if_empty) ? 0.f : s / c;
+        nvalid_out[0] = c;
+    }
+}
+
+// backward: grad_pred = gout * 2 (p - t) / n_valid on valid maps, 0 elsewhere
+template <bool FROM_KP>
+__global__ __launch_bounds__(256) void hm_grad_kernel(const float* __restrict__ targ, const float* __restrict__ pred,
+                                                      const float* __restrict__ kp, GaussSpec g, const int* __restrict__ valid,
+                                                      const float* __restrict__ nvalid, const float* __restrict__ gout,
+                                                      float* __restrict__ gpred, int accumulate) {
+    __shared__ float red[4];
+    const int bk = blockIdx.x, n = g.h * g.w;
+    float* gp = gpred + (size_t)bk * n;
+    if (!valid[bk]) {
+        if (!accumulate)
+            for (int i = threadIdx.x; i < n; i += 256) gp[i] = 0.f;
+        return;
+    }
+    const float scale = 2.f * gout[0] / nvalid[0];
+    const float* p = pred + (size_t)bk * n;
+    if (FROM_KP) {
+        float cx, cy;
+        gauss_centre(kp[bk * 2], kp[bk * 2 + 1], g, cx, cy);
+        float gs = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) gs += gauss_at(i, cx, cy, g);
+        const float inv = 1.f / block_sum<4>(gs, red);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float v = scale * (p[i] - gauss_at(i, cx, cy, g) * inv);
+            gp[i] = accumulate ? gp[i] + v : v;
+        }
+    } else {
+        const float* t = targ + (size_t)bk * n;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float v = scale * (p[i] - t[i]);
+            gp[i] = accumulate ? gp[i] + v : v;
+        }
+    }
+}
+
+// ---- spatial softmax (T = 1) over each (frame, keypoint) map, strided input -> dense NCHW output ------------
+// in element (b, k, i) lives at in[b*sb + i*si + k*sk]  (NHWC with padded channels: sb=n*C, si=C, sk=1).
+__global__ __launch_bounds__(256) void softmax2d_fwd_kernel(const float* __restrict__ in, long sb, long si, long sk, int K, int n,
+                                                            float* __restrict__ out) {
+    __shared__ float red[4];
+    const int bk = blockIdx.x, b = bk / K, k = bk - b * K;
+    const float* src = in + (size_t)b * sb + (size_t)k * sk;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, src[(size_t)i * si]);
+    mx = block_max<4>(mx, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += expf(src[(size_t)i * si] - mx);
+    s = block_sum<4>(s, red);
+    float* dst = out + (size_t)bk * n;
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = expf(src[(size_t)i * si] - mx) / s;
+}
+
+// dlogit_i = p_i (g_i - sum_j g_j p_j); written back in the strided layout of the logits
+__global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, int K,
+                                                            int n, float* __restrict__ gin, long sb, long si, long sk) {
+    __shared__ float red[4];
+    const int bk = blockIdx.x, b = bk / K, k = bk - b * K;
+    const float* p = prob + (size_t)bk * n;
+    const float* g = gprob + (size_t)bk * n;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) dot = fmaf(p[i], g[i], dot);
+    dot = block_sum<4>(dot, red);
+    float* dst = gin + (size_t)b * sb + (size_t)k * sk;
+    for (int i = threadIdx.x; i < n; i += 256) dst[(size_t)i * si] = p[i] * (g[i] - dot);
+}
+
+static GaussSpec make_spec(int img_h, int img_w, int h, int w, float sigma) {
+    GaussSpec g;
+    g.sx = (float)w / (float)img_w;
+    g.sy = (float)h / (float)img_h;
+    g.inv_two_var = 1.f / (2.f * sigma * sigma);
+    g.h = h;
+    g.w = w;
+    return g;
+}
+
+}  // namespace lp
+
+extern "C" int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w,
+                              float sigma, float* out, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(keypoints && out && B >= 0 && K > 0 && h > 0 && w > 0 && img_h > 0 && img_w > 0 && sigma > 0.f);
+    if (B == 0) return LP_OK;
+    hipLaunchKernelGGL(heatmap_gen_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, keypoints, visibility,
+                       make_spec(img_h, img_w, h, w, sigma), out);
+    return launch_status();
+}
+
+extern "C" size_t lp_heatmap_mse_workspace_bytes(int B, int K) { return (size_t)B * K * 8 + 16; }
+
+// workspace layout: float rowsum[B*K] | int valid[B*K] | float nvalid | pad
+extern "C" int lp_heatmap_mse_fwd(const float* targ, const float* pred, int B, int K, int h, int w, float* loss, void* workspace,
+                                  lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(targ && pred && loss && workspace && B > 0 && K > 0 && h > 0 && w > 0);
+    float* rowsum = (float*)workspace;
+    int* valid = (int*)(rowsum + (size_t)B * K);
+    float* nvalid = (float*)(valid + (size_t)B * K);
+    GaussSpec g = make_spec(1, 1, h, w, 1.f);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((hm_rowsq_kernel<false>), dim3(B * K), dim3(256), 0, st, targ, pred, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, g, rowsum, valid);
+    hipLaunchKernelGGL(hm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)rowsum, (const int*)valid, B * K, 0, loss, nvalid);
+    return launch_status();
+}
+
+extern "C" int lp_heatmap_mse_bwd(const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace,
+                                  const float* gout, float* gpred, int accumulate, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(targ && pred && workspace && gout && gpred && B > 0 && K > 0 && h > 0 && w > 0);
+    const float* rowsum = (const float*)workspace;
+    const int* valid = (const int*)(rowsum + (size_t)B * K);
+    const float* nvalid = (const float*)(valid + (size_t)B * K);
+    GaussSpec g = make_spec(1, 1, h, w, 1.f);
+    hipLaunchKernelGGL((hm_grad_kernel<false>), dim3(B * K), dim3(256), 0, (hipStream_t)stream, targ, pred, (const float*)nullptr,
+                       g, valid, nvalid, gout, gpred, accumulate);
+    return launch_status();
+}
+
+extern "C" int lp_unimodal_mse_fwd(const float* kp_aug, const float* pred, const float* conf, int S, int K, int img_h, int img_w,
+                                   int h, int w, float sigma, float prob_threshold, float* loss, void* workspace,
+                                   lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(kp_aug && pred && conf && loss && workspace && S > 0 && K > 0 && h > 0 && w > 0 && sigma > 0.f);
+    float* rowsum = (float*)workspace;
+    int* valid = (int*)(rowsum + (size_t)S * K);
+    float* nvalid = (float*)(valid + (size_t)S * K);
+    GaussSpec g = make_spec(img_h, img_w, h, w, sigma);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((hm_rowsq_kernel<true>), dim3(S * K), dim3(256), 0, st, (const float*)nullptr, pred, kp_aug, conf,
+                       prob_threshold, g, rowsum, valid);
+    hipLaunchKernelGGL(hm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)rowsum, (const int*)valid, S * K, 1, loss, nvalid);
+    return launch_status();
+}
+
+extern "C" int lp_unimodal_mse_bwd(const float* kp_aug, const float* pred, int S, int K, int img_h, int img_w, int h, int w,
+                                   float sigma, const void* workspace, const float* gout, float* gpred, int accumulate,
+                                   lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(kp_aug && pred && workspace && gout && gpred && S > 0 && K > 0 && h > 0 && w > 0 && sigma > 0.f);
+    const float* rowsum = (const float*)workspace;
+    const int* valid = (const int*)(rowsum + (size_t)S * K);
+    const float* nvalid = (const float*)(valid + (size_t)S * K);
+    GaussSpec g = make_spec(img_h, img_w, h, w, sigma);
+    hipLaunchKernelGGL((hm_grad_kernel<true>), dim3(S * K), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, pred, kp_aug, g,
+                       valid, nvalid, gout, gpred, accumulate);
+    return launch_status();
+}
+
+extern "C" int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, long stride_k, int B, int K, int n, float* out,
+                                lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(in && out && B >= 0 && K > 0 && n > 0);
+    if (B == 0) return LP_OK;
+    hipLaunchKernelGGL(softmax2d_fwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, in, stride_b, stride_i, stride_k, K, n, out);
+    return launch_status();
+}
+
+extern "C" int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, float* gin, long stride_b, long stride_i,
+                                long stride_k, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(prob && gprob && gin && B >= 0 && K > 0 && n > 0);
+    if (B == 0) return LP_OK;
+    hipLaunchKernelGGL(softmax2d_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, prob, gprob, K, n, gin, stride_b, stride_i,
+                       stride_k);
+    return launch_status();
+}

@@ -1,0 +1,162 @@
+// Keypoint-space losses of the step: temporal difference, PCA reprojection (single- and multi-view) and the
+// always-on RMSE diagnostic.  gfx950, fp32.  Each is a single small workgroup: the inputs are (S, K, 2) keypoints,
+// < 20 KB per pass, so these are launch-latency bound; what matters is that each loss is ONE launch producing
+// the scalar AND its unit-upstream gradient (the reference issues S-1 logical_or launches for the temporal mask
+// alone, losses/losses.py:643-644) and that no masked reduction synchronises with the host.
+//
+// Reference arithmetic (paths relative to the reference tree):
+//   losses/losses.py:576-703   TemporalLoss
+//   losses/losses.py:528-573   PCALoss ; utils/pca.py:97-190 (formatting), :266-309 (reprojection error)
+//   losses/losses.py:880-996   RegressionMSELoss.remove_nans / RegressionRMSELoss.compute_loss
+#include "lp_common.h"
+
+namespace lp {
+
+constexpr int kMaxPcaDim = 64;   // 2 * points per PCA sample
+constexpr int kMaxPcaComp = 16;
+
+// ---- temporal ------------------------------------------------------------------------------------------
+// loss = mean_{t<S-1,k} relu(mask * ||kp[t+1,k] - kp[t,k]|| - eps_k);  grad (for upstream 1) written per keypoint.
+__global__ __launch_bounds__(256) void temporal_kernel(const float* __restrict__ kp, const float* __restrict__ conf, int S, int K,
+                                                       const float* __restrict__ eps, float thr, float* __restrict__ loss,
+                                                       float* __restrict__ grad) {
+    __shared__ float red[4];
+    const float inv_n = 1.f / (float)((S - 1) * K);
+    float part = 0.f;
+    for (int e = threadIdx.x; e < S * K; e += 256) {
+        const int t = e / K, k = e - t * K;
+        const float x = kp[e * 2], y = kp[e * 2 + 1];
+        const bool low = conf != nullptr && conf[e] < thr;
+        float gx = 0.f, gy = 0.f;
+        if (t + 1 < S) {  // forward difference (t, t+1): this thread owns its loss term
+            const int e2 = e + K;
+            const float dx = kp[e2 * 2] - x, dy = kp[e2 * 2 + 1] - y;
+            const bool masked = low || (conf != nullptr && conf[e2] < thr);
+            const float d = masked ? 0.f : sqrtf(dx * dx + dy * dy);
+            const float v = d - eps[k];
+            if (v > 0.f) {
+                part += v;
+                gx -= dx / d;
+                gy -= dy / d;
+            }
+        }
+        if (t > 0) {  // backward difference (t-1, t): gradient only
+            const int e0 = e - K;
+            const float dx = x - kp[e0 * 2], dy = y - kp[e0 * 2 + 1];
+            const bool masked = low || (conf != nullptr && conf[e0] < thr);
+            const float d = masked ? 0.f : sqrtf(dx * dx + dy * dy);
+            if (d - eps[k] > 0.f) {
+                gx += dx / d;
+                gy += dy / d;
+            }
+        }
+        grad[e * 2] = gx * inv_n;
+        grad[e * 2 + 1] = gy * inv_n;
+    }
+    part = block_sum<4>(part, red);
+    if (threadIdx.x == 0) loss[0] = part * inv_n;
+}
+
+// ---- PCA reprojection ---------------------------------------------------------------------------------
+// sample (s, j): x[2p], x[2p+1] = kp[s, idx[j*P + p]];  r = (x-mu) - V^T V (x-mu);  loss = mean relu(||r_p|| - eps).
+// singleview: rows = 1, P = selected keypoints;  multiview: rows = matched keypoints, P = views.
+__global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ kp, int S, int K, const int* __restrict__ idx, int rows,
+                                                  int P, const float* __restrict__ mean, const float* __restrict__ evecs, int ncomp,
+                                                  float eps, float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float red[4];
+    const int D = 2 * P;
+    const float inv_n = 1.f / (float)(S * rows * P);
+    for (int i = threadIdx.x; i < S * K * 2; i += 256) grad[i] = 0.f;
+    __syncthreads();
+    float part = 0.f;
+    for (int smp = threadIdx.x; smp < S * rows; smp += 256) {
+        const int s = smp / rows, j = smp - s * rows;
+        float xc[kMaxPcaDim], r[kMaxPcaDim], u[kMaxPcaDim];
+        for (int p = 0; p < P; ++p) {
+            const int kk = idx[j * P + p];
+            xc[2 * p] = kp[(s * K + kk) * 2] - mean[2 * p];
+            xc[2 * p + 1] = kp[(s * K + kk) * 2 + 1] - mean[2 * p + 1];
+        }
+        for (int d = 0; d < D; ++d) r[d] = xc[d];
+        for (int c = 0; c < ncomp; ++c) {
+            float dot = 0.f;
+            for (int d = 0; d < D; ++d) dot = fmaf(xc[d], evecs[c * D + d], dot);
+            for (int d = 0; d < D; ++d) r[d] = fmaf(-dot, evecs[c * D + d], r[d]);
+        }
+        for (int p = 0; p < P; ++p) {
+            const float n = sqrtf(r[2 * p] * r[2 * p] + r[2 * p + 1] * r[2 * p + 1]);
+            const float v = n - eps;
+            if (v > 0.f) {
+                part += v;
+                u[2 * p] = r[2 * p] / n * inv_n;
+                u[2 * p + 1] = r[2 * p + 1] / n * inv_n;
+            } else {
+                u[2 * p] = 0.f;
+                u[2 * p + 1] = 0.f;
+            }
+        }
+        // dL/dx = (I - V^T V) u   (the projector is symmetric)
+        for (int c = 0; c < ncomp; ++c) {
+            float dot = 0.f;
+            for (int d = 0; d < D; ++d) dot = fmaf(u[d], evecs[c * D + d], dot);
+            for (int d = 0; d < D; ++d) xc[d] = (c == 0 ? u[d] : xc[d]) - dot * evecs[c * D + d];
+        }
+        if (ncomp == 0)
+            for (int d = 0; d < D; ++d) xc[d] = u[d];
+        for (int p = 0; p < P; ++p) {
+            const int kk = idx[j * P + p];
+            atomicAdd(&grad[(s * K + kk) * 2], xc[2 * p]);
+            atomicAdd(&grad[(s * K + kk) * 2 + 1], xc[2 * p + 1]);
+        }
+    }
+    part = block_sum<4>(part, red);
+    if (threadIdx.x == 0) loss[0] = part * inv_n;
+}
+
+// ---- RMSE diagnostic ------------------------------------------------------------------------------------
+// mean over labelled keypoints (target x and y both non-NaN) of sqrt(((tx-px)^2 + (ty-py)^2) / 2)
+__global__ __launch_bounds__(256) void rmse_kernel(const float* __restrict__ targ, const float* __restrict__ pred, int n_points,
+                                                   float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f, c = 0.f;
+    for (int e = threadIdx.x; e < n_points; e += 256) {
+        const float tx = targ[e * 2], ty = targ[e * 2 + 1];
+        if (tx == tx && ty == ty) {
+            const float dx = tx - pred[e * 2], dy = ty - pred[e * 2 + 1];
+            s += sqrtf((dx * dx + dy * dy) * 0.5f);
+            c += 1.f;
+        }
+    }
+    s = block_sum<4>(s, red);
+    c = block_sum<4>(c, red);
+    if (threadIdx.x == 0) loss[0] = s / c;
+}
+
+}  // namespace lp
+
+extern "C" int lp_temporal_fwd_bwd(const float* kp, const float* conf, int S, int K, const float* eps_per_kp, float prob_threshold,
+                                   float* loss, float* grad_unit, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(kp && eps_per_kp && loss && grad_unit && S >= 2 && K > 0);
+    hipLaunchKernelGGL(temporal_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kp, conf, S, K, eps_per_kp, prob_threshold, loss,
+                       grad_unit);
+    return launch_status();
+}
+
+extern "C" int lp_pca_fwd_bwd(const float* kp, int S, int K, const int* index, int rows, int points, const float* mean,
+                              const float* kept_eigenvectors, int ncomp, float epsilon, float* loss, float* grad_unit,
+                              lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(kp && index && mean && kept_eigenvectors && loss && grad_unit && S > 0 && K > 0 && rows > 0 && points > 0);
+    if (2 * points > kMaxPcaDim || ncomp > kMaxPcaComp || ncomp < 0) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pca_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kp, S, K, index, rows, points, mean, kept_eigenvectors,
+                       ncomp, epsilon, loss, grad_unit);
+    return launch_status();
+}
+
+extern "C" int lp_rmse_fwd(const float* kp_targ, const float* kp_pred, int n_points, float* loss, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(kp_targ && kp_pred && loss && n_points > 0);
+    hipLaunchKernelGGL(rmse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kp_targ, kp_pred, n_points, loss);
+    return launch_status();
+}

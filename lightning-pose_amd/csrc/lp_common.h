@@ -1,0 +1,81 @@
+// Shared device helpers for the lp_hip kernels (gfx950 / CDNA4, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lp_hip.h"
+
+namespace lp {
+
+constexpr int kWave = 64;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// ---- wave / block reductions ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// Sum over a workgroup of NW waves (blockDim.x == 64*NW); every thread gets the total.  `scratch` holds
+// >= NW floats of LDS; the trailing barrier makes it immediately reusable.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += scratch[i];
+    __syncthreads();
+    return t;
+}
+
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, scratch[i]);
+    __syncthreads();
+    return t;
+}
+
+// ---- host-side launch epilogue ------------------------------------------------------------------
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LP_OK : (int)e;
+}
+
+}  // namespace lp
+
+#define LP_REQUIRE(cond)                    \
+    do {                                    \
+        if (!(cond)) return LP_ERR_ARGUMENT; \
+    } while (0)

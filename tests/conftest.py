@@ -8,6 +8,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+import _lp_bootstrap  # noqa: E402,F401  registers lightning_pose_amd
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

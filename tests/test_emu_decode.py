@@ -1,0 +1,97 @@
+"""Kernel-logic tests of csrc/decode.hip on the CPU emulator (tests/hipemu) against the oracle and the golden
+vectors of the verbatim reference.  These run the SAME kernel source the GPU runs; the -m gpu tests repeat the
+comparison on the real device through the product path."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restated as O
+from tests.hipemu import emu
+from lightning_pose_amd import _lib
+
+
+@pytest.mark.parametrize("tag,dss", [("a", (1, 2, 3)), ("b", (1, 2)), ("edge", (2,)), ("flat", (2,))])
+def test_decode_fwd_matches_reference_golden(golden, tag, dss):
+    g = golden("decode")
+    heat = g[f"{tag}_in"]
+    for ds in dss:
+        kp_aug, kp_frame, conf, _ = emu.decode_fwd(heat, ds)
+        want_kp = g[f"{tag}_kp_ds{ds}"].reshape(kp_aug.shape)
+        np.testing.assert_allclose(kp_aug, want_kp, atol=1e-4, rtol=0)
+        np.testing.assert_allclose(kp_frame, want_kp, atol=1e-4, rtol=0)  # identity frame map
+        np.testing.assert_allclose(conf, g[f"{tag}_conf_ds{ds}"], atol=2e-5, rtol=0)
+
+
+def test_decode_fwd_kat_delta():
+    """reference tests/models/heads/test_heatmap.py:124-170: delta at (2,2),(4,4) on 8x8 -> val * 2^ds, conf 1."""
+    x = np.zeros((1, 2, 8, 8), np.float32)
+    x[0, 0, 2, 2] = 1
+    x[0, 1, 4, 4] = 1
+    for ds in (1, 2):
+        kp, _, conf, _ = emu.decode_fwd(x, ds)
+        np.testing.assert_allclose(kp.reshape(-1), np.array([2, 2, 4, 4]) * 2.0 ** ds, atol=1e-4)
+        np.testing.assert_allclose(conf, 1.0, atol=1e-6)
+
+
+def test_decode_fwd_wide_map_two_strips():
+    """W = 4*80 = 320 > 256 exercises the second (partial) column strip."""
+    g = torch.Generator().manual_seed(5)
+    heat = torch.softmax(3 * torch.randn(1, 3, 20 * 80, generator=g), -1).reshape(1, 3, 20, 80)
+    heat[0, 1] = 0
+    heat[0, 1, 10, 75] = 1.0  # peak in the second strip
+    kp, _, conf, _ = emu.decode_fwd(heat.numpy(), 2)
+    wkp, wconf = O.soft_argmax(heat, 2, 1000.0)
+    np.testing.assert_allclose(kp.reshape(1, -1), wkp.numpy(), atol=1e-4)
+    np.testing.assert_allclose(conf, wconf.numpy(), atol=2e-5)
+
+
+def test_decode_frame_map(golden):
+    g = golden("geometry")
+    gen = torch.Generator().manual_seed(6)
+    s, k = 6, 4
+    heat = torch.softmax(4 * torch.randn(s, k, 16 * 16, generator=gen), -1).reshape(s, k, 16, 16)
+    kp_aug, _ = O.soft_argmax(heat, 2, 1000.0)
+    bbox = g.t("bbox")
+    for mode, tf in ((_lib.TF_SINGLE, g.t("A")), (_lib.TF_PER_FRAME, g.t("As")), (_lib.TF_NONE, None)):
+        fm, keep = emu.frame_map(tf.numpy() if tf is not None else None, mode, bbox.numpy(), 1, k, 64, 64)
+        _, kp_frame, _, _ = emu.decode_fwd(heat.numpy(), 2, fm=fm)
+        want = O.model_to_frame(O.undo_affine(kp_aug, tf if tf is not None else torch.tensor([-1.0])), 64, 64, bbox)
+        np.testing.assert_allclose(kp_frame.reshape(s, -1), want.numpy(), atol=2e-4)
+    # multiview: 2 views x 2 keypoints, per-view transforms and bboxes
+    fm, keep = emu.frame_map(g.t("As")[:2].numpy(), _lib.TF_PER_VIEW, g.t("bbox2").numpy(), 2, k, 64, 64)
+    _, kp_frame, _, _ = emu.decode_fwd(heat.numpy(), 2, fm=fm)
+    want = O.model_to_frame(O.undo_affine(kp_aug, g.t("As")[:2], True), 64, 64, g.t("bbox2"), 2)
+    np.testing.assert_allclose(kp_frame.reshape(s, -1), want.numpy(), atol=2e-4)
+
+
+@pytest.mark.parametrize("shape,ds", [((2, 3, 16, 16), 2), ((1, 2, 12, 20), 1), ((1, 2, 16, 16), 3), ((1, 2, 20, 80), 2)])
+def test_decode_bwd_matches_autograd(shape, ds):
+    gen = torch.Generator().manual_seed(7)
+    b, k, h, w = shape
+    heat = torch.softmax(2 * torch.randn(b, k, h * w, generator=gen), -1).reshape(shape).requires_grad_(True)
+    kp, _ = O.soft_argmax(heat, ds, 1000.0)
+    gk = torch.randn(kp.shape, generator=gen)
+    (kp * gk).sum().backward()
+    _, _, _, stats = emu.decode_fwd(heat.detach().numpy(), ds)
+    g_heat = emu.decode_bwd(heat.detach().numpy(), ds, stats, g_aug=gk.reshape(b, k, 2).numpy())
+    ref = heat.grad.numpy()
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(g_heat, ref, atol=2e-3 * scale, rtol=0)
+
+
+def test_decode_bwd_through_frame_map(golden):
+    g = golden("geometry")
+    gen = torch.Generator().manual_seed(8)
+    s, k = 6, 4
+    heat = torch.softmax(2 * torch.randn(s, k, 16 * 16, generator=gen), -1).reshape(s, k, 16, 16).requires_grad_(True)
+    kp_aug, _ = O.soft_argmax(heat, 2, 1000.0)
+    kp_fr = O.model_to_frame(O.undo_affine(kp_aug, g.t("As")), 64, 64, g.t("bbox"))
+    ga, gf = torch.randn(kp_aug.shape, generator=gen), torch.randn(kp_fr.shape, generator=gen)
+    ((kp_aug * ga).sum() + (kp_fr * gf).sum()).backward()
+    fm, keep = emu.frame_map(g["As"], _lib.TF_PER_FRAME, g["bbox"], 1, k, 64, 64)
+    _, _, _, stats = emu.decode_fwd(heat.detach().numpy(), 2, fm=fm)
+    g_heat = emu.decode_bwd(heat.detach().numpy(), 2, stats, g_aug=ga.reshape(s, k, 2).numpy(),
+                            g_frame=gf.reshape(s, k, 2).numpy(), fm=fm)
+    ref = heat.grad.numpy()
+    np.testing.assert_allclose(g_heat, ref, atol=2e-3 * np.abs(ref).max(), rtol=0)

@@ -1,0 +1,117 @@
+"""Kernel-logic tests of csrc/heatmap.hip and csrc/kploss.hip on the CPU emulator vs the reference golden vectors
+and the oracle (values and gradients)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restated as O
+from tests.hipemu import emu
+
+
+def test_heatmap_gen_golden(golden):
+    g = golden("heatmaps")
+    np.testing.assert_allclose(emu.heatmap_gen(g["kp"], None, 128, 128, 32, 32), g["hm_novis"], atol=2e-7)
+    np.testing.assert_allclose(emu.heatmap_gen(g["kp"], g["vis"], 128, 128, 32, 32), g["hm_vis"], atol=2e-7)
+    np.testing.assert_allclose(emu.heatmap_gen(g["kp"], None, 128, 160, 32, 40, sigma=2.0), g["hm_rect"], atol=2e-7)
+
+
+def test_heatmap_mse_golden_and_grad(golden):
+    g = golden("losses")
+    loss, grad = emu.heatmap_mse(g["hm_targ"], g["hm_pred"], gout=0.7)
+    assert loss == pytest.approx(float(g["heatmap_mse"]), rel=1e-5)
+    p = g.t("hm_pred").clone().requires_grad_(True)
+    (0.7 * O.heatmap_mse_loss(g.t("hm_targ"), p)).backward()
+    np.testing.assert_allclose(grad, p.grad.numpy(), atol=1e-7, rtol=1e-5)
+
+
+def test_heatmap_mse_all_invalid_is_nan():
+    t = np.zeros((2, 2, 8, 8), np.float32)
+    loss, _ = emu.heatmap_mse(t, np.full_like(t, 0.1))
+    assert np.isnan(loss)
+
+
+def test_unimodal_mse_matches_oracle():
+    gen = torch.Generator().manual_seed(11)
+    s, k, h, w = 5, 4, 16, 16
+    pred = torch.softmax(3 * torch.randn(s, k, h * w, generator=gen), -1).reshape(s, k, h, w).requires_grad_(True)
+    kp = torch.rand(s, 2 * k, generator=gen) * 64
+    kp[0, 0:2] = float("nan")
+    kp[1, 2] = 500.0
+    conf = torch.rand(s, k, generator=gen)
+    want = O.unimodal_mse_loss(kp, pred, conf, 64, 64, prob_threshold=0.4)
+    (1.3 * want).backward()
+    loss, grad = emu.unimodal_mse(kp.reshape(s, k, 2).numpy(), pred.detach().numpy(), conf.numpy(), 64, 64, 0.4, gout=1.3)
+    assert loss == pytest.approx(float(want), rel=1e-5)
+    np.testing.assert_allclose(grad, pred.grad.numpy(), atol=1e-7, rtol=1e-4)
+    loss0, grad0 = emu.unimodal_mse(kp.reshape(s, k, 2).numpy(), pred.detach().numpy(), conf.numpy(), 64, 64, 2.0)
+    assert loss0 == 0.0 and not grad0.any()
+
+
+def test_softmax2d_fwd_bwd():
+    gen = torch.Generator().manual_seed(12)
+    b, k, n, c = 2, 5, 48, 8
+    logits = torch.randn(b, n, c, generator=gen)
+    x = logits[:, :, :k].permute(0, 2, 1).clone().requires_grad_(True)  # (b,k,n)
+    p = torch.softmax(x, -1)
+    gp = torch.randn(b, k, n, generator=gen)
+    (p * gp).sum().backward()
+    got = emu.softmax2d(logits.numpy(), k)
+    np.testing.assert_allclose(got, p.detach().numpy(), atol=1e-7, rtol=1e-5)
+    gin = emu.softmax2d_bwd(got, gp.numpy(), c)
+    np.testing.assert_allclose(gin[:, :, :k], x.grad.permute(0, 2, 1).numpy(), atol=1e-6, rtol=1e-4)
+    assert not gin[:, :, k:].any()
+
+
+def test_temporal_golden_and_grad(golden):
+    g = golden("losses")
+    kp, conf = g["t_kp"], g["t_conf"]
+    s = kp.shape[0]
+    kp3 = kp.reshape(s, -1, 2)
+    assert emu.temporal(kp3, None, 0.0, 0.0)[0] == pytest.approx(float(g["temporal_plain"]), rel=1e-5)
+    assert emu.temporal(kp3, None, 5.0, 0.0)[0] == pytest.approx(float(g["temporal_eps"]), rel=1e-5)
+    assert emu.temporal(kp3, conf, 3.0, 0.3)[0] == pytest.approx(float(g["temporal_conf"]), rel=1e-5)
+    loss, grad = emu.temporal(kp3, conf, g["t_eps_list"], 0.3)
+    assert loss == pytest.approx(float(g["temporal_epslist"]), rel=1e-5)
+    x = g.t("t_kp").clone().requires_grad_(True)
+    O.temporal_loss(x, g.t("t_conf"), g.t("t_eps_list"), 0.3).backward()
+    np.testing.assert_allclose(grad.reshape(s, -1), x.grad.numpy(), atol=1e-6, rtol=1e-4)
+
+
+def test_temporal_kat():
+    """reference tests/losses/test_losses.py:314-408."""
+    kp = np.array([[[0.0, 0.0]], [[2 ** 0.5, 2 ** 0.5]]], np.float32)
+    assert emu.temporal(kp, None, 0.0, 0.0)[0] == pytest.approx(2.0, rel=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["sv99", "sv3"])
+def test_pca_singleview_golden_and_grad(golden, tag):
+    g = golden("losses")
+    cols = g["pca_cols"].astype(np.int32).reshape(1, -1)
+    test = g[f"pca_{tag}_test"]
+    s = test.shape[0]
+    loss, grad = emu.pca(test.reshape(s, -1, 2), cols, g[f"pca_{tag}_mean"], g[f"pca_{tag}_kept"], float(g[f"pca_{tag}_eps"]))
+    assert loss == pytest.approx(float(g[f"pca_{tag}_loss"]), rel=1e-4, abs=1e-6)
+    x = g.t(f"pca_{tag}_test").clone().requires_grad_(True)
+    O.pca_loss(O.pca_format_singleview(x, [int(c) for c in cols[0]]), g.t(f"pca_{tag}_mean"), g.t(f"pca_{tag}_kept"),
+               float(g[f"pca_{tag}_eps"])).backward()
+    np.testing.assert_allclose(grad.reshape(s, -1), x.grad.numpy(), atol=1e-6, rtol=1e-3)
+
+
+def test_pca_multiview_golden_and_grad(golden):
+    g = golden("losses")
+    mcm = g["pca_mv_mcm"].astype(np.int32)  # (views, J)
+    index = np.ascontiguousarray(mcm.T)     # (J rows, V points)
+    test = g["pca_mv_test"]
+    s = test.shape[0]
+    loss, grad = emu.pca(test.reshape(s, -1, 2), index, g["pca_mv_mean"], g["pca_mv_kept"], float(g["pca_mv_eps"]))
+    assert loss == pytest.approx(float(g["pca_mv_loss"]), rel=1e-4, abs=1e-6)
+    x = g.t("pca_mv_test").clone().requires_grad_(True)
+    O.pca_loss(O.pca_format_multiview(x, [[int(c) for c in r] for r in mcm]), g.t("pca_mv_mean"), g.t("pca_mv_kept"),
+               float(g["pca_mv_eps"])).backward()
+    np.testing.assert_allclose(grad.reshape(s, -1), x.grad.numpy(), atol=1e-6, rtol=1e-3)
+
+
+def test_rmse_golden(golden):
+    g = golden("losses")
+    assert emu.rmse(g["r_targ"], g["r_pred"]) == pytest.approx(float(g["rmse"]), rel=1e-5)
