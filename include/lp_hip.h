@@ -105,7 +105,8 @@ int lp_unimodal_mse_bwd(const float* kp_aug, const float* pred, int S, int K, in
 /* models/heads/heatmap.py:209-211 spatial_softmax2d(T=1).  Input element (b,k,i) at in[b*sb + i*si + k*sk]. */
 int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, long stride_k, int B, int K, int n, float* out,
                      lp_stream_t stream);
-int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, float* gin, long stride_b, long stride_i,
+/* gin_bf16: bf16 gradient of the logits in the same strided layout (it feeds the MFMA kernels) */
+int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, void* gin_bf16, long stride_b, long stride_i,
                      long stride_k, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -122,6 +123,62 @@ int lp_pca_fwd_bwd(const float* kp, int S, int K, const int* index, int rows, in
 
 /* losses/losses.py:880-996 RegressionRMSELoss (always-on diagnostic, models/base.py:528). */
 int lp_rmse_fwd(const float* kp_targ, const float* kp_pred, int n_points, float* loss, lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Backbone / head contractions on the matrix cores (bf16 NHWC activations, fp32 accumulate).
+ * Replace cuDNN behind `self.backbone(images)` (models/base.py:398; models/backbones/factory.py:322-325) and
+ * nn.ConvTranspose2d in the head (models/heads/heatmap.py:60-69).  A ConvTranspose2d(k3,s2,p1,op1) forward is
+ * lp_conv_dgrad of the mirrored convolution, its data-gradient is lp_conv_fwd, its weight-gradient lp_conv_wgrad.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct lp_conv_geom {
+    int B, Hi, Wi, Ci; /* input  tensor, NHWC */
+    int Ho, Wo, Co;    /* output tensor, NHWC */
+    int R, S, stride, pad;
+} lp_conv_geom;
+
+/* w: bf16 [Co][R][S][Ci] (Ci % 64 == 0).  Output row-major [B*Ho*Wo][ldo], columns < n_store written. */
+int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
+                int n_store, lp_stream_t stream);
+/* wd: bf16 [Ci][R][S][Co] (Co % 64 == 0); optional bf16 addend (same layout as dx) is summed in. */
+int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend, void* dx_bf16,
+                  float* dx_f32, int ldo, int n_store, lp_stream_t stream);
+/* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split. */
+int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, lp_stream_t stream);
+/* ResNet stem 7x7/2: x4 = NHWC4 bf16 (channel 3 zero), weights / gradients in the padded [64][8][8][4] layout. */
+int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_stream_t stream);
+int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * HBM-bound glue of the trunk (NHWC bf16): BatchNorm2d training mode, ReLU, residual add, MaxPool2d(3,2,1),
+ * PixelShuffle(2), input layout.  torchvision Bottleneck semantics; called from
+ * `self.backbone(images)` (models/base.py:398) and HeatmapHead.forward (models/heads/heatmap.py:44,208).
+ * ------------------------------------------------------------------------------------------------------ */
+/* sums (2,C) fp32, accumulated into (zero first): [sum x, sum x^2] over the M rows.  SyncBatchNorm = all-reduce it. */
+int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream);
+int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
+                   float* running_mean, float* running_var, lp_stream_t stream);
+int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
+                int relu, int M, int C, void* y, lp_stream_t stream);
+/* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL); dbeta/dgamma accumulate too */
+int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
+                     float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
+int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
+                    const float* sums, float count, int M, int C, void* dx, void* dres, lp_stream_t stream);
+int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, lp_stream_t stream);
+int lp_maxpool_bwd(const void* x, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
+int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_bf16, lp_stream_t stream);
+/* (B,h,w,4*c_out) -> (B,2h,2w,c_out); inverse = 1 maps the gradient back */
+int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int inverse, void* out, lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Optimiser: torch.optim.Adam / AdamW semantics (models/base.py:458-479) over one flat fp32 range, also emitting
+ * the bf16 copy the GEMMs read.  lr may be 0 (frozen backbone, callbacks.py:79-196): moments still move.
+ * ------------------------------------------------------------------------------------------------------ */
+int lp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int decoupled, int step, float grad_scale, void* params_bf16, lp_stream_t stream);
+int lp_cast_bf16(const float* src, size_t n, void* dst, lp_stream_t stream);
+/* dst[c][b][a] = src[a][b][c] on bf16: weights [Co][R*S][Ci] -> data-gradient copy [Ci][R*S][Co] */
+int lp_permute_cba(const void* src, int A, int B, int C, void* dst, lp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,10 @@ class FrameMap(C.Structure):
                 ("kp_per_view", C.c_int), ("model_h", C.c_float), ("model_w", C.c_float)]
 
 
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "R", "S", "stride", "pad")]
+
+
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -50,6 +54,23 @@ PROTOTYPES = {
     "lp_temporal_fwd_bwd": (_I, [_P, _P, _I, _I, _P, _F, _P, _P, _P]),
     "lp_pca_fwd_bwd": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "lp_rmse_fwd": (_I, [_P, _P, _I, _P, _P]),
+    "lp_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _I, _P]),
+    "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _I, _I, _P]),
+    "lp_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P]),
+    "lp_stem_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P]),
+    "lp_stem_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P]),
+    "lp_bn_stats": (_I, [_P, _I, _I, _P, _P]),
+    "lp_bn_finalize": (_I, [_P, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
+    "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "lp_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
+    "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
+    "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),
+    "lp_permute_cba": (_I, [_P, _I, _I, _I, _P, _P]),
 }
 
 

@@ -1,0 +1,411 @@
+// HBM-bound glue of the ResNet-50 trunk on NHWC bf16 activations: training-mode BatchNorm (statistics, apply +
+// ReLU + residual, backward), 3x3/2 max-pool, input layout conversion and the head's PixelShuffle.  gfx950.
+//
+// Replaces the ATen/cuDNN BatchNorm2d, ReLU, MaxPool2d and PixelShuffle calls inside `self.backbone(images)` /
+// `HeatmapHead.forward` (lightning_pose/models/base.py:398, models/heads/heatmap.py:44,208; torchvision Bottleneck
+// semantics in SURVEY.md Appendix A).  Statistics are per call (= per forward pass: the labeled and the unlabeled
+// batch are normalised separately, models/base.py:682-695) and are exposed as raw [sum, sum of squares] so that
+// SyncBatchNorm (train.py:427) is one small all-reduce on that buffer before lp_bn_finalize.
+//
+// Every kernel moves 16 B per lane (8 bf16 channels), keeps per-channel scale/shift in registers and reduces in
+// fp32.  Roofline: HBM; algorithmic bytes are listed per kernel in DESIGN.md.
+#include "lp_common.h"
+
+namespace lp {
+
+__device__ __forceinline__ void unpack8(const u16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32(v[i]);
+}
+
+__device__ __forceinline__ u16x8 pack8(const float (&f)[8]) {
+    u16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(f[i]);
+    return v;
+}
+
+// ---- per-channel sums over rows: sums[0][c] += sum x, sums[1][c] += sum x*y  (y = x when X2 is null) -------------
+// MODE 0: plain statistics (sum x, sum x^2)
+// MODE 1: BN backward reductions: dz = relu-masked dy;  sum dz, sum dz * xhat
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Yout,
+                                                        const unsigned short* __restrict__ X, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, int M, int C, int rows_per_block,
+                                                        float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
+    __shared__ float red[2][256][8];
+    const int chunks = C >> 3;                       // 16-B chunks per row
+    const int cpb = chunks < 256 ? chunks : 256;     // chunks handled per block pass
+    const int lanes_r = 256 / cpb;                   // row lanes
+    const int ch = threadIdx.x % cpb, rl = threadIdx.x / cpb;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int cbase = blockIdx.y * cpb; cbase < chunks; cbase += gridDim.y * cpb) {
+        const int c = (cbase + ch) * 8;
+        float s0[8], s1[8], mu[8], is[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s0[i] = s1[i] = 0.f;
+        const bool cv = (cbase + ch) < chunks && rl < lanes_r;
+        if (MODE == 1 && cv) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mu[i] = mean[c + i];
+                is[i] = invstd[c + i];
+            }
+        }
+        if (cv) {
+            for (int r = r0 + rl; r < r1; r += lanes_r) {
+                float a[8];
+                unpack8(*reinterpret_cast<const u16x8*>(A + (size_t)r * C + c), a);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        s0[i] += a[i];
+                        s1[i] = fmaf(a[i], a[i], s1[i]);
+                    }
+                } else {
+                    float x[8];
+                    unpack8(*reinterpret_cast<const u16x8*>(X + (size_t)r * C + c), x);
+                    if (Yout != nullptr) {
+                        const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + (size_t)r * C + c);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if ((yo[i] & 0x7fff) == 0 || (yo[i] & 0x8000)) a[i] = 0.f;  // relu'(y): y <= 0
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        s0[i] += a[i];
+                        s1[i] = fmaf(a[i], (x[i] - mu[i]) * is[i], s1[i]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[0][threadIdx.x][i] = s0[i];
+            red[1][threadIdx.x][i] = s1[i];
+        }
+        __syncthreads();
+        if (rl == 0 && cv) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t0 = 0.f, t1 = 0.f;
+                for (int q = 0; q < lanes_r; ++q) {
+                    t0 += red[0][q * cpb + ch][i];
+                    t1 += red[1][q * cpb + ch][i];
+                }
+                atomicAdd(&sums[c + i], t0);
+                atomicAdd(&sums[C + c + i], t1);
+                if (acc0) atomicAdd(&acc0[c + i], t0);  // d beta
+                if (acc1) atomicAdd(&acc1[c + i], t1);  // d gamma
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// mean / invstd from [sum, sumsq]; running statistics updated with torch's momentum rule (unbiased variance)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = sums[c] / count;
+    float var = sums[C + c] / count - mu * mu;
+    var = fmaxf(var, 0.f);
+    mean[c] = mu;
+    invstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean != nullptr) {
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const unsigned short* __restrict__ residual,
+                                                       int relu, size_t n_chunks, int C, unsigned short* __restrict__ Y) {
+    const int chunks = C >> 3;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
+        const int c = (int)(q % chunks) * 8;
+        float x[8], o[8];
+        unpack8(*reinterpret_cast<const u16x8*>(X + q * 8), x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sc = invstd[c + i] * gamma[c + i];
+            o[i] = fmaf(x[i] - mean[c + i], sc, beta[c + i]);
+        }
+        if (residual != nullptr) {
+            float r[8];
+            unpack8(*reinterpret_cast<const u16x8*>(residual + q * 8), r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += r[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
+        }
+        *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(o);
+    }
+}
+
+// dx = gamma * invstd * (dz - sum(dz)/N - xhat * sum(dz*xhat)/N);  dz = relu-masked dy; optionally dz is also
+// written out (gradient of the residual branch)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
+                                                           const unsigned short* __restrict__ X, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float inv_count, size_t n_chunks, int C,
+                                                           unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES) {
+    const int chunks = C >> 3;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
+        const int c = (int)(q % chunks) * 8;
+        float dz[8], x[8], o[8];
+        unpack8(*reinterpret_cast<const u16x8*>(DY + q * 8), dz);
+        unpack8(*reinterpret_cast<const u16x8*>(X + q * 8), x);
+        if (Yout != nullptr) {
+            const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + q * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((yo[i] & 0x7fff) == 0 || (yo[i] & 0x8000)) dz[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float is = invstd[c + i];
+            const float xh = (x[i] - mean[c + i]) * is;
+            o[i] = gamma[c + i] * is * (dz[i] - sums[c + i] * inv_count - xh * sums[C + c + i] * inv_count);
+        }
+        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(o);
+        if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + q * 8) = pack8(dz);
+    }
+}
+
+// ---- 3x3 stride-2 pad-1 max-pool on NHWC bf16 --------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ X, int B, int Hi, int Wi, int C, int Ho,
+                                                          int Wo, unsigned short* __restrict__ Y) {
+    const int chunks = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * chunks;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        size_t p = q / chunks;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho), b = (int)(p / Ho);
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            if (hi < 0 || hi >= Hi) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * 2 - 1 + kw;
+                if (wi < 0 || wi >= Wi) continue;
+                float x[8];
+                unpack8(*reinterpret_cast<const u16x8*>(X + (((size_t)b * Hi + hi) * Wi + wi) * C + ch * 8), x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], x[i]);
+            }
+        }
+        *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(m);
+    }
+}
+
+// gather form: each input pixel collects dy from the (<= 4) windows whose FIRST maximum (row-major scan, strict >,
+// as ATen's max_pool2d_with_indices) is this pixel
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
+                                                          int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                          unsigned short* __restrict__ DX) {
+    const int chunks = C >> 3;
+    const size_t total = (size_t)B * Hi * Wi * chunks;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        size_t p = q / chunks;
+        const int wi = (int)(p % Wi);
+        p /= Wi;
+        const int hi = (int)(p % Hi), b = (int)(p / Hi);
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = 0.f;
+        const int ho_lo = max(0, (hi) / 2), ho_hi = min(Ho - 1, (hi + 1) / 2);
+        const int wo_lo = max(0, (wi) / 2), wo_hi = min(Wo - 1, (wi + 1) / 2);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                float best[8];
+                bool mine[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    best[i] = -INFINITY;
+                    mine[i] = false;
+                }
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int y = ho * 2 - 1 + kh;
+                    if (y < 0 || y >= Hi) continue;
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int x = wo * 2 - 1 + kw;
+                        if (x < 0 || x >= Wi) continue;
+                        float v[8];
+                        unpack8(*reinterpret_cast<const u16x8*>(X + (((size_t)b * Hi + y) * Wi + x) * C + ch * 8), v);
+                        const bool self = (y == hi) && (x == wi);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (v[i] > best[i]) {
+                                best[i] = v[i];
+                                mine[i] = self;
+                            }
+                    }
+                }
+                float d[8];
+                unpack8(*reinterpret_cast<const u16x8*>(DY + (((size_t)b * Ho + ho) * Wo + wo) * C + ch * 8), d);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (mine[i]) g[i] += d[i];
+            }
+        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(g);
+    }
+}
+
+// ---- images (B,3,H,W) fp32 NCHW -> (B,H,W,4) bf16, channel 3 = 0 ----------------------------------------------
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ X, int B, int HW, unsigned short* __restrict__ Y) {
+    const size_t total = (size_t)B * HW;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const size_t b = q / HW, p = q % HW;
+        const float* src = X + b * 3 * HW + p;
+        u16x4 v = {f32_to_bf16(src[0]), f32_to_bf16(src[HW]), f32_to_bf16(src[2 * (size_t)HW]), 0};
+        *reinterpret_cast<u16x4*>(Y + q * 4) = v;
+    }
+}
+
+// ---- PixelShuffle(2) on NHWC: out[b][2y+i][2x+j][c] = in[b][y][x][4c + 2i + j] ;  inverse for the gradient ------------
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short* __restrict__ IN, int B, int h, int w, int Cout,
+                                                            unsigned short* __restrict__ OUT) {
+    // thread = one low-res pixel x 8 consecutive LOW-res channels (16 B) ; they map to 2 output channels x 4 positions
+    const int cin = Cout * 4, chunks = cin >> 3;
+    const size_t total = (size_t)B * h * w * chunks;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        size_t p = q / chunks;
+        const int x = (int)(p % w);
+        p /= w;
+        const int y = (int)(p % h), b = (int)(p / h);
+        u16x8 v;
+        if (!INVERSE) v = *reinterpret_cast<const u16x8*>(IN + q * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cl = ch * 8 + e;           // low-res channel = 4c + 2i + j
+            const int c = cl >> 2, i = (cl >> 1) & 1, j = cl & 1;
+            const size_t o = ((((size_t)b * 2 * h + 2 * y + i) * 2 * w) + 2 * x + j) * Cout + c;
+            if (INVERSE) v[e] = IN[o];
+            else OUT[o] = v[e];
+        }
+        if (INVERSE) *reinterpret_cast<u16x8*>(OUT + q * 8) = v;
+    }
+}
+
+static int grid_for(size_t work_items) {
+    size_t blocks = (work_items + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    return blocks < 1 ? 1 : (int)blocks;
+}
+
+}  // namespace lp
+
+extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && sums && M > 0 && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int rows = 256;
+    dim3 grid((M + rows - 1) / rows, 1);
+    hipLaunchKernelGGL((colreduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr, (const float*)nullptr, M,
+                       C, rows, sums, (float*)nullptr, (float*)nullptr);
+    return launch_status();
+}
+
+extern "C" int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
+                              float* running_mean, float* running_var, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(sums && mean && invstd && C > 0 && count > 0.f);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, C, eps, momentum, mean,
+                       invstd, running_mean, running_var);
+    return launch_status();
+}
+
+extern "C" int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const void* residual, int relu, int M, int C, void* y, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const size_t n_chunks = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
+                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y);
+    return launch_status();
+}
+
+extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
+                                float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(dy && x && mean && invstd && sums && M > 0 && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int rows = 256;
+    dim3 grid((M + rows - 1) / rows, 1);
+    hipLaunchKernelGGL((colreduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, M, C, rows, sums, dbeta_acc, dgamma_acc);
+    return launch_status();
+}
+
+extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
+                               const float* gamma, const float* sums, float count, int M, int C, void* dx, void* dres,
+                               lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && M > 0 && C > 0 && count > 0.f);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const size_t n_chunks = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count, n_chunks, C,
+                       (unsigned short*)dx, (unsigned short*)dres);
+    return launch_status();
+}
+
+extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, B, Hi, Wi, C, Ho, Wo, (unsigned short*)y);
+    return launch_status();
+}
+
+extern "C" int lp_maxpool_bwd(const void* x, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && dy && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)B * Hi * Wi * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, (const unsigned short*)dy, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
+    return launch_status();
+}
+
+extern "C" int lp_images_to_nhwc4(const float* images, int B, int H, int W, void* out, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(images && out && B > 0 && H > 0 && W > 0);
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, images, B, H * W,
+                       (unsigned short*)out);
+    return launch_status();
+}
+
+extern "C" int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int inverse, void* out, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(in && out && B > 0 && h > 0 && w > 0 && c_out > 0);
+    if ((c_out * 4) % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const size_t work = (size_t)B * h * w * (c_out * 4 / 8);
+    if (inverse)
+        hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, B,
+                           h, w, c_out, (unsigned short*)out);
+    else
+        hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, B,
+                           h, w, c_out, (unsigned short*)out);
+    return launch_status();
+}

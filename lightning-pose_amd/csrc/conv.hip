@@ -1,0 +1,469 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores: forward, data-gradient and weight-gradient for the
+// ResNet-50 trunk and the transposed-convolution head of the heatmap tracker.  gfx950, bf16 in / fp32 accumulate.
+//
+// Replaces the cuDNN calls behind `self.backbone(images)` (lightning_pose/models/base.py:398, built at
+// models/backbones/factory.py:322-325) and `nn.ConvTranspose2d` in the head (models/heads/heatmap.py:60-69);
+// SURVEY.md section 2.1 K1/K2, Appendix B lists every GEMM shape.
+//
+// Data layout (chosen for the hardware, not inherited): activations NHWC bf16 so the GEMM K index (r, s, c) is
+// contiguous in c; weights bf16 [Cout][R][S][Cin] (= torch channels_last) so BOTH operands of every GEMM are
+// "K-contiguous rows" and share one staging path; a second copy [Cin][R][S][Cout] feeds the data-gradient.
+//
+// Tiling: 256 threads = 4 waves (2 x 2).  Workgroup tile 128 x BN (BN = 128 or 64), K step 64.  Each wave owns a
+// 64 x BN/2 sub-tile as 2 x (BN/64) MFMA tiles of `v_mfma_f32_32x32x16_bf16`.  Operands are staged global -> VGPR
+// -> LDS (16 B per lane; the im2col gather, zero padding and stride handling happen in the address computation,
+// nothing is materialised), double-buffered in LDS with ONE barrier per K step; LDS rows are padded to 144 B so
+// the 16-B fragment reads are bank-conflict free.  Tile ids are remapped so each XCD's L2 sees a contiguous range
+// of tiles that share the activation panel.  The weight-gradient contracts over pixels, which are strided in
+// memory, so its operands are transposed on the way into LDS (4x8 register transpose + ds_write_b64) and partial
+// sums of the split-K slices are combined with fp32 atomics straight into the flat gradient buffer.
+#include "lp_common.h"
+
+namespace lp {
+
+constexpr int kBM = 128;
+constexpr int kBK = 64;
+constexpr int kLD = kBK + 8;  // LDS row stride (bf16 elements): 144 B, conflict-free for ds_read_b128
+
+struct ConvGeom {
+    int B, Hi, Wi, Ci;  // input  tensor (NHWC)
+    int Ho, Wo, Co;     // output tensor (NHWC)
+    int R, S, stride, pad;
+};
+
+struct ConvEpilogue {
+    unsigned short* out_bf16;      // [M][ldo] or nullptr
+    float* out_f32;                // [M][ldo] or nullptr
+    int ldo;
+    int n_store;                   // columns >= n_store are not written
+    const float* bias;             // [n] or nullptr
+    const unsigned short* addend;  // [M][ldo] bf16 added before the store (gradient accumulation), or nullptr
+};
+
+enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2 };
+
+// XCD-aware bijective tile remap (cdna_hip_programming.md T1): block b runs on XCD b % 8; give each XCD a
+// contiguous chunk of the tile space.
+__device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+template <int NT>
+__device__ __forceinline__ void mma_kstep(const unsigned short* sA, const unsigned short* sB, int wm, int wn, int lane,
+                                          f32x16 (&acc)[2][NT]) {
+    const int r = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+        bf16x8 a[2], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            a[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sA + (wm * 64 + mt * 32 + r) * kLD + kk * 16 + g * 8));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            b[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sB + (wn * (NT * 32) + nt * 32 + r) * kLD + kk * 16 + g * 8));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ u16x8 zero8() {
+    u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return z;
+}
+
+__device__ __forceinline__ u16x8 load8(const unsigned short* p) { return *reinterpret_cast<const u16x8*>(p); }
+
+// two 8-byte halves (stem: NHWC4 pixels are only 8-byte aligned)
+__device__ __forceinline__ u16x8 load4x2(const unsigned short* p0, bool ok0, const unsigned short* p1, bool ok1) {
+    u16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+    if (ok0) lo = *reinterpret_cast<const u16x4*>(p0);
+    if (ok1) hi = *reinterpret_cast<const u16x4*>(p1);
+    u16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward / data-gradient:  out[m][n] = sum_k A[m][k] * Wt[n][k]
+//   kModeFwd   m = (b, ho, wo)  k = (r, s, ci)   A = x[b][ho*st - pad + r][wo*st - pad + s][ci]
+//   kModeDgrad m = (b, hi, wi)  k = (r, s, co)   A = dy[b][(hi + pad - r)/st][(wi + pad - s)/st][co] where divisible
+//   kModeStem  forward of the 7x7/2 stem on NHWC4 input, k = (r, s8, c4) padded to 256
+// ------------------------------------------------------------------------------------------------------------
+template <int BN, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
+                                                         ConvGeom g, int M, int N, int K, int tiles_n, ConvEpilogue ep) {
+    constexpr int NT = BN / 64;
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][kBM * kLD];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * kLD];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * kBM, n0 = (tile % tiles_n) * BN;
+
+    const int kchunk = tid & 7, rbase = tid >> 3;  // 8 x 16-B chunks per 64-wide K row; 32 rows per pass
+
+    // per-thread row coordinates of the 4 A rows this thread stages
+    int pb[4], py[4], px[4];
+    bool pv[4];
+    const int rows_y = (MODE == kModeDgrad) ? g.Hi : g.Ho;
+    const int rows_x = (MODE == kModeDgrad) ? g.Wi : g.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + rbase + 32 * i;
+        pv[i] = m < M;
+        const int mm = pv[i] ? m : 0;
+        const int b = mm / (rows_y * rows_x);
+        const int rem = mm - b * rows_y * rows_x;
+        const int y = rem / rows_x;
+        pb[i] = b;
+        if (MODE == kModeDgrad) {
+            py[i] = y + g.pad;
+            px[i] = rem - y * rows_x + g.pad;
+        } else {
+            py[i] = y * g.stride - g.pad;
+            px[i] = (rem - y * rows_x) * g.stride - g.pad;
+        }
+    }
+    const int ck = (MODE == kModeDgrad) ? g.Co : g.Ci;  // channels of the gathered tensor
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    u16x8 ra[4], rb[BN / 32];
+    int tr = 0, ts = 0, tc = 0;  // filter tap (r, s) and channel offset of the NEXT K step to load
+
+    auto load_step = [&](int kt) {
+        // ---- A: gathered activations
+        if (MODE == kModeStem) {
+            const int r = kt * 2 + (kchunk >> 2), s0 = (kchunk & 3) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hi = py[i] + r, wi = px[i] + s0;
+                const bool okr = pv[i] && r < g.R && hi >= 0 && hi < g.Hi;
+                const size_t base = ((size_t)(pb[i] * g.Hi + hi) * g.Wi + wi) * 4;
+                ra[i] = load4x2(X + base, okr && wi >= 0 && wi < g.Wi, X + base + 4, okr && s0 + 1 < g.S && wi + 1 >= 0 && wi + 1 < g.Wi);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bool ok = pv[i];
+                int sy, sx;
+                if (MODE == kModeDgrad) {
+                    const int th = py[i] - tr, tw = px[i] - ts;
+                    sy = th / g.stride;
+                    sx = tw / g.stride;
+                    ok = ok && th >= 0 && tw >= 0 && (sy * g.stride == th) && (sx * g.stride == tw) && sy < g.Ho && sx < g.Wo;
+                    ra[i] = ok ? load8(X + ((size_t)(pb[i] * g.Ho + sy) * g.Wo + sx) * ck + tc + kchunk * 8) : zero8();
+                } else {
+                    sy = py[i] + tr;
+                    sx = px[i] + ts;
+                    ok = ok && sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
+                    ra[i] = ok ? load8(X + ((size_t)(pb[i] * g.Hi + sy) * g.Wi + sx) * ck + tc + kchunk * 8) : zero8();
+                }
+            }
+            tc += kBK;
+            if (tc >= ck) {
+                tc = 0;
+                if (++ts == g.S) {
+                    ts = 0;
+                    ++tr;
+                }
+            }
+        }
+        // ---- B: weights [N][K], K-contiguous
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int n = n0 + rbase + 32 * i;
+            rb[i] = (n < N) ? load8(Wt + (size_t)n * K + kt * kBK + kchunk * 8) : zero8();
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = rb[i];
+    };
+
+    const int KT = K / kBK;
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_step(kt + 1);  // global loads in flight under the MFMAs
+        mma_kstep<NT>(sA[cur], sB[cur], wm, wn, lane, acc);
+        if (kt + 1 < KT) store_step(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile
+    const int col = lane & 31, rg = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wn * (NT * 32) + nt * 32 + col;
+            if (n >= ep.n_store) continue;
+            const float bias = ep.bias ? ep.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
+                if (m < M) {
+                    float v = acc[mt][nt][e] + bias;
+                    const size_t o = (size_t)m * ep.ldo + n;
+                    if (ep.addend) v += bf16_to_f32(ep.addend[o]);
+                    if (ep.out_bf16) ep.out_bf16[o] = f32_to_bf16(v);
+                    if (ep.out_f32) ep.out_f32[o] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][j] += sum_m xg[m][j] * dy[m][n],  j = (r, s, ci),  m = (b, ho, wo) split over blockIdx.y
+// computed as D[j][n] (rows j from the gathered activations, columns n from dy), both transposed into LDS.
+// ------------------------------------------------------------------------------------------------------------
+template <int BN, bool STEM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
+                                                         ConvGeom g, int M, int Kw, int tiles_n, int m_per_split,
+                                                         float* __restrict__ dW) {
+    constexpr int NT = BN / 64;
+    constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][kBM * kLD];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * kLD];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int j0 = (tile / tiles_n) * kBM, n0 = (tile % tiles_n) * BN;
+    const int m_begin = blockIdx.y * m_per_split;
+    const int m_end = min(M, m_begin + m_per_split);
+
+    // A operand (gathered activations): thread -> 8 consecutive j (one 16-B chunk), 4 consecutive pixels
+    const int mgA = tid & 15, jc = tid >> 4;
+    const int j = j0 + jc * 8;
+    const bool jv = j < Kw;
+    int tr = 0, ts = 0, tcn = 0;
+    if (STEM) {  // j = (r, s8, c4): 32 per r; chunk = pixels (s0, s0+1) x 4 channels
+        tr = j >> 5;
+        ts = (j & 31) >> 2;
+    } else {
+        const int tap = (jv ? j : 0) / g.Ci;
+        tcn = (jv ? j : 0) - tap * g.Ci;
+        tr = tap / g.S;
+        ts = tap - tr * g.S;
+    }
+    // B operand (dy): thread -> 8 consecutive n, RB consecutive pixels
+    constexpr int NCH = BN / 8;
+    const int mgB = tid % (256 / NCH), nc = tid / (256 / NCH);
+    const int nB = n0 + nc * 8;
+    const bool nv = nB < g.Co;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    u16x8 ra[4], rb[RB];
+    const int hw = g.Ho * g.Wo;
+
+    auto load_step = [&](int mk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mk + mgA * 4 + i;
+            bool ok = jv && m < m_end;
+            const int mm = ok ? m : 0;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+            const int hi = ho * g.stride - g.pad + tr, wi = wo * g.stride - g.pad + ts;
+            if (STEM) {
+                const bool okr = ok && tr < g.R && hi >= 0 && hi < g.Hi;
+                const size_t base = ((size_t)(b * g.Hi + hi) * g.Wi + wi) * 4;
+                ra[i] = load4x2(X + base, okr && wi >= 0 && wi < g.Wi, X + base + 4, okr && ts + 1 < g.S && wi + 1 >= 0 && wi + 1 < g.Wi);
+            } else {
+                ok = ok && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi;
+                ra[i] = ok ? load8(X + ((size_t)(b * g.Hi + hi) * g.Wi + wi) * g.Ci + tcn) : zero8();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int m = mk + mgB * RB + i;
+            rb[i] = (nv && m < m_end) ? load8(DY + (size_t)m * g.Co + nB) : zero8();
+        }
+    };
+    auto store_step = [&](int buf) {
+        // transpose 4 pixels x 8 columns -> 8 rows of 4 consecutive-k values
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u16x4 v = {ra[0][c], ra[1][c], ra[2][c], ra[3][c]};
+            *reinterpret_cast<u16x4*>(&sA[buf][(jc * 8 + c) * kLD + mgA * 4]) = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (RB == 4) {
+                u16x4 v = {rb[0][c], rb[1][c], rb[RB > 2 ? 2 : 0][c], rb[RB > 2 ? 3 : 0][c]};
+                *reinterpret_cast<u16x4*>(&sB[buf][(nc * 8 + c) * kLD + mgB * 4]) = v;
+            } else {
+                const unsigned v = (unsigned)rb[0][c] | ((unsigned)rb[1][c] << 16);
+                *reinterpret_cast<unsigned*>(&sB[buf][(nc * 8 + c) * kLD + mgB * 2]) = v;
+            }
+        }
+    };
+
+    const int KT = (m_end - m_begin + kBK - 1) / kBK;
+    if (KT > 0) {
+        load_step(m_begin);
+        store_step(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) load_step(m_begin + (kt + 1) * kBK);
+            mma_kstep<NT>(sA[cur], sB[cur], wm, wn, lane, acc);
+            if (kt + 1 < KT) store_step(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    const int col = lane & 31, rg = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wn * (NT * 32) + nt * 32 + col;
+            if (n >= g.Co) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int jj = j0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
+                if (jj < Kw) atomicAdd(&dW[(size_t)n * Kw + jj], acc[mt][nt][e]);
+            }
+        }
+}
+
+static bool geom_ok(const lp_conv_geom* c) {
+    return c && c->B > 0 && c->Hi > 0 && c->Wi > 0 && c->Ci > 0 && c->Ho > 0 && c->Wo > 0 && c->Co > 0 && c->R > 0 && c->S > 0 &&
+           c->stride > 0 && c->pad >= 0;
+}
+
+static ConvGeom to_geom(const lp_conv_geom* c) {
+    ConvGeom g{c->B, c->Hi, c->Wi, c->Ci, c->Ho, c->Wo, c->Co, c->R, c->S, c->stride, c->pad};
+    return g;
+}
+
+}  // namespace lp
+
+// out[b][ho][wo][co] = sum x[b][ho*st-pad+r][wo*st-pad+s][ci] * w[co][r][s][ci]  (+bias) ; x, w bf16
+extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32,
+                           int ldo, int n_store, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
+    ConvGeom g = to_geom(geom);
+    if (g.Ci % kBK != 0) return LP_ERR_UNSUPPORTED;
+    const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
+    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr};
+    const int tm = (M + kBM - 1) / kBM;
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 64) {
+        const int tn = (N + 127) / 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<128, kModeFwd>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)w, g, M, N, K, tn, ep);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<64, kModeFwd>), dim3(tm), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)w, g, M, N, K, 1, ep);
+    }
+    return launch_status();
+}
+
+// dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
+extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
+                             void* dx_bf16, float* dx_f32, int ldo, int n_store, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
+    ConvGeom g = to_geom(geom);
+    if (g.Co % kBK != 0) return LP_ERR_UNSUPPORTED;
+    const int M = g.B * g.Hi * g.Wi, N = g.Ci, K = g.R * g.S * g.Co;
+    ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend};
+    const int tm = (M + kBM - 1) / kBM;
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 64) {
+        const int tn = (N + 127) / 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<128, kModeDgrad>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)dy,
+                           (const unsigned short*)wd, g, M, N, K, tn, ep);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<64, kModeDgrad>), dim3(tm), dim3(256), 0, st, (const unsigned short*)dy,
+                           (const unsigned short*)wd, g, M, N, K, 1, ep);
+    }
+    return launch_status();
+}
+
+// dw[co][r][s][ci] (fp32, pre-zeroed or accumulating) += sum_m x_gather[m][(r,s,ci)] * dy[m][co]
+extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && dy && geom_ok(geom) && dw);
+    ConvGeom g = to_geom(geom);
+    if (g.Ci % 8 != 0 || g.Co % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int M = g.B * g.Ho * g.Wo, Kw = g.R * g.S * g.Ci;
+    const int tj = (Kw + kBM - 1) / kBM;
+    const bool wide = g.Co > 64;
+    const int tn = wide ? (g.Co + 127) / 128 : 1;
+    int split = split_hint > 0 ? split_hint : (1024 + tj * tn - 1) / (tj * tn);
+    const int ksteps = (M + kBK - 1) / kBK;
+    if (split > ksteps) split = ksteps;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    const int per = ((ksteps + split - 1) / split) * kBK;
+    split = (M + per - 1) / per;
+    hipStream_t st = (hipStream_t)stream;
+    if (wide) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tj * tn, split), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)dy, g, M, Kw, tn, per, dw);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tj * tn, split), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)dy, g, M, Kw, tn, per, dw);
+    }
+    return launch_status();
+}
+
+// 7x7/2 stem on NHWC4 bf16 input (channel 3 = 0): weights [64][7+1][8][4] zero padded (K = 256)
+extern "C" int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x4 && w && geom_ok(geom) && out_bf16);
+    ConvGeom g = to_geom(geom);
+    if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
+    const int M = g.B * g.Ho * g.Wo;
+    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr};
+    hipLaunchKernelGGL((conv_igemm_kernel<64, kModeStem>), dim3((M + kBM - 1) / kBM), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x4, (const unsigned short*)w, g, M, 64, 256, 1, ep);
+    return launch_status();
+}
+
+// dw[64][8][8][4] fp32 (K = 256 layout of lp_stem_fwd) += ...
+extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x4 && dy && geom_ok(geom) && dw);
+    ConvGeom g = to_geom(geom);
+    if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
+    const int M = g.B * g.Ho * g.Wo, Kw = 256;
+    const int tj = 2;
+    int split = split_hint > 0 ? split_hint : 512;
+    const int ksteps = (M + kBK - 1) / kBK;
+    if (split > ksteps) split = ksteps;
+    const int per = ((ksteps + split - 1) / split) * kBK;
+    split = (M + per - 1) / per;
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(tj, split), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x4,
+                       (const unsigned short*)dy, g, M, Kw, 1, per, dw);
+    return launch_status();
+}

@@ -172,9 +172,9 @@ __global__ __launch_bounds__(256) void softmax2d_fwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = expf(src[(size_t)i * si] - mx) / s;
 }
 
-// dlogit_i = p_i (g_i - sum_j g_j p_j); written back in the strided layout of the logits
+// dlogit_i = p_i (g_i - sum_j g_j p_j); written back as bf16 (it feeds the MFMA kernels) in the strided layout of the logits
 __global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, int K,
-                                                            int n, float* __restrict__ gin, long sb, long si, long sk) {
+                                                            int n, unsigned short* __restrict__ gin, long sb, long si, long sk) {
     __shared__ float red[4];
     const int bk = blockIdx.x, b = bk / K, k = bk - b * K;
     const float* p = prob + (size_t)bk * n;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const float* __restr
     float dot = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) dot = fmaf(p[i], g[i], dot);
     dot = block_sum<4>(dot, red);
-    float* dst = gin + (size_t)b * sb + (size_t)k * sk;
-    for (int i = threadIdx.x; i < n; i += 256) dst[(size_t)i * si] = p[i] * (g[i] - dot);
+    unsigned short* dst = gin + (size_t)b * sb + (size_t)k * sk;
+    for (int i = threadIdx.x; i < n; i += 256) dst[(size_t)i * si] = f32_to_bf16(p[i] * (g[i] - dot));
 }
 
 static GaussSpec make_spec(int img_h, int img_w, int h, int w, float sigma) {
@@ -278,12 +278,12 @@ extern "C" int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, l
     return launch_status();
 }
 
-extern "C" int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, float* gin, long stride_b, long stride_i,
+extern "C" int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, void* gin_bf16, long stride_b, long stride_i,
                                 long stride_k, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(prob && gprob && gin && B >= 0 && K > 0 && n > 0);
+    LP_REQUIRE(prob && gprob && gin_bf16 && B >= 0 && K > 0 && n > 0);
     if (B == 0) return LP_OK;
-    hipLaunchKernelGGL(softmax2d_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, prob, gprob, K, n, gin, stride_b, stride_i,
-                       stride_k);
+    hipLaunchKernelGGL(softmax2d_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, prob, gprob, K, n, (unsigned short*)gin_bf16,
+                       stride_b, stride_i, stride_k);
     return launch_status();
 }

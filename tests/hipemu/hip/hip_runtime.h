@@ -325,6 +325,8 @@ inline int atomicMax(int* p, int v) {
 }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 
+using std::max;
+using std::min;
 // ---- math ---------------------------------------------------------------------------------------
 inline float __expf(float x) { return std::exp(x); }
 inline float __fdividef(float a, float b) { return a / b; }

@@ -1,0 +1,122 @@
+"""Kernel-logic tests of csrc/conv.hip (MFMA implicit GEMM) on the CPU emulator vs torch fp32 convolutions of the
+SAME bf16-rounded operands (so the only difference is fp32 summation order)."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.hipemu import emu
+
+bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+
+
+def nhwc(t):  # (B,C,H,W) -> (B,H,W,C)
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # B, Hi, Wi, Ci, Co, R, stride, pad
+    (2, 8, 8, 64, 64, 1, 1, 0),      # 1x1, N = 64 tile
+    (1, 9, 7, 64, 128, 3, 1, 1),     # 3x3, M = 63 (partial tile), N = 128
+    (2, 10, 10, 128, 192, 3, 2, 1),  # 3x3 stride 2, N = 192 (partial second N tile), two K steps per tap
+    (3, 8, 8, 128, 64, 1, 2, 0),     # 1x1 stride 2 (downsample)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    B, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = bf(torch.randn(B, Ci, Hi, Wi, generator=gen)).requires_grad_(True)
+    w = bf(torch.randn(Co, Ci, R, R, generator=gen) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=st, padding=pad)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    xb = emu.to_bf16_bits(nhwc(x.detach()))
+    wg = emu.to_bf16_bits(w.detach().permute(0, 2, 3, 1))  # [Co][R][S][Ci]
+    wd = emu.to_bf16_bits(w.detach().permute(1, 2, 3, 0))  # [Ci][R][S][Co]
+    dyb = emu.to_bf16_bits(nhwc(dy))
+    # forward (bf16 + fp32 outputs)
+    ob, of = emu.conv_fwd(xb, wg, g, f32_out=True)
+    want = nhwc(y.detach()).reshape(-1, Co)
+    torch.testing.assert_close(torch.from_numpy(of), want, atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(emu.from_bf16_bits(ob), bf(want), atol=2e-2, rtol=1e-2)
+    # data gradient (+ addend)
+    add = bf(torch.randn(B * Hi * Wi, Ci, generator=gen))
+    _, df = emu.conv_dgrad(dyb, wd, g, addend_bits=emu.to_bf16_bits(add), f32_out=True)
+    want = nhwc(x.grad).reshape(-1, Ci) + add
+    torch.testing.assert_close(torch.from_numpy(df), want, atol=5e-4, rtol=5e-4)
+    # weight gradient (split-K over pixels, atomics)
+    for split in (0, 3):
+        dw = emu.conv_wgrad(xb, dyb, g, split=split)
+        want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+        torch.testing.assert_close(torch.from_numpy(dw), want, atol=2e-3, rtol=2e-3)
+
+
+def test_conv_bias_and_column_mask():
+    gen = torch.Generator().manual_seed(3)
+    x = bf(torch.randn(1, 64, 6, 6, generator=gen))
+    w = bf(torch.randn(64, 64, 1, 1, generator=gen) / 8)
+    bias = torch.randn(64, generator=gen)
+    g = emu.geom(1, 6, 6, 64, 64, 1, 1, 1, 0)
+    _, of = emu.conv_fwd(emu.to_bf16_bits(nhwc(x)), emu.to_bf16_bits(w.permute(0, 2, 3, 1)), g, bias=bias.numpy(), f32_out=True,
+                         ldo=32, n_store=17)
+    want = nhwc(F.conv2d(x, w, bias)).reshape(-1, 64)
+    torch.testing.assert_close(torch.from_numpy(of[:, :17]), want[:, :17], atol=2e-4, rtol=2e-4)
+    assert not of[:, 17:].any()
+
+
+def test_conv_transpose_via_dgrad():
+    """ConvTranspose2d(k3,s2,p1,op1) forward == lp_conv_dgrad of the mirrored conv; backward-data == lp_conv_fwd."""
+    gen = torch.Generator().manual_seed(4)
+    B, cin, cout, h = 2, 64, 17, 6
+    x = bf(torch.randn(B, cin, h, h, generator=gen)).requires_grad_(True)
+    wt = bf(torch.randn(cin, cout, 3, 3, generator=gen) / 24).requires_grad_(True)
+    bias = torch.randn(cout, generator=gen)
+    y = F.conv_transpose2d(x, wt, bias, stride=2, padding=1, output_padding=1)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    cpad = 64
+    # mirrored conv: input = big tensor (2h, cpad channels), output = small tensor (h, cin)
+    g = emu.geom(B, 2 * h, 2 * h, cpad, cin, 3, 3, 2, 1, Ho=h, Wo=h)
+    wg = torch.zeros(cin, 3, 3, cpad)
+    wg[..., :cout] = wt.detach().permute(0, 2, 3, 1)           # [Co=cin][R][S][Ci=cout_pad]
+    wd = wg.permute(3, 1, 2, 0).contiguous()                    # [Ci][R][S][Co]
+    bpad = torch.zeros(cpad)
+    bpad[:cout] = bias
+    _, yf = emu.conv_dgrad(emu.to_bf16_bits(nhwc(x.detach())), emu.to_bf16_bits(wd), g, bias=bpad.numpy(), f32_out=True)
+    want = nhwc(y.detach()).reshape(-1, cout)
+    torch.testing.assert_close(torch.from_numpy(yf[:, :cout]), want, atol=3e-4, rtol=3e-4)
+    assert not yf[:, cout:].any()
+    # backward-data through lp_conv_fwd on the padded gradient
+    dyp = torch.zeros(B, 2 * h, 2 * h, cpad)
+    dyp[..., :cout] = nhwc(dy)
+    _, dxf = emu.conv_fwd(emu.to_bf16_bits(dyp), emu.to_bf16_bits(wg), g, f32_out=True)
+    torch.testing.assert_close(torch.from_numpy(dxf), nhwc(x.grad).reshape(-1, cin), atol=5e-4, rtol=5e-4)
+    # weight gradient
+    dw = emu.conv_wgrad(emu.to_bf16_bits(dyp), emu.to_bf16_bits(nhwc(x.detach())), g)
+    want = wt.grad.permute(0, 2, 3, 1)  # [cin][3][3][cout]
+    torch.testing.assert_close(torch.from_numpy(dw).reshape(cin, 3, 3, cpad)[..., :cout], want, atol=2e-3, rtol=2e-3)
+
+
+def test_stem_fwd_wgrad():
+    gen = torch.Generator().manual_seed(5)
+    B, H = 2, 20
+    x = bf(torch.randn(B, 3, H, H, generator=gen))
+    w = bf(torch.randn(64, 3, 7, 7, generator=gen) / 12).requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=3)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    x4 = torch.zeros(B, H, H, 4)
+    x4[..., :3] = nhwc(x)
+    wp = torch.zeros(64, 8, 8, 4)
+    wp[:, :7, :7, :3] = w.detach().permute(0, 2, 3, 1)
+    g = emu.geom(B, H, H, 4, 64, 7, 7, 2, 3)
+    ob = emu.stem_fwd(emu.to_bf16_bits(x4), emu.to_bf16_bits(wp), g)
+    want = nhwc(y.detach()).reshape(-1, 64)
+    torch.testing.assert_close(emu.from_bf16_bits(ob), bf(want), atol=3e-2, rtol=2e-2)
+    dw = torch.from_numpy(emu.stem_wgrad(emu.to_bf16_bits(x4), emu.to_bf16_bits(nhwc(dy)), g)).reshape(64, 8, 8, 4)
+    torch.testing.assert_close(dw[:, :7, :7, :3], w.grad.permute(0, 2, 3, 1), atol=3e-3, rtol=3e-3)
+    assert not dw[:, 7].any() and not dw[:, :, 7].any() and not dw[..., 3].any()

@@ -59,7 +59,7 @@ def test_softmax2d_fwd_bwd():
     got = emu.softmax2d(logits.numpy(), k)
     np.testing.assert_allclose(got, p.detach().numpy(), atol=1e-7, rtol=1e-5)
     gin = emu.softmax2d_bwd(got, gp.numpy(), c)
-    np.testing.assert_allclose(gin[:, :, :k], x.grad.permute(0, 2, 1).numpy(), atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(gin[:, :, :k], x.grad.permute(0, 2, 1).numpy(), atol=1e-4, rtol=1e-2)  # bf16 output
     assert not gin[:, :, k:].any()
 
 
