@@ -80,6 +80,11 @@ int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int downsample_
                   const lp_decode_tables* tables, const lp_frame_map* frame_map, const float* stats, const float* g_kp_aug,
                   const float* g_kp_frame, float* g_heat, int accumulate, lp_stream_t stream);
 
+/* data/utils.py:191-234 undo_affine_transform_batch + data/bboxes.py:222-288 model_to_frame_batch on their own
+ * (target keypoints; backward = 1 applies the transposed Jacobian to a gradient). */
+int lp_frame_map_apply(const float* kp_in, int B, int K, const lp_frame_map* frame_map, int backward, float* kp_out,
+                       lp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Heat-map targets and heat-map losses
  * ------------------------------------------------------------------------------------------------------ */

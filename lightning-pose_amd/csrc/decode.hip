@@ -381,6 +381,20 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
     }
 }
 
+// standalone keypoint epilogue (targets, or callers that decode elsewhere): kp_out = frame_map(kp_in); inverse-transpose
+// for the gradient
+__global__ __launch_bounds__(256) void frame_map_kernel(const float* __restrict__ in, int n, int K, FrameMap fm, int backward,
+                                                        float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / K, k = i - b * K;
+    float x, y;
+    if (backward) frame_grad_to_aug(in[i * 2], in[i * 2 + 1], b, k, fm, x, y);
+    else to_frame(in[i * 2], in[i * 2 + 1], b, k, fm, x, y);
+    out[i * 2] = x;
+    out[i * 2 + 1] = y;
+}
+
 static size_t decode_smem_bytes(int h, int w, int strip_cols) { return (size_t)(h * w + h * strip_cols) * sizeof(float); }
 
 // Largest strip (256/128/64 output columns) whose Z buffer fits next to the heatmap tile in LDS, trimmed to the map.
@@ -482,5 +496,16 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
     else return LP_ERR_UNSUPPORTED;
 #undef LP_DISPATCH_NE
 #undef LP_LAUNCH_BWD
+    return launch_status();
+}
+
+extern "C" int lp_frame_map_apply(const float* kp_in, int B, int K, const lp_frame_map* f, int backward, float* kp_out,
+                                  lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(kp_in && kp_out && f && B >= 0 && K > 0);
+    if (B == 0) return LP_OK;
+    FrameMap fm{f->transforms, f->tf_mode, f->bbox, f->bbox_stride, f->kp_per_view, f->model_h, f->model_w};
+    hipLaunchKernelGGL(frame_map_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, kp_in, B * K, K, fm, backward,
+                       kp_out);
     return launch_status();
 }

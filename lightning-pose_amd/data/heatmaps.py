@@ -1,0 +1,31 @@
+"""Heat-map target generation (reference: lightning_pose/data/heatmaps.py:11-87) on the lp_hip kernels.
+
+``evaluate_heatmaps_at_location`` (reference :90-142) has no standalone entry point here: the 5x5 confidence window is
+the epilogue of the fused decode kernel (``lightning_pose_amd.ops.decode``), which is the only place the training
+step calls it (models/heads/heatmap.py:129).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+
+
+def generate_heatmaps(
+    keypoints: torch.Tensor,
+    height: int,
+    width: int,
+    output_shape: tuple[int, int],
+    sigma: float = 1.25,
+    keep_gradients: bool = False,
+    visibility: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """2-D Gaussian targets, (B, K, 2) image-px keypoints -> (B, K, h, w).  Same semantics as the reference:
+    sigma in heat-map px, maps normalised to sum 1, NaN / out-of-bounds -> zeros, visibility 0 -> zeros,
+    1 -> uniform, 2 -> Gaussian."""
+    if keep_gradients and keypoints.requires_grad:
+        raise NotImplementedError(
+            "generate_heatmaps(keep_gradients=True) is only needed by the 3-D reprojection losses, which are outside the "
+            "heatmap-tracker hot path implemented here")
+    return ops.generate_heatmaps(keypoints, height, width, tuple(output_shape), sigma, visibility)

@@ -1,0 +1,92 @@
+"""One process per GPU over RCCL (torch.distributed backend "nccl" on ROCm): the data-parallel wiring of the step.
+
+The reference relies on Lightning DDP (train.py:411-431): per-rank data shards, NCCL all-reduce of 25 MB gradient
+buckets, SyncBatchNorm, parameter broadcast at start, ``sync_dist=True`` metric means (SURVEY.md sections 3.5, 8e).
+Here gradients already live in ONE flat fp32 buffer, so the exchange is a handful of large all-reduces sized for
+xGMI's per-link bandwidth rather than DDP's 25 MB default; nothing else crosses GPUs (losses are local means, as in
+the reference), and the unlabeled window is never split across ranks.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+GRAD_BUCKET_BYTES = 64 << 20  # 94 MB of fp32 gradients -> 2 buckets; large messages keep the xGMI ring bandwidth-bound
+
+
+def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract) and initialise the default group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def labeled_batch_per_gpu(train_batch_size: int, num_gpus: int) -> int:
+    """reference data/factory.py:252-255"""
+    return -(-train_batch_size // num_gpus)
+
+
+def sequence_length_per_gpu(sequence_length: int, num_gpus: int) -> int:
+    """reference data/factory.py:274-276: whole windows per rank, never a split window"""
+    return -(-sequence_length // num_gpus)
+
+
+class DataParallel:
+    """Wraps an Engine: parameter broadcast, SyncBatchNorm switch, bucketed gradient all-reduce (mean)."""
+
+    def __init__(self, engine, process_group=None, sync_bn: bool = True, bucket_bytes: int = GRAD_BUCKET_BYTES):
+        self.engine = engine
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        engine.process_group = process_group
+        engine.sync_bn = bool(sync_bn and self.world > 1)
+        self._works: list = []
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world == 1:
+            return
+        e = self.engine
+        dist.broadcast(e.P, src=src, group=self.pg)
+        dist.broadcast(e.R, src=src, group=self.pg)
+        e.refresh_weight_copies()
+
+    def all_reduce_gradients(self, async_op: bool = True) -> None:
+        """SUM all-reduce of the flat gradient buffer in large buckets; pair with optimizer.grad_scale = 1/world."""
+        if self.world == 1:
+            return
+        g = self.engine.G
+        # backward produces the tail of the buffer (head, layer4) first: reduce from the end
+        hi = g.numel()
+        while hi > 0:
+            lo = max(0, hi - self.bucket_elems)
+            self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
+            hi = lo
+
+    def wait(self) -> None:
+        for w in self._works:
+            if w is not None:
+                w.wait()
+        self._works.clear()
+
+    def mean_scalars(self, values: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
+        """``self.log(..., sync_dist=True)`` for all logged scalars in ONE all-reduce (reference base.py:535-544)."""
+        if self.world == 1 or not values:
+            return values
+        keys = sorted(values)
+        packed = torch.stack([values[k].detach().float().reshape(()).to(self.engine.device) for k in keys])
+        dist.all_reduce(packed, group=self.pg)
+        packed /= self.world
+        return {k: packed[i] for i, k in enumerate(keys)}

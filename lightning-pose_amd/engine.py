@@ -1,0 +1,489 @@
+"""Explicit forward/backward executor for the heatmap tracker's network (ResNet-50 trunk + PixelShuffle /
+ConvTranspose head + spatial softmax) on top of the lp_hip kernels.
+
+Design (MI355X-first, not a translation of the reference's module tree):
+  * ONE flat fp32 buffer each for parameters, gradients and Adam moments (plus a flat bf16 operand copy and a
+    flat buffer of transposed copies for the data-gradient GEMMs).  Gradients therefore all-reduce as a few large
+    RCCL buckets and the optimiser is one launch per parameter group.
+  * activations NHWC bf16, conv weights [Cout][R][S][Cin] (torch ``channels_last``), so every contraction is a
+    K-contiguous GEMM on the MFMA units (csrc/conv.hip); BatchNorm / ReLU / residual / pooling are 16-byte-per-lane
+    streaming kernels (csrc/bn.hip).
+  * the network is static, so forward records a plain Python "tape" of tensors and backward walks it in reverse
+    calling dgrad / wgrad kernels directly - no autograd graph, no tracing compiler.  288 GB of HBM lets every
+    activation stay resident (about 0.13 GB per 384x384 frame), nothing is recomputed.
+
+Reference behaviour reproduced (paths relative to the reference tree): torchvision ResNet-50 children[:-2]
+(models/backbones/factory.py:322-348), HeatmapHead (models/heads/heatmap.py:20-83,147-212), training-mode
+BatchNorm per forward call with running-stat updates, SyncBatchNorm across ranks (train.py:427).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check
+from . import ops
+from .ops import _p
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+CPAD = 64  # channel padding of the head's narrow tensors (K = 17 -> 64) so they are MFMA K/N operands
+
+
+@dataclass
+class ConvP:
+    name: str
+    kind: str            # "conv" | "stem" | "convT"
+    cin: int             # logical channels (torch view)
+    cout: int
+    k: int
+    stride: int
+    pad: int
+    Co: int              # storage dims of the GEMM weight [Co][k][k][Ci]
+    Ci: int
+    w_off: int = 0
+    wd_off: int = 0
+    bias_off: int = -1   # convT only (padded to CPAD)
+
+    @property
+    def numel(self) -> int:
+        kk = 8 if self.kind == "stem" else self.k
+        return self.Co * kk * kk * self.Ci
+
+
+@dataclass
+class BNP:
+    name: str
+    C: int
+    g_off: int = 0
+    b_off: int = 0
+    r_off: int = 0       # running_mean at r_off, running_var at r_off + C (in the running-stat buffer)
+
+
+@dataclass
+class Block:
+    conv1: ConvP
+    bn1: BNP
+    conv2: ConvP
+    bn2: BNP
+    conv3: ConvP
+    bn3: BNP
+    down: ConvP | None = None
+    dbn: BNP | None = None
+
+
+@dataclass
+class Plan:
+    stem: ConvP
+    stem_bn: BNP
+    blocks: list[Block]
+    head: list[ConvP]
+    n_backbone: int = 0   # flat range [0, n_backbone) is the "backbone" optimiser group
+    n_total: int = 0
+    n_wd: int = 0
+    n_running: int = 0
+    convs: list[ConvP] = field(default_factory=list)
+    bns: list[BNP] = field(default_factory=list)
+
+
+def build_plan(num_keypoints: int, downsample_factor: int) -> Plan:
+    """Layer list + flat offsets, parameters in torchvision ``state_dict`` order (backbone first, then head)."""
+    if num_keypoints > CPAD:
+        raise NotImplementedError(f"at most {CPAD} heat-map channels (keypoints x views) are supported, got {num_keypoints}")
+    stem = ConvP("backbone.0", "stem", 3, 64, 7, 2, 3, 64, 4)
+    stem_bn = BNP("backbone.1", 64)
+    blocks: list[Block] = []
+    inplanes = 64
+    for li, (planes, nblk, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))):
+        for bi in range(nblk):
+            pre = f"backbone.{4 + li}.{bi}"
+            st = stride if bi == 0 else 1
+            blk = Block(
+                ConvP(f"{pre}.conv1", "conv", inplanes, planes, 1, 1, 0, planes, inplanes), BNP(f"{pre}.bn1", planes),
+                ConvP(f"{pre}.conv2", "conv", planes, planes, 3, st, 1, planes, planes), BNP(f"{pre}.bn2", planes),
+                ConvP(f"{pre}.conv3", "conv", planes, planes * 4, 1, 1, 0, planes * 4, planes), BNP(f"{pre}.bn3", planes * 4))
+            if bi == 0 and (st != 1 or inplanes != planes * 4):
+                blk.down = ConvP(f"{pre}.downsample.0", "conv", inplanes, planes * 4, 1, st, 0, planes * 4, inplanes)
+                blk.dbn = BNP(f"{pre}.downsample.1", planes * 4)
+            blocks.append(blk)
+            inplanes = planes * 4
+    n_layers = int(math.log2(32)) - downsample_factor - 1
+    if n_layers < 1:
+        raise NotImplementedError(f"downsample_factor={downsample_factor} leaves no upsampling layer for a stride-32 backbone")
+    head: list[ConvP] = []
+    cin = 2048 // 4
+    for i in range(n_layers):
+        # ConvTranspose2d(cin -> K): stored as the mirrored conv's weight [Co = cin][3][3][Ci = K padded]
+        co_store = cin if cin % 64 == 0 else CPAD
+        head.append(ConvP(f"head.upsampling_layers.{i + 1}", "convT", cin, num_keypoints, 3, 2, 1, co_store, CPAD))
+        cin = num_keypoints
+
+    plan = Plan(stem, stem_bn, blocks, head)
+    off = 0
+    wd = 0
+    run = 0
+
+    def add_conv(c: ConvP):
+        nonlocal off, wd
+        c.w_off = off
+        off += c.numel
+        if c.kind != "stem":
+            c.wd_off = wd
+            wd += c.numel
+        if c.kind == "convT":
+            c.bias_off = off
+            off += CPAD
+        plan.convs.append(c)
+
+    def add_bn(b: BNP):
+        nonlocal off, run
+        b.g_off = off
+        b.b_off = off + b.C
+        off += 2 * b.C
+        b.r_off = run
+        run += 2 * b.C
+        plan.bns.append(b)
+
+    add_conv(stem)
+    add_bn(stem_bn)
+    for blk in blocks:
+        add_conv(blk.conv1); add_bn(blk.bn1)
+        add_conv(blk.conv2); add_bn(blk.bn2)
+        add_conv(blk.conv3); add_bn(blk.bn3)
+        if blk.down is not None:
+            add_conv(blk.down); add_bn(blk.dbn)
+    plan.n_backbone = off
+    for c in head:
+        add_conv(c)
+    plan.n_total = off
+    plan.n_wd = wd
+    plan.n_running = run
+    return plan
+
+
+class Tape:
+    """Tensors one forward pass leaves behind for its backward pass."""
+
+    def __init__(self):
+        self.t: dict[str, torch.Tensor] = {}
+        self.meta: dict[str, object] = {}
+
+
+class Engine:
+    def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
+        self.device = torch.device(device)
+        ops.require_device_type(self.device)
+        _lib.lib()  # fail loudly now if liblp_hip.so is missing
+        self.K = num_keypoints
+        self.ds = downsample_factor
+        self.plan = build_plan(num_keypoints, downsample_factor)
+        n = self.plan.n_total
+        dev = self.device
+        self.P = torch.zeros(n, device=dev, dtype=torch.float32)      # master parameters
+        self.G = torch.zeros(n, device=dev, dtype=torch.float32)      # gradients
+        self.Wb = torch.zeros(n, device=dev, dtype=torch.bfloat16)    # bf16 operand copy (same offsets)
+        self.Wd = torch.zeros(self.plan.n_wd, device=dev, dtype=torch.bfloat16)  # [Ci][R][S][Co] copies for dgrad
+        self.R = torch.zeros(self.plan.n_running, device=dev, dtype=torch.float32)
+        for b in self.plan.bns:
+            self.P[b.g_off:b.g_off + b.C] = 1.0
+            self.R[b.r_off + b.C:b.r_off + 2 * b.C] = 1.0
+        self.nbt = torch.zeros((), dtype=torch.long)  # shared num_batches_tracked of every BatchNorm
+        self.sync_bn = False          # set by the DDP wrapper when world_size > 1 (reference: train.py:427)
+        self.process_group = None
+        self._lib = _lib.lib()
+
+    # ------------------------------------------------------------------------------------------------ params
+    def param_view(self, c: ConvP | BNP, which: str = "weight", buf: torch.Tensor | None = None) -> torch.Tensor:
+        """torch-shaped (state_dict compatible) view into a flat buffer (parameters by default)."""
+        buf = self.P if buf is None else buf
+        if isinstance(c, BNP):
+            off = c.g_off if which == "weight" else c.b_off
+            return buf[off:off + c.C]
+        if which == "bias":
+            return buf[c.bias_off:c.bias_off + c.cout]
+        flat = buf[c.w_off:c.w_off + c.numel]
+        if c.kind == "stem":
+            return flat.view(64, 8, 8, 4)[:, :7, :7, :3].permute(0, 3, 1, 2)
+        if c.kind == "convT":  # torch ConvTranspose2d weight (cin, cout, kh, kw)
+            return flat.view(c.Co, 3, 3, c.Ci)[:c.cin, :, :, :c.cout].permute(0, 3, 1, 2)
+        return flat.view(c.Co, c.k, c.k, c.Ci).permute(0, 3, 1, 2)
+
+    def running_view(self, b: BNP, which: str) -> torch.Tensor:
+        off = b.r_off if which == "running_mean" else b.r_off + b.C
+        return self.R[off:off + b.C]
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        """Reference-compatible keys/shapes: backbone.{0,1,4..7}.*, head.upsampling_layers.{i}.{weight,bias}."""
+        sd: dict[str, torch.Tensor] = {}
+        plan = self.plan
+
+        def put_bn(b: BNP):
+            sd[f"{b.name}.weight"] = self.param_view(b, "weight")
+            sd[f"{b.name}.bias"] = self.param_view(b, "bias")
+            sd[f"{b.name}.running_mean"] = self.running_view(b, "running_mean")
+            sd[f"{b.name}.running_var"] = self.running_view(b, "running_var")
+            sd[f"{b.name}.num_batches_tracked"] = self.nbt
+
+        sd[f"{plan.stem.name}.weight"] = self.param_view(plan.stem)
+        put_bn(plan.stem_bn)
+        for blk in plan.blocks:
+            for c, b in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)):
+                sd[f"{c.name}.weight"] = self.param_view(c)
+                put_bn(b)
+            if blk.down is not None:
+                sd[f"{blk.down.name}.weight"] = self.param_view(blk.down)
+                put_bn(blk.dbn)
+        for c in plan.head:
+            sd[f"{c.name}.weight"] = self.param_view(c)
+            sd[f"{c.name}.bias"] = self.param_view(c, "bias")
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict[str, torch.Tensor], strict: bool = True) -> None:
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise KeyError(f"state_dict mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        for k, dst in own.items():
+            if k not in sd:
+                continue
+            if k.endswith("num_batches_tracked"):
+                self.nbt.fill_(int(sd[k]))
+                continue
+            dst.copy_(sd[k].to(device=self.device, dtype=torch.float32))
+        self.refresh_weight_copies()
+
+    def refresh_weight_copies(self, lo: int = 0, hi: int | None = None) -> None:
+        """bf16 operand copy of P[lo:hi] and the transposed copies of the conv weights inside that range."""
+        hi = self.plan.n_total if hi is None else hi
+        check(self._lib.lp_cast_bf16(_p(self.P[lo:hi]), hi - lo, _p(self.Wb[lo:hi]), ops._stream()), "lp_cast_bf16")
+        self.refresh_dgrad_copies(lo, hi)
+
+    def refresh_dgrad_copies(self, lo: int = 0, hi: int | None = None) -> None:
+        hi = self.plan.n_total if hi is None else hi
+        for c in self.plan.convs:
+            if c.kind == "stem" or not (lo <= c.w_off < hi):
+                continue
+            check(self._lib.lp_permute_cba(_p(self.Wb[c.w_off:]), c.Co, c.k * c.k, c.Ci, _p(self.Wd[c.wd_off:]), ops._stream()),
+                  "lp_permute_cba")
+
+    def zero_grad(self) -> None:
+        self.G.zero_()
+
+    # ------------------------------------------------------------------------------------------------ kernels
+    def _geom(self, c: ConvP, B: int, Hi: int, Wi: int) -> _lib.ConvGeom:
+        if c.kind == "convT":  # mirrored conv: input = the (2h x 2w) ConvT output, output = the ConvT input
+            return _lib.ConvGeom(B, 2 * Hi, 2 * Wi, c.Ci, Hi, Wi, c.Co, 3, 3, 2, 1)
+        Ho = (Hi + 2 * c.pad - c.k) // c.stride + 1
+        Wo = (Wi + 2 * c.pad - c.k) // c.stride + 1
+        return _lib.ConvGeom(B, Hi, Wi, c.Ci, Ho, Wo, c.Co, c.k, c.k, c.stride, c.pad)
+
+    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int):
+        g = self._geom(c, B, Hi, Wi)
+        out = torch.empty(B, g.Ho, g.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
+        w = self.Wb[c.w_off:]
+        if c.kind == "stem":
+            check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), ops._stream()), "lp_stem_fwd")
+        else:
+            check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, ops._stream()), "lp_conv_fwd")
+        return out, g
+
+    def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor):
+        mean = torch.empty(b.C, device=self.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        if training:
+            check(self._lib.lp_bn_stats(_p(z), M, b.C, _p(sums), ops._stream()), "lp_bn_stats")
+            count = float(M)
+            if self.sync_bn:
+                dist.all_reduce(sums, group=self.process_group)
+                count *= dist.get_world_size(self.process_group)
+            check(self._lib.lp_bn_finalize(_p(sums), count, b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd),
+                                           _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")),
+                                           ops._stream()), "lp_bn_finalize")
+        else:
+            mean.copy_(self.running_view(b, "running_mean"))
+            invstd.copy_((self.running_view(b, "running_var") + BN_EPS).rsqrt())
+        y = torch.empty_like(z)
+        check(self._lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias")),
+                                    _p(residual), int(relu), M, b.C, _p(y), ops._stream()), "lp_bn_apply")
+        return y, mean, invstd
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, images: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:
+        """images (B,3,H,W) fp32 NCHW -> heat-maps (B,K,H/2^ds,W/2^ds) fp32, plus the tape for backward()."""
+        ops.require_device(images)
+        images = images.to(torch.float32).contiguous()
+        B, _, H, W = images.shape
+        if H % 32 or W % 32:
+            raise ValueError(f"image size must be a multiple of 32, got {H}x{W}")
+        tp = Tape()
+        T = tp.t
+        plan = self.plan
+        n_bn = sum(2 * b.C for b in plan.bns)
+        sums_all = torch.zeros(n_bn, device=self.device, dtype=torch.float32)
+        so = [0]
+
+        def next_sums(b: BNP) -> torch.Tensor:
+            s = sums_all[so[0]:so[0] + 2 * b.C]
+            so[0] += 2 * b.C
+            return s
+
+        x4 = torch.empty(B, H, W, 4, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_images_to_nhwc4(_p(images), B, H, W, _p(x4), ops._stream()), "lp_images_to_nhwc4")
+        T["x4"] = x4
+        z, g = self._conv_fwd(plan.stem, x4, B, H, W)
+        h, w = g.Ho, g.Wo
+        a, mu, iv = self._bn_fwd(plan.stem_bn, z, B * h * w, None, True, training, next_sums(plan.stem_bn))
+        T["stem.z"], T["stem.a"], T["stem.mu"], T["stem.iv"] = z, a, mu, iv
+        ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        x = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_maxpool_fwd(_p(a), B, h, w, 64, _p(x), ops._stream()), "lp_maxpool_fwd")
+        h, w = ph, pw
+        tp.meta["stem_hw"] = (g.Ho, g.Wo)
+
+        for i, blk in enumerate(plan.blocks):
+            key = f"b{i}"
+            T[f"{key}.x"] = x
+            tp.meta[f"{key}.hw"] = (h, w)
+            z1, _ = self._conv_fwd(blk.conv1, x, B, h, w)
+            a1, m1, v1 = self._bn_fwd(blk.bn1, z1, B * h * w, None, True, training, next_sums(blk.bn1))
+            z2, g2 = self._conv_fwd(blk.conv2, a1, B, h, w)
+            ho, wo = g2.Ho, g2.Wo
+            a2, m2, v2 = self._bn_fwd(blk.bn2, z2, B * ho * wo, None, True, training, next_sums(blk.bn2))
+            z3, _ = self._conv_fwd(blk.conv3, a2, B, ho, wo)
+            if blk.down is not None:
+                zd, _ = self._conv_fwd(blk.down, x, B, h, w)
+                idt, md, vd = self._bn_fwd(blk.dbn, zd, B * ho * wo, None, False, training, next_sums(blk.dbn))
+                T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"] = zd, md, vd
+            else:
+                idt = x
+            out, m3, v3 = self._bn_fwd(blk.bn3, z3, B * ho * wo, idt, True, training, next_sums(blk.bn3))
+            for nm, val in (("z1", z1), ("a1", a1), ("m1", m1), ("v1", v1), ("z2", z2), ("a2", a2), ("m2", m2), ("v2", v2),
+                            ("z3", z3), ("m3", m3), ("v3", v3), ("out", out)):
+                T[f"{key}.{nm}"] = val
+            x, h, w = out, ho, wo
+
+        # ---- head: PixelShuffle(2) -> ConvTranspose2d x n -> spatial softmax
+        cs = 2048 // 4
+        ps = torch.empty(B, 2 * h, 2 * w, cs, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_pixel_shuffle(_p(x), B, h, w, cs, 0, _p(ps), ops._stream()), "lp_pixel_shuffle")
+        h, w = 2 * h, 2 * w
+        T["head.in0"] = ps
+        cur = ps
+        logits = None
+        for li, c in enumerate(plan.head):
+            g = self._geom(c, B, h, w)
+            last = li == len(plan.head) - 1
+            bias = self.P[c.bias_off:c.bias_off + CPAD]
+            wd = self.Wd[c.wd_off:]
+            if last:
+                logits = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.float32)
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(logits), CPAD, self.K, ops._stream()),
+                      "lp_conv_dgrad(head)")
+            else:
+                nxt = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.bfloat16)
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, _p(nxt), None, CPAD, CPAD, ops._stream()),
+                      "lp_conv_dgrad(head)")
+                cur = nxt
+                T[f"head.in{li + 1}"] = cur
+            h, w = 2 * h, 2 * w
+        n = h * w
+        heat = torch.empty(B, self.K, h, w, device=self.device, dtype=torch.float32)
+        check(self._lib.lp_softmax2d_fwd(_p(logits), n * CPAD, CPAD, 1, B, self.K, n, _p(heat), ops._stream()), "lp_softmax2d_fwd")
+        T["heat"] = heat
+        tp.meta.update(B=B, H=H, W=W, training=training)
+        if training:
+            self.nbt += 1
+        return heat, tp
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool):
+        sums = torch.zeros(2 * b.C, device=self.device, dtype=torch.float32)
+        check(self._lib.lp_bn_bwd_reduce(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), M, b.C, _p(sums),
+                                         _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), ops._stream()), "lp_bn_bwd_reduce")
+        count = float(M)
+        if self.sync_bn:
+            dist.all_reduce(sums, group=self.process_group)
+            count *= dist.get_world_size(self.process_group)
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if want_dres else None
+        check(self._lib.lp_bn_bwd_apply(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(sums),
+                                        count, M, b.C, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply")
+        return dz, dres
+
+    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None):
+        g = self._geom(c, B, Hi, Wi)
+        check(self._lib.lp_conv_wgrad(_p(x), _p(dz), C.byref(g), _p(self.G[c.w_off:]), 0, ops._stream()), "lp_conv_wgrad")
+        if not need_dx:
+            return None
+        dx = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(dx), None, c.Ci, 0, ops._stream()),
+              "lp_conv_dgrad")
+        return dx
+
+    def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
+        """Accumulate d loss / d parameters into self.G given d loss / d heat-maps (B,K,h,w) fp32.
+
+        ``trace`` (tests only): receives the gradient tensor at every block boundary."""
+        T, plan = tp.t, self.plan
+        B, H, W = tp.meta["B"], tp.meta["H"], tp.meta["W"]
+        heat = T["heat"]
+        _, K, h, w = heat.shape
+        n = h * w
+        g_heat = g_heat.to(torch.float32).contiguous()
+        dcur = torch.zeros(B, h, w, CPAD, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_softmax2d_bwd(_p(heat), _p(g_heat), B, K, n, _p(dcur), n * CPAD, CPAD, 1, ops._stream()), "lp_softmax2d_bwd")
+        # head, last layer first.  ConvT backward-data is the mirrored conv's forward; its wgrad is lp_conv_wgrad.
+        for li in range(len(plan.head) - 1, -1, -1):
+            c = plan.head[li]
+            hs, ws = h // 2, w // 2
+            g = self._geom(c, B, hs, ws)
+            x_small = T[f"head.in{li}"]
+            bsum = torch.zeros(2 * CPAD, device=self.device, dtype=torch.float32)
+            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
+            self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
+            check(self._lib.lp_conv_wgrad(_p(dcur), _p(x_small), C.byref(g), _p(self.G[c.w_off:]), 0, ops._stream()), "lp_conv_wgrad(head)")
+            dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
+            check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
+                  "lp_conv_fwd(head bwd)")
+            dcur, h, w = dx, hs, ws
+        fh, fw = h // 2, w // 2
+        d = torch.empty(B, fh, fw, 2048, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_pixel_shuffle(_p(dcur), B, fh, fw, 512, 1, _p(d), ops._stream()), "lp_pixel_shuffle(inv)")
+
+        for i in range(len(plan.blocks) - 1, -1, -1):
+            blk, key = plan.blocks[i], f"b{i}"
+            if trace is not None:
+                trace[f"{key}.dout"] = d
+            hi, wi = tp.meta[f"{key}.hw"]
+            st = blk.conv2.stride
+            ho, wo = (hi - 1) // st + 1, (wi - 1) // st + 1
+            Mo, Mi = B * ho * wo, B * hi * wi
+            x = T[f"{key}.x"]
+            dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True)
+            da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True)
+            dz2, _ = self._bn_bwd(blk.bn2, da2, T[f"{key}.a2"], T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False)
+            da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True)
+            dz1, _ = self._bn_bwd(blk.bn1, da1, T[f"{key}.a1"], T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False)
+            if blk.down is not None:
+                dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False)
+                dpart = self._conv_bwd(blk.down, x, dzd, B, hi, wi, True)
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dpart)
+            else:
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres)
+
+        if trace is not None:
+            trace["stem.dpool"] = d
+        sh, sw = tp.meta["stem_hw"]
+        da = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_maxpool_bwd(_p(T["stem.a"]), _p(d), B, sh, sw, 64, _p(da), ops._stream()), "lp_maxpool_bwd")
+        dz, _ = self._bn_bwd(plan.stem_bn, da, T["stem.a"], T["stem.z"], T["stem.mu"], T["stem.iv"], B * sh * sw, False)
+        g = self._geom(plan.stem, B, H, W)
+        check(self._lib.lp_stem_wgrad(_p(T["x4"]), _p(dz), C.byref(g), _p(self.G[plan.stem.w_off:]), 0, ops._stream()), "lp_stem_wgrad")

@@ -1,0 +1,284 @@
+"""Torch-tensor front end of the lp_hip C ABI: device checks, stream plumbing, autograd glue.
+
+Every function here enqueues hand-written HIP kernels from ``liblp_hip.so`` on torch's current stream.  PyTorch is
+used for device memory, streams and autograd bookkeeping only.  There is no CPU path: tensors must live on a ROCm
+device, otherwise ``LpHipUnavailable`` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import functools
+
+import numpy as np
+import torch
+
+from . import _lib, _tables
+from ._lib import LpHipUnavailable, check
+
+__all__ = [
+    "decode", "DecodeFrameMap", "generate_heatmaps", "heatmap_mse", "unimodal_mse", "temporal_loss", "pca_loss",
+    "rmse", "require_device",
+]
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise LpHipUnavailable(
+                "lightning_pose_amd ops run only on a ROCm device (got a CPU tensor); there is no CPU fallback")
+        dev = t.device
+    return dev
+
+
+def require_device_type(device: torch.device) -> None:
+    if device.type != "cuda":
+        raise LpHipUnavailable(f"lightning_pose_amd needs a ROCm device (got {device}); there is no CPU fallback")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: torch.Tensor | None) -> C.c_void_p | None:
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------------
+# decode
+# --------------------------------------------------------------------------------------------------------
+
+@functools.lru_cache(maxsize=16)
+def _device_tables(h: int, w: int, ds: int, dev: torch.device):
+    ty, tx = _tables.axis_tables(h, ds), _tables.axis_tables(w, ds)
+    keep = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+            (ty["row_base"], ty["row_taps"], tx["col_start"], tx["col_taps"], tx["colT_start"], tx["colT_taps"])]
+    struct = _lib.DecodeTables(*[t.data_ptr() for t in keep], ty["ty"], tx["tx"], tx["tc"])
+    return struct, keep
+
+
+class DecodeFrameMap:
+    """undo-affine + model->frame epilogue parameters (reference: data/utils.py:191-234, data/bboxes.py:222-288)."""
+
+    def __init__(self, transforms: torch.Tensor | None, is_multiview: bool, bbox: torch.Tensor | None, num_views: int,
+                 model_h: int, model_w: int, num_keypoints: int):
+        self.keep = []
+        tf_mode, tf = _lib.TF_NONE, None
+        if transforms is not None and transforms.shape[-1] == 3:
+            tf = _f32c(transforms)
+            if is_multiview:
+                tf_mode = _lib.TF_PER_VIEW
+            elif tf.dim() == 2:
+                tf_mode = _lib.TF_SINGLE
+            else:
+                tf_mode = _lib.TF_PER_FRAME
+            self.keep.append(tf)
+        bb = None
+        if bbox is not None:
+            bb = _f32c(bbox)
+            self.keep.append(bb)
+        self.struct = _lib.FrameMap(_p(tf), tf_mode, _p(bb), 4 * num_views, max(1, num_keypoints // num_views),
+                                    float(model_h), float(model_w))
+
+
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, heat, ds, temperature, frame_map):
+        require_device(heat)
+        heat = heat.contiguous()
+        b, k, h, w = heat.shape
+        tables, keep = _device_tables(h, w, ds, heat.device)
+        kp_aug = torch.empty(b, k, 2, device=heat.device, dtype=torch.float32)
+        kp_frame = torch.empty_like(kp_aug)
+        conf = torch.empty(b, k, device=heat.device, dtype=torch.float32)
+        stats = torch.empty(b, k, 4, device=heat.device, dtype=torch.float32)
+        check(_lib.lib().lp_decode_fwd(_p(heat), b, k, h, w, ds, float(temperature), C.byref(tables),
+                                       C.byref(frame_map.struct), _p(kp_aug), _p(kp_frame), _p(conf), _p(stats), _stream()),
+              "lp_decode_fwd")
+        ctx.save_for_backward(heat, stats)
+        ctx.args = (ds, float(temperature), frame_map, tables, keep)
+        ctx.mark_non_differentiable(conf)
+        return kp_aug.reshape(b, 2 * k), kp_frame.reshape(b, 2 * k), conf
+
+    @staticmethod
+    def backward(ctx, g_aug, g_frame, _g_conf):
+        heat, stats = ctx.saved_tensors
+        ds, temperature, frame_map, tables, _keep = ctx.args
+        b, k, h, w = heat.shape
+        ga = _f32c(g_aug) if g_aug is not None else None
+        gf = _f32c(g_frame) if g_frame is not None else None
+        g_heat = torch.empty_like(heat)
+        check(_lib.lib().lp_decode_bwd(_p(heat), b, k, h, w, ds, temperature, C.byref(tables), C.byref(frame_map.struct),
+                                       _p(stats), _p(ga), _p(gf), _p(g_heat), 0, _stream()), "lp_decode_bwd")
+        return g_heat, None, None, None
+
+
+class _FrameMapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kp, frame_map):
+        require_device(kp)
+        x = _f32c(kp)
+        b, k = x.shape[0], x.shape[1] // 2
+        out = torch.empty_like(x)
+        check(_lib.lib().lp_frame_map_apply(_p(x), b, k, C.byref(frame_map.struct), 0, _p(out), _stream()), "lp_frame_map_apply")
+        ctx.frame_map = frame_map
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        b, k = g.shape[0], g.shape[1] // 2
+        out = torch.empty_like(g)
+        check(_lib.lib().lp_frame_map_apply(_p(g), b, k, C.byref(ctx.frame_map.struct), 1, _p(out), _stream()), "lp_frame_map_apply")
+        return out, None
+
+
+def frame_map_apply(keypoints: torch.Tensor, frame_map: DecodeFrameMap) -> torch.Tensor:
+    """keypoints (B, 2K) in model px -> frame px through the undo-affine / bbox map (differentiable)."""
+    return _FrameMapFn.apply(keypoints, frame_map)
+
+
+def decode(heatmaps: torch.Tensor, downsample_factor: int, temperature: float, frame_map: DecodeFrameMap):
+    """heatmaps (B,K,h,w) -> keypoints in model px (B,2K), keypoints in frame px (B,2K), confidences (B,K)."""
+    return _DecodeFn.apply(heatmaps, int(downsample_factor), float(temperature), frame_map)
+
+
+# --------------------------------------------------------------------------------------------------------
+# heat-map targets / losses
+# --------------------------------------------------------------------------------------------------------
+
+def generate_heatmaps(keypoints: torch.Tensor, height: int, width: int, output_shape: tuple[int, int], sigma: float = 1.25,
+                      visibility: torch.Tensor | None = None) -> torch.Tensor:
+    require_device(keypoints)
+    kp = _f32c(keypoints)
+    b, k, _ = kp.shape
+    h, w = output_shape
+    vis = visibility.to(torch.int32).contiguous() if visibility is not None else None
+    out = torch.empty(b, k, h, w, device=kp.device, dtype=torch.float32)
+    check(_lib.lib().lp_heatmap_gen(_p(kp), _p(vis), b, k, int(height), int(width), h, w, float(sigma), _p(out), _stream()),
+          "lp_heatmap_gen")
+    return out
+
+
+class _HeatmapMSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, targ, pred):
+        require_device(targ, pred)
+        targ, pred = _f32c(targ), pred.contiguous()
+        b, k, h, w = pred.shape
+        ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(b, k), device=pred.device, dtype=torch.uint8)
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        check(_lib.lib().lp_heatmap_mse_fwd(_p(targ), _p(pred), b, k, h, w, _p(loss), _p(ws), _stream()), "lp_heatmap_mse_fwd")
+        ctx.save_for_backward(targ, pred, ws)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        targ, pred, ws = ctx.saved_tensors
+        b, k, h, w = pred.shape
+        g = torch.empty_like(pred)
+        go = _f32c(gout).reshape(1)
+        check(_lib.lib().lp_heatmap_mse_bwd(_p(targ), _p(pred), b, k, h, w, _p(ws), _p(go), _p(g), 0, _stream()),
+              "lp_heatmap_mse_bwd")
+        return None, g
+
+
+def heatmap_mse(targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+    return _HeatmapMSEFn.apply(targets, predictions)
+
+
+class _UnimodalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kp_aug, pred, conf, img_h, img_w, sigma, thr):
+        require_device(kp_aug, pred, conf)
+        kp, pred, conf = _f32c(kp_aug), pred.contiguous(), _f32c(conf)
+        s, k, h, w = pred.shape
+        ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(s, k), device=pred.device, dtype=torch.uint8)
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        check(_lib.lib().lp_unimodal_mse_fwd(_p(kp), _p(pred), _p(conf), s, k, img_h, img_w, h, w, sigma, thr, _p(loss), _p(ws),
+                                             _stream()), "lp_unimodal_mse_fwd")
+        ctx.save_for_backward(kp, pred, ws)
+        ctx.args = (img_h, img_w, sigma)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        kp, pred, ws = ctx.saved_tensors
+        img_h, img_w, sigma = ctx.args
+        s, k, h, w = pred.shape
+        g = torch.empty_like(pred)
+        go = _f32c(gout).reshape(1)
+        check(_lib.lib().lp_unimodal_mse_bwd(_p(kp), _p(pred), s, k, img_h, img_w, h, w, sigma, _p(ws), _p(go), _p(g), 0,
+                                             _stream()), "lp_unimodal_mse_bwd")
+        return None, g, None, None, None, None, None
+
+
+def unimodal_mse(keypoints_pred_augmented: torch.Tensor, heatmaps_pred: torch.Tensor, confidences: torch.Tensor,
+                 image_height: int, image_width: int, sigma: float = 1.25, prob_threshold: float = 0.0) -> torch.Tensor:
+    return _UnimodalFn.apply(keypoints_pred_augmented, heatmaps_pred, confidences, int(image_height), int(image_width),
+                             float(sigma), float(prob_threshold))
+
+
+# --------------------------------------------------------------------------------------------------------
+# keypoint-space losses
+# --------------------------------------------------------------------------------------------------------
+
+class _UnitGradFn(torch.autograd.Function):
+    """loss whose gradient for unit upstream was produced together with the value (one launch)."""
+
+    @staticmethod
+    def forward(ctx, kp, loss, grad_unit):
+        ctx.save_for_backward(grad_unit)
+        ctx.shape = kp.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad_unit,) = ctx.saved_tensors
+        return (grad_unit * gout).reshape(ctx.shape), None, None
+
+
+def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None, epsilon: torch.Tensor, prob_threshold: float):
+    """keypoints (S, 2K) -> scalar (reference losses/losses.py:674-703)."""
+    require_device(keypoints)
+    kp = _f32c(keypoints)
+    s = kp.shape[0]
+    k = kp.shape[1] // 2
+    conf = _f32c(confidences) if confidences is not None else None
+    eps = epsilon.to(device=kp.device, dtype=torch.float32).reshape(-1)
+    eps = eps.expand(k).contiguous() if eps.numel() == 1 else eps.contiguous()
+    if eps.numel() != k:
+        raise ValueError(f"temporal epsilon must be a scalar or have one entry per keypoint ({k}), got {eps.numel()}")
+    loss = torch.empty(1, device=kp.device, dtype=torch.float32)
+    grad = torch.empty_like(kp)
+    check(_lib.lib().lp_temporal_fwd_bwd(_p(kp), _p(conf), s, k, _p(eps), float(prob_threshold), _p(loss), _p(grad), _stream()),
+          "lp_temporal_fwd_bwd")
+    return _UnitGradFn.apply(keypoints, loss.reshape(()), grad)
+
+
+def pca_loss(keypoints: torch.Tensor, index: torch.Tensor, mean: torch.Tensor, kept_eigenvectors: torch.Tensor, epsilon: float):
+    """keypoints (S, 2K); index (rows, points) int32 keypoint ids per PCA sample -> scalar (losses/losses.py:548-573)."""
+    require_device(keypoints, index, mean, kept_eigenvectors)
+    kp = _f32c(keypoints)
+    s, k = kp.shape[0], kp.shape[1] // 2
+    rows, pts = index.shape
+    loss = torch.empty(1, device=kp.device, dtype=torch.float32)
+    grad = torch.empty_like(kp)
+    check(_lib.lib().lp_pca_fwd_bwd(_p(kp), s, k, _p(index), rows, pts, _p(mean), _p(kept_eigenvectors),
+                                    kept_eigenvectors.shape[0], float(epsilon), _p(loss), _p(grad), _stream()), "lp_pca_fwd_bwd")
+    return _UnitGradFn.apply(keypoints, loss.reshape(()), grad)
+
+
+def rmse(keypoints_targ: torch.Tensor, keypoints_pred: torch.Tensor) -> torch.Tensor:
+    require_device(keypoints_targ, keypoints_pred)
+    t, p = _f32c(keypoints_targ), _f32c(keypoints_pred)
+    loss = torch.empty(1, device=p.device, dtype=torch.float32)
+    check(_lib.lib().lp_rmse_fwd(_p(t), _p(p), t.numel() // 2, _p(loss), _stream()), "lp_rmse_fwd")
+    return loss.reshape(())

@@ -486,3 +486,62 @@ def training_step(model: OracleTracker, batch: dict, unsup_cfg: dict[str, dict] 
     total = loss_sup + loss_unsup
     logs["total_loss"] = total
     return total, logs
+
+
+# ======================================================================================
+# bf16-mixed precision policy oracle
+# ======================================================================================
+# The reference trains in fp32 only.  The MI355X path stores activations and GEMM operands in bf16
+# with fp32 accumulation, fp32 BatchNorm statistics, fp32 logits/softmax/losses and fp32 master weights (DESIGN.md
+# "precision policy" - Lightning's `bf16-mixed` semantics).  `forward_bf16_policy` restates exactly that policy on top of
+# the fp32 OracleTracker weights by rounding at the same points (forward values AND, through autograd, gradients),
+# so the HIP engine can be checked against it to rounding-order accuracy; the fp32 forward stays the end-to-end oracle.
+
+
+def _q(x: torch.Tensor) -> torch.Tensor:
+    """round to bf16, keep fp32 dtype; autograd rounds the incoming gradient to bf16 at the same place"""
+    return x.to(torch.bfloat16).float()
+
+
+class _RoundGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def _bn_train(z: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor | None, relu: bool) -> torch.Tensor:
+    y = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, training=True, momentum=bn.momentum, eps=bn.eps)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return _q(y)
+
+
+def forward_bf16_policy(model: OracleTracker, images: torch.Tensor) -> torch.Tensor:
+    """Training-mode forward of `model` under the bf16-mixed policy (updates BN running statistics like train())."""
+    bb = model.backbone
+    x = _q(images)
+    x = _q(F.conv2d(x, _q(bb[0].weight), stride=2, padding=3))
+    x = _bn_train(x, bb[1], None, True)
+    x = F.max_pool2d(x, 3, 2, 1)
+    for layer in (bb[4], bb[5], bb[6], bb[7]):
+        for blk in layer:
+            idt = x
+            o = _bn_train(_q(F.conv2d(x, _q(blk.conv1.weight))), blk.bn1, None, True)
+            o = _bn_train(_q(F.conv2d(o, _q(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True)
+            z3 = _q(F.conv2d(o, _q(blk.conv3.weight)))
+            if blk.downsample is not None:
+                zd = _q(F.conv2d(x, _q(blk.downsample[0].weight), stride=blk.stride))
+                idt = _bn_train(zd, blk.downsample[1], None, False)
+            x = _bn_train(z3, blk.bn3, idt, True)
+    x = F.pixel_shuffle(x, 2)
+    cts = [m for m in model.head.upsampling_layers if isinstance(m, nn.ConvTranspose2d)]
+    for i, ct in enumerate(cts):
+        x = F.conv_transpose2d(x, _q(ct.weight), ct.bias, stride=2, padding=1, output_padding=1)
+        x = _RoundGrad.apply(x) if i == len(cts) - 1 else _q(x)
+    return tp.spatial_softmax2d(x, 1.0)

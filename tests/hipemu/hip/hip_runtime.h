@@ -352,6 +352,10 @@ inline float bf16_bits_to_f32(unsigned short b) {
 
 struct AB16 { unsigned short a[8]; unsigned short b[8]; };
 
+inline const unsigned short* slot_u16(const unsigned char* base, int lane) {
+    return reinterpret_cast<const unsigned short*>(base + (size_t)lane * kSlotBytes);
+}
+
 inline v16f mfma_32x32x16_bf16(v8bf16 a, v8bf16 b, v16f c, int, int, int) {
     AB16 ab;
     std::memcpy(ab.a, &a, 16);
@@ -359,16 +363,16 @@ inline v16f mfma_32x32x16_bf16(v8bf16 a, v8bf16 b, v16f c, int, int, int) {
     unsigned char* base = exchange(&ab, sizeof(ab));
     const int lane = flat_tid() & 63;
     const int col = lane & 31;
+    float bcol[16];
+    for (int k = 0; k < 16; ++k) bcol[k] = bf16_bits_to_f32(slot_u16(base, col + 32 * (k >> 3))[8 + (k & 7)]);
     v16f d = c;
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const unsigned short* a0 = slot_u16(base, row);
+        const unsigned short* a1 = slot_u16(base, row + 32);
         float acc = 0.f;
-        for (int k = 0; k < 16; ++k) {
-            AB16 ra, rb;
-            std::memcpy(&ra, base + (size_t)(row + 32 * (k >> 3)) * kSlotBytes, sizeof(AB16));
-            std::memcpy(&rb, base + (size_t)(col + 32 * (k >> 3)) * kSlotBytes, sizeof(AB16));
-            acc += bf16_bits_to_f32(ra.a[k & 7]) * bf16_bits_to_f32(rb.b[k & 7]);
-        }
+        for (int k = 0; k < 8; ++k) acc += bf16_bits_to_f32(a0[k]) * bcol[k];
+        for (int k = 0; k < 8; ++k) acc += bf16_bits_to_f32(a1[k]) * bcol[8 + k];
         d[r] = c[r] + acc;
     }
     return d;
@@ -385,12 +389,8 @@ inline v4f mfma_16x16x32_bf16(v8bf16 a, v8bf16 b, v4f c, int, int, int) {
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * (lane >> 4) + r;
         float acc = 0.f;
-        for (int k = 0; k < 32; ++k) {
-            AB16 ra, rb;
-            std::memcpy(&ra, base + (size_t)(row + 16 * (k >> 3)) * kSlotBytes, sizeof(AB16));
-            std::memcpy(&rb, base + (size_t)(col + 16 * (k >> 3)) * kSlotBytes, sizeof(AB16));
-            acc += bf16_bits_to_f32(ra.a[k & 7]) * bf16_bits_to_f32(rb.b[k & 7]);
-        }
+        for (int k = 0; k < 32; ++k)
+            acc += bf16_bits_to_f32(slot_u16(base, row + 16 * (k >> 3))[k & 7]) * bf16_bits_to_f32(slot_u16(base, col + 16 * (k >> 3))[8 + (k & 7)]);
         d[r] = c[r] + acc;
     }
     return d;

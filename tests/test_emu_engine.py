@@ -1,0 +1,125 @@
+"""Wiring test of lightning_pose_amd.engine.Engine (ResNet-50 trunk + head, forward AND hand-written backward) on the
+CPU-emulated kernels, against the bf16-mixed policy oracle (oracle.restated.forward_bf16_policy pieces).
+
+A 50-layer BatchNorm network at batch 4 / 64x64 is chaotic (1-ulp bf16 flips decorrelate deep gradients), so the
+comparison is LOCAL: every block is re-run in torch from the engine's own inputs and its gradient is checked from the
+engine's own upstream gradient.  Each comparison therefore isolates one block's kernels + plumbing."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restated as O
+from oracle import thirdparty as tp
+from oracle.restated import _bn_train, _q, _RoundGrad
+from tests.hipemu import emu
+
+
+@pytest.fixture()
+def emulated(monkeypatch):
+    from lightning_pose_amd import _lib, ops
+
+    monkeypatch.setattr(_lib, "_lib", emu.lib())
+    monkeypatch.setattr(ops, "require_device", lambda *a: None)
+    monkeypatch.setattr(ops, "require_device_type", lambda d: None)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    yield
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2).contiguous()
+
+
+def close(name, a, b, cos_min=0.995, ratio_tol=0.03):
+    cos = F.cosine_similarity(a.reshape(-1).float(), b.reshape(-1).float(), dim=0).item()
+    ratio = (a.norm() / (b.norm() + 1e-30)).item()
+    assert cos > cos_min and abs(ratio - 1) < ratio_tol, f"{name}: cos {cos:.5f} ratio {ratio:.4f}"
+
+
+def test_engine_forward_backward_blockwise(emulated):
+    from lightning_pose_amd.engine import Engine
+    from lightning_pose_amd.models.backbones._init import seeded_state_dict
+
+    K = 3
+    torch.manual_seed(7)
+    sd = seeded_state_dict(K, 2)
+    gen = torch.Generator().manual_seed(0)
+    for k in sd:  # give the head a visible signal (the reference's gain-0.01 init makes heat-maps numerically flat)
+        if k.startswith("head") and k.endswith("weight"):
+            sd[k] = sd[k] * 60
+        if k.startswith("head") and k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.1
+    eng = Engine(K, 2, "cpu")
+    eng.load_state_dict(sd, strict=False)
+    ref = O.OracleTracker(K, 2, torch_seed=7)
+    ref.load_state_dict(sd, strict=False)
+    ref.train()
+    images = torch.randn(4, 3, 64, 64, generator=gen)
+    heat, tape = eng.forward(images, True)
+    gh = torch.randn(heat.shape, generator=gen)
+    eng.zero_grad()
+    trace: dict = {}
+    eng.backward(tape, gh, trace)
+    T = tape.t
+    G = {}
+    for c in eng.plan.convs:
+        G[c.name + ".weight"] = eng.param_view(c, "weight", buf=eng.G)
+        if c.kind == "convT":
+            G[c.name + ".bias"] = eng.param_view(c, "bias", buf=eng.G)
+    for b in eng.plan.bns:
+        G[b.name + ".weight"] = eng.param_view(b, "weight", buf=eng.G)
+        G[b.name + ".bias"] = eng.param_view(b, "bias", buf=eng.G)
+    bb = ref.backbone
+
+    # ---- stem forward (exact up to 1 bf16 ulp) and running statistics
+    with torch.no_grad():
+        z = _q(F.conv2d(_q(images), _q(bb[0].weight), stride=2, padding=3))
+        torch.testing.assert_close(nchw(T["stem.z"]), z, atol=2e-2, rtol=1e-2)
+    # ---- head: forward from the engine's trunk output, backward from gh
+    x = nchw(T["b15.out"]).requires_grad_(True)
+    y = F.pixel_shuffle(x, 2)
+    cts = [m for m in ref.head.upsampling_layers if isinstance(m, torch.nn.ConvTranspose2d)]
+    for i, ct in enumerate(cts):
+        y = F.conv_transpose2d(y, _q(ct.weight), ct.bias, stride=2, padding=1, output_padding=1)
+        y = _RoundGrad.apply(y) if i == len(cts) - 1 else _q(y)
+    h = tp.spatial_softmax2d(y, 1.0)
+    torch.testing.assert_close(heat, h.detach(), atol=1e-6, rtol=1e-3)
+    h.backward(gh)
+    close("d(trunk output)", nchw(trace["b15.dout"]), x.grad)
+    for i, ct in enumerate(cts):
+        close(f"head.{i + 1}.weight", G[f"head.upsampling_layers.{i + 1}.weight"], ct.weight.grad)
+    close("head.1.bias", G["head.upsampling_layers.1.bias"], cts[0].bias.grad)  # last bias grad is identically ~0
+
+    # ---- every bottleneck block, locally
+    blocks = [blk for layer in (bb[4], bb[5], bb[6], bb[7]) for blk in layer]
+    names = [f"backbone.{4 + li}.{bi}" for li, layer in enumerate((bb[4], bb[5], bb[6], bb[7])) for bi in range(len(layer))]
+    for i in range(15, -1, -1):
+        blk, key, nm = blocks[i], f"b{i}", names[i]
+        ref.zero_grad()
+        x = nchw(T[key + ".x"]).requires_grad_(True)
+        o = _bn_train(_q(F.conv2d(x, _q(blk.conv1.weight))), blk.bn1, None, True)
+        o = _bn_train(_q(F.conv2d(o, _q(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True)
+        z3 = _q(F.conv2d(o, _q(blk.conv3.weight)))
+        idt = x
+        if blk.downsample is not None:
+            idt = _bn_train(_q(F.conv2d(x, _q(blk.downsample[0].weight), stride=blk.stride)), blk.downsample[1], None, False)
+        out = _bn_train(z3, blk.bn3, idt, True)
+        torch.testing.assert_close(nchw(T[key + ".out"]), out.detach(), atol=7e-2, rtol=2e-2)  # <= 1 bf16 ulp
+        out.backward(nchw(trace[key + ".dout"]))
+        din = trace[f"b{i - 1}.dout"] if i > 0 else trace["stem.dpool"]
+        close(f"{key} d_in", nchw(din), x.grad)
+        for pn in ("conv1.weight", "bn1.weight", "bn1.bias", "conv2.weight", "bn2.weight", "bn2.bias", "conv3.weight", "bn3.weight", "bn3.bias"):
+            mod, attr = pn.split(".")
+            close(f"{nm}.{pn}", G[f"{nm}.{pn}"], getattr(getattr(blk, mod), attr).grad)
+        if blk.downsample is not None:
+            close(f"{nm}.downsample.0.weight", G[f"{nm}.downsample.0.weight"], blk.downsample[0].weight.grad)
+            close(f"{nm}.downsample.1.weight", G[f"{nm}.downsample.1.weight"], blk.downsample[1].weight.grad)
+            close(f"{nm}.downsample.1.bias", G[f"{nm}.downsample.1.bias"], blk.downsample[1].bias.grad)
+    # ---- stem backward
+    ref.zero_grad()
+    z = _q(F.conv2d(_q(images), _q(bb[0].weight), stride=2, padding=3))
+    p = F.max_pool2d(_bn_train(z, bb[1], None, True), 3, 2, 1)
+    p.backward(nchw(trace["stem.dpool"]))
+    close("backbone.0.weight", G["backbone.0.weight"], bb[0].weight.grad)
+    close("backbone.1.weight", G["backbone.1.weight"], bb[1].weight.grad)
+    close("backbone.1.bias", G["backbone.1.bias"], bb[1].bias.grad)
