@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py - training frames/s of the MI355X-native heatmap-tracker step (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full optimisation step of ResNet-50 SemiSupervisedHeatmapTracker at 384x384, K=17, on synthetic
+data: forward + backward over 64 labeled and 128 unlabeled frames per GPU (BASELINE config C2/C3), heatmap_mse +
+temporal + pca_singleview + unimodal_mse losses, gradient all-reduce over RCCL when N > 1, fused Adam.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      MFMA roofline of the convolution kernels (the dominant cost): algorithmic FLOPs / HIP-event time per
+                launch, measured on the launch stream inside the timed steps; by_kernel gives per-symbol averages that
+                the committed rocprofv3 summary (profiles/) must reproduce.
+  cpu_baseline  the CPU oracle (oracle/restated.py: the reference's arithmetic restated in torch fp32, pinned against
+                the verbatim reference modules) timed on this host's cores for a bounded sample of the same workload.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import _lp_bootstrap  # noqa: E402,F401
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+TRAIN_GFLOP_PER_FRAME = {384: 72.4, 256: 32.2}  # 3 x 2 x (trunk + head) MACs
+
+
+def synth_batch(dev, rank: int, size: int, n_lab: int, n_unlab: int, K: int):
+    """Seeded synthetic labeled + unlabeled batch of SURVEY.md section 8(d), generated on the device."""
+    from lightning_pose_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    images = torch.randn(n_lab, 3, size, size, generator=g).to(dev)
+    kp = torch.rand(n_lab, K, 2, generator=g) * size
+    nan = torch.rand(n_lab, K, generator=g) < 0.088          # NaN rate of the bundled mirror-mouse labels
+    kp[nan] = float("nan")
+    vis = torch.where(nan, torch.ones_like(nan, dtype=torch.int32), torch.full_like(nan, 2, dtype=torch.int32))
+    kp_d = kp.to(dev)
+    heat = ops.generate_heatmaps(kp_d, size, size, (size // 4, size // 4), 1.25, vis.to(dev))
+    bbox = torch.tensor([[0.0, 0.0, float(size), float(size)]])
+    # temporally coherent unlabeled window: K blobs following a random walk over low-amplitude noise
+    centres = torch.cumsum(torch.randn(n_unlab, K, 2, generator=g) * 4.0, dim=0) + torch.rand(1, K, 2, generator=g) * size
+    centres = centres.clamp(8, size - 8).to(dev)
+    ys = torch.arange(size, device=dev).view(1, 1, size, 1).float()
+    xs = torch.arange(size, device=dev).view(1, 1, 1, size).float()
+    frames = torch.randn(n_unlab, 3, size, size, generator=g).to(dev) * 0.5
+    for k0 in range(K):  # accumulate blobs without materialising (S, K, H, W)
+        blob = 3.0 * torch.exp(-((xs - centres[:, k0, 0].view(-1, 1, 1, 1)) ** 2 + (ys - centres[:, k0, 1].view(-1, 1, 1, 1)) ** 2) / 72.0)
+        frames += blob
+    th = math.radians(float(torch.rand(1, generator=g)) * 20 - 10)
+    sc = 0.8 + 0.4 * float(torch.rand(1, generator=g))
+    c = size / 2
+    a = torch.tensor([[sc * math.cos(th), -sc * math.sin(th), 0.0], [sc * math.sin(th), sc * math.cos(th), 0.0]])
+    a[:, 2] = torch.tensor([c, c]) - a[:, :2] @ torch.tensor([c, c])
+    return {
+        "labeled": {"images": images, "keypoints": kp_d.reshape(n_lab, 2 * K), "heatmaps": heat,
+                    "bbox": bbox.repeat(n_lab, 1).to(dev), "idxs": torch.arange(n_lab)},
+        "unlabeled": {"frames": frames, "transforms": a.to(dev), "bbox": bbox.repeat(n_unlab, 1).to(dev), "is_multiview": False},
+    }
+
+
+def pca_training_array(K: int, size: int) -> torch.Tensor:
+    """Synthetic stand-in for the labelled keypoints the PCA is fitted on (no dataset files on the GPU box)."""
+    g = torch.Generator().manual_seed(99)
+    basis = torch.randn(6, 2 * K, generator=g)
+    data = torch.randn(300, 6, generator=g) @ basis * (size / 16) + size / 2 + torch.randn(300, 2 * K, generator=g)
+    return data
+
+
+def build_model(dev, K: int, size: int, torch_seed: int = 0):
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+
+    cols = [k for k in range(K) if k not in (7, 15, 16)] if K == 17 else list(range(K))
+    sup = LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    unsup = LossFactory({
+        "temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05},
+        "pca_singleview": {"loss_name": "pca_singleview", "log_weight": 5.0, "components_to_keep": 0.99,
+                           "columns_for_singleview_pca": cols, "data_arr": pca_training_array(K, size), "device": str(dev)},
+        "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05, "original_image_height": size, "original_image_width": size},
+    }, None)
+    return SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+                                        downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev)
+
+
+def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 3) -> dict:
+    """Oracle (fp32 torch CPU restatement of the reference path) timed on the host cores for a bounded sample."""
+    from oracle import restated as O
+
+    torch.manual_seed(0)
+    model = O.OracleTracker(K, 2, torch_seed=0)
+    opt = torch.optim.Adam([{"params": model.backbone.parameters(), "lr": 0.0}, {"params": model.head.parameters()}], lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    kp = torch.rand(n_lab, 2 * K, generator=g) * size
+    batch = {
+        "labeled": {"images": torch.randn(n_lab, 3, size, size, generator=g), "keypoints": kp,
+                    "heatmaps": O.generate_heatmaps(kp.reshape(n_lab, K, 2), size, size, (size // 4, size // 4)),
+                    "bbox": torch.tensor([[0.0, 0.0, size, size]]).repeat(n_lab, 1)},
+        "unlabeled": {"frames": torch.randn(n_unlab, 3, size, size, generator=g),
+                      "transforms": torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]),
+                      "bbox": torch.tensor([[0.0, 0.0, size, size]]).repeat(n_unlab, 1), "is_multiview": False},
+    }
+    cfg = {"temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05}, "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05}}
+    model.train()
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _ = O.training_step(model, batch, cfg, 1.0)
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round((n_lab + n_unlab) / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed full steps (fwd+bwd+Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, fp32, "
+                      f"median {med:.2f} s/step; oracle/restated.py OracleTracker + training_step"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--labeled", type=int, default=64)
+    ap.add_argument("--unlabeled", type=int, default=128)
+    ap.add_argument("--keypoints", type=int, default=17)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    from lightning_pose_amd.distributed import init_process_group_from_env
+    from lightning_pose_amd.trainer import Trainer
+
+    rank, local_rank, world = init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    model = build_model(dev, args.keypoints, args.size)
+    batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
+    trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True)
+    trainer.setup(model)
+    model.train()
+    model.total_unsupervised_importance = torch.tensor(1.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        trainer.training_batch(model, batch, i)
+    torch.cuda.synchronize()
+    barrier()
+    if not args.no_profile:
+        model.net.profile = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.training_batch(model, batch, args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model.net.profile or []
+    model.net.profile = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    frames_per_step = (args.labeled + args.unlabeled) * world
+    value = frames_per_step * args.steps / elapsed
+    out = {
+        "metric": "training frames/sec (whole node), ResNet-50 384x384 17-kp semi-sup",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"C2/C3: ResNet-50 SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
+                               f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
+                               "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
+                   "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": world > 1,
+                   "final_loss": round(float(loss), 6)},
+    }
+    if rank == 0:
+        if prof:
+            by: dict[str, list[float]] = {}
+            tot_ms, tot_flops = 0.0, 0.0
+            for tag, flops, e0, e1 in prof:
+                ms = e0.elapsed_time(e1)
+                rec = by.setdefault(tag, [0, 0.0, 0.0])
+                rec[0] += 1
+                rec[1] += ms
+                rec[2] += flops
+                tot_ms += ms
+                tot_flops += flops
+            ach = tot_flops / (tot_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches)",
+                "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches_per_step": len(prof) // args.steps, "conv_ms_per_step": round(tot_ms / args.steps, 3),
+                "by_kernel": {k: {"launches_per_step": v[0] // args.steps, "avg_us": round(1000 * v[1] / v[0], 2),
+                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(by.items())},
+            }
+        gf = TRAIN_GFLOP_PER_FRAME.get(args.size)
+        if gf:
+            out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
+            out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

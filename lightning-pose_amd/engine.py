@@ -197,6 +197,26 @@ class Engine:
         self.sync_bn = False          # set by the DDP wrapper when world_size > 1 (reference: train.py:427)
         self.process_group = None
         self._lib = _lib.lib()
+        self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
+
+    def _timed(self, tag: str, flops: float, fn):
+        """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
+        if self.profile is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.profile.append((tag, flops, e0, e1))
+        return out
+
+    @staticmethod
+    def _flops(c: "ConvP", g) -> float:
+        """Algorithmic FLOPs of one contraction over this layer (2 x MACs, logical channels, no padding)."""
+        kk = c.k * c.k
+        if c.kind == "convT":
+            return 2.0 * g.B * g.Ho * g.Wo * c.cin * kk * c.cout
+        return 2.0 * g.B * g.Ho * g.Wo * c.cout * kk * c.cin
 
     # ------------------------------------------------------------------------------------------------ params
     def param_view(self, c: ConvP | BNP, which: str = "weight", buf: torch.Tensor | None = None) -> torch.Tensor:
@@ -290,9 +310,12 @@ class Engine:
         out = torch.empty(B, g.Ho, g.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
         w = self.Wb[c.w_off:]
         if c.kind == "stem":
-            check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), ops._stream()), "lp_stem_fwd")
+            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g),
+                        lambda: check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), ops._stream()), "lp_stem_fwd"))
         else:
-            check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, ops._stream()), "lp_conv_fwd")
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g),
+                        lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, ops._stream()),
+                                      "lp_conv_fwd"))
         return out, g
 
     def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor):
@@ -420,12 +443,14 @@ class Engine:
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None):
         g = self._geom(c, B, Hi, Wi)
-        check(self._lib.lp_conv_wgrad(_p(x), _p(dz), C.byref(g), _p(self.G[c.w_off:]), 0, ops._stream()), "lp_conv_wgrad")
+        self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g),
+                    lambda: check(self._lib.lp_conv_wgrad(_p(x), _p(dz), C.byref(g), _p(self.G[c.w_off:]), 0, ops._stream()), "lp_conv_wgrad"))
         if not need_dx:
             return None
         dx = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(dx), None, c.Ci, 0, ops._stream()),
-              "lp_conv_dgrad")
+        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g),
+                    lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(dx), None, c.Ci,
+                                                          0, ops._stream()), "lp_conv_dgrad"))
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -486,4 +511,6 @@ class Engine:
         check(self._lib.lp_maxpool_bwd(_p(T["stem.a"]), _p(d), B, sh, sw, 64, _p(da), ops._stream()), "lp_maxpool_bwd")
         dz, _ = self._bn_bwd(plan.stem_bn, da, T["stem.a"], T["stem.z"], T["stem.mu"], T["stem.iv"], B * sh * sw, False)
         g = self._geom(plan.stem, B, H, W)
-        check(self._lib.lp_stem_wgrad(_p(T["x4"]), _p(dz), C.byref(g), _p(self.G[plan.stem.w_off:]), 0, ops._stream()), "lp_stem_wgrad")
+        self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
+                    lambda: check(self._lib.lp_stem_wgrad(_p(T["x4"]), _p(dz), C.byref(g), _p(self.G[plan.stem.w_off:]), 0, ops._stream()),
+                                  "lp_stem_wgrad"))

@@ -39,3 +39,34 @@ def has_reference() -> bool:
 
 
 needs_reference = pytest.mark.skipif(not has_reference(), reason="/root/reference not present")
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def kernel_backend(request):
+    """Run a kernel-level test twice: on the CPU-emulated build of the kernel sources (default CPU suite) and, under
+    `-m gpu`, on the real device through the product library liblp_hip.so."""
+    from tests.hipemu import emu
+
+    emu.BACKEND = request.param
+    yield request.param
+    emu.BACKEND = "emu"
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def stack_backend(request, monkeypatch):
+    """Device for tests of the product host stack: 'cpu' with the kernel library swapped for its emulated build (CPU
+    suite), or the real 'cuda:0' with nothing patched (`-m gpu`)."""
+    from lightning_pose_amd import _lib, ops
+
+    if request.param == "gpu":
+        yield torch.device("cuda:0")
+        return
+    from tests.hipemu import emu
+
+    monkeypatch.setattr(_lib, "_lib", emu.emu_lib())
+    monkeypatch.setattr(ops, "require_device", lambda *a: None)
+    monkeypatch.setattr(ops, "require_device_type", lambda d: None)
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    ops._device_tables.cache_clear()
+    yield torch.device("cpu")
+    ops._device_tables.cache_clear()

@@ -19,9 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 BUILD = os.path.join(ROOT, "lightning-pose_amd", "csrc", "build.sh")
 
 _emu = None
+BACKEND = "emu"  # "emu": CPU-emulated build, numpy buffers;  "gpu": the product liblp_hip.so, torch ROCm buffers
 
 
-def lib() -> C.CDLL:
+def emu_lib() -> C.CDLL:
     global _emu
     if _emu is None:
         subprocess.run(["bash", BUILD, "emu"], check=True, capture_output=True)
@@ -29,11 +30,46 @@ def lib() -> C.CDLL:
     return _emu
 
 
-def ptr(a: np.ndarray | None):
+def lib() -> C.CDLL:
+    return _lib.lib() if BACKEND == "gpu" else emu_lib()
+
+
+def stream():
+    if BACKEND == "gpu":
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+class Buf:
+    """A kernel argument buffer: numpy memory on the emulator, a torch ROCm tensor on the GPU."""
+
+    def __init__(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        self.dtype, self.shape = a.dtype, a.shape
+        if BACKEND == "gpu":
+            import torch
+            raw = a.view(np.int16) if a.dtype == np.uint16 else a
+            self.t = torch.from_numpy(raw.copy()).cuda()
+            self.p = C.c_void_p(self.t.data_ptr())
+        else:
+            self.a = a.copy()
+            self.p = self.a.ctypes.data_as(C.c_void_p)
+
+    def np(self) -> np.ndarray:
+        if BACKEND == "gpu":
+            import torch
+            torch.cuda.synchronize()
+            out = self.t.cpu().numpy()
+            return out.view(np.uint16) if self.dtype == np.uint16 else out
+        return self.a
+
+
+def ptr(a):
+    """Device pointer of a Buf (or None)."""
     if a is None:
         return None
-    assert a.flags["C_CONTIGUOUS"]
-    return a.ctypes.data_as(C.c_void_p)
+    return a.p
 
 
 def f32(a) -> np.ndarray:
@@ -44,18 +80,33 @@ def i32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
 
 
+def B(a, dtype=None):
+    """Stage an input array (None passes through)."""
+    if a is None:
+        return None
+    a = np.asarray(a) if dtype is None else np.asarray(a, dtype=dtype)
+    return Buf(a)
+
+
+def Z(shape, dtype=np.float32):
+    return Buf(np.zeros(shape, dtype))
+
+
+def ok(rc):
+    assert rc == 0, rc
+
+
 class Tables:
-    """Keeps the numpy tables alive next to the ctypes struct."""
+    """Keeps the staged tables alive next to the ctypes struct."""
 
     def __init__(self, h: int, w: int, ds: int):
         ty, tx = _tables.axis_tables(h, ds), _tables.axis_tables(w, ds)
-        self.keep = [ty["row_base"], ty["row_taps"], tx["col_start"], tx["col_taps"], tx["colT_start"], tx["colT_taps"]]
-        self.keep = [np.ascontiguousarray(a) for a in self.keep]
-        self.struct = _lib.DecodeTables(*[ptr(a) for a in self.keep], ty["ty"], tx["tx"], tx["tc"])
+        self.keep = [Buf(a) for a in (ty["row_base"], ty["row_taps"], tx["col_start"], tx["col_taps"], tx["colT_start"], tx["colT_taps"])]
+        self.struct = _lib.DecodeTables(*[b.p for b in self.keep], ty["ty"], tx["tx"], tx["tc"])
 
 
 def frame_map(transforms=None, tf_mode=_lib.TF_NONE, bbox=None, views=1, K=1, model_h=1.0, model_w=1.0):
-    keep = [f32(transforms) if transforms is not None else None, f32(bbox) if bbox is not None else None]
+    keep = [B(transforms, np.float32), B(bbox, np.float32)]
     fm = _lib.FrameMap(ptr(keep[0]), tf_mode, ptr(keep[1]), 4 * views, max(1, K // views), float(model_h), float(model_w))
     return fm, keep
 
@@ -67,12 +118,11 @@ def decode_fwd(heat, ds, temperature=1000.0, fm=None):
     keep = None
     if fm is None:
         fm, keep = frame_map(K=k)
-    kp_aug, kp_frame = np.zeros((b, k, 2), np.float32), np.zeros((b, k, 2), np.float32)
-    conf, stats = np.zeros((b, k), np.float32), np.zeros((b, k, 4), np.float32)
-    rc = lib().lp_decode_fwd(ptr(heat), b, k, h, w, ds, temperature, C.byref(tb.struct), C.byref(fm), ptr(kp_aug),
-                             ptr(kp_frame), ptr(conf), ptr(stats), None)
-    assert rc == 0, rc
-    return kp_aug, kp_frame, conf, stats
+    hb = Buf(heat)
+    kp_aug, kp_frame, conf, stats = Z((b, k, 2)), Z((b, k, 2)), Z((b, k)), Z((b, k, 4))
+    ok(lib().lp_decode_fwd(hb.p, b, k, h, w, ds, temperature, C.byref(tb.struct), C.byref(fm), kp_aug.p, kp_frame.p, conf.p, stats.p,
+                           stream()))
+    return kp_aug.np(), kp_frame.np(), conf.np(), stats.np()
 
 
 def decode_bwd(heat, ds, stats, g_aug=None, g_frame=None, temperature=1000.0, fm=None):
@@ -82,76 +132,68 @@ def decode_bwd(heat, ds, stats, g_aug=None, g_frame=None, temperature=1000.0, fm
     keep = None
     if fm is None:
         fm, keep = frame_map(K=k)
-    g_heat = np.zeros_like(heat)
-    ga = f32(g_aug) if g_aug is not None else None
-    gf = f32(g_frame) if g_frame is not None else None
-    rc = lib().lp_decode_bwd(ptr(heat), b, k, h, w, ds, temperature, C.byref(tb.struct), C.byref(fm), ptr(f32(stats)),
-                             ptr(ga), ptr(gf), ptr(g_heat), 0, None)
-    assert rc == 0, rc
-    return g_heat
+    hb, sb, ga, gf = Buf(heat), Buf(f32(stats)), B(g_aug, np.float32), B(g_frame, np.float32)
+    g_heat = Z(heat.shape)
+    ok(lib().lp_decode_bwd(hb.p, b, k, h, w, ds, temperature, C.byref(tb.struct), C.byref(fm), sb.p, ptr(ga), ptr(gf), g_heat.p, 0,
+                           stream()))
+    return g_heat.np()
 
 
 def heatmap_gen(kp, vis, img_h, img_w, h, w, sigma=1.25):
     kp = f32(kp)
     b, k, _ = kp.shape
-    out = np.zeros((b, k, h, w), np.float32)
-    v = i32(vis) if vis is not None else None
-    rc = lib().lp_heatmap_gen(ptr(kp), ptr(v), b, k, img_h, img_w, h, w, sigma, ptr(out), None)
-    assert rc == 0, rc
-    return out
+    kb, vb, out = Buf(kp), B(vis, np.int32), Z((b, k, h, w))
+    ok(lib().lp_heatmap_gen(kb.p, ptr(vb), b, k, img_h, img_w, h, w, sigma, out.p, stream()))
+    return out.np()
 
 
 def heatmap_mse(targ, pred, gout=1.0):
     targ, pred = f32(targ), f32(pred)
     b, k, h, w = pred.shape
-    ws = np.zeros(lib().lp_heatmap_mse_workspace_bytes(b, k), np.uint8)
-    loss = np.zeros(1, np.float32)
-    assert lib().lp_heatmap_mse_fwd(ptr(targ), ptr(pred), b, k, h, w, ptr(loss), ptr(ws), None) == 0
-    g = np.zeros_like(pred)
-    go = f32([gout])
-    assert lib().lp_heatmap_mse_bwd(ptr(targ), ptr(pred), b, k, h, w, ptr(ws), ptr(go), ptr(g), 0, None) == 0
-    return loss[0], g
+    tb, pb = Buf(targ), Buf(pred)
+    ws = Z(lib().lp_heatmap_mse_workspace_bytes(b, k), np.uint8)
+    loss, g, go = Z(1), Z(pred.shape), Buf(f32([gout]))
+    ok(lib().lp_heatmap_mse_fwd(tb.p, pb.p, b, k, h, w, loss.p, ws.p, stream()))
+    ok(lib().lp_heatmap_mse_bwd(tb.p, pb.p, b, k, h, w, ws.p, go.p, g.p, 0, stream()))
+    return loss.np()[0], g.np()
 
 
 def unimodal_mse(kp_aug, pred, conf, img_h, img_w, thr, sigma=1.25, gout=1.0):
     kp_aug, pred, conf = f32(kp_aug), f32(pred), f32(conf)
     s, k, h, w = pred.shape
-    ws = np.zeros(lib().lp_heatmap_mse_workspace_bytes(s, k), np.uint8)
-    loss = np.zeros(1, np.float32)
-    assert lib().lp_unimodal_mse_fwd(ptr(kp_aug), ptr(pred), ptr(conf), s, k, img_h, img_w, h, w, sigma, thr, ptr(loss),
-                                     ptr(ws), None) == 0
-    g = np.zeros_like(pred)
-    go = f32([gout])
-    assert lib().lp_unimodal_mse_bwd(ptr(kp_aug), ptr(pred), s, k, img_h, img_w, h, w, sigma, ptr(ws), ptr(go), ptr(g), 0,
-                                     None) == 0
-    return loss[0], g
+    kb, pb, cb = Buf(kp_aug), Buf(pred), Buf(conf)
+    ws = Z(lib().lp_heatmap_mse_workspace_bytes(s, k), np.uint8)
+    loss, g, go = Z(1), Z(pred.shape), Buf(f32([gout]))
+    ok(lib().lp_unimodal_mse_fwd(kb.p, pb.p, cb.p, s, k, img_h, img_w, h, w, sigma, thr, loss.p, ws.p, stream()))
+    ok(lib().lp_unimodal_mse_bwd(kb.p, pb.p, s, k, img_h, img_w, h, w, sigma, ws.p, go.p, g.p, 0, stream()))
+    return loss.np()[0], g.np()
 
 
 def softmax2d(logits_nhwc, K):
     """logits (B, n, C) channel-padded -> prob (B, K, n)"""
     x = f32(logits_nhwc)
     b, n, c = x.shape
-    out = np.zeros((b, K, n), np.float32)
-    assert lib().lp_softmax2d_fwd(ptr(x), n * c, c, 1, b, K, n, ptr(out), None) == 0
-    return out
+    xb, out = Buf(x), Z((b, K, n))
+    ok(lib().lp_softmax2d_fwd(xb.p, n * c, c, 1, b, K, n, out.p, stream()))
+    return out.np()
 
 
-def softmax2d_bwd(prob, gprob, C):
+def softmax2d_bwd(prob, gprob, Cn):
     prob, gprob = f32(prob), f32(gprob)
     b, k, n = prob.shape
-    gin = np.zeros((b, n, C), np.uint16)
-    assert lib().lp_softmax2d_bwd(ptr(prob), ptr(gprob), b, k, n, ptr(gin), n * C, C, 1, None) == 0
-    return from_bf16_bits(gin).numpy()
+    pb, gb, gin = Buf(prob), Buf(gprob), Z((b, n, Cn), np.uint16)
+    ok(lib().lp_softmax2d_bwd(pb.p, gb.p, b, k, n, gin.p, n * Cn, Cn, 1, stream()))
+    return from_bf16_bits(gin.np()).numpy()
 
 
 def temporal(kp, conf, eps, thr):
     kp = f32(kp)
     s, k, _ = kp.shape
-    c = f32(conf) if conf is not None else None
-    e = f32(np.broadcast_to(np.asarray(eps, np.float32), (k,)))
-    loss, g = np.zeros(1, np.float32), np.zeros_like(kp)
-    assert lib().lp_temporal_fwd_bwd(ptr(kp), ptr(c), s, k, ptr(e), thr, ptr(loss), ptr(g), None) == 0
-    return loss[0], g
+    kb, cb = Buf(kp), B(conf, np.float32)
+    eb = Buf(f32(np.broadcast_to(np.asarray(eps, np.float32), (k,))))
+    loss, g = Z(1), Z(kp.shape)
+    ok(lib().lp_temporal_fwd_bwd(kb.p, ptr(cb), s, k, eb.p, thr, loss.p, g.p, stream()))
+    return loss.np()[0], g.np()
 
 
 def pca(kp, index, mean, kept, eps):
@@ -159,18 +201,18 @@ def pca(kp, index, mean, kept, eps):
     s, k, _ = kp.shape
     idx = i32(index)
     rows, pts = idx.shape
-    mean, kept = f32(mean), f32(kept)
-    loss, g = np.zeros(1, np.float32), np.zeros_like(kp)
-    assert lib().lp_pca_fwd_bwd(ptr(kp), s, k, ptr(idx), rows, pts, ptr(mean), ptr(kept), kept.shape[0], float(eps), ptr(loss),
-                                ptr(g), None) == 0
-    return loss[0], g
+    kept = f32(kept)
+    kb, ib, mb, vb = Buf(kp), Buf(idx), Buf(f32(mean)), Buf(kept)
+    loss, g = Z(1), Z(kp.shape)
+    ok(lib().lp_pca_fwd_bwd(kb.p, s, k, ib.p, rows, pts, mb.p, vb.p, kept.shape[0], float(eps), loss.p, g.p, stream()))
+    return loss.np()[0], g.np()
 
 
 def rmse(targ, pred):
     targ, pred = f32(targ), f32(pred)
-    loss = np.zeros(1, np.float32)
-    assert lib().lp_rmse_fwd(ptr(targ), ptr(pred), targ.size // 2, ptr(loss), None) == 0
-    return loss[0]
+    tb, pb, loss = Buf(targ), Buf(pred), Z(1)
+    ok(lib().lp_rmse_fwd(tb.p, pb.p, targ.size // 2, loss.p, stream()))
+    return loss.np()[0]
 
 
 # ---- bf16 helpers / conv wrappers -------------------------------------------------------------------
@@ -185,115 +227,112 @@ def from_bf16_bits(a: np.ndarray) -> "torch.Tensor":
     return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
 
 
-def geom(B, Hi, Wi, Ci, Co, R, S, stride, pad, Ho=None, Wo=None):
+def geom(Bn, Hi, Wi, Ci, Co, R, S, stride, pad, Ho=None, Wo=None):
     if Ho is None:
         Ho = (Hi + 2 * pad - R) // stride + 1
         Wo = (Wi + 2 * pad - S) // stride + 1
-    return _lib.ConvGeom(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad)
+    return _lib.ConvGeom(Bn, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad)
 
 
 def conv_fwd(x_nhwc_bits, w_bits, g, bias=None, f32_out=False, ldo=None, n_store=0):
     M = g.B * g.Ho * g.Wo
     ldo = ldo or g.Co
-    ob = np.zeros((M, ldo), np.uint16)
-    of = np.zeros((M, ldo), np.float32) if f32_out else None
-    b = f32(bias) if bias is not None else None
-    rc = lib().lp_conv_fwd(ptr(x_nhwc_bits), ptr(w_bits), C.byref(g), ptr(b), ptr(ob), ptr(of), ldo, n_store, None)
-    assert rc == 0, rc
-    return ob, of
+    xb, wb, bb = Buf(x_nhwc_bits), Buf(w_bits), B(bias, np.float32)
+    ob = Z((M, ldo), np.uint16)
+    of = Z((M, ldo)) if f32_out else None
+    ok(lib().lp_conv_fwd(xb.p, wb.p, C.byref(g), ptr(bb), ob.p, ptr(of), ldo, n_store, stream()))
+    return ob.np(), (of.np() if of is not None else None)
 
 
 def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, ldo=None, n_store=0):
     M = g.B * g.Hi * g.Wi
     ldo = ldo or g.Ci
-    ob = np.zeros((M, ldo), np.uint16)
-    of = np.zeros((M, ldo), np.float32) if f32_out else None
-    b = f32(bias) if bias is not None else None
-    rc = lib().lp_conv_dgrad(ptr(dy_bits), ptr(wd_bits), C.byref(g), ptr(b), ptr(addend_bits), ptr(ob), ptr(of), ldo, n_store, None)
-    assert rc == 0, rc
-    return ob, of
+    db, wb, ab, bb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(bias, np.float32)
+    ob = Z((M, ldo), np.uint16)
+    of = Z((M, ldo)) if f32_out else None
+    ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), ptr(bb), ptr(ab), ob.p, ptr(of), ldo, n_store, stream()))
+    return ob.np(), (of.np() if of is not None else None)
 
 
 def conv_wgrad(x_bits, dy_bits, g, split=0):
-    dw = np.zeros((g.Co, g.R * g.S * g.Ci), np.float32)
-    rc = lib().lp_conv_wgrad(ptr(x_bits), ptr(dy_bits), C.byref(g), ptr(dw), split, None)
-    assert rc == 0, rc
-    return dw
+    xb, db, dw = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
+    ok(lib().lp_conv_wgrad(xb.p, db.p, C.byref(g), dw.p, split, stream()))
+    return dw.np()
 
 
 def stem_fwd(x4_bits, w_bits, g):
-    ob = np.zeros((g.B * g.Ho * g.Wo, 64), np.uint16)
-    assert lib().lp_stem_fwd(ptr(x4_bits), ptr(w_bits), C.byref(g), ptr(ob), None) == 0
-    return ob
+    xb, wb, ob = Buf(x4_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, 64), np.uint16)
+    ok(lib().lp_stem_fwd(xb.p, wb.p, C.byref(g), ob.p, stream()))
+    return ob.np()
 
 
 def stem_wgrad(x4_bits, dy_bits, g, split=0):
-    dw = np.zeros((64, 256), np.float32)
-    assert lib().lp_stem_wgrad(ptr(x4_bits), ptr(dy_bits), C.byref(g), ptr(dw), split, None) == 0
-    return dw
+    xb, db, dw = Buf(x4_bits), Buf(dy_bits), Z((64, 256))
+    ok(lib().lp_stem_wgrad(xb.p, db.p, C.byref(g), dw.p, split, stream()))
+    return dw.np()
 
 
-def bn_forward(x_bits, M, C, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None):
-    sums = np.zeros((2, C), np.float32)
-    assert lib().lp_bn_stats(ptr(x_bits), M, C, ptr(sums), None) == 0
-    mean, invstd = np.zeros(C, np.float32), np.zeros(C, np.float32)
-    rm, rv = (running if running is not None else (None, None))
-    assert lib().lp_bn_finalize(ptr(sums), float(M), C, eps, momentum, ptr(mean), ptr(invstd), ptr(rm), ptr(rv), None) == 0
-    y = np.zeros((M, C), np.uint16)
-    g, b = f32(gamma), f32(beta)
-    assert lib().lp_bn_apply(ptr(x_bits), ptr(mean), ptr(invstd), ptr(g), ptr(b), ptr(residual_bits), int(relu), M, C, ptr(y), None) == 0
-    return y, mean, invstd
+def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None):
+    xb, rb = Buf(x_bits), B(residual_bits)
+    sums, mean, invstd = Z((2, Cn)), Z(Cn), Z(Cn)
+    ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, stream()))
+    rm = Buf(running[0]) if running is not None else None
+    rv = Buf(running[1]) if running is not None else None
+    ok(lib().lp_bn_finalize(sums.p, float(M), Cn, eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), stream()))
+    y, gb, bb = Z((M, Cn), np.uint16), Buf(f32(gamma)), Buf(f32(beta))
+    ok(lib().lp_bn_apply(xb.p, mean.p, invstd.p, gb.p, bb.p, ptr(rb), int(relu), M, Cn, y.p, stream()))
+    if running is not None:
+        running[0][:] = rm.np()
+        running[1][:] = rv.np()
+    return y.np(), mean.np(), invstd.np()
 
 
-def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, C, want_dres=False):
-    sums = np.zeros((2, C), np.float32)
-    dbeta, dgamma = np.zeros(C, np.float32), np.zeros(C, np.float32)
-    assert lib().lp_bn_bwd_reduce(ptr(dy_bits), ptr(y_bits), ptr(x_bits), ptr(mean), ptr(invstd), M, C, ptr(sums), ptr(dbeta),
-                                  ptr(dgamma), None) == 0
-    dx = np.zeros((M, C), np.uint16)
-    dres = np.zeros((M, C), np.uint16) if want_dres else None
-    g = f32(gamma)
-    assert lib().lp_bn_bwd_apply(ptr(dy_bits), ptr(y_bits), ptr(x_bits), ptr(mean), ptr(invstd), ptr(g), ptr(sums), float(M), M, C,
-                                 ptr(dx), ptr(dres), None) == 0
-    return dx, dres, dgamma, dbeta
+def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False):
+    db, yb, xb, mb, vb, gb = Buf(dy_bits), B(y_bits), Buf(x_bits), Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma))
+    sums, dbeta, dgamma = Z((2, Cn)), Z(Cn), Z(Cn)
+    ok(lib().lp_bn_bwd_reduce(db.p, ptr(yb), xb.p, mb.p, vb.p, M, Cn, sums.p, dbeta.p, dgamma.p, stream()))
+    dx = Z((M, Cn), np.uint16)
+    dres = Z((M, Cn), np.uint16) if want_dres else None
+    ok(lib().lp_bn_bwd_apply(db.p, ptr(yb), xb.p, mb.p, vb.p, gb.p, sums.p, float(M), M, Cn, dx.p, ptr(dres), stream()))
+    return dx.np(), (dres.np() if dres is not None else None), dgamma.np(), dbeta.np()
 
 
-def maxpool(x_bits, B, Hi, Wi, C):
+def maxpool(x_bits, Bn, Hi, Wi, Cn):
     Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
-    y = np.zeros((B, Ho, Wo, C), np.uint16)
-    assert lib().lp_maxpool_fwd(ptr(x_bits), B, Hi, Wi, C, ptr(y), None) == 0
-    return y
+    xb, y = Buf(x_bits), Z((Bn, Ho, Wo, Cn), np.uint16)
+    ok(lib().lp_maxpool_fwd(xb.p, Bn, Hi, Wi, Cn, y.p, stream()))
+    return y.np()
 
 
-def maxpool_bwd(x_bits, dy_bits, B, Hi, Wi, C):
-    dx = np.zeros((B, Hi, Wi, C), np.uint16)
-    assert lib().lp_maxpool_bwd(ptr(x_bits), ptr(dy_bits), B, Hi, Wi, C, ptr(dx), None) == 0
-    return dx
+def maxpool_bwd(x_bits, dy_bits, Bn, Hi, Wi, Cn):
+    xb, db, dx = Buf(x_bits), Buf(dy_bits), Z((Bn, Hi, Wi, Cn), np.uint16)
+    ok(lib().lp_maxpool_bwd(xb.p, db.p, Bn, Hi, Wi, Cn, dx.p, stream()))
+    return dx.np()
 
 
 def images_to_nhwc4(img):
     img = f32(img)
     b, _, h, w = img.shape
-    out = np.zeros((b, h, w, 4), np.uint16)
-    assert lib().lp_images_to_nhwc4(ptr(img), b, h, w, ptr(out), None) == 0
-    return out
+    ib, out = Buf(img), Z((b, h, w, 4), np.uint16)
+    ok(lib().lp_images_to_nhwc4(ib.p, b, h, w, out.p, stream()))
+    return out.np()
 
 
-def pixel_shuffle(x_bits, B, h, w, c_out, inverse=False):
-    out = np.zeros((B, h, w, 4 * c_out) if inverse else (B, 2 * h, 2 * w, c_out), np.uint16)
-    assert lib().lp_pixel_shuffle(ptr(x_bits), B, h, w, c_out, int(inverse), ptr(out), None) == 0
-    return out
+def pixel_shuffle(x_bits, Bn, h, w, c_out, inverse=False):
+    xb = Buf(x_bits)
+    out = Z((Bn, h, w, 4 * c_out) if inverse else (Bn, 2 * h, 2 * w, c_out), np.uint16)
+    ok(lib().lp_pixel_shuffle(xb.p, Bn, h, w, c_out, int(inverse), out.p, stream()))
+    return out.np()
 
 
 def adam(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, decoupled=False):
-    p, g, m, v = f32(p).copy(), f32(g), f32(m).copy(), f32(v).copy()
-    pb = np.zeros(p.shape, np.uint16)
-    assert lib().lp_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.size, lr, beta1, beta2, eps, wd, int(decoupled), step, 1.0, ptr(pb),
-                              None) == 0
-    return p, m, v, pb
+    pb, gb, mb, vb = Buf(f32(p)), Buf(f32(g)), Buf(f32(m)), Buf(f32(v))
+    wb = Z(np.shape(p), np.uint16)
+    ok(lib().lp_adam_step(pb.p, gb.p, mb.p, vb.p, int(np.size(p)), lr, beta1, beta2, eps, wd, int(decoupled), step, 1.0, wb.p, stream()))
+    return pb.np(), mb.np(), vb.np(), wb.np()
 
 
-def permute_cba(src_bits, A, B, Cn):
-    dst = np.zeros((Cn, B, A), np.uint16)
-    assert lib().lp_permute_cba(ptr(src_bits), A, B, Cn, ptr(dst), None) == 0
-    return dst
+def permute_cba(src_bits, A, Bm, Cn):
+    sb, dst = Buf(src_bits), Z((Cn, Bm, A), np.uint16)
+    ok(lib().lp_permute_cba(sb.p, A, Bm, Cn, dst.p, stream()))
+    return dst.np()

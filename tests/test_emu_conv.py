@@ -8,6 +8,8 @@ import torch.nn.functional as F
 
 from tests.hipemu import emu
 
+pytestmark = pytest.mark.usefixtures("kernel_backend")
+
 bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
 
 

@@ -15,17 +15,6 @@ from oracle.restated import _bn_train, _q, _RoundGrad
 from tests.hipemu import emu
 
 
-@pytest.fixture()
-def emulated(monkeypatch):
-    from lightning_pose_amd import _lib, ops
-
-    monkeypatch.setattr(_lib, "_lib", emu.lib())
-    monkeypatch.setattr(ops, "require_device", lambda *a: None)
-    monkeypatch.setattr(ops, "require_device_type", lambda d: None)
-    monkeypatch.setattr(ops, "_stream", lambda: None)
-    yield
-
-
 def nchw(t):
     return t.float().permute(0, 3, 1, 2).contiguous()
 
@@ -36,7 +25,8 @@ def close(name, a, b, cos_min=0.995, ratio_tol=0.03):
     assert cos > cos_min and abs(ratio - 1) < ratio_tol, f"{name}: cos {cos:.5f} ratio {ratio:.4f}"
 
 
-def test_engine_forward_backward_blockwise(emulated):
+def test_engine_forward_backward_blockwise(stack_backend):
+    dev = stack_backend
     from lightning_pose_amd.engine import Engine
     from lightning_pose_amd.models.backbones._init import seeded_state_dict
 
@@ -49,26 +39,28 @@ def test_engine_forward_backward_blockwise(emulated):
             sd[k] = sd[k] * 60
         if k.startswith("head") and k.endswith("bias"):
             sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.1
-    eng = Engine(K, 2, "cpu")
+    eng = Engine(K, 2, dev)
     eng.load_state_dict(sd, strict=False)
     ref = O.OracleTracker(K, 2, torch_seed=7)
     ref.load_state_dict(sd, strict=False)
     ref.train()
     images = torch.randn(4, 3, 64, 64, generator=gen)
-    heat, tape = eng.forward(images, True)
+    heat, tape = eng.forward(images.to(dev), True)
     gh = torch.randn(heat.shape, generator=gen)
     eng.zero_grad()
     trace: dict = {}
-    eng.backward(tape, gh, trace)
-    T = tape.t
+    eng.backward(tape, gh.to(dev), trace)
+    heat = heat.cpu()
+    trace = {k: v.cpu() for k, v in trace.items()}
+    T = {k: v.cpu() for k, v in tape.t.items()}
     G = {}
     for c in eng.plan.convs:
-        G[c.name + ".weight"] = eng.param_view(c, "weight", buf=eng.G)
+        G[c.name + ".weight"] = eng.param_view(c, "weight", buf=eng.G).cpu()
         if c.kind == "convT":
-            G[c.name + ".bias"] = eng.param_view(c, "bias", buf=eng.G)
+            G[c.name + ".bias"] = eng.param_view(c, "bias", buf=eng.G).cpu()
     for b in eng.plan.bns:
-        G[b.name + ".weight"] = eng.param_view(b, "weight", buf=eng.G)
-        G[b.name + ".bias"] = eng.param_view(b, "bias", buf=eng.G)
+        G[b.name + ".weight"] = eng.param_view(b, "weight", buf=eng.G).cpu()
+        G[b.name + ".bias"] = eng.param_view(b, "bias", buf=eng.G).cpu()
     bb = ref.backbone
 
     # ---- stem forward (exact up to 1 bf16 ulp) and running statistics

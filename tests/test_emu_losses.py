@@ -8,6 +8,8 @@ import torch
 from oracle import restated as O
 from tests.hipemu import emu
 
+pytestmark = pytest.mark.usefixtures("kernel_backend")
+
 
 def test_heatmap_gen_golden(golden):
     g = golden("heatmaps")

@@ -11,28 +11,17 @@ from oracle import restated as O
 from tests.hipemu import emu
 
 
-@pytest.fixture()
-def emulated(monkeypatch):
-    from lightning_pose_amd import _lib, ops
-
-    monkeypatch.setattr(_lib, "_lib", emu.lib())
-    monkeypatch.setattr(ops, "require_device", lambda *a: None)
-    monkeypatch.setattr(ops, "require_device_type", lambda d: None)
-    monkeypatch.setattr(ops, "_stream", lambda: None)
-    ops._device_tables.cache_clear()
-    yield
-    ops._device_tables.cache_clear()
-
-
-def _batch(g):
+def _batch(g, dev):
+    d = lambda k: g.t(k).to(dev)  # noqa: E731
     return {
-        "labeled": {"images": g.t("images"), "keypoints": g.t("keypoints"), "heatmaps": g.t("heatmaps"), "bbox": g.t("bbox_l"),
+        "labeled": {"images": d("images"), "keypoints": d("keypoints"), "heatmaps": d("heatmaps"), "bbox": d("bbox_l"),
                     "idxs": torch.arange(4)},
-        "unlabeled": {"frames": g.t("frames"), "transforms": g.t("A"), "bbox": g.t("bbox_u"), "is_multiview": False},
+        "unlabeled": {"frames": d("frames"), "transforms": d("A"), "bbox": d("bbox_u"), "is_multiview": False},
     }
 
 
-def test_tracker_training_step_vs_reference_golden(emulated, golden):
+def test_tracker_training_step_vs_reference_golden(stack_backend, golden):
+    dev = stack_backend
     from lightning_pose_amd.losses import LossFactory
     from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
 
@@ -40,9 +29,9 @@ def test_tracker_training_step_vs_reference_golden(emulated, golden):
     sup = LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
     unsup = LossFactory({"temporal": {"log_weight": 2.0, "epsilon": 1.0, "prob_threshold": 0.0}}, None)
     model = SemiSupervisedHeatmapTracker(num_keypoints=3, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
-                                         pretrained=False, torch_seed=7, device="cpu")
+                                         pretrained=False, torch_seed=7, device=dev)
     # seeded initialisation equals the reference's, and the state_dict uses the reference's names / shapes
-    sd = model.state_dict()
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
     assert float(sd["backbone.0.weight"].double().sum()) == pytest.approx(float(g["w_conv1_sum"]), rel=1e-9)
     assert float(sd["head.upsampling_layers.1.weight"].double().sum()) == pytest.approx(float(g["w_head1_sum"]), rel=1e-9)
     ref = O.OracleTracker(3, 2, torch_seed=7).state_dict()
@@ -55,7 +44,7 @@ def test_tracker_training_step_vs_reference_golden(emulated, golden):
     model.train()
     opt = model.configure_optimizers()["optimizer"]
     opt.zero_grad()
-    out = model.training_step(_batch(g), 0)
+    out = model.training_step(_batch(g, dev), 0)
     out["loss"].backward()
     want = dict(zip([str(n) for n in g["log_names"]], g["log_values"]))
     assert set(want) == set(model.logged)
