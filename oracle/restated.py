@@ -251,7 +251,7 @@ def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None = No
     """losses/losses.py:576-703: mean over ALL (S-1)*K of relu(mask * ||kp[t+1]-kp[t]|| - eps_k)."""
     s = keypoints.shape[0]
     d = (keypoints[1:] - keypoints[:-1]).reshape(s - 1, -1, 2)
-    dist = torch.sqrt((d ** 2).sum(-1))
+    dist = torch.linalg.norm(d, ord=2, dim=2)  # same op as the reference: zero sub-gradient at d = 0
     if confidences is not None:
         low = confidences < prob_threshold
         dist = torch.where(low[1:] | low[:-1], torch.zeros_like(dist), dist)
@@ -278,7 +278,7 @@ def pca_reprojection_error(data: torch.Tensor, mean: torch.Tensor, kept: torch.T
     """utils/pca.py:266-309: per-2D-keypoint norm of x - ((x-mu) V^T V + mu)."""
     c = data - mean
     resid = c - (c @ kept.T) @ kept
-    return torch.sqrt((resid.reshape(resid.shape[0], -1, 2) ** 2).sum(-1))
+    return torch.linalg.norm(resid.reshape(resid.shape[0], -1, 2), dim=2)
 
 
 def pca_loss(data: torch.Tensor, mean: torch.Tensor, kept: torch.Tensor, epsilon: float | torch.Tensor) -> torch.Tensor:
