@@ -209,6 +209,11 @@ def main() -> None:
                 rec[2] += flops
                 tot_ms += ms
                 tot_flops += flops
+            dump = os.environ.get("LP_DUMP_LAUNCHES")
+            if dump:  # per-launch (tag, GFLOP, us) of the LAST timed step, for kernel tuning
+                per_step = len(prof) // args.steps
+                with open(dump, "w") as fh:
+                    json.dump([[t, round(f / 1e9, 3), round(1000 * a.elapsed_time(b), 1)] for t, f, a, b in prof[-per_step:]], fh)
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches)",

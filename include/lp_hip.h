@@ -169,8 +169,9 @@ int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const flo
                      float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
 int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
                     const float* sums, float count, int M, int C, void* dx, void* dres, lp_stream_t stream);
-int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, lp_stream_t stream);
-int lp_maxpool_bwd(const void* x, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
+/* 3x3 / stride 2 / pad 1; argmax_u8 (B,Ho,Wo,C) records the winning tap (first maximum, ATen tie rule) for the backward gather */
+int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream);
+int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
 int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_bf16, lp_stream_t stream);
 /* (B,h,w,4*c_out) -> (B,2h,2w,c_out); inverse = 1 maps the gradient back */
 int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int inverse, void* out, lp_stream_t stream);

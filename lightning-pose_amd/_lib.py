@@ -65,7 +65,7 @@ PROTOTYPES = {
     "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
-    "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "lp_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
     "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -25,21 +25,21 @@ __device__ __forceinline__ u16x8 pack8(const float (&f)[8]) {
     return v;
 }
 
-// ---- per-channel sums over rows: sums[0][c] += sum x, sums[1][c] += sum x*y  (y = x when X2 is null) -------------
+// ---- per-channel sums over rows: sums[0][c] += sum a, sums[1][c] += sum a*b -------------------------------------
 // MODE 0: plain statistics (sum x, sum x^2)
 // MODE 1: BN backward reductions: dz = relu-masked dy;  sum dz, sum dz * xhat
+// Grid-stride over rows with register accumulators (4 independent 16-B loads in flight per lane), ONE LDS reduction and
+// 2*C atomics per workgroup; the grid is capped so that at most a few hundred workgroups contend on a channel.
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Yout,
                                                         const unsigned short* __restrict__ X, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, int M, int C, int rows_per_block,
+                                                        const float* __restrict__ invstd, int M, int C,
                                                         float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
     __shared__ float red[2][256][8];
     const int chunks = C >> 3;                       // 16-B chunks per row
     const int cpb = chunks < 256 ? chunks : 256;     // chunks handled per block pass
     const int lanes_r = 256 / cpb;                   // row lanes
     const int ch = threadIdx.x % cpb, rl = threadIdx.x / cpb;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(M, r0 + rows_per_block);
     for (int cbase = blockIdx.y * cpb; cbase < chunks; cbase += gridDim.y * cpb) {
         const int c = (cbase + ch) * 8;
         float s0[8], s1[8], mu[8], is[8];
@@ -54,9 +54,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
             }
         }
         if (cv) {
-            for (int r = r0 + rl; r < r1; r += lanes_r) {
+            const int rstep = gridDim.x * lanes_r;
+            for (int r = blockIdx.x * lanes_r + rl; r < M; r += rstep) {
+                const size_t off = (size_t)r * C + c;
                 float a[8];
-                unpack8(*reinterpret_cast<const u16x8*>(A + (size_t)r * C + c), a);
+                unpack8(*reinterpret_cast<const u16x8*>(A + off), a);
                 if (MODE == 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -65,9 +67,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
                     }
                 } else {
                     float x[8];
-                    unpack8(*reinterpret_cast<const u16x8*>(X + (size_t)r * C + c), x);
+                    unpack8(*reinterpret_cast<const u16x8*>(X + off), x);
                     if (Yout != nullptr) {
-                        const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + (size_t)r * C + c);
+                        const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + off);
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
                             if ((yo[i] & 0x7fff) == 0 || (yo[i] & 0x8000)) a[i] = 0.f;  // relu'(y): y <= 0
@@ -86,18 +88,20 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
             red[1][threadIdx.x][i] = s1[i];
         }
         __syncthreads();
-        if (rl == 0 && cv) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+        // every thread finishes one (chunk, component) pair: 256 threads >= cpb * 8 pairs only when cpb <= 32; loop otherwise
+        for (int pair = threadIdx.x; pair < cpb * 8; pair += 256) {
+            const int pc = pair >> 3, pi = pair & 7;
+            if (cbase + pc < chunks) {
                 float t0 = 0.f, t1 = 0.f;
                 for (int q = 0; q < lanes_r; ++q) {
-                    t0 += red[0][q * cpb + ch][i];
-                    t1 += red[1][q * cpb + ch][i];
+                    t0 += red[0][q * cpb + pc][pi];
+                    t1 += red[1][q * cpb + pc][pi];
                 }
-                atomicAdd(&sums[c + i], t0);
-                atomicAdd(&sums[C + c + i], t1);
-                if (acc0) atomicAdd(&acc0[c + i], t0);  // d beta
-                if (acc1) atomicAdd(&acc1[c + i], t1);  // d gamma
+                const int cc = (cbase + pc) * 8 + pi;
+                atomicAdd(&sums[cc], t0);
+                atomicAdd(&sums[C + cc], t1);
+                if (acc0) atomicAdd(&acc0[cc], t0);  // d beta
+                if (acc1) atomicAdd(&acc1[cc], t1);  // d gamma
             }
         }
         __syncthreads();
@@ -182,8 +186,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
 }
 
 // ---- 3x3 stride-2 pad-1 max-pool on NHWC bf16 --------------------------------------------------------------
+// forward also records which tap (kh*3+kw, first maximum in row-major scan with strict >, as ATen's
+// max_pool2d_with_indices) won, one byte per output element, so backward is a pure gather
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ X, int B, int Hi, int Wi, int C, int Ho,
-                                                          int Wo, unsigned short* __restrict__ Y) {
+                                                          int Wo, unsigned short* __restrict__ Y, unsigned char* __restrict__ IDX) {
     const int chunks = C >> 3;
     const size_t total = (size_t)B * Ho * Wo * chunks;
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
@@ -193,8 +199,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
         p /= Wo;
         const int ho = (int)(p % Ho), b = (int)(p / Ho);
         float m[8];
+        unsigned char arg[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+        for (int i = 0; i < 8; ++i) {
+            m[i] = -INFINITY;
+            arg[i] = 0;
+        }
         for (int kh = 0; kh < 3; ++kh) {
             const int hi = ho * 2 - 1 + kh;
             if (hi < 0 || hi >= Hi) continue;
@@ -204,16 +214,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
                 float x[8];
                 unpack8(*reinterpret_cast<const u16x8*>(X + (((size_t)b * Hi + hi) * Wi + wi) * C + ch * 8), x);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], x[i]);
+                for (int i = 0; i < 8; ++i)
+                    if (x[i] > m[i]) {
+                        m[i] = x[i];
+                        arg[i] = (unsigned char)(kh * 3 + kw);
+                    }
             }
         }
         *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(m);
+        uint2 packed;
+        packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+        packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+        *reinterpret_cast<uint2*>(IDX + q * 8) = packed;
     }
 }
 
-// gather form: each input pixel collects dy from the (<= 4) windows whose FIRST maximum (row-major scan, strict >,
-// as ATen's max_pool2d_with_indices) is this pixel
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
+// gather form: each input pixel collects dy from the (<= 4) windows whose recorded arg-max is this pixel
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
                                                           int B, int Hi, int Wi, int C, int Ho, int Wo,
                                                           unsigned short* __restrict__ DX) {
     const int chunks = C >> 3;
@@ -227,39 +244,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* 
         float g[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) g[i] = 0.f;
-        const int ho_lo = max(0, (hi) / 2), ho_hi = min(Ho - 1, (hi + 1) / 2);
-        const int wo_lo = max(0, (wi) / 2), wo_hi = min(Wo - 1, (wi + 1) / 2);
+        const int ho_lo = hi / 2, ho_hi = min(Ho - 1, (hi + 1) / 2);
+        const int wo_lo = wi / 2, wo_hi = min(Wo - 1, (wi + 1) / 2);
         for (int ho = ho_lo; ho <= ho_hi; ++ho)
             for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                float best[8];
-                bool mine[8];
+                const unsigned mine = (unsigned)((hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1)));
+                const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + ch * 8;
+                const uint2 packed = *reinterpret_cast<const uint2*>(IDX + o);
+                float d[8];
+                unpack8(*reinterpret_cast<const u16x8*>(DY + o), d);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    best[i] = -INFINITY;
-                    mine[i] = false;
+                    const unsigned a = ((i < 4 ? packed.x : packed.y) >> (8 * (i & 3))) & 0xffu;
+                    if (a == mine) g[i] += d[i];
                 }
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int y = ho * 2 - 1 + kh;
-                    if (y < 0 || y >= Hi) continue;
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int x = wo * 2 - 1 + kw;
-                        if (x < 0 || x >= Wi) continue;
-                        float v[8];
-                        unpack8(*reinterpret_cast<const u16x8*>(X + (((size_t)b * Hi + y) * Wi + x) * C + ch * 8), v);
-                        const bool self = (y == hi) && (x == wi);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            if (v[i] > best[i]) {
-                                best[i] = v[i];
-                                mine[i] = self;
-                            }
-                    }
-                }
-                float d[8];
-                unpack8(*reinterpret_cast<const u16x8*>(DY + (((size_t)b * Ho + ho) * Wo + wo) * C + ch * 8), d);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (mine[i]) g[i] += d[i];
             }
         *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(g);
     }
@@ -303,6 +301,16 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short
     }
 }
 
+// workgroups for a column reduction: enough to fill the chip (4 per CU), each owning >= 8 row passes
+static int colreduce_blocks(int M, int C) {
+    const int chunks = C / 8;
+    const int lanes_r = chunks < 256 ? 256 / chunks : 1;
+    long passes = ((long)M + lanes_r - 1) / lanes_r;
+    long blocks = (passes + 7) / 8;
+    if (blocks > 1024) blocks = 1024;
+    return blocks < 1 ? 1 : (int)blocks;
+}
+
 static int grid_for(size_t work_items) {
     size_t blocks = (work_items + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
@@ -315,11 +323,10 @@ extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t
     using namespace lp;
     LP_REQUIRE(x && sums && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
-    const int rows = 256;
-    dim3 grid((M + rows - 1) / rows, 1);
+    dim3 grid(colreduce_blocks(M, C), 1);
     hipLaunchKernelGGL((colreduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr, (const float*)nullptr, M,
-                       C, rows, sums, (float*)nullptr, (float*)nullptr);
+                       C, sums, (float*)nullptr, (float*)nullptr);
     return launch_status();
 }
 
@@ -348,10 +355,9 @@ extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x
     using namespace lp;
     LP_REQUIRE(dy && x && mean && invstd && sums && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
-    const int rows = 256;
-    dim3 grid((M + rows - 1) / rows, 1);
+    dim3 grid(colreduce_blocks(M, C), 1);
     hipLaunchKernelGGL((colreduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
-                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, M, C, rows, sums, dbeta_acc, dgamma_acc);
+                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, M, C, sums, dbeta_acc, dgamma_acc);
     return launch_status();
 }
 
@@ -368,23 +374,23 @@ extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x,
     return launch_status();
 }
 
-extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, lp_stream_t stream) {
+extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    LP_REQUIRE(x && y && argmax_u8 && B > 0 && Hi > 0 && Wi > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x, B, Hi, Wi, C, Ho, Wo, (unsigned short*)y);
+                       (const unsigned short*)x, B, Hi, Wi, C, Ho, Wo, (unsigned short*)y, (unsigned char*)argmax_u8);
     return launch_status();
 }
 
-extern "C" int lp_maxpool_bwd(const void* x, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream) {
+extern "C" int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(x && dy && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    LP_REQUIRE(argmax_u8 && dy && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)B * Hi * Wi * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x, (const unsigned short*)dy, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
+                       (const unsigned char*)argmax_u8, (const unsigned short*)dy, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
     return launch_status();
 }
 

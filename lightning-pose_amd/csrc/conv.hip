@@ -42,6 +42,25 @@ struct ConvEpilogue {
 
 enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2 };
 
+// n / d for 0 <= n < 2^31 without the ~40-instruction integer division: q = (n * ceil(2^sh / d)) >> sh
+struct FastDiv {
+    unsigned mul;
+    int sh;
+    int d;
+};
+
+static FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d;
+    int s = 0;
+    while ((1LL << s) < d) ++s;
+    f.sh = 31 + s;
+    f.mul = (unsigned)((((unsigned long long)1 << f.sh) + (unsigned)d - 1) / (unsigned)d);
+    return f;
+}
+
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
 // XCD-aware bijective tile remap (cdna_hip_programming.md T1): block b runs on XCD b % 8; give each XCD a
 // contiguous chunk of the tile space.
 __device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
@@ -110,8 +129,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
     // per-thread row coordinates of the 4 A rows this thread stages
     int pb[4], py[4], px[4];
     bool pv[4];
+    ptrdiff_t rowbase[4];  // element offset of the row's origin pixel in the gathered tensor (fwd / stride-1 dgrad)
     const int rows_y = (MODE == kModeDgrad) ? g.Hi : g.Ho;
     const int rows_x = (MODE == kModeDgrad) ? g.Wi : g.Wo;
+    const int ck = (MODE == kModeDgrad) ? g.Co : g.Ci;  // channels of the gathered tensor
+    const int src_h = (MODE == kModeDgrad) ? g.Ho : g.Hi;
+    const int src_w = (MODE == kModeDgrad) ? g.Wo : g.Wi;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + rbase + 32 * i;
@@ -128,8 +151,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
             py[i] = y * g.stride - g.pad;
             px[i] = (rem - y * rows_x) * g.stride - g.pad;
         }
+        rowbase[i] = (((ptrdiff_t)b * src_h + py[i]) * src_w + px[i]) * ck + kchunk * 8;
     }
-    const int ck = (MODE == kModeDgrad) ? g.Co : g.Ci;  // channels of the gathered tensor
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -141,6 +164,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
 
     u16x8 ra[4], rb[BN / 32];
     int tr = 0, ts = 0, tc = 0;  // filter tap (r, s) and channel offset of the NEXT K step to load
+    const unsigned short* wrow[BN / 32];
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+        const int n = n0 + rbase + 32 * i;
+        wrow[i] = (n < N) ? Wt + (size_t)n * K + kchunk * 8 : nullptr;
+    }
 
     auto load_step = [&](int kt) {
         // ---- A: gathered activations
@@ -154,21 +183,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
                 ra[i] = load4x2(X + base, okr && wi >= 0 && wi < g.Wi, X + base + 4, okr && s0 + 1 < g.S && wi + 1 >= 0 && wi + 1 < g.Wi);
             }
         } else {
+            if (MODE == kModeDgrad && g.stride != 1) {
+                // stride 2: tap (r, s) reaches output pixel ((py - r) / 2, (px - s) / 2) when both differences are even
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bool ok = pv[i];
-                int sy, sx;
-                if (MODE == kModeDgrad) {
+                for (int i = 0; i < 4; ++i) {
                     const int th = py[i] - tr, tw = px[i] - ts;
-                    sy = th / g.stride;
-                    sx = tw / g.stride;
-                    ok = ok && th >= 0 && tw >= 0 && (sy * g.stride == th) && (sx * g.stride == tw) && sy < g.Ho && sx < g.Wo;
-                    ra[i] = ok ? load8(X + ((size_t)(pb[i] * g.Ho + sy) * g.Wo + sx) * ck + tc + kchunk * 8) : zero8();
-                } else {
-                    sy = py[i] + tr;
-                    sx = px[i] + ts;
-                    ok = ok && sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
-                    ra[i] = ok ? load8(X + ((size_t)(pb[i] * g.Hi + sy) * g.Wi + sx) * ck + tc + kchunk * 8) : zero8();
+                    const int sy = th >> 1, sx = tw >> 1;
+                    const bool ok = pv[i] && th >= 0 && tw >= 0 && !((th | tw) & 1) && sy < g.Ho && sx < g.Wo;
+                    ra[i] = ok ? load8(X + (((ptrdiff_t)pb[i] * g.Ho + sy) * g.Wo + sx) * ck + tc + kchunk * 8) : zero8();
+                }
+            } else {
+                // tap offset is wave-uniform: fwd walks +(r, s), stride-1 dgrad walks -(r, s)
+                const int sgn = (MODE == kModeDgrad) ? -1 : 1;
+                const ptrdiff_t tapoff = (ptrdiff_t)sgn * ((ptrdiff_t)tr * src_w + ts) * ck + tc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sy = py[i] + sgn * tr, sx = px[i] + sgn * ts;
+                    const bool ok = pv[i] && sy >= 0 && sy < src_h && sx >= 0 && sx < src_w;
+                    ra[i] = ok ? load8(X + rowbase[i] + tapoff) : zero8();
                 }
             }
             tc += kBK;
@@ -182,10 +214,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
         }
         // ---- B: weights [N][K], K-contiguous
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int n = n0 + rbase + 32 * i;
-            rb[i] = (n < N) ? load8(Wt + (size_t)n * K + kt * kBK + kchunk * 8) : zero8();
-        }
+        for (int i = 0; i < BN / 32; ++i) rb[i] = wrow[i] ? load8(wrow[i] + kt * kBK) : zero8();
     };
     auto store_step = [&](int buf) {
 #pragma unroll
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
 template <int BN, bool STEM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                          ConvGeom g, int M, int Kw, int tiles_n, int m_per_split,
-                                                         float* __restrict__ dW) {
+                                                         FastDiv div_hw, FastDiv div_wo, float* __restrict__ dW) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][kBM * kLD];
@@ -287,8 +316,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
             const int m = mk + mgA * 4 + i;
             bool ok = jv && m < m_end;
             const int mm = ok ? m : 0;
-            const int b = mm / hw, rem = mm - b * hw;
-            const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+            const int b = fdiv(mm, div_hw), rem = mm - b * hw;
+            const int ho = fdiv(rem, div_wo), wo = rem - ho * g.Wo;
             const int hi = ho * g.stride - g.pad + tr, wi = wo * g.stride - g.pad + ts;
             if (STEM) {
                 const bool okr = ok && tr < g.R && hi >= 0 && hi < g.Hi;
@@ -393,7 +422,7 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
-    if (g.Co % kBK != 0) return LP_ERR_UNSUPPORTED;
+    if (g.Co % kBK != 0 || (g.stride != 1 && g.stride != 2)) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Hi * g.Wi, N = g.Ci, K = g.R * g.S * g.Co;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend};
     const int tm = (M + kBM - 1) / kBM;
@@ -429,10 +458,10 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
     hipStream_t st = (hipStream_t)stream;
     if (wide) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tj * tn, split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, g, M, Kw, tn, per, dw);
+                           (const unsigned short*)dy, g, M, Kw, tn, per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), dw);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tj * tn, split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, g, M, Kw, tn, per, dw);
+                           (const unsigned short*)dy, g, M, Kw, tn, per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), dw);
     }
     return launch_status();
 }
@@ -464,6 +493,6 @@ extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom*
     const int per = ((ksteps + split - 1) / split) * kBK;
     split = (M + per - 1) / per;
     hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(tj, split), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x4,
-                       (const unsigned short*)dy, g, M, Kw, 1, per, dw);
+                       (const unsigned short*)dy, g, M, Kw, 1, per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), dw);
     return launch_status();
 }

@@ -367,7 +367,8 @@ class Engine:
         T["stem.z"], T["stem.a"], T["stem.mu"], T["stem.iv"] = z, a, mu, iv
         ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         x = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_maxpool_fwd(_p(a), B, h, w, 64, _p(x), ops._stream()), "lp_maxpool_fwd")
+        T["pool.arg"] = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.uint8)
+        check(self._lib.lp_maxpool_fwd(_p(a), B, h, w, 64, _p(x), _p(T["pool.arg"]), ops._stream()), "lp_maxpool_fwd")
         h, w = ph, pw
         tp.meta["stem_hw"] = (g.Ho, g.Wo)
 
@@ -508,7 +509,7 @@ class Engine:
             trace["stem.dpool"] = d
         sh, sw = tp.meta["stem_hw"]
         da = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_maxpool_bwd(_p(T["stem.a"]), _p(d), B, sh, sw, 64, _p(da), ops._stream()), "lp_maxpool_bwd")
+        check(self._lib.lp_maxpool_bwd(_p(T["pool.arg"]), _p(d), B, sh, sw, 64, _p(da), ops._stream()), "lp_maxpool_bwd")
         dz, _ = self._bn_bwd(plan.stem_bn, da, T["stem.a"], T["stem.z"], T["stem.mu"], T["stem.iv"], B * sh * sw, False)
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),

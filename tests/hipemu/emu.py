@@ -299,14 +299,14 @@ def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=F
 
 def maxpool(x_bits, Bn, Hi, Wi, Cn):
     Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
-    xb, y = Buf(x_bits), Z((Bn, Ho, Wo, Cn), np.uint16)
-    ok(lib().lp_maxpool_fwd(xb.p, Bn, Hi, Wi, Cn, y.p, stream()))
-    return y.np()
+    xb, y, arg = Buf(x_bits), Z((Bn, Ho, Wo, Cn), np.uint16), Z((Bn, Ho, Wo, Cn), np.uint8)
+    ok(lib().lp_maxpool_fwd(xb.p, Bn, Hi, Wi, Cn, y.p, arg.p, stream()))
+    return y.np(), arg.np()
 
 
-def maxpool_bwd(x_bits, dy_bits, Bn, Hi, Wi, Cn):
-    xb, db, dx = Buf(x_bits), Buf(dy_bits), Z((Bn, Hi, Wi, Cn), np.uint16)
-    ok(lib().lp_maxpool_bwd(xb.p, db.p, Bn, Hi, Wi, Cn, dx.p, stream()))
+def maxpool_bwd(arg_u8, dy_bits, Bn, Hi, Wi, Cn):
+    ab, db, dx = Buf(arg_u8), Buf(dy_bits), Z((Bn, Hi, Wi, Cn), np.uint16)
+    ok(lib().lp_maxpool_bwd(ab.p, db.p, Bn, Hi, Wi, Cn, dx.p, stream()))
     return dx.np()
 
 

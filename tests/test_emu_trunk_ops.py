@@ -57,9 +57,9 @@ def test_maxpool_fwd_bwd_with_ties():
     dy = bf(torch.randn(y.shape, generator=gen))
     y.backward(dy)
     xb = emu.to_bf16_bits(x.detach().permute(0, 2, 3, 1))
-    yb = emu.maxpool(xb, B, H, W, C)
+    yb, arg = emu.maxpool(xb, B, H, W, C)
     torch.testing.assert_close(emu.from_bf16_bits(yb), y.detach().permute(0, 2, 3, 1))
-    dx = emu.maxpool_bwd(xb, emu.to_bf16_bits(dy.permute(0, 2, 3, 1)), B, H, W, C)
+    dx = emu.maxpool_bwd(arg, emu.to_bf16_bits(dy.permute(0, 2, 3, 1)), B, H, W, C)
     torch.testing.assert_close(emu.from_bf16_bits(dx), bf(x.grad.permute(0, 2, 3, 1)), atol=2e-2, rtol=2e-2)
 
 
