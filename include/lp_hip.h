@@ -147,11 +147,15 @@ int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const fl
 /* wd: bf16 [Ci][R][S][Co] (Co % 64 == 0); optional bf16 addend (same layout as dx) is summed in. */
 int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend, void* dx_bf16,
                   float* dx_f32, int ldo, int n_store, lp_stream_t stream);
-/* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split. */
-int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, lp_stream_t stream);
+/* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split.  The pixel slices leave
+ * partial tiles in `workspace` (lp_conv_wgrad_workspace_bytes) and a second kernel sums them in a fixed order: deterministic. */
+size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);
+int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
+                  size_t workspace_bytes, lp_stream_t stream);
 /* ResNet stem 7x7/2: x4 = NHWC4 bf16 (channel 3 zero), weights / gradients in the padded [64][8][8][4] layout. */
 int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_stream_t stream);
-int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, lp_stream_t stream);
+int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
+                  size_t workspace_bytes, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * HBM-bound glue of the trunk (NHWC bf16): BatchNorm2d training mode, ReLU, residual add, MaxPool2d(3,2,1),

@@ -198,6 +198,7 @@ class Engine:
         self.process_group = None
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
+        self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
 
     def _timed(self, tag: str, flops: float, fn):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -209,6 +210,14 @@ class Engine:
         e1.record()
         self.profile.append((tag, flops, e0, e1))
         return out
+
+    def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False) -> None:
+        need = self._lib.lp_conv_wgrad_workspace_bytes(C.byref(g), 0)
+        if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
+            self._wgrad_ws = torch.empty(max(need, 96 << 20), device=self.device, dtype=torch.uint8)
+        fn = self._lib.lp_stem_wgrad if stem else self._lib.lp_conv_wgrad
+        check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()),
+              "lp_stem_wgrad" if stem else "lp_conv_wgrad")
 
     @staticmethod
     def _flops(c: "ConvP", g) -> float:
@@ -444,8 +453,7 @@ class Engine:
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None):
         g = self._geom(c, B, Hi, Wi)
-        self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g),
-                    lambda: check(self._lib.lp_conv_wgrad(_p(x), _p(dz), C.byref(g), _p(self.G[c.w_off:]), 0, ops._stream()), "lp_conv_wgrad"))
+        self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g), lambda: self._wgrad(x, dz, g, self.G[c.w_off:]))
         if not need_dx:
             return None
         dx = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16)
@@ -475,7 +483,7 @@ class Engine:
             bsum = torch.zeros(2 * CPAD, device=self.device, dtype=torch.float32)
             check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
             self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
-            check(self._lib.lp_conv_wgrad(_p(dcur), _p(x_small), C.byref(g), _p(self.G[c.w_off:]), 0, ops._stream()), "lp_conv_wgrad(head)")
+            self._wgrad(dcur, x_small, g, self.G[c.w_off:])
             dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
             check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
                   "lp_conv_fwd(head bwd)")
@@ -513,5 +521,4 @@ class Engine:
         dz, _ = self._bn_bwd(plan.stem_bn, da, T["stem.a"], T["stem.z"], T["stem.mu"], T["stem.iv"], B * sh * sw, False)
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
-                    lambda: check(self._lib.lp_stem_wgrad(_p(T["x4"]), _p(dz), C.byref(g), _p(self.G[plan.stem.w_off:]), 0, ops._stream()),
-                                  "lp_stem_wgrad"))
+                    lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True))

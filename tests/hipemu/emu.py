@@ -256,7 +256,9 @@ def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, 
 
 def conv_wgrad(x_bits, dy_bits, g, split=0):
     xb, db, dw = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
-    ok(lib().lp_conv_wgrad(xb.p, db.p, C.byref(g), dw.p, split, stream()))
+    nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)
+    ws = Z(nws, np.uint8)
+    ok(lib().lp_conv_wgrad(xb.p, db.p, C.byref(g), dw.p, split, ws.p, nws, stream()))
     return dw.np()
 
 
@@ -268,7 +270,9 @@ def stem_fwd(x4_bits, w_bits, g):
 
 def stem_wgrad(x4_bits, dy_bits, g, split=0):
     xb, db, dw = Buf(x4_bits), Buf(dy_bits), Z((64, 256))
-    ok(lib().lp_stem_wgrad(xb.p, db.p, C.byref(g), dw.p, split, stream()))
+    nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)
+    ws = Z(nws, np.uint8)
+    ok(lib().lp_stem_wgrad(xb.p, db.p, C.byref(g), dw.p, split, ws.p, nws, stream()))
     return dw.np()
 
 

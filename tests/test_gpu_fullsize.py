@@ -94,7 +94,9 @@ def test_conv_real_layer_shapes(shape):
     assert lib.lp_conv_dgrad(_p(dyd), _p(wd), C.byref(g), None, None, None, _p(dx), Ci, 0, _stream()) == 0
     torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 1).reshape(-1, Ci), atol=2e-3, rtol=2e-3)
     dw = torch.zeros(Co, k * k * Ci, device=dev, dtype=torch.float32)
-    assert lib.lp_conv_wgrad(_p(xd), _p(dyd), C.byref(g), _p(dw), 0, _stream()) == 0
+    nws = lib.lp_conv_wgrad_workspace_bytes(C.byref(g), 0)
+    ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+    assert lib.lp_conv_wgrad(_p(xd), _p(dyd), C.byref(g), _p(dw), 0, _p(ws), nws, _stream()) == 0
     want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
     torch.testing.assert_close(dw.cpu(), want, atol=2e-2, rtol=5e-3)
 
