@@ -151,6 +151,8 @@ def main() -> None:
     rank, local_rank, world = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("LP_FORCE_DEVICE") is not None:  # functional multi-rank test on a 1-GPU box (with LP_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["LP_FORCE_DEVICE"])
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 

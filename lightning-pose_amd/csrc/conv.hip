@@ -453,6 +453,59 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// same reduction for layers with MANY slices and few tiles (layer1: 768 slices of one tile): one workgroup per 64
+// consecutive accumulator elements, its 4 waves stride over the slices, then combine through LDS (fixed order)
+template <int BN>
+__global__ __launch_bounds__(256) void wgrad_reduce_sliced_kernel(const float* __restrict__ ws, int slices, int tiles, int tiles_n,
+                                                                  int Kw, int Co, float* __restrict__ dW) {
+    constexpr int NT = BN / 64;
+    constexpr int PER_TILE = 4 * 2 * NT * 16 * 64;
+    __shared__ float part[4][64];
+    const size_t total = (size_t)tiles * PER_TILE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sl = w;
+    for (; sl + 12 < slices; sl += 16) {  // 4 independent loads in flight per lane
+        s0 += ws[(size_t)sl * total + i];
+        s1 += ws[(size_t)(sl + 4) * total + i];
+        s2 += ws[(size_t)(sl + 8) * total + i];
+        s3 += ws[(size_t)(sl + 12) * total + i];
+    }
+    for (; sl < slices; sl += 4) s0 += ws[(size_t)sl * total + i];
+    part[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0) {
+        const float sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        size_t t = i >> 6;
+        const int e = (int)(t & 15);
+        t >>= 4;
+        const int nt = (int)(t % NT);
+        t /= NT;
+        const int mt = (int)(t & 1);
+        t >>= 1;
+        const int wave = (int)(t & 3);
+        const int tile = (int)(t >> 2);
+        const int wm = wave >> 1, wn = wave & 1;
+        const int j = (tile / tiles_n) * kBM + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int n = (tile % tiles_n) * BN + wn * (NT * 32) + nt * 32 + (lane & 31);
+        if (j < Kw && n < Co) dW[(size_t)n * Kw + j] += sum;
+    }
+}
+
+template <int BN>
+static void launch_wgrad_reduce(const float* ws, int slices, int tiles, int tiles_n, int Kw, int Co, float* dw, hipStream_t st) {
+    constexpr int PER_TILE = 4 * 2 * (BN / 64) * 16 * 64;
+    if (slices >= 16) {
+        hipLaunchKernelGGL((wgrad_reduce_sliced_kernel<BN>), dim3(tiles * (PER_TILE / 64)), dim3(256), 0, st, ws, slices, tiles, tiles_n, Kw,
+                           Co, dw);
+    } else {
+        const int blocks = tiles * (PER_TILE / 256);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<BN>), dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, st, ws, slices, tiles, tiles_n, Kw,
+                           Co, dw);
+    }
+}
+
 struct WgradPlan {
     int tj, tn, split, per;
     bool wide;
@@ -556,13 +609,11 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
     if (p.wide) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tiles, p.split), dim3(256), 0, st, (const unsigned short*)x,
                            (const unsigned short*)dy, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
-        hipLaunchKernelGGL((wgrad_reduce_kernel<128>), dim3(min(2048, tiles * 32)), dim3(256), 0, st, (const float*)ws, p.split, tiles, p.tn,
-                           Kw, g.Co, dw);
+        launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tiles, p.split), dim3(256), 0, st, (const unsigned short*)x,
                            (const unsigned short*)dy, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
-        hipLaunchKernelGGL((wgrad_reduce_kernel<64>), dim3(min(2048, tiles * 16)), dim3(256), 0, st, (const float*)ws, p.split, tiles, p.tn,
-                           Kw, g.Co, dw);
+        launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     }
     return launch_status();
 }
@@ -594,6 +645,6 @@ extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom*
     float* ws = (float*)workspace;
     hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(p.tj, p.split), dim3(256), 0, st, (const unsigned short*)x4,
                        (const unsigned short*)dy, g, M, Kw, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
-    hipLaunchKernelGGL((wgrad_reduce_kernel<64>), dim3(p.tj * 16), dim3(256), 0, st, (const float*)ws, p.split, p.tj, 1, Kw, 64, dw);
+    launch_wgrad_reduce<64>(ws, p.split, p.tj, 1, Kw, 64, dw, st);
     return launch_status();
 }
