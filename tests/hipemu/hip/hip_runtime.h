@@ -6,7 +6,7 @@
 // GPU-less build container (`pytest -m "not gpu"`).  It is never linked into the product library, never
 // loaded by the product package, and says nothing about performance.
 //
-// Execution model: one OS thread runs one workgroup at a time; each work-item is a ucontext fiber.
+// Execution model: one OS thread runs one workgroup at a time; each work-item is a fiber (hand-rolled x86-64 context switch).
 // __syncthreads() and the wave-collective operations (shuffles, ballot, MFMA) yield to a cooperative
 // scheduler that releases a barrier when every live fiber of the workgroup / 64-lane wave has arrived.
 // A collective executed by only part of a wave deadlocks the scheduler and aborts with a message -
@@ -19,7 +19,6 @@
 //   32x32x2  f32  : A[l&31][l>>5], B[l>>5][l&31];  16x16x4 f32: A[l&15][l>>4], B[l>>4][l&15]
 #pragma once
 
-#include <ucontext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -28,7 +27,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -75,22 +76,33 @@ namespace hipemu {
 enum FiberState { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;  // saved stack pointer while the fiber is switched out
     int state;
     void* stack;
 };
+
+// Minimal x86-64 context switch (callee-saved registers + stack pointer).  glibc's swapcontext issues a
+// rt_sigprocmask system call per switch, which dominated the emulator's run time.
+__attribute__((naked, noinline)) static void switch_ctx(void** /*save_sp*/, void* /*load_sp*/) {
+    asm volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq %rsi, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret\n\t");
+}
 
 struct Tls {
     dim3 threadIdx, blockIdx, blockDim, gridDim;
     unsigned char* dyn_smem = nullptr;
     // scheduler
-    ucontext_t sched_ctx;
+    void* sched_sp = nullptr;
     std::vector<Fiber> fibers;
     int cur = -1;
     int nthreads = 0;
     const std::function<void()>* body = nullptr;
     // wave exchange: per wave, double-buffered 64 lanes x 128 bytes
-    std::vector<unsigned char> xbuf;
+    std::vector<unsigned char> xbuf, smem_buf;
     std::vector<unsigned> xcnt;  // per-fiber collective-op counter
 };
 
@@ -106,7 +118,7 @@ inline void yield_with(int state) {
     Tls& t = tls();
     Fiber& f = t.fibers[t.cur];
     f.state = state;
-    swapcontext(&f.ctx, &t.sched_ctx);
+    switch_ctx(&f.sp, t.sched_sp);
 }
 
 inline void set_ids(Tls& t, int tid) {
@@ -120,7 +132,8 @@ inline void fiber_entry() {
     (*t.body)();
     Tls& t2 = tls();
     t2.fibers[t2.cur].state = DONE;
-    swapcontext(&t2.fibers[t2.cur].ctx, &t2.sched_ctx);
+    switch_ctx(&t2.fibers[t2.cur].sp, t2.sched_sp);
+    std::abort();  // a finished fiber is never resumed
 }
 
 inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, dim3 bidx, size_t shmem) {
@@ -131,23 +144,25 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     t.body = &body;
     const int n = (int)(block.x * block.y * block.z);
     t.nthreads = n;
-    std::vector<unsigned char> smem(shmem + 64);
-    t.dyn_smem = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(smem.data()) + 63) & ~uintptr_t(63));
+    if (t.smem_buf.size() < shmem + 64) t.smem_buf.resize(shmem + 64);
+    t.dyn_smem = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(t.smem_buf.data()) + 63) & ~uintptr_t(63));
     if ((int)t.fibers.size() < n) {
         size_t old = t.fibers.size();
         t.fibers.resize(n);
         for (size_t i = old; i < (size_t)n; ++i) t.fibers[i].stack = std::malloc(kStackBytes);
     }
     const int nwaves = (n + 63) / 64;
-    t.xbuf.assign((size_t)nwaves * 2 * 64 * kSlotBytes, 0);
+    if (t.xbuf.size() < (size_t)nwaves * 2 * 64 * kSlotBytes) t.xbuf.resize((size_t)nwaves * 2 * 64 * kSlotBytes);
     t.xcnt.assign(n, 0);
     for (int i = 0; i < n; ++i) {
         Fiber& f = t.fibers[i];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStackBytes;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        // initial frame: six zeroed callee-saved registers, then fiber_entry as the "return address" of switch_ctx
+        uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + kStackBytes) & ~uintptr_t(15);
+        void** sp = reinterpret_cast<void**>(top);
+        *--sp = nullptr;                                   // fake return address of fiber_entry (keeps 16-B call alignment)
+        *--sp = reinterpret_cast<void*>(&fiber_entry);
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        f.sp = sp;
         f.state = RUNNABLE;
     }
     for (;;) {
@@ -157,7 +172,7 @@ inline void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
             if (t.fibers[i].state == RUNNABLE) {
                 t.cur = i;
                 set_ids(t, i);
-                swapcontext(&t.sched_ctx, &t.fibers[i].ctx);
+                switch_ctx(&t.sched_sp, t.fibers[i].sp);
                 progress = true;
             }
             if (t.fibers[i].state != DONE) ++alive;
@@ -202,11 +217,66 @@ inline int& max_host_threads() {
     return n;
 }
 
+// Persistent worker pool: worker threads (and their thread-local fiber stacks) live across launches; spawning
+// threads per launch made every launch re-map and re-fault 64 MB of fiber stacks per thread.
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void()>* job = nullptr;
+    unsigned long generation = 0;
+    int active = 0;
+    bool stop = false;
+
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) workers.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void()>* j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                j = job;
+            }
+            (*j)();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--active == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(const std::function<void()>& j) {
+        std::unique_lock<std::mutex> lk(mu);
+        job = &j;
+        active = (int)workers.size();
+        ++generation;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
+};
+
+inline Pool& pool() {
+    static Pool p(max_host_threads());
+    return p;
+}
+
 inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks == 0) return;
     std::atomic<size_t> next{0};
-    auto worker = [&]() {
+    std::function<void()> worker = [&]() {
         for (;;) {
             size_t b = next.fetch_add(1);
             if (b >= nblocks) break;
@@ -214,13 +284,12 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
             run_block(body, grid, block, bidx, shmem);
         }
     };
-    int nt = (int)std::min<size_t>(nblocks, (size_t)max_host_threads());
-    if (nt <= 1) {
+    if (nblocks == 1 || max_host_threads() <= 1) {
         worker();
     } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < nt; ++i) th.emplace_back(worker);
-        for (auto& x : th) x.join();
+        static std::mutex launch_mu;  // one launch at a time through the pool
+        std::lock_guard<std::mutex> lk(launch_mu);
+        pool().run(worker);
     }
 }
 
