@@ -128,15 +128,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
 
     const int kchunk = tid & 7, rbase = tid >> 3;  // 8 x 16-B chunks per 64-wide K row; 32 rows per pass
 
-    // per-thread row coordinates of the 4 A rows this thread stages
+    // Per-thread description of the 4 A rows this thread stages.  Everything that depends only on the row is hoisted
+    // out of the K loop: `rowoff` is the element offset of the row's origin in the gathered tensor and `vmask` has one
+    // bit per filter tap saying whether that tap reads a real pixel (zero padding / stride-2 parity / row >= M
+    // otherwise).  Inside the loop a tap costs one wave-uniform offset add, one bit test and an UNCONDITIONAL 16-B load
+    // (invalid taps read offset 0 and are zeroed by a select), so the loop has no divergent branches.
     int pb[4], py[4], px[4];
     bool pv[4];
-    ptrdiff_t rowbase[4];  // element offset of the row's origin pixel in the gathered tensor (fwd / stride-1 dgrad)
+    int rowoff[4];
+    unsigned vmask[4];
     const int rows_y = (MODE == kModeDgrad) ? g.Hi : g.Ho;
     const int rows_x = (MODE == kModeDgrad) ? g.Wi : g.Wo;
     const int ck = (MODE == kModeDgrad) ? g.Co : g.Ci;  // channels of the gathered tensor
     const int src_h = (MODE == kModeDgrad) ? g.Ho : g.Hi;
     const int src_w = (MODE == kModeDgrad) ? g.Wo : g.Wi;
+    const bool halved = (MODE == kModeDgrad) && g.stride == 2;  // stride-2 dgrad: tap (r,s) -> pixel ((py-r)/2, (px-s)/2)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + rbase + 32 * i;
@@ -153,7 +159,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
             py[i] = y * g.stride - g.pad;
             px[i] = (rem - y * rows_x) * g.stride - g.pad;
         }
-        rowbase[i] = (((ptrdiff_t)b * src_h + py[i]) * src_w + px[i]) * ck + kchunk * 8;
+        const int oy = halved ? (py[i] >> 1) : py[i], ox = halved ? (px[i] >> 1) : px[i];
+        rowoff[i] = ((b * src_h + oy) * src_w + ox) * ck + kchunk * 8;
+        unsigned mask = 0;
+        if (MODE != kModeStem && pv[i]) {
+            for (int r = 0; r < g.R; ++r)
+                for (int t = 0; t < g.S; ++t) {
+                    bool ok;
+                    if (MODE == kModeDgrad) {
+                        const int th = py[i] - r, tw = px[i] - t;
+                        if (halved) ok = th >= 0 && tw >= 0 && !((th | tw) & 1) && (th >> 1) < g.Ho && (tw >> 1) < g.Wo;
+                        else ok = th >= 0 && th < g.Ho && tw >= 0 && tw < g.Wo;
+                    } else {
+                        const int sy = py[i] + r, sx = px[i] + t;
+                        ok = sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
+                    }
+                    mask |= (ok ? 1u : 0u) << (r * g.S + t);
+                }
+        }
+        vmask[i] = mask;
     }
 
     f32x16 acc[2][NT];
@@ -165,12 +189,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
     u16x8 ra[4], rb[BN / 32];
+    unsigned okbits = 0xfu;      // which of ra[0..3] hold real data; applied when the registers are written to LDS, so
+                                 // nothing between the loads and the MFMA block waits on them
     int tr = 0, ts = 0, tc = 0;  // filter tap (r, s) and channel offset of the NEXT K step to load
     const unsigned short* wrow[BN / 32];
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
-        const int n = n0 + rbase + 32 * i;
-        wrow[i] = (n < N) ? Wt + (size_t)n * K + kchunk * 8 : nullptr;
+        int n = n0 + rbase + 32 * i;
+        if (n >= N) n = N - 1;  // rows past N are loaded (never stored): keeps the loop free of predicates
+        wrow[i] = Wt + (size_t)n * K + kchunk * 8;
     }
 
     auto load_step = [&](int kt) {
@@ -185,25 +212,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
                 ra[i] = load4x2(X + base, okr && wi >= 0 && wi < g.Wi, X + base + 4, okr && s0 + 1 < g.S && wi + 1 >= 0 && wi + 1 < g.Wi);
             }
         } else {
-            if (MODE == kModeDgrad && g.stride != 1) {
-                // stride 2: tap (r, s) reaches output pixel ((py - r) / 2, (px - s) / 2) when both differences are even
+            // wave-uniform tap offset: fwd walks +(r, s); dgrad walks -(r, s) (halved for stride 2, valid taps only)
+            const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
+            const int tapoff = ((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * ck + tc;
+            const int tap = tr * g.S + ts;
+            okbits = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int th = py[i] - tr, tw = px[i] - ts;
-                    const int sy = th >> 1, sx = tw >> 1;
-                    const bool ok = pv[i] && th >= 0 && tw >= 0 && !((th | tw) & 1) && sy < g.Ho && sx < g.Wo;
-                    ra[i] = ok ? load8(X + (((ptrdiff_t)pb[i] * g.Ho + sy) * g.Wo + sx) * ck + tc + kchunk * 8) : zero8();
-                }
-            } else {
-                // tap offset is wave-uniform: fwd walks +(r, s), stride-1 dgrad walks -(r, s)
-                const int sgn = (MODE == kModeDgrad) ? -1 : 1;
-                const ptrdiff_t tapoff = (ptrdiff_t)sgn * ((ptrdiff_t)tr * src_w + ts) * ck + tc;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sy = py[i] + sgn * tr, sx = px[i] + sgn * ts;
-                    const bool ok = pv[i] && sy >= 0 && sy < src_h && sx >= 0 && sx < src_w;
-                    ra[i] = ok ? load8(X + rowbase[i] + tapoff) : zero8();
-                }
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ok = (vmask[i] >> tap) & 1u;
+                okbits |= ok << i;
+                ra[i] = load8(X + (ok ? rowoff[i] + tapoff : 0));
             }
             tc += kBK;
             if (tc >= ck) {
@@ -216,11 +234,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
         }
         // ---- B: weights [N][K], K-contiguous
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) rb[i] = wrow[i] ? load8(wrow[i] + kt * kBK) : zero8();
+        for (int i = 0; i < BN / 32; ++i) rb[i] = load8(wrow[i] + kt * kBK);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ra[i];
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ((okbits >> i) & 1u) ? ra[i] : zero8();
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = rb[i];
     };
@@ -546,7 +565,7 @@ extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geo
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
-    if (g.Ci % kBK != 0) return LP_ERR_UNSUPPORTED;
+    if (g.Ci % kBK != 0 || g.R * g.S > 32 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
     ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr};
     const int tm = (M + kBM - 1) / kBM;
@@ -568,7 +587,8 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
-    if (g.Co % kBK != 0 || (g.stride != 1 && g.stride != 2)) return LP_ERR_UNSUPPORTED;
+    if (g.Co % kBK != 0 || (g.stride != 1 && g.stride != 2) || g.R * g.S > 32 || (long long)g.B * g.Ho * g.Wo * g.Co >= (1LL << 31))
+        return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Hi * g.Wi, N = g.Ci, K = g.R * g.S * g.Co;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend};
     const int tm = (M + kBM - 1) / kBM;
