@@ -38,9 +38,18 @@ struct ConvEpilogue {
     int n_store;                   // columns >= n_store are not written
     const float* bias;             // [n] or nullptr
     const unsigned short* addend;  // [M][ldo] bf16 added before the store (gradient accumulation), or nullptr
+    const unsigned short* relu_mask;  // [M][ldo] bf16 activation; outputs where it is <= 0 are zeroed (ReLU backward), or nullptr
 };
 
 enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2 };
+
+// One launch covers a sub-lattice of output pixels and of filter taps.  Ordinary launches use the full lattices; the data
+// gradient of a stride-2 convolution is split into its 4 output-parity classes, each of which only sees the taps of matching
+// parity (4 + 2 + 2 + 1 of the 9 taps of a 3x3, 1 + 0 + 0 + 0 for a 1x1): 4x fewer MFMAs than masking all taps.
+struct Lattice {
+    int h0, hstep, nh, w0, wstep, nw;  // output rows of this launch: y = h0 + hstep * iy, iy < nh (same for x)
+    int r0, rstep, nr, s0, sstep, ns;  // filter taps of this launch:  r = r0 + rstep * ir, ir < nr (same for s)
+};
 
 // n / d for 0 <= n < 2^31 without the ~40-instruction integer division: q = (n * ceil(2^sh / d)) >> sh
 struct FastDiv {
@@ -67,6 +76,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, local = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// row index in the output tensor of row m of this launch's pixel sub-lattice (identity for full-lattice launches)
+__device__ __forceinline__ int out_row(int m, const Lattice& lat, int rows_y, int rows_x, int full_h, int full_w) {
+    if (lat.hstep == 1 && lat.wstep == 1) return m;
+    const int b = m / (rows_y * rows_x), rem = m - b * rows_y * rows_x;
+    const int iy = rem / rows_x, ix = rem - iy * rows_x;
+    return (b * full_h + lat.h0 + lat.hstep * iy) * full_w + lat.w0 + lat.wstep * ix;
 }
 
 template <int NT>
@@ -113,7 +130,8 @@ __device__ __forceinline__ u16x8 load4x2(const unsigned short* p0, bool ok0, con
 // ------------------------------------------------------------------------------------------------------------
 template <int BN, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
-                                                         ConvGeom g, int M, int N, int K, int tiles_n, ConvEpilogue ep) {
+                                                         ConvGeom g, Lattice lat, int M, int N, int K, int tiles_n,
+                                                         ConvEpilogue ep) {
     constexpr int NT = BN / 64;
     // one LDS block: [2][128][72] A + [2][BN][72] B operand tiles, reused by the epilogue as a [128][BN+4] fp32 tile
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (kBM + BN) * kLD];
@@ -137,8 +155,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
     bool pv[4];
     int rowoff[4];
     unsigned vmask[4];
-    const int rows_y = (MODE == kModeDgrad) ? g.Hi : g.Ho;
-    const int rows_x = (MODE == kModeDgrad) ? g.Wi : g.Wo;
+    const int rows_y = lat.nh, rows_x = lat.nw;
+    const int full_h = (MODE == kModeDgrad) ? g.Hi : g.Ho;  // the output tensor's spatial size
+    const int full_w = (MODE == kModeDgrad) ? g.Wi : g.Wo;
     const int ck = (MODE == kModeDgrad) ? g.Co : g.Ci;  // channels of the gathered tensor
     const int src_h = (MODE == kModeDgrad) ? g.Ho : g.Hi;
     const int src_w = (MODE == kModeDgrad) ? g.Wo : g.Wi;
@@ -150,21 +169,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
         const int mm = pv[i] ? m : 0;
         const int b = mm / (rows_y * rows_x);
         const int rem = mm - b * rows_y * rows_x;
-        const int y = rem / rows_x;
+        const int iy = rem / rows_x;
+        const int y = lat.h0 + lat.hstep * iy, xq = lat.w0 + lat.wstep * (rem - iy * rows_x);
         pb[i] = b;
         if (MODE == kModeDgrad) {
             py[i] = y + g.pad;
-            px[i] = rem - y * rows_x + g.pad;
+            px[i] = xq + g.pad;
         } else {
             py[i] = y * g.stride - g.pad;
-            px[i] = (rem - y * rows_x) * g.stride - g.pad;
+            px[i] = xq * g.stride - g.pad;
         }
         const int oy = halved ? (py[i] >> 1) : py[i], ox = halved ? (px[i] >> 1) : px[i];
         rowoff[i] = ((b * src_h + oy) * src_w + ox) * ck + kchunk * 8;
         unsigned mask = 0;
         if (MODE != kModeStem && pv[i]) {
-            for (int r = 0; r < g.R; ++r)
-                for (int t = 0; t < g.S; ++t) {
+            for (int ir = 0; ir < lat.nr; ++ir)
+                for (int it = 0; it < lat.ns; ++it) {
+                    const int r = lat.r0 + lat.rstep * ir, t = lat.s0 + lat.sstep * it;
                     bool ok;
                     if (MODE == kModeDgrad) {
                         const int th = py[i] - r, tw = px[i] - t;
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
                         const int sy = py[i] + r, sx = px[i] + t;
                         ok = sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
                     }
-                    mask |= (ok ? 1u : 0u) << (r * g.S + t);
+                    mask |= (ok ? 1u : 0u) << (ir * lat.ns + it);
                 }
         }
         vmask[i] = mask;
@@ -191,16 +212,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
     u16x8 ra[4], rb[BN / 32];
     unsigned okbits = 0xfu;      // which of ra[0..3] hold real data; applied when the registers are written to LDS, so
                                  // nothing between the loads and the MFMA block waits on them
-    int tr = 0, ts = 0, tc = 0;  // filter tap (r, s) and channel offset of the NEXT K step to load
+    int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
     const unsigned short* wrow[BN / 32];
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
         int n = n0 + rbase + 32 * i;
         if (n >= N) n = N - 1;  // rows past N are loaded (never stored): keeps the loop free of predicates
-        wrow[i] = Wt + (size_t)n * K + kchunk * 8;
+        wrow[i] = Wt + (size_t)n * ((MODE == kModeStem) ? K : g.R * g.S * ck) + kchunk * 8;  // row stride = the FULL filter
     }
 
     auto load_step = [&](int kt) {
+        int woff = kt * kBK;
         // ---- A: gathered activations
         if (MODE == kModeStem) {
             const int r = kt * 2 + (kchunk >> 2), s0 = (kchunk & 3) * 2;
@@ -213,9 +235,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
             }
         } else {
             // wave-uniform tap offset: fwd walks +(r, s); dgrad walks -(r, s) (halved for stride 2, valid taps only)
+            const int tr = lat.r0 + lat.rstep * tir, ts = lat.s0 + lat.sstep * tis;
             const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
             const int tapoff = ((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * ck + tc;
-            const int tap = tr * g.S + ts;
+            const int tap = tir * lat.ns + tis;
+            woff = (tr * g.S + ts) * ck + tc;
             okbits = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -226,15 +250,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
             tc += kBK;
             if (tc >= ck) {
                 tc = 0;
-                if (++ts == g.S) {
-                    ts = 0;
-                    ++tr;
+                if (++tis == lat.ns) {
+                    tis = 0;
+                    ++tir;
                 }
             }
         }
-        // ---- B: weights [N][K], K-contiguous
+        // ---- B: weights [N][R*S*C], K-contiguous; the K offset follows the tap actually visited
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) rb[i] = load8(wrow[i] + kt * kBK);
+        for (int i = 0; i < BN / 32; ++i) rb[i] = load8(wrow[i] + woff);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
@@ -244,9 +268,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
         for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = rb[i];
     };
 
-    const int KT = K / kBK;
-    load_step(0);
-    store_step(0);
+    const int KT = K / kBK;  // 0 for a parity class without taps: the epilogue then just writes addend / zeros
+    if (KT > 0) {
+        load_step(0);
+        store_step(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
@@ -287,11 +313,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const size_t o = (size_t)m * ep.ldo + n;
+                    const size_t o = (size_t)out_row(m, lat, rows_y, rows_x, full_h, full_w) * ep.ldo + n;
                     if (ep.addend) {
                         const u16x8 a = load8(ep.addend + o);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(a[q]);
+                    }
+                    if (ep.relu_mask) {
+                        const u16x8 y = load8(ep.relu_mask + o);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if ((y[q] & 0x7fff) == 0 || (y[q] & 0x8000)) v[q] = 0.f;
                     }
                     u16x8 w;
 #pragma unroll
@@ -314,8 +346,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
                 const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
                 if (m < M) {
                     float v = acc[mt][nt][e] + bias;
-                    const size_t o = (size_t)m * ep.ldo + n;
+                    const size_t o = (size_t)out_row(m, lat, rows_y, rows_x, full_h, full_w) * ep.ldo + n;
                     if (ep.addend) v += bf16_to_f32(ep.addend[o]);
+                    if (ep.relu_mask) {
+                        const unsigned short y = ep.relu_mask[o];
+                        if ((y & 0x7fff) == 0 || (y & 0x8000)) v = 0.f;
+                    }
                     if (ep.out_bf16) ep.out_bf16[o] = f32_to_bf16(v);
                     if (ep.out_f32) ep.out_f32[o] = v;
                 }
@@ -567,39 +603,57 @@ extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geo
     ConvGeom g = to_geom(geom);
     if (g.Ci % kBK != 0 || g.R * g.S > 32 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
-    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr};
+    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr};
     const int tm = (M + kBM - 1) / kBM;
     hipStream_t st = (hipStream_t)stream;
+    const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     if (N > 64) {
         const int tn = (N + 127) / 128;
         hipLaunchKernelGGL((conv_igemm_kernel<128, kModeFwd>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)w, g, M, N, K, tn, ep);
+                           (const unsigned short*)w, g, lat, M, N, K, tn, ep);
     } else {
         hipLaunchKernelGGL((conv_igemm_kernel<64, kModeFwd>), dim3(tm), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)w, g, M, N, K, 1, ep);
+                           (const unsigned short*)w, g, lat, M, N, K, 1, ep);
     }
     return launch_status();
 }
 
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
 extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
-                             void* dx_bf16, float* dx_f32, int ldo, int n_store, lp_stream_t stream) {
+                             const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
     if (g.Co % kBK != 0 || (g.stride != 1 && g.stride != 2) || g.R * g.S > 32 || (long long)g.B * g.Ho * g.Wo * g.Co >= (1LL << 31))
         return LP_ERR_UNSUPPORTED;
-    const int M = g.B * g.Hi * g.Wi, N = g.Ci, K = g.R * g.S * g.Co;
-    ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend};
-    const int tm = (M + kBM - 1) / kBM;
+    const int N = g.Ci;
+    ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
+                    (const unsigned short*)relu_mask};
     hipStream_t st = (hipStream_t)stream;
-    if (N > 64) {
-        const int tn = (N + 127) / 128;
-        hipLaunchKernelGGL((conv_igemm_kernel<128, kModeDgrad>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)dy,
-                           (const unsigned short*)wd, g, M, N, K, tn, ep);
+    auto launch = [&](const Lattice& lat) {
+        const int M = g.B * lat.nh * lat.nw, K = lat.nr * lat.ns * g.Co;
+        if (M <= 0) return;
+        const int tm = (M + kBM - 1) / kBM;
+        if (N > 64) {
+            const int tn = (N + 127) / 128;
+            hipLaunchKernelGGL((conv_igemm_kernel<128, kModeDgrad>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)dy,
+                               (const unsigned short*)wd, g, lat, M, N, K, tn, ep);
+        } else {
+            hipLaunchKernelGGL((conv_igemm_kernel<64, kModeDgrad>), dim3(tm), dim3(256), 0, st, (const unsigned short*)dy,
+                               (const unsigned short*)wd, g, lat, M, N, K, 1, ep);
+        }
+    };
+    if (g.stride == 1) {
+        launch(Lattice{0, 1, g.Hi, 0, 1, g.Wi, 0, 1, g.R, 0, 1, g.S});
     } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<64, kModeDgrad>), dim3(tm), dim3(256), 0, st, (const unsigned short*)dy,
-                           (const unsigned short*)wd, g, M, N, K, 1, ep);
+        // stride 2: one launch per parity class of (hi + pad, wi + pad); taps of the same parity only
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                const int h0 = ((ph - g.pad) % 2 + 2) % 2, w0 = ((pw - g.pad) % 2 + 2) % 2;
+                const int nh = h0 < g.Hi ? (g.Hi - h0 + 1) / 2 : 0, nw = w0 < g.Wi ? (g.Wi - w0 + 1) / 2 : 0;
+                const int nr = ph < g.R ? (g.R - ph + 1) / 2 : 0, ns = pw < g.S ? (g.S - pw + 1) / 2 : 0;
+                launch(Lattice{h0, 2, nh, w0, 2, nw, ph, 2, nr, pw, 2, ns});
+            }
     }
     return launch_status();
 }
@@ -645,9 +699,10 @@ extern "C" int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* ge
     ConvGeom g = to_geom(geom);
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo;
-    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr};
+    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr};
+    const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     hipLaunchKernelGGL((conv_igemm_kernel<64, kModeStem>), dim3((M + kBM - 1) / kBM), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x4, (const unsigned short*)w, g, M, 64, 256, 1, ep);
+                       (const unsigned short*)x4, (const unsigned short*)w, g, lat, M, 64, 256, 1, ep);
     return launch_status();
 }
 

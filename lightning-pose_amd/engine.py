@@ -418,11 +418,11 @@ class Engine:
             wd = self.Wd[c.wd_off:]
             if last:
                 logits = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.float32)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(logits), CPAD, self.K, ops._stream()),
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, None, _p(logits), CPAD, self.K, ops._stream()),
                       "lp_conv_dgrad(head)")
             else:
                 nxt = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.bfloat16)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, _p(nxt), None, CPAD, CPAD, ops._stream()),
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, CPAD, CPAD, ops._stream()),
                       "lp_conv_dgrad(head)")
                 cur = nxt
                 T[f"head.in{li + 1}"] = cur
@@ -451,15 +451,16 @@ class Engine:
                                         count, M, b.C, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply")
         return dz, dres
 
-    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None):
+    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None):
+        """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward)."""
         g = self._geom(c, B, Hi, Wi)
         self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g), lambda: self._wgrad(x, dz, g, self.G[c.w_off:]))
         if not need_dx:
             return None
         dx = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16)
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g),
-                    lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(dx), None, c.Ci,
-                                                          0, ops._stream()), "lp_conv_dgrad"))
+                    lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),
+                                                          _p(dx), None, c.Ci, 0, ops._stream()), "lp_conv_dgrad"))
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -501,17 +502,26 @@ class Engine:
             ho, wo = (hi - 1) // st + 1, (wi - 1) // st + 1
             Mo, Mi = B * ho * wo, B * hi * wi
             x = T[f"{key}.x"]
-            dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True)
-            da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True)
-            dz2, _ = self._bn_bwd(blk.bn2, da2, T[f"{key}.a2"], T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False)
-            da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True)
-            dz1, _ = self._bn_bwd(blk.bn1, da1, T[f"{key}.a1"], T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False)
+            last = i == len(plan.blocks) - 1
+            # ReLU backward is fused into the dgrad that PRODUCES each gradient (relu_mask = the activation it belongs to), so
+            # the BatchNorm backward kernels never re-read the activations; only the trunk output (fed by the head) and the
+            # stem (fed by the max-pool) still mask inside the BN kernels.
+            if last:
+                dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True)
+            else:
+                dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False)
+                dres = d
+            da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True, relu_mask=T[f"{key}.a2"])
+            dz2, _ = self._bn_bwd(blk.bn2, da2, None, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False)
+            da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True, relu_mask=T[f"{key}.a1"])
+            dz1, _ = self._bn_bwd(blk.bn1, da1, None, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False)
+            mask_x = x if i > 0 else None  # block 0's input is the max-pool output: its ReLU is handled by the stem BN backward
             if blk.down is not None:
                 dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False)
                 dpart = self._conv_bwd(blk.down, x, dzd, B, hi, wi, True)
-                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dpart)
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dpart, relu_mask=mask_x)
             else:
-                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres)
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x)
 
         if trace is not None:
             trace["stem.dpool"] = d

@@ -244,13 +244,13 @@ def conv_fwd(x_nhwc_bits, w_bits, g, bias=None, f32_out=False, ldo=None, n_store
     return ob.np(), (of.np() if of is not None else None)
 
 
-def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, ldo=None, n_store=0):
+def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, ldo=None, n_store=0, mask_bits=None):
     M = g.B * g.Hi * g.Wi
     ldo = ldo or g.Ci
-    db, wb, ab, bb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(bias, np.float32)
+    db, wb, ab, bb, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(bias, np.float32), B(mask_bits)
     ob = Z((M, ldo), np.uint16)
     of = Z((M, ldo)) if f32_out else None
-    ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), ptr(bb), ptr(ab), ob.p, ptr(of), ldo, n_store, stream()))
+    ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), ptr(bb), ptr(ab), ptr(mb), ob.p, ptr(of), ldo, n_store, stream()))
     return ob.np(), (of.np() if of is not None else None)
 
 

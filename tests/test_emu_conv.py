@@ -50,7 +50,11 @@ def test_conv_fwd_dgrad_wgrad(case):
     _, df = emu.conv_dgrad(dyb, wd, g, addend_bits=emu.to_bf16_bits(add), f32_out=True)
     want = nhwc(x.grad).reshape(-1, Ci) + add
     torch.testing.assert_close(torch.from_numpy(df), want, atol=5e-4, rtol=5e-4)
-    # weight gradient (split-K over pixels, atomics)
+    # fused ReLU backward: bf16 output zeroed where the activation is <= 0, single rounding after the addend
+    act = bf(torch.relu(torch.randn(B * Hi * Wi, Ci, generator=gen)))
+    dbits, _ = emu.conv_dgrad(dyb, wd, g, addend_bits=emu.to_bf16_bits(add), mask_bits=emu.to_bf16_bits(act))
+    torch.testing.assert_close(emu.from_bf16_bits(dbits), bf(want * (act > 0)), atol=3e-2, rtol=2e-2)
+    # weight gradient (pixel slices reduced through the workspace)
     for split in (0, 3):
         dw = emu.conv_wgrad(xb, dyb, g, split=split)
         want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
