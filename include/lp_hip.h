@@ -145,9 +145,12 @@ typedef struct lp_conv_geom {
 int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
                 int n_store, lp_stream_t stream);
 /* wd: bf16 [Ci][R][S][Co] (Co % 64 == 0); optional bf16 addend (same layout as dx) is summed in; optional relu_mask (the
- * bf16 activation dx is the gradient of) zeroes dx where the activation is <= 0, i.e. the ReLU backward is fused here. */
+ * bf16 activation dx is the gradient of) zeroes dx where the activation is <= 0, i.e. the ReLU backward is fused here.
+ * addend may alias dx (in-place accumulation).  A stride-2 gradient runs as 4 parity-class launches; with skip_empty_classes the
+ * classes no filter tap reaches (3 of 4 for a 1x1) are not touched - use it when dx already holds addend there. */
 int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
-                  const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, lp_stream_t stream);
+                  const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
+                  lp_stream_t stream);
 /* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split.  The pixel slices leave
  * partial tiles in `workspace` (lp_conv_wgrad_workspace_bytes) and a second kernel sums them in a fixed order: deterministic. */
 size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);

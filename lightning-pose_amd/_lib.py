@@ -56,7 +56,7 @@ PROTOTYPES = {
     "lp_pca_fwd_bwd": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "lp_rmse_fwd": (_I, [_P, _P, _I, _P, _P]),
     "lp_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _I, _P]),
-    "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _I, _P]),
+    "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lp_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
     "lp_stem_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P]),

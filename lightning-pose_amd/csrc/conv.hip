@@ -620,7 +620,8 @@ extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geo
 
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
 extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
-                             const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, lp_stream_t stream) {
+                             const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
+                             lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -652,6 +653,8 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
                 const int h0 = ((ph - g.pad) % 2 + 2) % 2, w0 = ((pw - g.pad) % 2 + 2) % 2;
                 const int nh = h0 < g.Hi ? (g.Hi - h0 + 1) / 2 : 0, nw = w0 < g.Wi ? (g.Wi - w0 + 1) / 2 : 0;
                 const int nr = ph < g.R ? (g.R - ph + 1) / 2 : 0, ns = pw < g.S ? (g.S - pw + 1) / 2 : 0;
+                // a class no tap reaches only copies addend (or zeros): the caller may declare dx already correct there
+                if (skip_empty_classes && nr * ns == 0) continue;
                 launch(Lattice{h0, 2, nh, w0, 2, nw, ph, 2, nr, pw, 2, ns});
             }
     }

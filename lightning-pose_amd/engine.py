@@ -418,11 +418,11 @@ class Engine:
             wd = self.Wd[c.wd_off:]
             if last:
                 logits = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.float32)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, None, _p(logits), CPAD, self.K, ops._stream()),
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, None, _p(logits), CPAD, self.K, 0, ops._stream()),
                       "lp_conv_dgrad(head)")
             else:
                 nxt = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.bfloat16)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, CPAD, CPAD, ops._stream()),
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, CPAD, CPAD, 0, ops._stream()),
                       "lp_conv_dgrad(head)")
                 cur = nxt
                 T[f"head.in{li + 1}"] = cur
@@ -451,16 +451,21 @@ class Engine:
                                         count, M, b.C, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply")
         return dz, dres
 
-    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None):
-        """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward)."""
+    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None):
+        """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
+        ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
+        for stride-2 layers only the pixels a filter tap reaches are touched."""
         g = self._geom(c, B, Hi, Wi)
         self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g), lambda: self._wgrad(x, dz, g, self.G[c.w_off:]))
         if not need_dx:
             return None
-        dx = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16)
+        if accumulate_into is not None:
+            dx, addend, skip = accumulate_into, accumulate_into, 1
+        else:
+            dx, skip = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16), 0
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g),
                     lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),
-                                                          _p(dx), None, c.Ci, 0, ops._stream()), "lp_conv_dgrad"))
+                                                          _p(dx), None, c.Ci, 0, skip, ops._stream()), "lp_conv_dgrad"))
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -518,8 +523,10 @@ class Engine:
             mask_x = x if i > 0 else None  # block 0's input is the max-pool output: its ReLU is handled by the stem BN backward
             if blk.down is not None:
                 dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False)
-                dpart = self._conv_bwd(blk.down, x, dzd, B, hi, wi, True)
-                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dpart, relu_mask=mask_x)
+                # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
+                # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x)
+                self._conv_bwd(blk.down, x, dzd, B, hi, wi, True, relu_mask=mask_x, accumulate_into=d)
             else:
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x)
 

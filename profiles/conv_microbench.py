@@ -44,7 +44,7 @@ for name, H, Ci, Co, k, st, pad in SHAPES:
             if kind == "fwd":
                 rc = lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, Co, 0, _stream())
             elif kind == "dgrad":
-                rc = lib.lp_conv_dgrad(_p(dy), _p(wd), C.byref(g), None, None, None, _p(dx), None, Ci, 0, _stream())
+                rc = lib.lp_conv_dgrad(_p(dy), _p(wd), C.byref(g), None, None, None, _p(dx), None, Ci, 0, 0, _stream())
             else:
                 rc = lib.lp_conv_wgrad(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(ws), nws, _stream())
             assert rc == 0

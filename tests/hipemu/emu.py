@@ -250,7 +250,7 @@ def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, 
     db, wb, ab, bb, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(bias, np.float32), B(mask_bits)
     ob = Z((M, ldo), np.uint16)
     of = Z((M, ldo)) if f32_out else None
-    ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), ptr(bb), ptr(ab), ptr(mb), ob.p, ptr(of), ldo, n_store, stream()))
+    ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), ptr(bb), ptr(ab), ptr(mb), ob.p, ptr(of), ldo, n_store, 0, stream()))
     return ob.np(), (of.np() if of is not None else None)
 
 

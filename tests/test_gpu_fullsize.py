@@ -91,7 +91,7 @@ def test_conv_real_layer_shapes(shape):
     assert lib.lp_conv_fwd(_p(xd), _p(wg), C.byref(g), None, None, _p(out), Co, 0, _stream()) == 0
     torch.testing.assert_close(out.cpu(), y.detach().permute(0, 2, 3, 1).reshape(-1, Co), atol=1e-3, rtol=1e-3)
     dx = torch.empty(B * Hi * Wi, Ci, device=dev, dtype=torch.float32)
-    assert lib.lp_conv_dgrad(_p(dyd), _p(wd), C.byref(g), None, None, None, None, _p(dx), Ci, 0, _stream()) == 0
+    assert lib.lp_conv_dgrad(_p(dyd), _p(wd), C.byref(g), None, None, None, None, _p(dx), Ci, 0, 0, _stream()) == 0
     torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 1).reshape(-1, Ci), atol=2e-3, rtol=2e-3)
     dw = torch.zeros(Co, k * k * Ci, device=dev, dtype=torch.float32)
     nws = lib.lp_conv_wgrad_workspace_bytes(C.byref(g), 0)
