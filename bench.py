@@ -96,6 +96,17 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0):
                                         downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev)
 
 
+def pmc_traffic():
+    """Average HBM bytes per convolution launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_traffic.json, produced by profiles/summarize_pmc.py); None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return round(json.load(fh)["conv_hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 3) -> dict:
     """Oracle (fp32 torch CPU restatement of the reference path) timed on the host cores for a bounded sample."""
     from oracle import restated as O
@@ -220,7 +231,7 @@ def main() -> None:
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches)",
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(),
                 "launches_per_step": len(prof) // args.steps, "conv_ms_per_step": round(tot_ms / args.steps, 3),
                 "by_kernel": {k: {"launches_per_step": v[0] // args.steps, "avg_us": round(1000 * v[1] / v[0], 2),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(by.items())},

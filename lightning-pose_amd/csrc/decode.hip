@@ -174,18 +174,23 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const float* __restrict
         __syncthreads();
         const int cl = wave * 64 + lane;
         const int c = c0 + cl;
-        if (cl < strip_cols && c < W) {
+        // Every lane runs the column walk (lanes past the map re-read column 0 and are discarded afterwards): with no
+        // divergent branch around it the tap table is fetched with wave-uniform SCALAR loads instead of per-lane vector loads.
+        const bool valid = cl < strip_cols && c < W;
+        const int clc = valid ? cl : 0;
+        const float m_in = m, s_in = s, sx_in = sx, sy_in = sy;
+        {
             const float xc = (float)c;
             float win[TY];
             int base = tb.row_base[0];
 #pragma unroll
-            for (int t = 0; t < TY; ++t) win[t] = zs[(base + t) * strip_cols + cl];
+            for (int t = 0; t < TY; ++t) win[t] = zs[(base + t) * strip_cols + clc];
             for (int j = 0; j < h; ++j) {
                 const int nb = tb.row_base[j];
                 if (nb != base) {  // windows advance by exactly one input row (host asserts it)
 #pragma unroll
                     for (int t = 0; t < TY - 1; ++t) win[t] = win[t + 1];
-                    win[TY - 1] = zs[(nb + TY - 1) * strip_cols + cl];
+                    win[TY - 1] = zs[(nb + TY - 1) * strip_cols + clc];
                     base = nb;
                 }
                 const float* taps = tb.row_taps + (size_t)j * R * TY;
@@ -212,6 +217,12 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const float* __restrict
                     sy = fmaf(e, (float)(j * R + rr), sy);
                 }
             }
+        }
+        if (!valid) {
+            m = m_in;
+            s = s_in;
+            sx = sx_in;
+            sy = sy_in;
         }
         __syncthreads();  // zs is rebuilt by the next strip
     }
@@ -314,25 +325,27 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
         __syncthreads();
         const int cl = wave * 64 + lane;
         const int c = c0 + cl;
-        if (cl < strip_cols && c < W) {
+        const bool valid = cl < strip_cols && c < W;  // see the forward kernel: the walk itself is branch-free
+        const int clc = valid ? cl : 0;
+        {
             const float dxc = gxt * ((float)c - ex);
             float win[TY], acc[TY];
             int base = tb.row_base[0];
 #pragma unroll
             for (int t = 0; t < TY; ++t) {
-                win[t] = zs[(base + t) * strip_cols + cl];
+                win[t] = zs[(base + t) * strip_cols + clc];
                 acc[t] = 0.f;
             }
             for (int j = 0; j < h; ++j) {
                 const int nb = tb.row_base[j];
                 if (nb != base) {
-                    zs[base * strip_cols + cl] = acc[0];  // input row `base` is complete and no longer read
+                    if (valid) zs[base * strip_cols + cl] = acc[0];  // input row `base` is complete and no longer read
 #pragma unroll
                     for (int t = 0; t < TY - 1; ++t) {
                         win[t] = win[t + 1];
                         acc[t] = acc[t + 1];
                     }
-                    win[TY - 1] = zs[(nb + TY - 1) * strip_cols + cl];
+                    win[TY - 1] = zs[(nb + TY - 1) * strip_cols + clc];
                     acc[TY - 1] = 0.f;
                     base = nb;
                 }
@@ -348,9 +361,12 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
                     for (int t = 0; t < TY; ++t) acc[t] = fmaf(taps[rr * TY + t], g, acc[t]);
                 }
             }
+            if (valid) {
 #pragma unroll
-            for (int t = 0; t < TY; ++t) zs[(base + t) * strip_cols + cl] = acc[t];
-        } else if (cl < strip_cols) {
+                for (int t = 0; t < TY; ++t) zs[(base + t) * strip_cols + cl] = acc[t];
+            }
+        }
+        if (!valid && cl < strip_cols) {
             for (int r = 0; r < h; ++r) zs[r * strip_cols + cl] = 0.f;  // columns past W contribute nothing
         }
         __syncthreads();
