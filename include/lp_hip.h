@@ -151,6 +151,33 @@ int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const fl
 int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
                   const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
                   lp_stream_t stream);
+/* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
+ * for them (torch.nn.BatchNorm2d training forward / backward).  Every 128-row output tile leaves its
+ * column sums in `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds them into `sums`.
+ *   lp_conv_fwd_bn / lp_stem_fwd_bn:  sums (2,Co) += [sum z, sum z^2] of the bf16 output z  (== lp_bn_stats on it);
+ *                                     only sums / workspace / workspace_bytes are read.
+ *   lp_conv_dgrad_bn:                 dx is the gradient of a = relu(BN(z) [+ residual]); sums (2,Ci) += [sum dx, sum dx*xhat]
+ *                                     (== lp_bn_bwd_reduce), dbeta_acc / dgamma_acc (optional) receive the same totals.
+ *                                     mask_from_z = 1 recomputes the ReLU mask as bf16(gamma*invstd*(z-mean)+beta) > 0 (layers
+ *                                     without a residual branch; relu_mask must then be NULL), otherwise pass relu_mask. */
+typedef struct lp_bn_fuse {
+    const void* z;        /* bf16 [rows][C] pre-normalisation tensor (dgrad only) */
+    const float* mean;    /* (C,) batch mean      (dgrad only) */
+    const float* invstd;  /* (C,) 1/sqrt(var+eps) (dgrad only) */
+    const float* gamma;   /* (C,) weight, mask_from_z only */
+    const float* beta;    /* (C,) bias,   mask_from_z only */
+    int mask_from_z;
+    float* sums;          /* (2,C) fp32, accumulated into (zero first) */
+    float* dbeta_acc;     /* (C,) or NULL */
+    float* dgamma_acc;    /* (C,) or NULL */
+    void* workspace;
+    size_t workspace_bytes;
+} lp_bn_fuse;
+size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad);
+int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
+int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
+int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
+                     void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
 /* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split.  The pixel slices leave
  * partial tiles in `workspace` (lp_conv_wgrad_workspace_bytes) and a second kernel sums them in a fixed order: deterministic. */
 size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);

@@ -32,6 +32,12 @@ class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "R", "S", "stride", "pad")]
 
 
+class BnFuse(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("mask_from_z", C.c_int), ("sums", C.c_void_p), ("dbeta_acc", C.c_void_p), ("dgamma_acc", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -57,6 +63,10 @@ PROTOTYPES = {
     "lp_rmse_fwd": (_I, [_P, _P, _I, _P, _P]),
     "lp_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _I, _P]),
     "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
+    "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
+    "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
+    "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
     "lp_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
     "lp_stem_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P]),

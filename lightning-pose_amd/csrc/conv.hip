@@ -39,6 +39,17 @@ struct ConvEpilogue {
     const float* bias;             // [n] or nullptr
     const unsigned short* addend;  // [M][ldo] bf16 added before the store (gradient accumulation), or nullptr
     const unsigned short* relu_mask;  // [M][ldo] bf16 activation; outputs where it is <= 0 are zeroed (ReLU backward), or nullptr
+    // BatchNorm reductions fused into the store pass (bf16 outputs only).  `stats` receives, per 128-row tile, the column
+    // sums of the values actually stored (after rounding): [tile][0][c] = sum v, [tile][1][c] = sum v^2 (forward: the
+    // statistics of the next BatchNorm) or, with bn_z, sum v * xhat (backward: the two reductions of BatchNorm's gradient).
+    float* stats;                  // [stats_row0 + tile_m][2][N] or nullptr
+    int stats_row0;
+    const unsigned short* bn_z;    // [M][ldo] bf16 pre-normalisation tensor the gradient belongs to, or nullptr
+    const float* bn_mean;          // [N]
+    const float* bn_invstd;        // [N]
+    const float* bn_gamma;         // [N]  } only for mask_from_z: the ReLU mask is recomputed as
+    const float* bn_beta;          // [N]  } bf16(gamma * invstd * (z - mean) + beta) > 0 instead of reading the activation
+    int mask_from_z;
 };
 
 enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2 };
@@ -304,7 +315,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
         constexpr int RPP = 256 / CPR;       // rows per pass
         const int cc = tid % CPR, r0 = tid / CPR;
         const int n = n0 + cc * 8;
+        const bool want_stats = ep.stats != nullptr;
+        float s0[8], s1[8], mu[8], is[8], sc[8], be[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = is[q] = sc[q] = be[q] = 0.f;
         if (n < ep.n_store) {
+            if (ep.bn_z) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    mu[q] = ep.bn_mean[n + q];
+                    is[q] = ep.bn_invstd[n + q];
+                    if (ep.mask_from_z) {
+                        sc[q] = is[q] * ep.bn_gamma[n + q];
+                        be[q] = ep.bn_beta[n + q];
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < kBM / RPP; ++i) {
                 const int rl = r0 + i * RPP;
@@ -319,6 +345,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(a[q]);
                     }
+                    float zc[8];  // z - mean
+                    if (ep.bn_z) {
+                        const u16x8 z = load8(ep.bn_z + o);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(z[q]) - mu[q];
+                        if (ep.mask_from_z) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const unsigned short y = f32_to_bf16(fmaf(zc[q], sc[q], be[q]));  // == lp_bn_apply's output
+                                if ((y & 0x7fff) == 0 || (y & 0x8000)) v[q] = 0.f;
+                            }
+                        }
+                    }
                     if (ep.relu_mask) {
                         const u16x8 y = load8(ep.relu_mask + o);
 #pragma unroll
@@ -329,7 +368,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
 #pragma unroll
                     for (int q = 0; q < 8; ++q) w[q] = f32_to_bf16(v[q]);
                     *reinterpret_cast<u16x8*>(ep.out_bf16 + o) = w;
+                    if (want_stats) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float vr = bf16_to_f32(w[q]);
+                            s0[q] += vr;
+                            s1[q] = fmaf(vr, ep.bn_z ? zc[q] * is[q] : vr, s1[q]);
+                        }
+                    }
                 }
+            }
+        }
+        if (want_stats) {
+            // column sums of this tile: [2][RPP][BN] partials through LDS, then one thread per (component, column)
+            __syncthreads();  // every lane is done reading the fp32 tile
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                so[(0 * RPP + r0) * BN + cc * 8 + q] = s0[q];
+                so[(1 * RPP + r0) * BN + cc * 8 + q] = s1[q];
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int comp = tid / BN, cl = tid % BN;
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
+                if (n0 + cl < N) ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
             }
         }
         return;
@@ -561,6 +625,38 @@ static void launch_wgrad_reduce(const float* ws, int slices, int tiles, int tile
     }
 }
 
+// sums[(2,C)] += column sums of the per-tile partials written by the fused epilogues ([rows][2][C] fp32); the optional
+// accumulators receive the same totals (d beta, d gamma of the BatchNorm backward)
+__global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                float* __restrict__ sums, float* __restrict__ acc0,
+                                                                float* __restrict__ acc1) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (col < 2 * C)
+        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) s += partial[(size_t)r * 2 * C + col];
+    red[rl][lane] = s;
+    __syncthreads();
+    if (rl == 0 && col < 2 * C) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        atomicAdd(&sums[col], t);
+        if (col < C) {
+            if (acc0) atomicAdd(&acc0[col], t);
+        } else if (acc1) {
+            atomicAdd(&acc1[col - C], t);
+        }
+    }
+}
+
+static void launch_tile_stats_reduce(const float* partial, int rows, int C, float* sums, float* acc0, float* acc1, hipStream_t st) {
+    int gy = rows / 64;
+    gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
+    hipLaunchKernelGGL(tile_stats_reduce_kernel, dim3((2 * C + 63) / 64, gy), dim3(256), 0, st, partial, rows, C, sums, acc0, acc1);
+}
+
+static size_t bn_workspace_rows(long long m_out) { return (size_t)((m_out + kBM - 1) / kBM + 4); }
+
 struct WgradPlan {
     int tj, tn, split, per;
     bool wide;
@@ -596,15 +692,21 @@ static ConvGeom to_geom(const lp_conv_geom* c) {
 }  // namespace lp
 
 // out[b][ho][wo][co] = sum x[b][ho*st-pad+r][wo*st-pad+s][ci] * w[co][r][s][ci]  (+bias) ; x, w bf16
-extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32,
-                           int ldo, int n_store, lp_stream_t stream) {
+static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
+                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
     if (g.Ci % kBK != 0 || g.R * g.S > 32 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
-    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr};
+    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr,
+                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     const int tm = (M + kBM - 1) / kBM;
+    if (bn) {
+        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * N * sizeof(float));
+        if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
+        ep.stats = (float*)bn->workspace;
+    }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     if (N > 64) {
@@ -615,13 +717,33 @@ extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geo
         hipLaunchKernelGGL((conv_igemm_kernel<64, kModeFwd>), dim3(tm), dim3(256), 0, st, (const unsigned short*)x,
                            (const unsigned short*)w, g, lat, M, N, K, 1, ep);
     }
+    if (bn) launch_tile_stats_reduce(ep.stats, tm, N, bn->sums, nullptr, nullptr, st);
     return launch_status();
 }
 
+extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32,
+                           int ldo, int n_store, lp_stream_t stream) {
+    return conv_fwd_impl(x, w, geom, bias, out_bf16, out_f32, ldo, n_store, nullptr, stream);
+}
+
+extern "C" size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad) {
+    using namespace lp;
+    if (!geom_ok(geom)) return 0;
+    const long long rows = (long long)geom->B * (dgrad ? geom->Hi * geom->Wi : geom->Ho * geom->Wo);
+    return bn_workspace_rows(rows) * 2 * (size_t)(dgrad ? geom->Ci : geom->Co) * sizeof(float);
+}
+
+// conv + the [sum, sum of squares] of its (bf16-rounded) output per channel: the statistics pass of the BatchNorm that follows
+extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+                              lp_stream_t stream) {
+    LP_REQUIRE(bn && geom && out_bf16);
+    return conv_fwd_impl(x, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream);
+}
+
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
-extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
-                             const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
-                             lp_stream_t stream) {
+static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
+                           const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
+                           const lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -629,12 +751,29 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
         return LP_ERR_UNSUPPORTED;
     const int N = g.Ci;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
-                    (const unsigned short*)relu_mask};
+                    (const unsigned short*)relu_mask, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (bn) {
+        // the reductions cover every pixel exactly once, so no class may be skipped and the output must be the dense bf16 tensor
+        LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && bn->workspace && dx_bf16 && !dx_f32 && !skip_empty_classes &&
+                   ldo == N && ep.n_store == N && (!bn->mask_from_z || (bn->gamma && bn->beta)) &&
+                   bn->workspace_bytes >= bn_workspace_rows((long long)g.B * g.Hi * g.Wi) * 2 * N * sizeof(float));
+        if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
+        ep.stats = (float*)bn->workspace;
+        ep.bn_z = (const unsigned short*)bn->z;
+        ep.bn_mean = bn->mean;
+        ep.bn_invstd = bn->invstd;
+        ep.bn_gamma = bn->gamma;
+        ep.bn_beta = bn->beta;
+        ep.mask_from_z = bn->mask_from_z;
+    }
     hipStream_t st = (hipStream_t)stream;
+    int stats_rows = 0;
     auto launch = [&](const Lattice& lat) {
         const int M = g.B * lat.nh * lat.nw, K = lat.nr * lat.ns * g.Co;
         if (M <= 0) return;
         const int tm = (M + kBM - 1) / kBM;
+        ep.stats_row0 = stats_rows;
+        stats_rows += tm;
         if (N > 64) {
             const int tn = (N + 127) / 128;
             hipLaunchKernelGGL((conv_igemm_kernel<128, kModeDgrad>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)dy,
@@ -658,7 +797,21 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
                 launch(Lattice{h0, 2, nh, w0, 2, nw, ph, 2, nr, pw, 2, ns});
             }
     }
+    if (bn) launch_tile_stats_reduce(ep.stats, stats_rows, N, bn->sums, bn->dbeta_acc, bn->dgamma_acc, st);
     return launch_status();
+}
+
+extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
+                             const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
+                             lp_stream_t stream) {
+    return conv_dgrad_impl(dy, wd, geom, bias, addend, relu_mask, dx_bf16, dx_f32, ldo, n_store, skip_empty_classes, nullptr, stream);
+}
+
+// data gradient + ReLU backward + the two reductions of the BatchNorm backward that consumes dx (sum dx, sum dx * xhat)
+extern "C" int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
+                                void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream) {
+    LP_REQUIRE(bn && geom);
+    return conv_dgrad_impl(dy, wd, geom, nullptr, addend, relu_mask, dx_bf16, nullptr, geom->Ci, 0, 0, bn, stream);
 }
 
 extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint) {
@@ -696,17 +849,35 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
 }
 
 // 7x7/2 stem on NHWC4 bf16 input (channel 3 = 0): weights [64][7+1][8][4] zero padded (K = 256)
-extern "C" int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_stream_t stream) {
+static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+                         lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x4 && w && geom_ok(geom) && out_bf16);
     ConvGeom g = to_geom(geom);
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo;
-    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr};
+    const int tm = (M + kBM - 1) / kBM;
+    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr,
+                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (bn) {
+        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * 64 * sizeof(float));
+        ep.stats = (float*)bn->workspace;
+    }
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    hipLaunchKernelGGL((conv_igemm_kernel<64, kModeStem>), dim3((M + kBM - 1) / kBM), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((conv_igemm_kernel<64, kModeStem>), dim3(tm), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)x4, (const unsigned short*)w, g, lat, M, 64, 256, 1, ep);
+    if (bn) launch_tile_stats_reduce(ep.stats, tm, 64, bn->sums, nullptr, nullptr, (hipStream_t)stream);
     return launch_status();
+}
+
+extern "C" int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_stream_t stream) {
+    return stem_fwd_impl(x4, w, geom, out_bf16, nullptr, stream);
+}
+
+extern "C" int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+                              lp_stream_t stream) {
+    LP_REQUIRE(bn);
+    return stem_fwd_impl(x4, w, geom, out_bf16, bn, stream);
 }
 
 // dw[64][8][8][4] fp32 (K = 256 layout of lp_stem_fwd) += ...

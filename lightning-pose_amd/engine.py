@@ -199,6 +199,7 @@ class Engine:
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
         self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
+        self._bn_ws: torch.Tensor | None = None     # per-tile column sums of the fused BatchNorm reductions
 
     def _timed(self, tag: str, flops: float, fn):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -314,24 +315,50 @@ class Engine:
         Wo = (Wi + 2 * c.pad - c.k) // c.stride + 1
         return _lib.ConvGeom(B, Hi, Wi, c.Ci, Ho, Wo, c.Co, c.k, c.k, c.stride, c.pad)
 
-    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int):
+    def _bn_fuse(self, g: _lib.ConvGeom, dgrad: bool, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None,
+                 mask_from_z: bool = False) -> _lib.BnFuse:
+        """lp_bn_fuse for one launch; the per-tile workspace is one scratch buffer reused by every launch of the stream."""
+        need = int(self._lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
+        if self._bn_ws is None or self._bn_ws.numel() < need:
+            self._bn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        f = _lib.BnFuse()
+        f.sums, f.workspace, f.workspace_bytes = sums.data_ptr(), self._bn_ws.data_ptr(), need
+        if dgrad:
+            f.z, f.mean, f.invstd = z.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+            f.gamma, f.beta = self.param_view(b, "weight").data_ptr(), self.param_view(b, "bias").data_ptr()
+            f.mask_from_z = int(mask_from_z)
+            f.dbeta_acc, f.dgamma_acc = self.G[b.b_off:].data_ptr(), self.G[b.g_off:].data_ptr()
+        return f
+
+    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None):
+        """``sums`` (2,Co): also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics pass, fused)."""
         g = self._geom(c, B, Hi, Wi)
         out = torch.empty(B, g.Ho, g.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
         w = self.Wb[c.w_off:]
+        st = ops._stream()
         if c.kind == "stem":
-            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g),
-                        lambda: check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), ops._stream()), "lp_stem_fwd"))
+            if sums is None:
+                run = lambda: check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), st), "lp_stem_fwd")  # noqa: E731
+            else:
+                f = self._bn_fuse(g, False, sums)
+                run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
+            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run)
         else:
-            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g),
-                        lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, ops._stream()),
-                                      "lp_conv_fwd"))
+            if sums is None:
+                run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
+            else:
+                f = self._bn_fuse(g, False, sums)
+                run = lambda: check(self._lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_conv_fwd_bn")  # noqa: E731
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run)
         return out, g
 
-    def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor):
+    def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
+                have_sums: bool = False):
         mean = torch.empty(b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         if training:
-            check(self._lib.lp_bn_stats(_p(z), M, b.C, _p(sums), ops._stream()), "lp_bn_stats")
+            if not have_sums:
+                check(self._lib.lp_bn_stats(_p(z), M, b.C, _p(sums), ops._stream()), "lp_bn_stats")
             count = float(M)
             if self.sync_bn:
                 dist.all_reduce(sums, group=self.process_group)
@@ -370,9 +397,15 @@ class Engine:
         x4 = torch.empty(B, H, W, 4, device=self.device, dtype=torch.bfloat16)
         check(self._lib.lp_images_to_nhwc4(_p(images), B, H, W, _p(x4), ops._stream()), "lp_images_to_nhwc4")
         T["x4"] = x4
-        z, g = self._conv_fwd(plan.stem, x4, B, H, W)
+        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu):
+            """conv -> BatchNorm(+residual)(+ReLU); in training the statistics come out of the convolution's store pass"""
+            sums = next_sums(b)
+            zz, gg = self._conv_fwd(c, xin, B, hh, ww, sums if training else None)
+            aa, mm, vv = self._bn_fwd(b, zz, B * gg.Ho * gg.Wo, residual, relu, training, sums, have_sums=training)
+            return zz, aa, mm, vv, gg
+
+        z, a, mu, iv, g = conv_bn(plan.stem, plan.stem_bn, x4, H, W, None, True)
         h, w = g.Ho, g.Wo
-        a, mu, iv = self._bn_fwd(plan.stem_bn, z, B * h * w, None, True, training, next_sums(plan.stem_bn))
         T["stem.z"], T["stem.a"], T["stem.mu"], T["stem.iv"] = z, a, mu, iv
         ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         x = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.bfloat16)
@@ -385,19 +418,15 @@ class Engine:
             key = f"b{i}"
             T[f"{key}.x"] = x
             tp.meta[f"{key}.hw"] = (h, w)
-            z1, _ = self._conv_fwd(blk.conv1, x, B, h, w)
-            a1, m1, v1 = self._bn_fwd(blk.bn1, z1, B * h * w, None, True, training, next_sums(blk.bn1))
-            z2, g2 = self._conv_fwd(blk.conv2, a1, B, h, w)
+            z1, a1, m1, v1, _ = conv_bn(blk.conv1, blk.bn1, x, h, w, None, True)
+            z2, a2, m2, v2, g2 = conv_bn(blk.conv2, blk.bn2, a1, h, w, None, True)
             ho, wo = g2.Ho, g2.Wo
-            a2, m2, v2 = self._bn_fwd(blk.bn2, z2, B * ho * wo, None, True, training, next_sums(blk.bn2))
-            z3, _ = self._conv_fwd(blk.conv3, a2, B, ho, wo)
             if blk.down is not None:
-                zd, _ = self._conv_fwd(blk.down, x, B, h, w)
-                idt, md, vd = self._bn_fwd(blk.dbn, zd, B * ho * wo, None, False, training, next_sums(blk.dbn))
+                zd, idt, md, vd, _ = conv_bn(blk.down, blk.dbn, x, h, w, None, False)
                 T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"] = zd, md, vd
             else:
                 idt = x
-            out, m3, v3 = self._bn_fwd(blk.bn3, z3, B * ho * wo, idt, True, training, next_sums(blk.bn3))
+            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True)
             for nm, val in (("z1", z1), ("a1", a1), ("m1", m1), ("v1", v1), ("z2", z2), ("a2", a2), ("m2", m2), ("v2", v2),
                             ("z3", z3), ("m3", m3), ("v3", v3), ("out", out)):
                 T[f"{key}.{nm}"] = val
@@ -437,10 +466,12 @@ class Engine:
         return heat, tp
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool):
-        sums = torch.zeros(2 * b.C, device=self.device, dtype=torch.float32)
-        check(self._lib.lp_bn_bwd_reduce(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), M, b.C, _p(sums),
-                                         _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), ops._stream()), "lp_bn_bwd_reduce")
+    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None):
+        """``sums``: the (2,C) reductions [sum dy, sum dy*xhat] when the dgrad that produced ``dy`` already made them."""
+        if sums is None:
+            sums = torch.zeros(2 * b.C, device=self.device, dtype=torch.float32)
+            check(self._lib.lp_bn_bwd_reduce(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), M, b.C, _p(sums),
+                                             _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), ops._stream()), "lp_bn_bwd_reduce")
         count = float(M)
         if self.sync_bn:
             dist.all_reduce(sums, group=self.process_group)
@@ -451,21 +482,31 @@ class Engine:
                                         count, M, b.C, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply")
         return dz, dres
 
-    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None):
+    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None):
         """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
         ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
-        for stride-2 layers only the pixels a filter tap reaches are touched."""
+        for stride-2 layers only the pixels a filter tap reaches are touched.
+        ``bn`` = (BNP, z, mean, invstd, sums): dx is the gradient of relu(BN(z) [+ residual]); the launch also leaves BatchNorm's
+        two backward reductions in ``sums``.  Without ``relu_mask`` the ReLU mask is recomputed from z (no residual branch)."""
         g = self._geom(c, B, Hi, Wi)
         self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g), lambda: self._wgrad(x, dz, g, self.G[c.w_off:]))
         if not need_dx:
             return None
+        st = ops._stream()
         if accumulate_into is not None:
             dx, addend, skip = accumulate_into, accumulate_into, 1
         else:
             dx, skip = torch.empty(B, Hi, Wi, c.Ci, device=self.device, dtype=torch.bfloat16), 0
-        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g),
-                    lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),
-                                                          _p(dx), None, c.Ci, 0, skip, ops._stream()), "lp_conv_dgrad"))
+        if bn is not None:
+            assert accumulate_into is None
+            b, z, mean, invstd, sums = bn
+            f = self._bn_fuse(g, True, sums, b, z, mean, invstd, mask_from_z=relu_mask is None)
+            run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
+                                                           C.byref(f), st), "lp_conv_dgrad_bn")
+        else:
+            run = lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),  # noqa: E731
+                                                        _p(dx), None, c.Ci, 0, skip, st), "lp_conv_dgrad")
+        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run)
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -498,6 +539,16 @@ class Engine:
         d = torch.empty(B, fh, fw, 2048, device=self.device, dtype=torch.bfloat16)
         check(self._lib.lp_pixel_shuffle(_p(dcur), B, fh, fw, 512, 1, _p(d), ops._stream()), "lp_pixel_shuffle(inv)")
 
+        # One zeroed buffer for the reductions of every fused BatchNorm backward of this pass.
+        bsums_all = torch.zeros(sum(2 * b.C for b in plan.bns), device=self.device, dtype=torch.float32)
+        bo = [0]
+
+        def new_sums(b: BNP) -> torch.Tensor:
+            t = bsums_all[bo[0]:bo[0] + 2 * b.C]
+            bo[0] += 2 * b.C
+            return t
+
+        d_sums = None  # reductions of the current block's bn3 backward, when the dgrad that produced `d` already made them
         for i in range(len(plan.blocks) - 1, -1, -1):
             blk, key = plan.blocks[i], f"b{i}"
             if trace is not None:
@@ -508,25 +559,37 @@ class Engine:
             Mo, Mi = B * ho * wo, B * hi * wi
             x = T[f"{key}.x"]
             last = i == len(plan.blocks) - 1
-            # ReLU backward is fused into the dgrad that PRODUCES each gradient (relu_mask = the activation it belongs to), so
-            # the BatchNorm backward kernels never re-read the activations; only the trunk output (fed by the head) and the
-            # stem (fed by the max-pool) still mask inside the BN kernels.
+            # ReLU backward AND the two reductions of the BatchNorm backward are fused into the dgrad that PRODUCES each
+            # gradient: its store pass zeroes the gradient where the activation is <= 0 (mask recomputed from the saved
+            # pre-normalisation tensor, or read from the block output when there is a residual branch) and leaves
+            # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head), the stem (fed by the max-pool) and
+            # the inputs of the stride-2 blocks (two partial writers) still run lp_bn_bwd_reduce.
             if last:
                 dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True)
             else:
-                dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False)
+                dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False, sums=d_sums)
                 dres = d
-            da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True, relu_mask=T[f"{key}.a2"])
-            dz2, _ = self._bn_bwd(blk.bn2, da2, None, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False)
-            da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True, relu_mask=T[f"{key}.a1"])
-            dz1, _ = self._bn_bwd(blk.bn1, da1, None, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False)
+            s2 = new_sums(blk.bn2)
+            da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True,
+                                 bn=(blk.bn2, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], s2))
+            dz2, _ = self._bn_bwd(blk.bn2, da2, None, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False, sums=s2)
+            s1 = new_sums(blk.bn1)
+            da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True,
+                                 bn=(blk.bn1, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], s1))
+            dz1, _ = self._bn_bwd(blk.bn1, da1, None, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False, sums=s1)
             mask_x = x if i > 0 else None  # block 0's input is the max-pool output: its ReLU is handled by the stem BN backward
+            d_sums = None
             if blk.down is not None:
                 dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False)
                 # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
                 # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x)
                 self._conv_bwd(blk.down, x, dzd, B, hi, wi, True, relu_mask=mask_x, accumulate_into=d)
+            elif i > 0:
+                prev, pk = plan.blocks[i - 1], f"b{i - 1}"
+                d_sums = new_sums(prev.bn3)
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x,
+                                   bn=(prev.bn3, T[f"{pk}.z3"], T[f"{pk}.m3"], T[f"{pk}.v3"], d_sums))
             else:
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x)
 

@@ -254,6 +254,47 @@ def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, 
     return ob.np(), (of.np() if of is not None else None)
 
 
+def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, want_acc=False):
+    """lp_bn_fuse + the buffers it points at (kept alive on the returned object)."""
+    f = _lib.BnFuse()
+    f.keep = dict(z=B(z), mean=B(mean, np.float32), invstd=B(invstd, np.float32), gamma=B(gamma, np.float32), beta=B(beta, np.float32),
+                  sums=Z((2, Cn)), dbeta=Z(Cn) if want_acc else None, dgamma=Z(Cn) if want_acc else None)
+    nws = lib().lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad))
+    f.keep["ws"] = Buf(np.full(nws // 4, np.nan, np.float32))  # poisoned: every partial that is read must have been written
+    k = f.keep
+    f.z, f.mean, f.invstd, f.gamma, f.beta = (ptr(k[n]).value if k[n] is not None else None for n in ("z", "mean", "invstd", "gamma", "beta"))
+    f.mask_from_z = int(mask_from_z)
+    f.sums = k["sums"].p.value
+    f.dbeta_acc = k["dbeta"].p.value if want_acc else None
+    f.dgamma_acc = k["dgamma"].p.value if want_acc else None
+    f.workspace, f.workspace_bytes = k["ws"].p.value, nws
+    return f
+
+
+def conv_fwd_bn(x_nhwc_bits, w_bits, g):
+    """-> (z bits, sums (2,Co))"""
+    xb, wb, ob = Buf(x_nhwc_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
+    f = _bn_fuse(g, False, g.Co)
+    ok(lib().lp_conv_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
+    return ob.np(), f.keep["sums"].np()
+
+
+def stem_fwd_bn(x4_bits, w_bits, g):
+    xb, wb, ob = Buf(x4_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, 64), np.uint16)
+    f = _bn_fuse(g, False, 64)
+    ok(lib().lp_stem_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
+    return ob.np(), f.keep["sums"].np()
+
+
+def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None):
+    """-> (dx bits, sums (2,Ci), dbeta, dgamma); the ReLU mask comes from mask_bits if given, else is recomputed from z"""
+    db, wb, ab, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(mask_bits)
+    ob = Z((g.B * g.Hi * g.Wi, g.Ci), np.uint16)
+    f = _bn_fuse(g, True, g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None, want_acc=True)
+    ok(lib().lp_conv_dgrad_bn(db.p, wb.p, C.byref(g), ptr(ab), ptr(mb), ob.p, C.byref(f), stream()))
+    return ob.np(), f.keep["sums"].np(), f.keep["dbeta"].np(), f.keep["dgamma"].np()
+
+
 def conv_wgrad(x_bits, dy_bits, g, split=0):
     xb, db, dw = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
     nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)

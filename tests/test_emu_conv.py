@@ -126,3 +126,40 @@ def test_stem_fwd_wgrad():
     dw = torch.from_numpy(emu.stem_wgrad(emu.to_bf16_bits(x4), emu.to_bf16_bits(nhwc(dy)), g)).reshape(64, 8, 8, 4)
     torch.testing.assert_close(dw[:, :7, :7, :3], w.grad.permute(0, 2, 3, 1), atol=3e-3, rtol=3e-3)
     assert not dw[:, 7].any() and not dw[:, :, 7].any() and not dw[..., 3].any()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fused_batchnorm_reductions(case):
+    """lp_conv_fwd_bn == lp_conv_fwd + lp_bn_stats;  lp_conv_dgrad_bn == lp_conv_dgrad(+mask) + lp_bn_bwd_reduce, for both mask
+    sources (the activation tensor, or recomputed from the pre-normalisation tensor)."""
+    B, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(7 + sum(case))
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    x = emu.to_bf16_bits(torch.randn(B, Hi, Wi, Ci, generator=gen))
+    w = torch.randn(Co, R, R, Ci, generator=gen) / (Ci * R * R) ** 0.5
+    wg, wd = emu.to_bf16_bits(w), emu.to_bf16_bits(w.permute(3, 1, 2, 0))
+    # ---- forward statistics
+    z_plain, _ = emu.conv_fwd(x, wg, g)
+    z, sums = emu.conv_fwd_bn(x, wg, g)
+    assert np.array_equal(z, z_plain)
+    zf = emu.from_bf16_bits(z).double()
+    np.testing.assert_allclose(sums[0], zf.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(sums[1], (zf * zf).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    # ---- backward reductions: dx is the gradient of a = relu(BN(zin) [+ residual]) where zin has the conv INPUT's shape
+    Mi = B * Hi * Wi
+    zin = torch.randn(Mi, Ci, generator=gen)
+    zin_bits = emu.to_bf16_bits(zin)
+    gamma, beta = torch.rand(Ci, generator=gen) + 0.5, torch.randn(Ci, generator=gen) * 0.3
+    a_bits, mean, invstd = emu.bn_forward(zin_bits, Mi, Ci, gamma.numpy(), beta.numpy(), relu=True)
+    dy = emu.to_bf16_bits(torch.randn(B * g.Ho * g.Wo, Co, generator=gen))
+    add = emu.to_bf16_bits(torch.randn(Mi, Ci, generator=gen))
+    want_dx, _ = emu.conv_dgrad(dy, wd, g, addend_bits=add, mask_bits=a_bits)
+    _, _, want_dgamma, want_dbeta = emu.bn_backward(want_dx, None, zin_bits, mean, invstd, gamma.numpy(), Mi, Ci)
+    for mask in (a_bits, None):
+        dx, sums, dbeta, dgamma = emu.conv_dgrad_bn(dy, wd, g, zin_bits, mean, invstd, gamma.numpy(), beta.numpy(), addend_bits=add,
+                                                    mask_bits=mask)
+        assert np.array_equal(dx, want_dx)
+        np.testing.assert_allclose(sums[0], want_dbeta, rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(sums[1], want_dgamma, rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(dbeta, sums[0], rtol=0, atol=0)
+        np.testing.assert_allclose(dgamma, sums[1], rtol=0, atol=0)
