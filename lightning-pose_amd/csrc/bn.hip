@@ -18,12 +18,7 @@ __device__ __forceinline__ void unpack8(const u16x8& v, float (&f)[8]) {
     for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32(v[i]);
 }
 
-__device__ __forceinline__ u16x8 pack8(const float (&f)[8]) {
-    u16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = f32_to_bf16(f[i]);
-    return v;
-}
+__device__ __forceinline__ u16x8 pack8(const float (&f)[8]) { return pack_bf16x8(f); }
 
 // ---- per-channel sums over rows: sums[0][c] += sum a, sums[1][c] += sum a*b -------------------------------------
 // MODE 0: plain statistics (sum x, sum x^2)
@@ -72,7 +67,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
                         const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + off);
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if ((yo[i] & 0x7fff) == 0 || (yo[i] & 0x8000)) a[i] = 0.f;  // relu'(y): y <= 0
+                            if (!bf16_positive(yo[i])) a[i] = 0.f;  // relu'(y): y <= 0
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -172,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
             const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + q * 8);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if ((yo[i] & 0x7fff) == 0 || (yo[i] & 0x8000)) dz[i] = 0.f;
+                if (!bf16_positive(yo[i])) dz[i] = 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -17,6 +17,8 @@
 // of tiles that share the activation panel.  The weight-gradient contracts over pixels, which are strided in
 // memory, so its operands are transposed on the way into LDS (4x8 register transpose + ds_write_b64) and partial
 // sums of the split-K slices are combined with fp32 atomics straight into the flat gradient buffer.
+#include <stdlib.h>
+
 #include "lp_common.h"
 
 namespace lp {
@@ -90,10 +92,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
 }
 
 // row index in the output tensor of row m of this launch's pixel sub-lattice (identity for full-lattice launches)
-__device__ __forceinline__ int out_row(int m, const Lattice& lat, int rows_y, int rows_x, int full_h, int full_w) {
+__device__ __forceinline__ int out_row(int m, const Lattice& lat, const FastDiv& div_img, const FastDiv& div_row, int full_h, int full_w) {
     if (lat.hstep == 1 && lat.wstep == 1) return m;
-    const int b = m / (rows_y * rows_x), rem = m - b * rows_y * rows_x;
-    const int iy = rem / rows_x, ix = rem - iy * rows_x;
+    const int b = fdiv(m, div_img), rem = m - b * div_img.d;
+    const int iy = fdiv(rem, div_row), ix = rem - iy * div_row.d;
     return (b * full_h + lat.h0 + lat.hstep * iy) * full_w + lat.w0 + lat.wstep * ix;
 }
 
@@ -140,9 +142,9 @@ __device__ __forceinline__ u16x8 load4x2(const unsigned short* p0, bool ok0, con
 //   kModeStem  forward of the 7x7/2 stem on NHWC4 input, k = (r, s8, c4) padded to 256
 // ------------------------------------------------------------------------------------------------------------
 template <int BN, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
-                                                         ConvGeom g, Lattice lat, int M, int N, int K, int tiles_n,
-                                                         ConvEpilogue ep) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
+                                                         ConvGeom g, Lattice lat, FastDiv div_img, FastDiv div_row, int M, int N, int K,
+                                                         int tiles_n, int ntiles, ConvEpilogue ep) {
     constexpr int NT = BN / 64;
     // one LDS block: [2][128][72] A + [2][BN][72] B operand tiles, reused by the epilogue as a [128][BN+4] fp32 tile
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (kBM + BN) * kLD];
@@ -152,11 +154,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * kBM, n0 = (tile % tiles_n) * BN;
-
     const int kchunk = tid & 7, rbase = tid >> 3;  // 8 x 16-B chunks per 64-wide K row; 32 rows per pass
 
+    // Workgroups are persistent: each walks the tile list with stride gridDim.x, and the operands of the NEXT tile's first K
+    // step are already in flight (in registers) while the current tile's epilogue runs, so the store pass of one tile overlaps
+    // the load latency of the next.
+    //
     // Per-thread description of the 4 A rows this thread stages.  Everything that depends only on the row is hoisted
     // out of the K loop: `rowoff` is the element offset of the row's origin in the gathered tensor and `vmask` has one
     // bit per filter tap saying whether that tap reads a real pixel (zero padding / stride-2 parity / row >= M
@@ -173,70 +176,73 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
     const int src_h = (MODE == kModeDgrad) ? g.Ho : g.Hi;
     const int src_w = (MODE == kModeDgrad) ? g.Wo : g.Wi;
     const bool halved = (MODE == kModeDgrad) && g.stride == 2;  // stride-2 dgrad: tap (r,s) -> pixel ((py-r)/2, (px-s)/2)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + rbase + 32 * i;
-        pv[i] = m < M;
-        const int mm = pv[i] ? m : 0;
-        const int b = mm / (rows_y * rows_x);
-        const int rem = mm - b * rows_y * rows_x;
-        const int iy = rem / rows_x;
-        const int y = lat.h0 + lat.hstep * iy, xq = lat.w0 + lat.wstep * (rem - iy * rows_x);
-        pb[i] = b;
-        if (MODE == kModeDgrad) {
-            py[i] = y + g.pad;
-            px[i] = xq + g.pad;
-        } else {
-            py[i] = y * g.stride - g.pad;
-            px[i] = xq * g.stride - g.pad;
-        }
-        const int oy = halved ? (py[i] >> 1) : py[i], ox = halved ? (px[i] >> 1) : px[i];
-        rowoff[i] = ((b * src_h + oy) * src_w + ox) * ck + kchunk * 8;
-        unsigned mask = 0;
-        if (MODE != kModeStem && pv[i]) {
-            for (int ir = 0; ir < lat.nr; ++ir)
-                for (int it = 0; it < lat.ns; ++it) {
-                    const int r = lat.r0 + lat.rstep * ir, t = lat.s0 + lat.sstep * it;
-                    bool ok;
-                    if (MODE == kModeDgrad) {
-                        const int th = py[i] - r, tw = px[i] - t;
-                        if (halved) ok = th >= 0 && tw >= 0 && !((th | tw) & 1) && (th >> 1) < g.Ho && (tw >> 1) < g.Wo;
-                        else ok = th >= 0 && th < g.Ho && tw >= 0 && tw < g.Wo;
-                    } else {
-                        const int sy = py[i] + r, sx = px[i] + t;
-                        ok = sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
-                    }
-                    mask |= (ok ? 1u : 0u) << (ir * lat.ns + it);
-                }
-        }
-        vmask[i] = mask;
-    }
-
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    const int KT = K / kBK;  // 0 for a parity class without taps: the epilogue then just writes addend / zeros
 
     u16x8 ra[4], rb[BN / 32];
     unsigned okbits = 0xfu;      // which of ra[0..3] hold real data; applied when the registers are written to LDS, so
                                  // nothing between the loads and the MFMA block waits on them
     int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
     const unsigned short* wrow[BN / 32];
+    int m0n = 0, n0n = 0;        // origin of the tile being set up / loaded
+
+    auto setup = [&](int vt) {
+        const int tile = xcd_remap(vt, ntiles);
+        const int tm_ = tile / tiles_n;
+        m0n = tm_ * kBM;
+        n0n = (tile - tm_ * tiles_n) * BN;
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-        int n = n0 + rbase + 32 * i;
-        if (n >= N) n = N - 1;  // rows past N are loaded (never stored): keeps the loop free of predicates
-        wrow[i] = Wt + (size_t)n * ((MODE == kModeStem) ? K : g.R * g.S * ck) + kchunk * 8;  // row stride = the FULL filter
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0n + rbase + 32 * i;
+            pv[i] = m < M;
+            const int mm = pv[i] ? m : 0;
+            const int b = fdiv(mm, div_img);
+            const int rem = mm - b * rows_y * rows_x;
+            const int iy = fdiv(rem, div_row);
+            const int y = lat.h0 + lat.hstep * iy, xq = lat.w0 + lat.wstep * (rem - iy * rows_x);
+            pb[i] = b;
+            if (MODE == kModeDgrad) {
+                py[i] = y + g.pad;
+                px[i] = xq + g.pad;
+            } else {
+                py[i] = y * g.stride - g.pad;
+                px[i] = xq * g.stride - g.pad;
+            }
+            const int oy = halved ? (py[i] >> 1) : py[i], ox = halved ? (px[i] >> 1) : px[i];
+            rowoff[i] = ((b * src_h + oy) * src_w + ox) * ck + kchunk * 8;
+            unsigned mask = 0;
+            if (MODE != kModeStem && pv[i]) {
+                for (int ir = 0; ir < lat.nr; ++ir)
+                    for (int it = 0; it < lat.ns; ++it) {
+                        const int r = lat.r0 + lat.rstep * ir, t = lat.s0 + lat.sstep * it;
+                        bool ok;
+                        if (MODE == kModeDgrad) {
+                            const int th = py[i] - r, tw = px[i] - t;
+                            if (halved) ok = th >= 0 && tw >= 0 && !((th | tw) & 1) && (th >> 1) < g.Ho && (tw >> 1) < g.Wo;
+                            else ok = th >= 0 && th < g.Ho && tw >= 0 && tw < g.Wo;
+                        } else {
+                            const int sy = py[i] + r, sx = px[i] + t;
+                            ok = sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
+                        }
+                        mask |= (ok ? 1u : 0u) << (ir * lat.ns + it);
+                    }
+            }
+            vmask[i] = mask;
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            int n = n0n + rbase + 32 * i;
+            if (n >= N) n = N - 1;  // rows past N are loaded (never stored): keeps the loop free of predicates
+            wrow[i] = Wt + (size_t)n * ((MODE == kModeStem) ? K : g.R * g.S * ck) + kchunk * 8;  // row stride = the FULL filter
+        }
+        tir = tis = tc = 0;
+    };
 
     auto load_step = [&](int kt) {
         int woff = kt * kBK;
         // ---- A: gathered activations
         if (MODE == kModeStem) {
             const int r = kt * 2 + (kchunk >> 2), s0 = (kchunk & 3) * 2;
+            okbits = 0xfu;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hi = py[i] + r, wi = px[i] + s0;
@@ -279,148 +285,185 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const unsigned short* _
         for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = rb[i];
     };
 
-    const int KT = K / kBK;  // 0 for a parity class without taps: the epilogue then just writes addend / zeros
-    if (KT > 0) {
-        load_step(0);
-        store_step(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_step(kt + 1);  // global loads in flight under the MFMAs
-        mma_kstep<NT>(sA[cur], sB[cur], wm, wn, lane, acc);
-        if (kt + 1 < KT) store_step(cur ^ 1);
-        __syncthreads();
-    }
+    f32x16 acc[2][NT];
 
-    // ---- epilogue: D reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile
-    const int col = lane & 31, rg = lane >> 5;
-    if (ep.out_f32 == nullptr && (ep.n_store & 7) == 0 && (ep.ldo & 7) == 0) {
-        // bf16 output: stage the fp32 tile in LDS (the operand buffers are free after the last barrier), then every lane
-        // moves 16 B (8 channels) per store so a 128-column row leaves as two full 128-B lines; the addend (gradient
-        // accumulation) is read the same way and added in fp32 before the single rounding to bf16
-        constexpr int LDO = BN + 4;
-        float* so = reinterpret_cast<float*>(smem);
+    // ---- epilogue of the tile at (m0, n0): D reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile
+    auto epilogue = [&](const int m0, const int n0) {
+        const int col = lane & 31, rg = lane >> 5;
+        if (ep.out_f32 == nullptr && (ep.n_store & 7) == 0 && (ep.ldo & 7) == 0) {
+            // bf16 output: stage the fp32 tile in LDS (the operand buffers are free after the last barrier), then every lane
+            // moves 16 B (8 channels) per store so a 128-column row leaves as two full 128-B lines; the addend (gradient
+            // accumulation) is read the same way and added in fp32 before the single rounding to bf16
+            constexpr int LDO = BN + 4;
+            float* so = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int nl = wn * (NT * 32) + nt * 32 + col;
+                    const float bias = (ep.bias && n0 + nl < N) ? ep.bias[n0 + nl] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        so[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg) * LDO + nl] = acc[mt][nt][e] + bias;
+                }
+            __syncthreads();
+            constexpr int CPR = BN / 8;          // 16-B chunks per tile row
+            constexpr int RPP = 256 / CPR;       // rows per pass
+            const int cc = tid % CPR, r0 = tid / CPR;
+            const int n = n0 + cc * 8;
+            const bool want_stats = ep.stats != nullptr;
+            float s0[8], s1[8], mu[8], is[8], sc[8], be[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = is[q] = sc[q] = be[q] = 0.f;
+            if (n < ep.n_store) {
+                if (ep.bn_z) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        mu[q] = ep.bn_mean[n + q];
+                        is[q] = ep.bn_invstd[n + q];
+                        if (ep.mask_from_z) {
+                            sc[q] = is[q] * ep.bn_gamma[n + q];
+                            be[q] = ep.bn_beta[n + q];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kBM / RPP; ++i) {
+                    const int rl = r0 + i * RPP;
+                    const int m = m0 + rl;
+                    if (m < M) {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8 + 4);
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const size_t o = (size_t)out_row(m, lat, div_img, div_row, full_h, full_w) * ep.ldo + n;
+                        if (ep.addend) {
+                            const u16x8 a = load8(ep.addend + o);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(a[q]);
+                        }
+                        float zc[8];  // z - mean
+                        if (ep.bn_z) {
+                            const u16x8 z = load8(ep.bn_z + o);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(z[q]) - mu[q];
+                            if (ep.mask_from_z) {
+                                // lp_bn_apply stored bf16(max(o, 0)) with this same o; that is > 0 exactly when o exceeds half
+                                // the smallest bf16 subnormal (round-to-nearest-even)
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    if (!(fmaf(zc[q], sc[q], be[q]) > 0x1p-134f)) v[q] = 0.f;
+                            }
+                        }
+                        if (ep.relu_mask) {
+                            const u16x8 y = load8(ep.relu_mask + o);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (!bf16_positive(y[q])) v[q] = 0.f;
+                        }
+                        const u16x8 w = pack_bf16x8(v);
+                        *reinterpret_cast<u16x8*>(ep.out_bf16 + o) = w;
+                        if (want_stats) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const float vr = bf16_to_f32(w[q]);
+                                s0[q] += vr;
+                                s1[q] = fmaf(vr, ep.bn_z ? zc[q] * is[q] : vr, s1[q]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (want_stats) {
+                // column sums of this tile: [2][RPP][BN] partials through LDS, then one thread per (component, column)
+                __syncthreads();  // every lane is done reading the fp32 tile
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    so[(0 * RPP + r0) * BN + cc * 8 + q] = s0[q];
+                    so[(1 * RPP + r0) * BN + cc * 8 + q] = s1[q];
+                }
+                __syncthreads();
+                if (tid < 2 * BN) {
+                    const int comp = tid / BN, cl = tid % BN;
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
+                    if (n0 + cl < N) ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int nl = wn * (NT * 32) + nt * 32 + col;
-                const float bias = (ep.bias && n0 + nl < N) ? ep.bias[n0 + nl] : 0.f;
+                const int n = n0 + wn * (NT * 32) + nt * 32 + col;
+                if (n >= ep.n_store) continue;
+                const float bias = ep.bias ? ep.bias[n] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) so[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg) * LDO + nl] = acc[mt][nt][e] + bias;
-            }
-        __syncthreads();
-        constexpr int CPR = BN / 8;          // 16-B chunks per tile row
-        constexpr int RPP = 256 / CPR;       // rows per pass
-        const int cc = tid % CPR, r0 = tid / CPR;
-        const int n = n0 + cc * 8;
-        const bool want_stats = ep.stats != nullptr;
-        float s0[8], s1[8], mu[8], is[8], sc[8], be[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = is[q] = sc[q] = be[q] = 0.f;
-        if (n < ep.n_store) {
-            if (ep.bn_z) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    mu[q] = ep.bn_mean[n + q];
-                    is[q] = ep.bn_invstd[n + q];
-                    if (ep.mask_from_z) {
-                        sc[q] = is[q] * ep.bn_gamma[n + q];
-                        be[q] = ep.bn_beta[n + q];
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
+                    if (m < M) {
+                        float v = acc[mt][nt][e] + bias;
+                        const size_t o = (size_t)out_row(m, lat, div_img, div_row, full_h, full_w) * ep.ldo + n;
+                        if (ep.addend) v += bf16_to_f32(ep.addend[o]);
+                        if (ep.relu_mask) {
+                            if (!bf16_positive(ep.relu_mask[o])) v = 0.f;
+                        }
+                        if (ep.out_bf16) ep.out_bf16[o] = f32_to_bf16(v);
+                        if (ep.out_f32) ep.out_f32[o] = v;
                     }
                 }
             }
+    };
+
+    int vt = blockIdx.x;
+    if (KT == 0) {
+        // a parity class no filter tap reaches: the "gradient" is the addend (or zero), masked and reduced like any other tile.
+        // Kept apart so that the main walk below issues and consumes its prefetch unconditionally.
 #pragma unroll
-            for (int i = 0; i < kBM / RPP; ++i) {
-                const int rl = r0 + i * RPP;
-                const int m = m0 + rl;
-                if (m < M) {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8 + 4);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const size_t o = (size_t)out_row(m, lat, rows_y, rows_x, full_h, full_w) * ep.ldo + n;
-                    if (ep.addend) {
-                        const u16x8 a = load8(ep.addend + o);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(a[q]);
-                    }
-                    float zc[8];  // z - mean
-                    if (ep.bn_z) {
-                        const u16x8 z = load8(ep.bn_z + o);
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(z[q]) - mu[q];
-                        if (ep.mask_from_z) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const unsigned short y = f32_to_bf16(fmaf(zc[q], sc[q], be[q]));  // == lp_bn_apply's output
-                                if ((y & 0x7fff) == 0 || (y & 0x8000)) v[q] = 0.f;
-                            }
-                        }
-                    }
-                    if (ep.relu_mask) {
-                        const u16x8 y = load8(ep.relu_mask + o);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if ((y[q] & 0x7fff) == 0 || (y[q] & 0x8000)) v[q] = 0.f;
-                    }
-                    u16x8 w;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) w[q] = f32_to_bf16(v[q]);
-                    *reinterpret_cast<u16x8*>(ep.out_bf16 + o) = w;
-                    if (want_stats) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const float vr = bf16_to_f32(w[q]);
-                            s0[q] += vr;
-                            s1[q] = fmaf(vr, ep.bn_z ? zc[q] * is[q] : vr, s1[q]);
-                        }
-                    }
-                }
-            }
-        }
-        if (want_stats) {
-            // column sums of this tile: [2][RPP][BN] partials through LDS, then one thread per (component, column)
-            __syncthreads();  // every lane is done reading the fp32 tile
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                so[(0 * RPP + r0) * BN + cc * 8 + q] = s0[q];
-                so[(1 * RPP + r0) * BN + cc * 8 + q] = s1[q];
-            }
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        for (; vt < ntiles; vt += gridDim.x) {
+            const int tile = xcd_remap(vt, ntiles);
+            const int tm_ = tile / tiles_n;
+            epilogue(tm_ * kBM, (tile - tm_ * tiles_n) * BN);
             __syncthreads();
-            if (tid < 2 * BN) {
-                const int comp = tid / BN, cl = tid % BN;
-                float t = 0.f;
-#pragma unroll
-                for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
-                if (n0 + cl < N) ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
-            }
         }
         return;
     }
+    setup(vt);
+    load_step(0);
+    for (;;) {
+        const int m0 = m0n, n0 = n0n;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + wn * (NT * 32) + nt * 32 + col;
-            if (n >= ep.n_store) continue;
-            const float bias = ep.bias ? ep.bias[n] : 0.f;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
-                if (m < M) {
-                    float v = acc[mt][nt][e] + bias;
-                    const size_t o = (size_t)out_row(m, lat, rows_y, rows_x, full_h, full_w) * ep.ldo + n;
-                    if (ep.addend) v += bf16_to_f32(ep.addend[o]);
-                    if (ep.relu_mask) {
-                        const unsigned short y = ep.relu_mask[o];
-                        if ((y & 0x7fff) == 0 || (y & 0x8000)) v = 0.f;
-                    }
-                    if (ep.out_bf16) ep.out_bf16[o] = f32_to_bf16(v);
-                    if (ep.out_f32) ep.out_f32[o] = v;
-                }
-            }
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        store_step(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) load_step(kt + 1);  // global loads in flight under the MFMAs
+            mma_kstep<NT>(sA[cur], sB[cur], wm, wn, lane, acc);
+            if (kt + 1 < KT) store_step(cur ^ 1);
+            __syncthreads();
         }
+        vt += gridDim.x;
+        if (vt >= ntiles) {
+            epilogue(m0, n0);
+            break;
+        }
+        // next tile's row descriptors and first operands: in flight while this tile is stored
+        setup(vt);
+        load_step(0);
+        epilogue(m0, n0);
+        __syncthreads();  // the epilogue's LDS tile is dead before the next tile's operands land in it
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -657,6 +700,27 @@ static void launch_tile_stats_reduce(const float* partial, int rows, int C, floa
 
 static size_t bn_workspace_rows(long long m_out) { return (size_t)((m_out + kBM - 1) / kBM + 4); }
 
+// Persistent launch of conv_igemm_kernel: at most 2 workgroups per CU (the LDS limit) x 256 CUs, a multiple of 8 so the
+// stride walk keeps every workgroup on its XCD's tile range.  LP_CONV_MAX_WGS overrides the cap (tests use it to force several
+// tiles per workgroup on small problems).
+static int igemm_max_wgs() {
+    static int v = [] {
+        const char* e = getenv("LP_CONV_MAX_WGS");
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? n : 512;
+    }();
+    return v;
+}
+
+template <int BN, int MODE>
+static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
+                         hipStream_t st) {
+    const int tm = (M + kBM - 1) / kBM, tn = (N + BN - 1) / BN, ntiles = tm * tn;
+    const int grid = ntiles < igemm_max_wgs() ? ntiles : igemm_max_wgs();
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, MODE>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)w, g,
+                       lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
+}
+
 struct WgradPlan {
     int tj, tn, split, per;
     bool wide;
@@ -709,14 +773,8 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (N > 64) {
-        const int tn = (N + 127) / 128;
-        hipLaunchKernelGGL((conv_igemm_kernel<128, kModeFwd>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)w, g, lat, M, N, K, tn, ep);
-    } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<64, kModeFwd>), dim3(tm), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)w, g, lat, M, N, K, 1, ep);
-    }
+    if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     if (bn) launch_tile_stats_reduce(ep.stats, tm, N, bn->sums, nullptr, nullptr, st);
     return launch_status();
 }
@@ -774,14 +832,8 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         const int tm = (M + kBM - 1) / kBM;
         ep.stats_row0 = stats_rows;
         stats_rows += tm;
-        if (N > 64) {
-            const int tn = (N + 127) / 128;
-            hipLaunchKernelGGL((conv_igemm_kernel<128, kModeDgrad>), dim3(tm * tn), dim3(256), 0, st, (const unsigned short*)dy,
-                               (const unsigned short*)wd, g, lat, M, N, K, tn, ep);
-        } else {
-            hipLaunchKernelGGL((conv_igemm_kernel<64, kModeDgrad>), dim3(tm), dim3(256), 0, st, (const unsigned short*)dy,
-                               (const unsigned short*)wd, g, lat, M, N, K, 1, ep);
-        }
+        if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
     };
     if (g.stride == 1) {
         launch(Lattice{0, 1, g.Hi, 0, 1, g.Wi, 0, 1, g.R, 0, 1, g.S});
@@ -864,8 +916,7 @@ static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom
         ep.stats = (float*)bn->workspace;
     }
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    hipLaunchKernelGGL((conv_igemm_kernel<64, kModeStem>), dim3(tm), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x4, (const unsigned short*)w, g, lat, M, 64, 256, 1, ep);
+    launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
     if (bn) launch_tile_stats_reduce(ep.stats, tm, 64, bn->sums, nullptr, nullptr, (hipStream_t)stream);
     return launch_status();
 }

@@ -19,12 +19,35 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, two values per instruction); the arithmetic form is the same rounding and
+// is what the host-side logic build (tests/hipemu) compiles
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+#else
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     unsigned u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+#endif
+
+// 8 floats -> 8 bf16 (16 B)
+__device__ __forceinline__ u16x8 pack_bf16x8(const float (&f)[8]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const u32x4_t p = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+    return __builtin_bit_cast(u16x8, p);
+}
+
+// ReLU gate from a stored bf16 activation: positive (and not -0 / +0)  <=>  its bits read as int16 are > 0
+__device__ __forceinline__ bool bf16_positive(unsigned short y) { return (short)y > 0; }
 
 // ---- wave / block reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -163,3 +163,19 @@ def test_conv_fused_batchnorm_reductions(case):
         np.testing.assert_allclose(sums[1], want_dgamma, rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(dbeta, sums[0], rtol=0, atol=0)
         np.testing.assert_allclose(dgamma, sums[1], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("cap", ["1", "3"])
+def test_conv_persistent_tile_walk(cap, kernel_backend):
+    """The MFMA convolution kernel is persistent (one workgroup walks several tiles, prefetching the next tile's operands under
+    the current tile's store pass).  The workgroup cap is read once per process, so the multi-tile walk is exercised by
+    re-running this file's kernel tests in a child process with a tiny cap."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, LP_CONV_MAX_WGS=cap)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_emu_conv.py", "-q", "-x", "-m", "gpu" if kernel_backend == "gpu" else "not gpu", "-k",
+                        "fwd_dgrad_wgrad or fused_batchnorm or transpose", "-p", "no:cacheprovider"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
