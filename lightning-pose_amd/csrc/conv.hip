@@ -312,65 +312,93 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             const int cc = tid % CPR, r0 = tid / CPR;
             const int n = n0 + cc * 8;
             const bool want_stats = ep.stats != nullptr;
-            float s0[8], s1[8], mu[8], is[8], sc[8], be[8];
+            // only the data-gradient has tensors to read back in its store pass (addend, pre-normalisation tensor, activation)
+            constexpr bool kReads = (MODE == kModeDgrad);
+            float s0[8], s1[8], mu[8], sc[8], be[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = is[q] = sc[q] = be[q] = 0.f;
+            for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = sc[q] = be[q] = 0.f;
             if (n < ep.n_store) {
-                if (ep.bn_z) {
+                if (kReads && ep.bn_z) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         mu[q] = ep.bn_mean[n + q];
-                        is[q] = ep.bn_invstd[n + q];
                         if (ep.mask_from_z) {
-                            sc[q] = is[q] * ep.bn_gamma[n + q];
+                            sc[q] = ep.bn_invstd[n + q] * ep.bn_gamma[n + q];
                             be[q] = ep.bn_beta[n + q];
                         }
                     }
                 }
+                // The global reads of the store pass are issued in batches of 4 row passes (16 B per lane each), so a tile keeps
+                // up to 48 KB of epilogue traffic in flight; one pass at a time left the gradient kernels of the 1x1 layers
+                // latency-bound at ~3 TB/s.
+                constexpr int NP = kBM / RPP, HB = NP < 4 ? NP : 4;
 #pragma unroll
-                for (int i = 0; i < kBM / RPP; ++i) {
-                    const int rl = r0 + i * RPP;
-                    const int m = m0 + rl;
-                    if (m < M) {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8 + 4);
-                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        const size_t o = (size_t)out_row(m, lat, div_img, div_row, full_h, full_w) * ep.ldo + n;
-                        if (ep.addend) {
-                            const u16x8 a = load8(ep.addend + o);
+                for (int i0 = 0; i0 < NP; i0 += HB) {
+                    unsigned off[HB];
+                    bool rv[HB];
+                    u16x8 la[HB], lz[HB], lm[HB];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(a[q]);
-                        }
-                        float zc[8];  // z - mean
-                        if (ep.bn_z) {
-                            const u16x8 z = load8(ep.bn_z + o);
+                    for (int i = 0; i < HB; ++i) {
+                        const int m = m0 + r0 + (i0 + i) * RPP;
+                        rv[i] = m < M;
+                        off[i] = (unsigned)out_row(rv[i] ? m : 0, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)n;
+                    }
+                    if (kReads && ep.addend) {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(z[q]) - mu[q];
-                            if (ep.mask_from_z) {
-                                // lp_bn_apply stored bf16(max(o, 0)) with this same o; that is > 0 exactly when o exceeds half
-                                // the smallest bf16 subnormal (round-to-nearest-even)
+                        for (int i = 0; i < HB; ++i) la[i] = load8(ep.addend + off[i]);
+                    }
+                    if (kReads && ep.bn_z) {
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) lz[i] = load8(ep.bn_z + off[i]);
+                    }
+                    if (kReads && ep.relu_mask) {
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) lm[i] = load8(ep.relu_mask + off[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        const int rl = r0 + (i0 + i) * RPP;
+                        if (rv[i]) {
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8);
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8 + 4);
+                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            if (kReads && ep.addend) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(la[i][q]);
+                            }
+                            float zc[8];  // z - mean
+                            if (kReads && ep.bn_z) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(lz[i][q]) - mu[q];
+                                if (ep.mask_from_z) {
+                                    // lp_bn_apply stored bf16(max(o, 0)) with this same o; that is > 0 exactly when o exceeds
+                                    // half the smallest bf16 subnormal (round-to-nearest-even)
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q)
+                                        if (!(fmaf(zc[q], sc[q], be[q]) > 0x1p-134f)) v[q] = 0.f;
+                                }
+                            }
+                            if (kReads && ep.relu_mask) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q)
-                                    if (!(fmaf(zc[q], sc[q], be[q]) > 0x1p-134f)) v[q] = 0.f;
+                                    if (!bf16_positive(lm[i][q])) v[q] = 0.f;
                             }
-                        }
-                        if (ep.relu_mask) {
-                            const u16x8 y = load8(ep.relu_mask + o);
+                            const u16x8 w = pack_bf16x8(v);
+                            *reinterpret_cast<u16x8*>(ep.out_bf16 + off[i]) = w;
+                            if (want_stats) {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q)
-                                if (!bf16_positive(y[q])) v[q] = 0.f;
-                        }
-                        const u16x8 w = pack_bf16x8(v);
-                        *reinterpret_cast<u16x8*>(ep.out_bf16 + o) = w;
-                        if (want_stats) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const float vr = bf16_to_f32(w[q]);
-                                s0[q] += vr;
-                                s1[q] = fmaf(vr, ep.bn_z ? zc[q] * is[q] : vr, s1[q]);
+                                for (int q = 0; q < 8; ++q) {
+                                    const float vr = bf16_to_f32(w[q]);
+                                    s0[q] += vr;
+                                    s1[q] = fmaf(vr, (kReads && ep.bn_z) ? zc[q] : vr, s1[q]);  // backward: x invstd below
+                                }
                             }
                         }
                     }
+                }
+                if (kReads && ep.bn_z && want_stats) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s1[q] *= ep.bn_invstd[n + q];
                 }
             }
             if (want_stats) {
@@ -761,7 +789,9 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
-    if (g.Ci % kBK != 0 || g.R * g.S > 32 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    if (g.Ci % kBK != 0 || g.R * g.S > 32 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31) ||
+        (long long)g.B * g.Ho * g.Wo * ldo >= (1LL << 32))
+        return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
     ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -805,7 +835,8 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
-    if (g.Co % kBK != 0 || (g.stride != 1 && g.stride != 2) || g.R * g.S > 32 || (long long)g.B * g.Ho * g.Wo * g.Co >= (1LL << 31))
+    if (g.Co % kBK != 0 || (g.stride != 1 && g.stride != 2) || g.R * g.S > 32 || (long long)g.B * g.Ho * g.Wo * g.Co >= (1LL << 31) ||
+        (long long)g.B * g.Hi * g.Wi * ldo >= (1LL << 32))
         return LP_ERR_UNSUPPORTED;
     const int N = g.Ci;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
