@@ -122,61 +122,105 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
 }
 
 // y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
+// The grid stride is a multiple of the row length (host guarantees it), so a lane keeps ONE channel chunk for its whole walk:
+// its 8 (mean, scale, shift) triples live in registers and the loop is nothing but 16-B streams, 4 chunks in flight per lane.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_chunks, int C, unsigned short* __restrict__ Y) {
     const int chunks = C >> 3;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
-        const int c = (int)(q % chunks) * 8;
-        float x[8], o[8];
-        unpack8(*reinterpret_cast<const u16x8*>(X + q * 8), x);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(q % chunks) * 8;
+    float mu[8], sc[8], be[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float sc = invstd[c + i] * gamma[c + i];
-            o[i] = fmaf(x[i] - mean[c + i], sc, beta[c + i]);
-        }
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = mean[c + i];
+        sc[i] = invstd[c + i] * gamma[c + i];
+        be[i] = beta[c + i];
+    }
+    constexpr int U = 4;
+    for (; q < n_chunks; q += U * stride) {
+        u16x8 xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q + u * stride < n_chunks) xv[u] = *reinterpret_cast<const u16x8*>(X + (q + u * stride) * 8);
         if (residual != nullptr) {
-            float r[8];
-            unpack8(*reinterpret_cast<const u16x8*>(residual + q * 8), r);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] += r[i];
+            for (int u = 0; u < U; ++u)
+                if (q + u * stride < n_chunks) rv[u] = *reinterpret_cast<const u16x8*>(residual + (q + u * stride) * 8);
         }
-        if (relu) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
+        for (int u = 0; u < U; ++u) {
+            if (q + u * stride >= n_chunks) break;
+            float x[8], o[8];
+            unpack8(xv[u], x);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf(x[i] - mu[i], sc[i], be[i]);
+            if (residual != nullptr) {
+                float r[8];
+                unpack8(rv[u], r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += r[i];
+            }
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
+            }
+            *reinterpret_cast<u16x8*>(Y + (q + u * stride) * 8) = pack8(o);
         }
-        *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(o);
     }
 }
 
 // dx = gamma * invstd * (dz - sum(dz)/N - xhat * sum(dz*xhat)/N);  dz = relu-masked dy; optionally dz is also
-// written out (gradient of the residual branch)
+// written out (gradient of the residual branch).  Same walk as bn_apply_kernel: per-channel terms in registers.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
                                                            const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float inv_count, size_t n_chunks, int C,
                                                            unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES) {
     const int chunks = C >> 3;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
-        const int c = (int)(q % chunks) * 8;
-        float dz[8], x[8], o[8];
-        unpack8(*reinterpret_cast<const u16x8*>(DY + q * 8), dz);
-        unpack8(*reinterpret_cast<const u16x8*>(X + q * 8), x);
-        if (Yout != nullptr) {
-            const u16x8 yo = *reinterpret_cast<const u16x8*>(Yout + q * 8);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(q % chunks) * 8;
+    float mu[8], is[8], ga[8], k0[8], k1[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (!bf16_positive(yo[i])) dz[i] = 0.f;
-        }
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = mean[c + i];
+        is[i] = invstd[c + i];
+        ga[i] = gamma[c + i] * is[i];
+        k0[i] = sums[c + i] * inv_count;
+        k1[i] = sums[C + c + i] * inv_count;
+    }
+    constexpr int U = 2;
+    for (; q < n_chunks; q += U * stride) {
+        u16x8 dv[U], xv[U], yv[U];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float is = invstd[c + i];
-            const float xh = (x[i] - mean[c + i]) * is;
-            o[i] = gamma[c + i] * is * (dz[i] - sums[c + i] * inv_count - xh * sums[C + c + i] * inv_count);
+        for (int u = 0; u < U; ++u)
+            if (q + u * stride < n_chunks) {
+                dv[u] = *reinterpret_cast<const u16x8*>(DY + (q + u * stride) * 8);
+                xv[u] = *reinterpret_cast<const u16x8*>(X + (q + u * stride) * 8);
+                if (Yout != nullptr) yv[u] = *reinterpret_cast<const u16x8*>(Yout + (q + u * stride) * 8);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q + u * stride >= n_chunks) break;
+            float dz[8], x[8], o[8];
+            unpack8(dv[u], dz);
+            unpack8(xv[u], x);
+            if (Yout != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (!bf16_positive(yv[u][i])) dz[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (x[i] - mu[i]) * is[i];
+                o[i] = ga[i] * (dz[i] - k0[i] - xh * k1[i]);
+            }
+            *reinterpret_cast<u16x8*>(DX + (q + u * stride) * 8) = pack8(o);
+            if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + (q + u * stride) * 8) = pack8(dz);
         }
-        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(o);
-        if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + q * 8) = pack8(dz);
     }
 }
 
@@ -306,6 +350,25 @@ static int colreduce_blocks(int M, int C) {
     return blocks < 1 ? 1 : (int)blocks;
 }
 
+// grid for the BatchNorm elementwise walks: the stride (grid * 256 lanes) must be a multiple of the row length in chunks so a
+// lane stays on one channel chunk; rows of C/8 chunks with C/8 a divisor of 256 (every ResNet width) need no adjustment
+static int bn_grid(size_t n_chunks, int chunks) {
+    size_t blocks = (n_chunks + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    if (256 % chunks != 0) {  // make grid * 256 a multiple of `chunks`: round the grid up to a multiple of chunks / gcd(chunks, 256)
+        int a = chunks, b = 256;
+        while (b) {
+            const int t = a % b;
+            a = b;
+            b = t;
+        }
+        const size_t m = (size_t)(chunks / a);
+        blocks = (blocks + m - 1) / m * m;
+    }
+    return (int)blocks;
+}
+
 static int grid_for(size_t work_items) {
     size_t blocks = (work_items + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
@@ -340,7 +403,7 @@ extern "C" int lp_bn_apply(const void* x, const float* mean, const float* invstd
     LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
                        gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y);
     return launch_status();
 }
@@ -363,7 +426,7 @@ extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x,
     LP_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && M > 0 && C > 0 && count > 0.f);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
                        (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count, n_chunks, C,
                        (unsigned short*)dx, (unsigned short*)dres);
     return launch_status();

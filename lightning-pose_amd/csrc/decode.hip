@@ -13,12 +13,13 @@
 // Algorithm.  Both resampling steps are linear and separable, so the upsampled map is Y = Uy * Hm * Ux^T
 // with banded composite matrices U (<= 11 non-zeros per row, built in fp64 on the host and passed as
 // tap tables).  One workgroup owns one (frame, keypoint) heatmap: the h x w tile is staged once in LDS
-// (the only HBM read: h*w*4 algorithmic bytes), Z = Hm * Ux^T is produced per strip of 256 output columns
-// in LDS, and each lane walks DOWN one output column keeping a sliding window of Z in registers, so Y is
-// never stored anywhere.  The softmax(T*Y) expectation is accumulated online (running max / sum / sum*x /
-// sum*y per lane, merged with wave shuffles).  The 25-tap confidence window is recomputed from the LDS
-// tile once the global max and sum are known.  Backward recomputes Y the same way, forms
-// G = T*p*(gx*(x-ex) + gy*(y-ey)) on the fly and applies the transposed operators in place in LDS.
+// (the only HBM read: h*w*4 algorithmic bytes) and each lane walks DOWN one output column keeping a sliding
+// window of Z = Hm * Ux^T in registers; a new window row costs TX LDS reads + FMAs and is produced by the lane
+// itself, so neither Z nor Y is stored anywhere and the LDS footprint is just the tile (4 workgroups per CU).
+// The softmax(T*Y) expectation is accumulated online (running max / sum / sum*x / sum*y per lane, merged with
+// wave shuffles).  The 25-tap confidence window is recomputed from the LDS tile once the global max and sum are
+// known.  Backward recomputes Y the same way (8 waves = 8 row segments of a 64-column strip), forms
+// G = T*p*(gx*(x-ex) + gy*(y-ey)) on the fly, scatters Uy^T G into a [h][64] LDS strip and applies Ux^T from there.
 //
 // This kernel is fp32-VALU bound by construction (about 350 FLOP per algorithmic byte): see DESIGN.md.
 #include "lp_common.h"
@@ -26,7 +27,6 @@
 namespace lp {
 
 constexpr int kTXM = 12;        // padded column-tap count
-constexpr int kStripCols = 256; // output columns per strip = 4 waves x 64 lanes
 
 struct DecodeTables {
     const int* row_base;     // [h]            first input row of group j's window
@@ -59,25 +59,15 @@ __device__ __forceinline__ void merge_softmax(float& m, float& s, float& sx, flo
     m = mm;
 }
 
-// Z strip: zs[r][cl] = sum_t Hm[r][xs+t] * tap[t]   for the strip's columns (one column per thread).
-__device__ __forceinline__ void build_z_strip(const float* hs, float* zs, int h, int w, int W, int c0, int strip_cols,
-                                              const DecodeTables& tb) {
-    const int cl = threadIdx.x;
-    const int c = c0 + cl;
-    if (cl < strip_cols && c < W) {
-        float tx[kTXM];
-        const int xs = tb.col_start[c];
+// One element of Z = Hm * Ux^T for this lane's output column: `hcol` = tile + first input column of the lane's taps.
+template <bool FULLTX>
+__device__ __forceinline__ float z_value(const float* hcol, int r, int w, const float (&tx)[kTXM], int TX) {
+    const float* row = hcol + r * w;
+    float a = 0.f;
 #pragma unroll
-        for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
-        for (int r = 0; r < h; ++r) {
-            const float* row = hs + r * w + xs;
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t < kTXM; ++t)
-                if (t < tb.TX) acc = fmaf(row[t], tx[t], acc);
-            zs[r * strip_cols + cl] = acc;
-        }
-    }
+    for (int t = 0; t < kTXM; ++t)
+        if (FULLTX || t < TX) a = fmaf(row[t], tx[t], a);
+    return a;
 }
 
 // One upsampled value from the LDS tile (used for the confidence window).
@@ -148,86 +138,72 @@ __device__ __forceinline__ void frame_grad_to_aug(float gxf, float gyf, int b, i
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int R, int TY>
-__global__ __launch_bounds__(256) void decode_fwd_kernel(const float* __restrict__ heat, int K, int h, int w, float temperature,
-                                                         float offset, DecodeTables tb, FrameMap fm, int strip_cols,
+template <int R, int TY, bool FULLTX>
+__global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict__ heat, int K, int h, int w, float temperature,
+                                                         float offset, DecodeTables tb, FrameMap fm,
                                                          float* __restrict__ kp_aug, float* __restrict__ kp_frame,
                                                          float* __restrict__ conf, float* __restrict__ stats) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* hs = smem;                 // [h][w]
-    float* zs = smem + h * w;         // [h][strip_cols]
-    __shared__ float red[4 * 4 + 8];
+    __shared__ float red[8 * 4];
 
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
     const int H = h * R, W = w * R;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
 
     const float* src = heat + (size_t)bk * h * w;
-    for (int i = tid; i < h * w; i += 256) hs[i] = src[i];
+    for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
     __syncthreads();
 
     float m = -INFINITY, s = 0.f, sx = 0.f, sy = 0.f;
-    for (int c0 = 0; c0 < W; c0 += strip_cols) {
-        build_z_strip(hs, zs, h, w, W, c0, strip_cols, tb);
-        __syncthreads();
-        const int cl = wave * 64 + lane;
-        const int c = c0 + cl;
-        // Every lane runs the column walk (lanes past the map re-read column 0 and are discarded afterwards): with no
-        // divergent branch around it the tap table is fetched with wave-uniform SCALAR loads instead of per-lane vector loads.
-        const bool valid = cl < strip_cols && c < W;
-        const int clc = valid ? cl : 0;
-        const float m_in = m, s_in = s, sx_in = sx, sy_in = sy;
-        {
-            const float xc = (float)c;
-            float win[TY];
-            int base = tb.row_base[0];
+    for (int c = tid; c < W; c += nthreads) {  // one trip when the block covers the row (the host sizes it so)
+        float tx[kTXM];
 #pragma unroll
-            for (int t = 0; t < TY; ++t) win[t] = zs[(base + t) * strip_cols + clc];
-            for (int j = 0; j < h; ++j) {
-                const int nb = tb.row_base[j];
-                if (nb != base) {  // windows advance by exactly one input row (host asserts it)
+        for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
+        const float* hcol = hs + tb.col_start[c];
+        const float xc = (float)c;
+        float win[TY];
+        int base = tb.row_base[0];
 #pragma unroll
-                    for (int t = 0; t < TY - 1; ++t) win[t] = win[t + 1];
-                    win[TY - 1] = zs[(nb + TY - 1) * strip_cols + clc];
-                    base = nb;
-                }
-                const float* taps = tb.row_taps + (size_t)j * R * TY;
-                float z[R];
-                float gm = m;
+        for (int t = 0; t < TY; ++t) win[t] = z_value<FULLTX>(hcol, base + t, w, tx, tb.TX);
+        for (int j = 0; j < h; ++j) {
+            const int nb = tb.row_base[j];
+            if (nb != base) {  // windows advance by exactly one input row (host asserts it)
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) {
-                    float y = 0.f;
+                for (int t = 0; t < TY - 1; ++t) win[t] = win[t + 1];
+                win[TY - 1] = z_value<FULLTX>(hcol, nb + TY - 1, w, tx, tb.TX);
+                base = nb;
+            }
+            const float* taps = tb.row_taps + (size_t)j * R * TY;
+            float z[R];
+            float gm = m;
 #pragma unroll
-                    for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], win[t], y);
-                    z[rr] = y * temperature;
-                    gm = fmaxf(gm, z[rr]);
-                }
-                const float sc = (m == -INFINITY) ? 0.f : __expf(m - gm);
-                s *= sc;
-                sx *= sc;
-                sy *= sc;
-                m = gm;
+            for (int rr = 0; rr < R; ++rr) {
+                float y = 0.f;
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) {
-                    const float e = __expf(z[rr] - gm);
-                    s += e;
-                    sx = fmaf(e, xc, sx);
-                    sy = fmaf(e, (float)(j * R + rr), sy);
-                }
+                for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], win[t], y);
+                z[rr] = y * temperature;
+                gm = fmaxf(gm, z[rr]);
+            }
+            const float sc = (m == -INFINITY) ? 0.f : __expf(m - gm);
+            s *= sc;
+            sx *= sc;
+            sy *= sc;
+            m = gm;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const float e = __expf(z[rr] - gm);
+                s += e;
+                sx = fmaf(e, xc, sx);
+                sy = fmaf(e, (float)(j * R + rr), sy);
             }
         }
-        if (!valid) {
-            m = m_in;
-            s = s_in;
-            sx = sx_in;
-            sy = sy_in;
-        }
-        __syncthreads();  // zs is rebuilt by the next strip
     }
 
-    // merge the per-lane online-softmax states: wave shuffles, then across the 4 waves through LDS
+    // merge the per-lane online-softmax states: wave shuffles, then across the waves through LDS
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const float m2 = __shfl_xor(m, d, 64), s2 = __shfl_xor(s, d, 64);
@@ -245,8 +221,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const float* __restrict
     s = red[1];
     sx = red[2];
     sy = red[3];
-#pragma unroll
-    for (int i = 1; i < 4; ++i) merge_softmax(m, s, sx, sy, red[i * 4 + 0], red[i * 4 + 1], red[i * 4 + 2], red[i * 4 + 3]);
+    for (int i = 1; i < nwaves; ++i) merge_softmax(m, s, sx, sy, red[i * 4 + 0], red[i * 4 + 1], red[i * 4 + 2], red[i * 4 + 3]);
     const float ex = sx / s, ey = sy / s;
 
     // confidence: softmax mass in the 5x5 window at trunc(ex, ey), zero outside the map
@@ -281,24 +256,31 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // backward: d(loss)/d(heat) from d(loss)/d(kp_aug) (+ d(loss)/d(kp_frame) chained through the frame map)
 // ------------------------------------------------------------------------------------------------
-template <int R, int TY, int NE>
-__global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict__ heat, int K, int h, int w, float temperature,
-                                                         DecodeTables tb, FrameMap fm, int strip_cols,
-                                                         const float* __restrict__ stats, const float* __restrict__ g_aug,
-                                                         const float* __restrict__ g_frame, float* __restrict__ g_heat,
-                                                         int accumulate) {
+constexpr int kBwdStrip = 64;  // output columns per strip = one wave of lanes; the block's waves split the rows
+
+// (second launch bound = waves per SIMD: two 8-wave workgroups per CU for the usual map sizes, LDS allows it)
+template <int R, int TY, int NE, bool FULLTX>
+__global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(const float* __restrict__ heat, int K, int h, int w, float temperature,
+                                                         DecodeTables tb, FrameMap fm, const float* __restrict__ stats,
+                                                         const float* __restrict__ g_aug, const float* __restrict__ g_frame,
+                                                         float* __restrict__ g_heat, int accumulate) {
     HIP_DYNAMIC_SHARED(float, smem)
-    float* hs = smem;
-    float* zs = smem + h * w;  // Z strip, overwritten in place by the W = Uy^T G strip
+    float* hs = smem;          // [h][w]
+    float* zs = smem + h * w;  // [h][64]: the strip of Uy^T G, summed over the row segments with LDS float adds (every
+                               // element has at most two contributing segments, so the sum does not depend on their order)
+    constexpr int SC = kBwdStrip;
 
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
     const int W = w * R;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int seg = (h + nwaves - 1) / nwaves;  // row groups per wave (host keeps it >= TY)
+    const int j0 = wave * seg, j1 = min(h, j0 + seg);
 
     const float* src = heat + (size_t)bk * h * w;
-    for (int i = tid; i < h * w; i += 256) hs[i] = src[i];
+    for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
 
     float gx = 0.f, gy = 0.f;
     if (g_aug != nullptr) {
@@ -318,34 +300,35 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
     float dacc[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) dacc[i] = 0.f;
-    __syncthreads();
+    const float inv_w = 1.f / (float)w;
 
-    for (int c0 = 0; c0 < W; c0 += strip_cols) {
-        build_z_strip(hs, zs, h, w, W, c0, strip_cols, tb);
-        __syncthreads();
-        const int cl = wave * 64 + lane;
-        const int c = c0 + cl;
-        const bool valid = cl < strip_cols && c < W;  // see the forward kernel: the walk itself is branch-free
-        const int clc = valid ? cl : 0;
-        {
+    for (int c0 = 0; c0 < W; c0 += SC) {
+        for (int i = tid; i < h * SC; i += nthreads) zs[i] = 0.f;
+        __syncthreads();  // (first trip: also the tile load)
+        const int c = c0 + lane;
+        if (c < W && j0 < j1) {
+            float tx[kTXM];
+#pragma unroll
+            for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
+            const float* hcol = hs + tb.col_start[c];
             const float dxc = gxt * ((float)c - ex);
             float win[TY], acc[TY];
-            int base = tb.row_base[0];
+            int base = tb.row_base[j0];
 #pragma unroll
             for (int t = 0; t < TY; ++t) {
-                win[t] = zs[(base + t) * strip_cols + clc];
+                win[t] = z_value<FULLTX>(hcol, base + t, w, tx, tb.TX);
                 acc[t] = 0.f;
             }
-            for (int j = 0; j < h; ++j) {
+            for (int j = j0; j < j1; ++j) {
                 const int nb = tb.row_base[j];
                 if (nb != base) {
-                    if (valid) zs[base * strip_cols + cl] = acc[0];  // input row `base` is complete and no longer read
+                    atomicAdd(&zs[base * SC + lane], acc[0]);  // this segment is done with input row `base`
 #pragma unroll
                     for (int t = 0; t < TY - 1; ++t) {
                         win[t] = win[t + 1];
                         acc[t] = acc[t + 1];
                     }
-                    win[TY - 1] = zs[(nb + TY - 1) * strip_cols + clc];
+                    win[TY - 1] = z_value<FULLTX>(hcol, nb + TY - 1, w, tx, tb.TX);
                     acc[TY - 1] = 0.f;
                     base = nb;
                 }
@@ -361,29 +344,25 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
                     for (int t = 0; t < TY; ++t) acc[t] = fmaf(taps[rr * TY + t], g, acc[t]);
                 }
             }
-            if (valid) {
 #pragma unroll
-                for (int t = 0; t < TY; ++t) zs[(base + t) * strip_cols + cl] = acc[t];
-            }
-        }
-        if (!valid && cl < strip_cols) {
-            for (int r = 0; r < h; ++r) zs[r * strip_cols + cl] = 0.f;  // columns past W contribute nothing
+            for (int t = 0; t < TY; ++t) atomicAdd(&zs[(base + t) * SC + lane], acc[t]);
         }
         __syncthreads();
-        // dH[r][q] += sum_c Wst[r][c] * Ux[c][q]  over this strip's columns
+        // dH[r][q] += sum_c Wst[r][c] * Ux[c][q]  over this strip's columns (columns past W hold zeros)
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * 256;
+            int e = tid + i * nthreads;
+            LP_OPAQUE(e);  // (r, q, cs, tt) are recomputed per strip instead of living in 5 registers per element
             if (e < h * w) {
-                const int r = e / w, q = e - r * w;
+                const int r = (int)(((float)e + 0.5f) * inv_w), q = e - r * w;  // exact for e < 2^22
                 const int cs = tb.colT_start[q];
                 const float* tt = tb.colT_taps + (size_t)q * tb.TC;
                 int t0 = c0 - cs;
                 if (t0 < 0) t0 = 0;
-                int t1 = c0 + strip_cols - cs;
+                int t1 = c0 + SC - cs;
                 if (t1 > tb.TC) t1 = tb.TC;
                 float a = dacc[i];
-                for (int t = t0; t < t1; ++t) a = fmaf(zs[r * strip_cols + (cs + t - c0)], tt[t], a);
+                for (int t = t0; t < t1; ++t) a = fmaf(zs[r * SC + (cs + t - c0)], tt[t], a);
                 dacc[i] = a;
             }
         }
@@ -392,7 +371,7 @@ __global__ __launch_bounds__(256) void decode_bwd_kernel(const float* __restrict
     float* dst = g_heat + (size_t)bk * h * w;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * nthreads;
         if (e < h * w) dst[e] = accumulate ? dst[e] + dacc[i] : dacc[i];
     }
 }
@@ -413,18 +392,17 @@ __global__ __launch_bounds__(256) void frame_map_kernel(const float* __restrict_
 
 static size_t decode_smem_bytes(int h, int w, int strip_cols) { return (size_t)(h * w + h * strip_cols) * sizeof(float); }
 
-// Largest strip (256/128/64 output columns) whose Z buffer fits next to the heatmap tile in LDS, trimmed to the map.
-static int pick_strip(int h, int w, int W) {
-    int sc = 0;
-    for (int cand = kStripCols; cand >= 64; cand >>= 1) {
-        if (decode_smem_bytes(h, w, cand) <= 150 * 1024) {
-            sc = cand;
-            break;
-        }
-    }
-    if (sc == 0) return 0;
-    const int need = (W + 63) / 64 * 64;
-    return need < sc ? need : sc;
+// forward: one lane per output column, whole waves, at most 512 threads (wider maps take several trips)
+static int decode_fwd_threads(int W) {
+    const int t = (W + 63) / 64 * 64;
+    return t > 512 ? 512 : t;
+}
+
+// backward: as many waves (= row segments) as keep a segment at least one window tall, at most 8
+static int decode_bwd_threads(int h, int TY) {
+    int waves = h / TY;
+    waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
+    return waves * 64;
 }
 
 template <typename Kern>
@@ -455,24 +433,30 @@ extern "C" int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int 
     const int TY = lp_decode_window(downsample_factor, h);
     if (TY == 0 || t->ty != TY || t->tx > kTXM || t->tx > w) return LP_ERR_UNSUPPORTED;
     const int R = 1 << downsample_factor;
-    const int sc = pick_strip(h, w, w * R);
-    if (sc == 0) return LP_ERR_UNSUPPORTED;
     DecodeTables tb{t->row_base, t->row_taps, t->col_start, t->col_taps, t->colT_start, t->colT_taps, t->tx, t->tc};
     FrameMap fm{f->transforms, f->tf_mode, f->bbox, f->bbox_stride, f->kp_per_view, f->model_h, f->model_w};
     const float offset = downsample_factor == 1 ? 0.5f : downsample_factor == 2 ? 1.5f : 2.5f;
-    const size_t smem = decode_smem_bytes(h, w, sc);
+    const size_t smem = decode_smem_bytes(h, w, 0);
+    if (smem > 150 * 1024) return LP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B * K), block(256);
-#define LP_LAUNCH_FWD(RR, TT)                                                                                           \
-    allow_large_lds(decode_fwd_kernel<RR, TT>, smem);                                                                   \
-    hipLaunchKernelGGL((decode_fwd_kernel<RR, TT>), grid, block, smem, st, heat, K, h, w, temperature, offset, tb, fm, sc, \
+    dim3 grid(B * K), block(decode_fwd_threads(w * R));
+    const bool full = t->tx == kTXM;
+#define LP_LAUNCH_FWD2(RR, TT, FF)                                                                                      \
+    allow_large_lds(decode_fwd_kernel<RR, TT, FF>, smem);                                                               \
+    hipLaunchKernelGGL((decode_fwd_kernel<RR, TT, FF>), grid, block, smem, st, heat, K, h, w, temperature, offset, tb, fm, \
                        kp_aug, kp_frame, conf, stats)
+#define LP_LAUNCH_FWD(RR, TT)              \
+    do {                                   \
+        if (full) { LP_LAUNCH_FWD2(RR, TT, true); } \
+        else { LP_LAUNCH_FWD2(RR, TT, false); }     \
+    } while (0)
     if (R == 2 && TY == 8) { LP_LAUNCH_FWD(2, 8); }
     else if (R == 4 && TY == 8) { LP_LAUNCH_FWD(4, 8); }
     else if (R == 4 && TY == 9) { LP_LAUNCH_FWD(4, 9); }
     else if (R == 8 && TY == 11) { LP_LAUNCH_FWD(8, 11); }
     else return LP_ERR_UNSUPPORTED;
 #undef LP_LAUNCH_FWD
+#undef LP_LAUNCH_FWD2
     return launch_status();
 }
 
@@ -486,24 +470,31 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
     const int TY = lp_decode_window(downsample_factor, h);
     if (TY == 0 || t->ty != TY || t->tx > kTXM || t->tx > w || !t->colT_start || !t->colT_taps) return LP_ERR_UNSUPPORTED;
     const int R = 1 << downsample_factor;
-    const int sc = pick_strip(h, w, w * R);
-    if (sc == 0) return LP_ERR_UNSUPPORTED;
-    const int ne = (h * w + 255) / 256;
+    const int nthreads = decode_bwd_threads(h, TY);
+    const int ne = (h * w + nthreads - 1) / nthreads;
     if (ne > 64) return LP_ERR_UNSUPPORTED;
     DecodeTables tb{t->row_base, t->row_taps, t->col_start, t->col_taps, t->colT_start, t->colT_taps, t->tx, t->tc};
     FrameMap fm{f->transforms, f->tf_mode, f->bbox, f->bbox_stride, f->kp_per_view, f->model_h, f->model_w};
-    const size_t smem = decode_smem_bytes(h, w, sc);
+    const size_t smem = decode_smem_bytes(h, w, kBwdStrip);
+    if (smem > 150 * 1024) return LP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(B * K), block(256);
-#define LP_LAUNCH_BWD(RR, TT, NN)                                                                                       \
-    allow_large_lds(decode_bwd_kernel<RR, TT, NN>, smem);                                                               \
-    hipLaunchKernelGGL((decode_bwd_kernel<RR, TT, NN>), grid, block, smem, st, heat, K, h, w, temperature, tb, fm, sc, stats, \
+    dim3 grid(B * K), block(nthreads);
+    const bool full = t->tx == kTXM;
+#define LP_LAUNCH_BWD(RR, TT, NN, FF)                                                                                   \
+    allow_large_lds(decode_bwd_kernel<RR, TT, NN, FF>, smem);                                                           \
+    hipLaunchKernelGGL((decode_bwd_kernel<RR, TT, NN, FF>), grid, block, smem, st, heat, K, h, w, temperature, tb, fm, stats, \
                        g_aug, g_frame, g_heat, accumulate)
-#define LP_DISPATCH_NE(RR, TT)                   \
-    do {                                         \
-        if (ne <= 16) { LP_LAUNCH_BWD(RR, TT, 16); } \
-        else if (ne <= 36) { LP_LAUNCH_BWD(RR, TT, 36); } \
-        else { LP_LAUNCH_BWD(RR, TT, 64); }      \
+#define LP_DISPATCH_NE(RR, TT)                                   \
+    do {                                                         \
+        if (full) {                                              \
+            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, true); }     \
+            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, true); } \
+            else { LP_LAUNCH_BWD(RR, TT, 64, true); }            \
+        } else {                                                 \
+            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, false); }    \
+            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, false); } \
+            else { LP_LAUNCH_BWD(RR, TT, 64, false); }           \
+        }                                                        \
     } while (0)
     if (R == 2 && TY == 8) { LP_DISPATCH_NE(2, 8); }
     else if (R == 4 && TY == 8) { LP_DISPATCH_NE(4, 8); }

@@ -49,6 +49,14 @@ __device__ __forceinline__ u16x8 pack_bf16x8(const float (&f)[8]) {
 // ReLU gate from a stored bf16 activation: positive (and not -0 / +0)  <=>  its bits read as int16 are > 0
 __device__ __forceinline__ bool bf16_positive(unsigned short y) { return (short)y > 0; }
 
+// Hide a value's provenance from the optimiser (keeps it from hoisting per-element address arithmetic out of a loop into
+// dozens of long-lived registers)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LP_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define LP_OPAQUE(x) asm volatile("" : "+r"(x))
+#endif
+
 // ---- wave / block reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
