@@ -256,19 +256,27 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // backward: d(loss)/d(heat) from d(loss)/d(kp_aug) (+ d(loss)/d(kp_frame) chained through the frame map)
 // ------------------------------------------------------------------------------------------------
-constexpr int kBwdStrip = 64;  // output columns per strip = one wave of lanes; the block's waves split the rows
+constexpr int kBwdStrip = 64;          // output columns per strip = one wave of lanes; the block's waves split the rows
+constexpr int kBwdLd = kBwdStrip + 1;  // LDS row stride of the strip (odd: lanes that walk down a column hit distinct banks)
+
+__host__ __device__ inline int bwd_tap_ld(int TC) { return TC | 1; }  // odd row stride of the staged transposed tap table
 
 // (second launch bound = waves per SIMD: two 8-wave workgroups per CU for the usual map sizes, LDS allows it)
 template <int R, int TY, int NE, bool FULLTX>
-__global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(const float* __restrict__ heat, int K, int h, int w, float temperature,
-                                                         DecodeTables tb, FrameMap fm, const float* __restrict__ stats,
-                                                         const float* __restrict__ g_aug, const float* __restrict__ g_frame,
-                                                         float* __restrict__ g_heat, int accumulate) {
+__global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(const float* __restrict__ heat, int K, int h, int w,
+                                                                             float temperature, DecodeTables tb, FrameMap fm,
+                                                                             const float* __restrict__ stats,
+                                                                             const float* __restrict__ g_aug,
+                                                                             const float* __restrict__ g_frame,
+                                                                             float* __restrict__ g_heat, int accumulate) {
     HIP_DYNAMIC_SHARED(float, smem)
-    float* hs = smem;          // [h][w]
-    float* zs = smem + h * w;  // [h][64]: the strip of Uy^T G, summed over the row segments with LDS float adds (every
-                               // element has at most two contributing segments, so the sum does not depend on their order)
-    constexpr int SC = kBwdStrip;
+    constexpr int SC = kBwdStrip, LD = kBwdLd;
+    const int TCP = bwd_tap_ld(tb.TC);
+    float* hs = smem;            // [h][w]   heat-map tile; reused at the end to transpose the result for coalesced stores
+    float* zs = hs + h * w;      // [h][65]  strip of Uy^T G, summed over the row segments with LDS float adds (every element
+                                 //          has at most two contributing segments, so the sum does not depend on their order)
+    float* lt = zs + h * LD;     // [w][TCP] transposed column taps
+    int* lcs = reinterpret_cast<int*>(lt + w * TCP);  // [w] first output column touching input column q
 
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
@@ -281,6 +289,11 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
 
     const float* src = heat + (size_t)bk * h * w;
     for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
+    for (int i = tid; i < w * tb.TC; i += nthreads) {
+        const int q = i / tb.TC;
+        lt[q * TCP + (i - q * tb.TC)] = tb.colT_taps[i];
+    }
+    for (int i = tid; i < w; i += nthreads) lcs[i] = tb.colT_start[i];
 
     float gx = 0.f, gy = 0.f;
     if (g_aug != nullptr) {
@@ -297,14 +310,16 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
     const float ex = stats[bk * 4 + 2], ey = stats[bk * 4 + 3];
     const float gxt = gx * temperature, gyt = gy * temperature;
 
+    // this thread's elements of dH: e = tid + i * nthreads -> (q, r) = (e / h, e % h): consecutive lanes walk down one input
+    // column q, so the tap reads broadcast and the strip reads are conflict-free
     float dacc[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) dacc[i] = 0.f;
-    const float inv_w = 1.f / (float)w;
+    const float inv_h = 1.f / (float)h;
 
     for (int c0 = 0; c0 < W; c0 += SC) {
-        for (int i = tid; i < h * SC; i += nthreads) zs[i] = 0.f;
-        __syncthreads();  // (first trip: also the tile load)
+        for (int i = tid; i < h * LD; i += nthreads) zs[i] = 0.f;
+        __syncthreads();  // (first trip: also the tile / table staging)
         const int c = c0 + lane;
         if (c < W && j0 < j1) {
             float tx[kTXM];
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
             for (int j = j0; j < j1; ++j) {
                 const int nb = tb.row_base[j];
                 if (nb != base) {
-                    atomicAdd(&zs[base * SC + lane], acc[0]);  // this segment is done with input row `base`
+                    atomicAdd(&zs[base * LD + lane], acc[0]);  // this segment is done with input row `base`
 #pragma unroll
                     for (int t = 0; t < TY - 1; ++t) {
                         win[t] = win[t + 1];
@@ -345,35 +360,43 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 }
             }
 #pragma unroll
-            for (int t = 0; t < TY; ++t) atomicAdd(&zs[(base + t) * SC + lane], acc[t]);
+            for (int t = 0; t < TY; ++t) atomicAdd(&zs[(base + t) * LD + lane], acc[t]);
         }
         __syncthreads();
         // dH[r][q] += sum_c Wst[r][c] * Ux[c][q]  over this strip's columns (columns past W hold zeros)
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             int e = tid + i * nthreads;
-            LP_OPAQUE(e);  // (r, q, cs, tt) are recomputed per strip instead of living in 5 registers per element
+            LP_OPAQUE(e);  // (q, r, cs) are recomputed per strip instead of living in registers per element
             if (e < h * w) {
-                const int r = (int)(((float)e + 0.5f) * inv_w), q = e - r * w;  // exact for e < 2^22
-                const int cs = tb.colT_start[q];
-                const float* tt = tb.colT_taps + (size_t)q * tb.TC;
+                const int q = (int)(((float)e + 0.5f) * inv_h), r = e - q * h;  // exact for e < 2^22
+                const int cs = lcs[q];
                 int t0 = c0 - cs;
                 if (t0 < 0) t0 = 0;
                 int t1 = c0 + SC - cs;
                 if (t1 > tb.TC) t1 = tb.TC;
+                const float* zr = zs + r * LD + (cs - c0);
+                const float* tq = lt + q * TCP;
                 float a = dacc[i];
-                for (int t = t0; t < t1; ++t) a = fmaf(zs[r * SC + (cs + t - c0)], tt[t], a);
+#pragma unroll 4
+                for (int t = t0; t < t1; ++t) a = fmaf(zr[t], tq[t], a);
                 dacc[i] = a;
             }
         }
         __syncthreads();
     }
-    float* dst = g_heat + (size_t)bk * h * w;
+    // transpose through LDS (the tile is dead) so the map leaves in full rows
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = tid + i * nthreads;
-        if (e < h * w) dst[e] = accumulate ? dst[e] + dacc[i] : dacc[i];
+        if (e < h * w) {
+            const int q = (int)(((float)e + 0.5f) * inv_h), r = e - q * h;
+            hs[r * w + q] = dacc[i];
+        }
     }
+    __syncthreads();
+    float* dst = g_heat + (size_t)bk * h * w;
+    for (int i = tid; i < h * w; i += nthreads) dst[i] = accumulate ? dst[i] + hs[i] : hs[i];
 }
 
 // standalone keypoint epilogue (targets, or callers that decode elsewhere): kp_out = frame_map(kp_in); inverse-transpose
@@ -475,7 +498,7 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
     if (ne > 64) return LP_ERR_UNSUPPORTED;
     DecodeTables tb{t->row_base, t->row_taps, t->col_start, t->col_taps, t->colT_start, t->colT_taps, t->tx, t->tc};
     FrameMap fm{f->transforms, f->tf_mode, f->bbox, f->bbox_stride, f->kp_per_view, f->model_h, f->model_w};
-    const size_t smem = decode_smem_bytes(h, w, kBwdStrip);
+    const size_t smem = ((size_t)h * w + (size_t)h * kBwdLd + (size_t)w * bwd_tap_ld(t->tc) + (size_t)w) * sizeof(float);
     if (smem > 150 * 1024) return LP_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B * K), block(nthreads);
