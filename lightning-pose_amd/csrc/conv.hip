@@ -143,8 +143,9 @@ __device__ __forceinline__ u16x8 load4x2(const unsigned short* p0, bool ok0, con
 // ------------------------------------------------------------------------------------------------------------
 template <int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
-                                                         ConvGeom g, Lattice lat, FastDiv div_img, FastDiv div_row, int M, int N, int K,
-                                                         int tiles_n, int ntiles, ConvEpilogue ep) {
+                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
+                                                         FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles,
+                                                         ConvEpilogue ep) {
     constexpr int NT = BN / 64;
     // one LDS block: [2][128][72] A + [2][BN][72] B operand tiles, reused by the epilogue as a [128][BN+4] fp32 tile
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (kBM + BN) * kLD];
@@ -161,13 +162,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     // the load latency of the next.
     //
     // Per-thread description of the 4 A rows this thread stages.  Everything that depends only on the row is hoisted
-    // out of the K loop: `rowoff` is the element offset of the row's origin in the gathered tensor and `vmask` has one
+    // out of the K loop: `rowoff` is the BYTE offset of the row's origin in the gathered tensor and `vmask` has one
     // bit per filter tap saying whether that tap reads a real pixel (zero padding / stride-2 parity / row >= M
-    // otherwise).  Inside the loop a tap costs one wave-uniform offset add, one bit test and an UNCONDITIONAL 16-B load
-    // (invalid taps read offset 0 and are zeroed by a select), so the loop has no divergent branches.
+    // otherwise).  Operands are fetched with raw buffer loads: a tap costs one wave-uniform offset add and one OR per row
+    // (an invalid tap gets the offset 0xffffffff, which the hardware range check turns into zeros), the weight rows use a
+    // fixed per-lane offset plus a scalar K offset - no selects, no 64-bit address arithmetic, no divergent branches.
+    const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_w = make_buf_rsrc(Wt, w_bytes);
     int pb[4], py[4], px[4];
     bool pv[4];
-    int rowoff[4];
+    unsigned rowoff[4];
     unsigned vmask[4];
     const int rows_y = lat.nh, rows_x = lat.nw;
     const int full_h = (MODE == kModeDgrad) ? g.Hi : g.Ho;  // the output tensor's spatial size
@@ -179,10 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     const int KT = K / kBK;  // 0 for a parity class without taps: the epilogue then just writes addend / zeros
 
     u16x8 ra[4], rb[BN / 32];
-    unsigned okbits = 0xfu;      // which of ra[0..3] hold real data; applied when the registers are written to LDS, so
-                                 // nothing between the loads and the MFMA block waits on them
     int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
-    const unsigned short* wrow[BN / 32];
+    unsigned wrow[BN / 32];        // byte offset of this lane's chunk in each weight row it stages
     int m0n = 0, n0n = 0;        // origin of the tile being set up / loaded
 
     auto setup = [&](int vt) {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 px[i] = xq * g.stride - g.pad;
             }
             const int oy = halved ? (py[i] >> 1) : py[i], ox = halved ? (px[i] >> 1) : px[i];
-            rowoff[i] = ((b * src_h + oy) * src_w + ox) * ck + kchunk * 8;
+            rowoff[i] = (unsigned)(((b * src_h + oy) * src_w + ox) * ck + kchunk * 8) * 2u;
             unsigned mask = 0;
             if (MODE != kModeStem && pv[i]) {
                 for (int ir = 0; ir < lat.nr; ++ir)
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         for (int i = 0; i < BN / 32; ++i) {
             int n = n0n + rbase + 32 * i;
             if (n >= N) n = N - 1;  // rows past N are loaded (never stored): keeps the loop free of predicates
-            wrow[i] = Wt + (size_t)n * ((MODE == kModeStem) ? K : g.R * g.S * ck) + kchunk * 8;  // row stride = the FULL filter
+            wrow[i] = (unsigned)(n * ((MODE == kModeStem) ? K : g.R * g.S * ck) + kchunk * 8) * 2u;  // row stride = the FULL filter
         }
         tir = tis = tc = 0;
     };
@@ -242,7 +243,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         // ---- A: gathered activations
         if (MODE == kModeStem) {
             const int r = kt * 2 + (kchunk >> 2), s0 = (kchunk & 3) * 2;
-            okbits = 0xfu;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hi = py[i] + r, wi = px[i] + s0;
@@ -256,13 +256,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
             const int tapoff = ((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * ck + tc;
             const int tap = tir * lat.ns + tis;
+            const unsigned tapoff_b = (unsigned)tapoff * 2u;
             woff = (tr * g.S + ts) * ck + tc;
-            okbits = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned ok = (vmask[i] >> tap) & 1u;
-                okbits |= ok << i;
-                ra[i] = load8(X + (ok ? rowoff[i] + tapoff : 0));
+                ra[i] = buf_load16(rsrc_x, (rowoff[i] + tapoff_b) | (ok - 1u), 0u);  // ok - 1 = 0 (valid) or ~0 (-> zeros)
             }
             tc += kBK;
             if (tc >= ck) {
@@ -275,12 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         }
         // ---- B: weights [N][R*S*C], K-contiguous; the K offset follows the tap actually visited
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) rb[i] = load8(wrow[i] + woff);
+        for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], (unsigned)woff * 2u);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ((okbits >> i) & 1u) ? ra[i] : zero8();
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = rb[i];
     };
@@ -745,8 +743,11 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                          hipStream_t st) {
     const int tm = (M + kBM - 1) / kBM, tn = (N + BN - 1) / BN, ntiles = tm * tn;
     const int grid = ntiles < igemm_max_wgs() ? ntiles : igemm_max_wgs();
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, MODE>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)w, g,
-                       lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
+    // byte sizes of the gathered tensor and of the weight matrix (the entry points keep both below 4 GiB)
+    const unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
+    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * (MODE == kModeStem ? (size_t)K : (size_t)g.R * g.S * (MODE == kModeDgrad ? g.Co : g.Ci)));
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, MODE>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)w,
+                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
 struct WgradPlan {

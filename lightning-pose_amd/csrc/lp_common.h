@@ -49,6 +49,33 @@ __device__ __forceinline__ u16x8 pack_bf16x8(const float (&f)[8]) {
 // ReLU gate from a stored bf16 activation: positive (and not -0 / +0)  <=>  its bits read as int16 are > 0
 __device__ __forceinline__ bool bf16_positive(unsigned short y) { return (short)y > 0; }
 
+// ---- raw buffer addressing: 32-bit byte offsets against a (base, size) descriptor; loads past the end return zeros.
+// The im2col gathers use it for zero padding: an invalid tap is simply given the offset 0xffffffff, so the loop needs no
+// select on the loaded data and no 64-bit address arithmetic.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+__device__ __forceinline__ buf_rsrc make_buf_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+// 16 B at byte offset voff + soff (soff wave-uniform, not range-checked); zeros if voff is out of range
+__device__ __forceinline__ u16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned soff) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(u16x8, v);
+}
+#else
+struct buf_rsrc {
+    const char* p;
+    unsigned bytes;
+};
+__device__ __forceinline__ buf_rsrc make_buf_rsrc(const void* p, unsigned bytes) { return buf_rsrc{(const char*)p, bytes}; }
+__device__ __forceinline__ u16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned soff) {
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (voff < r.bytes && (unsigned long long)voff + 16 <= r.bytes) v = *reinterpret_cast<const u16x8*>(r.p + voff + soff);
+    return v;
+}
+#endif
+
 // Hide a value's provenance from the optimiser (keeps it from hoisting per-element address arithmetic out of a loop into
 // dozens of long-lived registers)
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -16,6 +16,8 @@ dev = torch.device("cuda:0")
 lib = _lib.lib()
 B = 128
 SHAPES = [  # name, Hi, Ci, Co, k, stride, pad
+    ("l1_conv1_1x1_256_64", 96, 256, 64, 1, 1, 0),
+    ("l1_conv2_3x3_64", 96, 64, 64, 3, 1, 1),
     ("l1_conv3_1x1_64_256", 96, 64, 256, 1, 1, 0),
     ("l2_conv2_3x3_128", 48, 128, 128, 3, 1, 1),
     ("l3_conv2_3x3_256", 24, 256, 256, 3, 1, 1),
