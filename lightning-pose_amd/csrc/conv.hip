@@ -99,23 +99,32 @@ __device__ __forceinline__ int out_row(int m, const Lattice& lat, const FastDiv&
     return (b * full_h + lat.h0 + lat.hstep * iy) * full_w + lat.w0 + lat.wstep * ix;
 }
 
+// one K step (64 deep) of a wave's 64 x (NT*32) tile: the fragments of k-slice kk+1 are read from LDS while the MFMAs of
+// slice kk issue, so the LDS latency is exposed once per K step instead of once per slice
 template <int NT>
 __device__ __forceinline__ void mma_kstep(const unsigned short* sA, const unsigned short* sB, int wm, int wn, int lane,
                                           f32x16 (&acc)[2][NT]) {
     const int r = lane & 31, g = lane >> 5;
+    const unsigned short* pa = sA + (wm * 64 + r) * kLD + g * 8;
+    const unsigned short* pb = sB + (wn * (NT * 32) + r) * kLD + g * 8;
+    bf16x8 a[2][2], b[2][NT];
+    auto fetch = [&](int kk, int set) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[set][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(pa + mt * 32 * kLD + kk * 16));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[set][nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(pb + nt * 32 * kLD + kk * 16));
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
-        bf16x8 a[2], b[NT];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            a[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sA + (wm * 64 + mt * 32 + r) * kLD + kk * 16 + g * 8));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            b[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sB + (wn * (NT * 32) + nt * 32 + r) * kLD + kk * 16 + g * 8));
+        if (kk + 1 < kBK / 16) fetch(kk + 1, (kk + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next slice's reads ahead of this slice's MFMAs
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mt], b[kk & 1][nt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -183,6 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 
     u16x8 ra[4], rb[BN / 32];
     int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
+    unsigned voff[4];              // byte offsets of the 4 A rows for the current tap (~0 where the tap is padding)
+    unsigned wtap = 0;             // byte offset of the current tap inside a weight row
     unsigned wrow[BN / 32];        // byte offset of this lane's chunk in each weight row it stages
     int m0n = 0, n0n = 0;        // origin of the tile being set up / loaded
 
@@ -239,9 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     };
 
     auto load_step = [&](int kt) {
-        int woff = kt * kBK;
-        // ---- A: gathered activations
-        if (MODE == kModeStem) {
+        if (MODE == kModeStem) {  // A: two 8-byte pixel halves per chunk (NHWC4); B: the padded [64][256] weight rows
             const int r = kt * 2 + (kchunk >> 2), s0 = (kchunk & 3) * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -250,19 +259,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 const size_t base = ((size_t)(pb[i] * g.Hi + hi) * g.Wi + wi) * 4;
                 ra[i] = load4x2(X + base, okr && wi >= 0 && wi < g.Wi, X + base + 4, okr && s0 + 1 < g.S && wi + 1 >= 0 && wi + 1 < g.Wi);
             }
-        } else {
-            // wave-uniform tap offset: fwd walks +(r, s); dgrad walks -(r, s) (halved for stride 2, valid taps only)
-            const int tr = lat.r0 + lat.rstep * tir, ts = lat.s0 + lat.sstep * tis;
-            const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
-            const int tapoff = ((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * ck + tc;
-            const int tap = tir * lat.ns + tis;
-            const unsigned tapoff_b = (unsigned)tapoff * 2u;
-            woff = (tr * g.S + ts) * ck + tc;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned ok = (vmask[i] >> tap) & 1u;
-                ra[i] = buf_load16(rsrc_x, (rowoff[i] + tapoff_b) | (ok - 1u), 0u);  // ok - 1 = 0 (valid) or ~0 (-> zeros)
+            for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], (unsigned)(kt * kBK) * 2u);
+        } else {
+            // A tap is visited for ck / 64 consecutive K steps.  Its per-row offsets are computed once, when it is entered
+            // (wave-uniform offset: fwd walks +(r, s); dgrad walks -(r, s), halved for stride 2, valid taps only); the channel
+            // offset inside the tap rides in the loads' scalar offset, which the range check ignores.
+            if (tc == 0) {
+                const int tr = lat.r0 + lat.rstep * tir, ts = lat.s0 + lat.sstep * tis;
+                const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
+                const unsigned tapoff_b = (unsigned)(((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * ck) * 2u;
+                const int tap = tir * lat.ns + tis;
+                wtap = (unsigned)((tr * g.S + ts) * ck) * 2u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned ok = (vmask[i] >> tap) & 1u;
+                    voff[i] = (rowoff[i] + tapoff_b) | (ok - 1u);  // ok - 1 = 0 (valid) or ~0 (-> zeros)
+                }
             }
+            const unsigned tcb = (unsigned)tc * 2u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = buf_load16(rsrc_x, voff[i], tcb);
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], wtap + tcb);  // weights [N][R*S*C], K-contiguous
             tc += kBK;
             if (tc >= ck) {
                 tc = 0;
@@ -272,9 +291,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 }
             }
         }
-        // ---- B: weights [N][R*S*C], K-contiguous; the K offset follows the tap actually visited
-#pragma unroll
-        for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], (unsigned)woff * 2u);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
