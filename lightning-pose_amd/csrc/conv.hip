@@ -517,8 +517,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 // ------------------------------------------------------------------------------------------------------------
 template <int BN, bool STEM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
-                                                         ConvGeom g, int M, int Kw, int tiles_n, int m_per_split,
-                                                         FastDiv div_hw, FastDiv div_wo, float* __restrict__ ws) {
+                                                         unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles_n,
+                                                         int m_per_split, FastDiv div_hw, FastDiv div_wo, float* __restrict__ ws) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][kBM * kLD];
@@ -563,7 +563,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     u16x8 ra[4], rb[RB];
     const int hw = g.Ho * g.Wo;
 
-    auto load_step = [&](int mk) {
+    // Fast addressing for stride-1 "same" convolutions (every 1x1 and 3x3 of the trunk except the three stride-2 blocks): the
+    // input pixel of output pixel m under tap (r, s) is m + const, so a lane's byte offsets are fixed (raw buffer loads: the K
+    // step rides in the scalar offset, padding taps get the offset ~0 and read zeros) and the only per-step arithmetic is the
+    // (row, column) walk that decides padding.  Everything else (stride 2, the stem, a ragged last step) takes the generic path.
+    const bool fast = !STEM && g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.Wo >= 8 && g.Ho >= 8;
+    const bool nomask = fast && g.R == 1 && g.S == 1 && g.pad == 0;
+    const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_dy = make_buf_rsrc(DY, dy_bytes);
+    const unsigned ci2 = (unsigned)g.Ci * 2u;
+    const int qw = 64 / g.Wo, rw = 64 - qw * g.Wo;
+    int fwo = 0, fho = 0, lo_h = 0, span_h = 0, lo_w = 0, span_w = 0;
+    unsigned voffA = ~0u, voffB[RB];
+    if (fast) {
+        const int p0 = m_begin + mgA * 4;
+        const int pc = p0 < M ? p0 : 0;
+        const int rem = pc - fdiv(pc, div_hw) * hw;
+        fho = fdiv(rem, div_wo);
+        fwo = rem - fho * g.Wo;
+        if (jv) voffA = (unsigned)((p0 + (tr - g.pad) * g.Wi + (ts - g.pad)) * g.Ci + tcn) * 2u;
+        lo_h = max(0, g.pad - tr);
+        span_h = min(g.Ho, g.Hi + g.pad - tr) - lo_h;
+        lo_w = max(0, g.pad - ts);
+        span_w = min(g.Wo, g.Wi + g.pad - ts) - lo_w;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) voffB[i] = nv ? (unsigned)((m_begin + mgB * RB + i) * g.Co + nB) * 2u : ~0u;
+    }
+    const unsigned jinv = jv ? 0u : ~0u;
+
+    auto load_fast = [&](int mk) {  // whole K step inside [m_begin, m_end)
+        const unsigned step = (unsigned)(mk - m_begin);
+        const unsigned soffA = step * ci2, soffB = step * (unsigned)g.Co * 2u;
+        if (nomask) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = buf_load16(rsrc_x, (voffA + i * ci2) | jinv, soffA);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int wo = fwo + i, ho = fho;
+                if (wo >= g.Wo) {
+                    wo -= g.Wo;
+                    ho = (ho + 1 == g.Ho) ? 0 : ho + 1;
+                }
+                const bool ok = (unsigned)(ho - lo_h) < (unsigned)span_h && (unsigned)(wo - lo_w) < (unsigned)span_w;
+                // the range check sees only the vector offset, and voffA alone may be "negative" for the taps above / left of
+                // the first pixel: the step offset has to be added into it, not ride in the scalar offset
+                ra[i] = buf_load16(rsrc_x, (voffA + soffA + i * ci2) | (ok ? 0u : ~0u) | jinv, 0u);
+            }
+            fwo += rw;
+            fho += qw;
+            if (fwo >= g.Wo) {
+                fwo -= g.Wo;
+                ++fho;
+            }
+            if (fho >= g.Ho) fho -= g.Ho;
+            if (fho >= g.Ho) fho -= g.Ho;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rsrc_dy, voffB[i], soffB);
+    };
+
+    auto load_generic = [&](int mk) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mk + mgA * 4 + i;
@@ -586,6 +645,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
             const int m = mk + mgB * RB + i;
             rb[i] = (nv && m < m_end) ? load8(DY + (size_t)m * g.Co + nB) : zero8();
         }
+    };
+    auto load_step = [&](int mk) {
+        if (fast && mk + kBK <= m_end) load_fast(mk);
+        else load_generic(mk);
     };
     auto store_step = [&](int buf) {
         // transpose 4 pixels x 8 columns -> 8 rows of 4 consecutive-k values
@@ -929,8 +992,11 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
     using namespace lp;
     LP_REQUIRE(x && dy && geom_ok(geom) && dw && workspace);
     ConvGeom g = to_geom(geom);
-    if (g.Ci % 8 != 0 || g.Co % 8 != 0) return LP_ERR_UNSUPPORTED;
+    if (g.Ci % 8 != 0 || g.Co % 8 != 0 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31) ||
+        (long long)g.B * g.Ho * g.Wo * g.Co >= (1LL << 31))
+        return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, Kw = g.R * g.S * g.Ci;
+    const unsigned x_bytes = (unsigned)(2ull * g.B * g.Hi * g.Wi * g.Ci), dy_bytes = (unsigned)(2ull * M * g.Co);
     const WgradPlan p = plan_wgrad(M, Kw, g.Co, split_hint, 768);
     LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
@@ -938,11 +1004,13 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
     const int tiles = p.tj * p.tn;
     if (p.wide) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tiles, p.split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
+                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
+                           make_fastdiv(g.Wo), ws);
         launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tiles, p.split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
+                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
+                           make_fastdiv(g.Wo), ws);
         launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     }
     return launch_status();
@@ -992,7 +1060,7 @@ extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom*
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(p.tj, p.split), dim3(256), 0, st, (const unsigned short*)x4,
-                       (const unsigned short*)dy, g, M, Kw, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
+                       (const unsigned short*)dy, 0u, 0u, g, M, Kw, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
     launch_wgrad_reduce<64>(ws, p.split, p.tj, 1, Kw, 64, dw, st);
     return launch_status();
 }

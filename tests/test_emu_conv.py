@@ -23,6 +23,8 @@ CASES = [
     (1, 9, 7, 64, 128, 3, 1, 1),     # 3x3, M = 63 (partial tile), N = 128
     (2, 10, 10, 128, 192, 3, 2, 1),  # 3x3 stride 2, N = 192 (partial second N tile), two K steps per tap
     (3, 8, 8, 128, 64, 1, 2, 0),     # 1x1 stride 2 (downsample)
+    (2, 12, 9, 64, 64, 3, 1, 1),     # 3x3 "same": the weight-gradient's fixed-offset addressing incl. image wrap, ragged last K step
+    (3, 16, 16, 64, 128, 3, 1, 1),   # same, M a multiple of 64, several images per pixel slice
 ]
 
 
