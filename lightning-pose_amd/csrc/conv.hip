@@ -521,8 +521,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
                                                          int m_per_split, FastDiv div_hw, FastDiv div_wo, float* __restrict__ ws) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][kBM * kLD];
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * kLD];
+    // Operand tiles stay in their memory orientation, [pixel][channel] (K = pixel is the ROW index): the 16-B chunks go to LDS
+    // with plain ds_write_b128 and the MFMA fragments (8 consecutive pixels of one channel per lane) come out of
+    // ds_read_b64_tr_b16.  Row stride = tile width + 64 B, so the 4 pixel rows of a transpose read sit in distinct bank quarters.
+    constexpr int LDA = kBM + 32, LDB = BN + 32;
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][kBK * LDA];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][kBK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -532,8 +536,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     const int m_begin = blockIdx.y * m_per_split;
     const int m_end = min(M, m_begin + m_per_split);
 
-    // A operand (gathered activations): thread -> 8 consecutive j (one 16-B chunk), 4 consecutive pixels
-    const int mgA = tid & 15, jc = tid >> 4;
+    // A operand (gathered activations): thread -> 8 consecutive j (one 16-B chunk) of 4 consecutive pixels; 16 consecutive
+    // lanes cover the 256-B tile row of one pixel
+    const int jc = tid & 15, pgA = tid >> 4;
     const int j = j0 + jc * 8;
     const bool jv = j < Kw;
     int tr = 0, ts = 0, tcn = 0;
@@ -546,9 +551,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         tr = tap / g.S;
         ts = tap - tr * g.S;
     }
-    // B operand (dy): thread -> 8 consecutive n, RB consecutive pixels
+    // B operand (dy): thread -> 8 consecutive n of RB consecutive pixels
     constexpr int NCH = BN / 8;
-    const int mgB = tid % (256 / NCH), nc = tid / (256 / NCH);
+    const int nc = tid % NCH, pgB = tid / NCH;
     const int nB = n0 + nc * 8;
     const bool nv = nB < g.Co;
 
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     int fwo = 0, fho = 0, lo_h = 0, span_h = 0, lo_w = 0, span_w = 0;
     unsigned voffA = ~0u, voffB[RB];
     if (fast) {
-        const int p0 = m_begin + mgA * 4;
+        const int p0 = m_begin + pgA * 4;
         const int pc = p0 < M ? p0 : 0;
         const int rem = pc - fdiv(pc, div_hw) * hw;
         fho = fdiv(rem, div_wo);
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         lo_w = max(0, g.pad - ts);
         span_w = min(g.Wo, g.Wi + g.pad - ts) - lo_w;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) voffB[i] = nv ? (unsigned)((m_begin + mgB * RB + i) * g.Co + nB) * 2u : ~0u;
+        for (int i = 0; i < RB; ++i) voffB[i] = nv ? (unsigned)((m_begin + pgB * RB + i) * g.Co + nB) * 2u : ~0u;
     }
     const unsigned jinv = jv ? 0u : ~0u;
 
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     auto load_generic = [&](int mk) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = mk + mgA * 4 + i;
+            const int m = mk + pgA * 4 + i;
             bool ok = jv && m < m_end;
             const int mm = ok ? m : 0;
             const int b = fdiv(mm, div_hw), rem = mm - b * hw;
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int m = mk + mgB * RB + i;
+            const int m = mk + pgB * RB + i;
             rb[i] = (nv && m < m_end) ? load8(DY + (size_t)m * g.Co + nB) : zero8();
         }
     };
@@ -651,21 +656,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         else load_generic(mk);
     };
     auto store_step = [&](int buf) {
-        // transpose 4 pixels x 8 columns -> 8 rows of 4 consecutive-k values
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            u16x4 v = {ra[0][c], ra[1][c], ra[2][c], ra[3][c]};
-            *reinterpret_cast<u16x4*>(&sA[buf][(jc * 8 + c) * kLD + mgA * 4]) = v;
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(pgA * 4 + i) * LDA + jc * 8]) = ra[i];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (RB == 4) {
-                u16x4 v = {rb[0][c], rb[1][c], rb[RB > 2 ? 2 : 0][c], rb[RB > 2 ? 3 : 0][c]};
-                *reinterpret_cast<u16x4*>(&sB[buf][(nc * 8 + c) * kLD + mgB * 4]) = v;
-            } else {
-                const unsigned v = (unsigned)rb[0][c] | ((unsigned)rb[1][c] << 16);
-                *reinterpret_cast<unsigned*>(&sB[buf][(nc * 8 + c) * kLD + mgB * 2]) = v;
-            }
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(pgB * RB + i) * LDB + nc * 8]) = rb[i];
+    };
+
+    // fragment of 32 channels x 16 pixels (k-slice kk) out of a [pixel][channel] tile: lane l of 16-lane group q = l / 16
+    // supplies pixel row 8 * (q / 2) + (l % 16) / 4 (+4 for the second read), channels 16 * (q % 2) + 4 * (l % 4) .. +3, and
+    // receives channel 16 * (q % 2) + l % 16 = l % 32, pixels 8 * (l / 32) .. +7: exactly the MFMA operand layout
+    const int fq = lane >> 4, fi = lane & 15;
+    const int frow = (fq >> 1) * 8 + (fi >> 2), fcol = (fq & 1) * 16 + (fi & 3) * 4;
+    auto frag = [&](const unsigned short* tile_, int ld, int ch0, int kk) -> bf16x8 {
+        const unsigned short* p = tile_ + (kk * 16 + frow) * ld + ch0 + fcol;
+        const s16x4_t lo = lds_read_tr16(p), hi = lds_read_tr16(p + 4 * ld);
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto mma_step = [&](int buf) {
+        bf16x8 a[2][2], b[2][NT];
+        auto fetch = [&](int kk, int set) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[set][mt] = frag(sA[buf], LDA, wm * 64 + mt * 32, kk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[set][nt] = frag(sB[buf], LDB, wn * (NT * 32) + nt * 32, kk);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < kBK / 16; ++kk) {
+            if (kk + 1 < kBK / 16) fetch(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the next slice's reads ahead of this slice's MFMAs
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mt], b[kk & 1][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -677,7 +704,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < KT) load_step(m_begin + (kt + 1) * kBK);
-            mma_kstep<NT>(sA[cur], sB[cur], wm, wn, lane, acc);
+            mma_step(cur);
             if (kt + 1 < KT) store_step(cur ^ 1);
             __syncthreads();
         }

@@ -76,6 +76,29 @@ __device__ __forceinline__ u16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned 
 }
 #endif
 
+// ---- LDS transpose read (ds_read_b64_tr_b16): within every group of 16 lanes the 16 addresses name a [4 rows][16 columns]
+// block of 16-bit elements - lanes 4e .. 4e+3 supply row e as four runs of 4 contiguous elements - and lane c receives column
+// c, i.e. {row0[c], row1[c], row2[c], row3[c]}.  It turns a [k][channel] LDS image into MFMA operand fragments (8 consecutive
+// k per lane = two reads) without any register transposes.  (Lane mapping measured on gfx950: profiles/probe/tr_probe.hip.)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+#elif defined(__HIP__)  // host pass of hipcc: declaration only, never executed
+__device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short*) { return s16x4_t{0, 0, 0, 0}; }
+#else  // CPU logic build (tests/hipemu): the same lane exchange spelled with shuffles
+__device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short* p) {
+    const int lane = threadIdx.x & 63, base = lane & ~15, c = lane & 15;
+    s16x4_t r;
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short* q = __shfl(p, base + 4 * e + (c >> 2), 64);
+        r[e] = (short)q[c & 3];
+    }
+    return r;
+}
+#endif
+
 // Hide a value's provenance from the optimiser (keeps it from hoisting per-element address arithmetic out of a loop into
 // dozens of long-lived registers)
 #if defined(__HIP_DEVICE_COMPILE__)
