@@ -517,8 +517,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 // ------------------------------------------------------------------------------------------------------------
 template <int BN, bool STEM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
-                                                         unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles_n,
-                                                         int m_per_split, FastDiv div_hw, FastDiv div_wo, float* __restrict__ ws) {
+                                                         unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles,
+                                                         int tiles_n, int m_per_split, FastDiv div_hw, FastDiv div_wo,
+                                                         float* __restrict__ ws) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
     // Operand tiles stay in their memory orientation, [pixel][channel] (K = pixel is the ROW index): the 16-B chunks go to LDS
@@ -531,9 +532,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
+    // 1-D grid over (pixel slice, tile) with the slice slow: the XCD remap hands each XCD a contiguous range of slices with ALL
+    // their tiles, so the tiles that re-read one slice of x / dy share an L2 instead of fetching it once per XCD
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int slice = work / tiles, tile = work - slice * tiles;
     const int j0 = (tile / tiles_n) * kBM, n0 = (tile % tiles_n) * BN;
-    const int m_begin = blockIdx.y * m_per_split;
+    const int m_begin = slice * m_per_split;
     const int m_end = min(M, m_begin + m_per_split);
 
     // A operand (gathered activations): thread -> 8 consecutive j (one 16-B chunk) of 4 consecutive pixels; 16 consecutive
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     }
 
     // partial tile -> workspace[slice][tile][wave][mt][nt][e][lane]
-    float* dst = ws + ((((size_t)blockIdx.y * gridDim.x + tile) * 4 + wave) * (2 * NT * 16)) * 64 + lane;
+    float* dst = ws + ((((size_t)slice * tiles + tile) * 4 + wave) * (2 * NT * 16)) * 64 + lane;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -856,6 +860,8 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                        x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
+constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
+
 struct WgradPlan {
     int tj, tn, split, per;
     bool wide;
@@ -867,7 +873,8 @@ static WgradPlan plan_wgrad(int M, int Kw, int Co, int split_hint, int target_wg
     p.tj = (Kw + kBM - 1) / kBM;
     p.wide = Co > 64;
     p.tn = p.wide ? (Co + 127) / 128 : 1;
-    int split = split_hint > 0 ? split_hint : (target_wgs + p.tj * p.tn - 1) / (p.tj * p.tn);
+    // the chip holds 512 of these workgroups at once (2 per CU, LDS-bound): aim just below a whole number of rounds
+    int split = split_hint > 0 ? split_hint : target_wgs / (p.tj * p.tn);
     const int ksteps = (M + kBK - 1) / kBK;
     if (split > ksteps) split = ksteps;
     if (split < 1) split = 1;
@@ -1010,7 +1017,7 @@ extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int sp
     ConvGeom g = to_geom(geom);
     const bool stem = (g.Ci == 4 && g.R == 7);
     const int Kw = stem ? 256 : g.R * g.S * g.Ci;
-    return plan_wgrad(g.B * g.Ho * g.Wo, Kw, g.Co, split_hint, stem ? 1024 : 768).ws_floats * sizeof(float);
+    return plan_wgrad(g.B * g.Ho * g.Wo, Kw, g.Co, split_hint, kWgradWgs).ws_floats * sizeof(float);
 }
 
 // dw[co][r][s][ci] (fp32, accumulated into) += sum_m x_gather[m][(r,s,ci)] * dy[m][co]
@@ -1024,19 +1031,19 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
         return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, Kw = g.R * g.S * g.Ci;
     const unsigned x_bytes = (unsigned)(2ull * g.B * g.Hi * g.Wi * g.Ci), dy_bytes = (unsigned)(2ull * M * g.Co);
-    const WgradPlan p = plan_wgrad(M, Kw, g.Co, split_hint, 768);
+    const WgradPlan p = plan_wgrad(M, Kw, g.Co, split_hint, kWgradWgs);
     LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const int tiles = p.tj * p.tn;
     if (p.wide) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tiles, p.split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tiles * p.split), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
                            make_fastdiv(g.Wo), ws);
         launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     } else {
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tiles, p.split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tiles * p.split), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
                            make_fastdiv(g.Wo), ws);
         launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     }
@@ -1082,12 +1089,12 @@ extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom*
     ConvGeom g = to_geom(geom);
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, Kw = 256;
-    const WgradPlan p = plan_wgrad(M, Kw, 64, split_hint, 1024);
+    const WgradPlan p = plan_wgrad(M, Kw, 64, split_hint, kWgradWgs);
     LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(p.tj, p.split), dim3(256), 0, st, (const unsigned short*)x4,
-                       (const unsigned short*)dy, 0u, 0u, g, M, Kw, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(p.tj * p.split), dim3(256), 0, st, (const unsigned short*)x4,
+                       (const unsigned short*)dy, 0u, 0u, g, M, Kw, p.tj, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
     launch_wgrad_reduce<64>(ws, p.split, p.tj, 1, Kw, 64, dw, st);
     return launch_status();
 }
