@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         tir = tis = tc = 0;
     };
 
-    auto load_step = [&](int kt) {
+    // `with_b = false` (the data-gradient's prefetch across its register-hungry store pass) leaves the weight rows for
+    // load_b_deferred(): they are L2-resident, so fetching them after the store pass costs little and frees 16 VGPRs there
+    unsigned b_deferred = 0;
+    auto load_step = [&](int kt, bool with_b = true) {
         if (MODE == kModeStem) {  // A: two 8-byte pixel halves per chunk (NHWC4); B: the padded [64][256] weight rows
             const int r = kt * 2 + (kchunk >> 2), s0 = (kchunk & 3) * 2;
 #pragma unroll
@@ -280,8 +283,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             const unsigned tcb = (unsigned)tc * 2u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = buf_load16(rsrc_x, voff[i], tcb);
+            if (with_b) {
 #pragma unroll
-            for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], wtap + tcb);  // weights [N][R*S*C], K-contiguous
+                for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], wtap + tcb);  // weights [N][R*S*C], K-contiguous
+            } else {
+                b_deferred = wtap + tcb;
+            }
             tc += kBK;
             if (tc >= ck) {
                 tc = 0;
@@ -291,6 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 }
             }
         }
+    };
+    auto load_b_deferred = [&]() {
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], b_deferred);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
@@ -502,8 +513,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         }
         // next tile's row descriptors and first operands: in flight while this tile is stored
         setup(vt);
-        load_step(0);
+        load_step(0, MODE != kModeDgrad);
         epilogue(m0, n0);
+        if (MODE == kModeDgrad) load_b_deferred();
         __syncthreads();  // the epilogue's LDS tile is dead before the next tile's operands land in it
     }
 }
