@@ -159,7 +159,8 @@ int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, cons
  *   lp_conv_dgrad_bn:                 dx is the gradient of a = relu(BN(z) [+ residual]); sums (2,Ci) += [sum dx, sum dx*xhat]
  *                                     (== lp_bn_bwd_reduce), dbeta_acc / dgamma_acc (optional) receive the same totals.
  *                                     mask_from_z = 1 recomputes the ReLU mask as bf16(gamma*invstd*(z-mean)+beta) > 0 (layers
- *                                     without a residual branch; relu_mask must then be NULL), otherwise pass relu_mask. */
+ *                                     without a residual branch; relu_mask must then be NULL), otherwise pass relu_mask or
+ *                                     bn->relu_bits. */
 typedef struct lp_bn_fuse {
     const void* z;        /* bf16 [rows][C] pre-normalisation tensor (dgrad only) */
     const float* mean;    /* (C,) batch mean      (dgrad only) */
@@ -167,6 +168,7 @@ typedef struct lp_bn_fuse {
     const float* gamma;   /* (C,) weight, mask_from_z only */
     const float* beta;    /* (C,) bias,   mask_from_z only */
     int mask_from_z;
+    const void* relu_bits; /* dgrad only, optional: 1-bit ReLU mask written by lp_bn_apply (then relu_mask must be NULL) */
     float* sums;          /* (2,C) fp32, accumulated into (zero first) */
     float* dbeta_acc;     /* (C,) or NULL */
     float* dgamma_acc;    /* (C,) or NULL */
@@ -197,8 +199,9 @@ int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, floa
 int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream);
 int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, lp_stream_t stream);
+/* relu_bits (optional, M*C/8 bytes): bit q of byte i = (y[8*i + q] > 0): a 16x smaller ReLU mask for the backward pass */
 int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
-                int relu, int M, int C, void* y, lp_stream_t stream);
+                int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream);
 /* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL); dbeta/dgamma accumulate too */
 int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
                      float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);

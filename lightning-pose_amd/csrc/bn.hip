@@ -127,7 +127,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
-                                                       int relu, size_t n_chunks, int C, unsigned short* __restrict__ Y) {
+                                                       int relu, size_t n_chunks, int C, unsigned short* __restrict__ Y,
+                                                       unsigned char* __restrict__ bits) {
     const int chunks = C >> 3;
     const size_t stride = (size_t)gridDim.x * 256;
     size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -168,6 +169,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                 for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
             }
             *reinterpret_cast<u16x8*>(Y + (q + u * stride) * 8) = pack8(o);
+            if (bits != nullptr) {  // 1-bit ReLU mask: o > 2^-134 is exactly "the stored bf16 is > 0"
+                unsigned m = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m |= (o[i] > 0x1p-134f ? 1u : 0u) << i;
+                bits[q + u * stride] = (unsigned char)m;
+            }
         }
     }
 }
@@ -398,13 +405,13 @@ extern "C" int lp_bn_finalize(const float* sums, float count, int C, float eps, 
 }
 
 extern "C" int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                           const void* residual, int relu, int M, int C, void* y, lp_stream_t stream) {
+                           const void* residual, int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
-                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y);
+                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits);
     return launch_status();
 }
 

@@ -41,6 +41,7 @@ struct ConvEpilogue {
     const float* bias;             // [n] or nullptr
     const unsigned short* addend;  // [M][ldo] bf16 added before the store (gradient accumulation), or nullptr
     const unsigned short* relu_mask;  // [M][ldo] bf16 activation; outputs where it is <= 0 are zeroed (ReLU backward), or nullptr
+    const unsigned char* relu_bits;   // same mask at 1 bit per element ([M][ldo/8] bytes, written by lp_bn_apply), or nullptr
     // BatchNorm reductions fused into the store pass (bf16 outputs only).  `stats` receives, per 128-row tile, the column
     // sums of the values actually stored (after rounding): [tile][0][c] = sum v, [tile][1][c] = sum v^2 (forward: the
     // statistics of the next BatchNorm) or, with bn_z, sum v * xhat (backward: the two reductions of BatchNorm's gradient).
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     unsigned off[HB];
                     bool rv[HB];
                     u16x8 la[HB], lz[HB], lm[HB];
+                    unsigned lb[HB];
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
                         const int m = m0 + r0 + (i0 + i) * RPP;
@@ -379,6 +381,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     if (kReads && ep.relu_mask) {
 #pragma unroll
                         for (int i = 0; i < HB; ++i) lm[i] = load8(ep.relu_mask + off[i]);
+                    }
+                    if (kReads && ep.relu_bits) {
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) lb[i] = ep.relu_bits[off[i] >> 3];
                     }
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
@@ -407,6 +413,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 #pragma unroll
                                 for (int q = 0; q < 8; ++q)
                                     if (!bf16_positive(lm[i][q])) v[q] = 0.f;
+                            }
+                            if (kReads && ep.relu_bits) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    if (!((lb[i] >> q) & 1u)) v[q] = 0.f;
                             }
                             const u16x8 w = pack_bf16x8(v);
                             *reinterpret_cast<u16x8*>(ep.out_bf16 + off[i]) = w;
@@ -919,7 +930,7 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         (long long)g.B * g.Ho * g.Wo * ldo >= (1LL << 32))
         return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
-    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr,
+    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     const int tm = (M + kBM - 1) / kBM;
     if (bn) {
@@ -966,7 +977,7 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         return LP_ERR_UNSUPPORTED;
     const int N = g.Ci;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
-                    (const unsigned short*)relu_mask, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    (const unsigned short*)relu_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (bn) {
         // the reductions cover every pixel exactly once, so no class may be skipped and the output must be the dense bf16 tensor
         LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && bn->workspace && dx_bf16 && !dx_f32 && !skip_empty_classes &&
@@ -980,6 +991,8 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         ep.bn_gamma = bn->gamma;
         ep.bn_beta = bn->beta;
         ep.mask_from_z = bn->mask_from_z;
+        ep.relu_bits = (const unsigned char*)bn->relu_bits;
+        LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)));
     }
     hipStream_t st = (hipStream_t)stream;
     int stats_rows = 0;
@@ -1071,7 +1084,7 @@ static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo;
     const int tm = (M + kBM - 1) / kBM;
-    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr,
+    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (bn) {
         LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * 64 * sizeof(float));

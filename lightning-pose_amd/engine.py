@@ -316,7 +316,7 @@ class Engine:
         return _lib.ConvGeom(B, Hi, Wi, c.Ci, Ho, Wo, c.Co, c.k, c.k, c.stride, c.pad)
 
     def _bn_fuse(self, g: _lib.ConvGeom, dgrad: bool, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None,
-                 mask_from_z: bool = False) -> _lib.BnFuse:
+                 mask_from_z: bool = False, relu_bits=None) -> _lib.BnFuse:
         """lp_bn_fuse for one launch; the per-tile workspace is one scratch buffer reused by every launch of the stream."""
         need = int(self._lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
         if self._bn_ws is None or self._bn_ws.numel() < need:
@@ -327,6 +327,7 @@ class Engine:
             f.z, f.mean, f.invstd = z.data_ptr(), mean.data_ptr(), invstd.data_ptr()
             f.gamma, f.beta = self.param_view(b, "weight").data_ptr(), self.param_view(b, "bias").data_ptr()
             f.mask_from_z = int(mask_from_z)
+            f.relu_bits = relu_bits.data_ptr() if relu_bits is not None else None
             f.dbeta_acc, f.dgamma_acc = self.G[b.b_off:].data_ptr(), self.G[b.g_off:].data_ptr()
         return f
 
@@ -353,7 +354,8 @@ class Engine:
         return out, g
 
     def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
-                have_sums: bool = False):
+                have_sums: bool = False, want_bits: bool = False):
+        """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass"""
         mean = torch.empty(b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         if training:
@@ -370,8 +372,11 @@ class Engine:
             mean.copy_(self.running_view(b, "running_mean"))
             invstd.copy_((self.running_view(b, "running_var") + BN_EPS).rsqrt())
         y = torch.empty_like(z)
+        bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
         check(self._lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias")),
-                                    _p(residual), int(relu), M, b.C, _p(y), ops._stream()), "lp_bn_apply")
+                                    _p(residual), int(relu), M, b.C, _p(y), _p(bits), ops._stream()), "lp_bn_apply")
+        if want_bits:
+            return y, mean, invstd, bits
         return y, mean, invstd
 
     # ------------------------------------------------------------------------------------------------ forward
@@ -397,11 +402,17 @@ class Engine:
         x4 = torch.empty(B, H, W, 4, device=self.device, dtype=torch.bfloat16)
         check(self._lib.lp_images_to_nhwc4(_p(images), B, H, W, _p(x4), ops._stream()), "lp_images_to_nhwc4")
         T["x4"] = x4
-        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu):
-            """conv -> BatchNorm(+residual)(+ReLU); in training the statistics come out of the convolution's store pass"""
+        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu, bits_key=None):
+            """conv -> BatchNorm(+residual)(+ReLU); in training the statistics come out of the convolution's store pass.
+            ``bits_key``: keep the output's 1-bit ReLU mask on the tape (block outputs: their backward reads it instead of the
+            activation itself)"""
             sums = next_sums(b)
             zz, gg = self._conv_fwd(c, xin, B, hh, ww, sums if training else None)
-            aa, mm, vv = self._bn_fwd(b, zz, B * gg.Ho * gg.Wo, residual, relu, training, sums, have_sums=training)
+            res = self._bn_fwd(b, zz, B * gg.Ho * gg.Wo, residual, relu, training, sums, have_sums=training,
+                               want_bits=bits_key is not None and training)
+            if len(res) == 4:
+                T[bits_key] = res[3]
+            aa, mm, vv = res[:3]
             return zz, aa, mm, vv, gg
 
         z, a, mu, iv, g = conv_bn(plan.stem, plan.stem_bn, x4, H, W, None, True)
@@ -426,7 +437,7 @@ class Engine:
                 T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"] = zd, md, vd
             else:
                 idt = x
-            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True)
+            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits")
             for nm, val in (("z1", z1), ("a1", a1), ("m1", m1), ("v1", v1), ("z2", z2), ("a2", a2), ("m2", m2), ("v2", v2),
                             ("z3", z3), ("m3", m3), ("v3", v3), ("out", out)):
                 T[f"{key}.{nm}"] = val
@@ -482,7 +493,8 @@ class Engine:
                                         count, M, b.C, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply")
         return dz, dres
 
-    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None):
+    def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
+                  relu_bits=None):
         """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
         ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
         for stride-2 layers only the pixels a filter tap reaches are touched.
@@ -500,7 +512,10 @@ class Engine:
         if bn is not None:
             assert accumulate_into is None
             b, z, mean, invstd, sums = bn
-            f = self._bn_fuse(g, True, sums, b, z, mean, invstd, mask_from_z=relu_mask is None)
+            if relu_bits is not None:
+                relu_mask = None  # the 1-bit form replaces the activation tensor as the mask source
+            f = self._bn_fuse(g, True, sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None,
+                              relu_bits=relu_bits)
             run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
                                                            C.byref(f), st), "lp_conv_dgrad_bn")
         else:
@@ -589,7 +604,8 @@ class Engine:
                 prev, pk = plan.blocks[i - 1], f"b{i - 1}"
                 d_sums = new_sums(prev.bn3)
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x,
-                                   bn=(prev.bn3, T[f"{pk}.z3"], T[f"{pk}.m3"], T[f"{pk}.v3"], d_sums))
+                                   bn=(prev.bn3, T[f"{pk}.z3"], T[f"{pk}.m3"], T[f"{pk}.v3"], d_sums),
+                                   relu_bits=T.get(f"{pk}.out_bits"))
             else:
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x)
 

@@ -254,7 +254,7 @@ def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, 
     return ob.np(), (of.np() if of is not None else None)
 
 
-def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, want_acc=False):
+def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, want_acc=False, relu_bits=None):
     """lp_bn_fuse + the buffers it points at (kept alive on the returned object)."""
     f = _lib.BnFuse()
     f.keep = dict(z=B(z), mean=B(mean, np.float32), invstd=B(invstd, np.float32), gamma=B(gamma, np.float32), beta=B(beta, np.float32),
@@ -264,6 +264,8 @@ def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None
     k = f.keep
     f.z, f.mean, f.invstd, f.gamma, f.beta = (ptr(k[n]).value if k[n] is not None else None for n in ("z", "mean", "invstd", "gamma", "beta"))
     f.mask_from_z = int(mask_from_z)
+    k["bits"] = B(relu_bits)
+    f.relu_bits = k["bits"].p.value if relu_bits is not None else None
     f.sums = k["sums"].p.value
     f.dbeta_acc = k["dbeta"].p.value if want_acc else None
     f.dgamma_acc = k["dgamma"].p.value if want_acc else None
@@ -286,11 +288,13 @@ def stem_fwd_bn(x4_bits, w_bits, g):
     return ob.np(), f.keep["sums"].np()
 
 
-def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None):
-    """-> (dx bits, sums (2,Ci), dbeta, dgamma); the ReLU mask comes from mask_bits if given, else is recomputed from z"""
+def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None, relu_bits=None):
+    """-> (dx bits, sums (2,Ci), dbeta, dgamma); the ReLU mask comes from mask_bits (bf16 activation) or relu_bits (1 bit per
+    element) if given, else is recomputed from z"""
     db, wb, ab, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(mask_bits)
     ob = Z((g.B * g.Hi * g.Wi, g.Ci), np.uint16)
-    f = _bn_fuse(g, True, g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None, want_acc=True)
+    f = _bn_fuse(g, True, g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None and relu_bits is None, want_acc=True,
+                 relu_bits=relu_bits)
     ok(lib().lp_conv_dgrad_bn(db.p, wb.p, C.byref(g), ptr(ab), ptr(mb), ob.p, C.byref(f), stream()))
     return ob.np(), f.keep["sums"].np(), f.keep["dbeta"].np(), f.keep["dgamma"].np()
 
@@ -317,7 +321,7 @@ def stem_wgrad(x4_bits, dy_bits, g, split=0):
     return dw.np()
 
 
-def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None):
+def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False):
     xb, rb = Buf(x_bits), B(residual_bits)
     sums, mean, invstd = Z((2, Cn)), Z(Cn), Z(Cn)
     ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, stream()))
@@ -325,10 +329,13 @@ def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e
     rv = Buf(running[1]) if running is not None else None
     ok(lib().lp_bn_finalize(sums.p, float(M), Cn, eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), stream()))
     y, gb, bb = Z((M, Cn), np.uint16), Buf(f32(gamma)), Buf(f32(beta))
-    ok(lib().lp_bn_apply(xb.p, mean.p, invstd.p, gb.p, bb.p, ptr(rb), int(relu), M, Cn, y.p, stream()))
+    bits = Z(M * Cn // 8, np.uint8) if want_bits else None
+    ok(lib().lp_bn_apply(xb.p, mean.p, invstd.p, gb.p, bb.p, ptr(rb), int(relu), M, Cn, y.p, ptr(bits), stream()))
     if running is not None:
         running[0][:] = rm.np()
         running[1][:] = rv.np()
+    if want_bits:
+        return y.np(), mean.np(), invstd.np(), bits.np()
     return y.np(), mean.np(), invstd.np()
 
 

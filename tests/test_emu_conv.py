@@ -133,7 +133,7 @@ def test_stem_fwd_wgrad():
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fused_batchnorm_reductions(case):
     """lp_conv_fwd_bn == lp_conv_fwd + lp_bn_stats;  lp_conv_dgrad_bn == lp_conv_dgrad(+mask) + lp_bn_bwd_reduce, for both mask
-    sources (the activation tensor, or recomputed from the pre-normalisation tensor)."""
+    sources (the activation tensor, its 1-bit form written by lp_bn_apply, or recomputed from the pre-normalisation tensor)."""
     B, Hi, Wi, Ci, Co, R, st, pad = case
     gen = torch.Generator().manual_seed(7 + sum(case))
     g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
@@ -152,14 +152,16 @@ def test_conv_fused_batchnorm_reductions(case):
     zin = torch.randn(Mi, Ci, generator=gen)
     zin_bits = emu.to_bf16_bits(zin)
     gamma, beta = torch.rand(Ci, generator=gen) + 0.5, torch.randn(Ci, generator=gen) * 0.3
-    a_bits, mean, invstd = emu.bn_forward(zin_bits, Mi, Ci, gamma.numpy(), beta.numpy(), relu=True)
+    a_bits, mean, invstd, relu_bits = emu.bn_forward(zin_bits, Mi, Ci, gamma.numpy(), beta.numpy(), relu=True, want_bits=True)
+    want_bits = np.packbits((emu.from_bf16_bits(a_bits).numpy() > 0).reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    assert np.array_equal(relu_bits, want_bits)
     dy = emu.to_bf16_bits(torch.randn(B * g.Ho * g.Wo, Co, generator=gen))
     add = emu.to_bf16_bits(torch.randn(Mi, Ci, generator=gen))
     want_dx, _ = emu.conv_dgrad(dy, wd, g, addend_bits=add, mask_bits=a_bits)
     _, _, want_dgamma, want_dbeta = emu.bn_backward(want_dx, None, zin_bits, mean, invstd, gamma.numpy(), Mi, Ci)
-    for mask in (a_bits, None):
+    for mask, bits in ((a_bits, None), (None, None), (None, relu_bits)):
         dx, sums, dbeta, dgamma = emu.conv_dgrad_bn(dy, wd, g, zin_bits, mean, invstd, gamma.numpy(), beta.numpy(), addend_bits=add,
-                                                    mask_bits=mask)
+                                                    mask_bits=mask, relu_bits=bits)
         assert np.array_equal(dx, want_dx)
         np.testing.assert_allclose(sums[0], want_dbeta, rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(sums[1], want_dgamma, rtol=1e-4, atol=1e-3)
