@@ -99,6 +99,14 @@ int lp_heatmap_mse_fwd(const float* targ, const float* pred, int B, int K, int h
                        lp_stream_t stream);
 int lp_heatmap_mse_bwd(const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace, const float* gout,
                        float* gpred, int accumulate, lp_stream_t stream);
+/* The same masked mean for the three supervised heat-map losses: kind = LP_HM_MSE (above), LP_HM_KL (HeatmapKLLoss,
+ * losses/losses.py:338-379) or LP_HM_JS (HeatmapJSLoss, :382-423) - kornia's kl_div_loss_2d / js_div_loss_2d of the maps
+ * + 1e-10, summed over each map, averaged over the labelled maps.  Workspace as lp_heatmap_mse_workspace_bytes. */
+enum { LP_HM_MSE = 0, LP_HM_KL = 1, LP_HM_JS = 2 };
+int lp_heatmap_loss_fwd(int kind, const float* targ, const float* pred, int B, int K, int h, int w, float* loss, void* workspace,
+                        lp_stream_t stream);
+int lp_heatmap_loss_bwd(int kind, const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace,
+                        const float* gout, float* gpred, int accumulate, lp_stream_t stream);
 
 /* "unimodal_mse" (not in the reference snapshot; defined by oracle/restated.py unimodal_mse_loss,
  * structurally losses/losses.py:1129-1260).  Same workspace size as lp_heatmap_mse. */

@@ -38,6 +38,7 @@ class BnFuse(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+HM_MSE, HM_KL, HM_JS = 0, 1, 2
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -54,6 +55,8 @@ PROTOTYPES = {
     "lp_heatmap_mse_workspace_bytes": (_Z, [_I, _I]),
     "lp_heatmap_mse_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_heatmap_mse_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "lp_heatmap_loss_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_heatmap_loss_bwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "lp_unimodal_mse_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "lp_unimodal_mse_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
     "lp_softmax2d_fwd": (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _P]),

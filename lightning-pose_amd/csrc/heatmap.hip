@@ -60,12 +60,33 @@ __global__ __launch_bounds__(256) void heatmap_gen_kernel(const float* __restric
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = gauss_at(i, cx, cy, g) / total;
 }
 
-// ---- masked heat-map MSE -----------------------------------------------------------------------------
-// pass 1: per map, sum (t-p)^2 and a validity flag.  FROM_KP: the target is the Gaussian at kp (unimodal loss).
+// ---- masked heat-map losses (MSE / KL / JS) -----------------------------------------------------------
+// per-pixel term of the three supervised heat-map losses (reference losses/losses.py:293-423; the divergences are kornia's
+// kl_div_loss_2d / js_div_loss_2d on t + 1e-10, p + 1e-10, summed per map) and its derivative with respect to p
+__device__ __forceinline__ float hm_term(int kind, float t, float p) {
+    if (kind == LP_HM_MSE) {
+        const float d = t - p;
+        return d * d;
+    }
+    const float te = t + 1e-10f, pe = p + 1e-10f;
+    if (kind == LP_HM_KL) return te * (logf(te) - logf(pe));
+    const float lm = logf(0.5f * (te + pe));
+    return 0.5f * te * (logf(te) - lm) + 0.5f * pe * (logf(pe) - lm);
+}
+
+__device__ __forceinline__ float hm_dterm(int kind, float t, float p) {
+    if (kind == LP_HM_MSE) return 2.f * (p - t);
+    const float te = t + 1e-10f, pe = p + 1e-10f;
+    if (kind == LP_HM_KL) return -te / pe;
+    return 0.5f * (logf(pe) - logf(0.5f * (te + pe)));
+}
+
+// pass 1: per map, the sum of the per-pixel terms and a validity flag.  FROM_KP: the target is the Gaussian at kp
+// (unimodal loss, MSE only).
 template <bool FROM_KP>
 __global__ __launch_bounds__(256) void hm_rowsq_kernel(const float* __restrict__ targ, const float* __restrict__ pred,
                                                        const float* __restrict__ kp, const float* __restrict__ conf,
-                                                       float prob_threshold, GaussSpec g, float* __restrict__ rowsum,
+                                                       float prob_threshold, GaussSpec g, int kind, float* __restrict__ rowsum,
                                                        int* __restrict__ valid) {
     __shared__ float red[4];
     const int bk = blockIdx.x, n = g.h * g.w;
@@ -89,8 +110,7 @@ __global__ __launch_bounds__(256) void hm_rowsq_kernel(const float* __restrict__
         float nz = 0.f;
         for (int i = threadIdx.x; i < n; i += 256) {
             const float tv = t[i];
-            const float d = tv - p[i];
-            part = fmaf(d, d, part);
+            part += hm_term(kind, tv, p[i]);
             nz += (tv != 0.f) ? 1.f : 0.f;
         }
         ok = block_sum<4>(nz, red) > 0.f;
@@ -120,12 +140,12 @@ __global__ __launch_bounds__(256) void hm_finish_kernel(const float* __restrict_
     }
 }
 
-// backward: grad_pred = gout * 2 (p - t) / n_valid on valid maps, 0 elsewhere
+// backward: grad_pred = gout * d term / d p / n_valid on valid maps (MSE: 2 (p - t)), 0 elsewhere
 template <bool FROM_KP>
 __global__ __launch_bounds__(256) void hm_grad_kernel(const float* __restrict__ targ, const float* __restrict__ pred,
-                                                      const float* __restrict__ kp, GaussSpec g, const int* __restrict__ valid,
-                                                      const float* __restrict__ nvalid, const float* __restrict__ gout,
-                                                      float* __restrict__ gpred, int accumulate) {
+                                                      const float* __restrict__ kp, GaussSpec g, int kind,
+                                                      const int* __restrict__ valid, const float* __restrict__ nvalid,
+                                                      const float* __restrict__ gout, float* __restrict__ gpred, int accumulate) {
     __shared__ float red[4];
     const int bk = blockIdx.x, n = g.h * g.w;
     float* gp = gpred + (size_t)bk * n;
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(256) void hm_grad_kernel(const float* __restrict__ 
             for (int i = threadIdx.x; i < n; i += 256) gp[i] = 0.f;
         return;
     }
-    const float scale = 2.f * gout[0] / nvalid[0];
+    const float scale = gout[0] / nvalid[0];
     const float* p = pred + (size_t)bk * n;
     if (FROM_KP) {
         float cx, cy;
@@ -143,13 +163,13 @@ __global__ __launch_bounds__(256) void hm_grad_kernel(const float* __restrict__ 
         for (int i = threadIdx.x; i < n; i += 256) gs += gauss_at(i, cx, cy, g);
         const float inv = 1.f / block_sum<4>(gs, red);
         for (int i = threadIdx.x; i < n; i += 256) {
-            const float v = scale * (p[i] - gauss_at(i, cx, cy, g) * inv);
+            const float v = scale * 2.f * (p[i] - gauss_at(i, cx, cy, g) * inv);
             gp[i] = accumulate ? gp[i] + v : v;
         }
     } else {
         const float* t = targ + (size_t)bk * n;
         for (int i = threadIdx.x; i < n; i += 256) {
-            const float v = scale * (p[i] - t[i]);
+            const float v = scale * hm_dterm(kind, t[i], p[i]);
             gp[i] = accumulate ? gp[i] + v : v;
         }
     }
@@ -211,32 +231,44 @@ extern "C" int lp_heatmap_gen(const float* keypoints, const int* visibility, int
 extern "C" size_t lp_heatmap_mse_workspace_bytes(int B, int K) { return (size_t)B * K * 8 + 16; }
 
 // workspace layout: float rowsum[B*K] | int valid[B*K] | float nvalid | pad
-extern "C" int lp_heatmap_mse_fwd(const float* targ, const float* pred, int B, int K, int h, int w, float* loss, void* workspace,
-                                  lp_stream_t stream) {
+extern "C" int lp_heatmap_loss_fwd(int kind, const float* targ, const float* pred, int B, int K, int h, int w, float* loss,
+                                   void* workspace, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(targ && pred && loss && workspace && B > 0 && K > 0 && h > 0 && w > 0);
+    LP_REQUIRE(kind == LP_HM_MSE || kind == LP_HM_KL || kind == LP_HM_JS);
     float* rowsum = (float*)workspace;
     int* valid = (int*)(rowsum + (size_t)B * K);
     float* nvalid = (float*)(valid + (size_t)B * K);
     GaussSpec g = make_spec(1, 1, h, w, 1.f);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((hm_rowsq_kernel<false>), dim3(B * K), dim3(256), 0, st, targ, pred, (const float*)nullptr,
-                       (const float*)nullptr, 0.f, g, rowsum, valid);
+                       (const float*)nullptr, 0.f, g, kind, rowsum, valid);
     hipLaunchKernelGGL(hm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)rowsum, (const int*)valid, B * K, 0, loss, nvalid);
     return launch_status();
 }
 
-extern "C" int lp_heatmap_mse_bwd(const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace,
-                                  const float* gout, float* gpred, int accumulate, lp_stream_t stream) {
+extern "C" int lp_heatmap_mse_fwd(const float* targ, const float* pred, int B, int K, int h, int w, float* loss, void* workspace,
+                                  lp_stream_t stream) {
+    return lp_heatmap_loss_fwd(LP_HM_MSE, targ, pred, B, K, h, w, loss, workspace, stream);
+}
+
+extern "C" int lp_heatmap_loss_bwd(int kind, const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace,
+                                   const float* gout, float* gpred, int accumulate, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(targ && pred && workspace && gout && gpred && B > 0 && K > 0 && h > 0 && w > 0);
+    LP_REQUIRE(kind == LP_HM_MSE || kind == LP_HM_KL || kind == LP_HM_JS);
     const float* rowsum = (const float*)workspace;
     const int* valid = (const int*)(rowsum + (size_t)B * K);
     const float* nvalid = (const float*)(valid + (size_t)B * K);
     GaussSpec g = make_spec(1, 1, h, w, 1.f);
     hipLaunchKernelGGL((hm_grad_kernel<false>), dim3(B * K), dim3(256), 0, (hipStream_t)stream, targ, pred, (const float*)nullptr,
-                       g, valid, nvalid, gout, gpred, accumulate);
+                       g, kind, valid, nvalid, gout, gpred, accumulate);
     return launch_status();
+}
+
+extern "C" int lp_heatmap_mse_bwd(const float* targ, const float* pred, int B, int K, int h, int w, const void* workspace,
+                                  const float* gout, float* gpred, int accumulate, lp_stream_t stream) {
+    return lp_heatmap_loss_bwd(LP_HM_MSE, targ, pred, B, K, h, w, workspace, gout, gpred, accumulate, stream);
 }
 
 extern "C" int lp_unimodal_mse_fwd(const float* kp_aug, const float* pred, const float* conf, int S, int K, int img_h, int img_w,
@@ -250,7 +282,7 @@ extern "C" int lp_unimodal_mse_fwd(const float* kp_aug, const float* pred, const
     GaussSpec g = make_spec(img_h, img_w, h, w, sigma);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((hm_rowsq_kernel<true>), dim3(S * K), dim3(256), 0, st, (const float*)nullptr, pred, kp_aug, conf,
-                       prob_threshold, g, rowsum, valid);
+                       prob_threshold, g, (int)LP_HM_MSE, rowsum, valid);
     hipLaunchKernelGGL(hm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)rowsum, (const int*)valid, S * K, 1, loss, nvalid);
     return launch_status();
 }
@@ -265,7 +297,7 @@ extern "C" int lp_unimodal_mse_bwd(const float* kp_aug, const float* pred, int S
     const float* nvalid = (const float*)(valid + (size_t)S * K);
     GaussSpec g = make_spec(img_h, img_w, h, w, sigma);
     hipLaunchKernelGGL((hm_grad_kernel<true>), dim3(S * K), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, pred, kp_aug, g,
-                       valid, nvalid, gout, gpred, accumulate);
+                       (int)LP_HM_MSE, valid, nvalid, gout, gpred, accumulate);
     return launch_status();
 }
 

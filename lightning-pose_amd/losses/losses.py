@@ -73,6 +73,24 @@ class HeatmapMSELoss(HeatmapLoss):
         return ops.heatmap_mse(targets, predictions)
 
 
+class HeatmapKLLoss(HeatmapLoss):
+    """mean over labelled maps of KL(target || prediction) summed over the map, both + 1e-10 (reference :338-379)."""
+
+    loss_name = "heatmap_kl"
+
+    def compute(self, targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+        return ops.heatmap_kl(targets, predictions)
+
+
+class HeatmapJSLoss(HeatmapLoss):
+    """mean over labelled maps of the Jensen-Shannon divergence of target and prediction (reference :382-423)."""
+
+    loss_name = "heatmap_js"
+
+    def compute(self, targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+        return ops.heatmap_js(targets, predictions)
+
+
 class TemporalLoss(Loss):
     """mean over (S-1) x K of relu(||kp[t+1] - kp[t]|| - eps_k), zeroed next to low-confidence frames (reference :576-703)."""
 

@@ -167,16 +167,19 @@ def generate_heatmaps(keypoints: torch.Tensor, height: int, width: int, output_s
     return out
 
 
-class _HeatmapMSEFn(torch.autograd.Function):
+class _HeatmapLossFn(torch.autograd.Function):
+    """masked mean over the labelled maps of a per-map sum: kind = HM_MSE / HM_KL / HM_JS"""
+
     @staticmethod
-    def forward(ctx, targ, pred):
+    def forward(ctx, targ, pred, kind):
         require_device(targ, pred)
         targ, pred = _f32c(targ), pred.contiguous()
         b, k, h, w = pred.shape
         ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(b, k), device=pred.device, dtype=torch.uint8)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
-        check(_lib.lib().lp_heatmap_mse_fwd(_p(targ), _p(pred), b, k, h, w, _p(loss), _p(ws), _stream()), "lp_heatmap_mse_fwd")
+        check(_lib.lib().lp_heatmap_loss_fwd(kind, _p(targ), _p(pred), b, k, h, w, _p(loss), _p(ws), _stream()), "lp_heatmap_loss_fwd")
         ctx.save_for_backward(targ, pred, ws)
+        ctx.kind = kind
         return loss.reshape(())
 
     @staticmethod
@@ -185,13 +188,21 @@ class _HeatmapMSEFn(torch.autograd.Function):
         b, k, h, w = pred.shape
         g = torch.empty_like(pred)
         go = _f32c(gout).reshape(1)
-        check(_lib.lib().lp_heatmap_mse_bwd(_p(targ), _p(pred), b, k, h, w, _p(ws), _p(go), _p(g), 0, _stream()),
-              "lp_heatmap_mse_bwd")
-        return None, g
+        check(_lib.lib().lp_heatmap_loss_bwd(ctx.kind, _p(targ), _p(pred), b, k, h, w, _p(ws), _p(go), _p(g), 0, _stream()),
+              "lp_heatmap_loss_bwd")
+        return None, g, None
 
 
 def heatmap_mse(targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
-    return _HeatmapMSEFn.apply(targets, predictions)
+    return _HeatmapLossFn.apply(targets, predictions, _lib.HM_MSE)
+
+
+def heatmap_kl(targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+    return _HeatmapLossFn.apply(targets, predictions, _lib.HM_KL)
+
+
+def heatmap_js(targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
+    return _HeatmapLossFn.apply(targets, predictions, _lib.HM_JS)
 
 
 class _UnimodalFn(torch.autograd.Function):

@@ -158,6 +158,18 @@ def heatmap_mse(targ, pred, gout=1.0):
     return loss.np()[0], g.np()
 
 
+def heatmap_div(kind, targ, pred, gout=1.0):
+    """kind: _lib.HM_KL / _lib.HM_JS (or HM_MSE) -> (loss, grad wrt pred)"""
+    targ, pred = f32(targ), f32(pred)
+    b, k, h, w = pred.shape
+    tb, pb = Buf(targ), Buf(pred)
+    ws = Z(lib().lp_heatmap_mse_workspace_bytes(b, k), np.uint8)
+    loss, g, go = Z(1), Z(pred.shape), Buf(f32([gout]))
+    ok(lib().lp_heatmap_loss_fwd(kind, tb.p, pb.p, b, k, h, w, loss.p, ws.p, stream()))
+    ok(lib().lp_heatmap_loss_bwd(kind, tb.p, pb.p, b, k, h, w, ws.p, go.p, g.p, 0, stream()))
+    return loss.np()[0], g.np()
+
+
 def unimodal_mse(kp_aug, pred, conf, img_h, img_w, thr, sigma=1.25, gout=1.0):
     kp_aug, pred, conf = f32(kp_aug), f32(pred), f32(conf)
     s, k, h, w = pred.shape

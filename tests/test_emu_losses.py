@@ -27,6 +27,21 @@ def test_heatmap_mse_golden_and_grad(golden):
     np.testing.assert_allclose(grad, p.grad.numpy(), atol=1e-7, rtol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["heatmap_kl", "heatmap_js"])
+def test_heatmap_divergences_golden_and_grad(golden, name):
+    """HeatmapKLLoss / HeatmapJSLoss: value vs the golden of the verbatim reference classes, gradient vs autograd through the
+    restated kornia divergences"""
+    from lightning_pose_amd import _lib
+    g = golden("losses")
+    kind = _lib.HM_KL if name == "heatmap_kl" else _lib.HM_JS
+    loss, grad = emu.heatmap_div(kind, g["hm_targ"], g["hm_pred"], gout=0.7)
+    assert loss == pytest.approx(float(g[name]), rel=2e-5, abs=1e-7)
+    p = g.t("hm_pred").clone().requires_grad_(True)
+    fn = O.heatmap_kl_loss if name == "heatmap_kl" else O.heatmap_js_loss
+    (0.7 * fn(g.t("hm_targ"), p)).backward()
+    np.testing.assert_allclose(grad, p.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
 def test_heatmap_mse_all_invalid_is_nan():
     t = np.zeros((2, 2, 8, 8), np.float32)
     loss, _ = emu.heatmap_mse(t, np.full_like(t, 0.1))

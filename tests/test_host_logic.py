@@ -125,8 +125,9 @@ def test_registry_surface_and_validation():
     facs["unsupervised"].loss_instance_dict["bad"] = NeedsMissing()
     with pytest.raises(ValueError, match="embedding"):
         _validate_loss_model_compatibility(SemiSupervisedHeatmapTracker, facs)
+    assert {"heatmap_kl", "heatmap_js"} <= set(get_loss_classes())
     with pytest.raises(NotImplementedError):
-        LossFactory({"heatmap_kl": {"log_weight": 0.0}}, None)
+        LossFactory({"temporal_heatmap_mse": {"log_weight": 0.0}}, None)
     # constructor signature of the reference classes is preserved
     sig = inspect.signature(SemiSupervisedHeatmapTracker.__init__)
     for name in ("num_keypoints", "loss_factory", "loss_factory_unsupervised", "backbone", "downsample_factor", "pretrained",
