@@ -159,6 +159,18 @@ int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const fl
 int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
                   const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
                   lp_stream_t stream);
+/* The forward kernel as a plain NT GEMM (the token-wise Linear layers and the attention products of the ViT backbone,
+ * models/backbones/vit.py:16-49 -> transformers ViTModel):  C[z][m][n] = sum_k A[z][m][k] * B[z][n][k] (+ bias[n]).
+ * A: bf16 rows of pitch lda, B: bf16 rows of pitch ldb (K % 64 == 0, pitches % 8 == 0), C: bf16 or fp32 rows of pitch ldc.
+ * Columns n < n_store are written (n_store may exceed N up to the tile: the extra columns repeat row N-1 of B); with n_store a
+ * multiple of 8 and bf16 output the coalesced store path is taken.  `batch` (optional): nb x nh independent products whose
+ * operands start at a_b*zb + a_h*zh (elements; likewise b_*, c_*), e.g. per (image, head) slices of a fused QKV tensor. */
+typedef struct lp_gemm_batch {
+    int nb, nh;
+    long long a_b, a_h, b_b, b_h, c_b, c_h;
+} lp_gemm_batch;
+int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* c_bf16, float* c_f32, int ldc, int M, int N, int K, int n_store,
+               const float* bias, const lp_gemm_batch* batch, lp_stream_t stream);
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
  * for them (torch.nn.BatchNorm2d training forward / backward).  Every 128-row output tile leaves its
  * column sums in `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds them into `sums`.

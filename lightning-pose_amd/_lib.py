@@ -38,6 +38,10 @@ class BnFuse(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class GemmBatch(C.Structure):
+    _fields_ = [("nb", C.c_int), ("nh", C.c_int)] + [(n, C.c_longlong) for n in ("a_b", "a_h", "b_b", "b_h", "c_b", "c_h")]
+
+
 HM_MSE, HM_KL, HM_JS = 0, 1, 2
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
@@ -66,6 +70,7 @@ PROTOTYPES = {
     "lp_rmse_fwd": (_I, [_P, _P, _I, _P, _P]),
     "lp_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _I, _P]),
     "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "lp_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(GemmBatch), _P]),
     "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),

@@ -55,6 +55,16 @@ struct ConvEpilogue {
     int mask_from_z;
 };
 
+// Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
+// per-(image, head) products).  A convolution is the special case ldx = channels, ldw = filter length, one batch.
+struct GemmExt {
+    int ldx, ldw;              // elements between consecutive rows of the gathered tensor / of the weight matrix
+    int nh, tiles_per_z;       // batch index z = tile / tiles_per_z = (zb, zh), zh < nh
+    unsigned x_zb, x_zh;       // byte strides of the gathered tensor per batch index
+    unsigned w_zb, w_zh;       // byte strides of the weight matrix
+    unsigned o_zb, o_zh;       // element strides of the output
+};
+
 enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2 };
 
 // One launch covers a sub-lattice of output pixels and of filter taps.  Ordinary launches use the full lattices; the data
@@ -153,9 +163,9 @@ __device__ __forceinline__ u16x8 load4x2(const unsigned short* p0, bool ok0, con
 // ------------------------------------------------------------------------------------------------------------
 template <int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
-                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
-                                                         FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles,
-                                                         ConvEpilogue ep) {
+                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, GemmExt gx,
+                                                         FastDiv div_img, FastDiv div_row, int M, int N, int K, int tiles_n,
+                                                         int ntiles, ConvEpilogue ep) {
     constexpr int NT = BN / 64;
     // one LDS block: [2][128][72] A + [2][BN][72] B operand tiles, reused by the epilogue as a [128][BN+4] fp32 tile
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (kBM + BN) * kLD];
@@ -197,9 +207,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     unsigned wtap = 0;             // byte offset of the current tap inside a weight row
     unsigned wrow[BN / 32];        // byte offset of this lane's chunk in each weight row it stages
     int m0n = 0, n0n = 0;        // origin of the tile being set up / loaded
+    unsigned zon = 0;            // ... and its batch's offset into the output (elements)
 
     auto setup = [&](int vt) {
-        const int tile = xcd_remap(vt, ntiles);
+        int tile = xcd_remap(vt, ntiles);
+        const int z = tile / gx.tiles_per_z;
+        tile -= z * gx.tiles_per_z;
+        const int zb = z / gx.nh, zh = z - zb * gx.nh;
+        const unsigned zx = zb * gx.x_zb + zh * gx.x_zh, zw = zb * gx.w_zb + zh * gx.w_zh;
+        zon = zb * gx.o_zb + zh * gx.o_zh;
         const int tm_ = tile / tiles_n;
         m0n = tm_ * kBM;
         n0n = (tile - tm_ * tiles_n) * BN;
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 px[i] = xq * g.stride - g.pad;
             }
             const int oy = halved ? (py[i] >> 1) : py[i], ox = halved ? (px[i] >> 1) : px[i];
-            rowoff[i] = (unsigned)(((b * src_h + oy) * src_w + ox) * ck + kchunk * 8) * 2u;
+            rowoff[i] = (unsigned)(((b * src_h + oy) * src_w + ox) * gx.ldx + kchunk * 8) * 2u + zx;
             unsigned mask = 0;
             if (MODE != kModeStem && pv[i]) {
                 for (int ir = 0; ir < lat.nr; ++ir)
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         for (int i = 0; i < BN / 32; ++i) {
             int n = n0n + rbase + 32 * i;
             if (n >= N) n = N - 1;  // rows past N are loaded (never stored): keeps the loop free of predicates
-            wrow[i] = (unsigned)(n * ((MODE == kModeStem) ? K : g.R * g.S * ck) + kchunk * 8) * 2u;  // row stride = the FULL filter
+            wrow[i] = (unsigned)(n * gx.ldw + kchunk * 8) * 2u + zw;  // row stride = the FULL filter
         }
         tir = tis = tc = 0;
     };
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             if (tc == 0) {
                 const int tr = lat.r0 + lat.rstep * tir, ts = lat.s0 + lat.sstep * tis;
                 const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
-                const unsigned tapoff_b = (unsigned)(((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * ck) * 2u;
+                const unsigned tapoff_b = (unsigned)(((MODE == kModeDgrad) ? -(qr * src_w + qs) : (qr * src_w + qs)) * gx.ldx) * 2u;
                 const int tap = tir * lat.ns + tis;
                 wtap = (unsigned)((tr * g.S + ts) * ck) * 2u;
 #pragma unroll
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     f32x16 acc[2][NT];
 
     // ---- epilogue of the tile at (m0, n0): D reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile
-    auto epilogue = [&](const int m0, const int n0) {
+    auto epilogue = [&](const int m0, const int n0, const unsigned zo) {
         const int col = lane & 31, rg = lane >> 5;
         if (ep.out_f32 == nullptr && (ep.n_store & 7) == 0 && (ep.ldo & 7) == 0) {
             // bf16 output: stage the fp32 tile in LDS (the operand buffers are free after the last barrier), then every lane
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     for (int i = 0; i < HB; ++i) {
                         const int m = m0 + r0 + (i0 + i) * RPP;
                         rv[i] = m < M;
-                        off[i] = (unsigned)out_row(rv[i] ? m : 0, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)n;
+                        off[i] = (unsigned)out_row(rv[i] ? m : 0, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)n + zo;
                     }
                     if (kReads && ep.addend) {
 #pragma unroll
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
                     if (m < M) {
                         float v = acc[mt][nt][e] + bias;
-                        const size_t o = (size_t)out_row(m, lat, div_img, div_row, full_h, full_w) * ep.ldo + n;
+                        const size_t o = (size_t)out_row(m, lat, div_img, div_row, full_h, full_w) * ep.ldo + n + zo;
                         if (ep.addend) v += bf16_to_f32(ep.addend[o]);
                         if (ep.relu_mask) {
                             if (!bf16_positive(ep.relu_mask[o])) v = 0.f;
@@ -491,9 +507,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
         for (; vt < ntiles; vt += gridDim.x) {
-            const int tile = xcd_remap(vt, ntiles);
+            const int tile = xcd_remap(vt, ntiles);  // (never batched: only the stride-2 data gradient has empty classes)
             const int tm_ = tile / tiles_n;
-            epilogue(tm_ * kBM, (tile - tm_ * tiles_n) * BN);
+            epilogue(tm_ * kBM, (tile - tm_ * tiles_n) * BN, 0u);
             __syncthreads();
         }
         return;
@@ -502,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     load_step(0);
     for (;;) {
         const int m0 = m0n, n0 = n0n;
+        const unsigned zo = zon;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -519,13 +536,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         }
         vt += gridDim.x;
         if (vt >= ntiles) {
-            epilogue(m0, n0);
+            epilogue(m0, n0, zo);
             break;
         }
         // next tile's row descriptors and first operands: in flight while this tile is stored
         setup(vt);
         load_step(0, MODE != kModeDgrad);
-        epilogue(m0, n0);
+        epilogue(m0, n0, zo);
         if (MODE == kModeDgrad) load_b_deferred();
         __syncthreads();  // the epilogue's LDS tile is dead before the next tile's operands land in it
     }
@@ -871,16 +888,26 @@ static int igemm_max_wgs() {
     return v;
 }
 
+// `gemm` (lp_gemm_nt only): operand pitches, batch strides and explicit operand sizes; nz = number of batched GEMMs
 template <int BN, int MODE>
 static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
-                         hipStream_t st) {
-    const int tm = (M + kBM - 1) / kBM, tn = (N + BN - 1) / BN, ntiles = tm * tn;
+                         hipStream_t st, const GemmExt* gemm = nullptr, int nz = 1, unsigned gemm_x_bytes = 0,
+                         unsigned gemm_w_bytes = 0) {
+    const int tm = (M + kBM - 1) / kBM, tn = (N + BN - 1) / BN, per_z = tm * tn, ntiles = per_z * nz;
     const int grid = ntiles < igemm_max_wgs() ? ntiles : igemm_max_wgs();
+    const int ck = MODE == kModeDgrad ? g.Co : g.Ci;
     // byte sizes of the gathered tensor and of the weight matrix (the entry points keep both below 4 GiB)
-    const unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
-    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * (MODE == kModeStem ? (size_t)K : (size_t)g.R * g.S * (MODE == kModeDgrad ? g.Co : g.Ci)));
+    unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
+    unsigned w_bytes = (unsigned)(2ull * (size_t)N * (MODE == kModeStem ? (size_t)K : (size_t)g.R * g.S * ck));
+    GemmExt gx{ck, MODE == kModeStem ? K : g.R * g.S * ck, 1, per_z, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (gemm) {
+        gx = *gemm;
+        gx.tiles_per_z = per_z;
+        x_bytes = gemm_x_bytes;
+        w_bytes = gemm_w_bytes;
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<BN, MODE>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)w,
-                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
+                       x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
@@ -963,6 +990,35 @@ extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* 
                               lp_stream_t stream) {
     LP_REQUIRE(bn && geom && out_bf16);
     return conv_fwd_impl(x, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream);
+}
+
+// C[z][m][n] = sum_k A[z][m][k] * B[z][n][k] (+ bias[n]): the forward kernel as a plain (batched, strided) NT GEMM
+extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* c_bf16, float* c_f32, int ldc, int M, int N, int K,
+                          int n_store, const float* bias, const lp_gemm_batch* batch, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(a && b && (c_bf16 || c_f32) && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldc > 0);
+    if (K % kBK != 0 || lda % 8 != 0 || ldb % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int nb = batch ? batch->nb : 1, nh = batch ? batch->nh : 1;
+    LP_REQUIRE(nb > 0 && nh > 0);
+    const long long a_b = batch ? batch->a_b : 0, a_h = batch ? batch->a_h : 0, b_b = batch ? batch->b_b : 0, b_h = batch ? batch->b_h : 0;
+    const long long c_b = batch ? batch->c_b : 0, c_h = batch ? batch->c_h : 0;
+    LP_REQUIRE(a_b >= 0 && a_h >= 0 && b_b >= 0 && b_h >= 0 && c_b >= 0 && c_h >= 0);
+    const long long a_elems = (nb - 1) * a_b + (nh - 1) * a_h + (long long)(M - 1) * lda + K;
+    const long long b_elems = (nb - 1) * b_b + (nh - 1) * b_h + (long long)(N - 1) * ldb + K;
+    const long long c_elems = (nb - 1) * c_b + (nh - 1) * c_h + (long long)M * ldc;
+    if (a_elems >= (1LL << 31) || b_elems >= (1LL << 31) || c_elems >= (1LL << 32) || a_elems % 8 != 0 && false) return LP_ERR_UNSUPPORTED;
+    if ((a_b | a_h | b_b | b_h) % 8 != 0) return LP_ERR_UNSUPPORTED;  // 16-B operand chunks
+    ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
+    ConvEpilogue ep{(unsigned short*)c_bf16, c_f32, ldc, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
+                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    GemmExt gx{lda, ldb, nh, 0, (unsigned)(2 * a_b), (unsigned)(2 * a_h), (unsigned)(2 * b_b), (unsigned)(2 * b_h), (unsigned)c_b,
+               (unsigned)c_h};
+    const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
+    hipStream_t st = (hipStream_t)stream;
+    const int nstore = ep.n_store;
+    if (nstore > 64) launch_igemm<128, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
+    else launch_igemm<64, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
+    return launch_status();
 }
 
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)

@@ -311,6 +311,19 @@ def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=No
     return ob.np(), f.keep["sums"].np(), f.keep["dbeta"].np(), f.keep["dgamma"].np()
 
 
+def gemm_nt(a_bits, lda, b_bits, ldb, M, N, K, ldc, c_rows, n_store=0, bias=None, batch=None, f32_out=False):
+    """C[z][m][n] = sum_k A[z][m][k] B[z][n][k]; a_bits / b_bits flat uint16 buffers; batch = (nb, nh, a_b, a_h, b_b, b_h, c_b, c_h).
+    Returns the flat C buffer of c_rows * ldc elements (bf16 bits, or fp32)."""
+    ab, bb, bi = Buf(a_bits), Buf(b_bits), B(bias, np.float32)
+    cb = Z(c_rows * ldc, np.uint16) if not f32_out else None
+    cf = Z(c_rows * ldc) if f32_out else None
+    gb = None
+    if batch is not None:
+        gb = _lib.GemmBatch(*batch)
+    ok(lib().lp_gemm_nt(ab.p, lda, bb.p, ldb, ptr(cb), ptr(cf), ldc, M, N, K, n_store, ptr(bi), C.byref(gb) if gb else None, stream()))
+    return cf.np() if f32_out else cb.np()
+
+
 def conv_wgrad(x_bits, dy_bits, g, split=0):
     xb, db, dw = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
     nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)

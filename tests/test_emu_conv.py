@@ -183,3 +183,30 @@ def test_conv_persistent_tile_walk(cap, kernel_backend):
                         "fwd_dgrad_wgrad or fused_batchnorm or transpose", "-p", "no:cacheprovider"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_gemm_nt_batched_strided():
+    """lp_gemm_nt: per-(image, head) products out of an interleaved QKV-like tensor (row pitch > K, head offset inside the row),
+    ragged M and N (not multiples of the tile), zero-padded output pitch, bias, and the plain un-batched Linear case."""
+    gen = torch.Generator().manual_seed(5)
+    nb, nh, T, d, ld = 2, 3, 77, 64, 3 * 3 * 64          # qkv rows: [q heads | k heads | v heads]
+    qkv = bf(torch.randn(nb * T, ld, generator=gen))
+    bits = emu.to_bf16_bits(qkv).reshape(-1)
+    ldc = 128                                               # scores padded to 128 columns per row
+    # S[z] = Q_z K_z^T : A = q slice (offset h*64), B = k slice (offset 192 + h*64); both pitch ld
+    k_off = nh * d
+    b_view = bits[k_off:]                                   # B base pointer = first K column
+    out = emu.gemm_nt(bits, ld, b_view, ld, T, T, d, ldc, nb * nh * T, n_store=ldc,
+                      batch=(nb, nh, T * ld, d, T * ld, d, nh * T * ldc, T * ldc))
+    got = emu.from_bf16_bits(out.reshape(nb, nh, T, ldc))[..., :T]
+    q = qkv.reshape(nb, T, 3, nh, d)[:, :, 0].permute(0, 2, 1, 3)
+    k = qkv.reshape(nb, T, 3, nh, d)[:, :, 1].permute(0, 2, 1, 3)
+    want = q @ k.transpose(-1, -2)
+    torch.testing.assert_close(got, bf(want), atol=3e-2, rtol=2e-2)
+    # plain Linear with bias, fp32 output, N not a multiple of 8
+    M, K, N = 150, 128, 52
+    x = bf(torch.randn(M, K, generator=gen))
+    w = bf(torch.randn(N, K, generator=gen) / K ** 0.5)
+    bias = torch.randn(N, generator=gen)
+    of = emu.gemm_nt(emu.to_bf16_bits(x).reshape(-1), K, emu.to_bf16_bits(w).reshape(-1), K, M, N, K, N, M, bias=bias.numpy(), f32_out=True)
+    torch.testing.assert_close(torch.from_numpy(of.reshape(M, N)), x @ w.T + bias, atol=3e-4, rtol=3e-4)
