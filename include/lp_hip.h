@@ -235,6 +235,35 @@ int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_
 int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int inverse, void* out, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * ViT-S/16 backbone glue (models/backbones/vit.py:16-49 -> transformers ViTModel; backbone = "vits_dino",
+ * models/backbones/factory.py:188-190).  The Linear layers and attention products run on lp_gemm_nt / lp_conv_wgrad.
+ * Residual stream and statistics fp32, GEMM operands bf16.
+ * ------------------------------------------------------------------------------------------------------ */
+/* (B,3,H,W) fp32 -> [B*(H/P)*(W/P)][3*P*P] bf16 patch rows, k = (c, ky, kx) (= Conv2d weight.flatten(1)) */
+int lp_vit_patchify(const float* images_nchw, int B, int H, int W, int patch, void* out_bf16, lp_stream_t stream);
+/* x[b][0] = cls + pos[0], x[b][1+p] = patch[b][p] + pos[1+p]  (pos already interpolated, (1+Np, D) fp32) */
+int lp_vit_tokens_fwd(const void* patch_bf16, const float* cls, const float* pos, int B, int Np, int D, float* x, lp_stream_t stream);
+/* dpatch = bf16(dx[:, 1:]);  dpos[t] = sum_b dx[b][t]  (d cls = dpos[0]) */
+int lp_vit_tokens_bwd(const float* dx, int B, int Np, int D, void* dpatch_bf16, float* dpos, lp_stream_t stream);
+/* y (R,D) (+)= w (R,Q) @ x (Q,D), or with transpose_w: y (Q,D) (+)= w^T @ x (R,D): bicubic position-embedding interpolation */
+int lp_small_matmul(const float* w, const float* x, int R, int Q, int D, int transpose_w, int accumulate, float* y, lp_stream_t stream);
+/* x_out = x (+ delta_bf16);  y = LayerNorm(x_out) in bf16;  drop_T > 0: rows with row % drop_T == 0 ([CLS]) are dropped from y and
+ * the rest compacted (the (B, h, w, D) feature map).  x_out may alias x; mean / rstd (M,) are kept for the backward pass. */
+int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x_out, const float* gamma, const float* beta, float eps, int M,
+                     int D, int drop_T, void* y_bf16, float* mean, float* rstd, lp_stream_t stream);
+/* dx_acc += LayerNorm backward of dy (bf16, same row mapping as y);  dgamma_acc / dbeta_acc accumulate too */
+int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                     int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
+int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream);                       /* exact (erf) GELU */
+int lp_gelu_bwd(const void* x_bf16, const void* dy_bf16, size_t n, void* dx_bf16, lp_stream_t stream);
+/* in place: s[r][:n] = softmax(scale * s[r][:n]), s[r][n:ld] = 0   /   dp <- scale * p * (dp - sum(dp * p)) */
+int lp_softmax_rows_fwd(void* s_bf16, int rows, int n, int ld, float scale, lp_stream_t stream);
+int lp_softmax_rows_bwd(const void* p_bf16, void* dp_bf16, int rows, int n, int ld, float scale, lp_stream_t stream);
+/* out[z][c][r] = in[z][r][c] (r < R, c < Cc), out[z][c][R:ldo] = 0;  z = (zb, zh) with element strides */
+int lp_transpose_batched(const void* in_bf16, int R, int Cc, int ldi, long long in_b, long long in_h, void* out_bf16, int ldo,
+                         long long out_b, long long out_h, int nb, int nh, lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.Adam / AdamW semantics (models/base.py:458-479) over one flat fp32 range, also emitting
  * the bf16 copy the GEMMs read.  lr may be 0 (frozen backbone, callbacks.py:79-196): moments still move.
  * ------------------------------------------------------------------------------------------------------ */

@@ -88,6 +88,17 @@ PROTOTYPES = {
     "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "lp_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
     "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "lp_vit_patchify": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "lp_vit_tokens_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "lp_vit_tokens_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "lp_small_matmul": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "lp_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P]),
+    "lp_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "lp_gelu_fwd": (_I, [_P, _Z, _P, _P]),
+    "lp_gelu_bwd": (_I, [_P, _P, _Z, _P, _P]),
+    "lp_softmax_rows_fwd": (_I, [_P, _I, _I, _I, _F, _P]),
+    "lp_softmax_rows_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P]),
+    "lp_transpose_batched": (_I, [_P, _I, _I, _I, C.c_longlong, C.c_longlong, _P, _I, C.c_longlong, C.c_longlong, _I, _I, _P]),
     "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
     "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),
     "lp_permute_cba": (_I, [_P, _I, _I, _I, _P, _P]),

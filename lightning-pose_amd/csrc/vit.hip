@@ -1,0 +1,460 @@
+// Glue of the ViT-S/16 backbone between its GEMMs (which run on lp_gemm_nt / lp_conv_wgrad): patch extraction, token
+// assembly with interpolated position embeddings, LayerNorm, GELU, attention soft-max, batched transposes.  gfx950.
+//
+// Replaces the HuggingFace `ViTModel` called by `VisionEncoder.forward` (lightning_pose/models/backbones/vit.py:16-49,
+// selected by backbone = "vits_dino", models/backbones/factory.py:188-190):
+//   ViTEmbeddings (patch projection 16x16/16, [CLS], bicubic-interpolated position embeddings), 12 x ViTLayer
+//   (LayerNorm -> 6-head self-attention -> residual -> LayerNorm -> MLP with exact GELU -> residual), final LayerNorm.
+// Policy (bf16-mixed): the residual stream, LayerNorm statistics and all reductions are fp32;
+// GEMM operands are bf16.  Every kernel here is an HBM-bound stream or a per-row reduction.
+#include "lp_common.h"
+
+namespace lp {
+
+__device__ __forceinline__ void unpack8v(const u16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32(v[i]);
+}
+
+// ---- images (B,3,H,W) fp32 -> patch rows [B * (H/P) * (W/P)][3*P*P] bf16, k = (c, ky, kx) as Conv2d's weight.flatten(1) ---
+__global__ __launch_bounds__(256) void vit_patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P,
+                                                           unsigned short* __restrict__ out) {
+    const int gw = W / P, gh = H / P, kdim = 3 * P * P, chunks = kdim >> 3;
+    const size_t total = (size_t)B * gh * gw * chunks;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        size_t p = q / chunks;
+        const int px = (int)(p % gw);
+        p /= gw;
+        const int py = (int)(p % gh), b = (int)(p / gh);
+        const int k = ch * 8, c = k / (P * P), ky = (k - c * P * P) / P, kx = k % P;  // 8 consecutive kx (P % 8 == 0)
+        const float* src = img + (((size_t)b * 3 + c) * H + py * P + ky) * W + px * P + kx;
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = src[i];
+        *reinterpret_cast<u16x8*>(out + q * 8) = pack_bf16x8(f);
+    }
+}
+
+// ---- tokens: x[b][0] = cls + pos[0];  x[b][1+p] = patch[b][p] + pos[1+p]   (fp32 residual stream) ------------------
+__global__ __launch_bounds__(256) void vit_tokens_fwd_kernel(const unsigned short* __restrict__ patch, const float* __restrict__ cls,
+                                                             const float* __restrict__ pos, int B, int Np, int D,
+                                                             float* __restrict__ x) {
+    const int T = Np + 1, chunks = D >> 3;
+    const size_t total = (size_t)B * T * chunks;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        const size_t row = q / chunks;
+        const int t = (int)(row % T), b = (int)(row / T);
+        float v[8];
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = cls[ch * 8 + i];
+        } else {
+            unpack8v(*reinterpret_cast<const u16x8*>(patch + ((size_t)b * Np + t - 1) * D + ch * 8), v);
+        }
+        float* dst = x + row * D + ch * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = v[i] + pos[t * D + ch * 8 + i];
+    }
+}
+
+// backward: dpatch[b][p] = bf16(dx[b][1+p]);  dpos[t] = sum_b dx[b][t]  (d cls = dpos[0])
+__global__ __launch_bounds__(256) void vit_tokens_bwd_kernel(const float* __restrict__ dx, int B, int Np, int D,
+                                                             unsigned short* __restrict__ dpatch, float* __restrict__ dpos) {
+    const int T = Np + 1, chunks = D >> 3;
+    const int total = T * chunks;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
+        const int ch = q % chunks, t = q / chunks;
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* src = dx + ((size_t)b * T + t) * D + ch * 8;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = src[i];
+                s[i] += v[i];
+            }
+            if (t > 0) *reinterpret_cast<u16x8*>(dpatch + ((size_t)b * Np + t - 1) * D + ch * 8) = pack_bf16x8(v);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dpos[t * D + ch * 8 + i] = s[i];
+    }
+}
+
+// ---- Y[r][d] (+)= sum_q Wm[r][q] X[q][d]  (or Wm^T): the position-embedding interpolation and its adjoint (tiny) ------
+__global__ __launch_bounds__(256) void small_matmul_kernel(const float* __restrict__ Wm, const float* __restrict__ X, int R, int Q, int D,
+                                                           int transpose_w, int accumulate, float* __restrict__ Y) {
+    const int rows = transpose_w ? Q : R, inner = transpose_w ? R : Q;
+    const int total = rows * D;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int d = i % D, r = i / D;
+        float a = 0.f;
+        for (int k = 0; k < inner; ++k) a = fmaf(transpose_w ? Wm[k * Q + r] : Wm[r * Q + k], X[k * D + d], a);
+        Y[i] = accumulate ? Y[i] + a : a;
+    }
+}
+
+// ---- LayerNorm over D (one wave per row, D <= 64 * 16), optional residual add in front ------------------------------
+// x_out = x (+ delta);  y = (x_out - mean) * rstd * gamma + beta.  `drop_T` > 0: rows with (row % drop_T) == 0 ([CLS]) are
+// not written to y and the others are compacted (the feature map the head consumes).
+constexpr int kLnMax = 16;  // fp32 values per lane
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const unsigned short* __restrict__ delta,
+                                                            float* __restrict__ x_out, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int M, int D, int drop_T,
+                                                            unsigned short* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (D + 63) / 64;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        float v[kLnMax];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMax; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = 0.f;
+            if (i < per && c < D) {
+                v[i] = x[(size_t)row * D + c];
+                if (delta != nullptr) v[i] += bf16_to_f32(delta[(size_t)row * D + c]);
+                s += v[i];
+            }
+        }
+        const float mu = wave_sum(s) / (float)D;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMax; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < D) {
+                const float d = v[i] - mu;
+                ss = fmaf(d, d, ss);
+            }
+        }
+        const float rs = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+        int yrow = row;
+        bool wy = true;
+        if (drop_T > 0) {
+            const int b = row / drop_T, t = row - b * drop_T;
+            wy = t > 0;
+            yrow = b * (drop_T - 1) + t - 1;
+        }
+#pragma unroll
+        for (int i = 0; i < kLnMax; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < D) {
+                if (x_out != nullptr) x_out[(size_t)row * D + c] = v[i];
+                if (wy) y[(size_t)yrow * D + c] = f32_to_bf16(fmaf((v[i] - mu) * rs, gamma[c], beta[c]));
+            }
+        }
+    }
+}
+
+// dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-workgroup partial d gamma / d beta -> atomics
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, int M, int D, int drop_T,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+    __shared__ float red[2][4][64 * kLnMax / 4];  // [gamma|beta][wave][column slot]  (D <= 1024 -> per <= 16; sized for D <= 1024)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (D + 63) / 64;
+    float ag[kLnMax], ab[kLnMax];
+#pragma unroll
+    for (int i = 0; i < kLnMax; ++i) ag[i] = ab[i] = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        int yrow = row;
+        bool has = true;
+        if (drop_T > 0) {
+            const int b = row / drop_T, t = row - b * drop_T;
+            has = t > 0;
+            yrow = b * (drop_T - 1) + t - 1;
+        }
+        const float mu = mean[row], rs = rstd[row];
+        float g[kLnMax], xh[kLnMax];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMax; ++i) {
+            const int c = lane + 64 * i;
+            g[i] = xh[i] = 0.f;
+            if (i < per && c < D) {
+                const float d = has ? bf16_to_f32(dy[(size_t)yrow * D + c]) : 0.f;
+                xh[i] = (x[(size_t)row * D + c] - mu) * rs;
+                ag[i] = fmaf(d, xh[i], ag[i]);
+                ab[i] += d;
+                g[i] = d * gamma[c];
+                s1 += g[i];
+                s2 = fmaf(g[i], xh[i], s2);
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < kLnMax; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < D) dx[(size_t)row * D + c] += rs * (g[i] - s1 - xh[i] * s2);
+        }
+    }
+    // column sums of this workgroup: 4 waves -> LDS -> one atomic per column
+    for (int i0 = 0; i0 < per; i0 += 4) {  // 4 column slots (256 columns) at a time through the LDS scratch
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < per && i0 + j < kLnMax) {
+                red[0][wave][j * 64 + lane] = ag[i0 + j];
+                red[1][wave][j * 64 + lane] = ab[i0 + j];
+            }
+        }
+        __syncthreads();
+        const int j = threadIdx.x >> 6, l = threadIdx.x & 63;  // thread -> (slot j, lane l)
+        if (i0 + j < per) {
+            const int c = l + 64 * (i0 + j);
+            if (c < D) {
+                const float tg = (red[0][0][j * 64 + l] + red[0][1][j * 64 + l]) + (red[0][2][j * 64 + l] + red[0][3][j * 64 + l]);
+                const float tb = (red[1][0][j * 64 + l] + red[1][1][j * 64 + l]) + (red[1][2][j * 64 + l] + red[1][3][j * 64 + l]);
+                atomicAdd(&dgamma[c], tg);
+                atomicAdd(&dbeta[c], tb);
+            }
+        }
+    }
+}
+
+// ---- GELU (exact, erf) on bf16 streams --------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const unsigned short* __restrict__ x, size_t n_chunks, unsigned short* __restrict__ y) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
+        float v[8];
+        unpack8v(*reinterpret_cast<const u16x8*>(x + q * 8), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+        *reinterpret_cast<u16x8*>(y + q * 8) = pack_bf16x8(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                       size_t n_chunks, unsigned short* __restrict__ dx) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
+        float v[8], d[8];
+        unpack8v(*reinterpret_cast<const u16x8*>(x + q * 8), v);
+        unpack8v(*reinterpret_cast<const u16x8*>(dy + q * 8), d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] *= gelu_df(v[i]);
+        *reinterpret_cast<u16x8*>(dx + q * 8) = pack_bf16x8(d);
+    }
+}
+
+// ---- attention soft-max over the n valid columns of bf16 rows of pitch ld, in place; pad columns are zeroed ---------------
+constexpr int kSmMax = 16;  // columns per lane: ld <= 1024
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(unsigned short* __restrict__ s, int rows, int n, int ld, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (ld + 63) / 64;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        unsigned short* p = s + (size_t)row * ld;
+        float v[kSmMax];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kSmMax; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = -INFINITY;
+            if (i < per && c < n) {
+                v[i] = bf16_to_f32(p[c]) * scale;
+                mx = fmaxf(mx, v[i]);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSmMax; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < n) {
+                v[i] = __expf(v[i] - mx);
+                sum += v[i];
+            }
+        }
+        const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < kSmMax; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < ld) p[c] = c < n ? f32_to_bf16(v[i] * inv) : (unsigned short)0;
+        }
+    }
+}
+
+// ds = scale * p * (dp - sum_j dp_j p_j), in place over dp; pad columns zeroed
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const unsigned short* __restrict__ prob, unsigned short* __restrict__ dp,
+                                                               int rows, int n, int ld, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (ld + 63) / 64;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const unsigned short* p = prob + (size_t)row * ld;
+        unsigned short* d = dp + (size_t)row * ld;
+        float pv[kSmMax], dv[kSmMax];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSmMax; ++i) {
+            const int c = lane + 64 * i;
+            pv[i] = dv[i] = 0.f;
+            if (i < per && c < n) {
+                pv[i] = bf16_to_f32(p[c]);
+                dv[i] = bf16_to_f32(d[c]);
+                dot = fmaf(pv[i], dv[i], dot);
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < kSmMax; ++i) {
+            const int c = lane + 64 * i;
+            if (i < per && c < ld) d[c] = c < n ? f32_to_bf16(scale * pv[i] * (dv[i] - dot)) : (unsigned short)0;
+        }
+    }
+}
+
+// ---- batched 2-D transpose of bf16 matrices: out[z][c][r] = in[z][r][c], r < R, c < Cc; out columns [R, ldo) zeroed ----------
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const unsigned short* __restrict__ in, int R, int Cc, int ldi, long long in_b,
+                                                                long long in_h, unsigned short* __restrict__ out, int ldo, long long out_b,
+                                                                long long out_h, int nh) {
+    __shared__ unsigned short tile[64][66];
+    const int z = blockIdx.z, zb = z / nh, zh = z - zb * nh;
+    const unsigned short* src = in + zb * in_b + zh * in_h;
+    unsigned short* dst = out + zb * out_b + zh * out_h;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;  // the output pad region is covered by r tiles up to ldo
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? src[(size_t)r * ldi + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cc && r < ldo) dst[(size_t)c * ldo + r] = tile[tx][i];
+    }
+}
+
+static int vit_grid(size_t work_items) {
+    size_t blocks = (work_items + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return blocks < 1 ? 1 : (int)blocks;
+}
+
+}  // namespace lp
+
+extern "C" int lp_vit_patchify(const float* images, int B, int H, int W, int patch, void* out_bf16, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(images && out_bf16 && B > 0 && H > 0 && W > 0 && patch > 0);
+    if (patch % 8 != 0 || H % patch != 0 || W % patch != 0) return LP_ERR_UNSUPPORTED;
+    const size_t work = (size_t)B * (H / patch) * (W / patch) * (3 * patch * patch / 8);
+    hipLaunchKernelGGL(vit_patchify_kernel, dim3(vit_grid(work)), dim3(256), 0, (hipStream_t)stream, images, B, H, W, patch,
+                       (unsigned short*)out_bf16);
+    return launch_status();
+}
+
+extern "C" int lp_vit_tokens_fwd(const void* patch_bf16, const float* cls, const float* pos, int B, int Np, int D, float* x,
+                                 lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(patch_bf16 && cls && pos && x && B > 0 && Np > 0 && D > 0);
+    if (D % 8 != 0) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vit_tokens_fwd_kernel, dim3(vit_grid((size_t)B * (Np + 1) * (D / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)patch_bf16, cls, pos, B, Np, D, x);
+    return launch_status();
+}
+
+extern "C" int lp_vit_tokens_bwd(const float* dx, int B, int Np, int D, void* dpatch_bf16, float* dpos, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(dx && dpatch_bf16 && dpos && B > 0 && Np > 0 && D > 0);
+    if (D % 8 != 0) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vit_tokens_bwd_kernel, dim3(vit_grid((size_t)(Np + 1) * (D / 8))), dim3(256), 0, (hipStream_t)stream, dx, B, Np, D,
+                       (unsigned short*)dpatch_bf16, dpos);
+    return launch_status();
+}
+
+extern "C" int lp_small_matmul(const float* w, const float* x, int R, int Q, int D, int transpose_w, int accumulate, float* y,
+                               lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(w && x && y && R > 0 && Q > 0 && D > 0);
+    const int rows = transpose_w ? Q : R;
+    hipLaunchKernelGGL(small_matmul_kernel, dim3(vit_grid((size_t)rows * D)), dim3(256), 0, (hipStream_t)stream, w, x, R, Q, D, transpose_w,
+                       accumulate, y);
+    return launch_status();
+}
+
+extern "C" int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x_out, const float* gamma, const float* beta, float eps,
+                                int M, int D, int drop_T, void* y_bf16, float* mean, float* rstd, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && M > 0 && D > 0 && drop_T >= 0 && (delta_bf16 == nullptr || x_out != nullptr));
+    if (D > 64 * kLnMax) return LP_ERR_UNSUPPORTED;
+    int blocks = (M + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const unsigned short*)delta_bf16, x_out,
+                       gamma, beta, eps, M, D, drop_T, (unsigned short*)y_bf16, mean, rstd);
+    return launch_status();
+}
+
+extern "C" int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                                int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(dy_bf16 && x && mean && rstd && gamma && dx_acc && dgamma_acc && dbeta_acc && M > 0 && D > 0 && drop_T >= 0);
+    if (D > 64 * kLnMax) return LP_ERR_UNSUPPORTED;
+    int blocks = (M + 3) / 4;
+    if (blocks > 512) blocks = 512;  // bounds the d gamma / d beta atomics per column
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, rstd,
+                       gamma, M, D, drop_T, dx_acc, dgamma_acc, dbeta_acc);
+    return launch_status();
+}
+
+extern "C" int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x_bf16 && y_bf16 && n > 0);
+    if (n % 8 != 0) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(vit_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16, n / 8,
+                       (unsigned short*)y_bf16);
+    return launch_status();
+}
+
+extern "C" int lp_gelu_bwd(const void* x_bf16, const void* dy_bf16, size_t n, void* dx_bf16, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x_bf16 && dy_bf16 && dx_bf16 && n > 0);
+    if (n % 8 != 0) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(vit_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16,
+                       (const unsigned short*)dy_bf16, n / 8, (unsigned short*)dx_bf16);
+    return launch_status();
+}
+
+extern "C" int lp_softmax_rows_fwd(void* s_bf16, int rows, int n, int ld, float scale, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(s_bf16 && rows > 0 && n > 0 && ld >= n);
+    if (ld > 64 * kSmMax) return LP_ERR_UNSUPPORTED;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned short*)s_bf16, rows, n, ld, scale);
+    return launch_status();
+}
+
+extern "C" int lp_softmax_rows_bwd(const void* p_bf16, void* dp_bf16, int rows, int n, int ld, float scale, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(p_bf16 && dp_bf16 && rows > 0 && n > 0 && ld >= n);
+    if (ld > 64 * kSmMax) return LP_ERR_UNSUPPORTED;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)p_bf16,
+                       (unsigned short*)dp_bf16, rows, n, ld, scale);
+    return launch_status();
+}
+
+extern "C" int lp_transpose_batched(const void* in_bf16, int R, int Cc, int ldi, long long in_b, long long in_h, void* out_bf16, int ldo,
+                                    long long out_b, long long out_h, int nb, int nh, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(in_bf16 && out_bf16 && R > 0 && Cc > 0 && ldi >= Cc && ldo >= R && nb > 0 && nh > 0);
+    if ((long long)nb * nh > 65535) return LP_ERR_UNSUPPORTED;
+    dim3 grid((Cc + 63) / 64, (ldo + 63) / 64, nb * nh);
+    hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in_bf16, R, Cc, ldi, in_b, in_h,
+                       (unsigned short*)out_bf16, ldo, out_b, out_h, nh);
+    return launch_status();
+}

@@ -413,3 +413,84 @@ def permute_cba(src_bits, A, Bm, Cn):
     sb, dst = Buf(src_bits), Z((Cn, Bm, A), np.uint16)
     ok(lib().lp_permute_cba(sb.p, A, Bm, Cn, dst.p, stream()))
     return dst.np()
+
+
+# ---- ViT glue (csrc/vit.hip) ------------------------------------------------------------------------------------------
+def vit_patchify(img, patch):
+    img = f32(img)
+    b, _, h, w = img.shape
+    ib, ob = Buf(img), Z((b * (h // patch) * (w // patch), 3 * patch * patch), np.uint16)
+    ok(lib().lp_vit_patchify(ib.p, b, h, w, patch, ob.p, stream()))
+    return ob.np()
+
+
+def vit_tokens_fwd(patch_bits, cls, pos, Bn, Np, D):
+    pb, cb, qb, xb = Buf(patch_bits), Buf(f32(cls)), Buf(f32(pos)), Z((Bn, Np + 1, D))
+    ok(lib().lp_vit_tokens_fwd(pb.p, cb.p, qb.p, Bn, Np, D, xb.p, stream()))
+    return xb.np()
+
+
+def vit_tokens_bwd(dx, Bn, Np, D):
+    db, pb, qb = Buf(f32(dx)), Z((Bn * Np, D), np.uint16), Z((Np + 1, D))
+    ok(lib().lp_vit_tokens_bwd(db.p, Bn, Np, D, pb.p, qb.p, stream()))
+    return pb.np(), qb.np()
+
+
+def small_matmul(w, x, transpose_w=False, y0=None):
+    w, x = f32(w), f32(x)
+    r, q = w.shape
+    d = x.shape[1]
+    wb, xb = Buf(w), Buf(x)
+    yb = Buf(f32(y0)) if y0 is not None else Z((q if transpose_w else r, d))
+    ok(lib().lp_small_matmul(wb.p, xb.p, r, q, d, int(transpose_w), int(y0 is not None), yb.p, stream()))
+    return yb.np()
+
+
+def layernorm_fwd(x, gamma, beta, eps, delta_bits=None, drop_T=0):
+    x = f32(x)
+    m, d = x.shape
+    rows_y = m - m // drop_T if drop_T else m
+    xb, db, gb, bb = Buf(x), B(delta_bits), Buf(f32(gamma)), Buf(f32(beta))
+    xo = Z((m, d)) if delta_bits is not None else None
+    y, mean, rstd = Z((rows_y, d), np.uint16), Z(m), Z(m)
+    ok(lib().lp_layernorm_fwd(xb.p, ptr(db), ptr(xo), gb.p, bb.p, eps, m, d, drop_T, y.p, mean.p, rstd.p, stream()))
+    return y.np(), mean.np(), rstd.np(), (xo.np() if xo is not None else None)
+
+
+def layernorm_bwd(dy_bits, x, mean, rstd, gamma, dx0, drop_T=0):
+    x = f32(x)
+    m, d = x.shape
+    db, xb, mb, rb, gb = Buf(dy_bits), Buf(x), Buf(f32(mean)), Buf(f32(rstd)), Buf(f32(gamma))
+    dx, dg, dbeta = Buf(f32(dx0)), Z(d), Z(d)
+    ok(lib().lp_layernorm_bwd(db.p, xb.p, mb.p, rb.p, gb.p, m, d, drop_T, dx.p, dg.p, dbeta.p, stream()))
+    return dx.np(), dg.np(), dbeta.np()
+
+
+def gelu(x_bits, dy_bits=None):
+    xb = Buf(x_bits)
+    n = int(np.prod(xb.shape))
+    if dy_bits is None:
+        y = Z(xb.shape, np.uint16)
+        ok(lib().lp_gelu_fwd(xb.p, n, y.p, stream()))
+        return y.np()
+    db, dx = Buf(dy_bits), Z(xb.shape, np.uint16)
+    ok(lib().lp_gelu_bwd(xb.p, db.p, n, dx.p, stream()))
+    return dx.np()
+
+
+def softmax_rows(s_bits, n, scale, p_bits=None):
+    """forward (p_bits None): softmax in place of a copy; backward: s_bits = dp, returns ds"""
+    sb = Buf(s_bits)
+    rows, ld = sb.shape
+    if p_bits is None:
+        ok(lib().lp_softmax_rows_fwd(sb.p, rows, n, ld, scale, stream()))
+    else:
+        pb = Buf(p_bits)
+        ok(lib().lp_softmax_rows_bwd(pb.p, sb.p, rows, n, ld, scale, stream()))
+    return sb.np()
+
+
+def transpose_batched(in_bits, R, Cc, ldi, in_b, in_h, ldo, out_b, out_h, nb, nh, out_elems):
+    ib, ob = Buf(in_bits), Buf(np.full(out_elems, 0x7fc0, np.uint16))  # NaN-poisoned: pads must be written
+    ok(lib().lp_transpose_batched(ib.p, R, Cc, ldi, in_b, in_h, ob.p, ldo, out_b, out_h, nb, nh, stream()))
+    return ob.np()

@@ -1,0 +1,110 @@
+"""Kernel-logic tests of csrc/vit.hip (the ViT-S/16 glue between the GEMMs) against plain torch fp32, on the CPU emulator and,
+under -m gpu, on the device."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.hipemu import emu
+
+pytestmark = pytest.mark.usefixtures("kernel_backend")
+
+bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+bits, unbits = emu.to_bf16_bits, emu.from_bf16_bits
+
+
+def test_patchify_and_tokens():
+    gen = torch.Generator().manual_seed(0)
+    B, H, W, P, D = 2, 32, 48, 16, 64
+    img = torch.randn(B, 3, H, W, generator=gen)
+    got = unbits(emu.vit_patchify(img.numpy(), P))
+    want = F.unfold(img, kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)  # (c, ky, kx) order, row-major patches
+    torch.testing.assert_close(got, bf(want), atol=0, rtol=0)
+    Np = (H // P) * (W // P)
+    patch = bf(torch.randn(B * Np, D, generator=gen))
+    cls, pos = torch.randn(D, generator=gen), torch.randn(Np + 1, D, generator=gen)
+    x = torch.from_numpy(emu.vit_tokens_fwd(bits(patch), cls.numpy(), pos.numpy(), B, Np, D))
+    want = torch.cat([cls.expand(B, 1, D), patch.reshape(B, Np, D)], 1) + pos
+    torch.testing.assert_close(x, want, atol=1e-6, rtol=0)
+    dx = torch.randn(B, Np + 1, D, generator=gen)
+    dpatch, dpos = emu.vit_tokens_bwd(dx.numpy(), B, Np, D)
+    torch.testing.assert_close(unbits(dpatch), bf(dx[:, 1:].reshape(-1, D)), atol=0, rtol=0)
+    torch.testing.assert_close(torch.from_numpy(dpos), dx.sum(0), atol=1e-5, rtol=1e-5)
+
+
+def test_small_matmul_is_interpolation_and_adjoint():
+    gen = torch.Generator().manual_seed(1)
+    w, x = torch.randn(24, 9, generator=gen), torch.randn(9, 40, generator=gen)
+    torch.testing.assert_close(torch.from_numpy(emu.small_matmul(w.numpy(), x.numpy())), w @ x, atol=1e-5, rtol=1e-5)
+    g = torch.randn(24, 40, generator=gen)
+    y0 = torch.randn(9, 40, generator=gen)
+    got = emu.small_matmul(w.numpy(), g.numpy(), transpose_w=True, y0=y0.numpy())
+    torch.testing.assert_close(torch.from_numpy(got), y0 + w.T @ g, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,D,drop_T", [(37, 384, 0), (3 * 5, 96, 5), (9, 1024, 0)])
+def test_layernorm_fwd_bwd(M, D, drop_T):
+    gen = torch.Generator().manual_seed(M + D)
+    x = (torch.randn(M, D, generator=gen) * 2 + 0.3)
+    delta = bf(torch.randn(M, D, generator=gen))
+    gamma, beta = torch.rand(D, generator=gen) + 0.5, torch.randn(D, generator=gen)
+    y, mean, rstd, xo = emu.layernorm_fwd(x.numpy(), gamma.numpy(), beta.numpy(), 1e-12, delta_bits=bits(delta), drop_T=drop_T)
+    xs = (x + delta).requires_grad_(True)
+    ref = F.layer_norm(xs, (D,), gamma, beta, 1e-12)
+    keep = torch.ones(M, dtype=torch.bool)
+    if drop_T:
+        keep[::drop_T] = False
+    torch.testing.assert_close(torch.from_numpy(xo), xs.detach(), atol=1e-6, rtol=0)
+    torch.testing.assert_close(unbits(y), bf(ref.detach()[keep]), atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(torch.from_numpy(mean), xs.detach().mean(1), atol=1e-5, rtol=1e-5)
+    dy = bf(torch.randn(int(keep.sum()), D, generator=gen))
+    dy_full = torch.zeros(M, D)
+    dy_full[keep] = dy
+    gamma_r, beta_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.layer_norm(xs, (D,), gamma_r, beta_r, 1e-12).backward(dy_full)
+    dx0 = torch.randn(M, D, generator=gen)
+    dx, dg, db = emu.layernorm_bwd(bits(dy), xs.detach().numpy(), mean, rstd, gamma.numpy(), dx0.numpy(), drop_T=drop_T)
+    torch.testing.assert_close(torch.from_numpy(dx), dx0 + xs.grad, atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(torch.from_numpy(dg), gamma_r.grad, atol=2e-3, rtol=2e-4)
+    torch.testing.assert_close(torch.from_numpy(db), beta_r.grad, atol=2e-3, rtol=2e-4)
+
+
+def test_gelu_fwd_bwd():
+    gen = torch.Generator().manual_seed(2)
+    x = bf(torch.randn(40, 64, generator=gen) * 2).requires_grad_(True)
+    y = F.gelu(x)
+    torch.testing.assert_close(unbits(emu.gelu(bits(x.detach()))), bf(y.detach()), atol=1e-2, rtol=1e-2)
+    dy = bf(torch.randn(40, 64, generator=gen))
+    y.backward(dy)
+    torch.testing.assert_close(unbits(emu.gelu(bits(x.detach()), bits(dy))), bf(x.grad), atol=2e-2, rtol=2e-2)
+
+
+def test_softmax_rows_fwd_bwd():
+    gen = torch.Generator().manual_seed(3)
+    rows, n, ld, scale = 21, 77, 128, 0.125
+    s = bf(torch.randn(rows, ld, generator=gen) * 4)
+    p = emu.softmax_rows(bits(s), n, scale)
+    pf = unbits(p)
+    want = torch.softmax(s[:, :n] * scale, -1)
+    torch.testing.assert_close(pf[:, :n], bf(want), atol=4e-3, rtol=1e-2)
+    assert not pf[:, n:].any()
+    dp = bf(torch.randn(rows, ld, generator=gen))
+    ds = unbits(emu.softmax_rows(bits(dp), n, scale, p_bits=p))
+    pp, dd = pf[:, :n], dp[:, :n]
+    want_ds = scale * pp * (dd - (dd * pp).sum(-1, keepdim=True))
+    torch.testing.assert_close(ds[:, :n], bf(want_ds), atol=2e-3, rtol=2e-2)
+    assert not ds[:, n:].any()
+
+
+def test_transpose_batched_with_head_strides_and_zero_pad():
+    gen = torch.Generator().manual_seed(4)
+    nb, nh, T, d, ld = 2, 3, 77, 64, 3 * 3 * 64
+    qkv = bf(torch.randn(nb * T, ld, generator=gen))
+    ldo = 128  # V^T[z][d][t], t padded to 128 with zeros
+    v_off = 2 * nh * d
+    out = emu.transpose_batched(bits(qkv).reshape(-1)[v_off:], T, d, ld, T * ld, d, ldo, nh * d * ldo, d * ldo, nb, nh, nb * nh * d * ldo)
+    got = unbits(out.reshape(nb, nh, d, ldo))
+    v = qkv.reshape(nb, T, 3, nh, d)[:, :, 2].permute(0, 2, 3, 1)  # (nb, nh, d, T)
+    torch.testing.assert_close(got[..., :T], v, atol=0, rtol=0)
+    assert not got[..., T:].any()
