@@ -231,8 +231,9 @@ int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const floa
 int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream);
 int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
 int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_bf16, lp_stream_t stream);
-/* (B,h,w,4*c_out) -> (B,2h,2w,c_out); inverse = 1 maps the gradient back */
-int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int inverse, void* out, lp_stream_t stream);
+/* (B,h,w,4*c_out) -> (B,2h,2w,c_out) stored with channel pitch ld >= c_out (pad channels untouched); inverse = 1 maps the
+ * gradient (pitch ld) back */
+int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int ld, int inverse, void* out, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * ViT-S/16 backbone glue (models/backbones/vit.py:16-49 -> transformers ViTModel; backbone = "vits_dino",

@@ -87,7 +87,7 @@ PROTOTYPES = {
     "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "lp_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
-    "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "lp_vit_patchify": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "lp_vit_tokens_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "lp_vit_tokens_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),

@@ -321,8 +321,9 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __rest
 }
 
 // ---- PixelShuffle(2) on NHWC: out[b][2y+i][2x+j][c] = in[b][y][x][4c + 2i + j] ;  inverse for the gradient ------------
+// the high-resolution tensor has channel pitch `ld` >= Cout (pad channels are never touched)
 template <bool INVERSE>
-__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short* __restrict__ IN, int B, int h, int w, int Cout,
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short* __restrict__ IN, int B, int h, int w, int Cout, int ld,
                                                             unsigned short* __restrict__ OUT) {
     // thread = one low-res pixel x 8 consecutive LOW-res channels (16 B) ; they map to 2 output channels x 4 positions
     const int cin = Cout * 4, chunks = cin >> 3;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short
         for (int e = 0; e < 8; ++e) {
             const int cl = ch * 8 + e;           // low-res channel = 4c + 2i + j
             const int c = cl >> 2, i = (cl >> 1) & 1, j = cl & 1;
-            const size_t o = ((((size_t)b * 2 * h + 2 * y + i) * 2 * w) + 2 * x + j) * Cout + c;
+            const size_t o = ((((size_t)b * 2 * h + 2 * y + i) * 2 * w) + 2 * x + j) * ld + c;
             if (INVERSE) v[e] = IN[o];
             else OUT[o] = v[e];
         }
@@ -467,16 +468,16 @@ extern "C" int lp_images_to_nhwc4(const float* images, int B, int H, int W, void
     return launch_status();
 }
 
-extern "C" int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int inverse, void* out, lp_stream_t stream) {
+extern "C" int lp_pixel_shuffle(const void* in, int B, int h, int w, int c_out, int ld, int inverse, void* out, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(in && out && B > 0 && h > 0 && w > 0 && c_out > 0);
+    LP_REQUIRE(in && out && B > 0 && h > 0 && w > 0 && c_out > 0 && ld >= c_out);
     if ((c_out * 4) % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t work = (size_t)B * h * w * (c_out * 4 / 8);
     if (inverse)
         hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, B,
-                           h, w, c_out, (unsigned short*)out);
+                           h, w, c_out, ld, (unsigned short*)out);
     else
         hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in, B,
-                           h, w, c_out, (unsigned short*)out);
+                           h, w, c_out, ld, (unsigned short*)out);
     return launch_status();
 }

@@ -92,6 +92,22 @@ class Plan:
     bns: list[BNP] = field(default_factory=list)
 
 
+def build_head(feat_channels: int, stride: int, num_keypoints: int, downsample_factor: int) -> list[ConvP]:
+    """PixelShuffle(2) + n x ConvTranspose2d(k3,s2,p1,op1) of HeatmapHead (reference models/heads/heatmap.py:20-71,186-196):
+    n = log2(stride) - downsample_factor - 1.  Each ConvTranspose2d(cin -> K) is stored as the mirrored convolution's weight
+    [Co = cin rounded up to 64][3][3][Ci = K padded to CPAD]."""
+    n_layers = int(math.log2(stride)) - downsample_factor - 1
+    if n_layers < 1:
+        raise NotImplementedError(f"downsample_factor={downsample_factor} leaves no upsampling layer for a stride-{stride} backbone")
+    head: list[ConvP] = []
+    cin = feat_channels // 4
+    for i in range(n_layers):
+        co_store = -(-cin // 64) * 64
+        head.append(ConvP(f"head.upsampling_layers.{i + 1}", "convT", cin, num_keypoints, 3, 2, 1, co_store, CPAD))
+        cin = num_keypoints
+    return head
+
+
 def build_plan(num_keypoints: int, downsample_factor: int) -> Plan:
     """Layer list + flat offsets, parameters in torchvision ``state_dict`` order (backbone first, then head)."""
     if num_keypoints > CPAD:
@@ -113,16 +129,7 @@ def build_plan(num_keypoints: int, downsample_factor: int) -> Plan:
                 blk.dbn = BNP(f"{pre}.downsample.1", planes * 4)
             blocks.append(blk)
             inplanes = planes * 4
-    n_layers = int(math.log2(32)) - downsample_factor - 1
-    if n_layers < 1:
-        raise NotImplementedError(f"downsample_factor={downsample_factor} leaves no upsampling layer for a stride-32 backbone")
-    head: list[ConvP] = []
-    cin = 2048 // 4
-    for i in range(n_layers):
-        # ConvTranspose2d(cin -> K): stored as the mirrored conv's weight [Co = cin][3][3][Ci = K padded]
-        co_store = cin if cin % 64 == 0 else CPAD
-        head.append(ConvP(f"head.upsampling_layers.{i + 1}", "convT", cin, num_keypoints, 3, 2, 1, co_store, CPAD))
-        cin = num_keypoints
+    head = build_head(2048, 32, num_keypoints, downsample_factor)
 
     plan = Plan(stem, stem_bn, blocks, head)
     off = 0
@@ -379,6 +386,71 @@ class Engine:
             return y, mean, invstd, bits
         return y, mean, invstd
 
+    # ------------------------------------------------------------------------------------------------ head
+    def _head_forward(self, x: torch.Tensor, B: int, h: int, w: int, T: dict) -> torch.Tensor:
+        """features (B,h,w,C) bf16 NHWC -> heat-maps (B,K,.,.) fp32: PixelShuffle(2) -> ConvTranspose2d x n -> spatial softmax
+        (reference models/heads/heatmap.py:203-212).  Leaves "head.in{i}" and "heat" on the tape."""
+        head = self.plan.head
+        cs = head[0].cin                       # channels after the pixel shuffle
+        ld = head[0].Co                        # ... stored with this pitch (zero padded up to a multiple of 64)
+        alloc = torch.zeros if ld != cs else torch.empty
+        ps = alloc(B, 2 * h, 2 * w, ld, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_pixel_shuffle(_p(x), B, h, w, cs, ld, 0, _p(ps), ops._stream()), "lp_pixel_shuffle")
+        h, w = 2 * h, 2 * w
+        T["head.in0"] = ps
+        cur = ps
+        logits = None
+        for li, c in enumerate(head):
+            g = self._geom(c, B, h, w)
+            last = li == len(head) - 1
+            bias = self.P[c.bias_off:c.bias_off + CPAD]
+            wd = self.Wd[c.wd_off:]
+            if last:
+                logits = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.float32)
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, None, _p(logits), CPAD, self.K, 0, ops._stream()),
+                      "lp_conv_dgrad(head)")
+            else:
+                nxt = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.bfloat16)
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, CPAD, CPAD, 0, ops._stream()),
+                      "lp_conv_dgrad(head)")
+                cur = nxt
+                T[f"head.in{li + 1}"] = cur
+            h, w = 2 * h, 2 * w
+        n = h * w
+        heat = torch.empty(B, self.K, h, w, device=self.device, dtype=torch.float32)
+        check(self._lib.lp_softmax2d_fwd(_p(logits), n * CPAD, CPAD, 1, B, self.K, n, _p(heat), ops._stream()), "lp_softmax2d_fwd")
+        T["heat"] = heat
+        return heat
+
+    def _head_backward(self, T: dict, B: int, g_heat: torch.Tensor) -> torch.Tensor:
+        """d loss / d heat-maps -> d loss / d features (B,h,w,C) bf16; head parameter gradients accumulate into G."""
+        head = self.plan.head
+        heat = T["heat"]
+        _, K, h, w = heat.shape
+        n = h * w
+        g_heat = g_heat.to(torch.float32).contiguous()
+        dcur = torch.zeros(B, h, w, CPAD, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_softmax2d_bwd(_p(heat), _p(g_heat), B, K, n, _p(dcur), n * CPAD, CPAD, 1, ops._stream()), "lp_softmax2d_bwd")
+        # last layer first.  ConvT backward-data is the mirrored conv's forward; its wgrad is lp_conv_wgrad.
+        for li in range(len(head) - 1, -1, -1):
+            c = head[li]
+            hs, ws = h // 2, w // 2
+            g = self._geom(c, B, hs, ws)
+            x_small = T[f"head.in{li}"]
+            bsum = torch.zeros(2 * CPAD, device=self.device, dtype=torch.float32)
+            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
+            self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
+            self._wgrad(dcur, x_small, g, self.G[c.w_off:])
+            dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
+            check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
+                  "lp_conv_fwd(head bwd)")
+            dcur, h, w = dx, hs, ws
+        fh, fw = h // 2, w // 2
+        cs, ld = head[0].cin, head[0].Co
+        d = torch.empty(B, fh, fw, 4 * cs, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_pixel_shuffle(_p(dcur), B, fh, fw, cs, ld, 1, _p(d), ops._stream()), "lp_pixel_shuffle(inv)")
+        return d
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:
         """images (B,3,H,W) fp32 NCHW -> heat-maps (B,K,H/2^ds,W/2^ds) fp32, plus the tape for backward()."""
@@ -443,33 +515,7 @@ class Engine:
                 T[f"{key}.{nm}"] = val
             x, h, w = out, ho, wo
 
-        # ---- head: PixelShuffle(2) -> ConvTranspose2d x n -> spatial softmax
-        cs = 2048 // 4
-        ps = torch.empty(B, 2 * h, 2 * w, cs, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_pixel_shuffle(_p(x), B, h, w, cs, 0, _p(ps), ops._stream()), "lp_pixel_shuffle")
-        h, w = 2 * h, 2 * w
-        T["head.in0"] = ps
-        cur = ps
-        logits = None
-        for li, c in enumerate(plan.head):
-            g = self._geom(c, B, h, w)
-            last = li == len(plan.head) - 1
-            bias = self.P[c.bias_off:c.bias_off + CPAD]
-            wd = self.Wd[c.wd_off:]
-            if last:
-                logits = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.float32)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, None, _p(logits), CPAD, self.K, 0, ops._stream()),
-                      "lp_conv_dgrad(head)")
-            else:
-                nxt = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.bfloat16)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, CPAD, CPAD, 0, ops._stream()),
-                      "lp_conv_dgrad(head)")
-                cur = nxt
-                T[f"head.in{li + 1}"] = cur
-            h, w = 2 * h, 2 * w
-        n = h * w
-        heat = torch.empty(B, self.K, h, w, device=self.device, dtype=torch.float32)
-        check(self._lib.lp_softmax2d_fwd(_p(logits), n * CPAD, CPAD, 1, B, self.K, n, _p(heat), ops._stream()), "lp_softmax2d_fwd")
+        heat = self._head_forward(x, B, h, w, T)
         T["heat"] = heat
         tp.meta.update(B=B, H=H, W=W, training=training)
         if training:
@@ -530,29 +576,7 @@ class Engine:
         ``trace`` (tests only): receives the gradient tensor at every block boundary."""
         T, plan = tp.t, self.plan
         B, H, W = tp.meta["B"], tp.meta["H"], tp.meta["W"]
-        heat = T["heat"]
-        _, K, h, w = heat.shape
-        n = h * w
-        g_heat = g_heat.to(torch.float32).contiguous()
-        dcur = torch.zeros(B, h, w, CPAD, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_softmax2d_bwd(_p(heat), _p(g_heat), B, K, n, _p(dcur), n * CPAD, CPAD, 1, ops._stream()), "lp_softmax2d_bwd")
-        # head, last layer first.  ConvT backward-data is the mirrored conv's forward; its wgrad is lp_conv_wgrad.
-        for li in range(len(plan.head) - 1, -1, -1):
-            c = plan.head[li]
-            hs, ws = h // 2, w // 2
-            g = self._geom(c, B, hs, ws)
-            x_small = T[f"head.in{li}"]
-            bsum = torch.zeros(2 * CPAD, device=self.device, dtype=torch.float32)
-            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
-            self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
-            self._wgrad(dcur, x_small, g, self.G[c.w_off:])
-            dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
-            check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
-                  "lp_conv_fwd(head bwd)")
-            dcur, h, w = dx, hs, ws
-        fh, fw = h // 2, w // 2
-        d = torch.empty(B, fh, fw, 2048, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_pixel_shuffle(_p(dcur), B, fh, fw, 512, 1, _p(d), ops._stream()), "lp_pixel_shuffle(inv)")
+        d = self._head_backward(T, B, g_heat)
 
         # One zeroed buffer for the reductions of every fused BatchNorm backward of this pass.
         bsums_all = torch.zeros(sum(2 * b.C for b in plan.bns), device=self.device, dtype=torch.float32)

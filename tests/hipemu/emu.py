@@ -395,10 +395,11 @@ def images_to_nhwc4(img):
     return out.np()
 
 
-def pixel_shuffle(x_bits, Bn, h, w, c_out, inverse=False):
+def pixel_shuffle(x_bits, Bn, h, w, c_out, inverse=False, ld=None):
+    ld = ld or c_out
     xb = Buf(x_bits)
-    out = Z((Bn, h, w, 4 * c_out) if inverse else (Bn, 2 * h, 2 * w, c_out), np.uint16)
-    ok(lib().lp_pixel_shuffle(xb.p, Bn, h, w, c_out, int(inverse), out.p, stream()))
+    out = Z((Bn, h, w, 4 * c_out) if inverse else (Bn, 2 * h, 2 * w, ld), np.uint16)
+    ok(lib().lp_pixel_shuffle(xb.p, Bn, h, w, c_out, ld, int(inverse), out.p, stream()))
     return out.np()
 
 

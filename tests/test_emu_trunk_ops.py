@@ -75,6 +75,12 @@ def test_images_and_pixel_shuffle():
     torch.testing.assert_close(emu.from_bf16_bits(got), want)
     back = emu.pixel_shuffle(got, 2, 3, 4, 8, inverse=True)
     torch.testing.assert_close(emu.from_bf16_bits(back), x.permute(0, 2, 3, 1))
+    # padded channel pitch (ViT head: 96 channels stored in 128): pad channels untouched (zero here), inverse ignores them
+    got16 = emu.pixel_shuffle(emu.to_bf16_bits(x.permute(0, 2, 3, 1)), 2, 3, 4, 8, ld=16)
+    torch.testing.assert_close(emu.from_bf16_bits(got16)[..., :8], want)
+    assert not got16[..., 8:].any()
+    back = emu.pixel_shuffle(got16, 2, 3, 4, 8, inverse=True, ld=16)
+    torch.testing.assert_close(emu.from_bf16_bits(back), x.permute(0, 2, 3, 1))
 
 
 @pytest.mark.parametrize("opt", ["Adam", "AdamW"])
