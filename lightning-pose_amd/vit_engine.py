@@ -1,0 +1,422 @@
+"""ViT-S/16 ("vits_dino") backbone + heat-map head on the MI355X kernels: the drop-in for
+``VisionEncoder`` -> HuggingFace ``ViTModel`` (reference models/backbones/vit.py:16-49, factory.py:188-190).
+
+Same contract as :class:`lightning_pose_amd.engine.Engine` (flat fp32 parameter / gradient buffers, bf16 operand copies,
+``forward`` -> (heat-maps, tape), hand-written ``backward``), parameters exposed under the reference's ``state_dict`` names
+(``backbone.vision_encoder.embeddings.*``, ``...layers.{i}.attention.{q,k,v,o}_proj.*``, ``...layers.{i}.mlp.fc{1,2}.*``,
+``...layernorm*``, ``head.upsampling_layers.*`` - the names of the installed transformers 5.x ``ViTModel``; the 4.x names
+``encoder.layer.{i}.attention.attention.query`` ... are accepted by ``load_state_dict``).
+
+Every Linear layer and both attention products run on the MFMA GEMM (``lp_gemm_nt``: forward and data-gradient; ``lp_conv_wgrad``:
+weight-gradient); everything between them is csrc/vit.hip.  Attention is evaluated per (image, head) as batched GEMMs on the fused
+QKV tensor with the probabilities materialised in bf16 (row pitch padded to a multiple of 64 so they are a GEMM K operand); the
+residual stream, LayerNorm statistics and all reductions are fp32.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .engine import CPAD, ConvP, Engine, Tape, build_head
+from .ops import _p
+
+LN_EPS = 1e-12  # ViTConfig.layer_norm_eps
+
+
+def bicubic_matrix(n_in: int, n_out: int) -> np.ndarray:
+    """(n_out, n_in) weights of torch's 1-D bicubic resize, align_corners=False (A = -0.75, border taps clamped)."""
+    A = -0.75
+    w = np.zeros((n_out, n_in), np.float64)
+    scale = n_in / n_out
+
+    def k1(t):
+        return ((A + 2) * t - (A + 3)) * t * t + 1
+
+    def k2(t):
+        return ((A * t - 5 * A) * t + 8 * A) * t - 4 * A
+
+    for i in range(n_out):
+        src = (i + 0.5) * scale - 0.5
+        i0 = math.floor(src)
+        t = src - i0
+        for tap, wt in zip((i0 - 1, i0, i0 + 1, i0 + 2), (k2(t + 1), k1(t), k1(1 - t), k2(2 - t))):
+            w[i, min(max(tap, 0), n_in - 1)] += wt
+    return w
+
+
+@dataclass
+class Lin:
+    name: str      # state_dict prefix (weight / bias), or a list of three for the fused q, k, v
+    N: int
+    K: int
+    w_off: int = 0
+    b_off: int = 0
+    wd_off: int = 0
+
+
+@dataclass
+class LNP:
+    name: str
+    g_off: int = 0
+    b_off: int = 0
+
+
+class ViTPlan:
+    def __init__(self, num_keypoints: int, downsample_factor: int, D: int, depth: int, heads: int, mlp: int, patch: int, n_pos: int):
+        self.D, self.depth, self.heads, self.mlp, self.patch, self.n_pos = D, depth, heads, mlp, patch, n_pos
+        pre = "backbone.vision_encoder"
+        off = wd = 0
+
+        def lin(name, N, K):
+            nonlocal off, wd
+            l = Lin(name, N, K, off, off + N * K, wd)
+            off += N * K + N
+            wd += N * K
+            return l
+
+        def ln(name):
+            nonlocal off
+            l = LNP(name, off, off + D)
+            off += 2 * D
+            return l
+
+        self.cls_off = off
+        off += D
+        self.pos_off = off
+        off += n_pos * D
+        self.patch_lin = lin(f"{pre}.embeddings.patch_embeddings.projection", D, 3 * patch * patch)
+        self.layers = []
+        for i in range(depth):
+            p = f"{pre}.layers.{i}"
+            self.layers.append(dict(
+                ln1=ln(f"{p}.layernorm_before"), qkv=lin(f"{p}.attention.qkv", 3 * D, D), proj=lin(f"{p}.attention.o_proj", D, D),
+                ln2=ln(f"{p}.layernorm_after"), fc1=lin(f"{p}.mlp.fc1", mlp, D), fc2=lin(f"{p}.mlp.fc2", D, mlp)))
+        self.lnf = ln(f"{pre}.layernorm")
+        self.n_backbone = off
+        self.head: list[ConvP] = build_head(D, patch, num_keypoints, downsample_factor)
+        self.convs: list[ConvP] = []
+        self.bns: list = []
+        for c in self.head:
+            c.w_off = off
+            off += c.numel
+            c.wd_off = wd
+            wd += c.numel
+            c.bias_off = off
+            off += CPAD
+            self.convs.append(c)
+        self.n_total, self.n_wd = off, wd
+        self.n_running = 0
+
+    def linears(self) -> list[Lin]:
+        out = [self.patch_lin]
+        for L in self.layers:
+            out += [L["qkv"], L["proj"], L["fc1"], L["fc2"]]
+        return out
+
+    def norms(self) -> list[LNP]:
+        out = []
+        for L in self.layers:
+            out += [L["ln1"], L["ln2"]]
+        return out + [self.lnf]
+
+
+class ViTEngine(Engine):
+    """ViT-S/16 defaults = facebook/dino-vits16 (hidden 384, 12 layers, 6 heads, MLP 1536, patch 16, 224-px position table)."""
+
+    def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0", hidden: int = 384,
+                 depth: int = 12, heads: int = 6, mlp: int = 1536, patch: int = 16, pretrain_grid: int = 14):
+        self.device = torch.device(device)
+        ops.require_device_type(self.device)
+        self._lib = _lib.lib()
+        self.K, self.ds = num_keypoints, downsample_factor
+        if hidden % 64 or (hidden // heads) != 64 or mlp % 64:
+            raise NotImplementedError("ViT widths must be multiples of 64 with 64-wide heads (ViT-S/B)")
+        self.grid0 = pretrain_grid
+        self.plan = ViTPlan(num_keypoints, downsample_factor, hidden, depth, heads, mlp, patch, 1 + pretrain_grid * pretrain_grid)
+        n, dev = self.plan.n_total, self.device
+        self.P = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.G = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.Wb = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        self.Wd = torch.zeros(self.plan.n_wd, device=dev, dtype=torch.bfloat16)
+        self.R = torch.zeros(0, device=dev, dtype=torch.float32)
+        for l in self.plan.norms():
+            self.P[l.g_off:l.g_off + hidden] = 1.0
+        self.nbt = torch.zeros((), dtype=torch.long)
+        self.sync_bn, self.process_group = False, None   # no BatchNorm here; kept for the DataParallel wrapper
+        self.profile = None
+        self._wgrad_ws = None
+        self._bn_ws = None
+        self._interp: dict[tuple[int, int], torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------------ params
+    def _views(self, buf: torch.Tensor) -> dict[str, torch.Tensor]:
+        pl, D = self.plan, self.plan.D
+        pre = "backbone.vision_encoder"
+        sd = {f"{pre}.embeddings.cls_token": buf[pl.cls_off:pl.cls_off + D].view(1, 1, D),
+              f"{pre}.embeddings.position_embeddings": buf[pl.pos_off:pl.pos_off + pl.n_pos * D].view(1, pl.n_pos, D)}
+        for l in pl.linears():
+            w, b = buf[l.w_off:l.w_off + l.N * l.K], buf[l.b_off:l.b_off + l.N]
+            if l.name.endswith("attention.qkv"):  # fused [q; k; v]: three reference parameters share one GEMM weight
+                stem = l.name[:-len("qkv")]
+                for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                    sd[f"{stem}{nm}.weight"] = w[j * D * D:(j + 1) * D * D].view(D, D)
+                    sd[f"{stem}{nm}.bias"] = b[j * D:(j + 1) * D]
+            elif l is pl.patch_lin:
+                sd[f"{l.name}.weight"] = w.view(D, 3, pl.patch, pl.patch)
+                sd[f"{l.name}.bias"] = b
+            else:
+                sd[f"{l.name}.weight"] = w.view(l.N, l.K)
+                sd[f"{l.name}.bias"] = b
+        for l in pl.norms():
+            sd[f"{l.name}.weight"] = buf[l.g_off:l.g_off + D]
+            sd[f"{l.name}.bias"] = buf[l.b_off:l.b_off + D]
+        for c in pl.head:
+            sd[f"{c.name}.weight"] = self.param_view(c, "weight", buf=buf)
+            sd[f"{c.name}.bias"] = self.param_view(c, "bias", buf=buf)
+        return sd
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        return self._views(self.P)
+
+    def grad_views(self) -> dict[str, torch.Tensor]:
+        return self._views(self.G)
+
+    _LEGACY = (("encoder.layer.", "layers."), ("attention.attention.query", "attention.q_proj"),
+               ("attention.attention.key", "attention.k_proj"), ("attention.attention.value", "attention.v_proj"),
+               ("attention.output.dense", "attention.o_proj"), ("intermediate.dense", "mlp.fc1"), ("output.dense", "mlp.fc2"))
+
+    @classmethod
+    def canonical_key(cls, k: str) -> str:
+        """transformers 4.x ViT parameter name -> the 5.x name used here (checkpoints saved by older reference installs)"""
+        if ".encoder.layer." in k:
+            for a, b in cls._LEGACY:
+                k = k.replace(a, b)
+        return k
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict[str, torch.Tensor], strict: bool = True) -> None:
+        sd = {self.canonical_key(k): v for k, v in sd.items()}
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise KeyError(f"state_dict mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        for k, dst in own.items():
+            if k in sd:
+                dst.copy_(sd[k].to(device=self.device, dtype=torch.float32).reshape(dst.shape))
+        self.refresh_weight_copies()
+
+    def refresh_dgrad_copies(self, lo: int = 0, hi: int | None = None) -> None:
+        hi = self.plan.n_total if hi is None else hi
+        for l in self.plan.linears():
+            if lo <= l.w_off < hi:  # [N][K] -> [K][N]
+                check(self._lib.lp_permute_cba(_p(self.Wb[l.w_off:]), l.N, 1, l.K, _p(self.Wd[l.wd_off:]), ops._stream()), "lp_permute_cba")
+        for c in self.plan.convs:
+            if lo <= c.w_off < hi:
+                check(self._lib.lp_permute_cba(_p(self.Wb[c.w_off:]), c.Co, c.k * c.k, c.Ci, _p(self.Wd[c.wd_off:]), ops._stream()),
+                      "lp_permute_cba")
+
+    # ------------------------------------------------------------------------------------------------ kernels
+    def _gemm(self, a, lda, b, ldb, M, N, K, out, ldc, n_store=0, bias=None, batch=None):
+        gb = _lib.GemmBatch(*batch) if batch is not None else None
+        check(self._lib.lp_gemm_nt(a, lda, b, ldb, _p(out), None, ldc, M, N, K, n_store, _p(bias), C.byref(gb) if gb else None,
+                                   ops._stream()), "lp_gemm_nt")
+
+    def _linear(self, x: torch.Tensor, l: Lin, M: int) -> torch.Tensor:
+        out = torch.empty(M, l.N, device=self.device, dtype=torch.bfloat16)
+        self._gemm(_p(x), l.K, _p(self.Wb[l.w_off:]), l.K, M, l.N, l.K, out, l.N, bias=self.P[l.b_off:l.b_off + l.N])
+        return out
+
+    def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True):
+        """bias / weight gradients into G; returns dX = dY W (bf16) if wanted"""
+        s = torch.zeros(2 * l.N, device=self.device, dtype=torch.float32)
+        check(self._lib.lp_bn_stats(_p(dy), M, l.N, _p(s), ops._stream()), "lp_bn_stats(bias)")
+        self.G[l.b_off:l.b_off + l.N] += s[:l.N]
+        rows, cols = self._wg_shape
+        g = _lib.ConvGeom(1, rows, cols, l.K, rows, cols, l.N, 1, 1, 1, 0) if rows * cols == M else _lib.ConvGeom(1, 1, M, l.K, 1, M, l.N, 1, 1, 1, 0)
+        self._wgrad(x, dy, g, self.G[l.w_off:])
+        if not need_dx:
+            return None
+        dx = torch.empty(M, l.K, device=self.device, dtype=torch.bfloat16)
+        self._gemm(_p(dy), l.N, _p(self.Wd[l.wd_off:]), l.N, M, l.K, l.N, dx, l.K)
+        return dx
+
+    def _ln(self, x, delta, l: LNP, M: int, drop_T: int = 0):
+        D = self.plan.D
+        xo = torch.empty_like(x) if delta is not None else None
+        rows = M - M // drop_T if drop_T else M
+        y = torch.empty(rows, D, device=self.device, dtype=torch.bfloat16)
+        mean = torch.empty(M, device=self.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(self._lib.lp_layernorm_fwd(_p(x), _p(delta), _p(xo), _p(self.P[l.g_off:]), _p(self.P[l.b_off:]), LN_EPS, M, D, drop_T, _p(y),
+                                         _p(mean), _p(rstd), ops._stream()), "lp_layernorm_fwd")
+        return y, mean, rstd, (xo if xo is not None else x)
+
+    def _ln_bwd(self, dy, x, mean, rstd, l: LNP, M: int, dx, drop_T: int = 0):
+        check(self._lib.lp_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(self.P[l.g_off:]), M, self.plan.D, drop_T, _p(dx),
+                                         _p(self.G[l.g_off:]), _p(self.G[l.b_off:]), ops._stream()), "lp_layernorm_bwd")
+
+    def _transpose(self, src_ptr, R, Cc, ldi, in_b, in_h, out, ldo, out_b, out_h, nb, nh):
+        check(self._lib.lp_transpose_batched(src_ptr, R, Cc, ldi, in_b, in_h, _p(out), ldo, out_b, out_h, nb, nh, ops._stream()),
+              "lp_transpose_batched")
+
+    def _pos(self, gh: int, gw: int) -> torch.Tensor:
+        """(1 + gh*gw, D) position embeddings: the [CLS] row + the pretraining grid resized bicubically (HF interpolate_pos_encoding)"""
+        pl, D = self.plan, self.plan.D
+        pos = self.P[pl.pos_off:pl.pos_off + pl.n_pos * D].view(pl.n_pos, D)
+        if gh == self.grid0 and gw == self.grid0:
+            return pos
+        key = (gh, gw)
+        if key not in self._interp:
+            w = np.kron(bicubic_matrix(self.grid0, gh), bicubic_matrix(self.grid0, gw)).astype(np.float32)
+            self._interp[key] = torch.from_numpy(w).to(self.device).contiguous()
+        out = torch.empty(1 + gh * gw, D, device=self.device, dtype=torch.float32)
+        out[0].copy_(pos[0])
+        check(self._lib.lp_small_matmul(_p(self._interp[key]), _p(pos[1:]), gh * gw, pl.n_pos - 1, D, 0, 0, _p(out[1:]), ops._stream()),
+              "lp_small_matmul")
+        return out
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, images: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:
+        ops.require_device(images)
+        images = images.to(torch.float32).contiguous()
+        B, _, H, W = images.shape
+        pl = self.plan
+        D, nh, pt = pl.D, pl.heads, pl.patch
+        if H % pt or W % pt:
+            raise ValueError(f"image size must be a multiple of the patch size {pt}, got {H}x{W}")
+        gh, gw = H // pt, W // pt
+        Np, Tn = gh * gw, gh * gw + 1
+        M, Tp = B * Tn, -(-Tn // 64) * 64
+        tp = Tape()
+        T = tp.t
+        dev = self.device
+        self._wg_shape = (B, Tn)
+
+        patches = torch.empty(B * Np, 3 * pt * pt, device=dev, dtype=torch.bfloat16)
+        check(self._lib.lp_vit_patchify(_p(images), B, H, W, pt, _p(patches), ops._stream()), "lp_vit_patchify")
+        pe = self._linear(patches, pl.patch_lin, B * Np)
+        x = torch.empty(M, D, device=dev, dtype=torch.float32)
+        pos = self._pos(gh, gw)  # (kept alive across the launch)
+        check(self._lib.lp_vit_tokens_fwd(_p(pe), _p(self.P[pl.cls_off:]), _p(pos), B, Np, D, _p(x), ops._stream()), "lp_vit_tokens_fwd")
+        T["patches"] = patches
+        delta = None
+        scale = 1.0 / math.sqrt(D // nh)
+        qs = 3 * D  # row pitch of the fused qkv tensor
+        for i, L in enumerate(pl.layers):
+            y1, m1, r1, x = self._ln(x, delta, L["ln1"], M)
+            qkv = self._linear(y1, L["qkv"], M)
+            # scores[b][h] = Q K^T  (bf16, row pitch Tp; columns >= Tn are junk until the soft-max zeroes them)
+            S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
+            self._gemm(_p(qkv), qs, qkv[:, D:].data_ptr(), qs, Tn, Tn, 64, S, Tp, n_store=Tp,
+                       batch=(B, nh, Tn * qs, 64, Tn * qs, 64, nh * Tn * Tp, Tn * Tp))
+            check(self._lib.lp_softmax_rows_fwd(_p(S), B * nh * Tn, Tn, Tp, scale, ops._stream()), "lp_softmax_rows_fwd")
+            Vt = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)
+            self._transpose(qkv[:, 2 * D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, Vt, Tp, nh * 64 * Tp, 64 * Tp, B, nh)
+            attn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+            self._gemm(_p(S), Tp, _p(Vt), Tp, Tn, 64, Tp, attn, D, batch=(B, nh, nh * Tn * Tp, Tn * Tp, nh * 64 * Tp, 64 * Tp, Tn * D, 64))
+            proj = self._linear(attn, L["proj"], M)
+            x_in = x
+            y2, m2, r2, x = self._ln(x, proj, L["ln2"], M)
+            h1 = self._linear(y2, L["fc1"], M)
+            a1 = torch.empty_like(h1)
+            check(self._lib.lp_gelu_fwd(_p(h1), h1.numel(), _p(a1), ops._stream()), "lp_gelu_fwd")
+            delta = self._linear(a1, L["fc2"], M)
+            for nm, v in (("x_in", x_in), ("m1", m1), ("r1", r1), ("y1", y1), ("qkv", qkv), ("P", S), ("attn", attn), ("x_mid", x),
+                          ("m2", m2), ("r2", r2), ("y2", y2), ("h1", h1), ("a1", a1)):
+                T[f"l{i}.{nm}"] = v
+        feat, mf, rf, x = self._ln(x, delta, pl.lnf, M, drop_T=Tn)
+        T["x_last"], T["mf"], T["rf"] = x, mf, rf
+        heat = self._head_forward(feat.view(B, gh, gw, D), B, gh, gw, T)
+        tp.meta.update(B=B, H=H, W=W, gh=gh, gw=gw, training=training)
+        return heat, tp
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
+        T, pl = tp.t, self.plan
+        B, gh, gw = tp.meta["B"], tp.meta["gh"], tp.meta["gw"]
+        D, nh = pl.D, pl.heads
+        Np, Tn = gh * gw, gh * gw + 1
+        M, Tp = B * Tn, -(-Tn // 64) * 64
+        dev = self.device
+        self._wg_shape = (B, Tn)
+        scale = 1.0 / math.sqrt(D // nh)
+        qs = 3 * D
+
+        d_feat = self._head_backward(T, B, g_heat)                      # (B, gh, gw, D) bf16
+        dx = torch.zeros(M, D, device=dev, dtype=torch.float32)         # gradient of the residual stream
+        self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn)
+
+        def as_bf16(t32: torch.Tensor) -> torch.Tensor:
+            o = torch.empty(t32.shape, device=dev, dtype=torch.bfloat16)
+            check(self._lib.lp_cast_bf16(_p(t32), t32.numel(), _p(o), ops._stream()), "lp_cast_bf16")
+            return o
+
+        for i in range(pl.depth - 1, -1, -1):
+            L = pl.layers[i]
+            t = lambda nm: T[f"l{i}.{nm}"]  # noqa: E731
+            if trace is not None:
+                trace[f"l{i}.dout"] = dx.clone()
+            # ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+            dmlp = as_bf16(dx)
+            d_a1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M)
+            d_h1 = torch.empty_like(d_a1)
+            check(self._lib.lp_gelu_bwd(_p(t("h1")), _p(d_a1), d_a1.numel(), _p(d_h1), ops._stream()), "lp_gelu_bwd")
+            d_y2 = self._linear_bwd(L["fc1"], t("y2"), d_h1, M)
+            self._ln_bwd(d_y2, t("x_mid"), t("m2"), t("r2"), L["ln2"], M, dx)
+            # ---- attention branch: x_mid = x_in + proj(softmax(Q K^T / 8) V)
+            dproj = as_bf16(dx)
+            d_attn = self._linear_bwd(L["proj"], t("attn"), dproj, M)
+            qkv, Pm = t("qkv"), t("P")
+            dqkv = torch.empty(M, qs, device=dev, dtype=torch.bfloat16)
+            zP = (nh * Tn * Tp, Tn * Tp)       # batch strides of a [B][nh][Tn][Tp] tensor
+            zT = (nh * 64 * Tp, 64 * Tp)       # ... of a [B][nh][64][Tp] transposed head slice
+            # dP = dO V^T, then dS = scale * P (dP - sum(dP P)) in place
+            dP = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
+            self._gemm(_p(d_attn), D, qkv[:, 2 * D:].data_ptr(), qs, Tn, Tn, 64, dP, Tp, n_store=Tp,
+                       batch=(B, nh, Tn * D, 64, Tn * qs, 64, *zP))
+            check(self._lib.lp_softmax_rows_bwd(_p(Pm), _p(dP), B * nh * Tn, Tn, Tp, scale, ops._stream()), "lp_softmax_rows_bwd")
+            dS = dP
+            tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
+            bigT = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [Tn][Tp] square
+            # dV = P^T dO
+            self._transpose(_p(Pm), Tn, Tn, Tp, *zP, bigT, Tp, *zP, B, nh)
+            self._transpose(_p(d_attn), Tn, 64, D, Tn * D, 64, tmpT, Tp, *zT, B, nh)
+            self._gemm(_p(bigT), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv[:, 2 * D:], qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
+            # dQ = dS K
+            self._transpose(qkv[:, D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)
+            self._gemm(_p(dS), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv, qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
+            # dK = dS^T Q
+            self._transpose(_p(dS), Tn, Tn, Tp, *zP, bigT, Tp, *zP, B, nh)
+            self._transpose(_p(qkv), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)
+            self._gemm(_p(bigT), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv[:, D:], qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
+            if trace is not None:
+                trace[f"l{i}.dqkv"] = dqkv
+            d_y1 = self._linear_bwd(L["qkv"], t("y1"), dqkv, M)
+            self._ln_bwd(d_y1, t("x_in"), t("m1"), t("r1"), L["ln1"], M, dx)
+        if trace is not None:
+            trace["tokens.dx"] = dx
+        # ---- embeddings
+        dpatch = torch.empty(B * Np, D, device=dev, dtype=torch.bfloat16)
+        dpos = torch.empty(Tn, D, device=dev, dtype=torch.float32)
+        check(self._lib.lp_vit_tokens_bwd(_p(dx), B, Np, D, _p(dpatch), _p(dpos), ops._stream()), "lp_vit_tokens_bwd")
+        self.G[pl.cls_off:pl.cls_off + D] += dpos[0]
+        gpos = self.G[pl.pos_off:pl.pos_off + pl.n_pos * D].view(pl.n_pos, D)
+        gpos[0] += dpos[0]
+        if gh == self.grid0 and gw == self.grid0:
+            gpos[1:] += dpos[1:]
+        else:
+            check(self._lib.lp_small_matmul(_p(self._interp[(gh, gw)]), _p(dpos[1:]), Np, pl.n_pos - 1, D, 1, 1, _p(gpos[1:]), ops._stream()),
+                  "lp_small_matmul(adjoint)")
+        self._wg_shape = (B, Np)
+        self._linear_bwd(pl.patch_lin, T["patches"], dpatch, B * Np, need_dx=False)
+
+    def _gemm_out_ptr(self, t):  # (kept for symmetry with Engine helpers)
+        return _p(t)

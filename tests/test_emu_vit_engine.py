@@ -1,0 +1,80 @@
+"""ViT backbone + head (lightning_pose_amd.vit_engine.ViTEngine) against the third-party module the reference calls -
+HuggingFace ``ViTModel`` with ``interpolate_pos_encoding=True`` (models/backbones/vit.py:16-49) - plus the reference head,
+in fp32 on the CPU.  A small configuration (2 layers, 2 heads of 64, 3x3 pretraining grid resized to 4x4) keeps it emulator-sized;
+the bf16-mixed policy bounds the agreement."""
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+transformers = pytest.importorskip("transformers")
+
+
+def _oracle(K, hidden, depth, heads, mlp, grid0, seed):
+    from transformers import ViTConfig, ViTModel
+    torch.manual_seed(seed)
+    cfg = ViTConfig(hidden_size=hidden, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=mlp, image_size=16 * grid0,
+                    patch_size=16, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vit = ViTModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():  # make every parameter non-trivial (HF initialises biases / LayerNorm to 0 / 1)
+        for n, p in vit.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+        vit.embeddings.cls_token.normal_(std=0.5)
+        vit.embeddings.position_embeddings.normal_(std=0.5)
+    head = nn.Sequential(nn.PixelShuffle(2), nn.ConvTranspose2d(hidden // 4, K, 3, 2, 1, 1))
+    with torch.no_grad():
+        head[1].weight.normal_(std=0.3)
+        head[1].bias.normal_(std=0.1)
+    return vit, head
+
+
+def _oracle_forward(vit, head, images):
+    hs = vit(images, interpolate_pos_encoding=True).last_hidden_state[:, 1:]
+    n = int(hs.shape[1] ** 0.5)
+    feat = hs.reshape(images.shape[0], n, n, -1).permute(0, 3, 1, 2)
+    logits = head(feat)
+    b, k, h, w = logits.shape
+    return torch.softmax(logits.reshape(b, k, -1), -1).reshape(b, k, h, w)
+
+
+def test_vit_engine_forward_backward_vs_hf(stack_backend):
+    from lightning_pose_amd.vit_engine import ViTEngine
+
+    dev = stack_backend
+    K, hidden, depth, heads, mlp, grid0 = 5, 128, 2, 2, 256, 3
+    vit, head = _oracle(K, hidden, depth, heads, mlp, grid0, seed=0)
+    eng = ViTEngine(K, 2, dev, hidden=hidden, depth=depth, heads=heads, mlp=mlp, patch=16, pretrain_grid=grid0)
+    sd = {f"backbone.vision_encoder.{k}": v for k, v in vit.state_dict().items()}
+    sd["head.upsampling_layers.1.weight"] = head[1].weight.detach()
+    sd["head.upsampling_layers.1.bias"] = head[1].bias.detach()
+    eng.load_state_dict(sd, strict=True)
+    # the state_dict round-trips under the reference's names and shapes
+    for k, v in eng.state_dict().items():
+        torch.testing.assert_close(v.cpu(), sd[k].reshape(v.shape), atol=0, rtol=0)
+
+    gen = torch.Generator().manual_seed(1)
+    images = torch.randn(2, 3, 64, 64, generator=gen)
+    heat, tape = eng.forward(images.to(dev), True)
+    want = _oracle_forward(vit, head, images)
+    assert heat.shape == want.shape == (2, K, 16, 16)
+    torch.testing.assert_close(heat.cpu(), want.detach(), atol=2e-3, rtol=5e-2)  # bf16 operands vs fp32
+
+    g = torch.randn(want.shape, generator=gen)
+    (want * g).sum().backward()
+    eng.zero_grad()
+    eng.backward(tape, g.to(dev))
+    grads = eng.grad_views()
+    ref = {f"backbone.vision_encoder.{k}": p.grad for k, p in vit.named_parameters()}
+    ref["head.upsampling_layers.1.weight"] = head[1].weight.grad
+    ref["head.upsampling_layers.1.bias"] = head[1].bias.grad
+    for k, gr in ref.items():
+        got = grads[k].cpu().reshape(gr.shape)
+        if gr.norm() < 1e-5:
+            # analytically zero (soft-max is invariant to the key bias and to the head's per-channel bias): only rounding noise
+            assert got.norm() < 5e-3, (k, got.norm().item())
+            continue
+        cos = F.cosine_similarity(got.flatten(), gr.flatten(), dim=0).item()
+        rel = ((got - gr).norm() / gr.norm()).item()
+        assert cos > 0.999 and rel < 0.03, (k, cos, rel)  # torch.autocast(bf16) of the same model: cos 0.9999, rel 0.010-0.015
