@@ -66,3 +66,48 @@ def seeded_state_dict(num_keypoints: int, n_head_layers: int) -> dict[str, torch
         sd[f"head.upsampling_layers.{i + 1}.weight"] = ct.weight.detach()
         sd[f"head.upsampling_layers.{i + 1}.bias"] = ct.bias.detach()
     return sd
+
+
+def head_state_dict(in_channels: int, num_keypoints: int, n_head_layers: int) -> dict[str, torch.Tensor]:
+    """HeatmapHead initialisation alone (reference models/heads/heatmap.py:43-83): every ConvTranspose2d constructed first,
+    then xavier-uniform(gain 0.01) weights and zero biases in order."""
+    layers = []
+    cin = in_channels // 4
+    for _ in range(n_head_layers):
+        layers.append(nn.ConvTranspose2d(cin, num_keypoints, 3, stride=2, padding=1, output_padding=1))
+        cin = num_keypoints
+    sd: dict[str, torch.Tensor] = {}
+    for i, ct in enumerate(layers):
+        nn.init.xavier_uniform_(ct.weight, gain=0.01)
+        nn.init.zeros_(ct.bias)
+        sd[f"head.upsampling_layers.{i + 1}.weight"] = ct.weight.detach()
+        sd[f"head.upsampling_layers.{i + 1}.bias"] = ct.bias.detach()
+    return sd
+
+
+def vit_seeded_state_dict(hidden: int, depth: int, heads: int, mlp: int, patch: int, grid: int) -> dict[str, torch.Tensor]:
+    """Random ViT weights under the reference's ``backbone.vision_encoder.*`` names.  The reference only ever loads pretrained
+    weights (``ViTModel.from_pretrained``, models/backbones/vit.py:27); without network access ``pretrained=False`` uses the
+    initialisation of ``transformers.ViTModel(config)`` (truncated normal 0.02 / zeros / ones) - through transformers when it is
+    installed, so the values are what that constructor would give under the current seed."""
+    try:
+        from transformers import ViTConfig, ViTModel
+        cfg = ViTConfig(hidden_size=hidden, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=mlp,
+                        image_size=patch * grid, patch_size=patch)
+        sd = ViTModel(cfg, add_pooling_layer=False).state_dict()
+        return {f"backbone.vision_encoder.{k}": v.detach() for k, v in sd.items()}
+    except ImportError:
+        pre = "backbone.vision_encoder"
+        tn = lambda *shape: nn.init.trunc_normal_(torch.empty(*shape), std=0.02)  # noqa: E731
+        sd = {f"{pre}.embeddings.cls_token": tn(1, 1, hidden), f"{pre}.embeddings.position_embeddings": tn(1, 1 + grid * grid, hidden),
+              f"{pre}.embeddings.patch_embeddings.projection.weight": tn(hidden, 3, patch, patch),
+              f"{pre}.embeddings.patch_embeddings.projection.bias": torch.zeros(hidden)}
+        for i in range(depth):
+            p = f"{pre}.layers.{i}"
+            for nm, (n, k) in (("attention.q_proj", (hidden, hidden)), ("attention.k_proj", (hidden, hidden)), ("attention.v_proj", (hidden, hidden)),
+                               ("attention.o_proj", (hidden, hidden)), ("mlp.fc1", (mlp, hidden)), ("mlp.fc2", (hidden, mlp))):
+                sd[f"{p}.{nm}.weight"], sd[f"{p}.{nm}.bias"] = tn(n, k), torch.zeros(n)
+            for nm in ("layernorm_before", "layernorm_after"):
+                sd[f"{p}.{nm}.weight"], sd[f"{p}.{nm}.bias"] = torch.ones(hidden), torch.zeros(hidden)
+        sd[f"{pre}.layernorm.weight"], sd[f"{pre}.layernorm.bias"] = torch.ones(hidden), torch.zeros(hidden)
+        return sd

@@ -20,7 +20,8 @@ from ..data.bboxes import batch_num_views, model_dims, model_to_frame_batch
 from ..engine import Engine
 from ..losses.losses import RegressionRMSELoss
 from .backbones import backbone_features
-from .backbones._init import seeded_state_dict
+from .backbones._init import head_state_dict, seeded_state_dict, vit_seeded_state_dict
+from .backbones.factory import VIT_CONFIGS
 from .base import BaseSupervisedTracker, SemiSupervisedTrackerMixin
 from .datatypes import HeatmapTrackerLabeledOutputsDict, HeatmapTrackerUnlabeledOutputsDict
 from .heads.heatmap import HeatmapHead, _Holder
@@ -67,24 +68,47 @@ class HeatmapTracker(BaseSupervisedTracker):
         self.downsample_factor = downsample_factor
 
         device = torch.device(kwargs.get("device") or _default_device())
-        self.net = Engine(num_keypoints, downsample_factor, device)
         self.head = HeatmapHead(backbone_arch=backbone, in_channels=self.num_fc_input_features, out_channels=num_keypoints,
                                 downsample_factor=downsample_factor)
         self.backbone = _Holder()
-        init = seeded_state_dict(num_keypoints, self.head.n_layers)
         checkpoint = kwargs.get("backbone_checkpoint")
-        if pretrained:
-            if checkpoint is None:
-                raise RuntimeError("pretrained=True needs ImageNet weights, which cannot be downloaded here; pass "
-                                   "backbone_checkpoint=<state_dict file with torchvision resnet50 keys> or pretrained=False")
-            tv = torch.load(checkpoint, map_location="cpu")
-            tv = tv.get("state_dict", tv)
-            names = {"conv1": "backbone.0", "bn1": "backbone.1", "layer1": "backbone.4", "layer2": "backbone.5",
-                     "layer3": "backbone.6", "layer4": "backbone.7"}
-            for k, v in tv.items():
-                top, _, rest = k.partition(".")
-                if top in names and f"{names[top]}.{rest}" in init:
-                    init[f"{names[top]}.{rest}"] = v
+        if backbone in VIT_CONFIGS:
+            from ..vit_engine import ViTEngine
+            hidden, depth, heads, mlp, patch, grid = VIT_CONFIGS[backbone]
+            self.net = ViTEngine(num_keypoints, downsample_factor, device, hidden=hidden, depth=depth, heads=heads, mlp=mlp, patch=patch,
+                                 pretrain_grid=grid)
+            init = vit_seeded_state_dict(hidden, depth, heads, mlp, patch, grid)
+            init.update(head_state_dict(self.num_fc_input_features, num_keypoints, self.head.n_layers))
+            if pretrained:
+                if checkpoint is None:
+                    raise RuntimeError("pretrained=True needs the DINO weights, which cannot be downloaded here; pass "
+                                       "backbone_checkpoint=<state_dict / safetensors file of facebook/dino-vits16> or pretrained=False")
+                if str(checkpoint).endswith(".safetensors"):
+                    import safetensors.torch
+                    hf = safetensors.torch.load_file(checkpoint, device="cpu")
+                else:
+                    hf = torch.load(checkpoint, map_location="cpu")
+                    hf = hf.get("state_dict", hf)
+                for k, v in hf.items():
+                    k = k[len("vit."):] if k.startswith("vit.") else k
+                    key = ViTEngine.canonical_key(f"backbone.vision_encoder.{k}")
+                    if key in init and init[key].shape == v.shape:
+                        init[key] = v
+        else:
+            self.net = Engine(num_keypoints, downsample_factor, device)
+            init = seeded_state_dict(num_keypoints, self.head.n_layers)
+            if pretrained:
+                if checkpoint is None:
+                    raise RuntimeError("pretrained=True needs ImageNet weights, which cannot be downloaded here; pass "
+                                       "backbone_checkpoint=<state_dict file with torchvision resnet50 keys> or pretrained=False")
+                tv = torch.load(checkpoint, map_location="cpu")
+                tv = tv.get("state_dict", tv)
+                names = {"conv1": "backbone.0", "bn1": "backbone.1", "layer1": "backbone.4", "layer2": "backbone.5",
+                         "layer3": "backbone.6", "layer4": "backbone.7"}
+                for k, v in tv.items():
+                    top, _, rest = k.partition(".")
+                    if top in names and f"{names[top]}.{rest}" in init:
+                        init[f"{names[top]}.{rest}"] = v
         self.net.load_state_dict(init, strict=False)
         self._bind_parameters()
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
@@ -106,7 +130,7 @@ class HeatmapTracker(BaseSupervisedTracker):
                     mod.add_module(part, _Holder())
                 mod = getattr(mod, part)
             leaf = path[-1]
-            if leaf in ("weight", "bias"):
+            if key in grads:  # trainable: weights, biases, the ViT [CLS] token and position table
                 p = nn.Parameter(view, requires_grad=True)
                 p.grad = grads[key]
                 mod.register_parameter(leaf, p)
@@ -115,6 +139,8 @@ class HeatmapTracker(BaseSupervisedTracker):
 
     def _grad_views(self) -> dict[str, torch.Tensor]:
         net, out = self.net, {}
+        if hasattr(net, "grad_views"):
+            return net.grad_views()
         for c in net.plan.convs:
             out[f"{c.name}.weight"] = net.param_view(c, "weight", buf=net.G)
             if c.kind == "convT":

@@ -78,3 +78,37 @@ def test_vit_engine_forward_backward_vs_hf(stack_backend):
         cos = F.cosine_similarity(got.flatten(), gr.flatten(), dim=0).item()
         rel = ((got - gr).norm() / gr.norm()).item()
         assert cos > 0.999 and rel < 0.03, (k, cos, rel)  # torch.autocast(bf16) of the same model: cos 0.9999, rel 0.010-0.015
+
+
+def test_vit_tracker_trains_through_the_reference_surface(stack_backend, monkeypatch):
+    """backbone="vits_dino" through the registry surface: construction, state_dict names, one semi-supervised style step with the
+    fused optimiser (loss goes down on a fixed batch).  A 2-layer / 2-head ViT is substituted for speed."""
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import get_model_class
+    from lightning_pose_amd.models.backbones import factory as bf
+    from lightning_pose_amd.trainer import Trainer
+
+    dev = stack_backend
+    monkeypatch.setitem(bf.VIT_CONFIGS, "vits_dino", (128, 2, 2, 256, 16, 3))
+    monkeypatch.setitem(bf._IMPLEMENTED, "vits_dino", 128)
+    cls = get_model_class("heatmap", False)
+    K = 3
+    model = cls(num_keypoints=K, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="vits_dino",
+                pretrained=False, torch_seed=0, device=dev, optimizer="AdamW", optimizer_params={"learning_rate": 1e-3})
+    sd = model.state_dict()
+    assert "backbone.vision_encoder.embeddings.cls_token" in sd and "backbone.vision_encoder.layers.1.mlp.fc2.weight" in sd
+    assert "head.upsampling_layers.1.weight" in sd and sd["head.upsampling_layers.1.weight"].shape == (128 // 4, K, 3, 3)
+    names = {n for n, _ in model.named_parameters()}
+    assert "backbone.vision_encoder.embeddings.position_embeddings" in names
+    gen = torch.Generator().manual_seed(0)
+    from lightning_pose_amd import ops
+    kp = torch.rand(2, K, 2, generator=gen) * 60 + 2
+    batch = {"images": torch.randn(2, 3, 64, 64, generator=gen).to(dev), "keypoints": kp.reshape(2, -1).to(dev),
+             "heatmaps": ops.generate_heatmaps(kp.to(dev), 64, 64, (16, 16)), "bbox": torch.tensor([[0.0, 0.0, 64.0, 64.0]] * 2).to(dev)}
+    tr = Trainer(data_parallel=False)
+    tr.setup(model)
+    model.train()
+    for g in model.optimizers().param_groups:  # unfreeze the backbone for this check
+        g["lr"] = 1e-3
+    losses = [float(tr.training_batch(model, batch, i)) for i in range(5)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
