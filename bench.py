@@ -36,6 +36,7 @@ import _lp_bootstrap  # noqa: E402,F401
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_FRAME = {384: 72.4, 256: 32.2}  # 3 x 2 x (trunk + head) MACs
+VIT_S_TRAIN_GFLOP_PER_FRAME = {384: 93.1, 256: 36.9}  # SURVEY.md section 8(d), ViT-S/16
 
 
 def synth_batch(dev, rank: int, size: int, n_lab: int, n_unlab: int, K: int):
@@ -80,7 +81,7 @@ def pca_training_array(K: int, size: int) -> torch.Tensor:
     return data
 
 
-def build_model(dev, K: int, size: int, torch_seed: int = 0):
+def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "resnet50"):
     from lightning_pose_amd.losses import LossFactory
     from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
 
@@ -92,7 +93,7 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0):
                            "columns_for_singleview_pca": cols, "data_arr": pca_training_array(K, size), "device": str(dev)},
         "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05, "original_image_height": size, "original_image_width": size},
     }, None)
-    return SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+    return SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone=backbone,
                                         downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev)
 
 
@@ -150,6 +151,8 @@ def main() -> None:
     ap.add_argument("--labeled", type=int, default=64)
     ap.add_argument("--unlabeled", type=int, default=128)
     ap.add_argument("--keypoints", type=int, default=17)
+    ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "vits_dino", "vitb_dino"],
+                    help="resnet50 = BASELINE configs C2/C3 (the headline metric); vits_dino = config C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args()
@@ -167,7 +170,7 @@ def main() -> None:
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
-    model = build_model(dev, args.keypoints, args.size)
+    model = build_model(dev, args.keypoints, args.size, backbone=args.backbone)
     batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True)
     trainer.setup(model)
@@ -199,12 +202,14 @@ def main() -> None:
 
     frames_per_step = (args.labeled + args.unlabeled) * world
     value = frames_per_step * args.steps / elapsed
+    is_vit = args.backbone != "resnet50"
+    arch = {"resnet50": "ResNet-50", "vits_dino": "ViT-S/16", "vitb_dino": "ViT-B/16"}[args.backbone]
     out = {
-        "metric": "training frames/sec (whole node), ResNet-50 384x384 17-kp semi-sup",
+        "metric": f"training frames/sec (whole node), {arch} {args.size}x{args.size} {args.keypoints}-kp semi-sup",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"C2/C3: ResNet-50 SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
+        "config": {"workload": f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
                                "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": world > 1,
@@ -236,11 +241,16 @@ def main() -> None:
                 "by_kernel": {k: {"launches_per_step": v[0] // args.steps, "avg_us": round(1000 * v[1] / v[0], 2),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(by.items())},
             }
-        gf = TRAIN_GFLOP_PER_FRAME.get(args.size)
+        gf = (VIT_S_TRAIN_GFLOP_PER_FRAME if args.backbone == "vits_dino" else {} if is_vit else TRAIN_GFLOP_PER_FRAME).get(args.size)
+        if gf and is_vit:  # no per-launch events on this path yet: the roofline entry is the end-to-end model rate
+            ach = value / world * gf / 1e3
+            out["roofline"] = {"bound": "mfma", "kernel": "lp_gemm_nt + conv_wgrad_kernel (Linear layers and attention products), end to end",
+                               "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
         if gf:
             out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
             out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is_vit:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)
             except Exception as e:  # noqa: BLE001 - the baseline must never cost the measured line
