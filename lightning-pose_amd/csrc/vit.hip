@@ -318,14 +318,55 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const unsigned sh
 }
 
 // ---- batched 2-D transpose of bf16 matrices: out[z][c][r] = in[z][r][c], r < R, c < Cc; out columns [R, ldo) zeroed ----------
+// 64 x 64 tiles through LDS; both global sides move 16 B per lane when the pitches / offsets allow it (they do for every
+// caller here: pitches and batch strides are multiples of 8), 2 B otherwise.
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const unsigned short* __restrict__ in, int R, int Cc, int ldi, long long in_b,
                                                                 long long in_h, unsigned short* __restrict__ out, int ldo, long long out_b,
-                                                                long long out_h, int nh) {
-    __shared__ unsigned short tile[64][66];
+                                                                long long out_h, int nh, int vec) {
+    __shared__ unsigned short tile[64][72];  // row pitch 144 B: 16-B aligned rows, conflict-light column reads
     const int z = blockIdx.z, zb = z / nh, zh = z - zb * nh;
     const unsigned short* src = in + zb * in_b + zh * in_h;
     unsigned short* dst = out + zb * out_b + zh * out_h;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;  // the output pad region is covered by r tiles up to ldo
+    if (vec) {
+        // load: thread -> (row i, 8-column chunk j); 2 passes of 32 rows
+        const int j = threadIdx.x & 7, i0 = threadIdx.x >> 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = i0 + 32 * p, r = r0 + i, c = c0 + j * 8;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < R) {
+                if (c + 8 <= Cc) {
+                    v = *reinterpret_cast<const u16x8*>(src + (size_t)r * ldi + c);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c + e < Cc) v[e] = src[(size_t)r * ldi + c + e];
+                }
+            }
+            *reinterpret_cast<u16x8*>(&tile[i][j * 8]) = v;
+        }
+        __syncthreads();
+        // store: thread -> (output row = input column ci, 8-row chunk jr)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ci = (threadIdx.x >> 3) + 32 * p, jr = threadIdx.x & 7;
+            const int c = c0 + ci, r = r0 + jr * 8;
+            if (c < Cc && r < ldo) {
+                u16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[jr * 8 + e][ci];
+                if (r + 8 <= ldo) {
+                    *reinterpret_cast<u16x8*>(dst + (size_t)c * ldo + r) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (r + e < ldo) dst[(size_t)c * ldo + r + e] = v[e];
+                }
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
@@ -454,7 +495,9 @@ extern "C" int lp_transpose_batched(const void* in_bf16, int R, int Cc, int ldi,
     LP_REQUIRE(in_bf16 && out_bf16 && R > 0 && Cc > 0 && ldi >= Cc && ldo >= R && nb > 0 && nh > 0);
     if ((long long)nb * nh > 65535) return LP_ERR_UNSUPPORTED;
     dim3 grid((Cc + 63) / 64, (ldo + 63) / 64, nb * nh);
+    const int vec = (ldi % 8 == 0 && ldo % 8 == 0 && in_b % 8 == 0 && in_h % 8 == 0 && out_b % 8 == 0 && out_h % 8 == 0 &&
+                     ((uintptr_t)in_bf16 % 16 == 0) && ((uintptr_t)out_bf16 % 16 == 0)) ? 1 : 0;
     hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)in_bf16, R, Cc, ldi, in_b, in_h,
-                       (unsigned short*)out_bf16, ldo, out_b, out_h, nh);
+                       (unsigned short*)out_bf16, ldo, out_b, out_h, nh, vec);
     return launch_status();
 }

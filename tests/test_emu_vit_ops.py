@@ -108,3 +108,13 @@ def test_transpose_batched_with_head_strides_and_zero_pad():
     v = qkv.reshape(nb, T, 3, nh, d)[:, :, 2].permute(0, 2, 3, 1)  # (nb, nh, d, T)
     torch.testing.assert_close(got[..., :T], v, atol=0, rtol=0)
     assert not got[..., T:].any()
+
+
+def test_transpose_batched_scalar_path():
+    gen = torch.Generator().manual_seed(6)
+    R, Cc, ldi, ldo = 19, 13, 15, 21  # odd pitches: the 2-byte path
+    x = bf(torch.randn(3, R, ldi, generator=gen))
+    out = emu.transpose_batched(bits(x).reshape(-1), R, Cc, ldi, R * ldi, 0, ldo, Cc * ldo, 0, 3, 1, 3 * Cc * ldo)
+    got = unbits(out.reshape(3, Cc, ldo))
+    torch.testing.assert_close(got[..., :R], x[..., :Cc].transpose(1, 2), atol=0, rtol=0)
+    assert not got[..., R:].any()
