@@ -444,7 +444,7 @@ extern "C" int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float
     LP_REQUIRE(dy_bf16 && x && mean && rstd && gamma && dx_acc && dgamma_acc && dbeta_acc && M > 0 && D > 0 && drop_T >= 0);
     if (D > 64 * kLnMax) return LP_ERR_UNSUPPORTED;
     int blocks = (M + 3) / 4;
-    if (blocks > 512) blocks = 512;  // bounds the d gamma / d beta atomics per column
+    if (blocks > 2048) blocks = 2048;  // 8 waves per SIMD; also bounds the d gamma / d beta atomics per column
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, rstd,
                        gamma, M, D, drop_T, dx_acc, dgamma_acc, dbeta_acc);
     return launch_status();
