@@ -192,6 +192,88 @@ __global__ __launch_bounds__(256) void softmax2d_fwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = expf(src[(size_t)i * si] - mx) / s;
 }
 
+// Same soft-max for pixel-major logits (sk == 1: the K logits of a pixel are contiguous, as the head's last layer writes them).
+// One 1024-lane workgroup per frame: every lane owns pixels i = lane, lane + 1024, ... and reads a pixel's K logits as 16-B
+// pieces (the per-map kernel above reads the same cache lines K times with a 4-B stride); pass 1 keeps K online (max, sum)
+// pairs per lane and merges them through LDS, pass 2 re-reads the (L2-resident) logits and writes each map with coalesced rows.
+constexpr int kSmK = 32;  // maps per frame handled by the pixel-major kernel
+__global__ __launch_bounds__(1024) void softmax2d_pixmajor_kernel(const float* __restrict__ in, long sb, long si, int K, int n,
+                                                                  float* __restrict__ out) {
+    __shared__ float red_m[16][kSmK], red_s[16][kSmK], fin_m[kSmK], fin_is[kSmK];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = in + (size_t)b * sb;
+    const int k4 = (K + 3) >> 2;
+    float m[kSmK], s[kSmK];
+#pragma unroll
+    for (int k = 0; k < kSmK; ++k) {
+        m[k] = -INFINITY;
+        s[k] = 0.f;
+    }
+    for (int i = tid; i < n; i += 1024) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(src + (size_t)i * si);
+#pragma unroll
+        for (int q = 0; q < kSmK / 4; ++q) {
+            if (q < k4) {
+                const f32x4 v = row[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = q * 4 + e;
+                    const float x = v[e];
+                    const float mm = fmaxf(m[k], x);
+                    s[k] = s[k] * __expf(m[k] - mm) + __expf(x - mm);  // exp(-inf - finite) = 0 on the first pixel
+                    m[k] = mm;
+                }
+            }
+        }
+    }
+    // merge across the wave, then across the 16 waves
+#pragma unroll
+    for (int k = 0; k < kSmK; ++k) {
+        if (k < K) {
+            float mk = m[k], sk_ = s[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float m2 = __shfl_xor(mk, d, 64), s2 = __shfl_xor(sk_, d, 64);
+                const float mm = fmaxf(mk, m2);
+                sk_ = (mk == -INFINITY ? 0.f : sk_ * __expf(mk - mm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mm));
+                mk = mm;
+            }
+            if (lane == 0) {
+                red_m[wave][k] = mk;
+                red_s[wave][k] = sk_;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < K) {
+        float mk = red_m[0][tid], sk_ = red_s[0][tid];
+        for (int w = 1; w < 16; ++w) {
+            const float m2 = red_m[w][tid], s2 = red_s[w][tid];
+            const float mm = fmaxf(mk, m2);
+            sk_ = (mk == -INFINITY ? 0.f : sk_ * __expf(mk - mm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mm));
+            mk = mm;
+        }
+        fin_m[tid] = mk;
+        fin_is[tid] = 1.f / sk_;
+    }
+    __syncthreads();
+    float* dst = out + (size_t)b * K * n;
+    for (int i = tid; i < n; i += 1024) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(src + (size_t)i * si);
+#pragma unroll
+        for (int q = 0; q < kSmK / 4; ++q) {
+            if (q < k4) {
+                const f32x4 v = row[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = q * 4 + e;
+                    if (k < K) dst[(size_t)k * n + i] = __expf(v[e] - fin_m[k]) * fin_is[k];
+                }
+            }
+        }
+    }
+}
+
 // dlogit_i = p_i (g_i - sum_j g_j p_j); written back as bf16 (it feeds the MFMA kernels) in the strided layout of the logits
 __global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, int K,
                                                             int n, unsigned short* __restrict__ gin, long sb, long si, long sk) {
@@ -306,7 +388,11 @@ extern "C" int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, l
     using namespace lp;
     LP_REQUIRE(in && out && B >= 0 && K > 0 && n > 0);
     if (B == 0) return LP_OK;
-    hipLaunchKernelGGL(softmax2d_fwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, in, stride_b, stride_i, stride_k, K, n, out);
+    // pixel-major logits (the head's layout): one workgroup per frame reading whole pixels; needs 16-B readable rows
+    if (stride_k == 1 && K <= kSmK && stride_i % 4 == 0 && stride_i >= ((K + 3) & ~3) && stride_b % 4 == 0 && ((uintptr_t)in & 15) == 0)
+        hipLaunchKernelGGL(softmax2d_pixmajor_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, in, stride_b, stride_i, K, n, out);
+    else
+        hipLaunchKernelGGL(softmax2d_fwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, in, stride_b, stride_i, stride_k, K, n, out);
     return launch_status();
 }
 

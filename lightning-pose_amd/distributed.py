@@ -60,7 +60,8 @@ class DataParallel:
             return
         e = self.engine
         dist.broadcast(e.P, src=src, group=self.pg)
-        dist.broadcast(e.R, src=src, group=self.pg)
+        if e.R.numel():  # BatchNorm running statistics (none for the ViT engine)
+            dist.broadcast(e.R, src=src, group=self.pg)
         e.refresh_weight_copies()
 
     def all_reduce_gradients(self, async_op: bool = True) -> None:

@@ -80,6 +80,17 @@ def test_softmax2d_fwd_bwd():
     assert not gin[:, :, k:].any()
 
 
+@pytest.mark.parametrize("b,k,n,c", [(3, 17, 2500, 64), (2, 17, 300, 17), (1, 32, 1100, 32)])
+def test_softmax2d_pixel_major_and_fallback(b, k, n, c):
+    """the head's layout (K logits of a pixel contiguous, padded to c): one 1024-lane workgroup per frame; c = 17 (rows not
+    16-B readable) takes the per-map kernel"""
+    gen = torch.Generator().manual_seed(b * 100 + k)
+    logits = torch.randn(b, n, c, generator=gen) * 3
+    want = torch.softmax(logits[:, :, :k].permute(0, 2, 1), -1)
+    got = emu.softmax2d(logits.numpy(), k)
+    np.testing.assert_allclose(got, want.numpy(), atol=1e-7, rtol=2e-5)
+
+
 def test_temporal_golden_and_grad(golden):
     g = golden("losses")
     kp, conf = g["t_kp"], g["t_conf"]
