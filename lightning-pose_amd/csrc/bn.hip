@@ -20,6 +20,15 @@ __device__ __forceinline__ void unpack8(const u16x8& v, float (&f)[8]) {
 
 __device__ __forceinline__ u16x8 pack8(const float (&f)[8]) { return pack_bf16x8(f); }
 
+// streaming 16-B load of data that is dead afterwards (keeps it from displacing reusable lines in L2 / MALL)
+__device__ __forceinline__ u16x8 load_stream8(const unsigned short* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p));
+#else
+    return *reinterpret_cast<const u16x8*>(p);
+#endif
+}
+
 // ---- per-channel sums over rows: sums[0][c] += sum a, sums[1][c] += sum a*b -------------------------------------
 // MODE 0: plain statistics (sum x, sum x^2)
 // MODE 1: BN backward reductions: dz = relu-masked dy;  sum dz, sum dz * xhat
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
         u16x8 xv[U], rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (q + u * stride < n_chunks) xv[u] = *reinterpret_cast<const u16x8*>(X + (q + u * stride) * 8);
+            if (q + u * stride < n_chunks) xv[u] = load_stream8(X + (q + u * stride) * 8);
         if (residual != nullptr) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -205,8 +214,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (q + u * stride < n_chunks) {
-                dv[u] = *reinterpret_cast<const u16x8*>(DY + (q + u * stride) * 8);
-                xv[u] = *reinterpret_cast<const u16x8*>(X + (q + u * stride) * 8);
+                dv[u] = load_stream8(DY + (q + u * stride) * 8);
+                xv[u] = load_stream8(X + (q + u * stride) * 8);
                 if (Yout != nullptr) yv[u] = *reinterpret_cast<const u16x8*>(Yout + (q + u * stride) * 8);
             }
 #pragma unroll
