@@ -222,10 +222,6 @@ int lp_bn_finalize(const float* sums, float count, int C, float eps, float momen
 /* relu_bits (optional, M*C/8 bytes): bit q of byte i = (y[8*i + q] > 0): a 16x smaller ReLU mask for the backward pass */
 int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                 int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream);
-/* lp_bn_finalize followed by lp_bn_apply as ONE launch (same arithmetic): the training-mode forward after the statistics */
-int lp_bn_finalize_apply(const void* x, const float* sums, float count, float eps, float momentum, float* mean, float* invstd,
-                         float* running_mean, float* running_var, const float* gamma, const float* beta, const void* residual, int relu,
-                         int M, int C, void* y, void* relu_bits, lp_stream_t stream);
 /* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL); dbeta/dgamma accumulate too */
 int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
                      float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);

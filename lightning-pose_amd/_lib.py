@@ -82,7 +82,6 @@ PROTOTYPES = {
     "lp_bn_stats": (_I, [_P, _I, _I, _P, _P]),
     "lp_bn_finalize": (_I, [_P, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
-    "lp_bn_finalize_apply": (_I, [_P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
     "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),

@@ -133,22 +133,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
 // y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
 // The grid stride is a multiple of the row length (host guarantees it), so a lane keeps ONE channel chunk for its whole walk:
 // its 8 (mean, scale, shift) triples live in registers and the loop is nothing but 16-B streams, 4 chunks in flight per lane.
-// FROM_SUMS: the statistics kernel is folded in - every lane derives mean / invstd of its 8 channels from the raw [sum, sumsq]
-// (same expressions as bn_finalize_kernel), and the first C/8 lanes of the grid also publish them (mean, invstd for the backward
-// pass) and update the running statistics.
-struct BnFinalize {
-    const float* sums;   // (2, C)
-    float count, eps, momentum;
-    float* mean_out;     // (C,)
-    float* invstd_out;   // (C,)
-    float* running_mean; // (C,) or nullptr
-    float* running_var;
-};
-
-template <bool FROM_SUMS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, BnFinalize fin,
-                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_chunks, int C, unsigned short* __restrict__ Y,
                                                        unsigned char* __restrict__ bits) {
@@ -159,26 +145,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
     float mu[8], sc[8], be[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        float is;
-        if (FROM_SUMS) {
-            mu[i] = fin.sums[c + i] / fin.count;
-            float var = fin.sums[C + c + i] / fin.count - mu[i] * mu[i];
-            var = fmaxf(var, 0.f);
-            is = 1.f / sqrtf(var + fin.eps);
-            if (q < (size_t)chunks) {  // one lane per channel chunk publishes
-                fin.mean_out[c + i] = mu[i];
-                fin.invstd_out[c + i] = is;
-                if (fin.running_mean != nullptr) {
-                    const float unbiased = fin.count > 1.f ? var * fin.count / (fin.count - 1.f) : var;
-                    fin.running_mean[c + i] = (1.f - fin.momentum) * fin.running_mean[c + i] + fin.momentum * mu[i];
-                    fin.running_var[c + i] = (1.f - fin.momentum) * fin.running_var[c + i] + fin.momentum * unbiased;
-                }
-            }
-        } else {
-            mu[i] = mean[c + i];
-            is = invstd[c + i];
-        }
-        sc[i] = is * gamma[c + i];
+        mu[i] = mean[c + i];
+        sc[i] = invstd[c + i] * gamma[c + i];
         be[i] = beta[c + i];
     }
     constexpr int U = 4;
@@ -452,22 +420,7 @@ extern "C" int lp_bn_apply(const void* x, const float* mean, const float* invstd
     LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
-    hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
-                       mean, invstd, BnFinalize{nullptr, 1.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr}, gamma, beta,
-                       (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits);
-    return launch_status();
-}
-
-// lp_bn_finalize + lp_bn_apply in one launch (training forward): statistics from the raw sums, published for the backward pass
-extern "C" int lp_bn_finalize_apply(const void* x, const float* sums, float count, float eps, float momentum, float* mean, float* invstd,
-                                    float* running_mean, float* running_var, const float* gamma, const float* beta, const void* residual,
-                                    int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream) {
-    using namespace lp;
-    LP_REQUIRE(x && sums && mean && invstd && gamma && beta && y && M > 0 && C > 0 && count > 0.f);
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
-    const size_t n_chunks = (size_t)M * (C / 8);
-    hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
-                       (const float*)nullptr, (const float*)nullptr, BnFinalize{sums, count, eps, momentum, mean, invstd, running_mean, running_var},
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
                        gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits);
     return launch_status();
 }

@@ -365,9 +365,6 @@ class Engine:
         """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass"""
         mean = torch.empty(b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
-        y = torch.empty_like(z)
-        bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
-        gamma, beta = self.param_view(b, "weight"), self.param_view(b, "bias")
         if training:
             if not have_sums:
                 check(self._lib.lp_bn_stats(_p(z), M, b.C, _p(sums), ops._stream()), "lp_bn_stats")
@@ -375,16 +372,16 @@ class Engine:
             if self.sync_bn:
                 dist.all_reduce(sums, group=self.process_group)
                 count *= dist.get_world_size(self.process_group)
-            # statistics -> (mean, invstd, running stats) and the normalisation itself in one launch
-            check(self._lib.lp_bn_finalize_apply(_p(z), _p(sums), count, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd),
-                                                 _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")),
-                                                 _p(gamma), _p(beta), _p(residual), int(relu), M, b.C, _p(y), _p(bits), ops._stream()),
-                  "lp_bn_finalize_apply")
+            check(self._lib.lp_bn_finalize(_p(sums), count, b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd),
+                                           _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")),
+                                           ops._stream()), "lp_bn_finalize")
         else:
             mean.copy_(self.running_view(b, "running_mean"))
             invstd.copy_((self.running_view(b, "running_var") + BN_EPS).rsqrt())
-            check(self._lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), int(relu), M, b.C, _p(y), _p(bits),
-                                        ops._stream()), "lp_bn_apply")
+        y = torch.empty_like(z)
+        bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
+        check(self._lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias")),
+                                    _p(residual), int(relu), M, b.C, _p(y), _p(bits), ops._stream()), "lp_bn_apply")
         if want_bits:
             return y, mean, invstd, bits
         return y, mean, invstd

@@ -346,22 +346,16 @@ def stem_wgrad(x4_bits, dy_bits, g, split=0):
     return dw.np()
 
 
-def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False,
-               fused=False):
-    """fused: lp_bn_finalize_apply (one launch) instead of lp_bn_finalize + lp_bn_apply"""
+def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False):
     xb, rb = Buf(x_bits), B(residual_bits)
     sums, mean, invstd = Z((2, Cn)), Z(Cn), Z(Cn)
     ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, stream()))
     rm = Buf(running[0]) if running is not None else None
     rv = Buf(running[1]) if running is not None else None
+    ok(lib().lp_bn_finalize(sums.p, float(M), Cn, eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), stream()))
     y, gb, bb = Z((M, Cn), np.uint16), Buf(f32(gamma)), Buf(f32(beta))
     bits = Z(M * Cn // 8, np.uint8) if want_bits else None
-    if fused:
-        ok(lib().lp_bn_finalize_apply(xb.p, sums.p, float(M), eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), gb.p, bb.p, ptr(rb),
-                                      int(relu), M, Cn, y.p, ptr(bits), stream()))
-    else:
-        ok(lib().lp_bn_finalize(sums.p, float(M), Cn, eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), stream()))
-        ok(lib().lp_bn_apply(xb.p, mean.p, invstd.p, gb.p, bb.p, ptr(rb), int(relu), M, Cn, y.p, ptr(bits), stream()))
+    ok(lib().lp_bn_apply(xb.p, mean.p, invstd.p, gb.p, bb.p, ptr(rb), int(relu), M, Cn, y.p, ptr(bits), stream()))
     if running is not None:
         running[0][:] = rm.np()
         running[1][:] = rv.np()

@@ -48,20 +48,6 @@ def test_batchnorm_fwd_bwd(M, C, relu, res):
         torch.testing.assert_close(emu.from_bf16_bits(dres), r.grad, **tol)
 
 
-@pytest.mark.parametrize("M,C", [(300, 64), (513, 24), (40, 2048)])
-def test_batchnorm_finalize_apply_fused_equals_two_launches(M, C):
-    gen = torch.Generator().manual_seed(M)
-    x = emu.to_bf16_bits(torch.randn(M, C, generator=gen) * 1.5 - 0.2)
-    gamma, beta = (torch.rand(C, generator=gen) + 0.5).numpy(), torch.randn(C, generator=gen).numpy()
-    outs = []
-    for fused in (False, True):
-        run = [np.zeros(C, np.float32), np.ones(C, np.float32)]
-        y, mean, invstd, bits = emu.bn_forward(x, M, C, gamma, beta, relu=True, running=run, want_bits=True, fused=fused)
-        outs.append((y, mean, invstd, bits, run[0].copy(), run[1].copy()))
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
-
-
 def test_maxpool_fwd_bwd_with_ties():
     gen = torch.Generator().manual_seed(1)
     B, H, W, C = 2, 9, 10, 16
