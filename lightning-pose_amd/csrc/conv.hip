@@ -146,6 +146,16 @@ __device__ __forceinline__ u16x8 zero8() {
 
 __device__ __forceinline__ u16x8 load8(const unsigned short* p) { return *reinterpret_cast<const u16x8*>(p); }
 
+// 16-B load of data that is dead after this read (the gradient addend, ReLU masks): non-temporal, so it does not displace the
+// tensors the next kernels re-read from L2 / MALL
+__device__ __forceinline__ u16x8 load8_stream(const unsigned short* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(p));
+#else
+    return *reinterpret_cast<const u16x8*>(p);
+#endif
+}
+
 // two 8-byte halves (stem: NHWC4 pixels are only 8-byte aligned)
 __device__ __forceinline__ u16x8 load4x2(const unsigned short* p0, bool ok0, const unsigned short* p1, bool ok1) {
     u16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     const int src_w = (MODE == kModeDgrad) ? g.Wo : g.Wi;
     const bool halved = (MODE == kModeDgrad) && g.stride == 2;  // stride-2 dgrad: tap (r,s) -> pixel ((py-r)/2, (px-s)/2)
     const int KT = K / kBK;  // 0 for a parity class without taps: the epilogue then just writes addend / zeros
+    const bool stream_a = tiles_n == 1 && lat.nr * lat.ns == 1;
 
     u16x8 ra[4], rb[BN / 32];
     int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
@@ -298,8 +309,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 }
             }
             const unsigned tcb = (unsigned)tc * 2u;
+            if (stream_a) {  // single column of tiles and a single tap: every activation byte is fetched exactly once
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = buf_load16(rsrc_x, voff[i], tcb);
+                for (int i = 0; i < 4; ++i) ra[i] = buf_load16_nt(rsrc_x, voff[i], tcb);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[i] = buf_load16(rsrc_x, voff[i], tcb);
+            }
             if (with_b) {
 #pragma unroll
                 for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], wtap + tcb);  // weights [N][R*S*C], K-contiguous
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     }
                     if (kReads && ep.addend) {
 #pragma unroll
-                        for (int i = 0; i < HB; ++i) la[i] = load8(ep.addend + off[i]);
+                        for (int i = 0; i < HB; ++i) la[i] = load8_stream(ep.addend + off[i]);
                     }
                     if (kReads && ep.bn_z) {
 #pragma unroll
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     }
                     if (kReads && ep.relu_mask) {
 #pragma unroll
-                        for (int i = 0; i < HB; ++i) lm[i] = load8(ep.relu_mask + off[i]);
+                        for (int i = 0; i < HB; ++i) lm[i] = load8_stream(ep.relu_mask + off[i]);
                     }
                     if (kReads && ep.relu_bits) {
 #pragma unroll

@@ -63,6 +63,12 @@ __device__ __forceinline__ u16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned 
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return __builtin_bit_cast(u16x8, v);
 }
+// same, marked non-temporal (streamed once: do not keep the lines in L2 / MALL)
+__device__ __forceinline__ u16x8 buf_load16_nt(buf_rsrc r, unsigned voff, unsigned soff) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
+    return __builtin_bit_cast(u16x8, v);
+}
 #else
 struct buf_rsrc {
     const char* p;
@@ -74,6 +80,7 @@ __device__ __forceinline__ u16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned 
     if (voff < r.bytes && (unsigned long long)voff + 16 <= r.bytes) v = *reinterpret_cast<const u16x8*>(r.p + voff + soff);
     return v;
 }
+__device__ __forceinline__ u16x8 buf_load16_nt(buf_rsrc r, unsigned voff, unsigned soff) { return buf_load16(r, voff, soff); }
 #endif
 
 // ---- LDS transpose read (ds_read_b64_tr_b16): within every group of 16 lanes the 16 addresses name a [4 rows][16 columns]
