@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblp_hip.so")
+LIB_PATH = os.environ.get("LP_HIP_LIB") or os.path.join(_HERE, "liblp_hip.so")  # LP_HIP_LIB: A/B builds of the same ABI
 
 
 class LpHipUnavailable(RuntimeError):
