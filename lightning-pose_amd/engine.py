@@ -20,6 +20,7 @@ BatchNorm per forward call with running-stat updates, SyncBatchNorm across ranks
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass, field
 
@@ -183,6 +184,10 @@ class Tape:
 
 
 class Engine:
+    # weight gradients on a side stream (measured on the ResNet step: +2 %; on the ViT step, whose main stream is already
+    # MFMA-bound, -8 %, so ViTEngine turns it off)
+    wgrad_side_stream = True
+
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
         self.device = torch.device(device)
         ops.require_device_type(self.device)
@@ -207,6 +212,8 @@ class Engine:
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
         self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
         self._bn_ws: torch.Tensor | None = None     # per-tile column sums of the fused BatchNorm reductions
+        self._side = None                            # side stream of the weight-gradient launches (created on first use)
+        self._side_busy = False
 
     def _timed(self, tag: str, flops: float, fn):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -220,12 +227,33 @@ class Engine:
         return out
 
     def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False) -> None:
+        """Weight gradient of one layer.  Nothing in the backward pass consumes it, so on the device it runs on a SIDE stream,
+        ordered after the kernel that produced ``dy``: its MFMA-bound tiles fill the CUs that the data-gradient's tails and the
+        HBM-bound BatchNorm kernels leave idle.  All weight gradients share that stream (and the split-K workspace);
+        ``_join_side_stream`` orders the main stream after them at the end of backward()."""
         need = self._lib.lp_conv_wgrad_workspace_bytes(C.byref(g), 0)
         if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
+            self._join_side_stream()  # the old workspace may still be in use
             self._wgrad_ws = torch.empty(max(need, 96 << 20), device=self.device, dtype=torch.uint8)
         fn = self._lib.lp_stem_wgrad if stem else self._lib.lp_conv_wgrad
-        check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()),
-              "lp_stem_wgrad" if stem else "lp_conv_wgrad")
+        what = "lp_stem_wgrad" if stem else "lp_conv_wgrad"
+        if self.device.type != "cuda" or not self.wgrad_side_stream or os.environ.get("LP_WGRAD_SIDE_STREAM", "1") == "0":
+            check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()), what)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)          # dy (and the zeroed / partially accumulated G) are ready
+        x.record_stream(self._side)           # keep the operands' memory from being recycled under the side stream
+        dy.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()), what)
+        self._side_busy = True
+
+    def _join_side_stream(self) -> None:
+        if getattr(self, "_side_busy", False):
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._side_busy = False
 
     @staticmethod
     def _flops(c: "ConvP", g) -> float:
@@ -642,3 +670,4 @@ class Engine:
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
                     lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True))
+        self._join_side_stream()

@@ -130,6 +130,8 @@ class ViTPlan:
 class ViTEngine(Engine):
     """ViT-S/16 defaults = facebook/dino-vits16 (hidden 384, 12 layers, 6 heads, MLP 1536, patch 16, 224-px position table)."""
 
+    wgrad_side_stream = False
+
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0", hidden: int = 384,
                  depth: int = 12, heads: int = 6, mlp: int = 1536, patch: int = 16, pretrain_grid: int = 14):
         self.device = torch.device(device)
@@ -153,6 +155,7 @@ class ViTEngine(Engine):
         self.profile = None
         self._wgrad_ws = None
         self._bn_ws = None
+        self._side, self._side_busy = None, False
         self._interp: dict[tuple[int, int], torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------ params
@@ -417,6 +420,7 @@ class ViTEngine(Engine):
                   "lp_small_matmul(adjoint)")
         self._wg_shape = (B, Np)
         self._linear_bwd(pl.patch_lin, T["patches"], dpatch, B * Np, need_dx=False)
+        self._join_side_stream()
 
     def _gemm_out_ptr(self, t):  # (kept for symmetry with Engine helpers)
         return _p(t)
