@@ -97,40 +97,61 @@ __global__ __launch_bounds__(256) void small_matmul_kernel(const float* __restri
     }
 }
 
-// ---- LayerNorm over D (one wave per row, D <= 64 * 16), optional residual add in front ------------------------------
+// ---- LayerNorm over D (one wave per row, D % 4 == 0, D <= 1024), optional residual add in front ---------------------------
 // x_out = x (+ delta);  y = (x_out - mean) * rstd * gamma + beta.  `drop_T` > 0: rows with (row % drop_T) == 0 ([CLS]) are
 // not written to y and the others are compacted (the feature map the head consumes).
-constexpr int kLnMax = 16;  // fp32 values per lane
+// A lane owns float4 pieces (piece index lane + 64 * pass): 16-B accesses on the fp32 streams, 8-B on the bf16 ones.
+constexpr int kLnPass = 4;  // D <= 4 * 64 * 4 = 1024
+__device__ __forceinline__ void unpack4(const u16x4& v, float (&f)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = bf16_to_f32(v[i]);
+}
+__device__ __forceinline__ u16x4 pack4(const float (&f)[4]) {
+    const unsigned lo = pack_bf16x2(f[0], f[1]), hi = pack_bf16x2(f[2], f[3]);
+    u16x4 v = {(unsigned short)(lo & 0xffffu), (unsigned short)(lo >> 16), (unsigned short)(hi & 0xffffu), (unsigned short)(hi >> 16)};
+    return v;
+}
+
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const unsigned short* __restrict__ delta,
                                                             float* __restrict__ x_out, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, int M, int D, int drop_T,
                                                             unsigned short* __restrict__ y, float* __restrict__ mean,
                                                             float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (D + 63) / 64;
+    const int pieces = D >> 2;
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        float v[kLnMax];
+        float v[kLnPass][4];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < kLnMax; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = 0.f;
-            if (i < per && c < D) {
-                v[i] = x[(size_t)row * D + c];
-                if (delta != nullptr) v[i] += bf16_to_f32(delta[(size_t)row * D + c]);
-                s += v[i];
+        for (int p = 0; p < kLnPass; ++p) {
+            const int pc = lane + 64 * p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[p][e] = 0.f;
+            if (pc < pieces) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + pc * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[p][e] = xv[e];
+                if (delta != nullptr) {
+                    float d[4];
+                    unpack4(*reinterpret_cast<const u16x4*>(delta + (size_t)row * D + pc * 4), d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[p][e] += d[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += v[p][e];
             }
         }
         const float mu = wave_sum(s) / (float)D;
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < kLnMax; ++i) {
-            const int c = lane + 64 * i;
-            if (i < per && c < D) {
-                const float d = v[i] - mu;
-                ss = fmaf(d, d, ss);
+        for (int p = 0; p < kLnPass; ++p)
+            if (lane + 64 * p < pieces) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[p][e] - mu;
+                    ss = fmaf(d, d, ss);
+                }
             }
-        }
         const float rs = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
         if (lane == 0) {
             mean[row] = mu;
@@ -144,11 +165,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             yrow = b * (drop_T - 1) + t - 1;
         }
 #pragma unroll
-        for (int i = 0; i < kLnMax; ++i) {
-            const int c = lane + 64 * i;
-            if (i < per && c < D) {
-                if (x_out != nullptr) x_out[(size_t)row * D + c] = v[i];
-                if (wy) y[(size_t)yrow * D + c] = f32_to_bf16(fmaf((v[i] - mu) * rs, gamma[c], beta[c]));
+        for (int p = 0; p < kLnPass; ++p) {
+            const int pc = lane + 64 * p;
+            if (pc < pieces) {
+                if (x_out != nullptr) {
+                    const f32x4 o = {v[p][0], v[p][1], v[p][2], v[p][3]};
+                    *reinterpret_cast<f32x4*>(x_out + (size_t)row * D + pc * 4) = o;
+                }
+                if (wy) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + pc * 4), bt = *reinterpret_cast<const f32x4*>(beta + pc * 4);
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf((v[p][e] - mu) * rs, g[e], bt[e]);
+                    *reinterpret_cast<u16x4*>(y + (size_t)yrow * D + pc * 4) = pack4(o);
+                }
             }
         }
     }
@@ -160,12 +190,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                                                             const float* __restrict__ gamma, int M, int D, int drop_T,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
-    __shared__ float red[2][4][64 * kLnMax / 4];  // [gamma|beta][wave][column slot]  (D <= 1024 -> per <= 16; sized for D <= 1024)
+    __shared__ float red[2][4][256];  // [gamma|beta][wave][column of the current pass]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (D + 63) / 64;
-    float ag[kLnMax], ab[kLnMax];
+    const int pieces = D >> 2;
+    float ag[kLnPass][4], ab[kLnPass][4], gm[kLnPass][4];
 #pragma unroll
-    for (int i = 0; i < kLnMax; ++i) ag[i] = ab[i] = 0.f;
+    for (int p = 0; p < kLnPass; ++p) {
+        const int pc = lane + 64 * p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ag[p][e] = ab[p][e] = 0.f;
+            gm[p][e] = pc < pieces ? gamma[pc * 4 + e] : 0.f;
+        }
+    }
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         int yrow = row;
         bool has = true;
@@ -175,50 +212,60 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             yrow = b * (drop_T - 1) + t - 1;
         }
         const float mu = mean[row], rs = rstd[row];
-        float g[kLnMax], xh[kLnMax];
+        float g[kLnPass][4], xh[kLnPass][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < kLnMax; ++i) {
-            const int c = lane + 64 * i;
-            g[i] = xh[i] = 0.f;
-            if (i < per && c < D) {
-                const float d = has ? bf16_to_f32(dy[(size_t)yrow * D + c]) : 0.f;
-                xh[i] = (x[(size_t)row * D + c] - mu) * rs;
-                ag[i] = fmaf(d, xh[i], ag[i]);
-                ab[i] += d;
-                g[i] = d * gamma[c];
-                s1 += g[i];
-                s2 = fmaf(g[i], xh[i], s2);
+        for (int p = 0; p < kLnPass; ++p) {
+            const int pc = lane + 64 * p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[p][e] = xh[p][e] = 0.f;
+            if (pc < pieces) {
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has) unpack4(*reinterpret_cast<const u16x4*>(dy + (size_t)yrow * D + pc * 4), d);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + pc * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[p][e] = (xv[e] - mu) * rs;
+                    ag[p][e] = fmaf(d[e], xh[p][e], ag[p][e]);
+                    ab[p][e] += d[e];
+                    g[p][e] = d[e] * gm[p][e];
+                    s1 += g[p][e];
+                    s2 = fmaf(g[p][e], xh[p][e], s2);
+                }
             }
         }
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int i = 0; i < kLnMax; ++i) {
-            const int c = lane + 64 * i;
-            if (i < per && c < D) dx[(size_t)row * D + c] += rs * (g[i] - s1 - xh[i] * s2);
+        for (int p = 0; p < kLnPass; ++p) {
+            const int pc = lane + 64 * p;
+            if (pc < pieces) {
+                f32x4* dst = reinterpret_cast<f32x4*>(dx + (size_t)row * D + pc * 4);
+                f32x4 o = *dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rs * (g[p][e] - s1 - xh[p][e] * s2);
+                *dst = o;
+            }
         }
     }
-    // column sums of this workgroup: 4 waves -> LDS -> one atomic per column
-    for (int i0 = 0; i0 < per; i0 += 4) {  // 4 column slots (256 columns) at a time through the LDS scratch
+    // column sums of this workgroup: 4 waves -> LDS -> one atomic per column, one 256-column pass at a time
+#pragma unroll
+    for (int p = 0; p < kLnPass; ++p) {
+        if (64 * p >= pieces) break;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < per && i0 + j < kLnMax) {
-                red[0][wave][j * 64 + lane] = ag[i0 + j];
-                red[1][wave][j * 64 + lane] = ab[i0 + j];
-            }
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][lane * 4 + e] = ag[p][e];
+            red[1][wave][lane * 4 + e] = ab[p][e];
         }
         __syncthreads();
-        const int j = threadIdx.x >> 6, l = threadIdx.x & 63;  // thread -> (slot j, lane l)
-        if (i0 + j < per) {
-            const int c = l + 64 * (i0 + j);
-            if (c < D) {
-                const float tg = (red[0][0][j * 64 + l] + red[0][1][j * 64 + l]) + (red[0][2][j * 64 + l] + red[0][3][j * 64 + l]);
-                const float tb = (red[1][0][j * 64 + l] + red[1][1][j * 64 + l]) + (red[1][2][j * 64 + l] + red[1][3][j * 64 + l]);
-                atomicAdd(&dgamma[c], tg);
-                atomicAdd(&dbeta[c], tb);
-            }
+        const int cl = threadIdx.x;            // column within this pass
+        const int c = 256 * p + cl;
+        if (c < D) {
+            const float tg = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+            const float tb = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+            atomicAdd(&dgamma[c], tg);
+            atomicAdd(&dbeta[c], tb);
         }
     }
 }
@@ -251,68 +298,93 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const unsigned short* __r
     }
 }
 
-// ---- attention soft-max over the n valid columns of bf16 rows of pitch ld, in place; pad columns are zeroed ---------------
-constexpr int kSmMax = 16;  // columns per lane: ld <= 1024
+// ---- attention soft-max over the n valid columns of bf16 rows of pitch ld (ld % 8 == 0, ld <= 1024), in place; pad columns are
+// zeroed.  One wave per row; a lane owns 16-B chunks (chunk index lane + 64 * pass), so a 640-wide row is two accesses per lane.
+constexpr int kSmPass = 2;
 __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(unsigned short* __restrict__ s, int rows, int n, int ld, float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (ld + 63) / 64;
+    const int chunks = ld >> 3;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         unsigned short* p = s + (size_t)row * ld;
-        float v[kSmMax];
+        float v[kSmPass][8];
         float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < kSmMax; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = -INFINITY;
-            if (i < per && c < n) {
-                v[i] = bf16_to_f32(p[c]) * scale;
-                mx = fmaxf(mx, v[i]);
+        for (int q = 0; q < kSmPass; ++q) {
+            const int ch = lane + 64 * q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[q][e] = -INFINITY;
+            if (ch < chunks) {
+                float f[8];
+                unpack8v(*reinterpret_cast<const u16x8*>(p + ch * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ch * 8 + e < n) {
+                        v[q][e] = f[e] * scale;
+                        mx = fmaxf(mx, v[q][e]);
+                    }
             }
         }
         mx = wave_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < kSmMax; ++i) {
-            const int c = lane + 64 * i;
-            if (i < per && c < n) {
-                v[i] = __expf(v[i] - mx);
-                sum += v[i];
+        for (int q = 0; q < kSmPass; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[q][e] = __expf(v[q][e] - mx);  // exp(-inf) = 0 for the pad / inactive slots
+                sum += v[q][e];
             }
-        }
         const float inv = 1.f / wave_sum(sum);
 #pragma unroll
-        for (int i = 0; i < kSmMax; ++i) {
-            const int c = lane + 64 * i;
-            if (i < per && c < ld) p[c] = c < n ? f32_to_bf16(v[i] * inv) : (unsigned short)0;
+        for (int q = 0; q < kSmPass; ++q) {
+            const int ch = lane + 64 * q;
+            if (ch < chunks) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = v[q][e] * inv;
+                *reinterpret_cast<u16x8*>(p + ch * 8) = pack_bf16x8(o);
+            }
         }
     }
 }
 
-// ds = scale * p * (dp - sum_j dp_j p_j), in place over dp; pad columns zeroed
+// ds = scale * p * (dp - sum_j dp_j p_j), in place over dp; pad columns zeroed (p is zero there)
 __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const unsigned short* __restrict__ prob, unsigned short* __restrict__ dp,
                                                                int rows, int n, int ld, float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (ld + 63) / 64;
+    const int chunks = ld >> 3;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const unsigned short* p = prob + (size_t)row * ld;
         unsigned short* d = dp + (size_t)row * ld;
-        float pv[kSmMax], dv[kSmMax];
+        float pv[kSmPass][8], dv[kSmPass][8];
         float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < kSmMax; ++i) {
-            const int c = lane + 64 * i;
-            pv[i] = dv[i] = 0.f;
-            if (i < per && c < n) {
-                pv[i] = bf16_to_f32(p[c]);
-                dv[i] = bf16_to_f32(d[c]);
-                dot = fmaf(pv[i], dv[i], dot);
+        for (int q = 0; q < kSmPass; ++q) {
+            const int ch = lane + 64 * q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[q][e] = dv[q][e] = 0.f;
+            if (ch < chunks) {
+                float a[8], b_[8];
+                unpack8v(*reinterpret_cast<const u16x8*>(p + ch * 8), a);
+                unpack8v(*reinterpret_cast<const u16x8*>(d + ch * 8), b_);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ch * 8 + e < n) {
+                        pv[q][e] = a[e];
+                        dv[q][e] = b_[e];
+                        dot = fmaf(a[e], b_[e], dot);
+                    }
             }
         }
         dot = wave_sum(dot);
 #pragma unroll
-        for (int i = 0; i < kSmMax; ++i) {
-            const int c = lane + 64 * i;
-            if (i < per && c < ld) d[c] = c < n ? f32_to_bf16(scale * pv[i] * (dv[i] - dot)) : (unsigned short)0;
+        for (int q = 0; q < kSmPass; ++q) {
+            const int ch = lane + 64 * q;
+            if (ch < chunks) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = scale * pv[q][e] * (dv[q][e] - dot);
+                *reinterpret_cast<u16x8*>(d + ch * 8) = pack_bf16x8(o);
+            }
         }
     }
 }
@@ -430,7 +502,7 @@ extern "C" int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x
                                 int M, int D, int drop_T, void* y_bf16, float* mean, float* rstd, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && M > 0 && D > 0 && drop_T >= 0 && (delta_bf16 == nullptr || x_out != nullptr));
-    if (D > 64 * kLnMax) return LP_ERR_UNSUPPORTED;
+    if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (M + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const unsigned short*)delta_bf16, x_out,
@@ -442,7 +514,7 @@ extern "C" int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float
                                 int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy_bf16 && x && mean && rstd && gamma && dx_acc && dgamma_acc && dbeta_acc && M > 0 && D > 0 && drop_T >= 0);
-    if (D > 64 * kLnMax) return LP_ERR_UNSUPPORTED;
+    if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;  // 8 waves per SIMD; also bounds the d gamma / d beta atomics per column
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, rstd,
@@ -471,7 +543,7 @@ extern "C" int lp_gelu_bwd(const void* x_bf16, const void* dy_bf16, size_t n, vo
 extern "C" int lp_softmax_rows_fwd(void* s_bf16, int rows, int n, int ld, float scale, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(s_bf16 && rows > 0 && n > 0 && ld >= n);
-    if (ld > 64 * kSmMax) return LP_ERR_UNSUPPORTED;
+    if (ld > 512 * kSmPass || ld % 8 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (rows + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned short*)s_bf16, rows, n, ld, scale);
@@ -481,7 +553,7 @@ extern "C" int lp_softmax_rows_fwd(void* s_bf16, int rows, int n, int ld, float 
 extern "C" int lp_softmax_rows_bwd(const void* p_bf16, void* dp_bf16, int rows, int n, int ld, float scale, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(p_bf16 && dp_bf16 && rows > 0 && n > 0 && ld >= n);
-    if (ld > 64 * kSmMax) return LP_ERR_UNSUPPORTED;
+    if (ld > 512 * kSmPass || ld % 8 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (rows + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)p_bf16,
