@@ -47,6 +47,11 @@ struct ConvEpilogue {
     // statistics of the next BatchNorm) or, with bn_z, sum v * xhat (backward: the two reductions of BatchNorm's gradient).
     float* stats;                  // [stats_row0 + tile_m][2][N] or nullptr
     int stats_row0;
+    // few row tiles (<= kStatsAtomicTiles): the tile sums are added straight into these (2, N) totals with atomics instead of
+    // going through `stats` and a second kernel (contention per address = number of row tiles); acc0 / acc1 receive them too
+    float* stats_sums;
+    float* stats_acc0;
+    float* stats_acc1;
     const unsigned short* bn_z;    // [M][ldo] bf16 pre-normalisation tensor the gradient belongs to, or nullptr
     const float* bn_mean;          // [N]
     const float* bn_invstd;        // [N]
@@ -483,7 +488,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     float t = 0.f;
 #pragma unroll
                     for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
-                    if (n0 + cl < N) ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
+                    if (n0 + cl < N) {
+                        if (ep.stats_sums != nullptr) {
+                            atomicAdd(&ep.stats_sums[comp * N + n0 + cl], t);
+                            float* acc = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
+                            if (acc != nullptr) atomicAdd(&acc[n0 + cl], t);
+                        } else {
+                            ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
+                        }
+                    }
                 }
             }
             return;
@@ -926,6 +939,7 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
+constexpr int kStatsAtomicTiles = 1152;  // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue)
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
 
 struct WgradPlan {
@@ -974,18 +988,19 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
     ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
-                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     const int tm = (M + kBM - 1) / kBM;
     if (bn) {
         LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * N * sizeof(float));
         if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
         ep.stats = (float*)bn->workspace;
+        if (tm <= kStatsAtomicTiles) ep.stats_sums = bn->sums;
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
-    if (bn) launch_tile_stats_reduce(ep.stats, tm, N, bn->sums, nullptr, nullptr, st);
+    if (bn && ep.stats_sums == nullptr) launch_tile_stats_reduce(ep.stats, tm, N, bn->sums, nullptr, nullptr, st);
     return launch_status();
 }
 
@@ -1026,7 +1041,7 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     if ((a_b | a_h | b_b | b_h) % 8 != 0) return LP_ERR_UNSUPPORTED;  // 16-B operand chunks
     ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
     ConvEpilogue ep{(unsigned short*)c_bf16, c_f32, ldc, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
-                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     GemmExt gx{lda, ldb, nh, 0, (unsigned)(2 * a_b), (unsigned)(2 * a_h), (unsigned)(2 * b_b), (unsigned)(2 * b_h), (unsigned)c_b,
                (unsigned)c_h};
     const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
@@ -1049,7 +1064,8 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         return LP_ERR_UNSUPPORTED;
     const int N = g.Ci;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
-                    (const unsigned short*)relu_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    (const unsigned short*)relu_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, 0};
     if (bn) {
         // the reductions cover every pixel exactly once, so no class may be skipped and the output must be the dense bf16 tensor
         LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && bn->workspace && dx_bf16 && !dx_f32 && !skip_empty_classes &&
@@ -1064,6 +1080,11 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         ep.bn_beta = bn->beta;
         ep.mask_from_z = bn->mask_from_z;
         ep.relu_bits = (const unsigned char*)bn->relu_bits;
+        if (((long long)g.B * g.Hi * g.Wi + kBM - 1) / kBM <= kStatsAtomicTiles) {
+            ep.stats_sums = bn->sums;
+            ep.stats_acc0 = bn->dbeta_acc;
+            ep.stats_acc1 = bn->dgamma_acc;
+        }
         LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)));
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1091,7 +1112,7 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
                 launch(Lattice{h0, 2, nh, w0, 2, nw, ph, 2, nr, pw, 2, ns});
             }
     }
-    if (bn) launch_tile_stats_reduce(ep.stats, stats_rows, N, bn->sums, bn->dbeta_acc, bn->dgamma_acc, st);
+    if (bn && ep.stats_sums == nullptr) launch_tile_stats_reduce(ep.stats, stats_rows, N, bn->sums, bn->dbeta_acc, bn->dgamma_acc, st);
     return launch_status();
 }
 
@@ -1157,7 +1178,7 @@ static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom
     const int M = g.B * g.Ho * g.Wo;
     const int tm = (M + kBM - 1) / kBM;
     ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr, nullptr,
-                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (bn) {
         LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * 64 * sizeof(float));
         ep.stats = (float*)bn->workspace;
