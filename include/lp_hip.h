@@ -171,6 +171,10 @@ typedef struct lp_gemm_batch {
 } lp_gemm_batch;
 int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* c_bf16, float* c_f32, int ldc, int M, int N, int K, int n_store,
                const float* bias, const lp_gemm_batch* batch, lp_stream_t stream);
+/* out[z][j][n] (bf16, pitch ldo) = sum_m x[z][m][j] * y[z][m][n]: both operands are contracted over their ROW index (the
+ * weight-gradient kernel used directly; attention's dV = P^T dO and dK = dS^T Q).  batch: a_* = x, b_* = y, c_* = out strides. */
+int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, int ldo, int M, int J, int N, const lp_gemm_batch* batch,
+               lp_stream_t stream);
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
  * for them (torch.nn.BatchNorm2d training forward / backward).  Every 128-row output tile leaves its
  * column sums in `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds them into `sums`.

@@ -577,6 +577,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     }
 }
 
+// Direct, batched use of the weight-gradient kernel as a TN GEMM (lp_gemm_tn: attention's dV = P^T dO and dK = dS^T Q):
+// out[z][j][n] = sum_m x[z][m][j] * y[z][m][n], one "slice" per batch z, result stored as bf16 instead of going to the split-K
+// workspace.  A null `out` means the ordinary weight-gradient.
+struct TnExt {
+    unsigned short* out;        // [z][j][n] bf16, pitch ldo; nullptr = weight-gradient mode
+    int ldx, ldy, ldo;          // row pitches (elements) of x, y, out
+    int nh;                     // batch index z = (zb, zh), zh < nh
+    unsigned x_zb, x_zh;        // byte strides of x / y per batch index
+    unsigned y_zb, y_zh;
+    unsigned o_zb, o_zh;        // element strides of out
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient:  dW[n][j] += sum_m xg[m][j] * dy[m][n],  j = (r, s, ci),  m = (b, ho, wo) split over blockIdx.y
 // computed as D[j][n] (rows j from the gathered activations, columns n from dy), both transposed into LDS.
@@ -588,7 +600,7 @@ template <int BN, bool STEM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                          unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles,
                                                          int tiles_n, int m_per_split, FastDiv div_hw, FastDiv div_wo,
-                                                         float* __restrict__ ws) {
+                                                         float* __restrict__ ws, TnExt tn) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
     // Operand tiles stay in their memory orientation, [pixel][channel] (K = pixel is the ROW index): the 16-B chunks go to LDS
@@ -606,8 +618,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     const int work = xcd_remap(blockIdx.x, gridDim.x);
     const int slice = work / tiles, tile = work - slice * tiles;
     const int j0 = (tile / tiles_n) * kBM, n0 = (tile % tiles_n) * BN;
-    const int m_begin = slice * m_per_split;
-    const int m_end = min(M, m_begin + m_per_split);
+    const bool direct = tn.out != nullptr;          // TN-GEMM mode: slice = batch index, rows [0, M) of that batch
+    const int m_begin = direct ? 0 : slice * m_per_split;
+    const int m_end = direct ? M : min(M, m_begin + m_per_split);
+    unsigned zx = 0, zy = 0, zo = 0;
+    if (direct) {
+        const int zb = slice / tn.nh, zh = slice - zb * tn.nh;
+        zx = zb * tn.x_zb + zh * tn.x_zh;
+        zy = zb * tn.y_zb + zh * tn.y_zh;
+        zo = zb * tn.o_zb + zh * tn.o_zh;
+    }
 
     // A operand (gathered activations): thread -> 8 consecutive j (one 16-B chunk) of 4 consecutive pixels; 16 consecutive
     // lanes cover the 256-B tile row of one pixel
@@ -645,10 +665,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     // input pixel of output pixel m under tap (r, s) is m + const, so a lane's byte offsets are fixed (raw buffer loads: the K
     // step rides in the scalar offset, padding taps get the offset ~0 and read zeros) and the only per-step arithmetic is the
     // (row, column) walk that decides padding.  Everything else (stride 2, the stem, a ragged last step) takes the generic path.
-    const bool fast = !STEM && g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.Wo >= 8 && g.Ho >= 8;
+    const bool fast = direct || (!STEM && g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo && g.Wo >= 8 && g.Ho >= 8);
     const bool nomask = fast && g.R == 1 && g.S == 1 && g.pad == 0;
     const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_dy = make_buf_rsrc(DY, dy_bytes);
-    const unsigned ci2 = (unsigned)g.Ci * 2u;
+    const int pitch_x = direct ? tn.ldx : g.Ci, pitch_y = direct ? tn.ldy : g.Co;
+    const unsigned ci2 = (unsigned)pitch_x * 2u;
     const int qw = 64 / g.Wo, rw = 64 - qw * g.Wo;
     int fwo = 0, fho = 0, lo_h = 0, span_h = 0, lo_w = 0, span_w = 0;
     unsigned voffA = ~0u, voffB[RB];
@@ -658,22 +679,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         const int rem = pc - fdiv(pc, div_hw) * hw;
         fho = fdiv(rem, div_wo);
         fwo = rem - fho * g.Wo;
-        if (jv) voffA = (unsigned)((p0 + (tr - g.pad) * g.Wi + (ts - g.pad)) * g.Ci + tcn) * 2u;
+        if (jv) voffA = (unsigned)((p0 + (tr - g.pad) * g.Wi + (ts - g.pad)) * pitch_x + tcn) * 2u + zx;
         lo_h = max(0, g.pad - tr);
         span_h = min(g.Ho, g.Hi + g.pad - tr) - lo_h;
         lo_w = max(0, g.pad - ts);
         span_w = min(g.Wo, g.Wi + g.pad - ts) - lo_w;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) voffB[i] = nv ? (unsigned)((m_begin + pgB * RB + i) * g.Co + nB) * 2u : ~0u;
+        for (int i = 0; i < RB; ++i) voffB[i] = nv ? (unsigned)((m_begin + pgB * RB + i) * pitch_y + nB) * 2u + zy : ~0u;
     }
     const unsigned jinv = jv ? 0u : ~0u;
 
     auto load_fast = [&](int mk) {  // whole K step inside [m_begin, m_end)
         const unsigned step = (unsigned)(mk - m_begin);
-        const unsigned soffA = step * ci2, soffB = step * (unsigned)g.Co * 2u;
+        const unsigned soffA = step * ci2, soffB = step * (unsigned)pitch_y * 2u;
         if (nomask) {
+            // (TN-GEMM mode takes its ragged last step here too: rows >= m_end get the offset ~0 and read zeros)
+            const bool ragged = mk + kBK > m_end;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = buf_load16(rsrc_x, (voffA + i * ci2) | jinv, soffA);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned rinv = (ragged && mk + pgA * 4 + i >= m_end) ? ~0u : 0u;
+                ra[i] = buf_load16(rsrc_x, (voffA + i * ci2) | jinv | rinv, soffA);
+            }
+            if (ragged) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rsrc_dy, voffB[i] | ((mk + pgB * RB + i >= m_end) ? ~0u : 0u), soffB);
+                return;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -725,7 +756,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         }
     };
     auto load_step = [&](int mk) {
-        if (fast && mk + kBK <= m_end) load_fast(mk);
+        if (fast && (direct || mk + kBK <= m_end)) load_fast(mk);
         else load_generic(mk);
     };
     auto store_step = [&](int buf) {
@@ -783,6 +814,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         }
     }
 
+    if (direct) {  // out[z][j][n] = bf16(acc): reg e of lane l is row j = (e&3) + 8*(e>>2) + 4*(l>>5), column n = l & 31 of its block
+        const int col = lane & 31, rg = lane >> 5;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + wn * (NT * 32) + nt * 32 + col;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jr = j0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg;
+                    if (jr < Kw && n < g.Co) tn.out[zo + (size_t)jr * tn.ldo + n] = f32_to_bf16(acc[mt][nt][e]);
+                }
+            }
+        return;
+    }
     // partial tile -> workspace[slice][tile][wave][mt][nt][e][lane]
     float* dst = ws + ((((size_t)slice * tiles + tile) * 4 + wave) * (2 * NT * 16)) * 64 + lane;
 #pragma unroll
@@ -1157,13 +1203,51 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
     if (p.wide) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tiles * p.split), dim3(256), 0, st, (const unsigned short*)x,
                            (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
-                           make_fastdiv(g.Wo), ws);
+                           make_fastdiv(g.Wo), ws, TnExt{});
         launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tiles * p.split), dim3(256), 0, st, (const unsigned short*)x,
                            (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
-                           make_fastdiv(g.Wo), ws);
+                           make_fastdiv(g.Wo), ws, TnExt{});
         launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
+    }
+    return launch_status();
+}
+
+// out[z][j][n] = sum_m x[z][m][j] * y[z][m][n]  (bf16 in / out, fp32 accumulate): the weight-gradient kernel as a batched TN GEMM
+extern "C" int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, int ldo, int M, int J, int N,
+                          const lp_gemm_batch* batch, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && y && out_bf16 && M > 0 && J > 0 && N > 0 && ldx >= J && ldy >= N && ldo >= N);
+    if (ldx % 8 != 0 || ldy % 8 != 0 || N % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int nb = batch ? batch->nb : 1, nh = batch ? batch->nh : 1;
+    LP_REQUIRE(nb > 0 && nh > 0);
+    const long long a_b = batch ? batch->a_b : 0, a_h = batch ? batch->a_h : 0, b_b = batch ? batch->b_b : 0, b_h = batch ? batch->b_h : 0;
+    const long long c_b = batch ? batch->c_b : 0, c_h = batch ? batch->c_h : 0;
+    LP_REQUIRE(a_b >= 0 && a_h >= 0 && b_b >= 0 && b_h >= 0 && c_b >= 0 && c_h >= 0);
+    if ((a_b | a_h | b_b | b_h) % 8 != 0) return LP_ERR_UNSUPPORTED;
+    // J (the rows of the result) is read in 16-B chunks: the last chunk of a row of x must stay inside its pitch
+    const int Jr = (J + 7) / 8 * 8;
+    LP_REQUIRE(Jr <= ldx);
+    const long long x_elems = (nb - 1) * a_b + (nh - 1) * a_h + (long long)(M - 1) * ldx + Jr;
+    const long long y_elems = (nb - 1) * b_b + (nh - 1) * b_h + (long long)(M - 1) * ldy + N;
+    const long long o_elems = (nb - 1) * c_b + (nh - 1) * c_h + (long long)J * ldo;
+    if (x_elems >= (1LL << 31) || y_elems >= (1LL << 31) || o_elems >= (1LL << 32)) return LP_ERR_UNSUPPORTED;
+    ConvGeom g{1, 1, M, Jr, 1, M, N, 1, 1, 1, 0};   // a 1x1 "convolution" over M pixels: Ci = J (chunk-rounded), Co = N
+    const int tj = (Jr + kBM - 1) / kBM;
+    TnExt tn{(unsigned short*)out_bf16, ldx, ldy, ldo, nh, (unsigned)(2 * a_b), (unsigned)(2 * a_h), (unsigned)(2 * b_b), (unsigned)(2 * b_h),
+             (unsigned)c_b, (unsigned)c_h};
+    hipStream_t st = (hipStream_t)stream;
+    const int nz = nb * nh;
+    if (N > 64) {
+        const int tn_ = (N + 127) / 128;
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tj * tn_ * nz), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)y, (unsigned)(2 * x_elems), (unsigned)(2 * y_elems), g, M, J, tj * tn_, tn_, M,
+                           make_fastdiv(M), make_fastdiv(M), (float*)nullptr, tn);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tj * nz), dim3(256), 0, st, (const unsigned short*)x,
+                           (const unsigned short*)y, (unsigned)(2 * x_elems), (unsigned)(2 * y_elems), g, M, J, tj, 1, M, make_fastdiv(M),
+                           make_fastdiv(M), (float*)nullptr, tn);
     }
     return launch_status();
 }
@@ -1212,7 +1296,7 @@ extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom*
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(p.tj * p.split), dim3(256), 0, st, (const unsigned short*)x4,
-                       (const unsigned short*)dy, 0u, 0u, g, M, Kw, p.tj, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
+                       (const unsigned short*)dy, 0u, 0u, g, M, Kw, p.tj, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws, TnExt{});
     launch_wgrad_reduce<64>(ws, p.split, p.tj, 1, Kw, 64, dw, st);
     return launch_status();
 }

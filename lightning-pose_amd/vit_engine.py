@@ -232,6 +232,11 @@ class ViTEngine(Engine):
         check(self._lib.lp_gemm_nt(a, lda, b, ldb, _p(out), None, ldc, M, N, K, n_store, _p(bias), C.byref(gb) if gb else None,
                                    ops._stream()), "lp_gemm_nt")
 
+    def _gemm_tn(self, x, ldx, y, ldy, M, J, N, out, ldo, batch):
+        """out[z][j][n] = sum_m x[z][m][j] y[z][m][n] (both operands contracted over their rows; no transposed copies)"""
+        gb = _lib.GemmBatch(*batch)
+        check(self._lib.lp_gemm_tn(x, ldx, y, ldy, _p(out), ldo, M, J, N, C.byref(gb), ops._stream()), "lp_gemm_tn")
+
     def _linear(self, x: torch.Tensor, l: Lin, M: int) -> torch.Tensor:
         out = torch.empty(M, l.N, device=self.device, dtype=torch.bfloat16)
         self._gemm(_p(x), l.K, _p(self.Wb[l.w_off:]), l.K, M, l.N, l.K, out, l.N, bias=self.P[l.b_off:l.b_off + l.N])
@@ -388,18 +393,13 @@ class ViTEngine(Engine):
             check(self._lib.lp_softmax_rows_bwd(_p(Pm), _p(dP), B * nh * Tn, Tn, Tp, scale, ops._stream()), "lp_softmax_rows_bwd")
             dS = dP
             tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
-            bigT = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [Tn][Tp] square
-            # dV = P^T dO
-            self._transpose(_p(Pm), Tn, Tn, Tp, *zP, bigT, Tp, *zP, B, nh)
-            self._transpose(_p(d_attn), Tn, 64, D, Tn * D, 64, tmpT, Tp, *zT, B, nh)
-            self._gemm(_p(bigT), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv[:, 2 * D:], qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
+            # dV = P^T dO  (TN GEMM: P and dO are both read in place, contracted over the query index)
+            self._gemm_tn(_p(Pm), Tp, _p(d_attn), D, Tn, Tn, 64, dqkv[:, 2 * D:], qs, batch=(B, nh, *zP, Tn * D, 64, Tn * qs, 64))
             # dQ = dS K
             self._transpose(qkv[:, D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)
             self._gemm(_p(dS), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv, qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
             # dK = dS^T Q
-            self._transpose(_p(dS), Tn, Tn, Tp, *zP, bigT, Tp, *zP, B, nh)
-            self._transpose(_p(qkv), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)
-            self._gemm(_p(bigT), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv[:, D:], qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
+            self._gemm_tn(_p(dS), Tp, _p(qkv), qs, Tn, Tn, 64, dqkv[:, D:], qs, batch=(B, nh, *zP, Tn * qs, 64, Tn * qs, 64))
             if trace is not None:
                 trace[f"l{i}.dqkv"] = dqkv
             d_y1 = self._linear_bwd(L["qkv"], t("y1"), dqkv, M)

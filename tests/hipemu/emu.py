@@ -324,6 +324,14 @@ def gemm_nt(a_bits, lda, b_bits, ldb, M, N, K, ldc, c_rows, n_store=0, bias=None
     return cf.np() if f32_out else cb.np()
 
 
+def gemm_tn(x_bits, ldx, y_bits, ldy, M, J, N, ldo, o_elems, batch=None):
+    """out[z][j][n] = sum_m x[z][m][j] y[z][m][n]; batch = (nb, nh, x_b, x_h, y_b, y_h, o_b, o_h). Returns the flat bf16 output."""
+    xb, yb, ob = Buf(x_bits), Buf(y_bits), Z(o_elems, np.uint16)
+    gb = _lib.GemmBatch(*batch) if batch is not None else None
+    ok(lib().lp_gemm_tn(xb.p, ldx, yb.p, ldy, ob.p, ldo, M, J, N, C.byref(gb) if gb else None, stream()))
+    return ob.np()
+
+
 def conv_wgrad(x_bits, dy_bits, g, split=0):
     xb, db, dw = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
     nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)

@@ -210,3 +210,21 @@ def test_gemm_nt_batched_strided():
     bias = torch.randn(N, generator=gen)
     of = emu.gemm_nt(emu.to_bf16_bits(x).reshape(-1), K, emu.to_bf16_bits(w).reshape(-1), K, M, N, K, N, M, bias=bias.numpy(), f32_out=True)
     torch.testing.assert_close(torch.from_numpy(of.reshape(M, N)), x @ w.T + bias, atol=3e-4, rtol=3e-4)
+
+
+@pytest.mark.parametrize("nh,M,J,N,ldx", [(2, 77, 77, 64, 80), (1, 130, 150, 136, 152), (2, 64, 8, 8, 8)])
+def test_gemm_tn_batched_strided(nh, M, J, N, ldx):
+    """lp_gemm_tn (attention's dV = P^T dO, dK = dS^T Q): both operands contracted over their row index; ragged M and J, x pitch wider
+    than J, y rows interleaving the heads (head h at column offset h * N, like the QKV rows), output pitch wider than N."""
+    torch.manual_seed(5)
+    nb = 2
+    ldy, ldo = nh * N, N + 8
+    xb = emu.to_bf16_bits(torch.randn(nb, nh, M, ldx))
+    yb = emu.to_bf16_bits(torch.randn(nb, M, nh, N))
+    xf, yf = emu.from_bf16_bits(xb).double(), emu.from_bf16_bits(yb).double()
+    out = emu.gemm_tn(xb.reshape(-1), ldx, yb.reshape(-1), ldy, M, J, N, ldo, nb * nh * J * ldo,
+                      batch=(nb, nh, nh * M * ldx, M * ldx, M * ldy, N, nh * J * ldo, J * ldo))
+    o = emu.from_bf16_bits(out).reshape(nb, nh, J, ldo)
+    ref = torch.einsum("bhmj,bmhn->bhjn", xf[..., :J], yf).float()
+    assert torch.allclose(o[..., :N], ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item())
+    assert (o[..., N:] == 0).all()  # the pitch padding of the output stays untouched
