@@ -190,11 +190,18 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.training_batch(model, batch, args.warmup + i)
+    host_enqueue = time.perf_counter() - t0  # the host is done enqueueing here; the GPU still drains (no sync inside a step)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = model.net.profile or []
     model.net.profile = None
+    # host cost of one step when nothing throttles it: enqueue a step onto the idle GPU and stop the clock BEFORE synchronising
+    # (in the timed loop above the host runs ahead until the runtime's queue back-pressure paces it to the GPU)
+    t1 = time.perf_counter()
+    trainer.training_batch(model, batch, args.warmup + args.steps)
+    host_idle_queue = time.perf_counter() - t1
+    torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,7 +214,9 @@ def main() -> None:
     out = {
         "metric": f"training frames/sec (whole node), {arch} {args.size}x{args.size} {args.keypoints}-kp semi-sup",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1000 * elapsed / args.steps, 3), "host_enqueue_ms_per_step": round(1000 * host_enqueue / args.steps, 3),
+        "host_enqueue_idle_queue_ms": round(1000 * host_idle_queue, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "

@@ -175,6 +175,15 @@ int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* c_bf16, flo
  * weight-gradient kernel used directly; attention's dV = P^T dO and dK = dS^T Q).  batch: a_* = x, b_* = y, c_* = out strides. */
 int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, int ldo, int M, int J, int N, const lp_gemm_batch* batch,
                lp_stream_t stream);
+/* Attention backward without materialising dP (replaces lp_gemm_nt + lp_softmax_rows_bwd of the composition; the reference's
+ * arithmetic is HF ViTSelfAttention's eager soft-max attention, models/backbones/vit.py:38-43):
+ *   lp_attn_rowdot   D[row][h] = sum_d a[row][h*64+d] * b[row][h*64+d]   (a = dO, b = O, head dimension 64, nh <= 8)
+ *   lp_attn_dscores  dS[z][m][n] = scale * P[z][m][n] * (sum_k dO[z][m][k] V[z][n][k] - D[z][m]), pad columns [N, ldc) zeroed;
+ *                    P has the layout of dS; D[z][m] sits at d_rows[zb*d_b + zh*d_h + m*d_row_stride]; batch as in lp_gemm_nt. */
+int lp_attn_rowdot(const void* a_bf16, const void* b_bf16, int rows, int nh, int ld, float* out, lp_stream_t stream);
+int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int ldv, const void* p_bf16, const float* d_rows, int d_row_stride,
+                    long long d_b, long long d_h, float scale, void* ds_bf16, int ldc, int M, int N, int K, const lp_gemm_batch* batch,
+                    lp_stream_t stream);
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
  * for them (torch.nn.BatchNorm2d training forward / backward).  Every 128-row output tile leaves its
  * column sums in `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds them into `sums`.

@@ -58,6 +58,11 @@ struct ConvEpilogue {
     const float* bn_gamma;         // [N]  } only for mask_from_z: the ReLU mask is recomputed as
     const float* bn_beta;          // [N]  } bf16(gamma * invstd * (z - mean) + beta) > 0 instead of reading the activation
     int mask_from_z;
+    // kModeAttn (lp_attn_dscores): the store pass turns the accumulated dP = dO V^T into the score gradient
+    // dS = attn_scale * P * (dP - D[row]) with P read at the output's own offsets and D = rowsum(dO * O) (GemmExt::d_*)
+    const unsigned short* attn_p;
+    const float* attn_d;
+    float attn_scale;
 };
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
@@ -68,9 +73,10 @@ struct GemmExt {
     unsigned x_zb, x_zh;       // byte strides of the gathered tensor per batch index
     unsigned w_zb, w_zh;       // byte strides of the weight matrix
     unsigned o_zb, o_zh;       // element strides of the output
+    unsigned d_zb, d_zh, d_row;  // kModeAttn: element strides of the per-row vector D (batch indices, output row)
 };
 
-enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2 };
+enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3 };  // kModeAttn = kModeFwd with the soft-max backward in the store pass
 
 // One launch covers a sub-lattice of output pixels and of filter taps.  Ordinary launches use the full lattices; the data
 // gradient of a stride-2 convolution is split into its 4 output-parity classes, each of which only sees the taps of matching
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     unsigned wrow[BN / 32];        // byte offset of this lane's chunk in each weight row it stages
     int m0n = 0, n0n = 0;        // origin of the tile being set up / loaded
     unsigned zon = 0;            // ... and its batch's offset into the output (elements)
+    unsigned zdn = 0;            // ... and into the row vector D (kModeAttn)
 
     auto setup = [&](int vt) {
         int tile = xcd_remap(vt, ntiles);
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         const int zb = z / gx.nh, zh = z - zb * gx.nh;
         const unsigned zx = zb * gx.x_zb + zh * gx.x_zh, zw = zb * gx.w_zb + zh * gx.w_zh;
         zon = zb * gx.o_zb + zh * gx.o_zh;
+        if (MODE == kModeAttn) zdn = zb * gx.d_zb + zh * gx.d_zh;
         const int tm_ = tile / tiles_n;
         m0n = tm_ * kBM;
         n0n = (tile - tm_ * tiles_n) * BN;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     f32x16 acc[2][NT];
 
     // ---- epilogue of the tile at (m0, n0): D reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile
-    auto epilogue = [&](const int m0, const int n0, const unsigned zo) {
+    auto epilogue = [&](const int m0, const int n0, const unsigned zo, const unsigned zd = 0u) {
         const int col = lane & 31, rg = lane >> 5;
         if (ep.out_f32 == nullptr && (ep.n_store & 7) == 0 && (ep.ldo & 7) == 0) {
             // bf16 output: stage the fp32 tile in LDS (the operand buffers are free after the last barrier), then every lane
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             const bool want_stats = ep.stats != nullptr;
             // only the data-gradient has tensors to read back in its store pass (addend, pre-normalisation tensor, activation)
             constexpr bool kReads = (MODE == kModeDgrad);
+            constexpr bool kAttn = (MODE == kModeAttn);
             float s0[8], s1[8], mu[8], sc[8], be[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = sc[q] = be[q] = 0.f;
@@ -401,11 +410,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     bool rv[HB];
                     u16x8 la[HB], lz[HB], lm[HB];
                     unsigned lb[HB];
+                    float ld_[HB];
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
                         const int m = m0 + r0 + (i0 + i) * RPP;
                         rv[i] = m < M;
                         off[i] = (unsigned)out_row(rv[i] ? m : 0, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)n + zo;
+                    }
+                    if (kAttn) {  // the probabilities (re-read by the dV product: ordinary loads) and this row's D
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) {
+                            la[i] = load8(ep.attn_p + off[i]);
+                            ld_[i] = ep.attn_d[zd + (unsigned)(rv[i] ? m0 + r0 + (i0 + i) * RPP : 0) * gx.d_row];
+                        }
                     }
                     if (kReads && ep.addend) {
 #pragma unroll
@@ -430,6 +447,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                             const f32x4 lo = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8);
                             const f32x4 hi = *reinterpret_cast<const f32x4*>(so + rl * LDO + cc * 8 + 4);
                             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            if (kAttn) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    v[q] = (n + q < N) ? ep.attn_scale * bf16_to_f32(la[i][q]) * (v[q] - ld_[i]) : 0.f;
+                            }
                             if (kReads && ep.addend) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(la[i][q]);
@@ -564,14 +586,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             __syncthreads();
         }
         vt += gridDim.x;
+        const unsigned zd = zdn;
         if (vt >= ntiles) {
-            epilogue(m0, n0, zo);
+            epilogue(m0, n0, zo, zd);
             break;
         }
         // next tile's row descriptors and first operands: in flight while this tile is stored
         setup(vt);
         load_step(0, MODE != kModeDgrad);
-        epilogue(m0, n0, zo);
+        epilogue(m0, n0, zo, zd);
         if (MODE == kModeDgrad) load_b_deferred();
         __syncthreads();  // the epilogue's LDS tile is dead before the next tile's operands land in it
     }
@@ -1083,7 +1106,7 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     const long long a_elems = (nb - 1) * a_b + (nh - 1) * a_h + (long long)(M - 1) * lda + K;
     const long long b_elems = (nb - 1) * b_b + (nh - 1) * b_h + (long long)(N - 1) * ldb + K;
     const long long c_elems = (nb - 1) * c_b + (nh - 1) * c_h + (long long)M * ldc;
-    if (a_elems >= (1LL << 31) || b_elems >= (1LL << 31) || c_elems >= (1LL << 32) || a_elems % 8 != 0 && false) return LP_ERR_UNSUPPORTED;
+    if (a_elems >= (1LL << 31) || b_elems >= (1LL << 31) || c_elems >= (1LL << 32)) return LP_ERR_UNSUPPORTED;
     if ((a_b | a_h | b_b | b_h) % 8 != 0) return LP_ERR_UNSUPPORTED;  // 16-B operand chunks
     ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
     ConvEpilogue ep{(unsigned short*)c_bf16, c_f32, ldc, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
@@ -1095,6 +1118,40 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     const int nstore = ep.n_store;
     if (nstore > 64) launch_igemm<128, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
     else launch_igemm<64, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
+    return launch_status();
+}
+
+// Attention backward, score gradient: dS[z] = scale * P[z] o (dO[z] V[z]^T - D[z] 1^T), D = rowsum(dO o O) (lp_attn_rowdot).  The
+// product is lp_gemm_nt's; the soft-max backward happens in its store pass, so dP is never written and P is read once here.
+extern "C" int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int ldv, const void* p_bf16, const float* d_rows, int d_row_stride,
+                               long long d_b, long long d_h, float scale, void* ds_bf16, int ldc, int M, int N, int K,
+                               const lp_gemm_batch* batch, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(d_out && v && p_bf16 && d_rows && ds_bf16 && batch && M > 0 && N > 0 && K > 0 && ld_do >= K && ldv >= K && ldc >= N &&
+               d_row_stride > 0 && d_b >= 0 && d_h >= 0);
+    if (K % kBK != 0 || ld_do % 8 != 0 || ldv % 8 != 0 || ldc % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int nb = batch->nb, nh = batch->nh;
+    LP_REQUIRE(nb > 0 && nh > 0 && batch->a_b >= 0 && batch->a_h >= 0 && batch->b_b >= 0 && batch->b_h >= 0 && batch->c_b >= 0 && batch->c_h >= 0);
+    const long long a_elems = (nb - 1) * batch->a_b + (nh - 1) * batch->a_h + (long long)(M - 1) * ld_do + K;
+    const long long b_elems = (nb - 1) * batch->b_b + (nh - 1) * batch->b_h + (long long)(N - 1) * ldv + K;
+    const long long c_elems = (nb - 1) * batch->c_b + (nh - 1) * batch->c_h + (long long)M * ldc;
+    const long long d_elems = (nb - 1) * d_b + (nh - 1) * d_h + (long long)(M - 1) * d_row_stride + 1;
+    if (a_elems >= (1LL << 31) || b_elems >= (1LL << 31) || c_elems >= (1LL << 32) || d_elems >= (1LL << 32)) return LP_ERR_UNSUPPORTED;
+    if ((batch->a_b | batch->a_h | batch->b_b | batch->b_h | batch->c_b | batch->c_h) % 8 != 0) return LP_ERR_UNSUPPORTED;
+    ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
+    ConvEpilogue ep{};
+    ep.out_bf16 = (unsigned short*)ds_bf16;
+    ep.ldo = ldc;
+    ep.n_store = ldc;  // the pad columns [N, ldc) are written as zeros, as lp_softmax_rows_bwd left them
+    ep.attn_p = (const unsigned short*)p_bf16;
+    ep.attn_d = d_rows;
+    ep.attn_scale = scale;
+    GemmExt gx{ld_do, ldv, nh, 0, (unsigned)(2 * batch->a_b), (unsigned)(2 * batch->a_h), (unsigned)(2 * batch->b_b), (unsigned)(2 * batch->b_h),
+               (unsigned)batch->c_b, (unsigned)batch->c_h, (unsigned)d_b, (unsigned)d_h, (unsigned)d_row_stride};
+    const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
+    hipStream_t st = (hipStream_t)stream;
+    if (ldc > 64) launch_igemm<128, kModeAttn>(d_out, v, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
+    else launch_igemm<64, kModeAttn>(d_out, v, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
     return launch_status();
 }
 

@@ -386,12 +386,14 @@ class ViTEngine(Engine):
             dqkv = torch.empty(M, qs, device=dev, dtype=torch.bfloat16)
             zP = (nh * Tn * Tp, Tn * Tp)       # batch strides of a [B][nh][Tn][Tp] tensor
             zT = (nh * 64 * Tp, 64 * Tp)       # ... of a [B][nh][64][Tp] transposed head slice
-            # dP = dO V^T, then dS = scale * P (dP - sum(dP P)) in place
-            dP = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
-            self._gemm(_p(d_attn), D, qkv[:, 2 * D:].data_ptr(), qs, Tn, Tn, 64, dP, Tp, n_store=Tp,
-                       batch=(B, nh, Tn * D, 64, Tn * qs, 64, *zP))
-            check(self._lib.lp_softmax_rows_bwd(_p(Pm), _p(dP), B * nh * Tn, Tn, Tp, scale, ops._stream()), "lp_softmax_rows_bwd")
-            dS = dP
+            # dS = scale * P o (dO V^T - rowsum(dO o O)): the soft-max backward rides in the store pass of the dO V^T product
+            # (rowsum(dP o P) == rowsum(dO o O) because O = P V), so dP never exists in memory
+            drow = torch.empty(M, nh, device=dev, dtype=torch.float32)
+            check(self._lib.lp_attn_rowdot(_p(d_attn), _p(t("attn")), M, nh, D, _p(drow), ops._stream()), "lp_attn_rowdot")
+            dS = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
+            gb = _lib.GemmBatch(B, nh, Tn * D, 64, Tn * qs, 64, *zP)
+            check(self._lib.lp_attn_dscores(_p(d_attn), D, qkv[:, 2 * D:].data_ptr(), qs, _p(Pm), _p(drow), nh, Tn * nh, 1, scale, _p(dS), Tp,
+                                            Tn, Tn, 64, C.byref(gb), ops._stream()), "lp_attn_dscores")
             tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
             # dV = P^T dO  (TN GEMM: P and dO are both read in place, contracted over the query index)
             self._gemm_tn(_p(Pm), Tp, _p(d_attn), D, Tn, Tn, 64, dqkv[:, 2 * D:], qs, batch=(B, nh, *zP, Tn * D, 64, Tn * qs, 64))

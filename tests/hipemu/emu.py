@@ -332,6 +332,20 @@ def gemm_tn(x_bits, ldx, y_bits, ldy, M, J, N, ldo, o_elems, batch=None):
     return ob.np()
 
 
+def attn_rowdot(a_bits, b_bits, rows, nh, ld):
+    ab, bb, o = Buf(a_bits), Buf(b_bits), Z((rows, nh))
+    ok(lib().lp_attn_rowdot(ab.p, bb.p, rows, nh, ld, o.p, stream()))
+    return o.np()
+
+
+def attn_dscores(do_bits, ld_do, v_bits, ldv, p_bits, d_rows, d_row_stride, d_b, d_h, scale, ldc, o_elems, M, N, K, batch):
+    """dS = scale * P o (dO V^T - D); batch = (nb, nh, do_b, do_h, v_b, v_h, c_b, c_h). Returns the flat bf16 dS (o_elems elements)."""
+    db, vb, pb, dr, ob = Buf(do_bits), Buf(v_bits), Buf(p_bits), B(d_rows, np.float32), Z(o_elems, np.uint16)
+    gb = _lib.GemmBatch(*batch)
+    ok(lib().lp_attn_dscores(db.p, ld_do, vb.p, ldv, pb.p, dr.p, d_row_stride, d_b, d_h, scale, ob.p, ldc, M, N, K, C.byref(gb), stream()))
+    return ob.np()
+
+
 def conv_wgrad(x_bits, dy_bits, g, split=0):
     xb, db, dw = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
     nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)

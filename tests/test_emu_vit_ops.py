@@ -118,3 +118,36 @@ def test_transpose_batched_scalar_path():
     got = unbits(out.reshape(3, Cc, ldo))
     torch.testing.assert_close(got[..., :R], x[..., :Cc].transpose(1, 2), atol=0, rtol=0)
     assert not got[..., R:].any()
+
+
+def test_attention_score_gradient_fused():
+    """lp_attn_rowdot + lp_attn_dscores == autograd of softmax(Q K^T scale) V with respect to the scaled scores' pre-scale input:
+    dS = scale * P o (dO V^T - rowsum(dO o O)), heads interleaved in the token rows (QKV layout), ragged T, padded score pitch."""
+    gen = torch.Generator().manual_seed(11)
+    nb, nh, T, d = 2, 3, 77, 64
+    D, Tp, scale = nh * d, 128 + 8, 0.125
+    q, k, v = (bf(torch.randn(nb, nh, T, d, generator=gen)) for _ in range(3))
+    s = (q @ k.transpose(-1, -2)).requires_grad_(True)
+    p = torch.softmax(s * scale, -1)
+    pb = bf(p.detach())                                         # the probabilities as the forward pass stored them
+    o = bf(pb @ v)                                              # attention output (b, h, T, d)
+    d_o = bf(torch.randn(nb, nh, T, d, generator=gen))
+    # reference: the soft-max backward on the stored probabilities
+    dp = d_o @ v.transpose(-1, -2)
+    want = scale * pb * (dp - (dp * pb).sum(-1, keepdim=True))
+    # device layout: token rows [nb*T][nh*d]
+    rows = lambda t: t.permute(0, 2, 1, 3).reshape(nb * T, D).contiguous()  # noqa: E731
+    do_bits, o_bits, v_bits = bits(rows(d_o)).reshape(-1), bits(rows(o)).reshape(-1), bits(rows(v)).reshape(-1)
+    drow = emu.attn_rowdot(do_bits, o_bits, nb * T, nh, D)
+    want_d = (d_o * o).sum(-1).permute(0, 2, 1).reshape(nb * T, nh)
+    torch.testing.assert_close(torch.from_numpy(drow), want_d, atol=1e-4, rtol=1e-5)
+    p_pad = torch.zeros(nb, nh, T, Tp)
+    p_pad[..., :T] = pb
+    out = emu.attn_dscores(do_bits, D, v_bits, D, bits(p_pad).reshape(-1), drow.reshape(-1), nh, T * nh, 1, scale, Tp, nb * nh * T * Tp,
+                           T, T, d, batch=(nb, nh, T * D, d, T * D, d, nh * T * Tp, T * Tp))
+    got = unbits(out).reshape(nb, nh, T, Tp)
+    assert (got[..., T:] == 0).all()
+    # rowsum(dP o P) and rowsum(dO o O) differ only by the bf16 rounding of O: compare at that level
+    assert torch.allclose(got[..., :T], want, atol=2e-2 * want.abs().max().item(), rtol=2e-2)
+    cos = F.cosine_similarity(got[..., :T].flatten(), want.flatten(), dim=0)
+    assert cos > 0.9995, cos
