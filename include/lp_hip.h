@@ -175,6 +175,12 @@ int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* c_bf16, flo
  * weight-gradient kernel used directly; attention's dV = P^T dO and dK = dS^T Q).  batch: a_* = x, b_* = y, c_* = out strides. */
 int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, int ldo, int M, int J, int N, const lp_gemm_batch* batch,
                lp_stream_t stream);
+/* Fused soft-max attention forward, head dimension 64 (HF ViTSelfAttention eager attention, reference models/backbones/vit.py:38-43):
+ * per (image b, head h):  P = softmax(scale * Q K^T) -> p_bf16[(b*nh + h)*T + q][ldp] (pad columns [T, ldp) zeroed; the backward pass
+ * reads it),  O = P V -> out_bf16[(b*T + q)*ldo + h*64 ..].  Token rows qkv_bf16[(b*T + t)*ld_qkv + ..] hold Q at column h*64, K at
+ * k_off + h*64 and V at v_off + h*64.  The scores stay on chip (two passes over the keys: running max / exp-sum, then P and O). */
+int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
+                void* out_bf16, int ldo, lp_stream_t stream);
 /* Attention backward without materialising dP (replaces lp_gemm_nt + lp_softmax_rows_bwd of the composition; the reference's
  * arithmetic is HF ViTSelfAttention's eager soft-max attention, models/backbones/vit.py:38-43):
  *   lp_attn_rowdot   D[row][h] = sum_d a[row][h*64+d] * b[row][h*64+d]   (a = dO, b = O, head dimension 64, nh <= 8)

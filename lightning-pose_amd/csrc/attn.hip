@@ -1,0 +1,242 @@
+// Fused soft-max attention forward for the ViT path (reference: HF ViTSelfAttention's eager attention behind
+// lightning_pose/models/backbones/vit.py:38-43):  P = softmax(scale * Q K^T),  O = P V  per (image, head), head dimension 64.
+//
+// The composition it replaces (lp_gemm_nt -> lp_softmax_rows_fwd -> lp_gemm_nt) writes the scores, reads and rewrites them as
+// probabilities and reads those again: 4 passes over a [B*heads][T][T] tensor (850 MB per layer at C4).  Here the scores never
+// leave the chip; the only large write is P itself, which the backward pass wants (lp_attn_dscores, lp_gemm_tn).
+//
+// One workgroup = one (image, head) and 128 query rows (a wave owns 32 of them); keys / values stream through LDS in tiles of
+// 64.  Everything is computed TRANSPOSED, S^T = K Q^T and O^T = V^T P^T, because of how the 32x32 MFMA lays out its result:
+// lane l holds column l%32 and 16 of the 32 rows.  With queries as columns a lane owns ONE query and 32 of a tile's 64 keys, so
+//   * the soft-max row reductions are per-lane loops plus one exchange with lane l^32 (no cross-lane butterflies), and
+//   * the probabilities a lane just computed are, register for register, the B operand of the O^T product: the contraction
+//     index of an MFMA may be visited in any order as long as both operands agree, so V^T is simply fetched in the order the
+//     accumulator layout dictates (ds_read_b64_tr_b16 picks its 4 source rows per lane group freely).
+// Two passes over the keys: pass 1 finds each query's running maximum and exp-sum (online, fp32), pass 2 recomputes the scores,
+// writes the normalised probabilities (staged through LDS so they leave as full 128-B lines) and accumulates O^T.  Recomputing
+// Q K^T costs 8 MFMAs per tile and wave; storing the scores instead would cost the traffic this kernel exists to avoid.
+#include "lp_common.h"
+
+namespace lp {
+
+constexpr int kAQ = 128;          // query rows per workgroup
+constexpr int kAK = 64;           // keys per tile
+constexpr int kAD = 64;           // head dimension
+constexpr int kLDK = kAD + 8;     // K tile pitch: 144 B, conflict-free 16-B fragment reads
+constexpr int kLDV = kAD + 32;    // V tile pitch: +64 B so the 4 rows of a transpose read fall in distinct bank quarters
+constexpr int kLDP = kAK + 8;     // P staging pitch
+
+struct AttnArgs {
+    const unsigned short* qkv;  // [B*T][ld] bf16 token rows; Q at column h*64, K at k_off + h*64, V at v_off + h*64
+    int ld, k_off, v_off;
+    int nh, T, qtiles;
+    float scale;
+    unsigned short* p;          // [B*nh][T][ldp] bf16 probabilities (pad columns [T, ldp) zeroed)
+    int ldp;
+    unsigned short* out;        // [B*T][ldo] bf16, head h at column h*64
+    int ldo;
+};
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sK[kAK * kLDK];
+    __shared__ __attribute__((aligned(16))) unsigned short sV[kAK * kLDV];
+    __shared__ __attribute__((aligned(16))) unsigned short sP[kAQ * kLDP];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int z = blockIdx.x / a.qtiles, qt = blockIdx.x - z * a.qtiles;
+    const int b = z / a.nh, h = z - b * a.nh;
+    const int T = a.T;
+    const int q0 = qt * kAQ;
+    const unsigned short* Qp = a.qkv + (size_t)b * T * a.ld + h * kAD;
+    const unsigned short* Kp = Qp + a.k_off;
+    const unsigned short* Vp = Qp + a.v_off;
+    const bool active = q0 + wave * 32 < T;  // wave-uniform: a wave whose 32 queries are all past T only helps with the staging
+
+    // this lane's query row as the B operand of S^T = K Q^T: 8 consecutive d per k-slice (rows past T alias the last row)
+    bf16x8 qf[kAD / 16];
+    {
+        int q = q0 + wave * 32 + col;
+        if (q >= T) q = T - 1;
+        const unsigned short* qr = Qp + (size_t)q * a.ld + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < kAD / 16; ++kk) qf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(qr + kk * 16));
+    }
+
+    // K / V tile staging: thread -> 16-B chunk (tid & 7) of rows (tid >> 3) and (tid >> 3) + 32
+    const int srow = tid >> 3, schunk = tid & 7;
+    u16x8 rk[2], rv[2];
+    auto fetch = [&](const unsigned short* base, int t, u16x8 (&r)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kv = t * kAK + srow + 32 * i;
+            u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kv < T) v = *reinterpret_cast<const u16x8*>(base + (size_t)kv * a.ld + schunk * 8);
+            r[i] = v;
+        }
+    };
+    auto stage = [&](unsigned short* dst, int ldd, const u16x8 (&r)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u16x8*>(dst + (srow + 32 * i) * ldd + schunk * 8) = r[i];
+    };
+
+    // S^T tile of this wave: [64 keys][32 queries] = 2 accumulator blocks; reg e of block blk is key blk*32 + (e&3) + 8*(e>>2) + 4*half
+    f32x16 s[2];
+    auto scores = [&]() {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[blk][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < kAD / 16; ++kk) {
+                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(&sK[(blk * 32 + col) * kLDK + kk * 16 + half * 8]));
+                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[blk], 0, 0, 0);
+            }
+        }
+    };
+
+    const int n_kv = (T + kAK - 1) / kAK;
+    // ---- pass 1: running maximum m and exp-sum l of this lane's half of every key tile
+    float m = -INFINITY, l = 0.f;
+    fetch(Kp, 0, rk);
+    for (int t = 0; t < n_kv; ++t) {
+        __syncthreads();  // the previous tile's fragment reads are done
+        stage(sK, kLDK, rk);
+        __syncthreads();
+        if (t + 1 < n_kv) fetch(Kp, t + 1, rk);
+        if (active) {
+            scores();
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kv = t * kAK + blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    s[blk][e] = kv < T ? s[blk][e] * a.scale : -INFINITY;
+                    tmax = fmaxf(tmax, s[blk][e]);
+                }
+            const float mn = fmaxf(m, tmax);
+            if (mn > -INFINITY) {  // (a lane's half of the ragged last tile may hold no valid key at all)
+                float sum = 0.f;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum += __expf(s[blk][e] - mn);
+                l = l * __expf(m - mn) + sum;
+                m = mn;
+            }
+        }
+    }
+    {   // merge the two halves of each query (lanes l and l^32)
+        const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+        const float mt = fmaxf(m, mo);
+        l = (m > -INFINITY ? l * __expf(m - mt) : 0.f) + (mo > -INFINITY ? lo * __expf(mo - mt) : 0.f);
+        m = mt;
+    }
+    const float inv_l = active ? 1.f / l : 0.f;
+
+    // ---- pass 2: probabilities (out through LDS) and O^T = V^T P^T
+    f32x16 o[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[blk][e] = 0.f;
+    const int fq = lane >> 4, fi = lane & 15;
+    const int vrow = 4 * (fq >> 1) + (fi >> 2), vcol = 16 * (fq & 1) + 4 * (fi & 3);  // transpose-read source of this lane
+    const int n_p = (a.ldp + kAK - 1) / kAK > n_kv ? (a.ldp + kAK - 1) / kAK : n_kv;  // tiles that only hold pad columns get zeros
+    __syncthreads();
+    fetch(Kp, 0, rk);
+    fetch(Vp, 0, rv);
+    for (int t = 0; t < n_p; ++t) {
+        stage(sK, kLDK, rk);
+        stage(sV, kLDV, rv);
+        __syncthreads();
+        if (t + 1 < n_kv) {
+            fetch(Kp, t + 1, rk);
+            fetch(Vp, t + 1, rv);
+        }
+        unsigned pk[2][8];  // the tile's probabilities as packed bf16 pairs: pk[blk][e/2] = regs e, e+1
+        if (active && t < n_kv) {
+            scores();
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int kv = t * kAK + blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    const float p0 = kv < T ? __expf(s[blk][e] * a.scale - m) * inv_l : 0.f;
+                    const float p1 = kv + 1 < T ? __expf(s[blk][e + 1] * a.scale - m) * inv_l : 0.f;
+                    pk[blk][e >> 1] = pack_bf16x2(p0, p1);
+                }
+            // O^T += V^T P^T: k-slab j contracts the 16 keys held in regs 8*(j&1) .. +7 of block j>>1 (both halves)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                const u32x4_t pw = {pk[j >> 1][4 * (j & 1)], pk[j >> 1][4 * (j & 1) + 1], pk[j >> 1][4 * (j & 1) + 2], pk[j >> 1][4 * (j & 1) + 3]};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+                const int kvb = 32 * (j >> 1) + 16 * (j & 1);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const unsigned short* vp = &sV[(kvb + vrow) * kLDV + db * 32 + vcol];
+                    const s16x4_t lo = lds_read_tr16(vp), hi = lds_read_tr16(vp + 8 * kLDV);
+                    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                    const s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[db], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[blk][e] = 0u;
+        }
+        // stage P[query][key]: regs e .. e+3 are 4 consecutive keys (8 B)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t w = {pk[blk][2 * g4], pk[blk][2 * g4 + 1]};
+                *reinterpret_cast<u32x2_t*>(&sP[(wave * 32 + col) * kLDP + blk * 32 + 8 * g4 + 4 * half]) = w;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 32 + srow, q = q0 + row, c = t * kAK + schunk * 8;
+            if (q < T && c < a.ldp)
+                *reinterpret_cast<u16x8*>(a.p + ((size_t)z * T + q) * a.ldp + c) = *reinterpret_cast<const u16x8*>(&sP[row * kLDP + schunk * 8]);
+        }
+        __syncthreads();  // sP, sK, sV are free again
+    }
+
+    // O[q][h*64 + d]: reg e of block db is d = db*32 + (e&3) + 8*(e>>2) + 4*half -> 4 consecutive d per store
+    const int q = q0 + wave * 32 + col;
+    if (active && q < T) {
+        unsigned short* orow = a.out + ((size_t)b * T + q) * a.ldo + h * kAD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t w = {pack_bf16x2(o[db][4 * g4], o[db][4 * g4 + 1]), pack_bf16x2(o[db][4 * g4 + 2], o[db][4 * g4 + 3])};
+                *reinterpret_cast<u32x2_t*>(orow + db * 32 + 8 * g4 + 4 * half) = w;
+            }
+    }
+}
+
+}  // namespace lp
+
+extern "C" int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
+                           void* out_bf16, int ldo, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(qkv_bf16 && p_bf16 && out_bf16 && B > 0 && nh > 0 && T > 0 && ldp >= T && ldo >= nh * kAD && k_off >= 0 && v_off >= 0 &&
+               ld_qkv >= nh * kAD);
+    if (ld_qkv % 8 != 0 || k_off % 8 != 0 || v_off % 8 != 0 || ldp % 8 != 0 || ldo % 4 != 0) return LP_ERR_UNSUPPORTED;
+    const int qtiles = (T + kAQ - 1) / kAQ;
+    const long long wgs = (long long)B * nh * qtiles;
+    if (wgs >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    AttnArgs a{(const unsigned short*)qkv_bf16, ld_qkv, k_off, v_off, nh, T, qtiles, scale, (unsigned short*)p_bf16, ldp,
+               (unsigned short*)out_bf16, ldo};
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}

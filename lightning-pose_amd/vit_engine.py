@@ -321,15 +321,11 @@ class ViTEngine(Engine):
         for i, L in enumerate(pl.layers):
             y1, m1, r1, x = self._ln(x, delta, L["ln1"], M)
             qkv = self._linear(y1, L["qkv"], M)
-            # scores[b][h] = Q K^T  (bf16, row pitch Tp; columns >= Tn are junk until the soft-max zeroes them)
+            # P = softmax(Q K^T / 8) (bf16, row pitch Tp, pad columns zero; kept for the backward pass) and attn = P V in one kernel:
+            # the scores themselves never reach memory
             S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
-            self._gemm(_p(qkv), qs, qkv[:, D:].data_ptr(), qs, Tn, Tn, 64, S, Tp, n_store=Tp,
-                       batch=(B, nh, Tn * qs, 64, Tn * qs, 64, nh * Tn * Tp, Tn * Tp))
-            check(self._lib.lp_softmax_rows_fwd(_p(S), B * nh * Tn, Tn, Tp, scale, ops._stream()), "lp_softmax_rows_fwd")
-            Vt = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)
-            self._transpose(qkv[:, 2 * D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, Vt, Tp, nh * 64 * Tp, 64 * Tp, B, nh)
             attn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-            self._gemm(_p(S), Tp, _p(Vt), Tp, Tn, 64, Tp, attn, D, batch=(B, nh, nh * Tn * Tp, Tn * Tp, nh * 64 * Tp, 64 * Tp, Tn * D, 64))
+            check(self._lib.lp_attn_fwd(_p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(S), Tp, _p(attn), D, ops._stream()), "lp_attn_fwd")
             proj = self._linear(attn, L["proj"], M)
             x_in = x
             y2, m2, r2, x = self._ln(x, proj, L["ln2"], M)

@@ -332,6 +332,13 @@ def gemm_tn(x_bits, ldx, y_bits, ldy, M, J, N, ldo, o_elems, batch=None):
     return ob.np()
 
 
+def attn_fwd(qkv_bits, ld, k_off, v_off, nb, nh, T, scale, ldp, ldo):
+    """-> (P bits [nb*nh*T][ldp], O bits [nb*T][ldo])"""
+    qb, pb, ob = Buf(qkv_bits), Z((nb * nh * T, ldp), np.uint16), Z((nb * T, ldo), np.uint16)
+    ok(lib().lp_attn_fwd(qb.p, ld, k_off, v_off, nb, nh, T, scale, pb.p, ldp, ob.p, ldo, stream()))
+    return pb.np(), ob.np()
+
+
 def attn_rowdot(a_bits, b_bits, rows, nh, ld):
     ab, bb, o = Buf(a_bits), Buf(b_bits), Z((rows, nh))
     ok(lib().lp_attn_rowdot(ab.p, bb.p, rows, nh, ld, o.p, stream()))

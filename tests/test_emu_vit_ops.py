@@ -151,3 +151,27 @@ def test_attention_score_gradient_fused():
     assert torch.allclose(got[..., :T], want, atol=2e-2 * want.abs().max().item(), rtol=2e-2)
     cos = F.cosine_similarity(got[..., :T].flatten(), want.flatten(), dim=0)
     assert cos > 0.9995, cos
+
+
+@pytest.mark.parametrize("nb,nh,T,ldp", [(2, 2, 77, 80), (1, 3, 130, 192), (1, 1, 64, 64), (1, 2, 5, 8)])
+def test_attention_forward_fused(nb, nh, T, ldp):
+    """lp_attn_fwd == softmax(scale Q K^T) and P V per (image, head) on bf16-rounded Q / K / V out of interleaved QKV token rows:
+    ragged T (partial key tile, partial query tile, idle waves), probability pitch wider than T (pad columns zero, incl. a whole
+    pad-only key tile), several heads."""
+    gen = torch.Generator().manual_seed(nb * 100 + T)
+    d, scale = 64, 0.125
+    D = nh * d
+    ld = 3 * D + 8
+    qkv = bf(torch.randn(nb * T, ld, generator=gen) * 1.5)
+    pbits, obits = emu.attn_fwd(bits(qkv).reshape(-1), ld, D, 2 * D, nb, nh, T, scale, ldp, D)
+    heads = lambda off: qkv[:, off:off + D].reshape(nb, T, nh, d).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = heads(0), heads(D), heads(2 * D)
+    p = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1)
+    got_p = unbits(pbits).reshape(nb, nh, T, ldp)
+    assert (got_p[..., T:] == 0).all()
+    torch.testing.assert_close(got_p[..., :T], p, atol=4e-3, rtol=1e-2)          # bf16 storage of values <= 1
+    torch.testing.assert_close(got_p[..., :T].sum(-1), torch.ones(nb, nh, T), atol=1e-2, rtol=0)
+    got_o = unbits(obits).reshape(nb, T, nh, d).permute(0, 2, 1, 3)
+    want_o = bf(got_p[..., :T]) @ v                                               # O is accumulated from the STORED probabilities
+    torch.testing.assert_close(got_o, want_o, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(got_o, p @ v, atol=3e-2, rtol=3e-2)
