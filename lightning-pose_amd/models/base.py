@@ -7,6 +7,7 @@ implementing the slice of the protocol the step touches (``log``, ``save_hyperpa
 
 from __future__ import annotations
 
+import inspect
 import os
 from typing import Any, Literal
 
@@ -41,7 +42,15 @@ except Exception:  # noqa: BLE001
             self.logged[name] = value.detach() if torch.is_tensor(value) else torch.tensor(float(value))
 
         def save_hyperparameters(self, *args: Any, ignore: list[str] | None = None, **kwargs: Any) -> None:
-            return None
+            """Keep the calling ``__init__``'s arguments in ``self.hparams`` (what Lightning stores as ``hyper_parameters``)."""
+            frame = inspect.currentframe().f_back
+            info = inspect.getargvalues(frame)
+            hp = {n: info.locals[n] for n in info.args if n != "self"}
+            if info.keywords:
+                hp.update(info.locals[info.keywords])
+            for n in ignore or []:
+                hp.pop(n, None)
+            self.hparams.update(hp)
 
         def optimizers(self):
             return self._optimizer

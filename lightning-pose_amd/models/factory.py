@@ -76,4 +76,9 @@ def get_model(cfg: Any, data_module: Any, loss_factories: dict[str, Any]):
     )
     if semi:
         kwargs["loss_factory_unsupervised"] = loss_factories["unsupervised"]
-    return cls(**kwargs)
+    net = cls(**kwargs)
+    ckpt = _get(model, "checkpoint", None)
+    if ckpt:  # warm start from a trained model (reference :299-317)
+        from ..checkpoint import load_weights
+        load_weights(net, str(ckpt))
+    return net
