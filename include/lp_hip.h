@@ -224,6 +224,10 @@ int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, c
 size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);
 int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
                   size_t workspace_bytes, lp_stream_t stream);
+/* same, plus dbias[co] += sum_m dy[m][co] (bias gradient of a Linear / ConvTranspose2d layer) out of the same pass over dy: fp32
+ * atomics, one per column and pixel slice, so the summation order (not the set of addends) can vary between runs */
+int lp_conv_wgrad_bias(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, float* dbias, int split_hint, void* workspace,
+                       size_t workspace_bytes, lp_stream_t stream);
 /* ResNet stem 7x7/2: x4 = NHWC4 bf16 (channel 3 zero), weights / gradients in the padded [64][8][8][4] layout. */
 int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_stream_t stream);
 int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,

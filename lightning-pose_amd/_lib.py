@@ -81,6 +81,7 @@ PROTOTYPES = {
     "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
     "lp_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
+    "lp_conv_wgrad_bias": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _I, _P, C.c_size_t, _P]),
     "lp_stem_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P]),
     "lp_stem_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
     "lp_bn_stats": (_I, [_P, _I, _I, _P, _P]),

@@ -610,6 +610,9 @@ struct TnExt {
     unsigned x_zb, x_zh;        // byte strides of x / y per batch index
     unsigned y_zb, y_zh;
     unsigned o_zb, o_zh;        // element strides of out
+    // weight-gradient mode only: += the column sums of dy (a Linear / ConvTranspose layer's bias gradient), taken by the tiles of
+    // the first row block while they stage dy anyway (fp32 atomics: one per column, slice and launch); nullptr = off
+    float* col_sums;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -619,7 +622,7 @@ struct TnExt {
 // wgrad_reduce_kernel then sums the slices in a fixed order and adds the result into dW - deterministic, and ~20x
 // cheaper than fp32 atomics (measured: 17 M atomics per launch cost 450 us, the same bytes as plain stores ~20 us).
 // ------------------------------------------------------------------------------------------------------------
-template <int BN, bool STEM>
+template <int BN, bool STEM, bool CS = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                          unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles,
                                                          int tiles_n, int m_per_split, FastDiv div_hw, FastDiv div_wo,
@@ -683,6 +686,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
 
     u16x8 ra[4], rb[RB];
     const int hw = g.Ho * g.Wo;
+    const bool want_cs = CS && j0 == 0;  // workgroup-uniform (CS: the instantiation that also takes dy's column sums)
+    float cs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cs[q] = 0.f;
 
     // Fast addressing for stride-1 "same" convolutions (every 1x1 and 3x3 of the trunk except the three stride-2 blocks): the
     // input pixel of output pixel m under tap (r, s) is m + const, so a lane's byte offsets are fixed (raw buffer loads: the K
@@ -787,6 +794,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(pgA * 4 + i) * LDA + jc * 8]) = ra[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i) *reinterpret_cast<u16x8*>(&sB[buf][(pgB * RB + i) * LDB + nc * 8]) = rb[i];
+        if (want_cs) {  // rows past the slice and columns past Co were loaded as zeros
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cs[q] += bf16_to_f32(rb[i][q]);
+        }
     };
 
     // fragment of 32 channels x 16 pixels (k-slice kk) out of a [pixel][channel] tile: lane l of 16-lane group q = l / 16
@@ -837,6 +850,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         }
     }
 
+    if (want_cs) {  // fold the 256 / NCH row groups, then one atomic per column (the operand tiles are dead after the last barrier)
+        float* red = reinterpret_cast<float*>(&sA[0][0]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[pgB * BN + nc * 8 + q] = cs[q];
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Co) {
+            float t = 0.f;
+            for (int r = 0; r < 256 / NCH; ++r) t += red[r * BN + tid];
+            atomicAdd(&tn.col_sums[n0 + tid], t);
+        }
+    }
     if (direct) {  // out[z][j][n] = bf16(acc): reg e of lane l is row j = (e&3) + 8*(e>>2) + 4*(l>>5), column n = l & 31 of its block
         const int col = lane & 31, rg = lane >> 5;
 #pragma unroll
@@ -1242,8 +1266,8 @@ extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int sp
 }
 
 // dw[co][r][s][ci] (fp32, accumulated into) += sum_m x_gather[m][(r,s,ci)] * dy[m][co]
-extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
-                             size_t workspace_bytes, lp_stream_t stream) {
+static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, float* dbias, int split_hint, void* workspace,
+                           size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && dy && geom_ok(geom) && dw && workspace);
     ConvGeom g = to_geom(geom);
@@ -1257,18 +1281,37 @@ extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* 
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const int tiles = p.tj * p.tn;
+    TnExt ext{};
+    ext.col_sums = dbias;
+    const dim3 grid(tiles * p.split), block(256);
+    const FastDiv dhw = make_fastdiv(g.Ho * g.Wo), dwo = make_fastdiv(g.Wo);
+    const unsigned short *xs = (const unsigned short*)x, *dys = (const unsigned short*)dy;
+#define LP_WGRAD_LAUNCH(BN_, CS_)                                                                                                \
+    hipLaunchKernelGGL((conv_wgrad_kernel<BN_, false, CS_>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, \
+                       p.per, dhw, dwo, ws, ext)
     if (p.wide) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, false>), dim3(tiles * p.split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
-                           make_fastdiv(g.Wo), ws, TnExt{});
+        if (dbias) LP_WGRAD_LAUNCH(128, true);
+        else LP_WGRAD_LAUNCH(128, false);
         launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     } else {
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, false>), dim3(tiles * p.split), dim3(256), 0, st, (const unsigned short*)x,
-                           (const unsigned short*)dy, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, p.per, make_fastdiv(g.Ho * g.Wo),
-                           make_fastdiv(g.Wo), ws, TnExt{});
+        if (dbias) LP_WGRAD_LAUNCH(64, true);
+        else LP_WGRAD_LAUNCH(64, false);
         launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
     }
+#undef LP_WGRAD_LAUNCH
     return launch_status();
+}
+
+extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
+                             size_t workspace_bytes, lp_stream_t stream) {
+    return conv_wgrad_impl(x, dy, geom, dw, nullptr, split_hint, workspace, workspace_bytes, stream);
+}
+
+// same, and dbias[co] += sum_m dy[m][co] out of the same pass over dy (Linear / ConvTranspose2d layers)
+extern "C" int lp_conv_wgrad_bias(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, float* dbias, int split_hint,
+                                  void* workspace, size_t workspace_bytes, lp_stream_t stream) {
+    LP_REQUIRE(dbias);
+    return conv_wgrad_impl(x, dy, geom, dw, dbias, split_hint, workspace, workspace_bytes, stream);
 }
 
 // out[z][j][n] = sum_m x[z][m][j] * y[z][m][n]  (bf16 in / out, fp32 accumulate): the weight-gradient kernel as a batched TN GEMM

@@ -226,7 +226,7 @@ class Engine:
         self.profile.append((tag, flops, e0, e1))
         return out
 
-    def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False) -> None:
+    def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False, dbias: torch.Tensor | None = None) -> None:
         """Weight gradient of one layer.  Nothing in the backward pass consumes it, so on the device it runs on a SIDE stream,
         ordered after the kernel that produced ``dy``: its MFMA-bound tiles fill the CUs that the data-gradient's tails and the
         HBM-bound BatchNorm kernels leave idle.  All weight gradients share that stream (and the split-K workspace);
@@ -237,6 +237,9 @@ class Engine:
             self._wgrad_ws = torch.empty(max(need, 96 << 20), device=self.device, dtype=torch.uint8)
         fn = self._lib.lp_stem_wgrad if stem else self._lib.lp_conv_wgrad
         what = "lp_stem_wgrad" if stem else "lp_conv_wgrad"
+        if dbias is not None:  # the layer's bias gradient (column sums of dy) rides in the same launch
+            what = "lp_conv_wgrad_bias"
+            fn = lambda x_, dy_, g_, dw_, split, ws, nws, st: self._lib.lp_conv_wgrad_bias(x_, dy_, g_, dw_, _p(dbias), split, ws, nws, st)  # noqa: E731
         if self.device.type != "cuda" or not self.wgrad_side_stream or os.environ.get("LP_WGRAD_SIDE_STREAM", "1") == "0":
             check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()), what)
             return

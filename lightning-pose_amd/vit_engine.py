@@ -244,12 +244,9 @@ class ViTEngine(Engine):
 
     def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True):
         """bias / weight gradients into G; returns dX = dY W (bf16) if wanted"""
-        s = torch.zeros(2 * l.N, device=self.device, dtype=torch.float32)
-        check(self._lib.lp_bn_stats(_p(dy), M, l.N, _p(s), ops._stream()), "lp_bn_stats(bias)")
-        self.G[l.b_off:l.b_off + l.N] += s[:l.N]
         rows, cols = self._wg_shape
         g = _lib.ConvGeom(1, rows, cols, l.K, rows, cols, l.N, 1, 1, 1, 0) if rows * cols == M else _lib.ConvGeom(1, 1, M, l.K, 1, M, l.N, 1, 1, 1, 0)
-        self._wgrad(x, dy, g, self.G[l.w_off:])
+        self._wgrad(x, dy, g, self.G[l.w_off:], dbias=self.G[l.b_off:])  # bias gradient = column sums of dy, same pass
         if not need_dx:
             return None
         dx = torch.empty(M, l.K, device=self.device, dtype=torch.bfloat16)

@@ -361,6 +361,15 @@ def conv_wgrad(x_bits, dy_bits, g, split=0):
     return dw.np()
 
 
+def conv_wgrad_bias(x_bits, dy_bits, g, split=0):
+    """-> (dw, dbias): the weight gradient and the column sums of dy from the same launch"""
+    xb, db, dw, dbias = Buf(x_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci)), Z(g.Co)
+    nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)
+    ws = Z(nws, np.uint8)
+    ok(lib().lp_conv_wgrad_bias(xb.p, db.p, C.byref(g), dw.p, dbias.p, split, ws.p, nws, stream()))
+    return dw.np(), dbias.np()
+
+
 def stem_fwd(x4_bits, w_bits, g):
     xb, wb, ob = Buf(x4_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, 64), np.uint16)
     ok(lib().lp_stem_fwd(xb.p, wb.p, C.byref(g), ob.p, stream()))

@@ -61,6 +61,10 @@ def test_conv_fwd_dgrad_wgrad(case):
         dw = emu.conv_wgrad(xb, dyb, g, split=split)
         want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
         torch.testing.assert_close(torch.from_numpy(dw), want, atol=2e-3, rtol=2e-3)
+    # ... and with the bias gradient (column sums of dy) taken in the same pass
+    dw, db = emu.conv_wgrad_bias(xb, dyb, g, split=3)
+    torch.testing.assert_close(torch.from_numpy(dw), want, atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(torch.from_numpy(db), nhwc(dy).reshape(-1, Co).sum(0), atol=1e-3, rtol=1e-4)
 
 
 def test_conv_bias_and_column_mask():
