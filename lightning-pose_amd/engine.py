@@ -240,7 +240,10 @@ class Engine:
         if dbias is not None:  # the layer's bias gradient (column sums of dy) rides in the same launch
             what = "lp_conv_wgrad_bias"
             fn = lambda x_, dy_, g_, dw_, split, ws, nws, st: self._lib.lp_conv_wgrad_bias(x_, dy_, g_, dw_, _p(dbias), split, ws, nws, st)  # noqa: E731
-        if self.device.type != "cuda" or not self.wgrad_side_stream or os.environ.get("LP_WGRAD_SIDE_STREAM", "1") == "0":
+        # (while bench.py's per-launch events are on, the launch stays on the main stream: an event pair there brackets exactly this
+        # kernel, as rocprofv3's serialised kernel trace does; on the side stream it would bracket nothing)
+        if (self.device.type != "cuda" or not self.wgrad_side_stream or self.profile is not None
+                or os.environ.get("LP_WGRAD_SIDE_STREAM", "1") == "0"):
             check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()), what)
             return
         if self._side is None:
