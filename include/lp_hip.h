@@ -253,6 +253,18 @@ int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const floa
 /* 3x3 / stride 2 / pad 1; argmax_u8 (B,Ho,Wo,C) records the winning tap (first maximum, ATen tie rule) for the backward gather */
 int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream);
 int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
+/* Stem: BatchNorm + ReLU + MaxPool2d(3, 2, 1) without ever storing the activation between them (torchvision resnet50 children
+ * bn1, relu, maxpool; reference models/backbones/factory.py:322-348).  Forward = lp_bn_apply(relu) -> lp_maxpool_fwd, bit for bit
+ * (each tap is rounded to bf16 as lp_bn_apply would have stored it).  Backward: the activation's gradient is rebuilt on the fly from
+ * the pooled gradient dy, the arg-max bytes and z (ReLU gate recomputed from z): lp_bn_pool_bwd_reduce leaves [sum g, sum g * xhat]
+ * in sums[2][C] (+= d beta / d gamma), lp_bn_pool_bwd_apply writes d z. */
+int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int B, int Hi, int Wi,
+                           int C, void* y, void* argmax_u8, lp_stream_t stream);
+int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, int B, int Hi, int Wi, int C, float* sums, float* dbeta_acc, float* dgamma_acc,
+                          lp_stream_t stream);
+int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const float* sums, float count, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
 int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_bf16, lp_stream_t stream);
 /* (B,h,w,4*c_out) -> (B,2h,2w,c_out) stored with channel pitch ld >= c_out (pad channels untouched); inverse = 1 maps the
  * gradient (pitch ld) back */

@@ -91,6 +91,9 @@ PROTOTYPES = {
     "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
     "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "lp_bn_relu_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_bn_pool_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "lp_bn_pool_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _P, _P]),
     "lp_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
     "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "lp_vit_patchify": (_I, [_P, _I, _I, _I, _I, _P, _P]),

@@ -284,6 +284,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
     }
 }
 
+// gradient reaching input pixel (b, hi, wi), channels ch*8..+7, from the (<= 4) windows whose recorded arg-max is this pixel
+__device__ __forceinline__ void pool_gather(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY, int b, int hi,
+                                            int wi, int ch, int C, int Ho, int Wo, float (&g)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+    const int ho_lo = hi / 2, ho_hi = min(Ho - 1, (hi + 1) / 2);
+    const int wo_lo = wi / 2, wo_hi = min(Wo - 1, (wi + 1) / 2);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            const unsigned mine = (unsigned)((hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1)));
+            const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + ch * 8;
+            const uint2 packed = *reinterpret_cast<const uint2*>(IDX + o);
+            float d[8];
+            unpack8(*reinterpret_cast<const u16x8*>(DY + o), d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned a = ((i < 4 ? packed.x : packed.y) >> (8 * (i & 3))) & 0xffu;
+                if (a == mine) g[i] += d[i];
+            }
+        }
+}
+
 // gather form: each input pixel collects dy from the (<= 4) windows whose recorded arg-max is this pixel
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
                                                           int B, int Hi, int Wi, int C, int Ho, int Wo,
@@ -297,24 +319,170 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
         p /= Wi;
         const int hi = (int)(p % Hi), b = (int)(p / Hi);
         float g[8];
+        pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
+        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(g);
+    }
+}
+
+// ---- stem: BatchNorm + ReLU + max-pool in one pass --------------------------------------------------------------------------
+// The stem's activation (B x 192 x 192 x 64 at 384^2: 0.9 GB per 192 frames) is consumed by the max-pool only, so it is never
+// written: the pooled value is max over the window of bf16(relu(bn(z))) - each tap rounded exactly as lp_bn_apply would have
+// stored it, so values AND arg-max ties equal the unfused lp_bn_apply -> lp_maxpool_fwd - and the backward kernels rebuild the
+// activation's gradient on the fly from the pooled gradient, the arg-max bytes and z (ReLU gate: o > 2^-134, see bn_apply_kernel).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const unsigned short* __restrict__ Z, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int B, int Hi, int Wi, int C, int Ho,
+                                                                  int Wo, unsigned short* __restrict__ Y, unsigned char* __restrict__ IDX) {
+    const int chunks = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * chunks;
+    int have = -1;
+    float mu[8], sc[8], be[8];
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        if (ch != have) {  // (a lane keeps its chunk whenever the grid stride is a multiple of the row length: every ResNet width)
+            have = ch;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g[i] = 0.f;
-        const int ho_lo = hi / 2, ho_hi = min(Ho - 1, (hi + 1) / 2);
-        const int wo_lo = wi / 2, wo_hi = min(Wo - 1, (wi + 1) / 2);
-        for (int ho = ho_lo; ho <= ho_hi; ++ho)
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                const unsigned mine = (unsigned)((hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1)));
-                const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + ch * 8;
-                const uint2 packed = *reinterpret_cast<const uint2*>(IDX + o);
-                float d[8];
-                unpack8(*reinterpret_cast<const u16x8*>(DY + o), d);
+            for (int i = 0; i < 8; ++i) {
+                mu[i] = mean[ch * 8 + i];
+                sc[i] = invstd[ch * 8 + i] * gamma[ch * 8 + i];
+                be[i] = beta[ch * 8 + i];
+            }
+        }
+        size_t p = q / chunks;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho), b = (int)(p / Ho);
+        float m[8];
+        unsigned char arg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            m[i] = -INFINITY;
+            arg[i] = 0;
+        }
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            if (hi < 0 || hi >= Hi) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * 2 - 1 + kw;
+                if (wi < 0 || wi >= Wi) continue;
+                float x[8];
+                unpack8(*reinterpret_cast<const u16x8*>(Z + (((size_t)b * Hi + hi) * Wi + wi) * C + ch * 8), x);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const unsigned a = ((i < 4 ? packed.x : packed.y) >> (8 * (i & 3))) & 0xffu;
-                    if (a == mine) g[i] += d[i];
+                    const float a = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(x[i] - mu[i], sc[i], be[i]), 0.f)));
+                    if (a > m[i]) {
+                        m[i] = a;
+                        arg[i] = (unsigned char)(kh * 3 + kw);
+                    }
                 }
             }
-        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(g);
+        }
+        *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(m);
+        uint2 packed;
+        packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+        packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+        *reinterpret_cast<uint2*>(IDX + q * 8) = packed;
+    }
+}
+
+// [sum g, sum g * xhat] with g = relu-gated gradient of the (never stored) stem activation, gathered from the pooled gradient.
+// chunks = C/8 must divide 256: thread -> (chunk tid % chunks, row lane tid / chunks), as colreduce_kernel.
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
+                                                                 const unsigned short* __restrict__ Z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                                 float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
+    __shared__ float red[2][256][8];
+    const int chunks = C >> 3, lanes_r = 256 / chunks;
+    const int ch = threadIdx.x % chunks, rl = threadIdx.x / chunks;
+    float mu[8], is[8], sc[8], be[8], s0[8], s1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = mean[ch * 8 + i];
+        is[i] = invstd[ch * 8 + i];
+        sc[i] = is[i] * gamma[ch * 8 + i];
+        be[i] = beta[ch * 8 + i];
+        s0[i] = s1[i] = 0.f;
+    }
+    const size_t pixels = (size_t)B * Hi * Wi;
+    for (size_t p = (size_t)blockIdx.x * lanes_r + rl; p < pixels; p += (size_t)gridDim.x * lanes_r) {
+        size_t t = p;
+        const int wi = (int)(t % Wi);
+        t /= Wi;
+        const int hi = (int)(t % Hi), b = (int)(t / Hi);
+        float z[8], g[8];
+        unpack8(*reinterpret_cast<const u16x8*>(Z + p * C + ch * 8), z);
+        pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float zc = z[i] - mu[i];
+            if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
+            s0[i] += g[i];
+            s1[i] = fmaf(g[i], zc * is[i], s1[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[0][threadIdx.x][i] = s0[i];
+        red[1][threadIdx.x][i] = s1[i];
+    }
+    __syncthreads();
+    for (int pair = threadIdx.x; pair < chunks * 8; pair += 256) {
+        const int pc = pair >> 3, pi = pair & 7;
+        float t0 = 0.f, t1 = 0.f;
+        for (int q = 0; q < lanes_r; ++q) {
+            t0 += red[0][q * chunks + pc][pi];
+            t1 += red[1][q * chunks + pc][pi];
+        }
+        const int cc = pc * 8 + pi;
+        atomicAdd(&sums[cc], t0);
+        atomicAdd(&sums[C + cc], t1);
+        if (acc0) atomicAdd(&acc0[cc], t0);  // d beta
+        if (acc1) atomicAdd(&acc1[cc], t1);  // d gamma
+    }
+}
+
+// dz = gamma * invstd * (g - sum(g)/N - xhat * sum(g * xhat)/N), g as above
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
+                                                                const unsigned short* __restrict__ Z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ sums,
+                                                                float inv_count, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                                unsigned short* __restrict__ DX) {
+    const int chunks = C >> 3;
+    const size_t total = (size_t)B * Hi * Wi * chunks;
+    int have = -1;
+    float mu[8], is[8], sc[8], be[8], ga[8], k0[8], k1[8];
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int ch = (int)(q % chunks);
+        if (ch != have) {
+            have = ch;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = ch * 8 + i;
+                mu[i] = mean[c];
+                is[i] = invstd[c];
+                ga[i] = gamma[c] * is[i];
+                sc[i] = ga[i];
+                be[i] = beta[c];
+                k0[i] = sums[c] * inv_count;
+                k1[i] = sums[C + c] * inv_count;
+            }
+        }
+        size_t p = q / chunks;
+        const int wi = (int)(p % Wi);
+        p /= Wi;
+        const int hi = (int)(p % Hi), b = (int)(p / Hi);
+        float z[8], g[8], o[8];
+        unpack8(load_stream8(Z + q * 8), z);
+        pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float zc = z[i] - mu[i];
+            if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
+            o[i] = ga[i] * (g[i] - k0[i] - zc * is[i] * k1[i]);
+        }
+        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(o);
     }
 }
 
@@ -466,6 +634,46 @@ extern "C" int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int 
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)B * Hi * Wi * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
+    return launch_status();
+}
+
+extern "C" int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int B,
+                                      int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(z && mean && invstd && gamma && beta && y && argmax_u8 && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi, Wi, C, Ho, Wo, (unsigned short*)y,
+                       (unsigned char*)argmax_u8);
+    return launch_status();
+}
+
+extern "C" int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, int B, int Hi, int Wi, int C, float* sums, float* dbeta_acc,
+                                     float* dgamma_acc, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    if (C % 8 != 0 || 256 % (C / 8) != 0) return LP_ERR_UNSUPPORTED;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const long long pixels = (long long)B * Hi * Wi;
+    if (pixels >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(colreduce_blocks((int)pixels, C)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi,
+                       Wi, C, Ho, Wo, sums, dbeta_acc, dgamma_acc);
+    return launch_status();
+}
+
+extern "C" int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, const float* sums, float count, int B, int Hi, int Wi, int C,
+                                    void* dx, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && count > 0.f);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for((size_t)B * Hi * Wi * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
+                       1.f / count, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
     return launch_status();
 }
 

@@ -394,9 +394,8 @@ class Engine:
             self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run)
         return out, g
 
-    def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
-                have_sums: bool = False, want_bits: bool = False):
-        """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass"""
+    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False):
+        """-> (mean, invstd) of this pass: batch statistics (running statistics updated) in training, running statistics otherwise"""
         mean = torch.empty(b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         if training:
@@ -412,6 +411,12 @@ class Engine:
         else:
             mean.copy_(self.running_view(b, "running_mean"))
             invstd.copy_((self.running_view(b, "running_var") + BN_EPS).rsqrt())
+        return mean, invstd
+
+    def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
+                have_sums: bool = False, want_bits: bool = False):
+        """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass"""
+        mean, invstd = self._bn_moments(b, z, M, training, sums, have_sums)
         y = torch.empty_like(z)
         bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
         check(self._lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias")),
@@ -521,13 +526,18 @@ class Engine:
             aa, mm, vv = res[:3]
             return zz, aa, mm, vv, gg
 
-        z, a, mu, iv, g = conv_bn(plan.stem, plan.stem_bn, x4, H, W, None, True)
+        # stem: conv -> [BatchNorm -> ReLU -> max-pool] in one pass; the full-resolution activation between them is never stored
+        sb = plan.stem_bn
+        s_sums = next_sums(sb)
+        z, g = self._conv_fwd(plan.stem, x4, B, H, W, s_sums if training else None)
         h, w = g.Ho, g.Wo
-        T["stem.z"], T["stem.a"], T["stem.mu"], T["stem.iv"] = z, a, mu, iv
+        mu, iv = self._bn_moments(sb, z, B * h * w, training, s_sums, have_sums=training)
+        T["stem.z"], T["stem.mu"], T["stem.iv"] = z, mu, iv
         ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         x = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.bfloat16)
         T["pool.arg"] = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.uint8)
-        check(self._lib.lp_maxpool_fwd(_p(a), B, h, w, 64, _p(x), _p(T["pool.arg"]), ops._stream()), "lp_maxpool_fwd")
+        check(self._lib.lp_bn_relu_maxpool_fwd(_p(z), _p(mu), _p(iv), _p(self.param_view(sb, "weight")), _p(self.param_view(sb, "bias")), B, h, w,
+                                               64, _p(x), _p(T["pool.arg"]), ops._stream()), "lp_bn_relu_maxpool_fwd")
         h, w = ph, pw
         tp.meta["stem_hw"] = (g.Ho, g.Wo)
 
@@ -670,9 +680,21 @@ class Engine:
         if trace is not None:
             trace["stem.dpool"] = d
         sh, sw = tp.meta["stem_hw"]
-        da = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_maxpool_bwd(_p(T["pool.arg"]), _p(d), B, sh, sw, 64, _p(da), ops._stream()), "lp_maxpool_bwd")
-        dz, _ = self._bn_bwd(plan.stem_bn, da, T["stem.a"], T["stem.z"], T["stem.mu"], T["stem.iv"], B * sh * sw, False)
+        # max-pool, ReLU and BatchNorm backward of the stem in two passes over z (the reductions, then dz): the activation's gradient
+        # is rebuilt on the fly from the pooled gradient and the arg-max bytes, the ReLU gate from z
+        sb = plan.stem_bn
+        ssum = torch.zeros(2 * sb.C, device=self.device, dtype=torch.float32)
+        gam, bet = self.param_view(sb, "weight"), self.param_view(sb, "bias")
+        check(self._lib.lp_bn_pool_bwd_reduce(_p(T["pool.arg"]), _p(d), _p(T["stem.z"]), _p(T["stem.mu"]), _p(T["stem.iv"]), _p(gam), _p(bet), B,
+                                              sh, sw, 64, _p(ssum), _p(self.G[sb.b_off:]), _p(self.G[sb.g_off:]), ops._stream()),
+              "lp_bn_pool_bwd_reduce")
+        count = float(B * sh * sw)
+        if self.sync_bn:
+            dist.all_reduce(ssum, group=self.process_group)
+            count *= dist.get_world_size(self.process_group)
+        dz = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_bn_pool_bwd_apply(_p(T["pool.arg"]), _p(d), _p(T["stem.z"]), _p(T["stem.mu"]), _p(T["stem.iv"]), _p(gam), _p(bet),
+                                             _p(ssum), count, B, sh, sw, 64, _p(dz), ops._stream()), "lp_bn_pool_bwd_apply")
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
                     lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True))

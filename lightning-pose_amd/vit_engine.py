@@ -7,10 +7,13 @@ Same contract as :class:`lightning_pose_amd.engine.Engine` (flat fp32 parameter 
 ``...layernorm*``, ``head.upsampling_layers.*`` - the names of the installed transformers 5.x ``ViTModel``; the 4.x names
 ``encoder.layer.{i}.attention.attention.query`` ... are accepted by ``load_state_dict``).
 
-Every Linear layer and both attention products run on the MFMA GEMM (``lp_gemm_nt``: forward and data-gradient; ``lp_conv_wgrad``:
-weight-gradient); everything between them is csrc/vit.hip.  Attention is evaluated per (image, head) as batched GEMMs on the fused
-QKV tensor with the probabilities materialised in bf16 (row pitch padded to a multiple of 64 so they are a GEMM K operand); the
-residual stream, LayerNorm statistics and all reductions are fp32.
+Every Linear layer runs on the MFMA GEMM (``lp_gemm_nt``: forward and data-gradient; ``lp_conv_wgrad_bias``: weight + bias gradient).
+Attention is ``lp_attn_fwd`` - one fused kernel per layer working straight on the (image, head) slices of the fused QKV tensor: the
+scores never leave the chip, the probabilities are written once in bf16 (row pitch padded to a multiple of 64) for the backward
+pass - and, backward, ``lp_attn_rowdot`` + ``lp_attn_dscores`` (soft-max backward in the store pass of dO V^T), ``lp_gemm_tn`` (dV, dK:
+both operands contracted over their rows, no transposed copies) and one more ``lp_gemm_nt`` (dQ).  The glue (LayerNorm, GELU, token
+assembly, the small head-slice transpose) is csrc/vit.hip.  The residual stream, LayerNorm statistics and all reductions are fp32;
+GEMM operands bf16.
 """
 
 from __future__ import annotations
@@ -416,6 +419,3 @@ class ViTEngine(Engine):
         self._wg_shape = (B, Np)
         self._linear_bwd(pl.patch_lin, T["patches"], dpatch, B * Np, need_dx=False)
         self._join_side_stream()
-
-    def _gemm_out_ptr(self, t):  # (kept for symmetry with Engine helpers)
-        return _p(t)

@@ -425,6 +425,25 @@ def maxpool_bwd(arg_u8, dy_bits, Bn, Hi, Wi, Cn):
     return dx.np()
 
 
+def bn_relu_maxpool(z_bits, mean, invstd, gamma, beta, Bn, Hi, Wi, Cn):
+    Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    zb, y, arg = Buf(z_bits), Z((Bn, Ho, Wo, Cn), np.uint16), Z((Bn, Ho, Wo, Cn), np.uint8)
+    mb, vb, gb, bb = Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma)), Buf(f32(beta))
+    ok(lib().lp_bn_relu_maxpool_fwd(zb.p, mb.p, vb.p, gb.p, bb.p, Bn, Hi, Wi, Cn, y.p, arg.p, stream()))
+    return y.np(), arg.np()
+
+
+def bn_pool_backward(arg_u8, dy_bits, z_bits, mean, invstd, gamma, beta, Bn, Hi, Wi, Cn):
+    """-> (dz bits, dgamma, dbeta, sums) of the fused stem backward"""
+    ab, db, zb = Buf(arg_u8), Buf(dy_bits), Buf(z_bits)
+    mb, vb, gb, bb = Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma)), Buf(f32(beta))
+    sums, dbeta, dgamma = Z((2, Cn)), Z(Cn), Z(Cn)
+    ok(lib().lp_bn_pool_bwd_reduce(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, Bn, Hi, Wi, Cn, sums.p, dbeta.p, dgamma.p, stream()))
+    dz = Z((Bn * Hi * Wi, Cn), np.uint16)
+    ok(lib().lp_bn_pool_bwd_apply(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, sums.p, float(Bn * Hi * Wi), Bn, Hi, Wi, Cn, dz.p, stream()))
+    return dz.np(), dgamma.np(), dbeta.np(), sums.np()
+
+
 def images_to_nhwc4(img):
     img = f32(img)
     b, _, h, w = img.shape

@@ -63,6 +63,38 @@ def test_maxpool_fwd_bwd_with_ties():
     torch.testing.assert_close(emu.from_bf16_bits(dx), bf(x.grad.permute(0, 2, 3, 1)), atol=2e-2, rtol=2e-2)
 
 
+def test_stem_bn_relu_maxpool_fused_equals_the_unfused_chain():
+    """lp_bn_relu_maxpool_fwd == lp_bn_apply(relu) -> lp_maxpool_fwd bit for bit (values AND arg-max bytes, ties included), and the
+    fused backward (gradient of the never-stored activation rebuilt from pooled gradient + arg-max + z) == lp_maxpool_bwd ->
+    lp_bn_bwd_reduce / lp_bn_bwd_apply, and both == autograd of BatchNorm -> ReLU -> max_pool2d."""
+    gen = torch.Generator().manual_seed(4)
+    B, H, W, C = 2, 10, 12, 64
+    M = B * H * W
+    z = bf(torch.randn(B, C, H, W, generator=gen) * 2 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=gen)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=gen) - 0.4).requires_grad_(True)  # plenty of negative pre-activations -> zeros -> ties
+    zb = emu.to_bf16_bits(z.detach().permute(0, 2, 3, 1)).reshape(M, C)
+    a_bits, mean, invstd = emu.bn_forward(zb, M, C, gamma.detach().numpy(), beta.detach().numpy(), relu=True)
+    y0, arg0 = emu.maxpool(a_bits, B, H, W, C)
+    y1, arg1 = emu.bn_relu_maxpool(zb, mean, invstd, gamma.detach().numpy(), beta.detach().numpy(), B, H, W, C)
+    assert np.array_equal(y0, y1) and np.array_equal(arg0, arg1)
+    # backward
+    y = F.max_pool2d(F.relu(F.batch_norm(z, None, None, gamma, beta, training=True, eps=1e-5)), 3, 2, 1)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    dyb = emu.to_bf16_bits(dy.permute(0, 2, 3, 1))
+    da = emu.maxpool_bwd(arg0, dyb, B, H, W, C).reshape(M, C)
+    dz0, _, dgamma0, dbeta0 = emu.bn_backward(da, a_bits, zb, mean, invstd, gamma.detach().numpy(), M, C)
+    dz1, dgamma1, dbeta1, _ = emu.bn_pool_backward(arg1, dyb, zb, mean, invstd, gamma.detach().numpy(), beta.detach().numpy(), B, H, W, C)
+    # the unfused chain rounds the gathered gradient to bf16 before reducing it; the fused one keeps it in fp32
+    torch.testing.assert_close(torch.from_numpy(dgamma1), torch.from_numpy(dgamma0), atol=3e-2, rtol=5e-3)
+    torch.testing.assert_close(torch.from_numpy(dbeta1), torch.from_numpy(dbeta0), atol=3e-2, rtol=5e-3)
+    torch.testing.assert_close(emu.from_bf16_bits(dz1), emu.from_bf16_bits(dz0), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(torch.from_numpy(dgamma1), gamma.grad, atol=5e-2, rtol=1e-2)
+    torch.testing.assert_close(torch.from_numpy(dbeta1), beta.grad, atol=5e-2, rtol=1e-2)
+    torch.testing.assert_close(emu.from_bf16_bits(dz1).reshape(B, H, W, C), z.grad.permute(0, 2, 3, 1), atol=2e-2, rtol=2e-2)
+
+
 def test_images_and_pixel_shuffle():
     gen = torch.Generator().manual_seed(2)
     img = torch.randn(2, 3, 6, 5, generator=gen)
