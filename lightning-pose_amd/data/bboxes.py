@@ -9,7 +9,7 @@ from .. import ops
 
 def batch_num_views(batch_dict: dict) -> int:
     """Number of camera views encoded in a batch (reference bboxes.py:254-271)."""
-    if "num_views" in batch_dict:
+    if "num_views" in batch_dict and (int(batch_dict["num_views"].max()) > 1 or batch_dict.get("is_multiview", False)):
         unique = torch.unique(batch_dict["num_views"])
         if unique.numel() != 1:
             raise ValueError(f"each batch element must contain the same number of views; found elements with {unique} views")
@@ -33,5 +33,8 @@ def model_to_frame_batch(batch_dict: dict, model_keypoints: torch.Tensor, in_pla
     mh, mw = model_dims(batch_dict)
     views = batch_num_views(batch_dict)
     k = model_keypoints.shape[1] // 2
-    fm = ops.DecodeFrameMap(None, False, batch_dict["bbox"], views, mh, mw, k)
+    bbox = batch_dict["bbox"]
+    if bbox.shape[0] != model_keypoints.shape[0]:  # context batch: no predictions for the first / last two frames (norm_to_frame :99-104)
+        bbox = bbox[2:-2]
+    fm = ops.DecodeFrameMap(None, False, bbox, views, mh, mw, k)
     return ops.frame_map_apply(model_keypoints, fm)

@@ -39,6 +39,24 @@ class Loss:
     def weight(self) -> torch.Tensor:
         return 1.0 / (2.0 * torch.exp(self.log_weight))
 
+    def rectify_epsilon(self, loss: torch.Tensor) -> torch.Tensor:
+        """``relu(loss - epsilon)``: errors below epsilon cost nothing (reference :117-133; the fused kernels apply the same rule)."""
+        return torch.relu(loss - self.epsilon.to(loss.device))
+
+    def reduce_loss(self, loss: torch.Tensor, method: str = "mean") -> torch.Tensor:
+        """reference :135-160"""
+        if method == "mean":
+            return torch.mean(loss)
+        if method == "sum":
+            return torch.sum(loss)
+        raise NotImplementedError(f"reduction method {method!r}")
+
+    def remove_nans(self, **kwargs: Any):
+        raise NotImplementedError
+
+    def compute_loss(self, **kwargs: Any):
+        raise NotImplementedError
+
     def log_loss(self, loss: torch.Tensor, stage: Literal["train", "val", "test"] | None) -> list[dict]:
         return [
             {"name": f"{stage}_{self.loss_name}_loss", "value": loss, "prog_bar": True},
