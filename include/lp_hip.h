@@ -181,6 +181,13 @@ int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, i
  * k_off + h*64 and V at v_off + h*64.  The scores stay on chip (two passes over the keys: running max / exp-sum, then P and O). */
 int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
                 void* out_bf16, int ldo, lp_stream_t stream);
+/* Attention backward, key / value side, in one pass over the stored probabilities (replaces lp_attn_dscores + 2 x lp_gemm_tn):
+ *   dS[z][q][k] = scale * P[z][q][k] * (sum_d dO[q][d] V[k][d] - D[q])   -> ds_bf16 (layout / pitch of P, pad columns zeroed; dQ = dS K reads it)
+ *   dV[k][d] = sum_q P[q][k] dO[q][d]  -> dqkv_bf16[(b*T + k)*ld_dqkv + dv_off + h*64 + d]
+ *   dK[k][d] = sum_q dS[q][k] Q[q][d]  -> dqkv_bf16[(b*T + k)*ld_dqkv + dk_off + h*64 + d]
+ * Q / V come from the token rows of lp_attn_fwd, dO from d_out_bf16[(b*T + q)*ld_do + h*64 ..], D = lp_attn_rowdot's [B*T][nh]. */
+int lp_attn_bwd_kv(const void* qkv_bf16, int ld_qkv, int v_off, const void* d_out_bf16, int ld_do, const void* p_bf16, int ldp, const float* d_rows,
+                   int B, int nh, int T, float scale, void* ds_bf16, void* dqkv_bf16, int ld_dqkv, int dk_off, int dv_off, lp_stream_t stream);
 /* Attention backward without materialising dP (replaces lp_gemm_nt + lp_softmax_rows_bwd of the composition; the reference's
  * arithmetic is HF ViTSelfAttention's eager soft-max attention, models/backbones/vit.py:38-43):
  *   lp_attn_rowdot   D[row][h] = sum_d a[row][h*64+d] * b[row][h*64+d]   (a = dO, b = O, head dimension 64, nh <= 8)

@@ -224,6 +224,205 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Backward, key / value side:  dS = scale * P o (dO V^T - D)  (written: the dQ product reads it),  dV = P^T dO,  dK = dS^T Q
+// in ONE pass over the stored probabilities (the composition lp_attn_dscores + 2 x lp_gemm_tn reads P twice and dS twice).
+//
+// Mirror image of the forward kernel: a workgroup owns 128 KEYS of one (image, head) (a wave 32 of them) and streams the queries
+// through LDS in tiles of 64.  dP = dO V^T is computed untransposed, so in the MFMA result layout a lane owns ONE key and 32 of a
+// tile's 64 queries; the stored P tile comes out of LDS in exactly that layout through ds_read_b64_tr_b16 (4 consecutive queries
+// of one key per read), dS is formed in registers, and both P and dS are - register for register - the B operands of
+// dV^T += dO^T P and dK^T += Q^T dS (contraction over the queries, visited in accumulator order; dO^T / Q^T are fetched in that
+// order by transpose reads of the [query][d] tiles).  dS replaces P in the LDS tile in place (a wave only touches its own 32
+// columns) and leaves as full rows.  The next tile's global loads are in flight (in registers) while the current one is computed.
+constexpr int kBQ = 64;            // queries per tile
+constexpr int kBK2 = 128;          // keys per workgroup
+constexpr int kLDT = kAD + 32;     // dO / Q tile pitch (transpose-read source: +64 B)
+constexpr int kLDP2 = kBK2 + 32;   // P / dS tile pitch
+
+struct AttnBwdArgs {
+    const unsigned short* qkv;   // token rows: Q at column h*64, V at v_off + h*64
+    int ld, v_off;
+    const unsigned short* d_out; // [B*T][ld_do], head h at column h*64
+    int ld_do;
+    const unsigned short* p;     // [B*nh][T][ldp]
+    int ldp;
+    const float* d_rows;         // [B*T][nh]: rowsum(dO o O)
+    int nh, T, ktiles;
+    float scale;
+    unsigned short* ds;          // [B*nh][T][ldp] (pad columns zeroed)
+    unsigned short* dqkv;        // token rows of pitch ld_dqkv: dK at dk_off + h*64, dV at dv_off + h*64
+    int ld_dqkv, dk_off, dv_off;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short sDO[kBQ * kLDT];
+    __shared__ __attribute__((aligned(16))) unsigned short sQ[kBQ * kLDT];
+    __shared__ __attribute__((aligned(16))) unsigned short sP[kBQ * kLDP2];
+    __shared__ __attribute__((aligned(16))) float sD[kBQ];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int z = blockIdx.x / a.ktiles, kt = blockIdx.x - z * a.ktiles;
+    const int b = z / a.nh, h = z - b * a.nh;
+    const int T = a.T;
+    const int kv0 = kt * kBK2;
+    const unsigned short* Qp = a.qkv + (size_t)b * T * a.ld + h * kAD;
+    const unsigned short* Vp = Qp + a.v_off;
+    const unsigned short* DOp = a.d_out + (size_t)b * T * a.ld_do + h * kAD;
+    const unsigned short* Pp = a.p + (size_t)z * T * a.ldp;
+    const bool active = kv0 + wave * 32 < T;
+
+    // this lane's key row of V as the B operand of dP = dO V^T (rows past T alias the last row: their P is zero)
+    bf16x8 vf[kAD / 16];
+    {
+        int kv = kv0 + wave * 32 + col;
+        if (kv >= T) kv = T - 1;
+        const unsigned short* vr = Vp + (size_t)kv * a.ld + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < kAD / 16; ++kk) vf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(vr + kk * 16));
+    }
+
+    // staging: dO / Q tiles -> thread owns chunk (tid & 7) of rows (tid >> 3) + 32 i; P tile -> chunk (tid & 15) of rows (tid >> 4) + 16 i
+    const int srow = tid >> 3, schunk = tid & 7, prow = tid >> 4, pchunk = tid & 15;
+    const bool pcol_ok = kv0 + pchunk * 8 < a.ldp;
+    u16x8 rdo[2], rq[2], rp[4];
+    float rd = 0.f;
+    auto fetch = [&](int t) {
+        const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = t * kBQ + srow + 32 * i;
+            rdo[i] = q < T ? *reinterpret_cast<const u16x8*>(DOp + (size_t)q * a.ld_do + schunk * 8) : zero;
+            rq[i] = q < T ? *reinterpret_cast<const u16x8*>(Qp + (size_t)q * a.ld + schunk * 8) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = t * kBQ + prow + 16 * i;
+            rp[i] = (q < T && pcol_ok) ? *reinterpret_cast<const u16x8*>(Pp + (size_t)q * a.ldp + kv0 + pchunk * 8) : zero;
+        }
+        if (tid < kBQ) {
+            const int q = t * kBQ + tid;
+            rd = q < T ? a.d_rows[((size_t)b * T + q) * a.nh + h] : 0.f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u16x8*>(&sDO[(srow + 32 * i) * kLDT + schunk * 8]) = rdo[i];
+            *reinterpret_cast<u16x8*>(&sQ[(srow + 32 * i) * kLDT + schunk * 8]) = rq[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sP[(prow + 16 * i) * kLDP2 + pchunk * 8]) = rp[i];
+        if (tid < kBQ) sD[tid] = rd;
+    };
+
+    f32x16 dv[2], dk[2];  // dV^T, dK^T: [d = db*32 + rows][key = this lane's]
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dv[db][e] = dk[db][e] = 0.f;
+    const int fq = lane >> 4, fi = lane & 15;
+    const int trow = 4 * (fq >> 1) + (fi >> 2), tcol = 16 * (fq & 1) + 4 * (fi & 3);  // transpose-read source of this lane
+
+    const int n_q = (T + kBQ - 1) / kBQ;
+    fetch(0);
+    for (int t = 0; t < n_q; ++t) {
+        stage();
+        __syncthreads();
+        if (t + 1 < n_q) fetch(t + 1);
+        if (active) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            unsigned pk[2][8];   // dS of this tile as packed bf16 pairs (regs e, e+1 = two consecutive queries)
+            s16x4_t pr[2][4];    // P: [block][e >> 2] = 4 consecutive queries of this lane's key
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                f32x16 dp;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < kAD / 16; ++kk) {
+                    const bf16x8 of = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(&sDO[(blk * 32 + col) * kLDT + kk * 16 + half * 8]));
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[kk], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int q0 = blk * 32 + 8 * g4;  // + 4 * half + (0..3)
+                    pr[blk][g4] = lds_read_tr16(&sP[(q0 + trow) * kLDP2 + wave * 32 + tcol]);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[q0 + 4 * half]);
+                    float s4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        s4[i] = a.scale * bf16_to_f32((unsigned short)pr[blk][g4][i]) * (dp[4 * g4 + i] - d4[i]);
+                    pk[blk][2 * g4] = pack_bf16x2(s4[0], s4[1]);
+                    pk[blk][2 * g4 + 1] = pack_bf16x2(s4[2], s4[3]);
+                }
+            }
+            // dV^T += dO^T P and dK^T += Q^T dS: k-slab j = the 16 queries in regs 8*(j&1) .. +7 of block j>>1 (both halves)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const s16x8_t pv = {pr[j >> 1][2 * (j & 1)][0], pr[j >> 1][2 * (j & 1)][1], pr[j >> 1][2 * (j & 1)][2], pr[j >> 1][2 * (j & 1)][3],
+                                    pr[j >> 1][2 * (j & 1) + 1][0], pr[j >> 1][2 * (j & 1) + 1][1], pr[j >> 1][2 * (j & 1) + 1][2],
+                                    pr[j >> 1][2 * (j & 1) + 1][3]};
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+                const u32x4_t sw = {pk[j >> 1][4 * (j & 1)], pk[j >> 1][4 * (j & 1) + 1], pk[j >> 1][4 * (j & 1) + 2], pk[j >> 1][4 * (j & 1) + 3]};
+                const bf16x8 sf = __builtin_bit_cast(bf16x8, sw);
+                const int qb = 32 * (j >> 1) + 16 * (j & 1);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const unsigned short* op = &sDO[(qb + trow) * kLDT + db * 32 + tcol];
+                    const s16x4_t olo = lds_read_tr16(op), ohi = lds_read_tr16(op + 8 * kLDT);
+                    const s16x8_t ov = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ov), pf, dv[db], 0, 0, 0);
+                    const unsigned short* qp = &sQ[(qb + trow) * kLDT + db * 32 + tcol];
+                    const s16x4_t qlo = lds_read_tr16(qp), qhi = lds_read_tr16(qp + 8 * kLDT);
+                    const s16x8_t qv = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qv), sf, dk[db], 0, 0, 0);
+                }
+            }
+            // dS over P, in place: this wave's 32 columns only
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int q = blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    sP[q * kLDP2 + wave * 32 + col] = (unsigned short)((pk[blk][e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                }
+        } else {  // keys past T: the probabilities there are zero, so is dS
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sP[(blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * kLDP2 + wave * 32 + col] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = t * kBQ + prow + 16 * i;
+            if (q < T && pcol_ok)
+                *reinterpret_cast<u16x8*>(a.ds + ((size_t)z * T + q) * a.ldp + kv0 + pchunk * 8) =
+                    *reinterpret_cast<const u16x8*>(&sP[(prow + 16 * i) * kLDP2 + pchunk * 8]);
+        }
+        __syncthreads();  // the tiles are free for the next staging
+    }
+
+    const int kv = kv0 + wave * 32 + col;
+    if (active && kv < T) {
+        unsigned short* row = a.dqkv + ((size_t)b * T + kv) * a.ld_dqkv + h * kAD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t wv = {pack_bf16x2(dv[db][4 * g4], dv[db][4 * g4 + 1]), pack_bf16x2(dv[db][4 * g4 + 2], dv[db][4 * g4 + 3])};
+                const u32x2_t wk = {pack_bf16x2(dk[db][4 * g4], dk[db][4 * g4 + 1]), pack_bf16x2(dk[db][4 * g4 + 2], dk[db][4 * g4 + 3])};
+                *reinterpret_cast<u32x2_t*>(row + a.dv_off + db * 32 + 8 * g4 + 4 * half) = wv;
+                *reinterpret_cast<u32x2_t*>(row + a.dk_off + db * 32 + 8 * g4 + 4 * half) = wk;
+            }
+    }
+}
+
 }  // namespace lp
 
 extern "C" int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
@@ -238,5 +437,22 @@ extern "C" int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_of
     AttnArgs a{(const unsigned short*)qkv_bf16, ld_qkv, k_off, v_off, nh, T, qtiles, scale, (unsigned short*)p_bf16, ldp,
                (unsigned short*)out_bf16, ldo};
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int lp_attn_bwd_kv(const void* qkv_bf16, int ld_qkv, int v_off, const void* d_out_bf16, int ld_do, const void* p_bf16, int ldp,
+                              const float* d_rows, int B, int nh, int T, float scale, void* ds_bf16, void* dqkv_bf16, int ld_dqkv, int dk_off,
+                              int dv_off, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(qkv_bf16 && d_out_bf16 && p_bf16 && d_rows && ds_bf16 && dqkv_bf16 && B > 0 && nh > 0 && T > 0 && ldp >= T &&
+               ld_qkv >= nh * kAD && ld_do >= nh * kAD && ld_dqkv >= nh * kAD && v_off >= 0 && dk_off >= 0 && dv_off >= 0);
+    if (ld_qkv % 8 != 0 || v_off % 8 != 0 || ld_do % 8 != 0 || ldp % 8 != 0 || ld_dqkv % 4 != 0 || dk_off % 4 != 0 || dv_off % 4 != 0)
+        return LP_ERR_UNSUPPORTED;
+    const int ktiles = (ldp + kBK2 - 1) / kBK2;  // every column of dS up to its pitch is written (pad columns: zeros)
+    const long long wgs = (long long)B * nh * ktiles;
+    if (wgs >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    AttnBwdArgs a{(const unsigned short*)qkv_bf16, ld_qkv, v_off, (const unsigned short*)d_out_bf16, ld_do, (const unsigned short*)p_bf16, ldp,
+                  d_rows, nh, T, ktiles, scale, (unsigned short*)ds_bf16, (unsigned short*)dqkv_bf16, ld_dqkv, dk_off, dv_off};
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     return launch_status();
 }

@@ -382,22 +382,17 @@ class ViTEngine(Engine):
             dqkv = torch.empty(M, qs, device=dev, dtype=torch.bfloat16)
             zP = (nh * Tn * Tp, Tn * Tp)       # batch strides of a [B][nh][Tn][Tp] tensor
             zT = (nh * 64 * Tp, 64 * Tp)       # ... of a [B][nh][64][Tp] transposed head slice
-            # dS = scale * P o (dO V^T - rowsum(dO o O)): the soft-max backward rides in the store pass of the dO V^T product
-            # (rowsum(dP o P) == rowsum(dO o O) because O = P V), so dP never exists in memory
+            # D = rowsum(dO o O) (== rowsum(dP o P) because O = P V), then ONE pass over the stored probabilities leaves
+            # dS = scale * P o (dO V^T - D), dV = P^T dO and dK = dS^T Q (dP never exists; P and dS are touched once each here)
             drow = torch.empty(M, nh, device=dev, dtype=torch.float32)
             check(self._lib.lp_attn_rowdot(_p(d_attn), _p(t("attn")), M, nh, D, _p(drow), ops._stream()), "lp_attn_rowdot")
             dS = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
-            gb = _lib.GemmBatch(B, nh, Tn * D, 64, Tn * qs, 64, *zP)
-            check(self._lib.lp_attn_dscores(_p(d_attn), D, qkv[:, 2 * D:].data_ptr(), qs, _p(Pm), _p(drow), nh, Tn * nh, 1, scale, _p(dS), Tp,
-                                            Tn, Tn, 64, C.byref(gb), ops._stream()), "lp_attn_dscores")
-            tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
-            # dV = P^T dO  (TN GEMM: P and dO are both read in place, contracted over the query index)
-            self._gemm_tn(_p(Pm), Tp, _p(d_attn), D, Tn, Tn, 64, dqkv[:, 2 * D:], qs, batch=(B, nh, *zP, Tn * D, 64, Tn * qs, 64))
+            check(self._lib.lp_attn_bwd_kv(_p(qkv), qs, 2 * D, _p(d_attn), D, _p(Pm), Tp, _p(drow), B, nh, Tn, scale, _p(dS), _p(dqkv), qs, D, 2 * D,
+                                           ops._stream()), "lp_attn_bwd_kv")
             # dQ = dS K
+            tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
             self._transpose(qkv[:, D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)
             self._gemm(_p(dS), Tp, _p(tmpT), Tp, Tn, 64, Tp, dqkv, qs, batch=(B, nh, *zP, *zT, Tn * qs, 64))
-            # dK = dS^T Q
-            self._gemm_tn(_p(dS), Tp, _p(qkv), qs, Tn, Tn, 64, dqkv[:, D:], qs, batch=(B, nh, *zP, Tn * qs, 64, Tn * qs, 64))
             if trace is not None:
                 trace[f"l{i}.dqkv"] = dqkv
             d_y1 = self._linear_bwd(L["qkv"], t("y1"), dqkv, M)

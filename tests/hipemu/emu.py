@@ -339,6 +339,14 @@ def attn_fwd(qkv_bits, ld, k_off, v_off, nb, nh, T, scale, ldp, ldo):
     return pb.np(), ob.np()
 
 
+def attn_bwd_kv(qkv_bits, ld, v_off, do_bits, ld_do, p_bits, ldp, d_rows, nb, nh, T, scale, ld_dqkv, dk_off, dv_off):
+    """-> (dS bits [nb*nh*T][ldp], dqkv bits [nb*T][ld_dqkv] with dK / dV filled in)"""
+    qb, db, pb, dr = Buf(qkv_bits), Buf(do_bits), Buf(p_bits), B(d_rows, np.float32)
+    ds, dq = Z((nb * nh * T, ldp), np.uint16), Z((nb * T, ld_dqkv), np.uint16)
+    ok(lib().lp_attn_bwd_kv(qb.p, ld, v_off, db.p, ld_do, pb.p, ldp, dr.p, nb, nh, T, scale, ds.p, dq.p, ld_dqkv, dk_off, dv_off, stream()))
+    return ds.np(), dq.np()
+
+
 def attn_rowdot(a_bits, b_bits, rows, nh, ld):
     ab, bb, o = Buf(a_bits), Buf(b_bits), Z((rows, nh))
     ok(lib().lp_attn_rowdot(ab.p, bb.p, rows, nh, ld, o.p, stream()))

@@ -175,3 +175,38 @@ def test_attention_forward_fused(nb, nh, T, ldp):
     want_o = bf(got_p[..., :T]) @ v                                               # O is accumulated from the STORED probabilities
     torch.testing.assert_close(got_o, want_o, atol=2e-2, rtol=2e-2)
     torch.testing.assert_close(got_o, p @ v, atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("nb,nh,T,ldp", [(2, 2, 77, 80), (1, 3, 130, 192), (1, 1, 64, 64), (1, 2, 5, 8), (1, 1, 200, 256)])
+def test_attention_backward_kv_fused(nb, nh, T, ldp):
+    """lp_attn_bwd_kv: dS, dV = P^T dO and dK = dS^T Q in one pass over the stored probabilities == the soft-max backward and the two
+    products spelled in torch on the same bf16 operands (ragged T: partial key workgroups, partial query tiles, idle waves, pad-only
+    key tiles)."""
+    gen = torch.Generator().manual_seed(nb * 1000 + T)
+    d, scale = 64, 0.125
+    D = nh * d
+    ld = 3 * D
+    qkv = bf(torch.randn(nb * T, ld, generator=gen))
+    heads = lambda t2, off: t2[:, off:off + D].reshape(nb, T, nh, d).permute(0, 2, 1, 3)  # noqa: E731
+    q, k, v = heads(qkv, 0), heads(qkv, D), heads(qkv, 2 * D)
+    p = bf(torch.softmax((q @ k.transpose(-1, -2)) * scale, -1))          # the probabilities as stored by the forward pass
+    o = bf(p @ v)
+    d_o_rows = bf(torch.randn(nb * T, D, generator=gen))
+    d_o = heads(d_o_rows, 0)
+    drow = (d_o * o).sum(-1).permute(0, 2, 1).reshape(nb * T, nh).contiguous()
+    p_pad = torch.zeros(nb, nh, T, ldp)
+    p_pad[..., :T] = p
+    ds_bits, dqkv_bits = emu.attn_bwd_kv(bits(qkv).reshape(-1), ld, 2 * D, bits(d_o_rows).reshape(-1), D, bits(p_pad).reshape(-1), ldp,
+                                         drow.numpy(), nb, nh, T, scale, ld, D, 2 * D)
+    dp = d_o @ v.transpose(-1, -2)
+    want_ds = scale * p * (dp - drow.reshape(nb, T, nh).permute(0, 2, 1).unsqueeze(-1))
+    got_ds = unbits(ds_bits).reshape(nb, nh, T, ldp)
+    assert (got_ds[..., T:] == 0).all()
+    torch.testing.assert_close(got_ds[..., :T], bf(want_ds), atol=2e-3 * want_ds.abs().max().item() + 1e-6, rtol=1e-2)
+    dqkv = unbits(dqkv_bits)
+    assert not dqkv[:, :D].any()                                           # the dQ columns are not this kernel's
+    want_dv = p.transpose(-1, -2) @ d_o
+    want_dk = bf(want_ds).transpose(-1, -2) @ q
+    for name, off, want in (("dK", D, want_dk), ("dV", 2 * D, want_dv)):
+        got = heads(dqkv, off)
+        torch.testing.assert_close(got, want, atol=2e-2 * want.abs().max().item(), rtol=2e-2, msg=lambda m, n=name: f"{n}: {m}")
