@@ -92,7 +92,8 @@ class _DecodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, heat, ds, temperature, frame_map):
         require_device(heat)
-        heat = heat.contiguous()
+        ctx.in_dtype = heat.dtype
+        heat = heat.to(torch.float32).contiguous()
         b, k, h, w = heat.shape
         tables, keep = _device_tables(h, w, ds, heat.device)
         kp_aug = torch.empty(b, k, 2, device=heat.device, dtype=torch.float32)
@@ -117,7 +118,7 @@ class _DecodeFn(torch.autograd.Function):
         g_heat = torch.empty_like(heat)
         check(_lib.lib().lp_decode_bwd(_p(heat), b, k, h, w, ds, temperature, C.byref(tables), C.byref(frame_map.struct),
                                        _p(stats), _p(ga), _p(gf), _p(g_heat), 0, _stream()), "lp_decode_bwd")
-        return g_heat, None, None, None
+        return g_heat.to(ctx.in_dtype), None, None, None
 
 
 class _FrameMapFn(torch.autograd.Function):
@@ -173,7 +174,8 @@ class _HeatmapLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, targ, pred, kind):
         require_device(targ, pred)
-        targ, pred = _f32c(targ), pred.contiguous()
+        ctx.in_dtype = pred.dtype
+        targ, pred = _f32c(targ), _f32c(pred)
         b, k, h, w = pred.shape
         ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(b, k), device=pred.device, dtype=torch.uint8)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
@@ -190,7 +192,7 @@ class _HeatmapLossFn(torch.autograd.Function):
         go = _f32c(gout).reshape(1)
         check(_lib.lib().lp_heatmap_loss_bwd(ctx.kind, _p(targ), _p(pred), b, k, h, w, _p(ws), _p(go), _p(g), 0, _stream()),
               "lp_heatmap_loss_bwd")
-        return None, g, None
+        return None, g.to(ctx.in_dtype), None
 
 
 def heatmap_mse(targets: torch.Tensor, predictions: torch.Tensor) -> torch.Tensor:
@@ -209,7 +211,8 @@ class _UnimodalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kp_aug, pred, conf, img_h, img_w, sigma, thr):
         require_device(kp_aug, pred, conf)
-        kp, pred, conf = _f32c(kp_aug), pred.contiguous(), _f32c(conf)
+        ctx.in_dtype = pred.dtype
+        kp, pred, conf = _f32c(kp_aug), _f32c(pred), _f32c(conf)
         s, k, h, w = pred.shape
         ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(s, k), device=pred.device, dtype=torch.uint8)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
@@ -228,7 +231,7 @@ class _UnimodalFn(torch.autograd.Function):
         go = _f32c(gout).reshape(1)
         check(_lib.lib().lp_unimodal_mse_bwd(_p(kp), _p(pred), s, k, img_h, img_w, h, w, sigma, _p(ws), _p(go), _p(g), 0,
                                              _stream()), "lp_unimodal_mse_bwd")
-        return None, g, None, None, None, None, None
+        return None, g.to(ctx.in_dtype), None, None, None, None, None
 
 
 def unimodal_mse(keypoints_pred_augmented: torch.Tensor, heatmaps_pred: torch.Tensor, confidences: torch.Tensor,
@@ -278,6 +281,10 @@ def pca_loss(keypoints: torch.Tensor, index: torch.Tensor, mean: torch.Tensor, k
     """keypoints (S, 2K); index (rows, points) int32 keypoint ids per PCA sample -> scalar (losses/losses.py:548-573)."""
     require_device(keypoints, index, mean, kept_eigenvectors)
     kp = _f32c(keypoints)
+    # raw pointers go to the kernel: every operand must be dense row-major fp32 / int32 (a transposed view of the eigenvector matrix,
+    # for instance, keeps its strides through .to(device))
+    mean, kept_eigenvectors = _f32c(mean), _f32c(kept_eigenvectors)
+    index = index.to(torch.int32).contiguous()
     s, k = kp.shape[0], kp.shape[1] // 2
     rows, pts = index.shape
     loss = torch.empty(1, device=kp.device, dtype=torch.float32)
