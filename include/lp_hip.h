@@ -297,6 +297,9 @@ int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x_out, const
 /* dx_acc += LayerNorm backward of dy (bf16, same row mapping as y);  dgamma_acc / dbeta_acc accumulate too */
 int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
                      int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
+/* same, and the updated dx_acc is also written rounded to bf16 (what the next Linear layer's backward reads) */
+int lp_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                          int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
 int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream);                       /* exact (erf) GELU */
 int lp_gelu_bwd(const void* x_bf16, const void* dy_bf16, size_t n, void* dx_bf16, lp_stream_t stream);
 /* in place: s[r][:n] = softmax(scale * s[r][:n]), s[r][n:ld] = 0   /   dp <- scale * p * (dp - sum(dp * p)) */

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "lp_small_matmul": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "lp_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P]),
     "lp_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "lp_layernorm_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "lp_gelu_fwd": (_I, [_P, _Z, _P, _P]),
     "lp_gelu_bwd": (_I, [_P, _P, _Z, _P, _P]),
     "lp_softmax_rows_fwd": (_I, [_P, _I, _I, _I, _F, _P]),

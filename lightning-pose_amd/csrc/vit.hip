@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int M, int D, int drop_T,
-                                                            float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            float* __restrict__ dx, unsigned short* __restrict__ dx_bf16,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float red[2][4][256];  // [gamma|beta][wave][column of the current pass]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pieces = D >> 2;
@@ -245,6 +245,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rs * (g[p][e] - s1 - xh[p][e] * s2);
                 *dst = o;
+                if (dx_bf16 != nullptr) {  // the updated residual-stream gradient as the next GEMM's operand (saves a cast pass)
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                    const u32x2_t w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(dx_bf16 + (size_t)row * D + pc * 4) = w;
+                }
             }
         }
     }
@@ -530,16 +535,28 @@ extern "C" int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x
     return launch_status();
 }
 
-extern "C" int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
-                                int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
+static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                              int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy_bf16 && x && mean && rstd && gamma && dx_acc && dgamma_acc && dbeta_acc && M > 0 && D > 0 && drop_T >= 0);
     if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;  // 8 waves per SIMD; also bounds the d gamma / d beta atomics per column
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, rstd,
-                       gamma, M, D, drop_T, dx_acc, dgamma_acc, dbeta_acc);
+                       gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc);
     return launch_status();
+}
+
+extern "C" int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                                int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
+    return layernorm_bwd_impl(dy_bf16, x, mean, rstd, gamma, M, D, drop_T, dx_acc, nullptr, dgamma_acc, dbeta_acc, stream);
+}
+
+// same, and the updated dx_acc also leaves rounded to bf16 (the operand of the next Linear layer's backward)
+extern "C" int lp_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                                     int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
+    LP_REQUIRE(dx_bf16);
+    return layernorm_bwd_impl(dy_bf16, x, mean, rstd, gamma, M, D, drop_T, dx_acc, dx_bf16, dgamma_acc, dbeta_acc, stream);
 }
 
 extern "C" int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream) {

@@ -267,9 +267,16 @@ class ViTEngine(Engine):
                                          _p(mean), _p(rstd), ops._stream()), "lp_layernorm_fwd")
         return y, mean, rstd, (xo if xo is not None else x)
 
-    def _ln_bwd(self, dy, x, mean, rstd, l: LNP, M: int, dx, drop_T: int = 0):
-        check(self._lib.lp_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(self.P[l.g_off:]), M, self.plan.D, drop_T, _p(dx),
-                                         _p(self.G[l.g_off:]), _p(self.G[l.b_off:]), ops._stream()), "lp_layernorm_bwd")
+    def _ln_bwd(self, dy, x, mean, rstd, l: LNP, M: int, dx, drop_T: int = 0, want_bf16: bool = False):
+        """dx (fp32, the residual stream's gradient) += LayerNorm backward of dy; ``want_bf16``: also return the updated dx in bf16"""
+        if not want_bf16:
+            check(self._lib.lp_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(self.P[l.g_off:]), M, self.plan.D, drop_T, _p(dx),
+                                             _p(self.G[l.g_off:]), _p(self.G[l.b_off:]), ops._stream()), "lp_layernorm_bwd")
+            return None
+        out = torch.empty(M, self.plan.D, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_layernorm_bwd_bf16(_p(dy), _p(x), _p(mean), _p(rstd), _p(self.P[l.g_off:]), M, self.plan.D, drop_T, _p(dx), _p(out),
+                                              _p(self.G[l.g_off:]), _p(self.G[l.b_off:]), ops._stream()), "lp_layernorm_bwd_bf16")
+        return out
 
     def _transpose(self, src_ptr, R, Cc, ldi, in_b, in_h, out, ldo, out_b, out_h, nb, nh):
         check(self._lib.lp_transpose_batched(src_ptr, R, Cc, ldi, in_b, in_h, _p(out), ldo, out_b, out_h, nb, nh, ops._stream()),
@@ -356,12 +363,8 @@ class ViTEngine(Engine):
 
         d_feat = self._head_backward(T, B, g_heat)                      # (B, gh, gw, D) bf16
         dx = torch.zeros(M, D, device=dev, dtype=torch.float32)         # gradient of the residual stream
-        self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn)
-
-        def as_bf16(t32: torch.Tensor) -> torch.Tensor:
-            o = torch.empty(t32.shape, device=dev, dtype=torch.bfloat16)
-            check(self._lib.lp_cast_bf16(_p(t32), t32.numel(), _p(o), ops._stream()), "lp_cast_bf16")
-            return o
+        # every LayerNorm backward also leaves the updated stream gradient in bf16: it is the operand of the next Linear backward
+        dx16 = self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn, want_bf16=True)
 
         for i in range(pl.depth - 1, -1, -1):
             L = pl.layers[i]
@@ -369,14 +372,14 @@ class ViTEngine(Engine):
             if trace is not None:
                 trace[f"l{i}.dout"] = dx.clone()
             # ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            dmlp = as_bf16(dx)
+            dmlp = dx16
             d_a1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M)
             d_h1 = torch.empty_like(d_a1)
             check(self._lib.lp_gelu_bwd(_p(t("h1")), _p(d_a1), d_a1.numel(), _p(d_h1), ops._stream()), "lp_gelu_bwd")
             d_y2 = self._linear_bwd(L["fc1"], t("y2"), d_h1, M)
-            self._ln_bwd(d_y2, t("x_mid"), t("m2"), t("r2"), L["ln2"], M, dx)
+            dx16 = self._ln_bwd(d_y2, t("x_mid"), t("m2"), t("r2"), L["ln2"], M, dx, want_bf16=True)
             # ---- attention branch: x_mid = x_in + proj(softmax(Q K^T / 8) V)
-            dproj = as_bf16(dx)
+            dproj = dx16
             d_attn = self._linear_bwd(L["proj"], t("attn"), dproj, M)
             qkv, Pm = t("qkv"), t("P")
             dqkv = torch.empty(M, qs, device=dev, dtype=torch.bfloat16)
@@ -396,7 +399,7 @@ class ViTEngine(Engine):
             if trace is not None:
                 trace[f"l{i}.dqkv"] = dqkv
             d_y1 = self._linear_bwd(L["qkv"], t("y1"), dqkv, M)
-            self._ln_bwd(d_y1, t("x_in"), t("m1"), t("r1"), L["ln1"], M, dx)
+            dx16 = self._ln_bwd(d_y1, t("x_in"), t("m1"), t("r1"), L["ln1"], M, dx, want_bf16=i > 0)
         if trace is not None:
             trace["tokens.dx"] = dx
         # ---- embeddings

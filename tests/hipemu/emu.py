@@ -523,11 +523,15 @@ def layernorm_fwd(x, gamma, beta, eps, delta_bits=None, drop_T=0):
     return y.np(), mean.np(), rstd.np(), (xo.np() if xo is not None else None)
 
 
-def layernorm_bwd(dy_bits, x, mean, rstd, gamma, dx0, drop_T=0):
+def layernorm_bwd(dy_bits, x, mean, rstd, gamma, dx0, drop_T=0, want_bf16=False):
     x = f32(x)
     m, d = x.shape
     db, xb, mb, rb, gb = Buf(dy_bits), Buf(x), Buf(f32(mean)), Buf(f32(rstd)), Buf(f32(gamma))
     dx, dg, dbeta = Buf(f32(dx0)), Z(d), Z(d)
+    if want_bf16:  # -> additionally the updated dx rounded to bf16
+        d16 = Z((m, d), np.uint16)
+        ok(lib().lp_layernorm_bwd_bf16(db.p, xb.p, mb.p, rb.p, gb.p, m, d, drop_T, dx.p, d16.p, dg.p, dbeta.p, stream()))
+        return dx.np(), dg.np(), dbeta.np(), d16.np()
     ok(lib().lp_layernorm_bwd(db.p, xb.p, mb.p, rb.p, gb.p, m, d, drop_T, dx.p, dg.p, dbeta.p, stream()))
     return dx.np(), dg.np(), dbeta.np()
 

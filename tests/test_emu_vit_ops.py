@@ -68,6 +68,10 @@ def test_layernorm_fwd_bwd(M, D, drop_T):
     torch.testing.assert_close(torch.from_numpy(dx), dx0 + xs.grad, atol=2e-4, rtol=2e-4)
     torch.testing.assert_close(torch.from_numpy(dg), gamma_r.grad, atol=2e-3, rtol=2e-4)
     torch.testing.assert_close(torch.from_numpy(db), beta_r.grad, atol=2e-3, rtol=2e-4)
+    # the variant that also leaves the updated stream gradient in bf16 (the next Linear backward's operand)
+    dx2, dg2, db2, d16 = emu.layernorm_bwd(bits(dy), xs.detach().numpy(), mean, rstd, gamma.numpy(), dx0.numpy(), drop_T=drop_T, want_bf16=True)
+    assert np.array_equal(dx2, dx)
+    torch.testing.assert_close(unbits(d16), bf(torch.from_numpy(dx)), atol=0, rtol=0)
 
 
 def test_gelu_fwd_bwd():
