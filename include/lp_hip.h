@@ -118,7 +118,8 @@ int lp_unimodal_mse_bwd(const float* kp_aug, const float* pred, int S, int K, in
 /* models/heads/heatmap.py:209-211 spatial_softmax2d(T=1).  Input element (b,k,i) at in[b*sb + i*si + k*sk]. */
 int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, long stride_k, int B, int K, int n, float* out,
                      lp_stream_t stream);
-/* gin_bf16: bf16 gradient of the logits in the same strided layout (it feeds the MFMA kernels) */
+/* gin_bf16: bf16 gradient of the logits in the same strided layout (it feeds the MFMA kernels).  Pixel-major rows (stride_k == 1,
+ * stride_i % 8 == 0) are written whole: the pad channels [K, stride_i) of every pixel come out as zeros. */
 int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, void* gin_bf16, long stride_b, long stride_i,
                      long stride_k, lp_stream_t stream);
 

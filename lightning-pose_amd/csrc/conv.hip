@@ -1005,7 +1005,11 @@ static int igemm_max_wgs() {
     static int v = [] {
         const char* e = getenv("LP_CONV_MAX_WGS");
         const int n = e ? atoi(e) : 0;
-        return n > 0 ? n : 512;
+        if (n > 0) return n;
+        int dev = 0, cus = 0;  // 2 workgroups per CU are resident (LDS-bound): 512 on a full MI355X, fewer on a partition
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return 2 * cus;
     }();
     return v;
 }

@@ -288,6 +288,52 @@ __global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < n; i += 256) dst[(size_t)i * si] = f32_to_bf16(p[i] * (g[i] - dot));
 }
 
+// Same backward for pixel-major gradients (sk == 1, channel pitch si a multiple of 8): one 1024-lane workgroup per frame.  Pass 1
+// keeps the K dots sum_i p g per lane (coalesced reads of every map), merged through LDS; pass 2 writes each pixel's WHOLE channel
+// row - the K gradients and zeros in the pad channels - as 16-B pieces, so the caller needs no zero fill and no 2-byte strided stores.
+__global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, int K,
+                                                                      int n, unsigned short* __restrict__ gin, long sb, long si) {
+    __shared__ float red[16][kSmK], fin[kSmK];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = prob + (size_t)b * K * n;
+    const float* g = gprob + (size_t)b * K * n;
+    float dot[kSmK];
+#pragma unroll
+    for (int k = 0; k < kSmK; ++k) dot[k] = 0.f;
+    for (int i = tid; i < n; i += 1024) {
+#pragma unroll
+        for (int k = 0; k < kSmK; ++k)
+            if (k < K) dot[k] = fmaf(p[(size_t)k * n + i], g[(size_t)k * n + i], dot[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kSmK; ++k) {
+        if (k < K) {
+            const float d = wave_sum(dot[k]);
+            if (lane == 0) red[wave][k] = d;
+        }
+    }
+    __syncthreads();
+    if (tid < K) {
+        float d = 0.f;
+        for (int w = 0; w < 16; ++w) d += red[w][tid];
+        fin[tid] = d;
+    }
+    __syncthreads();
+    unsigned short* dst = gin + (size_t)b * sb;
+    const int chunks = (int)(si >> 3);
+    for (int i = tid; i < n; i += 1024) {
+        for (int c = 0; c < chunks; ++c) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = c * 8 + e;
+                o[e] = k < K ? p[(size_t)k * n + i] * (g[(size_t)k * n + i] - fin[k]) : 0.f;
+            }
+            *reinterpret_cast<u16x8*>(dst + (size_t)i * si + c * 8) = pack_bf16x8(o);
+        }
+    }
+}
+
 static GaussSpec make_spec(int img_h, int img_w, int h, int w, float sigma) {
     GaussSpec g;
     g.sx = (float)w / (float)img_w;
@@ -401,7 +447,12 @@ extern "C" int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, in
     using namespace lp;
     LP_REQUIRE(prob && gprob && gin_bf16 && B >= 0 && K > 0 && n > 0);
     if (B == 0) return LP_OK;
-    hipLaunchKernelGGL(softmax2d_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, prob, gprob, K, n, (unsigned short*)gin_bf16,
-                       stride_b, stride_i, stride_k);
+    // pixel-major gradient rows (the head's layout): whole channel rows per pixel, pad channels [K, stride_i) written as zeros
+    if (stride_k == 1 && K <= kSmK && stride_i % 8 == 0 && stride_i >= K && stride_b % 8 == 0 && ((uintptr_t)gin_bf16 & 15) == 0)
+        hipLaunchKernelGGL(softmax2d_bwd_pixmajor_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, prob, gprob, K, n,
+                           (unsigned short*)gin_bf16, stride_b, stride_i);
+    else
+        hipLaunchKernelGGL(softmax2d_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, prob, gprob, K, n, (unsigned short*)gin_bf16,
+                           stride_b, stride_i, stride_k);
     return launch_status();
 }

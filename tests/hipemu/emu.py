@@ -193,7 +193,8 @@ def softmax2d(logits_nhwc, K):
 def softmax2d_bwd(prob, gprob, Cn):
     prob, gprob = f32(prob), f32(gprob)
     b, k, n = prob.shape
-    pb, gb, gin = Buf(prob), Buf(gprob), Z((b, n, Cn), np.uint16)
+    fill = 0x7fc0 if Cn % 8 == 0 else 0  # (bf16 NaN bits where the pixel-major kernel owns the whole row)
+    pb, gb, gin = Buf(prob), Buf(gprob), Buf(np.full((b, n, Cn), fill, np.uint16))
     ok(lib().lp_softmax2d_bwd(pb.p, gb.p, b, k, n, gin.p, n * Cn, Cn, 1, stream()))
     return from_bf16_bits(gin.np()).numpy()
 

@@ -65,9 +65,11 @@ def test_unimodal_mse_matches_oracle():
     assert loss0 == 0.0 and not grad0.any()
 
 
-def test_softmax2d_fwd_bwd():
+@pytest.mark.parametrize("b,k,n,c", [(2, 5, 48, 8), (2, 17, 2300, 64), (1, 5, 70, 6)])
+def test_softmax2d_fwd_bwd(b, k, n, c):
+    """forward + backward; c % 8 == 0 takes the pixel-major backward (whole channel rows, pad channels zeroed by the kernel: the output
+    buffer is pre-filled with garbage to prove it), c = 6 the per-map fallback (pad channels untouched: pre-filled with zeros)"""
     gen = torch.Generator().manual_seed(12)
-    b, k, n, c = 2, 5, 48, 8
     logits = torch.randn(b, n, c, generator=gen)
     x = logits[:, :, :k].permute(0, 2, 1).clone().requires_grad_(True)  # (b,k,n)
     p = torch.softmax(x, -1)
