@@ -108,3 +108,27 @@ def test_checkpoint_interchange_with_reference_layout(stack_backend, tmp_path):
     ck.load_weights(five, path)
     assert torch.equal(five.state_dict()["backbone.7.2.conv3.weight"].cpu(), a["backbone.7.2.conv3.weight"].cpu())
     assert torch.equal(five.state_dict()["head.upsampling_layers.2.weight"].cpu(), head_before)
+
+
+def test_checkpoint_semi_supervised_vit_round_trip(stack_backend, tmp_path):
+    """the same interchange for the ViT tracker and the semi-supervised class: hyper-parameters (backbone, image_size, ...) rebuild the
+    model, loss factories come back in through the overrides, HF parameter names survive the trip"""
+    dev = stack_backend
+    from lightning_pose_amd import checkpoint as ck
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+
+    sup = LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    unsup = LossFactory({"temporal": {"log_weight": 5.0, "epsilon": 5.0}}, None)
+    model = SemiSupervisedHeatmapTracker(num_keypoints=2, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="vits_dino",
+                                         pretrained=False, torch_seed=1, image_size=64, device=dev)
+    assert model.hparams["backbone"] == "vits_dino" and model.hparams["image_size"] == 64
+    path = ck.save_checkpoint(model, str(tmp_path / "vit.ckpt"), optimizer=model.configure_optimizers()["optimizer"])
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert any(k.startswith("backbone.vision_encoder.") for k in raw["state_dict"]) and "lp_amd_optimizer_state" in raw
+    again = ck.load_model_from_checkpoint(path, loss_factory=sup, loss_factory_unsupervised=unsup, device=dev)
+    assert type(again) is SemiSupervisedHeatmapTracker and again.loss_factory_unsup is unsup
+    a, b = model.state_dict(), again.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
+    with pytest.raises(ValueError):
+        ck.load_model_from_checkpoint(None)
