@@ -100,12 +100,15 @@ class HeatmapTracker(BaseSupervisedTracker):
             if pretrained:
                 if checkpoint is None:
                     raise RuntimeError("pretrained=True needs ImageNet weights, which cannot be downloaded here; pass "
-                                       "backbone_checkpoint=<state_dict file with torchvision resnet50 keys> or pretrained=False")
+                                       "backbone_checkpoint=<state_dict file with torchvision resnet50 keys, or the mmpose checkpoint of "
+                                       "the resnet50_animal_* / resnet50_human_* variants> or pretrained=False")
                 tv = torch.load(checkpoint, map_location="cpu")
                 tv = tv.get("state_dict", tv)
                 names = {"conv1": "backbone.0", "bn1": "backbone.1", "layer1": "backbone.4", "layer2": "backbone.5",
                          "layer3": "backbone.6", "layer4": "backbone.7"}
                 for k, v in tv.items():
+                    if k.startswith("backbone."):  # mmpose checkpoints (resnet50_animal_* / resnet50_human_*, reference :262-266)
+                        k = k[len("backbone."):]
                     top, _, rest = k.partition(".")
                     if top in names and f"{names[top]}.{rest}" in init:
                         init[f"{names[top]}.{rest}"] = v

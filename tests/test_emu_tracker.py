@@ -132,3 +132,34 @@ def test_checkpoint_semi_supervised_vit_round_trip(stack_backend, tmp_path):
     assert set(a) == set(b) and all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
     with pytest.raises(ValueError):
         ck.load_model_from_checkpoint(None)
+
+
+def test_reference_default_backbone_name_and_mmpose_checkpoint(stack_backend, tmp_path):
+    """the reference's shipped default is backbone='resnet50_animal_ap10k' (config_default.yaml:121): same ResNet-50, weights from an
+    mmpose checkpoint whose keys carry a 'backbone.' prefix (models/backbones/factory.py:253-266) - offline, that file is handed in
+    as backbone_checkpoint"""
+    dev = stack_backend
+    from lightning_pose_amd.models import HeatmapTracker
+    from lightning_pose_amd.models.backbones.factory import backbone_features
+
+    assert backbone_features("resnet50_animal_ap10k") == 2048
+    with pytest.raises(ValueError):
+        backbone_features("resnet51")
+    with pytest.raises(RuntimeError):  # pretrained weights cannot be downloaded here: fail loudly, never fall back to random init
+        HeatmapTracker(num_keypoints=3, backbone="resnet50_animal_ap10k", pretrained=True, device=dev)
+    ref = O.OracleTracker(3, 2, torch_seed=11).state_dict()
+    tv_names = {"backbone.0": "conv1", "backbone.1": "bn1", "backbone.4": "layer1", "backbone.5": "layer2", "backbone.6": "layer3",
+                "backbone.7": "layer4"}
+    mm = {}
+    for k, v in ref.items():
+        for ours, tv in tv_names.items():
+            if k.startswith(ours + "."):
+                mm["backbone." + tv + k[len(ours):]] = v.clone()
+    mm["keypoint_head.final_layer.weight"] = torch.zeros(3, 2048, 1, 1)  # mmpose heads are ignored
+    torch.save({"state_dict": mm, "meta": {}}, str(tmp_path / "res50_ap10k.pth"))
+    model = HeatmapTracker(num_keypoints=3, backbone="resnet50_animal_ap10k", pretrained=True, torch_seed=5,
+                           backbone_checkpoint=str(tmp_path / "res50_ap10k.pth"), device=dev)
+    sd = model.state_dict()
+    for k in ("backbone.0.weight", "backbone.4.0.conv1.weight", "backbone.7.2.bn3.running_var", "backbone.6.3.conv2.weight"):
+        assert torch.equal(sd[k].cpu().contiguous(), ref[k]), k
+    assert not torch.equal(sd["head.upsampling_layers.2.weight"].cpu(), ref["head.upsampling_layers.2.weight"])  # own seed (5 vs 11)
