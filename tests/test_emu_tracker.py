@@ -163,3 +163,43 @@ def test_reference_default_backbone_name_and_mmpose_checkpoint(stack_backend, tm
     for k in ("backbone.0.weight", "backbone.4.0.conv1.weight", "backbone.7.2.bn3.running_var", "backbone.6.3.conv2.weight"):
         assert torch.equal(sd[k].cpu().contiguous(), ref[k]), k
     assert not torch.equal(sd["head.upsampling_layers.2.weight"].cpu(), ref["head.upsampling_layers.2.weight"])  # own seed (5 vs 11)
+
+
+def test_reference_default_config_drives_the_registry(stack_backend, monkeypatch):
+    """scripts/configs/config_default.yaml of the reference (read here when /root/reference is present, else its relevant keys restated)
+    goes through get_loss_factories / get_model unchanged: backbone 'resnet50_animal_ap10k', heatmap_loss_type 'mse', the `losses`
+    hyper-parameter block, losses_to_use switching the semi-supervised class on."""
+    import os
+
+    import yaml
+
+    from lightning_pose_amd.losses.factory import get_loss_factories
+    from lightning_pose_amd.models import HeatmapTracker, SemiSupervisedHeatmapTracker, heatmap_tracker
+    from lightning_pose_amd.models.factory import get_model
+
+    dev = stack_backend
+    monkeypatch.setattr(heatmap_tracker, "_default_device", lambda: dev)
+    path = "/root/reference/scripts/configs/config_default.yaml"
+    if os.path.exists(path):
+        cfg = yaml.safe_load(open(path))
+    else:
+        cfg = {"data": {"mirrored_column_matches": None, "columns_for_singleview_pca": None},
+               "training": {"rng_seed_model_pt": 0, "optimizer": "Adam", "optimizer_params": {"learning_rate": 1e-3},
+                            "lr_scheduler": "multisteplr", "lr_scheduler_params": {"multisteplr": {"milestones": [150, 200, 250], "gamma": 0.5}}},
+               "model": {"losses_to_use": [], "backbone": "resnet50_animal_ap10k", "model_type": "heatmap", "heatmap_loss_type": "mse",
+                         "checkpoint": None},
+               "losses": {"temporal": {"log_weight": 11.0, "epsilon": 20.0, "prob_threshold": 0.05}}}
+    assert cfg["model"]["backbone"] == "resnet50_animal_ap10k"
+    cfg["data"].update(image_resize_dims={"height": 128, "width": 128}, num_keypoints=3, keypoint_names=["a", "b", "c"])
+    cfg["model"]["backbone_pretrained"] = False  # (the default True needs the mmpose weights: see the checkpoint test above)
+    factories = get_loss_factories(cfg, None)
+    assert list(factories["supervised"].loss_instance_dict) == ["heatmap_mse"] and not factories["unsupervised"].loss_instance_dict
+    model = get_model(cfg, None, factories)
+    assert type(model) is HeatmapTracker and model.backbone_arch == "resnet50_animal_ap10k" and model.downsample_factor == 2
+    opt = model.configure_optimizers()
+    assert opt["monitor"] == "val_supervised_loss" and [g["name"] for g in opt["optimizer"].param_groups] == ["backbone", "head"]
+    cfg["model"]["losses_to_use"] = ["temporal"]
+    factories = get_loss_factories(cfg, None)
+    t = factories["unsupervised"].loss_instance_dict["temporal"]
+    assert float(t.epsilon) == 20.0 and float(t.prob_threshold) == pytest.approx(0.05) and float(t.weight) == pytest.approx(0.5 / np.exp(11.0))
+    assert type(get_model(cfg, None, factories)) is SemiSupervisedHeatmapTracker
