@@ -337,3 +337,70 @@ def test_subpixmaxima_known_answers(dev):
     assert torch.allclose(c100.cpu(), torch.ones(1, 2), rtol=1e-3) and (c100.cpu() != 1.0).all()
     k10, _, c10 = ops.decode(maps.to(dev), 2, 10.0, ops.DecodeFrameMap(None, False, None, 1, 1, 1, 2))
     assert (k10.reshape(-1).cpu()[2:] != 16.0).all() and (c10.cpu() < 0.5).all()
+
+
+# --------------------------------------------------------------------------------------------------------------- utils/test_pca.py
+def test_pca_helper_classes_reference_cases():
+    """TestEmpiricalEpsilon, TestComponentChooser, TestFormatMultiviewDataForPca, test_convert_dict_values_to_tensors and TestNaNPCA
+    (host-side fit helpers of the PCA loss; scikit-learn's own PCA on the diabetes data is the yardstick, as in the reference)"""
+    from sklearn.datasets import load_diabetes
+    from sklearn.decomposition import PCA
+
+    from lightning_pose_amd.utils.pca import (ComponentChooser, EmpiricalEpsilon, NaNPCA, convert_dict_values_to_tensors,
+                                              format_multiview_data_for_pca)
+
+    ramp = np.arange(101, dtype="float")
+    assert EmpiricalEpsilon(percentile=90)(ramp) == 90 and EmpiricalEpsilon(percentile=90)(torch.tensor(ramp)) == 90
+    holes = ramp.copy()
+    holes[1::2] = np.nan
+    assert EmpiricalEpsilon(percentile=90)(holes) == 90
+
+    data = load_diabetes().data
+    skl = PCA(svd_solver="full").fit(data)
+    assert ComponentChooser(skl, 4)() == 4 and ComponentChooser(skl, 2)() < ComponentChooser(skl, 3)()
+    with pytest.raises(ValueError):
+        ComponentChooser(skl, 11)          # only 10 observation dimensions
+    n95 = ComponentChooser(skl, 0.95)()
+    assert 0 < n95 <= 10 and ComponentChooser(skl, 1.0)() == 10 and ComponentChooser(skl, 0.20)() < ComponentChooser(skl, 0.90)()
+    for bad in (1.04, -0.2):
+        with pytest.raises(ValueError):
+            ComponentChooser(skl, bad)
+
+    kp = torch.rand(12, 20, 2)
+    for matches in ([[0, 1, 2, 3], [4, 5, 6, 7]], [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]):
+        arr = format_multiview_data_for_pca(kp, matches)
+        assert arr.shape == torch.Size([12 * 4, 2 * len(matches)])
+    with pytest.raises(AssertionError):
+        format_multiview_data_for_pca(kp, [[0, 1, 2, 3], [4, 5, 6]])
+    conv = convert_dict_values_to_tensors({"a": 4.0, "b": 10.1, "c": 4}, device="cpu")
+    assert all(isinstance(v, torch.Tensor) and v.dtype == torch.float32 for v in conv.values())
+
+    # NaNPCA == sklearn on complete data ...
+    mine = NaNPCA().fit(data)
+    z = mine.transform(data)
+    assert data.shape == (442, 10) and skl.noise_variance_ == mine.noise_variance_ and skl.n_samples_ == mine.n_samples_
+    assert skl.n_components_ == mine.n_components_
+    for attr in ("components_", "explained_variance_", "explained_variance_ratio_", "singular_values_"):
+        assert np.allclose(getattr(skl, attr), getattr(mine, attr), rtol=1e-10), attr
+    assert np.allclose(skl.transform(data), z, rtol=1e-10)
+    # ... and degrades gracefully with missing entries: one NaN, a staircase of NaNs, a fully missing row
+    one = data.copy()
+    one[0, 0] = np.nan
+    p1 = NaNPCA().fit(one)
+    big = np.abs(mine.components_) > 0.05
+    assert not np.allclose(mine.components_[big], p1.components_[big], rtol=1e-10)
+    assert np.allclose(mine.components_[big], p1.components_[big], rtol=1e-1)
+    for attr in ("explained_variance_", "explained_variance_ratio_", "singular_values_"):
+        assert not np.allclose(getattr(mine, attr), getattr(p1, attr), rtol=1e-10) and np.allclose(getattr(mine, attr), getattr(p1, attr), rtol=1e-2)
+    assert np.allclose(z[1:], p1.transform(one)[1:], atol=1e-2)
+    rows, cols = list(range(13)), [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 8, 7, 6]
+    many = data.copy()
+    many[rows, cols] = np.nan
+    p2 = NaNPCA().fit(many)
+    assert np.allclose(p1.explained_variance_[:7], p2.explained_variance_[:7], rtol=1e-2)
+    assert np.allclose(p1.singular_values_[:7], p2.singular_values_[:7], rtol=1e-2)
+    assert np.allclose(z[13:], p2.transform(many)[13:], atol=1e-2)
+    gone = data.copy()
+    gone[0, :] = np.nan
+    zg = NaNPCA().fit(gone).transform(gone)
+    assert np.allclose(z[1:], zg[1:], atol=1e-2) and np.all(zg[0] == 0)
