@@ -175,6 +175,18 @@ class KeypointPCA:
         cols = self.columns_for_singleview_pca if self.columns_for_singleview_pca is not None else list(range(num_keypoints))
         return np.asarray(cols, dtype=np.int32).reshape(1, -1)
 
+    # -- diagnostics (the training loss itself is lp_pca_fwd_bwd; these serve metrics / inspection, reference :266-309) ---------
+    def reproject(self, data_arr: torch.Tensor) -> torch.Tensor:
+        """(N, obs) formatted samples -> their projection onto the kept subspace, back in observation space"""
+        evecs, mean = self.parameters["kept_eigenvectors"], self.parameters["mean"].unsqueeze(0)
+        assert data_arr.shape[1] == evecs.shape[1] == mean.shape[1] and data_arr.shape[1] % 2 == 0
+        return ((data_arr - mean) @ evecs.T) @ evecs + mean
+
+    def compute_reprojection_error(self, data_arr: torch.Tensor) -> torch.Tensor:
+        """(N, obs) -> (N, obs / 2): Euclidean distance of every 2-D keypoint to its reprojection"""
+        diff = data_arr - self.reproject(data_arr)
+        return torch.linalg.norm(diff.reshape(diff.shape[0], diff.shape[1] // 2, 2), dim=2)
+
     # -- fit ----------------------------------------------------------------------------------------------------
     def __call__(self) -> None:
         x = self._format_data(self._get_data())

@@ -150,6 +150,13 @@ def test_pca_loss_constructor_errors_and_subspace(dev):
     # (exactly 0 in the reference's CPU test; the device contracts the two skinny products with fused multiply-adds)
     assert float(loss) == pytest.approx(0.0, abs=2e-5), float(loss)
     assert logs[0]["name"] == f"{STAGE}_pca_multiview_loss"
+    # the diagnostic helpers of KeypointPCA (reproject / compute_reprojection_error) describe the same quantity the kernel reduces:
+    # loss = mean(relu(error - epsilon)) over (sample, keypoint)
+    rand = (torch.randn(10, 4, generator=torch.Generator().manual_seed(8)) * 5).to(dev)
+    err = fn.pca.compute_reprojection_error(rand)
+    assert err.shape == (10, 2) and torch.allclose(fn.pca.reproject(fn.pca.reproject(rand)), fn.pca.reproject(rand), atol=1e-5)
+    fn.epsilon = torch.tensor(0.5)
+    assert float(fn(rand, stage=STAGE)[0]) == pytest.approx(float(torch.relu(err - 0.5).mean()), rel=1e-4, abs=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------- losses/test_factory.py
