@@ -115,3 +115,41 @@ def test_fused_stem_pool_ragged(B, H, W, C):
     torch.testing.assert_close(unbits(dz1), unbits(dz0), atol=3e-2, rtol=3e-2)
     np.testing.assert_allclose(dg1, dg0, atol=5e-2, rtol=1e-2)
     np.testing.assert_allclose(db1, db0, atol=5e-2, rtol=1e-2)
+
+
+CONV = _cases(5, 8, lambda r: (int(r.integers(1, 4)), int(r.integers(3, 15)), int(r.integers(3, 15)), 64 * int(r.integers(1, 4)),
+                               64 * int(r.integers(1, 4)), int(r.choice([1, 3])), int(r.choice([1, 2]))))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,R,st", CONV)
+def test_fused_conv_bn_paths_ragged(B, H, W, Ci, Co, R, st):
+    """forward with the next BatchNorm's [sum, sum^2] from the store pass, and the data gradient with addend + ReLU gate recomputed from
+    z + the BatchNorm-backward reductions, on random geometries (partial row / column tiles, stride 2 parity classes, 1x1 and 3x3)"""
+    pad = 0 if (st == 2 and R == 1) else R // 2
+    gen = torch.Generator().manual_seed(H * 13 + W * 5 + Ci)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()  # noqa: E731
+    x = bf(torch.randn(B, Ci, H, W, generator=gen)).requires_grad_(True)
+    w = bf(torch.randn(Co, Ci, R, R, generator=gen) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=st, padding=pad)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    g = emu.geom(B, H, W, Ci, Co, R, R, st, pad)
+    zb, sums = emu.conv_fwd_bn(bits(nhwc(x.detach())), bits(w.detach().permute(0, 2, 3, 1)), g)
+    zf = unbits(zb)
+    torch.testing.assert_close(zf, bf(nhwc(y.detach()).reshape(-1, Co)), atol=3e-2, rtol=2e-2)
+    np.testing.assert_allclose(sums[0], zf.sum(0).numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(sums[1], (zf * zf).sum(0).numpy(), rtol=1e-3, atol=1e-2)
+    Mi = B * H * W
+    zin = bf(torch.randn(Mi, Ci, generator=gen))
+    mean, invstd = zin.mean(0), 1 / torch.sqrt(zin.var(0, unbiased=False) + 1e-5)
+    gamma, beta = 1 + 0.1 * torch.randn(Ci, generator=gen), 0.1 * torch.randn(Ci, generator=gen)
+    add = bf(torch.randn(Mi, Ci, generator=gen))
+    dxb, s2, _, _ = emu.conv_dgrad_bn(bits(nhwc(dy)), bits(w.detach().permute(1, 2, 3, 0)), g, bits(zin), mean.numpy(), invstd.numpy(),
+                                      gamma.numpy(), beta.numpy(), addend_bits=bits(add))
+    o = torch.addcmul(beta, zin - mean, invstd * gamma)
+    want = (nhwc(x.grad).reshape(-1, Ci) + add) * (bf(torch.relu(o)) > 0)
+    got = unbits(dxb)
+    sure = o.abs() > 1e-3                                   # (a gate exactly at its threshold may fall either way)
+    torch.testing.assert_close(got[sure], bf(want)[sure], atol=4e-2, rtol=3e-2)
+    np.testing.assert_allclose(s2[0], got.sum(0).numpy(), rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(s2[1], (got * (zin - mean) * invstd).sum(0).numpy(), rtol=2e-3, atol=3e-2)
