@@ -153,3 +153,21 @@ def test_fused_conv_bn_paths_ragged(B, H, W, Ci, Co, R, st):
     torch.testing.assert_close(got[sure], bf(want)[sure], atol=4e-2, rtol=3e-2)
     np.testing.assert_allclose(s2[0], got.sum(0).numpy(), rtol=2e-3, atol=2e-2)
     np.testing.assert_allclose(s2[1], (got * (zin - mean) * invstd).sum(0).numpy(), rtol=2e-3, atol=3e-2)
+
+
+DECODE = _cases(9, 6, lambda r: (int(r.choice([1, 2, 3])), int(r.integers(11, 40)), int(r.integers(11, 70)), int(r.integers(1, 3)),
+                                 int(r.integers(1, 4)), float(r.uniform(1, 6))))
+
+
+@pytest.mark.parametrize("ds,h,w,b,k,sharp", DECODE)
+def test_decode_forward_ragged(ds, h, w, b, k, sharp):
+    """fused decode at odd map sizes (partial row groups / column strips) and every downsample factor against the oracle's
+    upsample -> softmax(T=1000) -> expectation -> 5x5 confidence"""
+    from oracle import restated as O
+
+    g = torch.Generator().manual_seed(h * 100 + w)
+    heat = torch.softmax(sharp * torch.randn(b, k, h * w, generator=g), -1).reshape(b, k, h, w)
+    kp, _, conf, _ = emu.decode_fwd(heat.numpy(), ds)
+    want_kp, want_conf = O.soft_argmax(heat, ds, 1000.0)
+    np.testing.assert_allclose(kp.reshape(b, -1), want_kp.numpy(), atol=2e-3)
+    np.testing.assert_allclose(conf, want_conf.numpy(), atol=5e-5)
