@@ -68,3 +68,116 @@ def test_data_parallel_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _engine_worker(rank, world, port, q):
+    """one rank of 2-rank data-parallel steps of the REAL engine on the emulated kernels: SyncBatchNorm (statistics from the conv store
+    passes, the fused stem, every BatchNorm backward) + bucketed gradient all-reduce, against single-process runs on rank 0.
+
+    A random-init 50-layer BatchNorm network at batch 4 amplifies 1-ulp differences (another summation order is enough) by ~1.5x per
+    block, so "2 ranks x 2 frames == 1 process x 4 frames" can only be checked near the input.  The test therefore has three parts:
+    (A) different frames per rank: the synchronised moments of the stem and the first blocks equal the whole-batch ones and differ
+    from the local ones; (B) the SAME frames on both ranks: sums double and counts double exactly, so every moment, every gradient
+    (x 2) must be BIT-identical to the single-process run - this pins the world-size scaling everywhere; (C) every BatchNorm layer
+    issues exactly one all-reduce per direction."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["HIPEMU_THREADS"] = "1"  # one emulator thread: workgroups (and their fp32 atomics) run in a fixed order, so (B) can be exact
+    import _lp_bootstrap  # noqa: F401
+    from lightning_pose_amd import _lib, ops
+    from lightning_pose_amd.distributed import DataParallel
+    from lightning_pose_amd.engine import Engine
+    from lightning_pose_amd.models.backbones._init import seeded_state_dict
+    from tests.hipemu import emu
+
+    _lib._lib = emu.emu_lib()
+    ops.require_device = lambda *a: None
+    ops.require_device_type = lambda d: None
+    ops._stream = lambda: None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    calls = {"n": 0}
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **k):
+        calls["n"] += 1
+        return real_all_reduce(*a, **k)
+
+    dist.all_reduce = counting_all_reduce
+    K, dev = 3, torch.device("cpu")
+    torch.manual_seed(7)
+    sd = seeded_state_dict(K, 2)
+    gen = torch.Generator().manual_seed(0)
+    images = torch.randn(4, 3, 64, 64, generator=gen)
+    g_heat = torch.randn(4, K, 16, 16, generator=gen)
+
+    def make(sync):
+        e = Engine(K, 2, dev)
+        e.load_state_dict(sd, strict=False)
+        d = DataParallel(e, sync_bn=True) if sync else None
+        if d is not None:
+            d.broadcast_parameters()
+        return e, d
+
+    bad = []
+    # ---- (A) different frames per rank, forward only
+    eng, dp = make(True)
+    _, tape = eng.forward(images[2 * rank:2 * rank + 2], True)
+    if rank == 0:
+        whole, _ = make(False)
+        _, t_whole = whole.forward(images, True)
+        local, _ = make(False)
+        _, t_local = local.forward(images[:2], True)
+        for key in ("stem.mu", "stem.iv", "b0.m1", "b0.v1", "b0.m3", "b0.v3", "b0.md", "b1.m2", "b1.v2", "b2.m1"):
+            if not torch.allclose(tape.t[key], t_whole.t[key], atol=5e-3, rtol=5e-3):
+                bad.append(f"A:{key} != whole batch")
+        if torch.allclose(tape.t["stem.mu"], t_local.t["stem.mu"], atol=1e-4, rtol=1e-3):
+            bad.append("A:stem.mu equals the LOCAL statistics")
+    # ---- (B) + (C) the same frames on both ranks, forward + backward + gradient all-reduce
+    eng, dp = make(True)
+    n_bn = len(eng.plan.bns)
+    calls["n"] = 0
+    _, tape = eng.forward(images[:2], True)
+    n_fwd, calls["n"] = calls["n"], 0
+    eng.zero_grad()
+    eng.backward(tape, g_heat[:2])
+    n_bwd = calls["n"]
+    dp.all_reduce_gradients()
+    dp.wait()
+    if (n_fwd, n_bwd) != (n_bn, n_bn):
+        bad.append(f"C:{n_fwd} forward / {n_bwd} backward all-reduces for {n_bn} BatchNorm layers")
+    if rank == 0:
+        solo, _ = make(False)
+        _, t_solo = solo.forward(images[:2], True)
+        solo.zero_grad()
+        solo.backward(t_solo, g_heat[:2])
+        for key, v in t_solo.t.items():
+            if key.split(".")[-1] in ("mu", "iv", "m1", "v1", "m2", "v2", "m3", "v3", "md", "vd") and not torch.equal(tape.t[key], v):
+                bad.append(f"B:{key} not bit-identical")
+        if not torch.equal(eng.G, 2 * solo.G):
+            bad.append(f"B:summed gradient != 2 x single-process gradient (max diff {float((eng.G - 2 * solo.G).abs().max()):.3e})")
+        sb = eng.plan.stem_bn
+        if not torch.equal(eng.running_view(sb, "running_mean"), solo.running_view(sb, "running_mean")):
+            bad.append("B:stem running_mean")
+        m = 2 * 32 * 32  # stem pixels per rank: unbiased variance uses the GLOBAL count 2m
+        ratio = (eng.running_view(sb, "running_var") - 0.9) / (solo.running_view(sb, "running_var") - 0.9)
+        if not torch.allclose(ratio, torch.full_like(ratio, (2 * m / (2 * m - 1)) / (m / (m - 1))), rtol=1e-4):
+            bad.append("B:stem running_var (global count)")
+    q.put((rank, not bad, "; ".join(bad[:6])))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_engine_gloo_world2():
+    """SyncBatchNorm + summed gradients of the real engine across 2 gloo ranks (see _engine_worker)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True, ""), (1, True, "")], res
