@@ -17,3 +17,10 @@ def undo_affine_transform_batch(keypoints_augmented: torch.Tensor, transforms: t
     views = transforms.shape[0] if is_multiview else 1
     fm = ops.DecodeFrameMap(transforms, is_multiview, None, views, 1, 1, k)
     return ops.frame_map_apply(keypoints_augmented, fm)
+
+
+def undo_affine_transform(keypoints: torch.Tensor, transform: torch.Tensor) -> torch.Tensor:
+    """(S, K, 2) keypoints and one (2, 3) matrix or one per frame (S, 2, 3) -> the un-augmented (S, K, 2) keypoints
+    (reference data/utils.py:142-188); same kernel as the batch form."""
+    s, k = keypoints.shape[0], keypoints.shape[1]
+    return undo_affine_transform_batch(keypoints.reshape(s, 2 * k), transform, is_multiview=False).reshape(s, k, 2)

@@ -278,6 +278,12 @@ def test_undo_affine_transform_batch_cases(dev):
     assert torch.allclose(torch.cat(kps, -1), out.cpu(), atol=1e-4)
     plain = torch.randn(S, 2 * K, generator=g).to(dev)
     assert undo_affine_transform_batch(plain, torch.tensor([-1.0]).to(dev)) is plain  # "no augmentation": the input itself
+    # test_undo_affine_transform: the (S, K, 2) form, one matrix and one per frame
+    from lightning_pose_amd.data.utils import undo_affine_transform
+
+    kp = torch.randn(S, K, 2, generator=g)
+    for tf in (torch.randn(2, 3, generator=g), torch.randn(S, 2, 3, generator=g)):
+        assert torch.allclose(kp, undo_affine_transform(_affine(kp, tf).to(dev), tf.to(dev)).cpu(), atol=1e-4)
 
 
 # -------------------------------------------------------------------------------------------------------------- data/test_bboxes.py
