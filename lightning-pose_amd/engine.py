@@ -10,7 +10,8 @@ Design (MI355X-first, not a translation of the reference's module tree):
     streaming kernels (csrc/bn.hip).
   * the network is static, so forward records a plain Python "tape" of tensors and backward walks it in reverse
     calling dgrad / wgrad kernels directly - no autograd graph, no tracing compiler.  288 GB of HBM lets every
-    activation stay resident (about 0.13 GB per 384x384 frame), nothing is recomputed.
+    activation stay resident (about 0.13 GB per 384x384 frame); the one exception is the stem's BatchNorm -> ReLU -> max-pool,
+    fused so that the full-resolution activation between them (and its gradient) never exists.
 
 Reference behaviour reproduced (paths relative to the reference tree): torchvision ResNet-50 children[:-2]
 (models/backbones/factory.py:322-348), HeatmapHead (models/heads/heatmap.py:20-83,147-212), training-mode
@@ -645,8 +646,8 @@ class Engine:
             # ReLU backward AND the two reductions of the BatchNorm backward are fused into the dgrad that PRODUCES each
             # gradient: its store pass zeroes the gradient where the activation is <= 0 (mask recomputed from the saved
             # pre-normalisation tensor, or read from the block output when there is a residual branch) and leaves
-            # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head), the stem (fed by the max-pool) and
-            # the inputs of the stride-2 blocks (two partial writers) still run lp_bn_bwd_reduce.
+            # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head) and the inputs of the stride-2
+            # blocks (two partial writers) still run lp_bn_bwd_reduce; the stem has its own fused pair (lp_bn_pool_bwd_*).
             if last:
                 dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True)
             else:
