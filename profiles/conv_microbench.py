@@ -54,3 +54,44 @@ for name, H, Ci, Co, k, st, pad in SHAPES:
         torch.cuda.synchronize()
         us = 1000 * e0.elapsed_time(e1) / reps
         print(f"{name:24s} {kind:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+# ---- the launches DESIGN.md section 9 singles out: conv1 data gradients of the non-first blocks, with everything their store pass
+# fuses (residual addend, 1-bit ReLU mask of the previous block's output, that block's BatchNorm-backward reductions).  Reports the
+# launch time, TFLOP/s and the ALGORITHMIC traffic rate (dz + addend + z + bits read, dx written).
+C1 = [  # name, H (= W), C_mid (K of the GEMM), 4 * C_mid (N)
+    ("l1.c1_dgrad_fused", 96, 64, 256),
+    ("l2.c1_dgrad_fused", 48, 128, 512),
+    ("l3.c1_dgrad_fused", 24, 256, 1024),
+    ("l4.c1_dgrad_fused", 12, 512, 2048),
+]
+for name, H, Cm, Cn in C1:
+    M = B * H * H
+    g = _lib.ConvGeom(B, H, H, Cn, H, H, Cm, 1, 1, 1, 0)          # forward conv1: Cn -> Cm; its data gradient: M x Cm -> M x Cn
+    dz = torch.randn(M, Cm, device=dev).to(torch.bfloat16)
+    wd = (torch.randn(Cn, Cm, device=dev) * 0.05).to(torch.bfloat16)   # [Ci][R][S][Co] for a 1x1
+    addend = torch.randn(M, Cn, device=dev).to(torch.bfloat16)
+    z = torch.randn(M, Cn, device=dev).to(torch.bfloat16)
+    bits = torch.randint(0, 256, (M * Cn // 8,), device=dev, dtype=torch.uint8)
+    mean, invstd = torch.zeros(Cn, device=dev), torch.ones(Cn, device=dev)
+    gamma, beta = torch.ones(Cn, device=dev), torch.zeros(Cn, device=dev)
+    sums, dbeta, dgamma = torch.zeros(2 * Cn, device=dev), torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+    dx = torch.empty(M, Cn, device=dev, dtype=torch.bfloat16)
+    need = int(lib.lp_conv_bn_workspace_bytes(C.byref(g), 1))
+    wsb = torch.empty(max(need, 16), device=dev, dtype=torch.uint8)
+    f = _lib.BnFuse()
+    f.sums, f.workspace, f.workspace_bytes = sums.data_ptr(), wsb.data_ptr(), need
+    f.z, f.mean, f.invstd, f.gamma, f.beta = z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    f.mask_from_z, f.relu_bits = 0, bits.data_ptr()
+    f.dbeta_acc, f.dgamma_acc = dbeta.data_ptr(), dgamma.data_ptr()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for it in range(reps + 1):
+        if it == 1:
+            e0.record()
+        sums.zero_()
+        rc = lib.lp_conv_dgrad_bn(_p(dz), _p(wd), C.byref(g), _p(addend), None, _p(dx), C.byref(f), _stream())
+        assert rc == 0, rc
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1000 * e0.elapsed_time(e1) / reps
+    nbytes = 2.0 * M * Cm + 3 * 2.0 * M * Cn + M * Cn / 8
+    print(f"{name:24s} dgrad+ {us:9.1f} us  {2.0 * M * Cm * Cn / us / 1e6:8.1f} TFLOP/s  {nbytes / us / 1e6:6.2f} TB/s", flush=True)
