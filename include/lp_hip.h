@@ -182,7 +182,8 @@ int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, i
  * k_off + h*64 and V at v_off + h*64.  The scores stay on chip (two passes over the keys: running max / exp-sum, then P and O). */
 int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
                 void* out_bf16, int ldo, lp_stream_t stream);
-/* Attention backward, key / value side, in one pass over the stored probabilities (replaces lp_attn_dscores + 2 x lp_gemm_tn):
+/* Attention backward, key / value side, in one pass over the stored probabilities (the autograd of HF ViTSelfAttention's eager
+ * attention, reference models/backbones/vit.py:38-43 -> transformers ViTModel; replaces lp_attn_dscores + 2 x lp_gemm_tn):
  *   dS[z][q][k] = scale * P[z][q][k] * (sum_d dO[q][d] V[k][d] - D[q])   -> ds_bf16 (layout / pitch of P, pad columns zeroed; dQ = dS K reads it)
  *   dV[k][d] = sum_q P[q][k] dO[q][d]  -> dqkv_bf16[(b*T + k)*ld_dqkv + dv_off + h*64 + d]
  *   dK[k][d] = sum_q dS[q][k] Q[q][d]  -> dqkv_bf16[(b*T + k)*ld_dqkv + dk_off + h*64 + d]
@@ -232,7 +233,8 @@ int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, c
 size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);
 int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
                   size_t workspace_bytes, lp_stream_t stream);
-/* same, plus dbias[co] += sum_m dy[m][co] (bias gradient of a Linear / ConvTranspose2d layer) out of the same pass over dy: fp32
+/* same, plus dbias[co] += sum_m dy[m][co] (bias gradient of a Linear layer of the ViT backbone, reference models/backbones/vit.py:16-49,
+ * or of a ConvTranspose2d of the head, models/heads/heatmap.py:20-71) out of the same pass over dy: fp32
  * atomics, one per column and pixel slice, so the summation order (not the set of addends) can vary between runs */
 int lp_conv_wgrad_bias(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, float* dbias, int split_hint, void* workspace,
                        size_t workspace_bytes, lp_stream_t stream);
@@ -298,7 +300,8 @@ int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x_out, const
 /* dx_acc += LayerNorm backward of dy (bf16, same row mapping as y);  dgamma_acc / dbeta_acc accumulate too */
 int lp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
                      int drop_T, float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
-/* same, and the updated dx_acc is also written rounded to bf16 (what the next Linear layer's backward reads) */
+/* same, and the updated dx_acc is also written rounded to bf16 (what the next Linear layer's backward reads; the LayerNorms are
+ * those of transformers ViTLayer / ViTModel.layernorm behind reference models/backbones/vit.py:26-27) */
 int lp_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
                           int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
 int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream);                       /* exact (erf) GELU */
