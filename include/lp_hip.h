@@ -192,7 +192,7 @@ int lp_attn_bwd_kv(const void* qkv_bf16, int ld_qkv, int v_off, const void* d_ou
                    int B, int nh, int T, float scale, void* ds_bf16, void* dqkv_bf16, int ld_dqkv, int dk_off, int dv_off, lp_stream_t stream);
 /* Attention backward without materialising dP (replaces lp_gemm_nt + lp_softmax_rows_bwd of the composition; the reference's
  * arithmetic is HF ViTSelfAttention's eager soft-max attention, models/backbones/vit.py:38-43):
- *   lp_attn_rowdot   D[row][h] = sum_d a[row][h*64+d] * b[row][h*64+d]   (a = dO, b = O, head dimension 64, nh <= 8)
+ *   lp_attn_rowdot   D[row][h] = sum_d a[row][h*64+d] * b[row][h*64+d]   (a = dO, b = O, head dimension 64)
  *   lp_attn_dscores  dS[z][m][n] = scale * P[z][m][n] * (sum_k dO[z][m][k] V[z][n][k] - D[z][m]), pad columns [N, ldc) zeroed;
  *                    P has the layout of dS; D[z][m] sits at d_rows[zb*d_b + zh*d_h + m*d_row_stride]; batch as in lp_gemm_nt. */
 int lp_attn_rowdot(const void* a_bf16, const void* b_bf16, int rows, int nh, int ld, float* out, lp_stream_t stream);

@@ -395,22 +395,26 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const unsigned sh
 }
 
 // ---- D[row][h] = sum_d a[row][h*64 + d] * b[row][h*64 + d]  (attention backward: rowsum(dO o O) per head, the soft-max backward's
-// row term).  One wave per row: lane l owns the 16-B chunk l (8 chunks per 64-wide head), an 8-lane butterfly finishes a head.
+// row term).  One wave per row: lane l owns the 16-B chunk l (+ 64 per pass; 8 chunks per 64-wide head), an 8-lane butterfly finishes a head.
 __global__ __launch_bounds__(256) void attn_rowdot_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b, int rows,
                                                           int nh, int ld, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = nh * 8;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        float dot = 0.f;
-        if (lane < nh * 8) {
-            float x[8], y[8];
-            unpack8v(*reinterpret_cast<const u16x8*>(a + (size_t)row * ld + lane * 8), x);
-            unpack8v(*reinterpret_cast<const u16x8*>(b + (size_t)row * ld + lane * 8), y);
+        for (int c0 = 0; c0 < chunks; c0 += 64) {  // 8 heads per pass (ViT-S: one pass, ViT-B: two); wave-uniform trip count
+            const int c = c0 + lane;
+            float dot = 0.f;
+            if (c < chunks) {
+                float x[8], y[8];
+                unpack8v(*reinterpret_cast<const u16x8*>(a + (size_t)row * ld + c * 8), x);
+                unpack8v(*reinterpret_cast<const u16x8*>(b + (size_t)row * ld + c * 8), y);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot = fmaf(x[e], y[e], dot);
+                for (int e = 0; e < 8; ++e) dot = fmaf(x[e], y[e], dot);
+            }
+#pragma unroll
+            for (int m = 4; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+            if ((lane & 7) == 0 && c < chunks) out[(size_t)row * nh + (c >> 3)] = dot;
         }
-#pragma unroll
-        for (int m = 4; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
-        if ((lane & 7) == 0 && lane < nh * 8) out[(size_t)row * nh + (lane >> 3)] = dot;
     }
 }
 
@@ -601,7 +605,7 @@ extern "C" int lp_softmax_rows_bwd(const void* p_bf16, void* dp_bf16, int rows, 
 extern "C" int lp_attn_rowdot(const void* a_bf16, const void* b_bf16, int rows, int nh, int ld, float* out, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(a_bf16 && b_bf16 && out && rows > 0 && nh > 0 && ld >= nh * 64);
-    if (nh > 8 || ld % 8 != 0) return LP_ERR_UNSUPPORTED;  // head dimension 64, at most 8 heads per row (one wave per row)
+    if (ld % 8 != 0) return LP_ERR_UNSUPPORTED;  // head dimension 64; one wave per row, 8 heads per pass
     int blocks = (rows + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)a_bf16,

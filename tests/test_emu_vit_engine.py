@@ -39,11 +39,12 @@ def _oracle_forward(vit, head, images):
     return torch.softmax(logits.reshape(b, k, -1), -1).reshape(b, k, h, w)
 
 
-def test_vit_engine_forward_backward_vs_hf(stack_backend):
+@pytest.mark.parametrize("hidden,depth,heads,mlp", [(128, 2, 2, 256), (768, 1, 12, 768)])  # the second: ViT-B's width and 12 heads
+def test_vit_engine_forward_backward_vs_hf(stack_backend, hidden, depth, heads, mlp):
     from lightning_pose_amd.vit_engine import ViTEngine
 
     dev = stack_backend
-    K, hidden, depth, heads, mlp, grid0 = 5, 128, 2, 2, 256, 3
+    K, grid0 = 5, 3
     vit, head = _oracle(K, hidden, depth, heads, mlp, grid0, seed=0)
     eng = ViTEngine(K, 2, dev, hidden=hidden, depth=depth, heads=heads, mlp=mlp, patch=16, pretrain_grid=grid0)
     sd = {f"backbone.vision_encoder.{k}": v for k, v in vit.state_dict().items()}
@@ -59,7 +60,8 @@ def test_vit_engine_forward_backward_vs_hf(stack_backend):
     heat, tape = eng.forward(images.to(dev), True)
     want = _oracle_forward(vit, head, images)
     assert heat.shape == want.shape == (2, K, 16, 16)
-    torch.testing.assert_close(heat.cpu(), want.detach(), atol=2e-3, rtol=5e-2)  # bf16 operands vs fp32
+    # bf16 operands vs fp32; the 768-wide head sums 192 products per logit, its sharper soft-max doubles the relative error of a peak
+    torch.testing.assert_close(heat.cpu(), want.detach(), atol=2e-3, rtol=5e-2 if hidden == 128 else 1e-1)
 
     g = torch.randn(want.shape, generator=gen)
     (want * g).sum().backward()

@@ -124,6 +124,17 @@ def test_transpose_batched_scalar_path():
     assert not got[..., R:].any()
 
 
+@pytest.mark.parametrize("nh", [1, 6, 12])
+def test_attention_rowdot_head_counts(nh):
+    """lp_attn_rowdot for ViT-S (6 heads: one pass of the wave) and ViT-B (12 heads: two passes)"""
+    gen = torch.Generator().manual_seed(nh)
+    rows, D = 37, nh * 64
+    a, b = bf(torch.randn(rows, D + 8, generator=gen)), bf(torch.randn(rows, D + 8, generator=gen))
+    got = emu.attn_rowdot(bits(a).reshape(-1), bits(b).reshape(-1), rows, nh, D + 8)
+    want = (a[:, :D] * b[:, :D]).reshape(rows, nh, 64).sum(-1)
+    torch.testing.assert_close(torch.from_numpy(got), want, atol=1e-4, rtol=1e-5)
+
+
 def test_attention_score_gradient_fused():
     """lp_attn_rowdot + lp_attn_dscores == autograd of softmax(Q K^T scale) V with respect to the scaled scores' pre-scale input:
     dS = scale * P o (dO V^T - rowsum(dO o O)), heads interleaved in the token rows (QKV layout), ragged T, padded score pitch."""
