@@ -10,6 +10,7 @@ mode=${1:-hip}
 if [ "$mode" = emu ]; then
   out=../../tests/hipemu
   mkdir -p "$out/obj"
+  exec 9>"$out/obj/.lock"; flock 9   # concurrent callers (pytest-xdist workers) take turns; the link below is atomic
   objs=()
   for s in "${SRCS[@]}"; do
     [ -f "$s" ] || continue
@@ -20,7 +21,8 @@ if [ "$mode" = emu ]; then
     objs+=("$o")
   done
   wait
-  "$ROCM/lib/llvm/bin/clang++" -shared -o "$out/liblp_emu.so" "${objs[@]}" -lpthread
+  "$ROCM/lib/llvm/bin/clang++" -shared -o "$out/liblp_emu.so.$$" "${objs[@]}" -lpthread
+  mv -f "$out/liblp_emu.so.$$" "$out/liblp_emu.so"
   echo "built $out/liblp_emu.so"
 else
   mkdir -p obj
