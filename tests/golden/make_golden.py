@@ -293,11 +293,88 @@ def gen_tracker_step():
     save("tracker_step", **arrs)
 
 
+def _stub_prediction_imports():
+    """utils/predictions.py also imports cv2 / moviepy (video rendering, not on the path): empty stand-ins."""
+    import types
+    for n in ("cv2", "moviepy"):
+        if n not in sys.modules:
+            try:
+                __import__(n)
+            except Exception:  # noqa: BLE001
+                sys.modules[n] = types.ModuleType(n)
+    if not hasattr(sys.modules["moviepy"], "VideoFileClip"):
+        sys.modules["moviepy"].VideoFileClip = object
+
+
+def gen_predictions():
+    """PredictionHandler (utils/predictions.py:41-330) on seeded per-batch outputs: single-view video with a padded last
+    sequence, multiview video, labeled dataset with split column, and the context-model shift."""
+    _stub_prediction_imports()
+    P = R.load("utils.predictions")
+    g = torch.Generator().manual_seed(11)
+    K = 5
+    names = [f"kp{i}" for i in range(K)]
+
+    class H(P.PredictionHandler):  # the reference counts frames by opening the video with OpenCV; pin the count instead
+        n_frames = 0
+
+        @property
+        def frame_count(self):
+            return self.n_frames
+
+    def batches(n_batches, bsz, cols):
+        return [(torch.rand(bsz, 2 * cols, generator=g) * 300, torch.rand(bsz, cols, generator=g)) for _ in range(n_batches)]
+
+    arrs = {}
+    # (1) single-view video: 5 sequences of 16, 70 real frames
+    cfg = R._wrap({"data": {"keypoint_names": names}, "model": {"model_type": "heatmap"}})
+    pr = batches(5, 16, K)
+    h = H(cfg, video_file="clip.mp4"); h.n_frames = 70
+    df = h(preds=pr)
+    arrs.update(v1_kp=torch.vstack([p[0] for p in pr]), v1_conf=torch.vstack([p[1] for p in pr]), v1_table=df.to_numpy(),
+                v1_columns=np.array(["|".join(c) for c in df.columns]))
+    # (2) multiview video, 2 views
+    cfg_mv = R._wrap({"data": {"keypoint_names": names, "view_names": ["top", "bot"]}, "model": {"model_type": "heatmap_multiview_transformer"}})
+    pr = batches(3, 8, 2 * K)
+    h = H(cfg_mv, video_file="clip_top.mp4"); h.n_frames = 21
+    d = h(preds=pr, is_multiview_video=True)
+    arrs.update(v2_kp=torch.vstack([p[0] for p in pr]), v2_conf=torch.vstack([p[1] for p in pr]), v2_top=d["top"].to_numpy(),
+                v2_bot=d["bot"].to_numpy())
+    # (3) labeled dataset with split indices
+    class Sub:
+        def __init__(self, idx):
+            self.indices = idx
+
+    class DS:
+        do_context = False
+        image_names = [f"labeled-data/vid/img{i:03d}.png" for i in range(12)]
+
+        def __len__(self):
+            return 12
+
+    class DM:
+        dataset = DS()
+        train_dataset, val_dataset, test_dataset = Sub([0, 2, 4, 6, 8, 10]), Sub([1, 5]), Sub([3, 7])
+
+    pr = batches(3, 4, K)
+    df = P.PredictionHandler(cfg, data_module=DM())(preds=pr)
+    arrs.update(v3_kp=torch.vstack([p[0] for p in pr]), v3_conf=torch.vstack([p[1] for p in pr]),
+                v3_table=df.drop(columns="set", level=0).to_numpy().astype(np.float64),
+                v3_set=np.array(df[("set", "", "")].tolist()), v3_index=np.array(list(df.index)))
+    # (4) context shift (pure tensor logic; the context models themselves are out of scope)
+    cfg_ctx = R._wrap({"data": {"keypoint_names": names}, "model": {"model_type": "heatmap_mhcrnn"}})
+    pr = batches(2, 16, K)
+    h = H(cfg_ctx, video_file="clip.mp4"); h.n_frames = 30
+    df = h(preds=pr)
+    arrs.update(v4_kp=torch.vstack([p[0] for p in pr]), v4_conf=torch.vstack([p[1] for p in pr]), v4_table=df.to_numpy())
+    h.n_frames = 32  # exactly as many frames as rows
+    arrs.update(v4b_table=h(preds=pr).to_numpy())
+    save("predictions", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    gen_decode()
-    gen_heatmaps()
-    gen_geometry()
-    gen_losses()
-    gen_callbacks()
-    gen_tracker_step()
+    GENS = {"decode": gen_decode, "heatmaps": gen_heatmaps, "geometry": gen_geometry, "losses": gen_losses,
+            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions}
+    for name in (sys.argv[1:] or list(GENS)):  # `make_golden.py predictions` regenerates one fixture only
+        GENS[name]()
