@@ -314,6 +314,46 @@ int lp_transpose_batched(const void* in_bf16, int R, int Cc, int ldi, long long 
                          long long out_b, long long out_h, int nb, int nh, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Batch producers: what sits directly BEFORE the step.
+ *   lp_frames_resize / lp_frames_augment   the device half of data/video/dali.py:135-192 video_pipe after the decoder:
+ *        fn.resize -> [fn.warp_affine(matrix, fill_value=0, inverse_map=False) -> fn.brightness_contrast -> fn.noise.shot]
+ *        -> /255 -> fn.crop_mirror_normalize(mean, std, output_layout="FCHW"); the (2,3) matrix is the `transforms` entry of
+ *        UnlabeledBatchDict (data/video/dali.py:267-330) that lp_decode_fwd's frame map undoes.  DALI is not vendored:
+ *        its published operator definitions are restated (oracle/restated.py), parity unpinned.
+ *   lp_labeled_keypoints                   data/datasets.py:262-376 (imgaug Resize keypoint projection, hflip + left/right
+ *        swap), :465-472 (visibility synthesised from NaN labels), :496-508 (out-of-frame keypoints become NaN); feed the
+ *        result to lp_heatmap_gen for HeatmapDataset.compute_heatmap's targets.
+ * ------------------------------------------------------------------------------------------------------ */
+enum { LP_BORDER_RENORM = 0, /* filter window cut at the image edge and renormalised (PIL / torch antialias)       */
+       LP_BORDER_CLAMP = 1   /* edge pixels replicated under the full window (DALI resampling)                     */ };
+
+typedef struct lp_frame_norm {
+    float mean[3], std[3]; /* per channel, in [0,1] units (ImageNet statistics in the reference, data/__init__.py:46-47) */
+} lp_frame_norm;
+
+typedef struct lp_frame_augment {
+    int has_matrix;
+    float matrix[6];        /* row-major (2,3), maps SOURCE to DESTINATION pixel-centre coordinates (inverse_map=False)   */
+    float brightness, contrast, contrast_center; /* out = brightness * (center + contrast * (in - center)); DALI: 0.5 for float input */
+    float shot_factor;      /* out = Poisson(max(in,0) / factor) * factor on the [0,255] scale; 0 = off                   */
+    unsigned long long seed; /* counter-based generator: the noise depends only on (seed, frame, pixel, channel)         */
+} lp_frame_augment;
+
+/* src u8 (S, Hs, Ws, 3) with byte strides -> antialiased linear resize to (H, W).  finish_norm == NULL: dst = fp32 (S,H,W,3) in
+ * [0,255] (input of lp_frames_augment); else dst = fp32 (S,3,H,W) = (v/255 - mean) / std (imgaug="default": no augmentation) */
+int lp_frames_resize(const void* src_u8, int S, int Hs, int Ws, long long frame_stride, int row_stride, int H, int W, int border,
+                     const lp_frame_norm* finish_norm, float* dst, lp_stream_t stream);
+/* src fp32 (S,H,W,3) in [0,255] -> dst fp32 (S,3,H,W); one parameter set per call = per DALI sample (a whole sequence) */
+int lp_frames_augment(const float* src_hwc, int S, int H, int W, const lp_frame_augment* aug, const lp_frame_norm* norm,
+                      float* dst_nchw, lp_stream_t stream);
+/* kp_src (B,K,2) source px, src_hw (B,2) = source (height, width); optional affine (B,2,3) on source px, hflip (B) 0/1 with the
+ * keypoint permutation swap (K), vis_in (B,K) 0/1/2 (NULL: synthesised from NaN labels, NaN -> uniform_heatmaps ? 1 : 0, else 2).
+ * kp_out (B,K,2) model px with out-of-frame points set to NaN, vis_out (B,K).  kp_out must not alias kp_src. */
+int lp_labeled_keypoints(const float* kp_src, const float* src_hw, const float* affine, const int* hflip, const int* swap,
+                         const int* vis_in, int uniform_heatmaps, int B, int K, int H, int W, float* kp_out, int* vis_out,
+                         lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Optimiser: torch.optim.Adam / AdamW semantics (models/base.py:458-479) over one flat fp32 range, also emitting
  * the bf16 copy the GEMMs read.  lr may be 0 (frozen backbone, callbacks.py:79-196): moments still move.
  * ------------------------------------------------------------------------------------------------------ */

@@ -38,11 +38,21 @@ class BnFuse(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class FrameNorm(C.Structure):
+    _fields_ = [("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
+class FrameAugment(C.Structure):
+    _fields_ = [("has_matrix", C.c_int), ("matrix", C.c_float * 6), ("brightness", C.c_float), ("contrast", C.c_float),
+                ("contrast_center", C.c_float), ("shot_factor", C.c_float), ("seed", C.c_ulonglong)]
+
+
 class GemmBatch(C.Structure):
     _fields_ = [("nb", C.c_int), ("nh", C.c_int)] + [(n, C.c_longlong) for n in ("a_b", "a_h", "b_b", "b_h", "c_b", "c_h")]
 
 
 HM_MSE, HM_KL, HM_JS = 0, 1, 2
+BORDER_RENORM, BORDER_CLAMP = 0, 1
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -109,6 +119,9 @@ PROTOTYPES = {
     "lp_softmax_rows_fwd": (_I, [_P, _I, _I, _I, _F, _P]),
     "lp_softmax_rows_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "lp_transpose_batched": (_I, [_P, _I, _I, _I, C.c_longlong, C.c_longlong, _P, _I, C.c_longlong, C.c_longlong, _I, _I, _P]),
+    "lp_frames_resize": (_I, [_P, _I, _I, _I, C.c_longlong, _I, _I, _I, _I, C.POINTER(FrameNorm), _P, _P]),
+    "lp_frames_augment": (_I, [_P, _I, _I, _I, C.POINTER(FrameAugment), C.POINTER(FrameNorm), _P, _P]),
+    "lp_labeled_keypoints": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
     "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),
     "lp_permute_cba": (_I, [_P, _I, _I, _I, _P, _P]),

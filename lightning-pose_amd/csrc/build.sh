@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 ROCM=${ROCM_PATH:-/opt/rocm}
-SRCS=(api.hip decode.hip heatmap.hip kploss.hip conv.hip bn.hip optim.hip vit.hip attn.hip)
+SRCS=(api.hip decode.hip heatmap.hip kploss.hip conv.hip bn.hip optim.hip vit.hip attn.hip frames.hip)
 mode=${1:-hip}
 if [ "$mode" = emu ]; then
   out=../../tests/hipemu

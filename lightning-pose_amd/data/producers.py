@@ -1,0 +1,168 @@
+"""Batch producers on the device: what hands the training step its two batches.
+
+``VideoFramePipeline``   the device half of the reference's DALI ``video_pipe`` (data/video/dali.py:70-197) plus
+                         ``LitDaliWrapper._dali_output_to_tensors`` (:267-330): decoded uint8 frames already resident in HBM ->
+                         ``UnlabeledBatchDict`` / ``MultiviewUnlabeledBatchDict``.  Same constructor vocabulary (``resize_dims``,
+                         ``normalization_mean/std``, ``imgaug`` in {"default", "dlc", "dlc-top-down"}, a seed), same random
+                         ranges (rotation U(-10, 10) deg, scale U(0.8, 1.2)^2, brightness / contrast U(0.75, 1.25), shot-noise
+                         factor U(0, 10)), same outputs (the (2, 3) matrix the fused decode later undoes; the ``[-1]`` sentinel
+                         when nothing geometric happened).  Video DECODE is not here: frames arrive as a uint8 tensor.
+``LabeledBatchProducer`` the per-batch work of ``HeatmapDataset.__getitem__`` (data/datasets.py:262-376, :496-550) moved to the
+                         device: image resize + normalise, keypoint projection, optional flip with the left / right swap,
+                         out-of-frame -> NaN, visibility synthesis, Gaussian targets (``lp_heatmap_gen``) -> ``HeatmapLabeledBatchDict``
+                         with nothing but the uint8 images crossing PCIe.
+
+The image operators are restatements of DALI's / imgaug's published definitions (neither library is available to check against):
+parity of pixel values is UNPINNED; keypoints, visibility and targets are pinned against the verbatim reference dataset.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .. import ops
+from .datatypes import HeatmapLabeledBatchDict, MultiviewUnlabeledBatchDict, UnlabeledBatchDict
+
+_IMAGENET_MEAN = [0.485, 0.456, 0.406]  # reference data/__init__.py:46-47
+_IMAGENET_STD = [0.229, 0.224, 0.225]
+
+_IMGAUG_VIDEO = ("default", "none", "dlc", "dlc-lr", "dlc-top-down", "dlc-mv")
+
+
+def rotation_scale_matrix(angle_deg: float, scale_xy: Sequence[float], center_xy: Sequence[float]) -> np.ndarray:
+    """``fn.transforms.scale(fn.transforms.rotation(angle, center), scale, center)`` (data/video/dali.py:158-161): the (2, 3)
+    matrix, source -> destination, of a rotation about ``center`` followed by an axis scale about the same point."""
+    th = math.radians(angle_deg)
+    cx, cy = float(center_xy[0]), float(center_xy[1])
+    t0 = np.array([[1.0, 0.0, -cx], [0.0, 1.0, -cy], [0.0, 0.0, 1.0]])
+    t1 = np.array([[1.0, 0.0, cx], [0.0, 1.0, cy], [0.0, 0.0, 1.0]])
+    rot = np.array([[math.cos(th), math.sin(th), 0.0], [-math.sin(th), math.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    sc = np.diag([float(scale_xy[0]), float(scale_xy[1]), 1.0])
+    return (t1 @ sc @ t0 @ t1 @ rot @ t0)[:2]
+
+
+class VideoFramePipeline:
+    """Decoded frames -> the unlabeled batch of the semi-supervised step."""
+
+    def __init__(self, resize_dims: Sequence[int] | None, normalization_mean: Sequence[float] = _IMAGENET_MEAN,
+                 normalization_std: Sequence[float] = _IMAGENET_STD, imgaug: str = "default", seed: int = 123456,
+                 border: str = "clamp") -> None:
+        if imgaug not in _IMGAUG_VIDEO:
+            raise NotImplementedError(f"cfg.training.imgaug string {imgaug} must be in {list(_IMGAUG_VIDEO)}")
+        self.resize_dims = None if resize_dims is None else (int(resize_dims[0]), int(resize_dims[1]))
+        self.mean, self.std = list(normalization_mean), list(normalization_std)
+        self.imgaug = imgaug
+        self.augment = imgaug in ("dlc", "dlc-top-down")  # the reference's video pipe augments for exactly these (:153)
+        if self.augment and self.resize_dims is None:
+            raise AssertionError("resize_dims is required when imgaug augments the video frames")
+        self.border = border
+        # each rank draws its own augmentations: seed + LOCAL_RANK, as the reference seeds its DALI pipes (:558, :565-568)
+        self.seed = int(seed) + int(os.environ.get("LOCAL_RANK", "0"))
+        self._rng = np.random.default_rng(self.seed)
+        self._calls = 0
+
+    def _draw(self, h: int, w: int) -> dict:
+        r = self._rng
+        angle = r.uniform(-10.0, 10.0)
+        scale = r.uniform(0.8, 1.2, size=2)
+        center = (h / 2.0, w / 2.0)  # (sic) the reference passes (resize_dims[0] / 2, resize_dims[1] / 2) as the (x, y) centre
+        return {"matrix": rotation_scale_matrix(angle, scale, center), "contrast": r.uniform(0.75, 1.25),
+                "brightness": r.uniform(0.75, 1.25), "shot_factor": r.uniform(0.0, 10.0)}
+
+    def _one_view(self, frames_u8: torch.Tensor, params: dict | None):
+        if frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+            raise ValueError(f"frames must be (S, H, W, 3) uint8, got {tuple(frames_u8.shape)}")
+        s, hs, ws, _ = frames_u8.shape
+        h, w = self.resize_dims if self.resize_dims is not None else (hs, ws)
+        dev = frames_u8.device
+        if self.augment:
+            p = params if params is not None else self._draw(h, w)
+            raw = ops.frames_resize(frames_u8, h, w, self.border)
+            self._calls += 1
+            frames = ops.frames_augment(raw, self.mean, self.std, matrix=p["matrix"], brightness=p["brightness"], contrast=p["contrast"],
+                                        shot_factor=p["shot_factor"], seed=(self.seed << 20) + self._calls)
+            transform = torch.tensor(np.asarray(p["matrix"], dtype=np.float32)).to(dev)
+        else:
+            frames = ops.frames_resize(frames_u8, h, w, self.border, mean=self.mean, std=self.std)
+            transform = torch.tensor([-1.0]).to(dev)  # "no geometric transform to undo" (:170-172)
+        return frames, transform, (hs, ws)
+
+    def __call__(self, frames_u8: torch.Tensor | Sequence[torch.Tensor], params: dict | Sequence[dict] | None = None
+                 ) -> UnlabeledBatchDict | MultiviewUnlabeledBatchDict:
+        """One view: (S, Hs, Ws, 3) uint8 -> UnlabeledBatchDict.  A list of views (frame-synchronised by the caller) ->
+        MultiviewUnlabeledBatchDict.  ``params`` overrides the random draw (tests, replay)."""
+        if torch.is_tensor(frames_u8):
+            frames, transform, (hs, ws) = self._one_view(frames_u8, params)
+            bbox = torch.tensor([0.0, 0.0, float(hs), float(ws)], device=frames.device).repeat(frames.shape[0], 1)
+            return UnlabeledBatchDict(frames=frames, transforms=transform, bbox=bbox, is_multiview=False)
+        views = [self._one_view(f, None if params is None else params[i]) for i, f in enumerate(frames_u8)]
+        frames = torch.stack([v[0] for v in views], dim=1)                      # (S, V, 3, H, W)
+        transforms = torch.stack([v[1] for v in views], dim=0)                  # (V, 2, 3) or (V, 1)
+        bbox = torch.cat([torch.tensor([0.0, 0.0, float(v[2][0]), float(v[2][1])], device=frames.device) for v in views]
+                         ).repeat(frames.shape[0], 1)                           # (S, 4V)
+        return MultiviewUnlabeledBatchDict(frames=frames, transforms=transforms, bbox=bbox, is_multiview=True)
+
+
+class LabeledBatchProducer:
+    """uint8 labeled images + stored labels -> the labeled batch of the step, built on the device."""
+
+    def __init__(self, image_resize_height: int, image_resize_width: int, downsample_factor: int = 2, uniform_heatmaps: bool = False,
+                 hflip_swap_indices: Sequence[int] | None = None, normalization_mean: Sequence[float] = _IMAGENET_MEAN,
+                 normalization_std: Sequence[float] = _IMAGENET_STD, border: str = "renorm") -> None:
+        if image_resize_height % 128 != 0 or image_resize_width % 128 != 0:
+            raise ValueError("image dimensions (after transformation) must be repeatably divisible by 2; "
+                             f"current dimensions: height={image_resize_height}, width={image_resize_width}")
+        self.height, self.width = int(image_resize_height), int(image_resize_width)
+        self.downsample_factor = int(downsample_factor)
+        self.output_sigma = 1.25  # reference data/datasets.py:460
+        self.uniform_heatmaps = bool(uniform_heatmaps)
+        self.swap = None if hflip_swap_indices is None else torch.as_tensor(list(hflip_swap_indices), dtype=torch.int32)
+        self.mean, self.std = list(normalization_mean), list(normalization_std)
+        self.border = border
+
+    @property
+    def output_shape(self) -> tuple[int, int]:
+        return self.height // 2 ** self.downsample_factor, self.width // 2 ** self.downsample_factor
+
+    def __call__(self, images_u8: torch.Tensor, keypoints: torch.Tensor, idxs: torch.Tensor | None = None,
+                 visibility: torch.Tensor | None = None, bbox: torch.Tensor | None = None, affine: torch.Tensor | None = None,
+                 hflip: torch.Tensor | None = None) -> HeatmapLabeledBatchDict:
+        """images_u8 (B, Hs, Ws, 3) uint8 on the device; keypoints (B, 2K) or (B, K, 2) in source px (NaN = unlabeled);
+        optional per-sample augmentation ``affine`` (B, 2, 3) on source px (applied to image and labels alike) and ``hflip`` (B)."""
+        dev = images_u8.device
+        b, hs, ws, _ = images_u8.shape
+        kp = keypoints.reshape(b, -1, 2).to(dev)
+        k = kp.shape[1]
+        src_hw = torch.tensor([[float(hs), float(ws)]], device=dev).repeat(b, 1)
+        kp_model, vis = ops.labeled_keypoints(kp, src_hw, self.height, self.width, affine=affine, hflip=hflip, swap=self.swap,
+                                              visibility=visibility, uniform_heatmaps=self.uniform_heatmaps)
+        heatmaps = ops.generate_heatmaps(kp_model, self.height, self.width, self.output_shape, self.output_sigma, vis)
+        if affine is None and hflip is None:
+            images = ops.frames_resize(images_u8, self.height, self.width, self.border, mean=self.mean, std=self.std)
+        else:
+            raw = ops.frames_resize(images_u8, self.height, self.width, self.border)
+            sx, sy = self.width / ws, self.height / hs
+            to_model = np.array([[sx, 0.0, 0.0], [0.0, sy, 0.0], [0.0, 0.0, 1.0]])
+            flips = None if hflip is None else hflip.cpu().numpy().astype(bool)
+            aff = None if affine is None else affine.detach().cpu().numpy().astype(np.float64)
+            planes = []
+            for i in range(b):  # one parameter set per launch (a labeled batch is tens of images)
+                m = np.eye(3)
+                if aff is not None:
+                    a3 = np.eye(3)
+                    a3[:2] = aff[i]
+                    m = to_model @ a3 @ np.linalg.inv(to_model)   # the source-px affine expressed in model px
+                if flips is not None and flips[i]:
+                    m = np.array([[-1.0, 0.0, float(self.width)], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]) @ m
+                planes.append(ops.frames_augment(raw[i:i + 1], self.mean, self.std, matrix=m[:2]))
+            images = torch.cat(planes, 0)
+        if bbox is None:  # x, y, h, w of the whole source frame (reference :352-356)
+            bbox = torch.tensor([[0.0, 0.0, float(hs), float(ws)]], device=dev).repeat(b, 1)
+        if idxs is None:
+            idxs = torch.arange(b)
+        return HeatmapLabeledBatchDict(images=images, keypoints=kp_model.reshape(b, 2 * k), heatmaps=heatmaps, bbox=bbox.to(dev), idxs=idxs)

@@ -18,7 +18,7 @@ from ._lib import LpHipUnavailable, check
 
 __all__ = [
     "decode", "DecodeFrameMap", "generate_heatmaps", "heatmap_mse", "unimodal_mse", "temporal_loss", "pca_loss",
-    "rmse", "require_device",
+    "rmse", "require_device", "frames_resize", "frames_augment", "labeled_keypoints",
 ]
 
 
@@ -300,3 +300,72 @@ def rmse(keypoints_targ: torch.Tensor, keypoints_pred: torch.Tensor) -> torch.Te
     loss = torch.empty(1, device=p.device, dtype=torch.float32)
     check(_lib.lib().lp_rmse_fwd(_p(t), _p(p), t.numel() // 2, _p(loss), _stream()), "lp_rmse_fwd")
     return loss.reshape(())
+
+
+# --------------------------------------------------------------------------------------------------------
+# batch producers (csrc/frames.hip)
+# --------------------------------------------------------------------------------------------------------
+
+def _frame_norm(mean, std) -> _lib.FrameNorm:
+    return _lib.FrameNorm((C.c_float * 3)(*[float(m) for m in mean]), (C.c_float * 3)(*[float(v) for v in std]))
+
+
+def frames_resize(frames_u8: torch.Tensor, height: int, width: int, border: str = "clamp", mean=None, std=None) -> torch.Tensor:
+    """(S, Hs, Ws, 3) uint8 device frames -> antialiased linear resize.  Without mean/std: fp32 (S, height, width, 3) in
+    [0, 255] (input of ``frames_augment``); with them: fp32 (S, 3, height, width) normalised planes in one launch."""
+    require_device(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise ValueError(f"frames must be uint8 (S, H, W, 3), got {frames_u8.dtype} {tuple(frames_u8.shape)}")
+    if border not in ("clamp", "renorm"):
+        raise ValueError(f"border must be 'clamp' or 'renorm', got {border!r}")
+    if frames_u8.stride(3) != 1 or frames_u8.stride(2) != 3:
+        frames_u8 = frames_u8.contiguous()
+    s, hs, ws, _ = frames_u8.shape
+    finish = mean is not None
+    out = torch.empty((s, 3, height, width) if finish else (s, height, width, 3), device=frames_u8.device, dtype=torch.float32)
+    norm = _frame_norm(mean, std) if finish else None
+    check(_lib.lib().lp_frames_resize(_p(frames_u8), s, hs, ws, frames_u8.stride(0), frames_u8.stride(1), int(height), int(width),
+                                      _lib.BORDER_CLAMP if border == "clamp" else _lib.BORDER_RENORM,
+                                      C.byref(norm) if finish else None, _p(out), _stream()), "lp_frames_resize")
+    return out
+
+
+def frames_augment(frames_hwc: torch.Tensor, mean, std, matrix=None, brightness: float = 1.0, contrast: float = 1.0,
+                   contrast_center: float = 0.5, shot_factor: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """fp32 (S, H, W, 3) in [0, 255] -> warp_affine(matrix: source -> destination, fill 0) -> brightness / contrast -> shot
+    noise -> /255 -> normalise -> fp32 (S, 3, H, W).  ``matrix`` is a host (2, 3) array-like (one DALI sample = one sequence)."""
+    require_device(frames_hwc)
+    x = _f32c(frames_hwc)
+    s, h, w, c = x.shape
+    if c != 3:
+        raise ValueError(f"frames must be (S, H, W, 3), got {tuple(x.shape)}")
+    m = [0.0] * 6 if matrix is None else [float(v) for v in np.asarray(matrix, dtype=np.float64).reshape(-1)]
+    if len(m) != 6:
+        raise ValueError("matrix must have 6 entries (2, 3)")
+    aug = _lib.FrameAugment(int(matrix is not None), (C.c_float * 6)(*m), float(brightness), float(contrast), float(contrast_center),
+                            float(shot_factor), int(seed) & 0xFFFFFFFFFFFFFFFF)
+    norm = _frame_norm(mean, std)
+    out = torch.empty(s, 3, h, w, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lp_frames_augment(_p(x), s, h, w, C.byref(aug), C.byref(norm), _p(out), _stream()), "lp_frames_augment")
+    return out
+
+
+def labeled_keypoints(keypoints: torch.Tensor, src_hw: torch.Tensor, height: int, width: int, affine: torch.Tensor | None = None,
+                      hflip: torch.Tensor | None = None, swap: torch.Tensor | None = None, visibility: torch.Tensor | None = None,
+                      uniform_heatmaps: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    """(B, K, 2) source-px labels -> (model-px keypoints with out-of-frame points NaN, visibility (B, K) int32)."""
+    require_device(keypoints)
+    kp = _f32c(keypoints)
+    b, k, _ = kp.shape
+    dev = kp.device
+    hw = _f32c(src_hw.to(dev))
+    i32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int32).contiguous()  # noqa: E731
+    aff = None if affine is None else _f32c(affine.to(dev))
+    fl, sw, vi = i32(hflip), i32(swap), i32(visibility)
+    if hw.shape != (b, 2) or (aff is not None and aff.shape != (b, 2, 3)) or (sw is not None and sw.numel() != k):
+        raise ValueError("labeled_keypoints: src_hw must be (B, 2), affine (B, 2, 3), swap (K,)")
+    out = torch.empty_like(kp)
+    vis = torch.empty(b, k, device=dev, dtype=torch.int32)
+    check(_lib.lib().lp_labeled_keypoints(_p(kp), _p(hw), _p(aff), _p(fl), _p(sw), _p(vi), int(uniform_heatmaps), b, k, int(height),
+                                          int(width), _p(out), _p(vis), _stream()), "lp_labeled_keypoints")
+    return out, vis

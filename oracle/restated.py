@@ -212,6 +212,109 @@ def model_to_frame(keypoints: torch.Tensor, model_height: int, model_width: int,
 
 
 # ======================================================================================
+# batch producers.  The image operators live in NVIDIA DALI / imgaug, which
+# are not vendored and not installable here: their PUBLISHED definitions are restated, with
+# torch's own resampling (F.interpolate antialias, F.grid_sample) as the independent check.
+# Parity of the IMAGE half is UNPINNED; the keypoint / visibility half is pinned against the
+# verbatim HeatmapDataset.compute_heatmap (tests/golden/labeled_targets.npz).
+# ======================================================================================
+
+
+def frames_resize(frames_u8: torch.Tensor, height: int, width: int, border: str = "renorm") -> torch.Tensor:
+    """(S, Hs, Ws, 3) uint8 -> (S, height, width, 3) fp32 in [0, 255]: linear interpolation with antialiasing (triangle
+    filter of radius max(1, scale) source pixels, half-pixel centres) = DALI fn.resize defaults (interp_type=INTERP_LINEAR,
+    antialias=True; data/video/dali.py:151-152).  border="renorm": the window is cut at the image edge and renormalised
+    (exactly torch / PIL antialiased bilinear); border="clamp": edge pixels are replicated under the full window."""
+    x = frames_u8.permute(0, 3, 1, 2).to(torch.float64)
+    if border == "renorm":
+        y = F.interpolate(x, size=(height, width), mode="bilinear", align_corners=False, antialias=True)
+        return y.permute(0, 2, 3, 1).to(torch.float32)
+
+    def axis_matrix(n_src: int, n_dst: int) -> torch.Tensor:
+        scale = n_src / n_dst
+        r = max(1.0, scale)
+        m = torch.zeros(n_dst, n_src, dtype=torch.float64)
+        for i in range(n_dst):
+            c = (i + 0.5) * scale
+            lo, hi = math.floor(c - r + 0.5), math.floor(c + r + 0.5)
+            w = [max(0.0, 1.0 - abs((j + 0.5 - c) / r)) for j in range(lo, hi)]
+            tot = sum(w)
+            for j, wj in zip(range(lo, hi), w):
+                m[i, min(max(j, 0), n_src - 1)] += wj / tot
+        return m
+
+    my, mx = axis_matrix(x.shape[2], height), axis_matrix(x.shape[3], width)
+    y = torch.einsum("ij,scjk,lk->scil", my, x, mx)
+    return y.permute(0, 2, 3, 1).to(torch.float32)
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # data/__init__.py:46-47
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def frames_finish(frames_hwc: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """(S,H,W,3) in [0,255] -> (S,3,H,W): /255 then fn.crop_mirror_normalize(mean, std, output_layout="FCHW")
+    (data/video/dali.py:180-188)."""
+    x = frames_hwc.permute(0, 3, 1, 2) / 255.0
+    return (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+
+
+def frames_warp_affine(frames_hwc: torch.Tensor, matrix: torch.Tensor) -> torch.Tensor:
+    """fn.warp_affine(matrix, fill_value=0, inverse_map=False), linear interpolation, output size = input size
+    (data/video/dali.py:162-165): ``matrix`` (2,3) maps source to destination coordinates with pixel centres at half
+    integers; samples outside the source contribute 0.  Evaluated with torch's grid_sample as the independent sampler."""
+    s, h, w, _ = frames_hwc.shape
+    a = torch.eye(3, dtype=torch.float64)
+    a[:2] = matrix.to(torch.float64)
+    inv = torch.linalg.inv(a)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64) + 0.5, torch.arange(w, dtype=torch.float64) + 0.5, indexing="ij")
+    sx = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]  # source position, pixel-centre-at-half-integer convention
+    sy = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
+    grid = torch.stack([2 * sx / w - 1, 2 * sy / h - 1], -1).unsqueeze(0).expand(s, h, w, 2)
+    out = F.grid_sample(frames_hwc.permute(0, 3, 1, 2).to(torch.float64), grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    return out.permute(0, 2, 3, 1).to(torch.float32)
+
+
+def brightness_contrast(x: torch.Tensor, brightness: float, contrast: float, contrast_center: float = 0.5) -> torch.Tensor:
+    """fn.brightness_contrast: out = brightness_shift * range + brightness * (center + contrast * (in - center)) with
+    brightness_shift = 0; for float input DALI's default contrast_center is 0.5 (data/video/dali.py:167-169 feeds it the
+    reader's FLOAT frames in [0, 255])."""
+    return brightness * (contrast_center + contrast * (x - contrast_center))
+
+
+def labeled_keypoints(keypoints: torch.Tensor, src_hw: torch.Tensor, height: int, width: int, affine: torch.Tensor | None = None,
+                      hflip: torch.Tensor | None = None, swap: torch.Tensor | None = None, visibility: torch.Tensor | None = None,
+                      uniform_heatmaps: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    """(B,K,2) source px -> model px + visibility, as the labeled dataset does it: optional augmentation affine on source
+    px, imgaug Resize keypoint projection ``x / from_w * to_w`` (data/datasets.py:137-142, :279-286), optional horizontal flip
+    ``x = W - x`` followed by the left/right keypoint permutation (:288-293), keypoints outside [0,W) x [0,H) -> NaN
+    (:496-508); visibility as stored or synthesised from the stored label's NaNs (:465-472), permuted with the flip (:364-366)."""
+    kp = keypoints.clone().to(torch.float32)
+    b, k, _ = kp.shape
+    if visibility is None:
+        nan = torch.isnan(kp[:, :, 0])
+        vis = torch.where(nan, torch.full_like(nan, 1 if uniform_heatmaps else 0, dtype=torch.long), torch.full_like(nan, 2, dtype=torch.long))
+    else:
+        vis = visibility.clone().long()
+    if affine is not None:
+        x = affine[:, None, 0, 0] * kp[..., 0] + affine[:, None, 0, 1] * kp[..., 1] + affine[:, None, 0, 2]
+        y = affine[:, None, 1, 0] * kp[..., 0] + affine[:, None, 1, 1] * kp[..., 1] + affine[:, None, 1, 2]
+        kp = torch.stack([x, y], -1)
+    kp[..., 0] = kp[..., 0] / src_hw[:, None, 1] * width
+    kp[..., 1] = kp[..., 1] / src_hw[:, None, 0] * height
+    if hflip is not None:
+        for i in range(b):
+            if bool(hflip[i]):
+                kp[i, :, 0] = width - kp[i, :, 0]
+                if swap is not None:
+                    kp[i] = kp[i][swap.long()]
+                    vis[i] = vis[i][swap.long()]
+    out = (kp[..., 0] < 0) | (kp[..., 1] < 0) | (kp[..., 0] >= width) | (kp[..., 1] >= height)
+    kp[out] = float("nan")
+    return kp, vis
+
+
+# ======================================================================================
 # losses
 # ======================================================================================
 

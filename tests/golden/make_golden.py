@@ -372,9 +372,88 @@ def gen_predictions():
     save("predictions", **arrs)
 
 
+def _load_verbatim_datasets():
+    """data/datasets.py, executed unchanged under stand-ins for the image libraries it imports at module level (imgaug, cv2,
+    torchvision.transforms, the camera-group helper): only its keypoint / visibility / heat-map code is exercised."""
+    import importlib.util
+    import types
+
+    R.install_stubs()
+
+    class _Aug:
+        def add(self, *a, **k):
+            pass
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    for n in ("cv2",):
+        try:
+            __import__(n)
+        except Exception:  # noqa: BLE001
+            mod(n)
+    mod("imgaug")
+    mod("imgaug.augmenters", Sequential=_Aug, Resize=lambda *a, **k: None)
+    mod("imgaug.augmenters.size")
+    sys.modules["imgaug"].augmenters = sys.modules["imgaug.augmenters"]
+    sys.modules["imgaug.augmenters"].size = sys.modules["imgaug.augmenters.size"]
+    tv = sys.modules["torchvision"]
+    tv.transforms = mod("torchvision.transforms", ToTensor=lambda: None, Normalize=lambda **k: None, Compose=lambda l: None)
+    mod("lightning_pose.data.cameras", CameraGroup=object)
+    data_pkg = sys.modules["lightning_pose.data"]
+    data_pkg._IMAGENET_MEAN, data_pkg._IMAGENET_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    spec = importlib.util.spec_from_file_location("lightning_pose.data._datasets_verbatim",
+                                                  os.path.join(R.REFERENCE_ROOT, "lightning_pose", "data", "datasets.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m, _Aug
+
+
+def gen_labeled_targets():
+    """HeatmapDataset (data/datasets.py:380-550) on the bundled mirror-mouse labels: the verbatim __init__ parses the CSV and
+    synthesises visibility (:465-472); the verbatim compute_heatmap (:496-523) turns model-space keypoints into targets, with
+    out-of-frame points set to NaN.  Keypoints reach model space by imgaug's Resize projection x / from_w * to_w (imgaug is
+    not installed: that one line is applied here), after an augmentation affine that pushes some points out of the frame."""
+    D, Aug = _load_verbatim_datasets()
+    root = os.path.join(R.REFERENCE_ROOT, "data", "mirror-mouse-example")
+    H = W = 256
+    SRC_H, SRC_W = 406, 396  # size of the bundled frames (labeled-data/*.png)
+    out = {}
+    for tag, uniform in (("u0", False), ("u1", True)):
+        ds = D.HeatmapDataset(root_directory=root, csv_path="CollectedData.csv", image_resize_height=H, image_resize_width=W,
+                              imgaug_transform=Aug(), downsample_factor=2, uniform_heatmaps=uniform)
+        idxs = [0, 3, 7, 11, 20, 33, 41, 57]
+        kp_src = ds.keypoints[idxs].clone()                       # (8, 17, 2) source px, NaN where unlabeled
+        vis = ds.visibility[idxs].clone()
+        g = torch.Generator().manual_seed(3)
+        th = (torch.rand(len(idxs), generator=g) - 0.5) * 0.8
+        sc = 0.8 + 0.6 * torch.rand(len(idxs), generator=g)
+        A = torch.zeros(len(idxs), 2, 3)
+        A[:, 0, 0], A[:, 0, 1], A[:, 1, 0], A[:, 1, 1] = sc * torch.cos(th), -sc * torch.sin(th), sc * torch.sin(th), sc * torch.cos(th)
+        A[:, :, 2] = (torch.rand(len(idxs), 2, generator=g) - 0.5) * 160
+        A[0] = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+        x = A[:, None, 0, 0] * kp_src[..., 0] + A[:, None, 0, 1] * kp_src[..., 1] + A[:, None, 0, 2]
+        y = A[:, None, 1, 0] * kp_src[..., 0] + A[:, None, 1, 1] * kp_src[..., 1] + A[:, None, 1, 2]
+        kp_model = torch.stack([x / SRC_W * W, y / SRC_H * H], -1)
+        hms, kps = [], []
+        for i in range(len(idxs)):
+            ex = {"keypoints": kp_model[i].reshape(-1).clone(), "visibility": vis[i]}
+            hms.append(ds.compute_heatmap(ex))
+            kps.append(ex["keypoints"].reshape(-1, 2))  # compute_heatmap wrote the NaNs through the view
+        out.update({f"{tag}_vis": vis, f"{tag}_heatmaps": torch.stack(hms), f"{tag}_kp_model_nan": torch.stack(kps)})
+        if tag == "u0":
+            out.update(kp_src=kp_src, affine=A, src_hw=torch.tensor([[SRC_H, SRC_W]] * len(idxs), dtype=torch.float32))
+    # hflip with the left/right swap (:288-293, :364-366): restated sequence applied to the verbatim-parsed labels
+    save("labeled_targets", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     GENS = {"decode": gen_decode, "heatmaps": gen_heatmaps, "geometry": gen_geometry, "losses": gen_losses,
-            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions}
+            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions, "labeled_targets": gen_labeled_targets}
     for name in (sys.argv[1:] or list(GENS)):  # `make_golden.py predictions` regenerates one fixture only
         GENS[name]()

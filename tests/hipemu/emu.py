@@ -565,3 +565,38 @@ def transpose_batched(in_bits, R, Cc, ldi, in_b, in_h, ldo, out_b, out_h, nb, nh
     ib, ob = Buf(in_bits), Buf(np.full(out_elems, 0x7fc0, np.uint16))  # NaN-poisoned: pads must be written
     ok(lib().lp_transpose_batched(ib.p, R, Cc, ldi, in_b, in_h, ob.p, ldo, out_b, out_h, nb, nh, stream()))
     return ob.np()
+
+
+# ---- batch producers (csrc/frames.hip) ----------------------------------------------------------------------------------
+def frame_norm(mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    return _lib.FrameNorm((C.c_float * 3)(*mean), (C.c_float * 3)(*std))
+
+
+def frames_resize(src_u8, H, W, border=_lib.BORDER_RENORM, norm=None):
+    src = np.ascontiguousarray(src_u8, dtype=np.uint8)
+    S, Hs, Ws, _ = src.shape
+    sb = Buf(src)
+    out = Z((S, 3, H, W) if norm is not None else (S, H, W, 3))
+    ok(lib().lp_frames_resize(sb.p, S, Hs, Ws, Hs * Ws * 3, Ws * 3, H, W, border, C.byref(norm) if norm is not None else None, out.p, stream()))
+    return out.np()
+
+
+def frames_augment(src_hwc, matrix=None, brightness=1.0, contrast=1.0, contrast_center=0.5, shot_factor=0.0, seed=0, norm=None):
+    src = f32(src_hwc)
+    S, H, W, _ = src.shape
+    aug = _lib.FrameAugment(int(matrix is not None), (C.c_float * 6)(*(np.asarray(matrix, np.float32).reshape(-1) if matrix is not None else [0] * 6)),
+                            brightness, contrast, contrast_center, shot_factor, seed)
+    norm = norm if norm is not None else frame_norm()
+    sb, out = Buf(src), Z((S, 3, H, W))
+    ok(lib().lp_frames_augment(sb.p, S, H, W, C.byref(aug), C.byref(norm), out.p, stream()))
+    return out.np()
+
+
+def labeled_keypoints(kp, src_hw, H, W, affine=None, hflip=None, swap=None, vis=None, uniform=False):
+    kp = f32(kp)
+    b, k, _ = kp.shape
+    kb, hb = Buf(kp), Buf(f32(src_hw))
+    ab, fb, sb, vb = B(affine, np.float32), B(hflip, np.int32), B(swap, np.int32), B(vis, np.int32)
+    out, vout = Z((b, k, 2)), Z((b, k), np.int32)
+    ok(lib().lp_labeled_keypoints(kb.p, hb.p, ptr(ab), ptr(fb), ptr(sb), ptr(vb), int(uniform), b, k, H, W, out.p, vout.p, stream()))
+    return out.np(), vout.np()
