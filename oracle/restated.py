@@ -11,7 +11,8 @@ reference modules and the reference's known-answer tests in tests/test_oracle_*.
 against tests/golden/*.npz.
 
 Parity status: pinned for everything except ``unimodal_mse_loss`` (no such loss exists in the
-reference snapshot - SURVEY.md F3 - "parity unpinned").
+reference snapshot - SURVEY.md F3 - "parity unpinned") and the image operators of the batch
+producers, ``frames_*`` / ``brightness_contrast`` (DALI / imgaug are not vendored - "parity unpinned").
 """
 
 from __future__ import annotations
