@@ -93,6 +93,11 @@ int lp_frame_map_apply(const float* kp_in, int B, int K, const lp_frame_map* fra
 int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w, float sigma,
                    float* out, lp_stream_t stream);
 
+/* data/heatmaps.py:90-142 evaluate_heatmaps_at_location: out (B,K) = sum of the (2*radius+1)^2 window of heat (B,K,h,w) around
+ * int64(locs (B,K,2) = x, y), zero padded; radius = floor(sigma * num_stds) (2 for the defaults).  The training step gets the
+ * same number from lp_decode_fwd's epilogue; this is the standalone form the reference exports. */
+int lp_heatmap_confidence(const float* heat, const float* locs, int B, int K, int h, int w, int radius, float* out, lp_stream_t stream);
+
 /* losses/losses.py:229-290,314-335 HeatmapMSELoss (remove_nans -> mse*h*w -> mean).  workspace persists to bwd. */
 size_t lp_heatmap_mse_workspace_bytes(int B, int K);
 int lp_heatmap_mse_fwd(const float* targ, const float* pred, int B, int K, int h, int w, float* loss, void* workspace,

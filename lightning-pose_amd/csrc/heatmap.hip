@@ -344,6 +344,28 @@ static GaussSpec make_spec(int img_h, int img_w, int h, int w, float sigma) {
     return g;
 }
 
+// ---- evaluate_heatmaps_at_location (data/heatmaps.py:90-142): sum of the (2r+1)^2 window around int64(loc), zero padded.
+// One lane per (frame, keypoint); taps are added in the reference's order (row offset outer, column offset inner).
+__global__ __launch_bounds__(256) void heatmap_confidence_kernel(const float* __restrict__ heat, const float* __restrict__ locs, int n_maps,
+                                                                 int h, int w, int radius, float* __restrict__ out) {
+    const int bk = blockIdx.x * 256 + threadIdx.x;
+    if (bk >= n_maps) return;
+    const float lx = locs[bk * 2], ly = locs[bk * 2 + 1];
+    float acc = 0.f;
+    if (lx == lx && ly == ly && fabsf(lx) < 1e9f && fabsf(ly) < 1e9f) {
+        const int cx = (int)lx, cy = (int)ly;  // truncation toward zero, as Tensor.type(torch.int64)
+        const float* m = heat + (size_t)bk * h * w;
+        for (int dy = -radius; dy <= radius; ++dy) {
+            const int y = cy + dy;
+            for (int dx = -radius; dx <= radius; ++dx) {
+                const int x = cx + dx;
+                if (y >= 0 && y < h && x >= 0 && x < w) acc += m[y * w + x];
+            }
+        }
+    }
+    out[bk] = acc;
+}
+
 }  // namespace lp
 
 extern "C" int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w,
@@ -353,6 +375,16 @@ extern "C" int lp_heatmap_gen(const float* keypoints, const int* visibility, int
     if (B == 0) return LP_OK;
     hipLaunchKernelGGL(heatmap_gen_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, keypoints, visibility,
                        make_spec(img_h, img_w, h, w, sigma), out);
+    return launch_status();
+}
+
+extern "C" int lp_heatmap_confidence(const float* heat, const float* locs, int B, int K, int h, int w, int radius, float* out,
+                                     lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(heat && locs && out && B >= 0 && K > 0 && h > 0 && w > 0 && radius >= 0);
+    if (B == 0) return LP_OK;
+    hipLaunchKernelGGL(heatmap_confidence_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, heat, locs, B * K, h, w,
+                       radius, out);
     return launch_status();
 }
 

@@ -1,11 +1,13 @@
 """Heat-map target generation (reference: lightning_pose/data/heatmaps.py:11-87) on the lp_hip kernels.
 
-``evaluate_heatmaps_at_location`` (reference :90-142) has no standalone entry point here: the 5x5 confidence window is
-the epilogue of the fused decode kernel (``lightning_pose_amd.ops.decode``), which is the only place the training
-step calls it (models/heads/heatmap.py:129).
+``evaluate_heatmaps_at_location`` (reference :90-142) is exported in its standalone form; inside the training step the same
+5x5 confidence window is the epilogue of the fused decode kernel (``lightning_pose_amd.ops.decode``), which is where
+the reference calls it (models/heads/heatmap.py:129).
 """
 
 from __future__ import annotations
+
+import math
 
 import torch
 
@@ -29,3 +31,9 @@ def generate_heatmaps(
             "generate_heatmaps(keep_gradients=True) is only needed by the 3-D reprojection losses, which are outside the "
             "heatmap-tracker hot path implemented here")
     return ops.generate_heatmaps(keypoints, height, width, tuple(output_shape), sigma, visibility)
+
+
+def evaluate_heatmaps_at_location(heatmaps: torch.Tensor, locs: torch.Tensor, sigma: float = 1.25, num_stds: int = 2) -> torch.Tensor:
+    """(B, K, h, w) heat-maps and (B, K, 2) = (x, y) locations -> (B, K) confidence: the sum of all pixels within
+    ``floor(sigma * num_stds)`` of ``int64(loc)``, the map zero-padded by that margin (reference :90-142)."""
+    return ops.heatmap_confidence(heatmaps, locs.to(torch.float32), int(math.floor(sigma * num_stds)))

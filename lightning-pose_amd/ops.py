@@ -168,6 +168,17 @@ def generate_heatmaps(keypoints: torch.Tensor, height: int, width: int, output_s
     return out
 
 
+def heatmap_confidence(heatmaps: torch.Tensor, locs: torch.Tensor, radius: int) -> torch.Tensor:
+    require_device(heatmaps, locs)
+    heat, lc = _f32c(heatmaps), _f32c(locs)
+    b, k, h, w = heat.shape
+    if lc.shape != (b, k, 2):
+        raise ValueError(f"locs must be {(b, k, 2)}, got {tuple(lc.shape)}")
+    out = torch.empty(b, k, device=heat.device, dtype=torch.float32)
+    check(_lib.lib().lp_heatmap_confidence(_p(heat), _p(lc), b, k, h, w, int(radius), _p(out), _stream()), "lp_heatmap_confidence")
+    return out
+
+
 class _HeatmapLossFn(torch.autograd.Function):
     """masked mean over the labelled maps of a per-map sum: kind = HM_MSE / HM_KL / HM_JS"""
 

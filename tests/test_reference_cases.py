@@ -232,6 +232,45 @@ def test_generate_heatmaps_extreme_coordinates_stay_finite(dev):
     assert not _gen(dev, kp, torch.full((1, 4), 2, dtype=torch.long)).any()
 
 
+def test_evaluate_heatmaps_at_location_cases(dev):
+    """test_evaluate_heatmaps_at_location (tests/data/test_heatmaps.py:457-563): five 0.2 blobs around the location sum to exactly
+    1 for 1 / 5 frames x 1 / 6 keypoints incl. locations at the border; delta and Gaussian maps at the right, adjacent, wrong spot"""
+    from lightning_pose_amd.data.heatmaps import evaluate_heatmaps_at_location, generate_heatmaps
+
+    height, width = 24, 12
+    g = torch.Generator().manual_seed(4)
+    for n_batch in (1, 5):
+        for n_keypoints in (1, 6):
+            heatmaps = torch.zeros(n_batch, n_keypoints, height, width)
+            h_locs = torch.randint(0, height, (n_batch, n_keypoints), generator=g)
+            w_locs = torch.randint(0, width, (n_batch, n_keypoints), generator=g)
+            if n_batch == 5 and n_keypoints == 6:  # corners and edges
+                h_locs[0, :4], w_locs[0, :4] = torch.tensor([0, 0, height - 1, height - 1]), torch.tensor([0, width - 1, 0, width - 1])
+            locs = torch.stack([w_locs, h_locs], dim=2)
+            for i in range(n_batch):
+                for j in range(n_keypoints):
+                    for dy, dx in ((1, 1), (-1, -1), (0, 0), (1, -1), (-1, 1)):
+                        y = int(torch.clamp(locs[i, j, 1] + dy, 0, height - 1))
+                        x = int(torch.clamp(locs[i, j, 0] + dx, 0, width - 1))
+                        heatmaps[i, j, y, x] += 0.2
+            vals = evaluate_heatmaps_at_location(heatmaps=heatmaps.to(dev), locs=locs.to(dev)).cpu()
+            assert vals.shape == (n_batch, n_keypoints)
+            assert torch.all(vals == 1.0)
+    heatmaps = torch.zeros(1, 1, 32, 32)
+    heatmaps[0, 0, 5, 5] = 1
+    loc = lambda v: torch.full((1, 1, 2), float(v))  # noqa: E731
+    conf = lambda hm, v: evaluate_heatmaps_at_location(hm.to(dev), loc(v).to(dev)).cpu()  # noqa: E731
+    assert conf(heatmaps, 5).shape == (1, 1)
+    assert torch.allclose(conf(heatmaps, 5)[0], torch.tensor(1.0))
+    assert torch.allclose(conf(heatmaps, 6)[0], torch.tensor(1.0))
+    assert torch.allclose(conf(heatmaps, 25)[0], torch.tensor(0.0))
+    assert torch.allclose(conf(heatmaps, 5.9)[0], torch.tensor(1.0)) and torch.allclose(conf(heatmaps, 8.0)[0], torch.tensor(0.0))  # int64 truncation
+    hm_g = generate_heatmaps(loc(5).to(dev), height=32, width=32, output_shape=(32, 32)).cpu()
+    c0, c1, c2 = conf(hm_g, 5)[0], conf(hm_g, 6)[0], conf(hm_g, 25)[0]
+    assert 0 < float(c0) <= 1.0 and float(c0) > float(c1)
+    assert torch.allclose(c2, torch.tensor(0.0))
+
+
 def test_generate_heatmaps_detaches(dev):
     """TestGenerateHeatmaps::test_keep_gradients, the keep_gradients=False half (the True half belongs to the 3-D reprojection losses,
     outside this path: it raises instead of silently dropping the gradient)"""
