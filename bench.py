@@ -73,6 +73,64 @@ def synth_batch(dev, rank: int, size: int, n_lab: int, n_unlab: int, K: int):
     }
 
 
+def synth_multiview_batch(dev, rank: int, size: int, n_lab: int, n_unlab: int, K: int, V: int):
+    """Config C5: V views per frame, keypoint axis K*V (views of one frame stay on one GPU).  Every view sees
+    the same 3-D random walk through its own affine "camera", so the multiview PCA loss has a low-dimensional structure to find."""
+    from lightning_pose_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    cams = torch.eye(2).repeat(V, 1, 1) + 0.25 * torch.randn(V, 2, 2, generator=g)        # per-view linear map of the common track
+    shift = torch.rand(V, 1, 2, generator=g) * size * 0.2
+
+    def tracks(n):
+        base = torch.cumsum(torch.randn(n, K, 2, generator=g) * 3.0, dim=0) + size * (0.3 + 0.4 * torch.rand(1, K, 2, generator=g))
+        per_view = torch.einsum("vij,nkj->nvki", cams, base - size / 2) + size / 2 + shift.unsqueeze(0)
+        return per_view.clamp(6, size - 6)                                                 # (n, V, K, 2)
+
+    def render(centres):                                                                   # (n, V, K, 2) -> (n, V, 3, size, size)
+        n = centres.shape[0]
+        c = centres.reshape(n * V, K, 2).to(dev)
+        ys = torch.arange(size, device=dev).view(1, 1, size, 1).float()
+        xs = torch.arange(size, device=dev).view(1, 1, 1, size).float()
+        img = torch.randn(n * V, 3, size, size, generator=g).to(dev) * 0.5
+        for k0 in range(K):
+            img += 3.0 * torch.exp(-((xs - c[:, k0, 0].view(-1, 1, 1, 1)) ** 2 + (ys - c[:, k0, 1].view(-1, 1, 1, 1)) ** 2) / 72.0)
+        return img.reshape(n, V, 3, size, size)
+
+    lab = tracks(n_lab)
+    kp = lab.reshape(n_lab, V * K, 2).clone()
+    nan = torch.rand(n_lab, V * K, generator=g) < 0.088
+    kp[nan] = float("nan")
+    vis = torch.where(nan, torch.ones_like(nan, dtype=torch.int32), torch.full_like(nan, 2, dtype=torch.int32))
+    heat = ops.generate_heatmaps(kp.to(dev), size, size, (size // 4, size // 4), 1.25, vis.to(dev))
+    unl = tracks(n_unlab)
+    bbox = torch.tensor([[0.0, 0.0, float(size), float(size)] * V])
+    tfs = []
+    for _ in range(V):  # one augmentation matrix per view (data/video/dali.py:158-164)
+        th = math.radians(float(torch.rand(1, generator=g)) * 20 - 10)
+        sc = 0.8 + 0.4 * float(torch.rand(1, generator=g))
+        c = size / 2
+        a = torch.tensor([[sc * math.cos(th), -sc * math.sin(th), 0.0], [sc * math.sin(th), sc * math.cos(th), 0.0]])
+        a[:, 2] = torch.tensor([c, c]) - a[:, :2] @ torch.tensor([c, c])
+        tfs.append(a)
+    return {
+        "labeled": {"images": render(lab), "keypoints": kp.reshape(n_lab, 2 * K * V).to(dev), "heatmaps": heat,
+                    "bbox": bbox.repeat(n_lab, 1).to(dev), "num_views": torch.full((n_lab,), V), "idxs": torch.arange(n_lab)},
+        "unlabeled": {"frames": render(unl), "transforms": torch.stack(tfs).to(dev), "bbox": bbox.repeat(n_unlab, 1).to(dev),
+                      "is_multiview": True},
+    }
+
+
+def multiview_pca_training_array(K: int, V: int, size: int) -> torch.Tensor:
+    """Stand-in for the labelled multiview keypoints the PCA is fitted on: (N, 2*K*V), rows = frames, view-major keypoint axis; the views
+    are affine images of a common 3-D point cloud, so 3 components explain them (the reference keeps 3, losses/losses.py:505-508)."""
+    g = torch.Generator().manual_seed(98)
+    pts = torch.randn(400, K, 3, generator=g) * (size / 8)
+    proj = torch.randn(V, 2, 3, generator=g)
+    obs = torch.einsum("vij,nkj->nvki", proj, pts) + size / 2 + torch.randn(400, V, K, 2, generator=g)
+    return obs.reshape(400, V * K * 2)
+
+
 def pca_training_array(K: int, size: int) -> torch.Tensor:
     """Synthetic stand-in for the labelled keypoints the PCA is fitted on (no dataset files on the GPU box)."""
     g = torch.Generator().manual_seed(99)
@@ -81,12 +139,21 @@ def pca_training_array(K: int, size: int) -> torch.Tensor:
     return data
 
 
-def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "resnet50"):
+def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "resnet50", views: int = 1):
     from lightning_pose_amd.losses import LossFactory
     from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
 
     cols = [k for k in range(K) if k not in (7, 15, 16)] if K == 17 else list(range(K))
     sup = LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    if views > 1:  # config C5: pca_multiview + temporal (BASELINE.json configs[4]); keypoint k of view v is column v*K + k
+        mcm = [[v * K + k for k in range(K)] for v in range(views)]
+        unsup = LossFactory({
+            "temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05},
+            "pca_multiview": {"loss_name": "pca_multiview", "log_weight": 5.0, "components_to_keep": 3, "mirrored_column_matches": mcm,
+                              "data_arr": multiview_pca_training_array(K, views, size), "device": str(dev)},
+        }, None)
+        return SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone=backbone,
+                                            downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev)
     unsup = LossFactory({
         "temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05},
         "pca_singleview": {"loss_name": "pca_singleview", "log_weight": 5.0, "components_to_keep": 0.99,
@@ -156,6 +223,8 @@ def main() -> None:
     ap.add_argument("--keypoints", type=int, default=17)
     ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "vits_dino", "vitb_dino"],
                     help="resnet50 = BASELINE configs C2/C3 (the headline metric); vits_dino = config C4")
+    ap.add_argument("--views", type=int, default=1, help="4 = BASELINE config C5 (multiview: --size 256 --labeled 16 --unlabeled 32 "
+                    "gives the same 192 images per GPU); frames/s then counts view-images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args()
@@ -173,8 +242,11 @@ def main() -> None:
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
-    model = build_model(dev, args.keypoints, args.size, backbone=args.backbone)
-    batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
+    model = build_model(dev, args.keypoints, args.size, backbone=args.backbone, views=args.views)
+    if args.views > 1:
+        batch = synth_multiview_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints, args.views)
+    else:
+        batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True)
     trainer.setup(model)
     model.train()
@@ -216,7 +288,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    frames_per_step = (args.labeled + args.unlabeled) * world
+    frames_per_step = (args.labeled + args.unlabeled) * args.views * world
     value = frames_per_step * args.steps / elapsed
     is_vit = args.backbone != "resnet50"
     arch = {"resnet50": "ResNet-50", "vits_dino": "ViT-S/16", "vitb_dino": "ViT-B/16"}[args.backbone]
@@ -227,7 +299,10 @@ def main() -> None:
         "host_enqueue_idle_queue_ms": round(1000 * host_idle_queue, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
+        "config": {"workload": (f"C5: multiview {arch} SemiSupervisedHeatmapTracker, {args.views} views x {args.size}x{args.size}, K={args.keypoints} per "
+                                f"view, {args.labeled} labeled + {args.unlabeled} unlabeled frames (x {args.views} views) per GPU, heatmap_mse + "
+                                "temporal + pca_multiview, Adam (backbone lr=0 as at step 0), bf16-mixed; value counts view-images") if args.views > 1 else
+                               f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
                                "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": world > 1,
@@ -269,7 +344,7 @@ def main() -> None:
         if gf:
             out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
             out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
-        if world == 1 and not args.no_cpu_baseline and not is_vit:
+        if world == 1 and not args.no_cpu_baseline and not is_vit and args.views == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)
             except Exception as e:  # noqa: BLE001 - the baseline must never cost the measured line
