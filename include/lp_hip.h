@@ -93,6 +93,16 @@ int lp_frame_map_apply(const float* kp_in, int B, int K, const lp_frame_map* fra
 int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w, float sigma,
                    float* out, lp_stream_t stream);
 
+/* losses/losses.py:706-869 TemporalHeatmapLoss ("temporal_heatmap_mse" = LP_HM_MSE, "temporal_heatmap_kl" = LP_HM_KL): distance
+ * between the heat-maps of consecutive frames per keypoint, zeroed where either frame's confidence < prob_threshold, relu(. - epsilon[k]),
+ * mean over all (S-1)*K entries.  pred (S,K,h,w), conf (S,K), epsilon (K) device floats; workspace persists to bwd; loss is a device
+ * scalar (NaN for S = 1, the mean of an empty tensor).  bwd: gpred (S,K,h,w) = or += gout * d loss / d pred. */
+size_t lp_temporal_heatmap_workspace_bytes(int S, int K);
+int lp_temporal_heatmap_fwd(int kind, const float* pred, const float* conf, int S, int K, int h, int w, const float* epsilon,
+                            float prob_threshold, float* loss, void* workspace, lp_stream_t stream);
+int lp_temporal_heatmap_bwd(int kind, const float* pred, int S, int K, int h, int w, const void* workspace, const float* gout,
+                            float* gpred, int accumulate, lp_stream_t stream);
+
 /* data/heatmaps.py:90-142 evaluate_heatmaps_at_location: out (B,K) = sum of the (2*radius+1)^2 window of heat (B,K,h,w) around
  * int64(locs (B,K,2) = x, y), zero padded; radius = floor(sigma * num_stds) (2 for the defaults).  The training step gets the
  * same number from lp_decode_fwd's epilogue; this is the standalone form the reference exports. */

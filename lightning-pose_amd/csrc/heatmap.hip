@@ -366,6 +366,77 @@ __global__ __launch_bounds__(256) void heatmap_confidence_kernel(const float* __
     out[bk] = acc;
 }
 
+// ---- TemporalHeatmapLoss (losses/losses.py:706-869): per (t, k) a distance between the heat-maps of frames t and t+1 -----------
+//   temporal_heatmap_mse: mean over pixels of (p_t - p_t+1)^2                                             (:815-819)
+//   temporal_heatmap_kl : kornia kl_div_loss_2d(pred = p_t + 1e-10, target = p_t+1 + 1e-10, 'none')
+//                         = sum target (log target - log pred)                                            (:820-826)
+// then: 0 where conf_t or conf_t+1 < prob_threshold (:783-791), relu(d - epsilon_k) (:763), mean over ALL (S-1) K entries (:865).
+// pass 1: one workgroup per (t, k), t < S-1 -> d[t][k]
+__global__ __launch_bounds__(256) void temporal_hm_dist_kernel(const float* __restrict__ pred, int K, int n, int kind, float* __restrict__ d) {
+    __shared__ float red[4];
+    const int tk = blockIdx.x;  // t * K + k
+    const float* a = pred + (size_t)tk * n;        // frame t
+    const float* b = a + (size_t)K * n;            // frame t + 1
+    float part = 0.f;
+    if (kind == LP_HM_MSE) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float df = a[i] - b[i];
+            part = fmaf(df, df, part);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float pe = a[i] + 1e-10f, te = b[i] + 1e-10f;
+            part += te * (logf(te) - logf(pe));
+        }
+    }
+    const float tot = block_sum<4>(part, red);
+    if (threadIdx.x == 0) d[tk] = kind == LP_HM_MSE ? tot / (float)n : tot;
+}
+
+// pass 2 (one workgroup): mask, epsilon, mean; act[t][k] = 1 where the rectified term is active (its gradient is non-zero)
+__global__ __launch_bounds__(256) void temporal_hm_finish_kernel(const float* __restrict__ d, const float* __restrict__ conf,
+                                                                 const float* __restrict__ eps, float thr, int S, int K,
+                                                                 float* __restrict__ act, float* __restrict__ loss) {
+    __shared__ float red[4];
+    const int rows = (S - 1) * K;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        const int k = i % K;
+        const bool ignore = (conf[i] < thr) || (conf[i + K] < thr);
+        const float v = (ignore ? 0.f : d[i]) - eps[k];
+        const bool on = v > 0.f;
+        s += on ? v : 0.f;
+        act[i] = (on && !ignore) ? 1.f : 0.f;
+    }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) loss[0] = s / (float)rows;  // S == 1: 0 / 0 = NaN, the mean of an empty tensor
+}
+
+// backward: the map of frame t takes part in the pairs (t-1, t) and (t, t+1)
+__global__ __launch_bounds__(256) void temporal_hm_grad_kernel(const float* __restrict__ pred, const float* __restrict__ act, int S, int K, int n,
+                                                               int kind, const float* __restrict__ gout, float* __restrict__ gpred,
+                                                               int accumulate) {
+    const int tk = blockIdx.x, t = tk / K;
+    const float scale = gout[0] / (float)((S - 1) * K);
+    const float w_next = (t < S - 1) ? act[tk] * scale : 0.f;      // pair (t, t+1): this map is the first argument
+    const float w_prev = (t > 0) ? act[tk - K] * scale : 0.f;      // pair (t-1, t): this map is the second argument
+    const float* p = pred + (size_t)tk * n;
+    float* gp = gpred + (size_t)tk * n;
+    const float inv_n = 1.f / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float gv = 0.f;
+        if (w_next != 0.f) {
+            const float q = p[i + (size_t)K * n];
+            gv += w_next * (kind == LP_HM_MSE ? 2.f * (p[i] - q) * inv_n : -(q + 1e-10f) / (p[i] + 1e-10f));
+        }
+        if (w_prev != 0.f) {
+            const float q = p[(ptrdiff_t)i - (ptrdiff_t)K * n];
+            gv += w_prev * (kind == LP_HM_MSE ? 2.f * (p[i] - q) * inv_n : logf(p[i] + 1e-10f) - logf(q + 1e-10f) + 1.f);
+        }
+        gp[i] = accumulate ? gp[i] + gv : gv;
+    }
+}
+
 }  // namespace lp
 
 extern "C" int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w,
@@ -385,6 +456,33 @@ extern "C" int lp_heatmap_confidence(const float* heat, const float* locs, int B
     if (B == 0) return LP_OK;
     hipLaunchKernelGGL(heatmap_confidence_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, heat, locs, B * K, h, w,
                        radius, out);
+    return launch_status();
+}
+
+// workspace layout: float d[(S-1)*K] | float act[(S-1)*K]
+extern "C" size_t lp_temporal_heatmap_workspace_bytes(int S, int K) { return (size_t)(S > 1 ? S - 1 : 1) * K * 8 + 16; }
+
+extern "C" int lp_temporal_heatmap_fwd(int kind, const float* pred, const float* conf, int S, int K, int h, int w, const float* epsilon,
+                                       float prob_threshold, float* loss, void* workspace, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(pred && conf && epsilon && loss && workspace && S > 0 && K > 0 && h > 0 && w > 0);
+    LP_REQUIRE(kind == LP_HM_MSE || kind == LP_HM_KL);
+    float* d = (float*)workspace;
+    float* act = d + (size_t)(S > 1 ? S - 1 : 1) * K;
+    hipStream_t st = (hipStream_t)stream;
+    if (S > 1) hipLaunchKernelGGL(temporal_hm_dist_kernel, dim3((S - 1) * K), dim3(256), 0, st, pred, K, h * w, kind, d);
+    hipLaunchKernelGGL(temporal_hm_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)d, conf, epsilon, prob_threshold, S, K, act, loss);
+    return launch_status();
+}
+
+extern "C" int lp_temporal_heatmap_bwd(int kind, const float* pred, int S, int K, int h, int w, const void* workspace, const float* gout,
+                                       float* gpred, int accumulate, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(pred && workspace && gout && gpred && S > 0 && K > 0 && h > 0 && w > 0);
+    LP_REQUIRE(kind == LP_HM_MSE || kind == LP_HM_KL);
+    const float* act = (const float*)workspace + (size_t)(S > 1 ? S - 1 : 1) * K;
+    hipLaunchKernelGGL(temporal_hm_grad_kernel, dim3(S * K), dim3(256), 0, (hipStream_t)stream, pred, act, S, K, h * w, kind, gout, gpred,
+                       accumulate);
     return launch_status();
 }
 

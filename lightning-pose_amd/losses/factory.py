@@ -7,14 +7,14 @@ from typing import Any, Literal
 import numpy as np
 import torch
 
-from .losses import HeatmapJSLoss, HeatmapKLLoss, HeatmapMSELoss, Loss, PCALoss, TemporalLoss, UnimodalLoss
+from .losses import HeatmapJSLoss, HeatmapKLLoss, HeatmapMSELoss, Loss, PCALoss, TemporalHeatmapLoss, TemporalLoss, UnimodalLoss
 
 _HEATMAP_LOSSES = ("heatmap_mse", "heatmap_kl", "heatmap_js")
 
 
 def get_loss_classes() -> dict[str, type[Loss]]:
-    """Loss name -> class (reference :73-91).  Names outside the heatmap-tracker hot path (temporal_heatmap_*, regression, the
-    3-D supervised losses) are not registered here; ``unimodal_mse`` is added."""
+    """Loss name -> class (reference :73-91).  Names outside the heatmap-tracker hot path (regression, the 3-D supervised losses)
+    are not registered here; ``unimodal_mse`` is added."""
     return {
         HeatmapMSELoss.loss_name: HeatmapMSELoss,
         HeatmapKLLoss.loss_name: HeatmapKLLoss,
@@ -22,6 +22,8 @@ def get_loss_classes() -> dict[str, type[Loss]]:
         PCALoss.LOSS_NAME_MULTIVIEW: PCALoss,
         PCALoss.LOSS_NAME_SINGLEVIEW: PCALoss,
         TemporalLoss.loss_name: TemporalLoss,
+        TemporalHeatmapLoss.LOSS_NAME_MSE: TemporalHeatmapLoss,
+        TemporalHeatmapLoss.LOSS_NAME_KL: TemporalHeatmapLoss,
         UnimodalLoss.loss_name: UnimodalLoss,
     }
 

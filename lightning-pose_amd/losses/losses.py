@@ -18,7 +18,7 @@ import torch
 from .. import ops
 from ..utils.pca import KeypointPCA
 
-__all__ = ["Loss", "HeatmapLoss", "HeatmapMSELoss", "TemporalLoss", "PCALoss", "UnimodalLoss", "RegressionRMSELoss"]
+__all__ = ["Loss", "HeatmapLoss", "HeatmapMSELoss", "TemporalLoss", "TemporalHeatmapLoss", "PCALoss", "UnimodalLoss", "RegressionRMSELoss"]
 
 _DEFAULT_TORCH_DEVICE = "cpu"
 if torch.cuda.is_available():
@@ -122,6 +122,49 @@ class TemporalLoss(Loss):
     def __call__(self, keypoints_pred: torch.Tensor, confidences: torch.Tensor | None = None,
                  stage: Literal["train", "val", "test"] | None = None, **kwargs: Any):
         scalar_loss = ops.temporal_loss(keypoints_pred, confidences, self.epsilon, float(self.prob_threshold))
+        return scalar_loss, self.log_loss(loss=scalar_loss, stage=stage)
+
+
+class TemporalHeatmapLoss(Loss):
+    """mean over (S-1) x K of relu(d(heatmap[t], heatmap[t+1]) - eps_k), d = pixel-mean squared difference
+    ("temporal_heatmap_mse") or KL(heatmap[t+1] || heatmap[t]) ("temporal_heatmap_kl"), zeroed next to low-confidence frames
+    (reference :706-869)."""
+
+    LOSS_NAME_MSE = "temporal_heatmap_mse"
+    LOSS_NAME_KL = "temporal_heatmap_kl"
+
+    def __init__(self, loss_name: Literal["temporal_heatmap_mse", "temporal_heatmap_kl"], data_module: Any = None,
+                 epsilon: float | list[float] = 0.0, prob_threshold: float = 0.0, log_weight: float = 0.0, **kwargs: Any) -> None:
+        super().__init__(data_module=data_module, epsilon=epsilon, log_weight=log_weight)
+        if loss_name not in (self.LOSS_NAME_MSE, self.LOSS_NAME_KL):
+            raise ValueError(f"Invalid loss_name: {loss_name}")
+        self.loss_name = loss_name
+        self.prob_threshold = torch.tensor(prob_threshold, dtype=torch.float)
+
+    @property
+    def _kind(self) -> int:
+        from .._lib import HM_KL, HM_MSE
+
+        return HM_MSE if self.loss_name == self.LOSS_NAME_MSE else HM_KL
+
+    def compute_loss(self, predictions: torch.Tensor) -> torch.Tensor:
+        """(S, K, h, w) -> (S-1, K) distances between consecutive heat-maps (reference :793-829); diagnostic, not differentiable."""
+        return ops.temporal_heatmap_distances(predictions, self._kind)
+
+    def remove_nans(self, confidences: torch.Tensor, loss: torch.Tensor) -> torch.Tensor:
+        """Zero the entries next to a frame whose confidence is below ``prob_threshold``, in place (reference :766-791)."""
+        ignore = confidences < self.prob_threshold.to(confidences.device)
+        loss[torch.logical_or(ignore[:-1], ignore[1:]).to(loss.device)] = 0.0
+        return loss
+
+    def rectify_epsilon(self, loss: torch.Tensor) -> torch.Tensor:
+        """per-keypoint epsilon broadcast over the (S-1) rows (reference :754-764)"""
+        return torch.relu(loss - self.epsilon.to(loss.device).reshape(1, -1))
+
+    def __call__(self, heatmaps_pred: torch.Tensor, confidences: torch.Tensor, stage: Literal["train", "val", "test"] | None = None,
+                 **kwargs: Any):
+        kind = self._kind
+        scalar_loss = ops.temporal_heatmap_loss(heatmaps_pred, confidences, self.epsilon, float(self.prob_threshold), kind)
         return scalar_loss, self.log_loss(loss=scalar_loss, stage=stage)
 
 

@@ -288,6 +288,62 @@ def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None, eps
     return _UnitGradFn.apply(keypoints, loss.reshape(()), grad)
 
 
+class _TemporalHeatmapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, conf, eps, thr, kind):
+        require_device(pred, conf)
+        ctx.in_dtype = pred.dtype
+        pred, conf = _f32c(pred), _f32c(conf)
+        s, k, h, w = pred.shape
+        ws = torch.empty(_lib.lib().lp_temporal_heatmap_workspace_bytes(s, k), device=pred.device, dtype=torch.uint8)
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        check(_lib.lib().lp_temporal_heatmap_fwd(kind, _p(pred), _p(conf), s, k, h, w, _p(eps), float(thr), _p(loss), _p(ws), _stream()),
+              "lp_temporal_heatmap_fwd")
+        ctx.save_for_backward(pred, ws)
+        ctx.kind = kind
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, ws = ctx.saved_tensors
+        s, k, h, w = pred.shape
+        g = torch.empty_like(pred)
+        go = _f32c(gout).reshape(1)
+        check(_lib.lib().lp_temporal_heatmap_bwd(ctx.kind, _p(pred), s, k, h, w, _p(ws), _p(go), _p(g), 0, _stream()),
+              "lp_temporal_heatmap_bwd")
+        return g.to(ctx.in_dtype), None, None, None, None
+
+
+def temporal_heatmap_distances(heatmaps_pred: torch.Tensor, kind: int) -> torch.Tensor:
+    """(S, K, h, w) -> (S-1, K) distances between consecutive heat-maps (TemporalHeatmapLoss.compute_loss, reference :793-829);
+    no autograd (the differentiable form is ``temporal_heatmap_loss``)."""
+    require_device(heatmaps_pred)
+    pred = _f32c(heatmaps_pred)
+    s, k, h, w = pred.shape
+    if s < 2:
+        return torch.zeros(0, k, device=pred.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().lp_temporal_heatmap_workspace_bytes(s, k), device=pred.device, dtype=torch.uint8)
+    conf = torch.ones(s, k, device=pred.device, dtype=torch.float32)
+    eps = torch.zeros(k, device=pred.device, dtype=torch.float32)
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    check(_lib.lib().lp_temporal_heatmap_fwd(kind, _p(pred), _p(conf), s, k, h, w, _p(eps), 0.0, _p(loss), _p(ws), _stream()),
+          "lp_temporal_heatmap_fwd")
+    return ws[: (s - 1) * k * 4].view(torch.float32).reshape(s - 1, k).clone()
+
+
+def temporal_heatmap_loss(heatmaps_pred: torch.Tensor, confidences: torch.Tensor, epsilon: torch.Tensor, prob_threshold: float,
+                          kind: int) -> torch.Tensor:
+    """(S, K, h, w) heat-maps, (S, K) confidences -> scalar (reference losses/losses.py:841-869); kind = HM_MSE | HM_KL."""
+    k = heatmaps_pred.shape[1]
+    eps = epsilon.to(device=heatmaps_pred.device, dtype=torch.float32).reshape(-1)
+    eps = eps.expand(k).contiguous() if eps.numel() == 1 else eps.contiguous()
+    if eps.numel() != k:
+        raise ValueError(f"temporal heat-map epsilon must be a scalar or have one entry per keypoint ({k}), got {eps.numel()}")
+    if tuple(confidences.shape) != tuple(heatmaps_pred.shape[:2]):
+        raise ValueError(f"confidences must be {tuple(heatmaps_pred.shape[:2])}, got {tuple(confidences.shape)}")
+    return _TemporalHeatmapFn.apply(heatmaps_pred, confidences, eps, float(prob_threshold), kind)
+
+
 def pca_loss(keypoints: torch.Tensor, index: torch.Tensor, mean: torch.Tensor, kept_eigenvectors: torch.Tensor, epsilon: float):
     """keypoints (S, 2K); index (rows, points) int32 keypoint ids per PCA sample -> scalar (losses/losses.py:548-573)."""
     require_device(keypoints, index, mean, kept_eigenvectors)

@@ -451,9 +451,33 @@ def gen_labeled_targets():
     save("labeled_targets", **out)
 
 
+def gen_temporal_heatmap():
+    """TemporalHeatmapLoss (losses/losses.py:706-869), verbatim: mse / kl, scalar and per-keypoint epsilon, confidence threshold."""
+    L = R.load("losses.losses")
+    g = torch.Generator().manual_seed(21)
+    S, K, h, w = 6, 4, 16, 16
+    hm = peaked_heatmaps(g, S, K, h, w, sharp=0.6)
+    hm[3, 1] = hm[2, 1]                      # an identical pair: distance exactly 0
+    conf = torch.rand(S, K, generator=g)
+    out = dict(hm=hm, conf=conf)
+    cases = {"mse_plain": ("temporal_heatmap_mse", 0.0, 0.0), "kl_plain": ("temporal_heatmap_kl", 0.0, 0.0),
+             "mse_thr": ("temporal_heatmap_mse", 0.0, 0.4), "kl_thr_eps": ("temporal_heatmap_kl", 0.5, 0.4),
+             "mse_eps_list": ("temporal_heatmap_mse", [0.0, 2e-5, 1e-4, 1.0], 0.2)}
+    for tag, (name, eps, thr) in cases.items():
+        loss = L.TemporalHeatmapLoss(loss_name=name, epsilon=eps, prob_threshold=thr, log_weight=1.5)
+        p = hm.clone().requires_grad_(True)
+        val, logs = loss(heatmaps_pred=p, confidences=conf, stage="train")
+        (0.7 * val).backward()
+        out[f"{tag}_loss"], out[f"{tag}_grad"] = val, p.grad
+        out[f"{tag}_elementwise"] = loss.compute_loss(predictions=hm)
+    out["log_names"] = np.array([d["name"] for d in logs])
+    out["weight"] = logs[1]["value"]
+    save("temporal_heatmap", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     GENS = {"decode": gen_decode, "heatmaps": gen_heatmaps, "geometry": gen_geometry, "losses": gen_losses,
-            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions, "labeled_targets": gen_labeled_targets}
+            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions, "labeled_targets": gen_labeled_targets, "temporal_heatmap": gen_temporal_heatmap}
     for name in (sys.argv[1:] or list(GENS)):  # `make_golden.py predictions` regenerates one fixture only
         GENS[name]()

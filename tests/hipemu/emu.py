@@ -600,3 +600,15 @@ def labeled_keypoints(kp, src_hw, H, W, affine=None, hflip=None, swap=None, vis=
     out, vout = Z((b, k, 2)), Z((b, k), np.int32)
     ok(lib().lp_labeled_keypoints(kb.p, hb.p, ptr(ab), ptr(fb), ptr(sb), ptr(vb), int(uniform), b, k, H, W, out.p, vout.p, stream()))
     return out.np(), vout.np()
+
+
+def temporal_heatmap(kind, pred, conf, eps, thr, gout=1.0):
+    pred, conf = f32(pred), f32(conf)
+    s, k, h, w = pred.shape
+    eps = np.broadcast_to(f32(eps).reshape(-1), (k,)) if np.size(eps) == 1 else f32(eps)
+    pb, cb, eb = Buf(pred), Buf(conf), Buf(f32(eps))
+    ws = Z((lib().lp_temporal_heatmap_workspace_bytes(s, k),), np.uint8)
+    loss, grad, go = Z((1,)), Z(pred.shape), Buf(f32([gout]))
+    ok(lib().lp_temporal_heatmap_fwd(kind, pb.p, cb.p, s, k, h, w, eb.p, thr, loss.p, ws.p, stream()))
+    ok(lib().lp_temporal_heatmap_bwd(kind, pb.p, s, k, h, w, ws.p, go.p, grad.p, 0, stream()))
+    return float(loss.np()[0]), grad.np()

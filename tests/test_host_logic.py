@@ -126,8 +126,12 @@ def test_registry_surface_and_validation():
     with pytest.raises(ValueError, match="embedding"):
         _validate_loss_model_compatibility(SemiSupervisedHeatmapTracker, facs)
     assert {"heatmap_kl", "heatmap_js"} <= set(get_loss_classes())
+    assert {"temporal_heatmap_mse", "temporal_heatmap_kl"} <= set(get_loss_classes())
+    _validate_loss_model_compatibility(SemiSupervisedHeatmapTracker, {
+        "supervised": facs["supervised"],
+        "unsupervised": LossFactory({"temporal_heatmap_kl": {"loss_name": "temporal_heatmap_kl", "log_weight": 5.0}}, None)})
     with pytest.raises(NotImplementedError):
-        LossFactory({"temporal_heatmap_mse": {"log_weight": 0.0}}, None)
+        LossFactory({"regression": {"log_weight": 0.0}}, None)
     # constructor signature of the reference classes is preserved
     sig = inspect.signature(SemiSupervisedHeatmapTracker.__init__)
     for name in ("num_keypoints", "loss_factory", "loss_factory_unsupervised", "backbone", "downsample_factor", "pretrained",

@@ -114,6 +114,57 @@ def test_temporal_loss_cases(dev):
     assert float(with_conf) == pytest.approx(float(without) / 2, abs=1e-6)  # exactly one of the two keypoints is left
 
 
+def test_temporal_heatmap_loss_cases(dev):
+    """TestTemporalHeatmapLoss (tests/losses/test_losses.py:411-503): invalid name, zero for constant maps (mse exactly, kl to 1e-5),
+    positive for varying maps, compute_loss shape, low-confidence masking, epsilon rectification; plus the composition identity"""
+    from lightning_pose_amd.losses import TemporalHeatmapLoss
+    from lightning_pose_amd.losses.factory import get_loss_classes
+
+    assert get_loss_classes()["temporal_heatmap_mse"] is TemporalHeatmapLoss and get_loss_classes()["temporal_heatmap_kl"] is TemporalHeatmapLoss
+    with pytest.raises(ValueError):
+        TemporalHeatmapLoss(loss_name="bad_name")
+    mse, kl = TemporalHeatmapLoss(loss_name="temporal_heatmap_mse"), TemporalHeatmapLoss(loss_name="temporal_heatmap_kl")
+    g = torch.Generator().manual_seed(8)
+    S, K, h, w = 4, 3, 16, 16
+    ones = torch.ones(S, K).to(dev)
+    frame = torch.rand(1, K, h, w, generator=g)
+    loss, logs = mse(heatmaps_pred=frame.expand(S, -1, -1, -1).clone().to(dev), confidences=ones, stage=STAGE)
+    assert loss.shape == torch.Size([]) and loss.item() == 0.0
+    assert logs[0]["name"] == f"{STAGE}_temporal_heatmap_mse_loss" and logs[1]["name"] == "temporal_heatmap_mse_weight"
+    loss, _ = mse(heatmaps_pred=torch.rand(S, K, h, w, generator=g).to(dev), confidences=ones, stage=STAGE)
+    assert loss.item() > 0.0
+    sm = lambda x: torch.softmax(x.reshape(*x.shape[:2], -1), -1).reshape(x.shape)  # noqa: E731  (kornia spatial_softmax2d)
+    frame = sm(torch.randn(1, K, h, w, generator=g))
+    loss, logs = kl(heatmaps_pred=frame.expand(S, -1, -1, -1).clone().to(dev), confidences=ones, stage=STAGE)
+    assert loss.shape == torch.Size([]) and torch.isclose(loss.cpu(), torch.tensor(0.0), atol=1e-5)
+    assert logs[0]["name"] == f"{STAGE}_temporal_heatmap_kl_loss"
+    varying = sm(torch.randn(S, K, h, w, generator=g))
+    loss, _ = kl(heatmaps_pred=varying.to(dev), confidences=ones, stage=STAGE)
+    assert loss.item() > 0.0
+    assert mse.compute_loss(torch.rand(5, K, h, w, generator=g).to(dev)).shape == (4, K)
+    assert kl.compute_loss(sm(torch.randn(5, K, h, w, generator=g)).to(dev)).shape == (4, K)
+    # low-confidence masking
+    mse.prob_threshold = torch.tensor(0.5)
+    pred = torch.rand(3, 2, 8, 8, generator=g)
+    conf = torch.zeros(3, 2)
+    conf[:, 1] = 1.0
+    diffs = mse.compute_loss(pred.to(dev))
+    want = ((pred[1:] - pred[:-1]) ** 2).mean((-1, -2))
+    torch.testing.assert_close(diffs.cpu(), want, rtol=1e-5, atol=1e-8)
+    clean = mse.remove_nans(confidences=conf.to(dev), loss=diffs.clone())
+    assert torch.all(clean[:, 0] == 0.0) and torch.all(clean[:, 1] > 0.0)
+    # epsilon rectification
+    mse.epsilon = torch.tensor(1.0)
+    rect = mse.rectify_epsilon(torch.tensor([[0.5, 2.0], [1.5, 0.3]]))
+    assert rect[0, 0] == 0.0 and rect[0, 1] > 0.0 and rect[1, 0] > 0.0 and rect[1, 1] == 0.0
+    # __call__ == reduce(rectify(remove_nans(compute_loss))) with a per-keypoint epsilon
+    loss_obj = TemporalHeatmapLoss(loss_name="temporal_heatmap_kl", epsilon=[0.0, 0.05, 10.0], prob_threshold=0.3)
+    conf = torch.rand(S, K, generator=g)
+    got, _ = loss_obj(heatmaps_pred=varying.to(dev), confidences=conf.to(dev), stage=None)
+    parts = loss_obj.rectify_epsilon(loss_obj.remove_nans(conf.to(dev), loss_obj.compute_loss(varying.to(dev))))
+    assert float(got) == pytest.approx(float(loss_obj.reduce_loss(parts)), rel=1e-5)
+
+
 def test_rmse_loss(dev):
     """TestRegressionRMSELoss: equal -> 0; targets 2 vs predictions 0 -> exactly 2; NaN targets are skipped"""
     from lightning_pose_amd.losses.losses import RegressionRMSELoss

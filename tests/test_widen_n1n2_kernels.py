@@ -180,3 +180,23 @@ def test_labeled_keypoints_hflip_swap_and_explicit_visibility(golden):
     np.testing.assert_allclose(np.nan_to_num(kp), np.nan_to_num(want_kp.numpy()), atol=5e-5)
     # un-flipped samples are just the resize projection
     np.testing.assert_allclose(np.nan_to_num(kp[1]), np.nan_to_num((kp_src[1] * torch.tensor([256 / 396, 256 / 406])).numpy()), atol=5e-5)
+
+
+# ------------------------------------------------------------------------------------ TemporalHeatmapLoss (losses/losses.py:706-869)
+@pytest.mark.parametrize("tag,kind,eps,thr", [("mse_plain", _lib.HM_MSE, 0.0, 0.0), ("kl_plain", _lib.HM_KL, 0.0, 0.0),
+                                              ("mse_thr", _lib.HM_MSE, 0.0, 0.4), ("kl_thr_eps", _lib.HM_KL, 0.5, 0.4),
+                                              ("mse_eps_list", _lib.HM_MSE, [0.0, 2e-5, 1e-4, 1.0], 0.2)])
+def test_temporal_heatmap_loss_matches_verbatim_class(golden, tag, kind, eps, thr):
+    g = golden("temporal_heatmap")
+    loss, grad = emu.temporal_heatmap(kind, g["hm"], g["conf"], eps, thr, gout=0.7)
+    assert loss == pytest.approx(float(g[f"{tag}_loss"]), rel=2e-5, abs=1e-9)
+    scale = np.abs(g[f"{tag}_grad"]).max()
+    np.testing.assert_allclose(grad, g[f"{tag}_grad"], atol=2e-5 * max(scale, 1e-12), rtol=2e-4)
+    assert np.abs(g[f"{tag}_grad"]).max() > 0
+
+
+def test_temporal_heatmap_single_frame_is_nan():
+    hm = np.full((1, 2, 4, 4), 1 / 16, np.float32)
+    loss, grad = emu.temporal_heatmap(_lib.HM_MSE, hm, np.ones((1, 2), np.float32), 0.0, 0.0)
+    assert np.isnan(loss)  # the reference takes the mean of an empty (0, K) tensor
+    assert not grad.any()

@@ -134,3 +134,35 @@ def test_producers_feed_the_training_step(stack_backend):
     opt.step()
     assert torch.isfinite(loss).item()
     assert float(model.logged["train_heatmap_mse_loss"]) > 0
+
+
+def test_temporal_heatmap_losses_train_through_the_tracker(stack_backend):
+    """temporal_heatmap_mse / _kl as unsupervised losses of the semi-supervised tracker: value equals the oracle formula on the
+    tracker's own heat-maps, and the gradient reaches the trunk"""
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+
+    dev = stack_backend
+    K, HW = 3, 64
+    sup = LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    unsup = LossFactory({"temporal_heatmap_mse": {"loss_name": "temporal_heatmap_mse", "log_weight": 0.0, "prob_threshold": 0.0},
+                         "temporal_heatmap_kl": {"loss_name": "temporal_heatmap_kl", "log_weight": 0.0, "epsilon": 1e-6}}, None)
+    model = SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+                                         pretrained=False, torch_seed=2, device=dev)
+    g = torch.Generator().manual_seed(1)
+    batch = {"frames": torch.randn(4, 3, HW, HW, generator=g).to(dev), "transforms": torch.tensor([-1.0]).to(dev),
+             "bbox": torch.tensor([[0.0, 0.0, HW, HW]]).repeat(4, 1).to(dev), "is_multiview": False}
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    opt.zero_grad()
+    data = model.get_loss_inputs_unlabeled(batch)
+    loss, logs = model.loss_factory_unsup(stage="train", anneal_weight=1.0, **data)
+    loss.backward()
+    hm = data["heatmaps_pred"].detach().cpu()
+    want_mse = ((hm[1:] - hm[:-1]) ** 2).mean((-1, -2)).mean()
+    kl = ((hm[1:] + 1e-10) * (torch.log(hm[1:] + 1e-10) - torch.log(hm[:-1] + 1e-10))).sum((-1, -2))
+    want_kl = torch.relu(kl - 1e-6).mean()
+    got = {d["name"]: float(torch.as_tensor(d["value"]).detach()) for d in logs}
+    assert got["train_temporal_heatmap_mse_loss"] == pytest.approx(float(want_mse), rel=1e-4)
+    assert got["train_temporal_heatmap_kl_loss"] == pytest.approx(float(want_kl), rel=1e-4, abs=1e-9)
+    assert float(model.net.G.abs().sum()) > 0
