@@ -239,6 +239,15 @@ typedef struct lp_bn_fuse {
     size_t workspace_bytes;
 } lp_bn_fuse;
 size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad);
+/* Inference (predict_step, models/heatmap_tracker.py:155-191; eval-mode nn.BatchNorm2d uses its running statistics): the BatchNorm
+ * after a convolution is folded into it once per set of weights - lp_bn_fold: w_bf16[co][:] = bf16(w[co][:] * a[co]),
+ * bias[co] = beta[co] - running_mean[co] * a[co], a = gamma / sqrt(running_var + eps) - and the layer becomes ONE launch,
+ * lp_conv_fwd_act: out = [relu](conv(x, w_bf16) + bias + residual), residual = the block's identity / shortcut (bf16, layout of out)
+ * or NULL.  No BatchNorm pass, no pre-normalisation tensor, nothing kept for a backward pass. */
+int lp_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+               int Co, int per_co, void* w_bf16, float* bias, lp_stream_t stream);
+int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, const void* residual_bf16, int relu,
+                    void* out_bf16, lp_stream_t stream);
 int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
 int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
 int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
+    "lp_bn_fold": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
+    "lp_conv_fwd_act": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _I, _P, _P]),
     "lp_conv_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
     "lp_conv_wgrad_bias": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _I, _P, C.c_size_t, _P]),

@@ -560,6 +560,21 @@ static int grid_for(size_t work_items) {
     return blocks < 1 ? 1 : (int)blocks;
 }
 
+// ---- inference: fold a BatchNorm's running statistics into the preceding convolution -------------------------------------
+// y = gamma (conv(x, W) - mean) / sqrt(var + eps) + beta = conv(x, a W) + (beta - a mean),  a = gamma / sqrt(var + eps) per output
+// channel.  One workgroup per output channel; w rows are [Co][per_co] fp32 masters, the folded copy is the bf16 GEMM operand.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                      const float* __restrict__ rvar, float eps, int per_co,
+                                                      unsigned short* __restrict__ w_out, float* __restrict__ bias_out) {
+    const int co = blockIdx.x;
+    const float a = gamma[co] * rsqrtf(rvar[co] + eps);
+    const float* src = w + (size_t)co * per_co;
+    unsigned short* dst = w_out + (size_t)co * per_co;
+    for (int j = threadIdx.x; j < per_co; j += 256) dst[j] = f32_to_bf16(src[j] * a);
+    if (threadIdx.x == 0) bias_out[co] = beta[co] - rmean[co] * a;
+}
+
 }  // namespace lp
 
 extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream) {
@@ -570,6 +585,15 @@ extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t
     hipLaunchKernelGGL((colreduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr, (const float*)nullptr, M,
                        C, sums, (float*)nullptr, (float*)nullptr);
+    return launch_status();
+}
+
+extern "C" int lp_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, int Co, int per_co, void* w_bf16, float* bias, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(w && gamma && beta && running_mean && running_var && w_bf16 && bias && Co > 0 && per_co > 0 && eps > 0.f);
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(Co), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, running_mean, running_var, eps, per_co,
+                       (unsigned short*)w_bf16, bias);
     return launch_status();
 }
 

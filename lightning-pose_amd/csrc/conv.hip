@@ -63,6 +63,9 @@ struct ConvEpilogue {
     const unsigned short* attn_p;
     const float* attn_d;
     float attn_scale;
+    // kModeInfer (lp_conv_fwd_act): out = [relu](acc + bias + addend) - a BatchNorm folded into the weights and the bias, the
+    // residual read as `addend`, the ReLU applied to the value itself
+    int relu_fwd;
 };
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
@@ -76,7 +79,9 @@ struct GemmExt {
     unsigned d_zb, d_zh, d_row;  // kModeAttn: element strides of the per-row vector D (batch indices, output row)
 };
 
-enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3 };  // kModeAttn = kModeFwd with the soft-max backward in the store pass
+// kModeAttn = kModeFwd with the soft-max backward in the store pass; kModeInfer = kModeFwd whose store pass adds a residual and
+// applies the ReLU (inference with folded BatchNorm: its own instantiation, so the training kernels' code is untouched)
+enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3, kModeInfer = 4 };
 
 // One launch covers a sub-lattice of output pixels and of filter taps.  Ordinary launches use the full lattices; the data
 // gradient of a stride-2 convolution is split into its 4 output-parity classes, each of which only sees the taps of matching
@@ -384,13 +389,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             const int n = n0 + cc * 8;
             const bool want_stats = ep.stats != nullptr;
             // only the data-gradient has tensors to read back in its store pass (addend, pre-normalisation tensor, activation)
-            constexpr bool kReads = (MODE == kModeDgrad);
+            constexpr bool kReads = (MODE == kModeDgrad || MODE == kModeInfer);  // the addend (gradient accumulation / residual)
+            constexpr bool kBwd = (MODE == kModeDgrad);  // pre-normalisation tensor and ReLU masks: data gradient only
             constexpr bool kAttn = (MODE == kModeAttn);
             float s0[8], s1[8], mu[8], sc[8], be[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = sc[q] = be[q] = 0.f;
             if (n < ep.n_store) {
-                if (kReads && ep.bn_z) {
+                if (kBwd && ep.bn_z) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         mu[q] = ep.bn_mean[n + q];
@@ -428,15 +434,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 #pragma unroll
                         for (int i = 0; i < HB; ++i) la[i] = load8_stream(ep.addend + off[i]);
                     }
-                    if (kReads && ep.bn_z) {
+                    if (kBwd && ep.bn_z) {
 #pragma unroll
                         for (int i = 0; i < HB; ++i) lz[i] = load8(ep.bn_z + off[i]);
                     }
-                    if (kReads && ep.relu_mask) {
+                    if (kBwd && ep.relu_mask) {
 #pragma unroll
                         for (int i = 0; i < HB; ++i) lm[i] = load8_stream(ep.relu_mask + off[i]);
                     }
-                    if (kReads && ep.relu_bits) {
+                    if (kBwd && ep.relu_bits) {
 #pragma unroll
                         for (int i = 0; i < HB; ++i) lb[i] = ep.relu_bits[off[i] >> 3];
                     }
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                                 for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(la[i][q]);
                             }
                             float zc[8];  // z - mean
-                            if (kReads && ep.bn_z) {
+                            if (kBwd && ep.bn_z) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(lz[i][q]) - mu[q];
                                 if (ep.mask_from_z) {
@@ -468,15 +474,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                                         if (!(fmaf(zc[q], sc[q], be[q]) > 0x1p-134f)) v[q] = 0.f;
                                 }
                             }
-                            if (kReads && ep.relu_mask) {
+                            if (kBwd && ep.relu_mask) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q)
                                     if (!bf16_positive(lm[i][q])) v[q] = 0.f;
                             }
-                            if (kReads && ep.relu_bits) {
+                            if (kBwd && ep.relu_bits) {
 #pragma unroll
                                 for (int q = 0; q < 8; ++q)
                                     if (!((lb[i] >> q) & 1u)) v[q] = 0.f;
+                            }
+                            if (MODE == kModeInfer && ep.relu_fwd) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
                             }
                             const u16x8 w = pack_bf16x8(v);
                             *reinterpret_cast<u16x8*>(ep.out_bf16 + off[i]) = w;
@@ -485,13 +495,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                                 for (int q = 0; q < 8; ++q) {
                                     const float vr = bf16_to_f32(w[q]);
                                     s0[q] += vr;
-                                    s1[q] = fmaf(vr, (kReads && ep.bn_z) ? zc[q] : vr, s1[q]);  // backward: x invstd below
+                                    s1[q] = fmaf(vr, (kBwd && ep.bn_z) ? zc[q] : vr, s1[q]);  // backward: x invstd below
                                 }
                             }
                         }
                     }
                 }
-                if (kReads && ep.bn_z && want_stats) {
+                if (kBwd && ep.bn_z && want_stats) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) s1[q] *= ep.bn_invstd[n + q];
                 }
@@ -540,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                         if (ep.relu_mask) {
                             if (!bf16_positive(ep.relu_mask[o])) v = 0.f;
                         }
+                        if (MODE == kModeInfer && ep.relu_fwd) v = fmaxf(v, 0.f);
                         if (ep.out_bf16) ep.out_bf16[o] = f32_to_bf16(v);
                         if (ep.out_f32) ep.out_f32[o] = v;
                     }
@@ -1104,6 +1115,26 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
 extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32,
                            int ldo, int n_store, lp_stream_t stream) {
     return conv_fwd_impl(x, w, geom, bias, out_bf16, out_f32, ldo, n_store, nullptr, stream);
+}
+
+// out = [relu](conv(x, w) + bias + residual): the inference form of conv -> BatchNorm [-> + identity] [-> ReLU] once the BatchNorm
+// (running statistics) is folded into w and bias (lp_bn_fold)
+extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, const void* residual_bf16, int relu,
+                               void* out_bf16, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && w && geom_ok(geom) && out_bf16);
+    ConvGeom g = to_geom(geom);
+    if (g.Ci % kBK != 0 || g.Co % 8 != 0 || g.R * g.S > 32 || (long long)g.B * g.Hi * g.Wi * g.Ci >= (1LL << 31) ||
+        (long long)g.B * g.Ho * g.Wo * g.Co >= (1LL << 32))
+        return LP_ERR_UNSUPPORTED;
+    const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
+    ConvEpilogue ep{};
+    ep.out_bf16 = (unsigned short*)out_bf16, ep.ldo = N, ep.n_store = N, ep.bias = bias;
+    ep.addend = (const unsigned short*)residual_bf16, ep.relu_fwd = relu != 0;
+    const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
+    if (N > 64) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
+    else launch_igemm<64, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
+    return launch_status();
 }
 
 extern "C" size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad) {

@@ -612,3 +612,21 @@ def temporal_heatmap(kind, pred, conf, eps, thr, gout=1.0):
     ok(lib().lp_temporal_heatmap_fwd(kind, pb.p, cb.p, s, k, h, w, eb.p, thr, loss.p, ws.p, stream()))
     ok(lib().lp_temporal_heatmap_bwd(kind, pb.p, s, k, h, w, ws.p, go.p, grad.p, 0, stream()))
     return float(loss.np()[0]), grad.np()
+
+
+# ---- inference: folded BatchNorm + conv with residual / ReLU in the store pass -------------------------------------------------
+def bn_fold(w, gamma, beta, rmean, rvar, eps=1e-5):
+    w = f32(w)
+    Co, per = w.shape[0], int(np.prod(w.shape[1:]))
+    wb, gb, bb, mb, vb = Buf(w), Buf(f32(gamma)), Buf(f32(beta)), Buf(f32(rmean)), Buf(f32(rvar))
+    wo, bo = Z((Co, per), np.uint16), Z((Co,))
+    ok(lib().lp_bn_fold(wb.p, gb.p, bb.p, mb.p, vb.p, eps, Co, per, wo.p, bo.p, stream()))
+    return wo.np(), bo.np()
+
+
+def conv_fwd_act(x_nhwc_bits, w_bits, g, bias=None, residual_bits=None, relu=False):
+    M = g.B * g.Ho * g.Wo
+    xb, wb, bb, rb = Buf(x_nhwc_bits), Buf(w_bits), B(bias, np.float32), B(residual_bits)
+    ob = Z((M, g.Co), np.uint16)
+    ok(lib().lp_conv_fwd_act(xb.p, wb.p, C.byref(g), ptr(bb), ptr(rb), int(relu), ob.p, stream()))
+    return ob.np()
