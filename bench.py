@@ -212,6 +212,49 @@ def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int
                       f"median {med:.2f} s/step; oracle/restated.py OracleTracker + training_step"}
 
 
+def predict_bench(args, model, batch, dev, rank: int, world: int) -> None:
+    """Inference over the resident frames: predict_step (trunk with folded BatchNorm -> head -> fused decode incl. the bbox map)."""
+    import torch.distributed as dist
+
+    from lightning_pose_amd.utils.predictions import predict_batches
+
+    frames = torch.cat([batch["labeled"]["images"], batch["unlabeled"]["frames"]], 0)
+    bbox = torch.cat([batch["labeled"]["bbox"], batch["unlabeled"]["bbox"]], 0)
+    loader = [{"frames": frames, "bbox": bbox}]
+    for _ in range(args.warmup):
+        predict_batches(model, loader)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = predict_batches(model, loader)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    n = frames.shape[0] * (frames.shape[1] if frames.dim() == 5 else 1) * world
+    value = n * args.steps / elapsed
+    gf = TRAIN_GFLOP_PER_FRAME.get(args.size) if args.backbone == "resnet50" else VIT_S_TRAIN_GFLOP_PER_FRAME.get(args.size)
+    line = {"metric": f"inference frames/sec (whole node), {args.backbone} {args.size}x{args.size} {args.keypoints}-kp", "value": round(value, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"predict_step over {n // world} resident frames per GPU (eval mode, no tape), keypoints + confidences out",
+                       "global_batch": n, "parallelism": f"dp{world}", "finite": bool(torch.isfinite(out[0][0]).all())}}
+    if gf:  # forward only = a third of the training FLOPs per frame
+        line["model_tflops_per_gpu"] = round(value / world * gf / 3 / 1e3, 2)
+        line["mfma_frac_end_to_end"] = round(value / world * gf / 3 / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +268,8 @@ def main() -> None:
                     help="resnet50 = BASELINE configs C2/C3 (the headline metric); vits_dino = config C4")
     ap.add_argument("--views", type=int, default=1, help="4 = BASELINE config C5 (multiview: --size 256 --labeled 16 --unlabeled 32 "
                     "gives the same 192 images per GPU); frames/s then counts view-images")
+    ap.add_argument("--predict", action="store_true", help="secondary line: inference frames/s (eval mode, BatchNorm folded into the "
+                    "convolutions, fused decode) over the same frames; the headline metric stays the training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args()
@@ -247,6 +292,8 @@ def main() -> None:
         batch = synth_multiview_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints, args.views)
     else:
         batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
+    if args.predict:
+        return predict_bench(args, model, batch, dev, rank, world)
     trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True)
     trainer.setup(model)
     model.train()

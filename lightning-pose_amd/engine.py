@@ -215,6 +215,7 @@ class Engine:
         self._bn_ws: torch.Tensor | None = None     # per-tile column sums of the fused BatchNorm reductions
         self._side = None                            # side stream of the weight-gradient launches (created on first use)
         self._side_busy = False
+        self._fold: tuple[torch.Tensor, torch.Tensor] | None = None  # inference copies: BatchNorm folded into (bf16 weights, biases)
 
     def _timed(self, tag: str, flops: float, fn):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -332,8 +333,13 @@ class Engine:
             dst.copy_(sd[k].to(device=self.device, dtype=torch.float32))
         self.refresh_weight_copies()
 
+    def invalidate_inference_copies(self) -> None:
+        """Parameters or running statistics changed: the folded inference weights are rebuilt on the next forward_infer()."""
+        self._fold = None
+
     def refresh_weight_copies(self, lo: int = 0, hi: int | None = None) -> None:
         """bf16 operand copy of P[lo:hi] and the transposed copies of the conv weights inside that range."""
+        self._fold = None
         hi = self.plan.n_total if hi is None else hi
         check(self._lib.lp_cast_bf16(_p(self.P[lo:hi]), hi - lo, _p(self.Wb[lo:hi]), ops._stream()), "lp_cast_bf16")
         self.refresh_dgrad_copies(lo, hi)
@@ -565,7 +571,71 @@ class Engine:
         tp.meta.update(B=B, H=H, W=W, training=training)
         if training:
             self.nbt += 1
+            self._fold = None  # the running statistics moved
         return heat, tp
+
+    # ------------------------------------------------------------------------------------------------ inference
+    def _folded(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """(Wf, Bf): bf16 weights with each BatchNorm's gamma / sqrt(running_var + eps) folded in (same offsets as Wb) and the
+        matching per-channel biases (offsets of the BatchNorm's bias in P).  Rebuilt only after the parameters changed."""
+        if self._fold is None:
+            plan = self.plan
+            wf = torch.empty_like(self.Wb)
+            bf = torch.zeros(plan.n_total, device=self.device, dtype=torch.float32)
+            pairs = []
+            for blk in plan.blocks:
+                pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+                if blk.down is not None:
+                    pairs.append((blk.down, blk.dbn))
+            for c, b in pairs:
+                check(self._lib.lp_bn_fold(_p(self.P[c.w_off:]), _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias")),
+                                           _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")), BN_EPS,
+                                           c.Co, c.k * c.k * c.Ci, _p(wf[c.w_off:]), _p(bf[b.b_off:]), ops._stream()), "lp_bn_fold")
+            self._fold = (wf, bf)
+        return self._fold
+
+    def forward_infer(self, images: torch.Tensor) -> torch.Tensor:
+        """Inference forward (predict_step, reference models/heatmap_tracker.py:155-191, with eval-mode BatchNorm): every
+        conv -> BatchNorm [-> + identity] [-> ReLU] of the trunk is ONE launch on folded weights (lp_conv_fwd_act); no BatchNorm
+        passes, no pre-normalisation tensors, no tape.  images (B,3,H,W) fp32 -> heat-maps (B,K,H/2^ds,W/2^ds) fp32."""
+        ops.require_device(images)
+        images = images.to(torch.float32).contiguous()
+        B, _, H, W = images.shape
+        if H % 32 or W % 32:
+            raise ValueError(f"image size must be a multiple of 32, got {H}x{W}")
+        plan = self.plan
+        wf, bf = self._folded()
+        st = ops._stream()
+        x4 = torch.empty(B, H, W, 4, device=self.device, dtype=torch.bfloat16)
+        check(self._lib.lp_images_to_nhwc4(_p(images), B, H, W, _p(x4), st), "lp_images_to_nhwc4")
+        # stem: the 7x7 kernel has no bias / ReLU store pass; its BatchNorm -> ReLU -> max-pool is already one fused pass
+        sb = plan.stem_bn
+        z, g = self._conv_fwd(plan.stem, x4, B, H, W, None)
+        h, w = g.Ho, g.Wo
+        mu, iv = self._bn_moments(sb, z, B * h * w, False, None)
+        ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        x = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.bfloat16)
+        arg = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.uint8)
+        check(self._lib.lp_bn_relu_maxpool_fwd(_p(z), _p(mu), _p(iv), _p(self.param_view(sb, "weight")), _p(self.param_view(sb, "bias")), B, h, w,
+                                               64, _p(x), _p(arg), st), "lp_bn_relu_maxpool_fwd")
+        del z, arg
+        h, w = ph, pw
+
+        def layer(c: ConvP, b: BNP, xin, hh, ww, residual, relu):
+            g_ = self._geom(c, B, hh, ww)
+            out = torch.empty(B, g_.Ho, g_.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
+            run = lambda: check(self._lib.lp_conv_fwd_act(_p(xin), _p(wf[c.w_off:]), C.byref(g_), _p(bf[b.b_off:]), _p(residual), int(relu),  # noqa: E731
+                                                          _p(out), st), "lp_conv_fwd_act")
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},infer>", self._flops(c, g_), run)
+            return out, g_
+
+        for blk in plan.blocks:
+            a1, _ = layer(blk.conv1, blk.bn1, x, h, w, None, True)
+            a2, g2 = layer(blk.conv2, blk.bn2, a1, h, w, None, True)
+            idt = x if blk.down is None else layer(blk.down, blk.dbn, x, h, w, None, False)[0]
+            x, _ = layer(blk.conv3, blk.bn3, a2, g2.Ho, g2.Wo, idt, True)
+            h, w = g2.Ho, g2.Wo
+        return self._head_forward(x, B, h, w, {})
 
     # ------------------------------------------------------------------------------------------------ backward
     def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None):

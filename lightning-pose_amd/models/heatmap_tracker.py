@@ -176,6 +176,8 @@ class HeatmapTracker(BaseSupervisedTracker):
         x = images.reshape(-1, shape[-3], shape[-2], shape[-1]) if len(shape) > 4 else images
         if torch.is_grad_enabled():
             heat = _NetworkFn.apply(self._anchor, x, self.net, self.training)
+        elif not self.training and hasattr(self.net, "forward_infer"):
+            heat = self.net.forward_infer(x)  # eval + no_grad (predict / validation): BatchNorm folded, nothing kept
         else:
             heat, _ = self.net.forward(x, training=self.training)
         if len(shape) > 4:

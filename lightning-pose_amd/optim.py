@@ -51,6 +51,8 @@ class FusedAdam(torch.optim.Optimizer):
                   "lp_adam_step")
             if float(g["lr"]) != 0.0 or (float(g["weight_decay"]) != 0.0 and g["decoupled"]):
                 e.refresh_dgrad_copies(lo, hi)
+        if hasattr(e, "invalidate_inference_copies"):
+            e.invalidate_inference_copies()
         return loss
 
     def zero_grad(self, set_to_none: bool = False):  # gradients are views of one flat buffer: zero it in one memset
