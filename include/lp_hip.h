@@ -194,7 +194,8 @@ int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* out_bf16, i
 /* Fused soft-max attention forward, head dimension 64 (HF ViTSelfAttention eager attention, reference models/backbones/vit.py:38-43):
  * per (image b, head h):  P = softmax(scale * Q K^T) -> p_bf16[(b*nh + h)*T + q][ldp] (pad columns [T, ldp) zeroed; the backward pass
  * reads it),  O = P V -> out_bf16[(b*T + q)*ldo + h*64 ..].  Token rows qkv_bf16[(b*T + t)*ld_qkv + ..] hold Q at column h*64, K at
- * k_off + h*64 and V at v_off + h*64.  The scores stay on chip (two passes over the keys: running max / exp-sum, then P and O). */
+ * k_off + h*64 and V at v_off + h*64.  The scores stay on chip (two passes over the keys: running max / exp-sum, then P and O).
+ * p_bf16 == NULL (inference): P is used for O and dropped - nothing of size T x T is written. */
 int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
                 void* out_bf16, int ldo, lp_stream_t stream);
 /* Attention backward, key / value side, in one pass over the stored probabilities (the autograd of HF ViTSelfAttention's eager

@@ -37,6 +37,8 @@ struct AttnArgs {
     int ldo;
 };
 
+// WRITE_P = false (inference: a.p == nullptr): the probabilities are used for O and dropped - nothing of size T x T is written.
+template <bool WRITE_P>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[kAK * kLDK];
     __shared__ __attribute__((aligned(16))) unsigned short sV[kAK * kLDV];
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int e = 0; e < 16; ++e) o[blk][e] = 0.f;
     const int fq = lane >> 4, fi = lane & 15;
     const int vrow = 4 * (fq >> 1) + (fi >> 2), vcol = 16 * (fq & 1) + 4 * (fi & 3);  // transpose-read source of this lane
-    const int n_p = (a.ldp + kAK - 1) / kAK > n_kv ? (a.ldp + kAK - 1) / kAK : n_kv;  // tiles that only hold pad columns get zeros
+    // tiles that only hold pad columns of the stored P get zeros
+    const int n_p = (WRITE_P && (a.ldp + kAK - 1) / kAK > n_kv) ? (a.ldp + kAK - 1) / kAK : n_kv;
     __syncthreads();
     fetch(Kp, 0, rk);
     fetch(Vp, 0, rv);
@@ -190,21 +193,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pk[blk][e] = 0u;
         }
-        // stage P[query][key]: regs e .. e+3 are 4 consecutive keys (8 B)
+        if (WRITE_P) {
+            // stage P[query][key]: regs e .. e+3 are 4 consecutive keys (8 B)
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-                const u32x2_t w = {pk[blk][2 * g4], pk[blk][2 * g4 + 1]};
-                *reinterpret_cast<u32x2_t*>(&sP[(wave * 32 + col) * kLDP + blk * 32 + 8 * g4 + 4 * half]) = w;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                    const u32x2_t w = {pk[blk][2 * g4], pk[blk][2 * g4 + 1]};
+                    *reinterpret_cast<u32x2_t*>(&sP[(wave * 32 + col) * kLDP + blk * 32 + 8 * g4 + 4 * half]) = w;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + srow, q = q0 + row, c = t * kAK + schunk * 8;
+                if (q < T && c < a.ldp)
+                    *reinterpret_cast<u16x8*>(a.p + ((size_t)z * T + q) * a.ldp + c) = *reinterpret_cast<const u16x8*>(&sP[row * kLDP + schunk * 8]);
             }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 32 + srow, q = q0 + row, c = t * kAK + schunk * 8;
-            if (q < T && c < a.ldp)
-                *reinterpret_cast<u16x8*>(a.p + ((size_t)z * T + q) * a.ldp + c) = *reinterpret_cast<const u16x8*>(&sP[row * kLDP + schunk * 8]);
         }
         __syncthreads();  // sP, sK, sV are free again
     }
@@ -428,15 +433,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
 extern "C" int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, void* p_bf16, int ldp,
                            void* out_bf16, int ldo, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(qkv_bf16 && p_bf16 && out_bf16 && B > 0 && nh > 0 && T > 0 && ldp >= T && ldo >= nh * kAD && k_off >= 0 && v_off >= 0 &&
-               ld_qkv >= nh * kAD);
+    LP_REQUIRE(qkv_bf16 && out_bf16 && B > 0 && nh > 0 && T > 0 && (p_bf16 == nullptr || ldp >= T) && ldo >= nh * kAD && k_off >= 0 &&
+               v_off >= 0 && ld_qkv >= nh * kAD);
+    if (p_bf16 == nullptr) ldp = 8;  // unused
     if (ld_qkv % 8 != 0 || k_off % 8 != 0 || v_off % 8 != 0 || ldp % 8 != 0 || ldo % 4 != 0) return LP_ERR_UNSUPPORTED;
     const int qtiles = (T + kAQ - 1) / kAQ;
     const long long wgs = (long long)B * nh * qtiles;
     if (wgs >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     AttnArgs a{(const unsigned short*)qkv_bf16, ld_qkv, k_off, v_off, nh, T, qtiles, scale, (unsigned short*)p_bf16, ldp,
                (unsigned short*)out_bf16, ldo};
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    if (p_bf16) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     return launch_status();
 }
 

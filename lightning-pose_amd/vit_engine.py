@@ -300,6 +300,14 @@ class ViTEngine(Engine):
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:
+        return self._forward(images, training, keep=True)
+
+    def forward_infer(self, images: torch.Tensor) -> torch.Tensor:
+        """Inference forward (predict_step under eval + no_grad): the attention probabilities are never written (lp_attn_fwd with
+        p = NULL drops the 2 x 0.85 GB per layer the training pass stores for its backward) and no tape is kept."""
+        return self._forward(images, False, keep=False)[0]
+
+    def _forward(self, images: torch.Tensor, training: bool, keep: bool) -> tuple[torch.Tensor, Tape]:
         ops.require_device(images)
         images = images.to(torch.float32).contiguous()
         B, _, H, W = images.shape
@@ -321,7 +329,8 @@ class ViTEngine(Engine):
         x = torch.empty(M, D, device=dev, dtype=torch.float32)
         pos = self._pos(gh, gw)  # (kept alive across the launch)
         check(self._lib.lp_vit_tokens_fwd(_p(pe), _p(self.P[pl.cls_off:]), _p(pos), B, Np, D, _p(x), ops._stream()), "lp_vit_tokens_fwd")
-        T["patches"] = patches
+        if keep:
+            T["patches"] = patches
         delta = None
         scale = 1.0 / math.sqrt(D // nh)
         qs = 3 * D  # row pitch of the fused qkv tensor
@@ -330,7 +339,7 @@ class ViTEngine(Engine):
             qkv = self._linear(y1, L["qkv"], M)
             # P = softmax(Q K^T / 8) (bf16, row pitch Tp, pad columns zero; kept for the backward pass) and attn = P V in one kernel:
             # the scores themselves never reach memory
-            S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
+            S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16) if keep else None
             attn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             check(self._lib.lp_attn_fwd(_p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(S), Tp, _p(attn), D, ops._stream()), "lp_attn_fwd")
             proj = self._linear(attn, L["proj"], M)
@@ -340,12 +349,14 @@ class ViTEngine(Engine):
             a1 = torch.empty_like(h1)
             check(self._lib.lp_gelu_fwd(_p(h1), h1.numel(), _p(a1), ops._stream()), "lp_gelu_fwd")
             delta = self._linear(a1, L["fc2"], M)
-            for nm, v in (("x_in", x_in), ("m1", m1), ("r1", r1), ("y1", y1), ("qkv", qkv), ("P", S), ("attn", attn), ("x_mid", x),
-                          ("m2", m2), ("r2", r2), ("y2", y2), ("h1", h1), ("a1", a1)):
-                T[f"l{i}.{nm}"] = v
+            if keep:
+                for nm, v in (("x_in", x_in), ("m1", m1), ("r1", r1), ("y1", y1), ("qkv", qkv), ("P", S), ("attn", attn), ("x_mid", x),
+                              ("m2", m2), ("r2", r2), ("y2", y2), ("h1", h1), ("a1", a1)):
+                    T[f"l{i}.{nm}"] = v
         feat, mf, rf, x = self._ln(x, delta, pl.lnf, M, drop_T=Tn)
-        T["x_last"], T["mf"], T["rf"] = x, mf, rf
-        heat = self._head_forward(feat.view(B, gh, gw, D), B, gh, gw, T)
+        if keep:
+            T["x_last"], T["mf"], T["rf"] = x, mf, rf
+        heat = self._head_forward(feat.view(B, gh, gw, D), B, gh, gw, T if keep else {})
         tp.meta.update(B=B, H=H, W=W, gh=gh, gw=gw, training=training)
         return heat, tp
 

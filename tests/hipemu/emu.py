@@ -333,11 +333,12 @@ def gemm_tn(x_bits, ldx, y_bits, ldy, M, J, N, ldo, o_elems, batch=None):
     return ob.np()
 
 
-def attn_fwd(qkv_bits, ld, k_off, v_off, nb, nh, T, scale, ldp, ldo):
-    """-> (P bits [nb*nh*T][ldp], O bits [nb*T][ldo])"""
-    qb, pb, ob = Buf(qkv_bits), Z((nb * nh * T, ldp), np.uint16), Z((nb * T, ldo), np.uint16)
-    ok(lib().lp_attn_fwd(qb.p, ld, k_off, v_off, nb, nh, T, scale, pb.p, ldp, ob.p, ldo, stream()))
-    return pb.np(), ob.np()
+def attn_fwd(qkv_bits, ld, k_off, v_off, nb, nh, T, scale, ldp, ldo, write_p=True):
+    """-> (P bits [nb*nh*T][ldp] (None with write_p=False: the inference form), O bits [nb*T][ldo])"""
+    qb, ob = Buf(qkv_bits), Z((nb * T, ldo), np.uint16)
+    pb = Z((nb * nh * T, ldp), np.uint16) if write_p else None
+    ok(lib().lp_attn_fwd(qb.p, ld, k_off, v_off, nb, nh, T, scale, ptr(pb), ldp, ob.p, ldo, stream()))
+    return (pb.np() if write_p else None), ob.np()
 
 
 def attn_bwd_kv(qkv_bits, ld, v_off, do_bits, ld_do, p_bits, ldp, d_rows, nb, nh, T, scale, ld_dqkv, dk_off, dv_off):
