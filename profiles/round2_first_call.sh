@@ -1,0 +1,13 @@
+# First gpurun call of the next round: everything written after round 1's GPU budget was spent gets its first device run and timing.
+#   gpurun --timeout 1500 -- 'bash profiles/round2_first_call.sh'
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+(timeout 700 python -m pytest tests -q -m gpu 2>&1 | tail -15) > gpurun_out/r02_pytest_gpu.log; tail -3 gpurun_out/r02_pytest_gpu.log
+(timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3) > gpurun_out/r02_smoke.log; tail -1 gpurun_out/r02_smoke.log
+timeout 400 python bench.py > gpurun_out/r02_bench_n1.json.log 2>&1; tail -1 gpurun_out/r02_bench_n1.json.log | cut -c1-200
+for bb in resnet50 vits_dino; do
+  timeout 300 python bench.py --predict --backbone $bb --steps 10 --warmup 3 > gpurun_out/r02_bench_predict_${bb}.json.log 2>&1; tail -1 gpurun_out/r02_bench_predict_${bb}.json.log | cut -c1-200
+done
+timeout 300 python bench.py --views 4 --size 256 --labeled 16 --unlabeled 32 > gpurun_out/r02_bench_c5_multiview.json.log 2>&1; tail -1 gpurun_out/r02_bench_c5_multiview.json.log | cut -c1-200
+timeout 300 python profiles/producer_microbench.py > gpurun_out/r02_producer_microbench.txt 2>&1; tail -12 gpurun_out/r02_producer_microbench.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r02_prof_predict -o predict -- python bench.py --predict --steps 5 --warmup 2 > gpurun_out/r02_prof_predict.log 2>&1; tail -1 gpurun_out/r02_prof_predict.log | cut -c1-120
