@@ -138,6 +138,8 @@ class LabeledBatchProducer:
         b, hs, ws, _ = images_u8.shape
         kp = keypoints.reshape(b, -1, 2).to(dev)
         k = kp.shape[1]
+        if self.swap is not None and sorted(self.swap.tolist()) != list(range(k)):  # host-side list: checked before it indexes on the device
+            raise ValueError(f"hflip_swap_indices must be a permutation of range({k}), got {self.swap.tolist()}")
         src_hw = torch.tensor([[float(hs), float(ws)]], device=dev).repeat(b, 1)
         kp_model, vis = ops.labeled_keypoints(kp, src_hw, self.height, self.width, affine=affine, hflip=hflip, swap=self.swap,
                                               visibility=visibility, uniform_heatmaps=self.uniform_heatmaps)

@@ -109,6 +109,8 @@ def test_labeled_producer_flip_moves_image_and_labels_together(stack_backend):
     plain = O.frames_finish(O.frames_resize(imgs, 128, 128, "renorm"))
     torch.testing.assert_close(batch["images"][0].cpu(), plain[0].flip(-1), atol=3e-4, rtol=0)
     torch.testing.assert_close(batch["images"][1].cpu(), plain[1], atol=3e-4, rtol=0)
+    with pytest.raises(ValueError, match="permutation"):
+        LabeledBatchProducer(128, 128, hflip_swap_indices=[1, 0, 5])(imgs.to(dev), kp.to(dev), hflip=torch.tensor([1, 0]))
 
 
 def test_producers_feed_the_training_step(stack_backend):
