@@ -39,8 +39,13 @@ def _oracle_forward(vit, head, images):
     return torch.softmax(logits.reshape(b, k, -1), -1).reshape(b, k, h, w)
 
 
-@pytest.mark.parametrize("hidden,depth,heads,mlp", [(128, 2, 2, 256), (768, 1, 12, 768)])  # the second: ViT-B's width and 12 heads
+@pytest.mark.parametrize("hidden,depth,heads,mlp", [(128, 2, 2, 256)])
 def test_vit_engine_forward_backward_vs_hf(stack_backend, hidden, depth, heads, mlp):
+    check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp)
+
+
+def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp):
+    """(ViT-B's width and 12 heads run this from tests/test_widen_vitb_width.py)"""
     from lightning_pose_amd.vit_engine import ViTEngine
 
     dev = stack_backend
