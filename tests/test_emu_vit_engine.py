@@ -63,8 +63,6 @@ def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp):
     gen = torch.Generator().manual_seed(1)
     images = torch.randn(2, 3, 64, 64, generator=gen)
     heat, tape = eng.forward(images.to(dev), True)
-    # inference form (no tape, attention probabilities never written): the same heat-maps bit for bit
-    torch.testing.assert_close(eng.forward_infer(images.to(dev)).cpu(), heat.cpu(), atol=0, rtol=0)
     want = _oracle_forward(vit, head, images)
     assert heat.shape == want.shape == (2, K, 16, 16)
     # bf16 operands vs fp32; the 768-wide head sums 192 products per logit, its sharper soft-max doubles the relative error of a peak

@@ -190,10 +190,6 @@ def test_attention_forward_fused(nb, nh, T, ldp):
     want_o = bf(got_p[..., :T]) @ v                                               # O is accumulated from the STORED probabilities
     torch.testing.assert_close(got_o, want_o, atol=2e-2, rtol=2e-2)
     torch.testing.assert_close(got_o, p @ v, atol=3e-2, rtol=3e-2)
-    # inference form (p = NULL): the same O bit for bit, nothing of size T x T written
-    none, obits_inf = emu.attn_fwd(bits(qkv).reshape(-1), ld, D, 2 * D, nb, nh, T, scale, ldp, D, write_p=False)
-    assert none is None
-    np.testing.assert_array_equal(obits_inf, obits)
 
 
 @pytest.mark.parametrize("nb,nh,T,ldp", [(2, 2, 77, 80), (1, 3, 130, 192), (1, 1, 64, 64), (1, 2, 5, 8), (1, 1, 200, 256)])

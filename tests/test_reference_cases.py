@@ -114,57 +114,6 @@ def test_temporal_loss_cases(dev):
     assert float(with_conf) == pytest.approx(float(without) / 2, abs=1e-6)  # exactly one of the two keypoints is left
 
 
-def test_temporal_heatmap_loss_cases(dev):
-    """TestTemporalHeatmapLoss (tests/losses/test_losses.py:411-503): invalid name, zero for constant maps (mse exactly, kl to 1e-5),
-    positive for varying maps, compute_loss shape, low-confidence masking, epsilon rectification; plus the composition identity"""
-    from lightning_pose_amd.losses import TemporalHeatmapLoss
-    from lightning_pose_amd.losses.factory import get_loss_classes
-
-    assert get_loss_classes()["temporal_heatmap_mse"] is TemporalHeatmapLoss and get_loss_classes()["temporal_heatmap_kl"] is TemporalHeatmapLoss
-    with pytest.raises(ValueError):
-        TemporalHeatmapLoss(loss_name="bad_name")
-    mse, kl = TemporalHeatmapLoss(loss_name="temporal_heatmap_mse"), TemporalHeatmapLoss(loss_name="temporal_heatmap_kl")
-    g = torch.Generator().manual_seed(8)
-    S, K, h, w = 4, 3, 16, 16
-    ones = torch.ones(S, K).to(dev)
-    frame = torch.rand(1, K, h, w, generator=g)
-    loss, logs = mse(heatmaps_pred=frame.expand(S, -1, -1, -1).clone().to(dev), confidences=ones, stage=STAGE)
-    assert loss.shape == torch.Size([]) and loss.item() == 0.0
-    assert logs[0]["name"] == f"{STAGE}_temporal_heatmap_mse_loss" and logs[1]["name"] == "temporal_heatmap_mse_weight"
-    loss, _ = mse(heatmaps_pred=torch.rand(S, K, h, w, generator=g).to(dev), confidences=ones, stage=STAGE)
-    assert loss.item() > 0.0
-    sm = lambda x: torch.softmax(x.reshape(*x.shape[:2], -1), -1).reshape(x.shape)  # noqa: E731  (kornia spatial_softmax2d)
-    frame = sm(torch.randn(1, K, h, w, generator=g))
-    loss, logs = kl(heatmaps_pred=frame.expand(S, -1, -1, -1).clone().to(dev), confidences=ones, stage=STAGE)
-    assert loss.shape == torch.Size([]) and torch.isclose(loss.cpu(), torch.tensor(0.0), atol=1e-5)
-    assert logs[0]["name"] == f"{STAGE}_temporal_heatmap_kl_loss"
-    varying = sm(torch.randn(S, K, h, w, generator=g))
-    loss, _ = kl(heatmaps_pred=varying.to(dev), confidences=ones, stage=STAGE)
-    assert loss.item() > 0.0
-    assert mse.compute_loss(torch.rand(5, K, h, w, generator=g).to(dev)).shape == (4, K)
-    assert kl.compute_loss(sm(torch.randn(5, K, h, w, generator=g)).to(dev)).shape == (4, K)
-    # low-confidence masking
-    mse.prob_threshold = torch.tensor(0.5)
-    pred = torch.rand(3, 2, 8, 8, generator=g)
-    conf = torch.zeros(3, 2)
-    conf[:, 1] = 1.0
-    diffs = mse.compute_loss(pred.to(dev))
-    want = ((pred[1:] - pred[:-1]) ** 2).mean((-1, -2))
-    torch.testing.assert_close(diffs.cpu(), want, rtol=1e-5, atol=1e-8)
-    clean = mse.remove_nans(confidences=conf.to(dev), loss=diffs.clone())
-    assert torch.all(clean[:, 0] == 0.0) and torch.all(clean[:, 1] > 0.0)
-    # epsilon rectification
-    mse.epsilon = torch.tensor(1.0)
-    rect = mse.rectify_epsilon(torch.tensor([[0.5, 2.0], [1.5, 0.3]]))
-    assert rect[0, 0] == 0.0 and rect[0, 1] > 0.0 and rect[1, 0] > 0.0 and rect[1, 1] == 0.0
-    # __call__ == reduce(rectify(remove_nans(compute_loss))) with a per-keypoint epsilon
-    loss_obj = TemporalHeatmapLoss(loss_name="temporal_heatmap_kl", epsilon=[0.0, 0.05, 10.0], prob_threshold=0.3)
-    conf = torch.rand(S, K, generator=g)
-    got, _ = loss_obj(heatmaps_pred=varying.to(dev), confidences=conf.to(dev), stage=None)
-    parts = loss_obj.rectify_epsilon(loss_obj.remove_nans(conf.to(dev), loss_obj.compute_loss(varying.to(dev))))
-    assert float(got) == pytest.approx(float(loss_obj.reduce_loss(parts)), rel=1e-5)
-
-
 def test_rmse_loss(dev):
     """TestRegressionRMSELoss: equal -> 0; targets 2 vs predictions 0 -> exactly 2; NaN targets are skipped"""
     from lightning_pose_amd.losses.losses import RegressionRMSELoss
@@ -281,45 +230,6 @@ def test_generate_heatmaps_extreme_coordinates_stay_finite(dev):
     assert torch.isfinite(h).all() and h.shape == (1, 4, 64, 64) and not h.any()
     assert torch.allclose(_gen(dev, kp, torch.ones(1, 4, dtype=torch.long))[0, 0], torch.ones(64, 64) / 4096)
     assert not _gen(dev, kp, torch.full((1, 4), 2, dtype=torch.long)).any()
-
-
-def test_evaluate_heatmaps_at_location_cases(dev):
-    """test_evaluate_heatmaps_at_location (tests/data/test_heatmaps.py:457-563): five 0.2 blobs around the location sum to exactly
-    1 for 1 / 5 frames x 1 / 6 keypoints incl. locations at the border; delta and Gaussian maps at the right, adjacent, wrong spot"""
-    from lightning_pose_amd.data.heatmaps import evaluate_heatmaps_at_location, generate_heatmaps
-
-    height, width = 24, 12
-    g = torch.Generator().manual_seed(4)
-    for n_batch in (1, 5):
-        for n_keypoints in (1, 6):
-            heatmaps = torch.zeros(n_batch, n_keypoints, height, width)
-            h_locs = torch.randint(0, height, (n_batch, n_keypoints), generator=g)
-            w_locs = torch.randint(0, width, (n_batch, n_keypoints), generator=g)
-            if n_batch == 5 and n_keypoints == 6:  # corners and edges
-                h_locs[0, :4], w_locs[0, :4] = torch.tensor([0, 0, height - 1, height - 1]), torch.tensor([0, width - 1, 0, width - 1])
-            locs = torch.stack([w_locs, h_locs], dim=2)
-            for i in range(n_batch):
-                for j in range(n_keypoints):
-                    for dy, dx in ((1, 1), (-1, -1), (0, 0), (1, -1), (-1, 1)):
-                        y = int(torch.clamp(locs[i, j, 1] + dy, 0, height - 1))
-                        x = int(torch.clamp(locs[i, j, 0] + dx, 0, width - 1))
-                        heatmaps[i, j, y, x] += 0.2
-            vals = evaluate_heatmaps_at_location(heatmaps=heatmaps.to(dev), locs=locs.to(dev)).cpu()
-            assert vals.shape == (n_batch, n_keypoints)
-            assert torch.all(vals == 1.0)
-    heatmaps = torch.zeros(1, 1, 32, 32)
-    heatmaps[0, 0, 5, 5] = 1
-    loc = lambda v: torch.full((1, 1, 2), float(v))  # noqa: E731
-    conf = lambda hm, v: evaluate_heatmaps_at_location(hm.to(dev), loc(v).to(dev)).cpu()  # noqa: E731
-    assert conf(heatmaps, 5).shape == (1, 1)
-    assert torch.allclose(conf(heatmaps, 5)[0], torch.tensor(1.0))
-    assert torch.allclose(conf(heatmaps, 6)[0], torch.tensor(1.0))
-    assert torch.allclose(conf(heatmaps, 25)[0], torch.tensor(0.0))
-    assert torch.allclose(conf(heatmaps, 5.9)[0], torch.tensor(1.0)) and torch.allclose(conf(heatmaps, 8.0)[0], torch.tensor(0.0))  # int64 truncation
-    hm_g = generate_heatmaps(loc(5).to(dev), height=32, width=32, output_shape=(32, 32)).cpu()
-    c0, c1, c2 = conf(hm_g, 5)[0], conf(hm_g, 6)[0], conf(hm_g, 25)[0]
-    assert 0 < float(c0) <= 1.0 and float(c0) > float(c1)
-    assert torch.allclose(c2, torch.tensor(0.0))
 
 
 def test_generate_heatmaps_detaches(dev):

@@ -1,0 +1,64 @@
+"""Inference kernels (written after round 1's last device run, hence in a late-sorting file): lp_bn_fold + lp_conv_fwd_act (conv + folded
+BatchNorm + residual + ReLU in one launch) and lp_attn_fwd with p = NULL (no T x T write)."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.hipemu import emu
+
+pytestmark = pytest.mark.usefixtures("kernel_backend")
+
+bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+
+
+def nhwc(t):  # (B,C,H,W) -> (B,H,W,C)
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 1, 1, 0), (1, 9, 7, 64, 128, 3, 1, 1), (2, 10, 10, 128, 192, 3, 2, 1), (3, 8, 8, 128, 64, 1, 2, 0)])
+@pytest.mark.parametrize("residual,relu", [(False, True), (True, True), (False, False), (True, False)])
+def test_conv_fwd_act_folded_batchnorm(case, residual, relu):
+    """inference form of conv -> BatchNorm(running statistics) [-> + identity] [-> ReLU]: lp_bn_fold + ONE lp_conv_fwd_act launch
+    vs torch's eval-mode sequence on the same bf16-rounded folded operands"""
+    B, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(sum(case) + 7)
+    x = bf(torch.randn(B, Ci, Hi, Wi, generator=gen))
+    w = torch.randn(Co, Ci, R, R, generator=gen) / (Ci * R * R) ** 0.5
+    gamma, beta = 0.5 + torch.rand(Co, generator=gen), torch.randn(Co, generator=gen) * 0.3
+    rmean, rvar = torch.randn(Co, generator=gen) * 0.2, 0.3 + torch.rand(Co, generator=gen)
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    wf_bits, bias = emu.bn_fold(w.permute(0, 2, 3, 1).reshape(Co, -1).numpy(), gamma.numpy(), beta.numpy(), rmean.numpy(), rvar.numpy())
+    a = gamma / torch.sqrt(rvar + 1e-5)
+    torch.testing.assert_close(torch.from_numpy(bias), beta - rmean * a, atol=1e-6, rtol=1e-6)
+    wf = emu.from_bf16_bits(wf_bits).reshape(Co, R, R, Ci)
+    torch.testing.assert_close(wf, bf(w.permute(0, 2, 3, 1) * a.view(-1, 1, 1, 1)), atol=0, rtol=0)
+    res = bf(torch.randn(B * g.Ho * g.Wo, Co, generator=gen)) if residual else None
+    got = emu.from_bf16_bits(emu.conv_fwd_act(emu.to_bf16_bits(nhwc(x)), wf_bits, g, bias=bias,
+                                              residual_bits=emu.to_bf16_bits(res) if residual else None, relu=relu))
+    want = nhwc(F.conv2d(x, wf.permute(0, 3, 1, 2), stride=st, padding=pad)).reshape(-1, Co) + torch.from_numpy(bias)
+    if residual:
+        want = want + res
+    if relu:
+        want = torch.relu(want)
+    torch.testing.assert_close(got, bf(want), atol=2e-2, rtol=1e-2)
+    # and against the un-folded definition in fp32: eval-mode BatchNorm of the convolution with the original weights
+    ref = F.batch_norm(F.conv2d(x, bf(w), stride=st, padding=pad), rmean, rvar, gamma, beta, training=False, eps=1e-5)
+    ref = nhwc(ref).reshape(-1, Co) + (res if residual else 0)
+    ref = torch.relu(ref) if relu else ref
+    assert float((got - ref).abs().max()) < 0.06 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("nb,nh,T,ldp", [(2, 2, 77, 80), (1, 3, 130, 192), (1, 1, 64, 64), (1, 2, 5, 8)])
+def test_attention_forward_without_probabilities(nb, nh, T, ldp):
+    """inference form (p = NULL): the same O as the training form bit for bit, nothing of size T x T written"""
+    gen = torch.Generator().manual_seed(nb * 100 + T)
+    d, scale = 64, 0.125
+    D = nh * d
+    ld = 3 * D + 8
+    qkv = emu.to_bf16_bits(torch.randn(nb * T, ld, generator=gen) * 1.5)
+    _p, obits = emu.attn_fwd(qkv.reshape(-1), ld, D, 2 * D, nb, nh, T, scale, ldp, D)
+    none, obits_inf = emu.attn_fwd(qkv.reshape(-1), ld, D, 2 * D, nb, nh, T, scale, ldp, D, write_p=False)
+    assert none is None
+    np.testing.assert_array_equal(obits_inf, obits)
