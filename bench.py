@@ -175,6 +175,59 @@ def pmc_traffic():
         return None
 
 
+def hbm_rooflines(dev, size: int, K: int, frames: int, reps: int = 10) -> dict:
+    """HBM roofline of the heat-map kernels (decode and heat-map generation are HBM-bound): algorithmic bytes
+    per launch / time per launch, timed live with events on the launch stream (torch's current stream, where ops.* enqueue).
+    Bytes per frame: one K-stack of fp32 heat-maps = K*h*w*4 (626 688 B at 96x96, K = 17); decode fwd reads it once, decode bwd reads
+    and writes it once more, generation writes it once, heat-map MSE fwd+bwd reads two stacks and writes one."""
+    from lightning_pose_amd import ops
+
+    h = size // 4
+    stack = float(frames * K * h * h * 4)
+    heat = torch.softmax(torch.randn(frames, K, h * h, device=dev) * 4.0, -1).reshape(frames, K, h, h)
+    kp = torch.rand(frames, K, 2, device=dev) * size
+    fm = ops.DecodeFrameMap(None, False, None, 1, size, size, K)
+    targ = ops.generate_heatmaps(kp, size, size, (h, h))
+
+    def decode_fwd_bwd():
+        x = heat.detach().requires_grad_(True)
+        _aug, kp_frame, _conf = ops.decode(x, 2, 1000.0, fm)
+        kp_frame.backward(torch.ones_like(kp_frame))
+
+    def mse_fwd_bwd():
+        x = heat.detach().requires_grad_(True)
+        ops.heatmap_mse(targ, x).backward()
+
+    cases = {
+        "decode_fwd": (stack, lambda: ops.decode(heat, 2, 1000.0, fm)),
+        "decode_fwd_bwd": (3 * stack, decode_fwd_bwd),
+        "heatmap_gen": (stack, lambda: ops.generate_heatmaps(kp, size, size, (h, h))),
+        "heatmap_mse_fwd_bwd": (3 * stack, mse_fwd_bwd),
+    }
+    cuda = dev.type == "cuda"
+    out = {}
+    for name, (nbytes, fn) in cases.items():
+        for _ in range(2):
+            fn()
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1000.0 * e0.elapsed_time(e1) / reps
+        else:  # (tests drive this on the emulated kernels)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            us = 1e6 * (time.perf_counter() - t0) / reps
+        gbs = nbytes / us / 1e3
+        out[name] = {"us": round(us, 1), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frames": frames, "algorithmic_bytes_per_frame": int(stack / frames),
+            "note": "decode is fp32-VALU-bound by construction (one pass over the map, ~350 FLOP/B): HBM bytes are its floor", "kernels": out}
+
+
 def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 3) -> dict:
     """Oracle (fp32 torch CPU restatement of the reference path) timed on the host cores for a bounded sample."""
     from oracle import restated as O
@@ -391,6 +444,11 @@ def main() -> None:
         if gf:
             out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
             out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
+        if world == 1 and not args.no_profile and args.views == 1:
+            try:  # secondary rooflines; never allowed to cost the measured line
+                out["roofline_hbm"] = hbm_rooflines(dev, args.size, args.keypoints, args.labeled + args.unlabeled)
+            except Exception as e:  # noqa: BLE001
+                out["roofline_hbm"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not is_vit and args.views == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)

@@ -45,3 +45,11 @@ def test_multiview_workload_steps(stack_backend):
     # the fit data are affine views of one 3-D cloud: 3 components carry (almost) everything
     pca = model.loss_factory_unsup.loss_instance_dict["pca_multiview"].pca
     assert pca.parameters["kept_eigenvectors"].shape[0] == 3
+
+
+def test_hbm_rooflines_runs_the_heatmap_kernels(stack_backend):
+    out = bench.hbm_rooflines(stack_backend, 64, 3, 4, reps=1)
+    assert out["bound"] == "hbm" and out["algorithmic_bytes_per_frame"] == 3 * 16 * 16 * 4
+    assert set(out["kernels"]) == {"decode_fwd", "decode_fwd_bwd", "heatmap_gen", "heatmap_mse_fwd_bwd"}
+    for v in out["kernels"].values():
+        assert v["us"] > 0 and v["achieved"] >= 0  # (the emulator moves kilobytes per millisecond)
