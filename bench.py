@@ -39,6 +39,11 @@ TRAIN_GFLOP_PER_FRAME = {384: 72.4, 256: 32.2}  # 3 x 2 
 VIT_S_TRAIN_GFLOP_PER_FRAME = {384: 93.1, 256: 36.9}  # SURVEY.md section 8(d), ViT-S/16
 
 
+def _sync(dev) -> None:
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
 def synth_batch(dev, rank: int, size: int, n_lab: int, n_unlab: int, K: int):
     """Seeded synthetic labeled + unlabeled batch of SURVEY.md section 8(d), generated on the device."""
     from lightning_pose_amd import ops
@@ -276,13 +281,13 @@ def predict_bench(args, model, batch, dev, rank: int, world: int) -> None:
     loader = [{"frames": frames, "bbox": bbox}]
     for _ in range(args.warmup):
         predict_batches(model, loader)
-    torch.cuda.synchronize()
+    _sync(dev)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = predict_batches(model, loader)
-    torch.cuda.synchronize()
+    _sync(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -308,7 +313,8 @@ def predict_bench(args, model, batch, dev, rank: int, world: int) -> None:
         dist.destroy_process_group()
 
 
-def main() -> None:
+def main(argv: list[str] | None = None, device: torch.device | None = None) -> None:
+    """``device`` (tests only): run the whole flow on that device - the CPU with the emulated kernel library - instead of cuda:LOCAL_RANK."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -325,7 +331,7 @@ def main() -> None:
                     "convolutions, fused decode) over the same frames; the headline metric stays the training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch.distributed as dist
 
@@ -337,8 +343,9 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if os.environ.get("LP_FORCE_DEVICE") is not None:  # functional multi-rank test on a 1-GPU box (with LP_DIST_BACKEND=gloo)
         local_rank = int(os.environ["LP_FORCE_DEVICE"])
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
+    dev = torch.device(f"cuda:{local_rank}") if device is None else device
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
 
     model = build_model(dev, args.keypoints, args.size, backbone=args.backbone, views=args.views)
     if args.views > 1:
@@ -358,7 +365,7 @@ def main() -> None:
 
     for i in range(args.warmup):
         trainer.training_batch(model, batch, i)
-    torch.cuda.synchronize()
+    _sync(dev)
     barrier()
     # Per-launch HIP events (the roofline entry) bracket every convolution launch of a SAMPLE of the timed steps - every 5th,
     # starting with the 3rd: an event record is a barrier packet on the launch stream, and 632 of them per step cost ~4 % of the
@@ -372,7 +379,7 @@ def main() -> None:
         prof_steps += int(sampled)
         loss = trainer.training_batch(model, batch, args.warmup + i)
     host_enqueue = time.perf_counter() - t0  # the host is done enqueueing here; the GPU still drains (no sync inside a step)
-    torch.cuda.synchronize()
+    _sync(dev)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = prof_sink
@@ -382,7 +389,7 @@ def main() -> None:
     t1 = time.perf_counter()
     trainer.training_batch(model, batch, args.warmup + args.steps)
     host_idle_queue = time.perf_counter() - t1
-    torch.cuda.synchronize()
+    _sync(dev)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,50 +1,48 @@
-"""bench.py's synthetic workloads drive the product step (tiny sizes, emulated kernels on CPU / the device under -m gpu): the
-single-view C2 batch and the multiview C5 batch (--views)."""
+"""bench.py end to end at toy sizes (emulated kernels on CPU / the device under -m gpu): the driver's JSON contract for the headline
+training line, the multiview C5 workload (--views), the inference line (--predict) and the secondary HBM rooflines."""
 
-import numpy as np
+import json
+
 import torch
 
 import bench
 
-
-def _step(model, batch):
-    model.train()
-    model.total_unsupervised_importance = torch.tensor(1.0)
-    opt = model.configure_optimizers()["optimizer"]
-    opt.zero_grad()
-    loss = model.training_step(batch, 0)["loss"]
-    loss.backward()
-    opt.step()
-    return {k: float(v) for k, v in model.logged.items()}
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config")
 
 
-def test_singleview_workload_steps(stack_backend):
-    dev = stack_backend
-    K, size = 17, 64
-    model = bench.build_model(dev, K, size)
-    batch = bench.synth_batch(dev, 0, size, 2, 3, K)
-    assert tuple(batch["labeled"]["heatmaps"].shape) == (2, K, 16, 16) and tuple(batch["unlabeled"]["transforms"].shape) == (2, 3)
-    got = _step(model, batch)
-    for name in ("train_heatmap_mse_loss", "train_temporal_loss", "train_pca_singleview_loss", "train_unimodal_mse_loss", "total_loss"):
-        assert np.isfinite(got[name]), name
+def _run(capsys, dev, *argv):
+    bench.main(list(argv), device=dev)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    for key in CONTRACT:
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["unit"] == "frames/s" and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["data"] == "synthetic" and out["dtype"] == "bf16"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and "workload" in out["config"]
+    return out
 
 
-def test_multiview_workload_steps(stack_backend):
-    dev = stack_backend
-    K, V, size = 3, 2, 64
-    model = bench.build_model(dev, K, size, views=V)
-    batch = bench.synth_multiview_batch(dev, 0, size, 1, 3, K, V)
-    assert tuple(batch["labeled"]["images"].shape) == (1, V, 3, size, size)
-    assert tuple(batch["labeled"]["heatmaps"].shape) == (1, K * V, 16, 16) and tuple(batch["labeled"]["keypoints"].shape) == (1, 2 * K * V)
-    assert tuple(batch["unlabeled"]["frames"].shape) == (3, V, 3, size, size) and tuple(batch["unlabeled"]["transforms"].shape) == (V, 2, 3)
-    assert tuple(batch["unlabeled"]["bbox"].shape) == (3, 4 * V) and batch["unlabeled"]["is_multiview"] is True
-    got = _step(model, batch)
-    for name in ("train_heatmap_mse_loss", "train_temporal_loss", "train_pca_multiview_loss", "total_loss"):
-        assert np.isfinite(got[name]), name
-    assert float(model.net.G.abs().sum()) > 0
-    # the fit data are affine views of one 3-D cloud: 3 components carry (almost) everything
-    pca = model.loss_factory_unsup.loss_instance_dict["pca_multiview"].pca
-    assert pca.parameters["kept_eigenvectors"].shape[0] == 3
+def test_bench_training_line(stack_backend, capsys):
+    out = _run(capsys, stack_backend, "--steps", "1", "--warmup", "0", "--size", "64", "--labeled", "2", "--unlabeled", "3",
+               "--no-cpu-baseline", "--no-profile")
+    assert out["metric"].startswith("training frames/sec") and out["steps"] == 1 and out["warmup"] == 0
+    assert out["config"]["global_batch"] == 5 and out["config"]["parallelism"] == "dp1"
+    assert out["value"] == round(5 * 1 / (out["ms_per_step"] / 1000.0), 2) or abs(out["value"] * out["ms_per_step"] / 1000.0 - 5) < 0.01
+    assert torch.isfinite(torch.tensor(out["config"]["final_loss"]))
+
+
+def test_bench_multiview_line(stack_backend, capsys):
+    out = _run(capsys, stack_backend, "--steps", "1", "--warmup", "0", "--size", "64", "--labeled", "1", "--unlabeled", "3", "--views", "2",
+               "--keypoints", "3", "--no-cpu-baseline", "--no-profile")
+    assert out["config"]["workload"].startswith("C5: multiview") and out["config"]["global_batch"] == (1 + 3) * 2
+
+
+def test_bench_predict_line(stack_backend, capsys):
+    out = _run(capsys, stack_backend, "--predict", "--steps", "1", "--warmup", "0", "--size", "64", "--labeled", "2", "--unlabeled", "3",
+               "--keypoints", "3")
+    assert out["metric"].startswith("inference frames/sec") and out["config"]["global_batch"] == 5 and out["config"]["finite"] is True
 
 
 def test_hbm_rooflines_runs_the_heatmap_kernels(stack_backend):
