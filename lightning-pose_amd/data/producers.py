@@ -102,7 +102,7 @@ class VideoFramePipeline:
             return UnlabeledBatchDict(frames=frames, transforms=transform, bbox=bbox, is_multiview=False)
         views = [self._one_view(f, None if params is None else params[i]) for i, f in enumerate(frames_u8)]
         frames = torch.stack([v[0] for v in views], dim=1)                      # (S, V, 3, H, W)
-        transforms = torch.stack([v[1] for v in views], dim=0)                  # (V, 2, 3) or (V, 1)
+        transforms = torch.stack([v[1] if v[1].dim() == 2 else v[1].reshape(1, 1) for v in views], dim=0)  # (V, 2, 3) or (V, 1, 1)
         bbox = torch.cat([torch.tensor([0.0, 0.0, float(v[2][0]), float(v[2][1])], device=frames.device) for v in views]
                          ).repeat(frames.shape[0], 1)                           # (S, 4V)
         return MultiviewUnlabeledBatchDict(frames=frames, transforms=transforms, bbox=bbox, is_multiview=True)

@@ -69,10 +69,23 @@ def test_video_pipeline_multiview_layout(stack_backend):
     out = VideoFramePipeline([128, 128], imgaug="default")(views)
     assert out["is_multiview"] is True
     assert tuple(out["frames"].shape) == (3, 2, 3, 128, 128)
-    assert tuple(out["transforms"].shape) == (2, 1)
+    assert tuple(out["transforms"].shape) == (2, 1, 1)  # the per-view "nothing to undo" sentinel (data/datatypes.py:227-236)
     assert out["bbox"].cpu().tolist() == [[0.0, 0.0, 60.0, 80.0, 0.0, 0.0, 70.0, 50.0]] * 3
-    out = VideoFramePipeline([128, 128], imgaug="dlc")(views)
-    assert tuple(out["transforms"].shape) == (2, 2, 3)
+    out_aug = VideoFramePipeline([128, 128], imgaug="dlc")(views)
+    assert tuple(out_aug["transforms"].shape) == (2, 2, 3)
+    # both forms go straight into a multiview tracker: (S, V, 3, H, W) frames -> (S, K*V) keypoints in each view's frame coordinates
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+
+    model = SemiSupervisedHeatmapTracker(num_keypoints=2, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None),
+                                         loss_factory_unsupervised=LossFactory({"temporal": {"log_weight": 0.0}}, None), backbone="resnet50",
+                                         pretrained=False, torch_seed=0, device=dev)
+    model.eval()
+    with torch.no_grad():
+        for batch in (out, out_aug):
+            data = model.get_loss_inputs_unlabeled(batch)
+            assert tuple(data["heatmaps_pred"].shape) == (3, 4, 32, 32) and tuple(data["keypoints_pred"].shape) == (3, 8)
+            assert torch.isfinite(data["keypoints_pred"]).all() and torch.isfinite(data["confidences"]).all()
 
 
 def test_labeled_producer_matches_verbatim_dataset_targets(stack_backend, golden):
