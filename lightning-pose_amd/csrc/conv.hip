@@ -1047,6 +1047,19 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
+// Opt-in tile choice (LP_CONV_TAIL_BN64=1, read per call so a process can A/B it): with 128-column tiles a launch of T tiles runs
+// ceil(T / grid) rounds of the persistent grid, and a last round that is mostly empty wastes up to half the chip;
+// 64-column tiles double T at half the work per tile.  Default off: the narrower tile has lower arithmetic intensity and the trade has
+// not been measured yet.
+static bool tail_prefers_bn64(int M, int N) {
+    const char* e = getenv("LP_CONV_TAIL_BN64");
+    if (e == nullptr || atoi(e) <= 0 || N <= 64 || N % 64 != 0) return false;
+    const long long t = (long long)((M + kBM - 1) / kBM) * ((N + 127) / 128);
+    const long long grid = igemm_max_wgs();
+    const long long rounds = (t + grid - 1) / grid;
+    return (double)t < 0.8 * (double)(rounds * grid);
+}
+
 constexpr int kStatsAtomicTiles = 1152;  // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue)
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
 
@@ -1106,7 +1119,7 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     if (bn && ep.stats_sums == nullptr) launch_tile_stats_reduce(ep.stats, tm, N, bn->sums, nullptr, nullptr, st);
     return launch_status();
@@ -1132,7 +1145,7 @@ extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom*
     ep.out_bf16 = (unsigned short*)out_bf16, ep.ldo = N, ep.n_store = N, ep.bias = bias;
     ep.addend = (const unsigned short*)residual_bf16, ep.relu_fwd = relu != 0;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (N > 64) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
+    if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
     else launch_igemm<64, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
     return launch_status();
 }
@@ -1257,7 +1270,7 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         const int tm = (M + kBM - 1) / kBM;
         ep.stats_row0 = stats_rows;
         stats_rows += tm;
-        if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
         else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
     };
     if (g.stride == 1) {
