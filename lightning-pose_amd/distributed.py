@@ -68,6 +68,8 @@ class DataParallel:
         """SUM all-reduce of the flat gradient buffer in large buckets; pair with optimizer.grad_scale = 1/world."""
         if self.world == 1:
             return
+        if hasattr(self.engine, "wait_pending"):
+            self.engine.wait_pending()
         g = self.engine.G
         # backward produces the tail of the buffer (head, layer4) first: reduce from the end
         hi = g.numel()

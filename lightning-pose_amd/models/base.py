@@ -174,8 +174,26 @@ class SemiSupervisedTrackerMixin:
     def training_step(self, batch_dict: dict, batch_idx: int) -> dict[str, torch.Tensor]:
         unsup_importance = self.total_unsupervised_importance
         self.log("total_unsupervised_importance", unsup_importance, prog_bar=True)
-        loss_super = self.evaluate_labeled(batch_dict=batch_dict["labeled"], stage="train", anneal_weight=unsup_importance)
-        loss_unsuper = self.evaluate_unlabeled(batch_dict=batch_dict["unlabeled"], stage="train", anneal_weight=unsup_importance)
+        net = getattr(self, "net", None)
+        if net is not None and getattr(net, "two_streams_active", lambda: False)():
+            # opt-in (LP_TWO_STREAMS=1): the two passes are independent until their losses are added - each runs on its own stream
+            # (autograd replays a node's backward on its forward stream), joined before the sum
+            main = net._cur_stream()
+            for which, key in ((0, "labeled"), (1, "unlabeled")):
+                s_ = net.branch_streams()[which]
+                s_.wait_stream(main)
+                for v in batch_dict[key].values():  # the caller may free the batch while this stream still reads it
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(s_)
+            with net.stream_ctx(0):
+                loss_super = self.evaluate_labeled(batch_dict=batch_dict["labeled"], stage="train", anneal_weight=unsup_importance)
+            with net.stream_ctx(1):
+                loss_unsuper = self.evaluate_unlabeled(batch_dict=batch_dict["unlabeled"], stage="train", anneal_weight=unsup_importance)
+            for s_ in net.branch_streams():
+                main.wait_stream(s_)
+        else:
+            loss_super = self.evaluate_labeled(batch_dict=batch_dict["labeled"], stage="train", anneal_weight=unsup_importance)
+            loss_unsuper = self.evaluate_unlabeled(batch_dict=batch_dict["unlabeled"], stage="train", anneal_weight=unsup_importance)
         total_loss = loss_super + loss_unsuper
         self.log("total_loss", total_loss, prog_bar=True, sync_dist=True)
         return {"loss": total_loss}

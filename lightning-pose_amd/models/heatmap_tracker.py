@@ -35,11 +35,17 @@ class _NetworkFn(torch.autograd.Function):
     def forward(ctx, anchor: torch.Tensor, images: torch.Tensor, net: Engine, training: bool):
         heat, tape = net.forward(images, training=training)
         ctx.net, ctx.tape = net, tape
+        ctx.stream_key = net._stream_key() if hasattr(net, "_stream_key") else 0
         return heat
 
     @staticmethod
     def backward(ctx, g_heat: torch.Tensor):
-        ctx.net.backward(ctx.tape, g_heat)
+        if hasattr(ctx.net, "replay_ctx"):
+            with ctx.net.replay_ctx(ctx.stream_key):
+                ctx.net.backward(ctx.tape, g_heat)
+                ctx.net.note_backward_done()  # two-stream mode: the consumer of G waits for this stream
+        else:
+            ctx.net.backward(ctx.tape, g_heat)
         ctx.tape = None
         return None, None, None, None
 

@@ -41,6 +41,8 @@ class FusedAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         e = self.engine
         lib = _lib.lib()
+        if hasattr(e, "wait_pending"):
+            e.wait_pending()  # two-stream mode: both passes' backward streams are done before G is read
         for g in self.param_groups:
             lo, hi = self._ranges[g["name"]]
             g["step"] += 1

@@ -6,6 +6,8 @@ mkdir -p gpurun_out
 (timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3) > gpurun_out/r02_smoke.log; tail -1 gpurun_out/r02_smoke.log
 timeout 400 python bench.py > gpurun_out/r02_bench_n1.json.log 2>&1; tail -1 gpurun_out/r02_bench_n1.json.log | cut -c1-200
 LP_CONV_TAIL_BN64=1 timeout 400 python bench.py --no-cpu-baseline > gpurun_out/r02_bench_n1_tail_bn64.json.log 2>&1; tail -1 gpurun_out/r02_bench_n1_tail_bn64.json.log | cut -c1-200   # A/B: 64-column tiles for poorly filled rounds
+LP_TWO_STREAMS=1 timeout 400 python bench.py --no-cpu-baseline --no-profile > gpurun_out/r02_bench_n1_two_streams.json.log 2>&1; tail -1 gpurun_out/r02_bench_n1_two_streams.json.log | cut -c1-200   # A/B vs: python bench.py --no-profile
+timeout 400 python bench.py --no-cpu-baseline --no-profile > gpurun_out/r02_bench_n1_noprofile.json.log 2>&1; tail -1 gpurun_out/r02_bench_n1_noprofile.json.log | cut -c1-200
 for bb in resnet50 vits_dino; do
   timeout 300 python bench.py --predict --backbone $bb --steps 10 --warmup 3 > gpurun_out/r02_bench_predict_${bb}.json.log 2>&1; tail -1 gpurun_out/r02_bench_predict_${bb}.json.log | cut -c1-200
 done
