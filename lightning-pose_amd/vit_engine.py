@@ -159,7 +159,14 @@ class ViTEngine(Engine):
         self._wgrad_ws = None
         self._bn_ws = None
         self._side, self._side_busy = None, False
+        self._fold = None
+        self._branches, self._bn_ws_by_stream, self._rs_prev, self._rs_cur, self._pending = None, {}, [], [], []
         self._interp: dict[tuple[int, int], torch.Tensor] = {}
+
+    def two_streams_active(self) -> bool:
+        """Not for this engine: its weight gradients run on the pass's own stream (no side stream), so two concurrent passes would
+        race on the accumulation into G."""
+        return False
 
     # ------------------------------------------------------------------------------------------------ params
     def _views(self, buf: torch.Tensor) -> dict[str, torch.Tensor]:
