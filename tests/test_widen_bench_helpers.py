@@ -51,3 +51,36 @@ def test_hbm_rooflines_runs_the_heatmap_kernels(stack_backend):
     assert set(out["kernels"]) == {"decode_fwd", "decode_fwd_bwd", "heatmap_gen", "heatmap_mse_fwd_bwd"}
     for v in out["kernels"].values():
         assert v["us"] > 0 and v["achieved"] >= 0  # (the emulator moves kilobytes per millisecond)
+
+
+def test_bench_two_ranks_gloo():
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, env rendezvous on 127.0.0.1), on CPU: gloo backend, emulated
+    kernels.  Rank 0 prints ONE line whose value is the whole-job rate; SyncBatchNorm and the gradient all-reduce are on."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "32", "--labeled", "2", "--unlabeled", "2", "--keypoints", "3",
+            "--no-cpu-baseline", "--no-profile"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LP_DIST_BACKEND="gloo", HIPEMU_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_bench_2rank_probe.py"), *argv], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    lines1 = [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and lines1 == []  # only rank 0 reports
+    out = json.loads(lines0[0])
+    for key in CONTRACT:
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["sync_batchnorm"] is True and out["scaling"] == "weak" and out["value"] > 0
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
