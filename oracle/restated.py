@@ -363,6 +363,22 @@ def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None = No
     return F.relu(dist - eps).mean()
 
 
+def temporal_heatmap_loss(heatmaps: torch.Tensor, confidences: torch.Tensor, epsilon: float | torch.Tensor = 0.0,
+                          prob_threshold: float = 0.0, kind: str = "mse") -> torch.Tensor:
+    """losses/losses.py:706-869 `TemporalHeatmapLoss`: per (t, k) the pixel-mean squared difference of consecutive heat-maps ("mse",
+    :815-819) or kornia's kl_div_loss_2d(pred = h_t + 1e-10, target = h_t+1 + 1e-10) = sum target (log target - log pred) ("kl", :820-826);
+    zero where either frame's confidence is below the threshold (:783-791); relu(. - epsilon_k) (:763); mean over all (S-1) K (:865)."""
+    a, b = heatmaps[:-1], heatmaps[1:]
+    if kind == "mse":
+        d = ((a - b) ** 2).mean(dim=(-1, -2))
+    else:
+        d = ((b + 1e-10) * (torch.log(b + 1e-10) - torch.log(a + 1e-10))).sum(dim=(-1, -2))
+    ignore = confidences < prob_threshold
+    d = torch.where(ignore[:-1] | ignore[1:], torch.zeros_like(d), d)
+    eps = torch.as_tensor(epsilon, dtype=d.dtype).reshape(1, -1)
+    return F.relu(d - eps).mean()
+
+
 def pca_format_singleview(keypoints: torch.Tensor, columns: list[int] | None) -> torch.Tensor:
     """utils/pca.py:124-163 (no centring)."""
     kp = keypoints.reshape(keypoints.shape[0], -1, 2)

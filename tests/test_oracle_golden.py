@@ -105,3 +105,15 @@ def test_factory_totals(golden):
     tl = O.temporal_loss(g.t("t_kp"), g.t("t_conf"), 3.0, 0.3)
     for aw in (None, 0.0, 0.5, 1.0):
         close(O.factory_total({"temporal": (tl, 5.0)}, aw), g[f"fac_unsup_aw{aw}"], atol=1e-7)
+
+
+@pytest.mark.parametrize("tag,kind,eps,thr", [("mse_plain", "mse", 0.0, 0.0), ("kl_plain", "kl", 0.0, 0.0), ("mse_thr", "mse", 0.0, 0.4),
+                                              ("kl_thr_eps", "kl", 0.5, 0.4), ("mse_eps_list", "mse", [0.0, 2e-5, 1e-4, 1.0], 0.2)])
+def test_temporal_heatmap_loss(golden, tag, kind, eps, thr):
+    """oracle restatement vs the verbatim TemporalHeatmapLoss (value and gradient)"""
+    g = golden("temporal_heatmap")
+    p = g.t("hm").clone().requires_grad_(True)
+    val = O.temporal_heatmap_loss(p, g.t("conf"), eps, thr, kind)
+    (0.7 * val).backward()
+    assert float(val) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5, abs=1e-10)
+    torch.testing.assert_close(p.grad, g.t(f"{tag}_grad"), rtol=1e-4, atol=1e-9)
