@@ -27,7 +27,7 @@ def _np(t):
 
 
 def save(name, **arrs):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("LP_GOLDEN_OUT", HERE), name + ".npz")  # LP_GOLDEN_OUT: regenerate elsewhere (reproducibility test)
     np.savez_compressed(path, **{k: _np(v) for k, v in arrs.items()})
     print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
 

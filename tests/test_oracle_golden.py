@@ -1,6 +1,8 @@
 """Pin oracle.restated against golden vectors produced by the VERBATIM reference modules
 (tests/golden/make_golden.py).  CPU only."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -117,3 +119,23 @@ def test_temporal_heatmap_loss(golden, tag, kind, eps, thr):
     (0.7 * val).backward()
     assert float(val) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5, abs=1e-10)
     torch.testing.assert_close(p.grad, g.t(f"{tag}_grad"), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lightning_pose"), reason="/root/reference not present (build container only)")
+def test_committed_fixtures_are_what_the_reference_produces_now(tmp_path):
+    """tests/golden/make_golden.py re-run against the reference tree reproduces EVERY committed fixture bit for bit
+    (seeded inputs, verbatim reference modules): the fixtures are outputs of the reference, not of this repository."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["decode", "heatmaps", "geometry", "losses", "callbacks", "tracker_step", "predictions", "labeled_targets", "temporal_heatmap"]
+    env = dict(os.environ, LP_GOLDEN_OUT=str(tmp_path))
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), *names], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    for name in names:
+        with np.load(os.path.join(root, "tests", "golden", name + ".npz")) as a, np.load(tmp_path / (name + ".npz")) as b:
+            assert sorted(a.files) == sorted(b.files), name
+            for k in a.files:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"{name}:{k}")
