@@ -12,6 +12,10 @@
                          out-of-frame -> NaN, visibility synthesis, Gaussian targets (``lp_heatmap_gen``) -> ``HeatmapLabeledBatchDict``
                          with nothing but the uint8 images crossing PCIe.
 
+``FrameWindowSource``   the sequencing half of ``fn.readers.video`` for already-decoded videos (windows of ``sequence_length`` frames every
+                         ``step`` frames, seeded shuffling per rank, zero-padded tails) with the host -> device copy of the next window
+                         overlapping the step on the current one (pinned staging, copy stream).
+
 The image operators are restatements of DALI's / imgaug's published definitions (neither library is available to check against):
 parity of pixel values is UNPINNED; keypoints, visibility and targets are pinned against the verbatim reference dataset.
 """
@@ -168,3 +172,84 @@ class LabeledBatchProducer:
         if idxs is None:
             idxs = torch.arange(b)
         return HeatmapLabeledBatchDict(images=images, keypoints=kp_model.reshape(b, 2 * k), heatmaps=heatmaps, bbox=bbox.to(dev), idxs=idxs)
+
+
+class FrameWindowSource:
+    """The sequencing half of DALI's ``fn.readers.video`` (data/video/dali.py:135-151; pipe arguments :573-606) for videos that are already
+    decoded into uint8 arrays (numpy arrays / memmaps / tensors of shape (N, H, W, 3)): windows of ``sequence_length`` frames starting every
+    ``step`` frames, never across two videos; ``random_shuffle`` draws a seeded permutation of the windows per epoch (training; each rank seeds
+    with ``seed + LOCAL_RANK`` as the reference's pipes do, :558-568), otherwise windows come in order (prediction); with ``pad_sequences`` the
+    incomplete window at the end of a video is kept and its missing frames are zero (``PredictionHandler`` trims those rows), without it the
+    tail is dropped.  Windows are staged through pinned host memory and copied on a side stream one window ahead of the consumer, so the
+    copy of window i+1 overlaps the step on window i.  Decoding the container format is not done here."""
+
+    def __init__(self, videos, sequence_length: int, step: int | None = None, random_shuffle: bool = False, pad_sequences: bool = True,
+                 seed: int = 123456, device: torch.device | str | None = None) -> None:
+        if isinstance(videos, (np.ndarray, torch.Tensor)):
+            videos = [videos]
+        self.videos = list(videos)
+        for v in self.videos:
+            if v.ndim != 4 or v.shape[-1] != 3 or str(v.dtype).replace("torch.", "") != "uint8":
+                raise ValueError(f"each video must be a uint8 array of shape (N, H, W, 3), got {v.dtype} {tuple(v.shape)}")
+        if sequence_length <= 0:
+            raise ValueError("sequence_length must be positive")
+        self.sequence_length = int(sequence_length)
+        self.step = int(step) if step is not None else self.sequence_length
+        self.random_shuffle, self.pad_sequences = bool(random_shuffle), bool(pad_sequences)
+        self.seed = int(seed) + int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device(device) if device is not None else torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        self.epoch = 0
+        self.windows: list[tuple[int, int]] = []  # (video index, first frame)
+        for vi, v in enumerate(self.videos):
+            n, start = int(v.shape[0]), 0
+            while start < n:
+                if start + self.sequence_length <= n or self.pad_sequences:
+                    self.windows.append((vi, start))
+                start += self.step
+        self._copy_stream = None
+
+    def __len__(self) -> int:
+        return len(self.windows)
+
+    @property
+    def frame_count(self) -> int:
+        """frames of the first video (what ``PredictionHandler(video_file=..., frame_count=...)`` needs for one video)"""
+        return int(self.videos[0].shape[0])
+
+    def _host_window(self, vi: int, start: int) -> torch.Tensor:
+        v = self.videos[vi]
+        stop = min(start + self.sequence_length, int(v.shape[0]))
+        chunk = v[start:stop]
+        chunk = chunk if torch.is_tensor(chunk) else torch.from_numpy(np.ascontiguousarray(chunk))
+        if stop - start == self.sequence_length:
+            return chunk
+        out = torch.zeros((self.sequence_length, *chunk.shape[1:]), dtype=torch.uint8)  # pad_sequences: redundant frames are zero
+        out[: stop - start] = chunk
+        return out
+
+    def _to_device(self, host: torch.Tensor) -> tuple[torch.Tensor, object]:
+        if self.device.type != "cuda":
+            return host.to(self.device), None
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        pinned = host if host.is_pinned() else host.pin_memory()
+        with torch.cuda.stream(self._copy_stream):
+            dev = pinned.to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return dev, (done, pinned)  # the pinned buffer stays alive until the copy has been waited for
+
+    def __iter__(self):
+        order = list(range(len(self.windows)))
+        if self.random_shuffle:
+            order = np.random.default_rng(self.seed + self.epoch).permutation(len(order)).tolist()
+        self.epoch += 1
+        nxt = self._to_device(self._host_window(*self.windows[order[0]])) if order else None
+        for i in range(len(order)):
+            cur = nxt
+            nxt = self._to_device(self._host_window(*self.windows[order[i + 1]])) if i + 1 < len(order) else None
+            dev, token = cur
+            if token is not None:
+                torch.cuda.current_stream(self.device).wait_event(token[0])
+                dev.record_stream(torch.cuda.current_stream(self.device))
+            yield dev

@@ -181,3 +181,29 @@ def test_temporal_heatmap_losses_train_through_the_tracker(stack_backend):
     assert got["train_temporal_heatmap_mse_loss"] == pytest.approx(float(want_mse), rel=1e-4)
     assert got["train_temporal_heatmap_kl_loss"] == pytest.approx(float(want_kl), rel=1e-4, abs=1e-9)
     assert float(model.net.G.abs().sum()) > 0
+
+
+def test_frame_window_source_sequences_like_the_video_reader(stack_backend):
+    from lightning_pose_amd.data.producers import FrameWindowSource, VideoFramePipeline
+
+    dev = stack_backend
+    vid_a = (torch.arange(10).view(10, 1, 1, 1) + torch.zeros(10, 4, 6, 3)).to(torch.uint8)        # frame index in every pixel
+    vid_b = (100 + torch.arange(7).view(7, 1, 1, 1) + torch.zeros(7, 4, 6, 3)).to(torch.uint8)
+    # prediction: in order, the tail window padded with zero frames, windows never span two videos
+    src = FrameWindowSource([vid_a.numpy(), vid_b], sequence_length=4, random_shuffle=False, pad_sequences=True, device=dev)
+    firsts = [w[:, 0, 0, 0].cpu().tolist() for w in src]
+    assert firsts == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 0, 0], [100, 101, 102, 103], [104, 105, 106, 0]]
+    assert len(src) == 5 and src.frame_count == 10
+    # no padding: incomplete tails are dropped; a step smaller than the window overlaps windows (context loaders: step = length - 4)
+    src = FrameWindowSource(vid_a, sequence_length=6, step=2, pad_sequences=False, device=dev)
+    assert [w[0, 0, 0, 0].item() for w in src] == [0, 2, 4]
+    # training: a seeded permutation per epoch, reproducible, all windows exactly once
+    s1 = FrameWindowSource([vid_a, vid_b], 4, random_shuffle=True, seed=7, device=dev)
+    s2 = FrameWindowSource([vid_a, vid_b], 4, random_shuffle=True, seed=7, device=dev)
+    e1, e1b, e2 = [w[0, 0, 0, 0].item() for w in s1], [w[0, 0, 0, 0].item() for w in s1], [w[0, 0, 0, 0].item() for w in s2]
+    assert e1 == e2 and sorted(e1) == [0, 4, 8, 100, 104] and sorted(e1b) == sorted(e1)
+    # windows go straight into the frame pipeline
+    out = VideoFramePipeline([32, 32], imgaug="default")(next(iter(FrameWindowSource(vid_a, 4, device=dev))))
+    assert tuple(out["frames"].shape) == (4, 3, 32, 32) and out["bbox"].cpu().tolist() == [[0.0, 0.0, 4.0, 6.0]] * 4
+    with pytest.raises(ValueError):
+        FrameWindowSource(torch.zeros(3, 4, 6, 3), 2, device=dev)  # not uint8
