@@ -144,3 +144,24 @@ def test_predict_video_end_to_end(stack_backend, tmp_path):
     # softmax(T=1000) amplifies fp32 rounding of the up-sampled logits (measured 3e-5 px here; full-size bound 1e-3 px)
     torch.testing.assert_close(kp.reshape(-1, K, 2), want, atol=2e-3, rtol=0)
     torch.testing.assert_close(conf, want_conf, atol=2e-5, rtol=0)
+
+
+def test_decoded_video_to_prediction_table(stack_backend):
+    """uint8 video array -> FrameWindowSource (windows of 4, padded tail) -> VideoFramePipeline -> predict_video: one row per REAL frame,
+    keypoints in the original frame's pixel coordinates (bbox = the whole source frame)"""
+    dev = stack_backend
+    from lightning_pose_amd.data.producers import FrameWindowSource, VideoFramePipeline
+    from lightning_pose_amd.models import HeatmapTracker
+    from lightning_pose_amd.utils.predictions import predict_video
+
+    K = 2
+    g = torch.Generator().manual_seed(0)
+    video = torch.randint(0, 256, (6, 40, 56, 3), generator=g, dtype=torch.uint8)  # 6 frames of 40 x 56
+    model = HeatmapTracker(num_keypoints=K, backbone="resnet50", pretrained=False, torch_seed=1, device=dev)
+    src = FrameWindowSource(video, sequence_length=4, device=dev)
+    pipe = VideoFramePipeline([64, 64], imgaug="default")
+    df = predict_video("clip.mp4", model, (pipe(w) for w in src), cfg=_cfg(["a", "b"]), frame_count=src.frame_count)
+    assert df.shape == (6, 3 * K)  # 2 windows = 8 rows, the 2 zero-padded frames dropped
+    xy = df.to_numpy()
+    assert np.isfinite(xy).all()
+    assert (xy[:, 0::3] >= -8).all() and (xy[:, 0::3] <= 56 + 8).all() and (xy[:, 1::3] >= -8).all() and (xy[:, 1::3] <= 40 + 8).all()
