@@ -66,3 +66,38 @@ class BaseDataModule:
     def full_labeled_dataloader(self) -> Iterator[dict]:
         """Every labeled example in file order (what ``predict_dataset`` iterates, reference :248-261)."""
         return self._ordered(list(range(len(self.dataset))), self.val_batch_size)
+
+
+class UnlabeledDataModule(BaseDataModule):
+    """Labeled splits + an unlabeled video stream for the semi-supervised trackers (reference data/datamodules.py:252-356).
+
+    ``video_source`` yields uint8 frame windows (``FrameWindowSource``), ``video_pipeline`` turns a window into the ``UnlabeledBatchDict``
+    (``VideoFramePipeline``); together they stand where the reference has ``PrepareDALI`` / ``LitDaliWrapper``.  ``train_dataloader`` pairs
+    the two streams like ``CombinedLoader(mode="max_size_cycle")``: an epoch lasts as long as the LONGER stream, the shorter one restarts."""
+
+    def __init__(self, dataset, video_source, video_pipeline, **kwargs) -> None:
+        super().__init__(dataset, **kwargs)
+        self.video_source, self.video_pipeline = video_source, video_pipeline
+
+    def unlabeled_dataloader(self) -> Iterator[dict]:
+        for window in self.video_source:
+            yield self.video_pipeline(window)
+
+    def train_dataloader(self) -> Iterator[dict]:
+        makers = {"labeled": super().train_dataloader, "unlabeled": self.unlabeled_dataloader}
+        its = {k: iter(m()) for k, m in makers.items()}
+        exhausted = {k: False for k in makers}
+        while True:
+            batch = {}
+            for k in makers:
+                try:
+                    batch[k] = next(its[k])
+                except StopIteration:
+                    exhausted[k] = True
+                    if all(exhausted.values()):
+                        return
+                    its[k] = iter(makers[k]())  # the shorter stream cycles
+                    batch[k] = next(its[k])
+            if all(exhausted.values()):
+                return
+            yield batch

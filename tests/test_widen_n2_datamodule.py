@@ -81,3 +81,34 @@ def test_datamodule_splits_and_loaders(stack_backend, tmp_path):
     assert list(df.index) == ds.image_names
     dm2 = BaseDataModule(ds, train_probability=0.8, train_frames=1, torch_seed=42)
     assert len(dm2.train_dataset) == 2  # train_frames == 1 means "all" (a fraction of one)
+
+
+def test_semi_supervised_epoch_from_files_and_frames(stack_backend, tmp_path):
+    """label file + images + a decoded video -> UnlabeledDataModule -> Trainer.fit: one epoch of the semi-supervised tracker with no
+    hand-made tensors in between; the streams pair up like CombinedLoader(mode="max_size_cycle")"""
+    from lightning_pose_amd.data.datamodules import UnlabeledDataModule
+    from lightning_pose_amd.data.datasets import HeatmapDataset
+    from lightning_pose_amd.data.producers import FrameWindowSource, VideoFramePipeline
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+    from lightning_pose_amd.trainer import Trainer
+
+    dev = stack_backend
+    _write_project(tmp_path, with_visible=False)
+    ds = HeatmapDataset(str(tmp_path), "CollectedData.csv", 128, 128, uniform_heatmaps=True, device=dev)
+    video = torch.randint(0, 256, (9, 40, 56, 3), generator=torch.Generator().manual_seed(1), dtype=torch.uint8)
+    dm = UnlabeledDataModule(ds, FrameWindowSource(video, 3, random_shuffle=True, pad_sequences=False, device=dev),
+                             VideoFramePipeline([128, 128], imgaug="dlc", seed=2), train_batch_size=1, train_probability=0.8, torch_seed=0)
+    # 2 labeled batches of 1, 3 unlabeled windows of 3 frames -> 3 steps, the labeled stream restarting once
+    batches = list(dm.train_dataloader())
+    assert len(batches) == 3 and all(set(b) == {"labeled", "unlabeled"} for b in batches)
+    assert [tuple(b["unlabeled"]["frames"].shape) for b in batches] == [(3, 3, 128, 128)] * 3
+    labeled_ids = [b["labeled"]["idxs"].tolist()[0] for b in batches]
+    assert set(labeled_ids[:2]) == set(dm.train_dataset.indices) and labeled_ids[2] in dm.train_dataset.indices
+    model = SemiSupervisedHeatmapTracker(num_keypoints=3, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None),
+                                         loss_factory_unsupervised=LossFactory({"temporal": {"log_weight": 2.0, "epsilon": 0.5}}, None),
+                                         backbone="resnet50", pretrained=False, torch_seed=0, device=dev)
+    trainer = Trainer(max_epochs=1, data_parallel=False, limit_train_batches=1)  # (one step: the emulator is slow at 128 x 128)
+    trainer.fit(model, lambda epoch: dm.train_dataloader())
+    assert len(trainer.logged_history) == 1 and model.global_step == 1
+    assert all(torch.isfinite(torch.tensor(h["total_loss"])) for h in trainer.logged_history)
