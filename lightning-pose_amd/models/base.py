@@ -17,6 +17,9 @@ from torch.optim.lr_scheduler import MultiStepLR
 
 try:  # pragma: no cover - lightning is not installed in the build image
     from lightning.pytorch import LightningModule  # type: ignore
+
+    if not str(getattr(LightningModule, "__module__", "")).startswith(("lightning", "pytorch_lightning")):
+        raise ImportError("sys.modules['lightning.pytorch'] is a stand-in registered by other code, not Lightning")
 except Exception:  # noqa: BLE001
 
     class LightningModule(nn.Module):  # type: ignore[no-redef]
