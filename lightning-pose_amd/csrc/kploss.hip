@@ -12,8 +12,7 @@
 
 namespace lp {
 
-constexpr int kMaxPcaDim = 64;   // 2 * points per PCA sample
-constexpr int kMaxPcaComp = 16;
+constexpr int kMaxPcaDim = 128;  // 2 * points per PCA sample (64 selected keypoints single-view, 64 views multi-view)
 
 // ---- temporal ------------------------------------------------------------------------------------------
 // loss = mean_{t<S-1,k} relu(mask * ||kp[t+1,k] - kp[t,k]|| - eps_k);  grad (for upstream 1) written per keypoint.
@@ -148,7 +147,7 @@ extern "C" int lp_pca_fwd_bwd(const float* kp, int S, int K, const int* index, i
                               lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(kp && index && mean && kept_eigenvectors && loss && grad_unit && S > 0 && K > 0 && rows > 0 && points > 0);
-    if (2 * points > kMaxPcaDim || ncomp > kMaxPcaComp || ncomp < 0) return LP_ERR_UNSUPPORTED;
+    if (2 * points > kMaxPcaDim || ncomp > 2 * points || ncomp < 0) return LP_ERR_UNSUPPORTED;  // any number of kept components up to the dimension
     hipLaunchKernelGGL(pca_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kp, S, K, index, rows, points, mean, kept_eigenvectors,
                        ncomp, epsilon, loss, grad_unit);
     return launch_status();

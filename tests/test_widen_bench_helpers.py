@@ -34,7 +34,7 @@ def test_bench_training_line(stack_backend, capsys):
 
 
 def test_bench_multiview_line(stack_backend, capsys):
-    out = _run(capsys, stack_backend, "--steps", "1", "--warmup", "0", "--size", "64", "--labeled", "1", "--unlabeled", "3", "--views", "2",
+    out = _run(capsys, stack_backend, "--steps", "1", "--warmup", "0", "--size", "32", "--labeled", "1", "--unlabeled", "3", "--views", "2",
                "--keypoints", "3", "--no-cpu-baseline", "--no-profile")
     assert out["config"]["workload"].startswith("C5: multiview") and out["config"]["global_batch"] == (1 + 3) * 2
 

@@ -108,3 +108,26 @@ def test_temporal_heatmap_loss_cases(dev):
     got, _ = loss_obj(heatmaps_pred=varying.to(dev), confidences=conf.to(dev), stage=None)
     parts = loss_obj.rectify_epsilon(loss_obj.remove_nans(conf.to(dev), loss_obj.compute_loss(varying.to(dev))))
     assert float(got) == pytest.approx(float(loss_obj.reduce_loss(parts)), rel=1e-5)
+
+
+def test_pca_loss_keeps_any_number_of_components(dev):
+    """components_to_keep close to 1 on noisy labels keeps most of the 2K dimensions (the reference has no cap): 28 kept of 34, and
+    40 keypoints (80 dimensions) single-view"""
+    from lightning_pose_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    for K, ncomp in ((17, 28), (40, 33)):
+        D = 2 * K
+        q, _ = torch.linalg.qr(torch.randn(D, D, generator=g))
+        kept, mean = q[:ncomp].contiguous(), torch.randn(D, generator=g)
+        kp = (torch.randn(6, D, generator=g) * 5).requires_grad_(True)
+        idx = torch.arange(K, dtype=torch.int32).reshape(1, K)  # (rows = 1, points = K): single-view
+        x = kp.reshape(6, D) - mean
+        r = x - (x @ kept.T) @ kept
+        want = torch.relu(r.reshape(6, K, 2).norm(dim=-1) - 0.3).mean()
+        want.backward()
+        kd = kp.detach().to(dev).requires_grad_(True)
+        got = ops.pca_loss(kd, idx.to(dev), mean.to(dev), kept.to(dev), 0.3)
+        got.backward()
+        assert float(got.detach()) == pytest.approx(float(want.detach()), rel=1e-4)
+        torch.testing.assert_close(kd.grad.cpu(), kp.grad, atol=1e-5, rtol=1e-3)
