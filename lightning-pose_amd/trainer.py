@@ -25,6 +25,7 @@ class Trainer:
         self._want_dp = data_parallel
         self.dp: DataParallel | None = None
         self.logged_history: list[dict[str, float]] = []
+        self.validation_history: list[dict[str, float]] = []
 
     def _hook(self, name: str, *args: Any) -> None:
         for cb in self.callbacks:
@@ -63,7 +64,30 @@ class Trainer:
             model.global_step += 1
         return loss.detach()
 
-    def fit(self, model, batches: Callable[[int], Iterable[dict]] | Iterable[dict]) -> None:
+    @torch.no_grad()
+    def validate(self, model, batches: Iterable[dict], step_name: str = "validation_step") -> dict[str, float]:
+        """Lightning's validation / test loop for this module: eval mode (BatchNorm running statistics - the folded inference forward),
+        no autograd tape, ``validation_step`` per batch, every logged value averaged over the batches (what ``self.log(on_epoch=True)``
+        reports, e.g. the ``val_supervised_loss`` the scheduler / checkpointing monitor)."""
+        was_training = model.training
+        model.eval()
+        totals: dict[str, float] = {}
+        n = 0
+        try:
+            for batch_idx, batch in enumerate(batches):
+                model.logged = {}
+                getattr(model, step_name)(batch, batch_idx)
+                for k, v in model.logged.items():
+                    totals[k] = totals.get(k, 0.0) + float(v)
+                n += 1
+        finally:
+            model.train(was_training)
+        means = {k: v / max(n, 1) for k, v in totals.items()}
+        self.validation_history.append(means)
+        return means
+
+    def fit(self, model, batches: Callable[[int], Iterable[dict]] | Iterable[dict],
+            val_batches: Callable[[int], Iterable[dict]] | None = None) -> None:
         self.setup(model)
         model.train()
         self._hook("on_train_start", model)
@@ -76,4 +100,6 @@ class Trainer:
                     break
                 self.training_batch(model, batch, batch_idx)
                 self.logged_history.append({k: float(v) for k, v in getattr(model, "logged", {}).items()})
+            if val_batches is not None:  # check_val_every_n_epoch = 1
+                self.validate(model, val_batches(epoch))
             self.scheduler.step()

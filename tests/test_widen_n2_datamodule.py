@@ -109,6 +109,10 @@ def test_semi_supervised_epoch_from_files_and_frames(stack_backend, tmp_path):
                                          loss_factory_unsupervised=LossFactory({"temporal": {"log_weight": 2.0, "epsilon": 0.5}}, None),
                                          backbone="resnet50", pretrained=False, torch_seed=0, device=dev)
     trainer = Trainer(max_epochs=1, data_parallel=False, limit_train_batches=1)  # (one step: the emulator is slow at 128 x 128)
-    trainer.fit(model, lambda epoch: dm.train_dataloader())
+    trainer.fit(model, lambda epoch: dm.train_dataloader(), val_batches=lambda epoch: dm.val_dataloader())
     assert len(trainer.logged_history) == 1 and model.global_step == 1
+    # the epoch ended with a validation pass over the held-out labeled example (eval mode, folded-BatchNorm inference forward)
+    assert len(trainer.validation_history) == 1 and model.training
+    val = trainer.validation_history[0]
+    assert {"val_supervised_loss", "val_supervised_rmse", "val_heatmap_mse_loss"} <= set(val) and val["val_supervised_loss"] > 0
     assert all(torch.isfinite(torch.tensor(h["total_loss"])) for h in trainer.logged_history)
