@@ -115,4 +115,15 @@ def test_semi_supervised_epoch_from_files_and_frames(stack_backend, tmp_path):
     assert len(trainer.validation_history) == 1 and model.training
     val = trainer.validation_history[0]
     assert {"val_supervised_loss", "val_supervised_rmse", "val_heatmap_mse_loss"} <= set(val) and val["val_supervised_loss"] > 0
+    # ... and the trained module labels its own dataset: predict_dataset -> DLC-style CSV with the split column
+    import pandas as pd
+
+    from lightning_pose_amd.utils.predictions import predict_dataset
+
+    cfg = {"data": {"keypoint_names": ds.keypoint_names}, "model": {"model_type": "heatmap"}}
+    df = predict_dataset(model, dm, str(tmp_path / "predictions.csv"), cfg=cfg)
+    assert df.shape == (3, 3 * 3 + 1) and list(df.index) == ds.image_names
+    assert sorted(df[("set", "", "")].tolist()) == ["train", "train", "validation"]
+    back = pd.read_csv(tmp_path / "predictions.csv", header=[0, 1, 2], index_col=0)
+    assert back.shape == df.shape and torch.isfinite(torch.tensor(back.iloc[:, :9].to_numpy(dtype=float))).all()
     assert all(torch.isfinite(torch.tensor(h["total_loss"])) for h in trainer.logged_history)
