@@ -84,3 +84,11 @@ def test_bench_two_ranks_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["sync_batchnorm"] is True and out["scaling"] == "weak" and out["value"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+def test_smoke_entry_point_body(stack_backend, capsys):
+    """__graft_entry__.smoke() - the driver's round-end tier - runs its own body here (emulated kernels on CPU; the device under -m gpu)"""
+    import __graft_entry__ as entry
+
+    entry.smoke(device=stack_backend)
+    assert "smoke ok" in capsys.readouterr().out
