@@ -9,6 +9,6 @@ There is NO CPU fallback: every op raises ``LpHipUnavailable`` if ``liblp_hip.so
 are not on a ROCm device.
 """
 
-__version__ = "0.1.0"
+__version__ = "0.1.1"
 
 from . import _lib  # noqa: F401  (does not load the shared library until first use)

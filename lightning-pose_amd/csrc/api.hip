@@ -1,7 +1,7 @@
 // Library-level entry points of liblp_hip.so.
 #include "lp_common.h"
 
-extern "C" int lp_version(void) { return 100; }  // 0.1.0
+extern "C" int lp_version(void) { return 110; }  // 0.1.1: + batch producers, inference conv / fold, temporal heat-map loss, heat-map confidence
 
 extern "C" const char* lp_strerror(int code) {
     if (code == LP_OK) return "ok";
