@@ -263,9 +263,11 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ two-stream mode
     def two_streams_active(self) -> bool:
-        """Opted in, not profiling (HIP events bracket single-stream launches) and not synchronising BatchNorm across ranks on a
-        shared communicator from two streams."""
-        return two_streams_requested() and self.profile is None and not self.sync_bn
+        """Opted in, not profiling (HIP events bracket single-stream launches), not synchronising BatchNorm across ranks on a shared
+        communicator from two streams, and the weight gradients on their ONE side stream (what serialises both passes' accumulation
+        into G)."""
+        return (two_streams_requested() and self.profile is None and not self.sync_bn and self.wgrad_side_stream
+                and os.environ.get("LP_WGRAD_SIDE_STREAM", "1") != "0")
 
     def _cur_stream(self):
         return torch.cuda.current_stream(self.device) if self.device.type == "cuda" else _NoStream()
