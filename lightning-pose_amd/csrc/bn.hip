@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
                                                       const float* __restrict__ rvar, float eps, int per_co,
                                                       unsigned short* __restrict__ w_out, float* __restrict__ bias_out) {
     const int co = blockIdx.x;
-    const float a = gamma[co] * rsqrtf(rvar[co] + eps);
+    const float a = gamma[co] / sqrtf(rvar[co] + eps);  // IEEE divide + sqrt (what F.batch_norm(training=False) folds to), not the 1-ulp rsqrtf
     const float* src = w + (size_t)co * per_co;
     unsigned short* dst = w_out + (size_t)co * per_co;
     for (int j = threadIdx.x; j < per_co; j += 256) dst[j] = f32_to_bf16(src[j] * a);

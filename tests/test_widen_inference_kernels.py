@@ -33,7 +33,8 @@ def test_conv_fwd_act_folded_batchnorm(case, residual, relu):
     a = gamma / torch.sqrt(rvar + 1e-5)
     torch.testing.assert_close(torch.from_numpy(bias), beta - rmean * a, atol=1e-6, rtol=1e-6)
     wf = emu.from_bf16_bits(wf_bits).reshape(Co, R, R, Ci)
-    torch.testing.assert_close(wf, bf(w.permute(0, 2, 3, 1) * a.view(-1, 1, 1, 1)), atol=0, rtol=0)
+    # <= 1 bf16 ulp: the kernel's fp32 scale factor may differ from torch's by a rounding of the divide / sqrt on some hosts
+    torch.testing.assert_close(wf, bf(w.permute(0, 2, 3, 1) * a.view(-1, 1, 1, 1)), atol=0, rtol=2.0 ** -7)
     res = bf(torch.randn(B * g.Ho * g.Wo, Co, generator=gen)) if residual else None
     got = emu.from_bf16_bits(emu.conv_fwd_act(emu.to_bf16_bits(nhwc(x)), wf_bits, g, bias=bias,
                                               residual_bits=emu.to_bf16_bits(res) if residual else None, relu=relu))
