@@ -238,6 +238,11 @@ typedef struct lp_bn_fuse {
     float* dgamma_acc;    /* (C,) or NULL */
     void* workspace;
     size_t workspace_bytes;
+    /* Two BatchNorm segments in ONE launch: images [0, seg_images) and [seg_images, B) keep separate batch statistics - the labeled
+     * and the unlabeled frames of a semi-supervised step, which the reference normalises in two forward calls (models/base.py:682-695).
+     * Then sums is (2 segments, 2, C), mean / invstd are (2, C); dbeta_acc / dgamma_acc receive both segments.  seg_images times the
+     * launch's rows per image must be a multiple of 128 (LP_ERR_UNSUPPORTED otherwise: run the segments as two calls).  0 = one segment. */
+    int seg_images;
 } lp_bn_fuse;
 size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad);
 /* Inference (predict_step, models/heatmap_tracker.py:155-191; eval-mode nn.BatchNorm2d uses its running statistics): the BatchNorm
@@ -277,6 +282,10 @@ int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, floa
 int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream);
 int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, lp_stream_t stream);
+/* two segments at once: sums (2,2,C), mean / invstd (2,C); the running statistics take segment 0's update, then segment 1's - the
+ * order of the reference's two forward calls (labeled, then unlabeled: models/base.py:682-695) */
+int lp_bn_finalize2(const float* sums, float count0, float count1, int C, float eps, float momentum, float* mean, float* invstd,
+                    float* running_mean, float* running_var, lp_stream_t stream);
 /* relu_bits (optional, M*C/8 bytes): bit q of byte i = (y[8*i + q] > 0): a 16x smaller ReLU mask for the backward pass */
 int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                 int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream);

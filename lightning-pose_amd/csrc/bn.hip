@@ -113,20 +113,25 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
 }
 
 // mean / invstd from [sum, sumsq]; running statistics updated with torch's momentum rule (unbiased variance)
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, int C, float eps, float momentum,
+// `nseg` segments ([seg][2][C] sums -> [seg][C] moments), running statistics updated segment by segment in order
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count0, float count1, int nseg, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mu = sums[c] / count;
-    float var = sums[C + c] / count - mu * mu;
-    var = fmaxf(var, 0.f);
-    mean[c] = mu;
-    invstd[c] = 1.f / sqrtf(var + eps);
-    if (running_mean != nullptr) {
-        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const float count = sg == 0 ? count0 : count1;
+        const float* sm = sums + (size_t)sg * 2 * C;
+        const float mu = sm[c] / count;
+        float var = sm[C + c] / count - mu * mu;
+        var = fmaxf(var, 0.f);
+        mean[sg * C + c] = mu;
+        invstd[sg * C + c] = 1.f / sqrtf(var + eps);
+        if (running_mean != nullptr) {
+            const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
     }
 }
 
@@ -601,8 +606,17 @@ extern "C" int lp_bn_finalize(const float* sums, float count, int C, float eps, 
                               float* running_mean, float* running_var, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(sums && mean && invstd && C > 0 && count > 0.f);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, C, eps, momentum, mean,
-                       invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count, 1, C, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    return launch_status();
+}
+
+extern "C" int lp_bn_finalize2(const float* sums, float count0, float count1, int C, float eps, float momentum, float* mean, float* invstd,
+                               float* running_mean, float* running_var, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(sums && mean && invstd && C > 0 && count0 > 0.f && count1 > 0.f);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count0, count1, 2, C, eps,
+                       momentum, mean, invstd, running_mean, running_var);
     return launch_status();
 }
 

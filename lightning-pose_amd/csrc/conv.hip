@@ -14,9 +14,9 @@
 // -> LDS (16 B per lane; the im2col gather, zero padding and stride handling happen in the address computation,
 // nothing is materialised), double-buffered in LDS with ONE barrier per K step; LDS rows are padded to 144 B so
 // the 16-B fragment reads are bank-conflict free.  Tile ids are remapped so each XCD's L2 sees a contiguous range
-// of tiles that share the activation panel.  The weight-gradient contracts over pixels, which are strided in
-// memory, so its operands are transposed on the way into LDS (4x8 register transpose + ds_write_b64) and partial
-// sums of the split-K slices are combined with fp32 atomics straight into the flat gradient buffer.
+// of tiles that share the activation panel.  The weight-gradient contracts over pixels, which are the ROW index of both
+// operands in memory: its tiles keep their memory orientation in LDS and the MFMA fragments come out of ds_read_b64_tr_b16 (the
+// gfx950 LDS transpose read); the pixel slices' partial tiles go to a workspace and a second kernel sums them in a fixed order.
 #include <stdlib.h>
 
 #include "lp_common.h"
@@ -66,6 +66,11 @@ struct ConvEpilogue {
     // kModeInfer (lp_conv_fwd_act): out = [relu](acc + bias + addend) - a BatchNorm folded into the weights and the bias, the
     // residual read as `addend`, the ReLU applied to the value itself
     int relu_fwd;
+    // two BatchNorm segments in one launch (the labeled and the unlabeled frames of a semi-supervised step keep their own batch
+    // statistics, as the reference's two forward calls do): images [0, seg_images) are segment 0, the rest segment 1; a tile never
+    // straddles the boundary (host-checked: seg_images * rows per image is a multiple of the 128-row tile).  Segment s uses
+    // bn_mean / bn_invstd + s * N and adds into stats_sums + s * 2 * N; 0 = one segment
+    int seg_images;
 };
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
@@ -395,13 +400,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             float s0[8], s1[8], mu[8], sc[8], be[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) s0[q] = s1[q] = mu[q] = sc[q] = be[q] = 0.f;
+            // BatchNorm segment of this tile (workgroup-uniform)
+            const int seg_off = (ep.seg_images > 0 && m0 >= ep.seg_images * rows_y * rows_x) ? N : 0;
             if (n < ep.n_store) {
                 if (kBwd && ep.bn_z) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        mu[q] = ep.bn_mean[n + q];
+                        mu[q] = ep.bn_mean[seg_off + n + q];
                         if (ep.mask_from_z) {
-                            sc[q] = ep.bn_invstd[n + q] * ep.bn_gamma[n + q];
+                            sc[q] = ep.bn_invstd[seg_off + n + q] * ep.bn_gamma[n + q];
                             be[q] = ep.bn_beta[n + q];
                         }
                     }
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 }
                 if (kBwd && ep.bn_z && want_stats) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) s1[q] *= ep.bn_invstd[n + q];
+                    for (int q = 0; q < 8; ++q) s1[q] *= ep.bn_invstd[seg_off + n + q];
                 }
             }
             if (want_stats) {
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
                     if (n0 + cl < N) {
                         if (ep.stats_sums != nullptr) {
-                            atomicAdd(&ep.stats_sums[comp * N + n0 + cl], t);
+                            atomicAdd(&ep.stats_sums[2 * seg_off + comp * N + n0 + cl], t);
                             float* acc = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
                             if (acc != nullptr) atomicAdd(&acc[n0 + cl], t);
                         } else {
@@ -977,22 +984,33 @@ static void launch_wgrad_reduce(const float* ws, int slices, int tiles, int tile
     }
 }
 
-// sums[(2,C)] += column sums of the per-tile partials written by the fused epilogues ([rows][2][C] fp32); the optional
-// accumulators receive the same totals (d beta, d gamma of the BatchNorm backward)
-__global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __restrict__ partial, int rows, int C,
+// sums[seg][(2,C)] += column sums of the per-tile partials written by the fused epilogues ([rows][2][C] fp32); the optional
+// accumulators receive the totals of all segments (d beta, d gamma of the BatchNorm backward).  The partial rows of one call are up
+// to 4 ranges (the parity-class launches of a stride-2 data gradient), each split at `mid` into the rows of BatchNorm segment 0 and
+// of segment 1 (mid == end: one segment); blockIdx.z = segment.
+struct StatRanges {
+    int n;
+    int begin[4], mid[4], end[4];
+};
+
+__global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __restrict__ partial, StatRanges rg, int C,
                                                                 float* __restrict__ sums, float* __restrict__ acc0,
                                                                 float* __restrict__ acc1) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
+    const int seg = blockIdx.z;
     float s = 0.f;
     if (col < 2 * C)
-        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) s += partial[(size_t)r * 2 * C + col];
+        for (int i = 0; i < rg.n; ++i) {
+            const int lo = seg == 0 ? rg.begin[i] : rg.mid[i], hi = seg == 0 ? rg.mid[i] : rg.end[i];
+            for (int r = lo + blockIdx.y * 4 + rl; r < hi; r += gridDim.y * 4) s += partial[(size_t)r * 2 * C + col];
+        }
     red[rl][lane] = s;
     __syncthreads();
     if (rl == 0 && col < 2 * C) {
         const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        atomicAdd(&sums[col], t);
+        atomicAdd(&sums[(size_t)seg * 2 * C + col], t);
         if (col < C) {
             if (acc0) atomicAdd(&acc0[col], t);
         } else if (acc1) {
@@ -1001,10 +1019,22 @@ __global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __r
     }
 }
 
-static void launch_tile_stats_reduce(const float* partial, int rows, int C, float* sums, float* acc0, float* acc1, hipStream_t st) {
-    int gy = rows / 64;
+static void launch_tile_stats_reduce(const float* partial, const StatRanges& rg, int nseg, int C, float* sums, float* acc0, float* acc1,
+                                     hipStream_t st) {
+    int rows = 0;
+    for (int i = 0; i < rg.n; ++i) rows += rg.end[i] - rg.begin[i];
+    int gy = rows / 64 / nseg;
     gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
-    hipLaunchKernelGGL(tile_stats_reduce_kernel, dim3((2 * C + 63) / 64, gy), dim3(256), 0, st, partial, rows, C, sums, acc0, acc1);
+    hipLaunchKernelGGL(tile_stats_reduce_kernel, dim3((2 * C + 63) / 64, gy, nseg), dim3(256), 0, st, partial, rg, C, sums, acc0, acc1);
+}
+
+// rows of BatchNorm segment 0 in a launch whose images have `rows_per_image` output rows each; -1 if a 128-row tile would straddle
+// the boundary (unsupported), `M` itself for a single segment
+static long long seg_split_rows(int seg_images, int B, long long rows_per_image, long long M) {
+    if (seg_images <= 0) return M;
+    if (seg_images >= B) return -1;
+    const long long r = (long long)seg_images * rows_per_image;
+    return (r % kBM == 0) ? r : -1;
 }
 
 static size_t bn_workspace_rows(long long m_out) { return (size_t)((m_out + kBM - 1) / kBM + 4); }
@@ -1060,7 +1090,16 @@ static bool tail_prefers_bn64(int M, int N) {
     return (double)t < 0.8 * (double)(rounds * grid);
 }
 
-constexpr int kStatsAtomicTiles = 1152;  // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue)
+// row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue); LP_STATS_ATOMIC_TILES overrides it (tests force the
+// per-tile workspace + tile_stats_reduce path on small problems with 0)
+static int stats_atomic_tiles() {
+    static int v = [] {
+        const char* e = getenv("LP_STATS_ATOMIC_TILES");
+        return e ? atoi(e) : 1152;
+    }();
+    return v;
+}
+#define kStatsAtomicTiles stats_atomic_tiles()
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
 
 struct WgradPlan {
@@ -1111,9 +1150,13 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     const int tm = (M + kBM - 1) / kBM;
+    long long split = M;
     if (bn) {
-        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * N * sizeof(float));
+        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * N * sizeof(float) && bn->seg_images >= 0);
         if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
+        split = seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M);
+        if (split < 0) return LP_ERR_UNSUPPORTED;
+        ep.seg_images = bn->seg_images;
         ep.stats = (float*)bn->workspace;
         if (tm <= kStatsAtomicTiles) ep.stats_sums = bn->sums;
     }
@@ -1121,7 +1164,10 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
-    if (bn && ep.stats_sums == nullptr) launch_tile_stats_reduce(ep.stats, tm, N, bn->sums, nullptr, nullptr, st);
+    if (bn && ep.stats_sums == nullptr) {
+        const StatRanges rg{1, {0, 0, 0, 0}, {split == M ? tm : (int)(split / kBM), 0, 0, 0}, {tm, 0, 0, 0}};
+        launch_tile_stats_reduce(ep.stats, rg, bn->seg_images > 0 ? 2 : 1, N, bn->sums, nullptr, nullptr, st);
+    }
     return launch_status();
 }
 
@@ -1260,19 +1306,41 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
             ep.stats_acc0 = bn->dbeta_acc;
             ep.stats_acc1 = bn->dgamma_acc;
         }
-        LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)));
+        LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)) && bn->seg_images >= 0);
+        ep.seg_images = bn->seg_images;
     }
     hipStream_t st = (hipStream_t)stream;
     int stats_rows = 0;
+    StatRanges rg{};
+    bool seg_ok = true;
     auto launch = [&](const Lattice& lat) {
         const int M = g.B * lat.nh * lat.nw, K = lat.nr * lat.ns * g.Co;
         if (M <= 0) return;
         const int tm = (M + kBM - 1) / kBM;
         ep.stats_row0 = stats_rows;
+        if (bn) {
+            const long long split = seg_split_rows(bn->seg_images, g.B, (long long)lat.nh * lat.nw, M);
+            if (split < 0 || rg.n >= 4) {
+                seg_ok = false;
+                return;
+            }
+            rg.begin[rg.n] = stats_rows;
+            rg.mid[rg.n] = stats_rows + (split == M ? tm : (int)(split / kBM));
+            rg.end[rg.n] = stats_rows + tm;
+            ++rg.n;
+        }
         stats_rows += tm;
         if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
         else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
     };
+    if (bn && bn->seg_images > 0) {  // check every launch's segment boundary BEFORE anything is enqueued
+        if (bn->seg_images >= g.B) return LP_ERR_UNSUPPORTED;
+        const int hh[2] = {g.stride == 1 ? g.Hi : (g.Hi + 1) / 2, g.stride == 1 ? g.Hi : g.Hi / 2};
+        const int ww[2] = {g.stride == 1 ? g.Wi : (g.Wi + 1) / 2, g.stride == 1 ? g.Wi : g.Wi / 2};
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                if (hh[a] * ww[b] > 0 && ((long long)bn->seg_images * hh[a] * ww[b]) % kBM != 0) return LP_ERR_UNSUPPORTED;
+    }
     if (g.stride == 1) {
         launch(Lattice{0, 1, g.Hi, 0, 1, g.Wi, 0, 1, g.R, 0, 1, g.S});
     } else {
@@ -1287,7 +1355,9 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
                 launch(Lattice{h0, 2, nh, w0, 2, nw, ph, 2, nr, pw, 2, ns});
             }
     }
-    if (bn && ep.stats_sums == nullptr) launch_tile_stats_reduce(ep.stats, stats_rows, N, bn->sums, bn->dbeta_acc, bn->dgamma_acc, st);
+    if (!seg_ok) return LP_ERR_UNSUPPORTED;
+    if (bn && ep.stats_sums == nullptr)
+        launch_tile_stats_reduce(ep.stats, rg, bn->seg_images > 0 ? 2 : 1, N, bn->sums, bn->dbeta_acc, bn->dgamma_acc, st);
     return launch_status();
 }
 
@@ -1411,13 +1481,20 @@ static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom
     const int tm = (M + kBM - 1) / kBM;
     ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    long long split = M;
     if (bn) {
-        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * 64 * sizeof(float));
+        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * 64 * sizeof(float) && bn->seg_images >= 0);
+        split = seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M);
+        if (split < 0) return LP_ERR_UNSUPPORTED;
+        ep.seg_images = bn->seg_images;
         ep.stats = (float*)bn->workspace;
     }
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
-    if (bn) launch_tile_stats_reduce(ep.stats, tm, 64, bn->sums, nullptr, nullptr, (hipStream_t)stream);
+    if (bn) {
+        const StatRanges rg{1, {0, 0, 0, 0}, {split == M ? tm : (int)(split / kBM), 0, 0, 0}, {tm, 0, 0, 0}};
+        launch_tile_stats_reduce(ep.stats, rg, bn->seg_images > 0 ? 2 : 1, 64, bn->sums, nullptr, nullptr, (hipStream_t)stream);
+    }
     return launch_status();
 }
 

@@ -246,6 +246,8 @@ class Engine:
             self.R[b.r_off + b.C:b.r_off + 2 * b.C] = 1.0
         self.nbt = torch.zeros((), dtype=torch.long)  # shared num_batches_tracked of every BatchNorm
         self.sync_bn = False          # set by the DDP wrapper when world_size > 1 (reference: train.py:427)
+        self._bwd_training = True     # mode of the forward pass whose backward is running (eval: no batch-statistics terms)
+        self.sync_bn_messages = 0     # SyncBatchNorm all-reduces issued so far (bench.py reports them per step)
         self.process_group = None
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
@@ -460,7 +462,7 @@ class Engine:
         return _lib.ConvGeom(B, Hi, Wi, c.Ci, Ho, Wo, c.Co, c.k, c.k, c.stride, c.pad)
 
     def _bn_fuse(self, g: _lib.ConvGeom, dgrad: bool, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None,
-                 mask_from_z: bool = False, relu_bits=None) -> _lib.BnFuse:
+                 mask_from_z: bool = False, relu_bits=None, seg: int = 0) -> _lib.BnFuse:
         """lp_bn_fuse for one launch; the per-tile workspace is one scratch buffer reused by every launch of the stream."""
         need = int(self._lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
         if self.two_streams_active():  # the scratch is reused by every launch of ONE stream: one buffer per stream
@@ -474,6 +476,7 @@ class Engine:
             ws = self._bn_ws
         f = _lib.BnFuse()
         f.sums, f.workspace, f.workspace_bytes = sums.data_ptr(), ws.data_ptr(), need
+        f.seg_images = seg
         if dgrad:
             f.z, f.mean, f.invstd = z.data_ptr(), mean.data_ptr(), invstd.data_ptr()
             f.gamma, f.beta = self.param_view(b, "weight").data_ptr(), self.param_view(b, "bias").data_ptr()
@@ -482,8 +485,9 @@ class Engine:
             f.dbeta_acc, f.dgamma_acc = self.G[b.b_off:].data_ptr(), self.G[b.g_off:].data_ptr()
         return f
 
-    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None):
-        """``sums`` (2,Co): also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics pass, fused)."""
+    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None, seg: int = 0):
+        """``sums`` (segments,2,Co): also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics pass, fused);
+        ``seg`` > 0: images [0, seg) and [seg, B) are two BatchNorm segments with their own sums."""
         g = self._geom(c, B, Hi, Wi)
         out = torch.empty(B, g.Ho, g.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
         w = self.Wb[c.w_off:]
@@ -492,37 +496,58 @@ class Engine:
             if sums is None:
                 run = lambda: check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), st), "lp_stem_fwd")  # noqa: E731
             else:
-                f = self._bn_fuse(g, False, sums)
+                f = self._bn_fuse(g, False, sums, seg=seg)
                 run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
             self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run)
         else:
             if sums is None:
                 run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
             else:
-                f = self._bn_fuse(g, False, sums)
+                f = self._bn_fuse(g, False, sums, seg=seg)
                 run = lambda: check(self._lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_conv_fwd_bn")  # noqa: E731
             self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run)
         return out, g
 
-    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False):
-        """-> (mean, invstd) of this pass: batch statistics (running statistics updated) in training, running statistics otherwise"""
-        mean = torch.empty(b.C, device=self.device, dtype=torch.float32)
+    @staticmethod
+    def _segments(B: int, seg: int) -> list[tuple[int, int]]:
+        """[(first image, images)] of the BatchNorm segments of a pass over B images"""
+        return [(0, B)] if not seg else [(0, seg), (seg, B - seg)]
+
+    def can_segment(self, n0: int, H: int, W: int) -> bool:
+        """Can a pass over n0 + n1 images of H x W keep two BatchNorm segments in ONE launch per layer?  The segment boundary must
+        fall on a 128-row tile boundary of every fused launch; the smallest per-image row count (the trunk's output map, which is also
+        what a parity class of the stride-2 data gradients covers) decides, every other map is 4^k times larger."""
+        return n0 > 0 and H % 32 == 0 and W % 32 == 0 and (n0 * (H // 32) * (W // 32)) % 128 == 0
+
+    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False, seg: int = 0):
+        """-> (mean, invstd) of this pass, each (segments, C) flattened: batch statistics (running statistics updated, segment by
+        segment) in training, running statistics otherwise"""
+        B = z.shape[0]
+        rpi = M // B
+        segs = self._segments(B, seg if training else 0)
+        mean = torch.empty(len(segs) * b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         if training:
             if not have_sums:
-                check(self._lib.lp_bn_stats(_p(z), M, b.C, _p(sums), ops._stream()), "lp_bn_stats")
-            count = float(M)
-            if self.sync_bn:
+                for si, (i0, n) in enumerate(segs):
+                    check(self._lib.lp_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), ops._stream()), "lp_bn_stats")
+            counts = [float(n * rpi) for _, n in segs]
+            if self.sync_bn:  # ONE message carries every segment's [sum, sum of squares]
                 dist.all_reduce(sums, group=self.process_group)
-                count *= dist.get_world_size(self.process_group)
+                self.sync_bn_messages += 1
+                counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             ordered = self.two_streams_active()
             if ordered:  # this layer's running statistics: after the previous pass's update of the same layer (labeled, then unlabeled)
                 i = len(self._rs_cur)
                 if i < len(self._rs_prev):
                     self._cur_stream().wait_event(self._rs_prev[i])
-            check(self._lib.lp_bn_finalize(_p(sums), count, b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd),
-                                           _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")),
-                                           ops._stream()), "lp_bn_finalize")
+            rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
+            if len(segs) == 1:
+                check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
+                      "lp_bn_finalize")
+            else:
+                check(self._lib.lp_bn_finalize2(_p(sums), counts[0], counts[1], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv,
+                                                ops._stream()), "lp_bn_finalize2")
             if ordered:
                 ev = self._new_event()
                 ev.record(self._cur_stream())
@@ -533,13 +558,18 @@ class Engine:
         return mean, invstd
 
     def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
-                have_sums: bool = False, want_bits: bool = False):
+                have_sums: bool = False, want_bits: bool = False, seg: int = 0):
         """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass"""
-        mean, invstd = self._bn_moments(b, z, M, training, sums, have_sums)
+        mean, invstd = self._bn_moments(b, z, M, training, sums, have_sums, seg)
         y = torch.empty_like(z)
         bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
-        check(self._lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias")),
-                                    _p(residual), int(relu), M, b.C, _p(y), _p(bits), ops._stream()), "lp_bn_apply")
+        B = z.shape[0]
+        rpi = M // B
+        gam, bet = _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias"))
+        for si, (i0, n) in enumerate(self._segments(B, seg if training else 0)):
+            check(self._lib.lp_bn_apply(_p(z[i0:i0 + n]), _p(mean[si * b.C:]), _p(invstd[si * b.C:]), gam, bet,
+                                        _p(residual[i0:i0 + n]) if residual is not None else None, int(relu), n * rpi, b.C, _p(y[i0:i0 + n]),
+                                        _p(bits[i0 * rpi * b.C // 8:]) if want_bits else None, ops._stream()), "lp_bn_apply")
         if want_bits:
             return y, mean, invstd, bits
         return y, mean, invstd
@@ -620,38 +650,55 @@ class Engine:
         return d
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, images: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:
-        """images (B,3,H,W) fp32 NCHW -> heat-maps (B,K,H/2^ds,W/2^ds) fp32, plus the tape for backward()."""
-        ops.require_device(images)
-        images = images.to(torch.float32).contiguous()
-        B, _, H, W = images.shape
+    def forward(self, images, training: bool = True) -> tuple[torch.Tensor, Tape]:
+        """images (B,3,H,W) fp32 NCHW -> heat-maps (B,K,H/2^ds,W/2^ds) fp32, plus the tape for backward().
+
+        ``images`` may be a pair of tensors (the labeled and the unlabeled frames of a semi-supervised step, reference
+        models/base.py:682-695): both go through every layer in ONE launch, as two BatchNorm segments that keep their own batch
+        statistics and update the running statistics in order - the result of the reference's two forward calls at the launch count
+        and tile fill of one (check ``can_segment`` first)."""
+        parts = list(images) if isinstance(images, (list, tuple)) else [images]
+        for p_ in parts:
+            ops.require_device(p_)
+        parts = [p_.to(torch.float32).contiguous() for p_ in parts]
+        _, _, H, W = parts[0].shape
         if H % 32 or W % 32:
             raise ValueError(f"image size must be a multiple of 32, got {H}x{W}")
+        if len(parts) > 2 or any(p_.shape[1:] != parts[0].shape[1:] for p_ in parts):
+            raise ValueError("a joint pass takes at most two batches of equally sized images")
+        B = sum(p_.shape[0] for p_ in parts)
+        seg = parts[0].shape[0] if (len(parts) == 2 and training) else 0
+        if seg and not self.can_segment(seg, H, W):
+            raise NotImplementedError(f"{seg} images of {H}x{W} do not end on a tile boundary in every layer: run the two batches separately")
         tp = Tape()
         T = tp.t
         plan = self.plan
         if training and self.two_streams_active():
             self._rs_prev, self._rs_cur = self._rs_cur, []
-        n_bn = sum(2 * b.C for b in plan.bns)
+        nseg = 2 if seg else 1
+        n_bn = sum(2 * b.C for b in plan.bns) * nseg
         sums_all = torch.zeros(n_bn, device=self.device, dtype=torch.float32)
         so = [0]
 
         def next_sums(b: BNP) -> torch.Tensor:
-            s = sums_all[so[0]:so[0] + 2 * b.C]
-            so[0] += 2 * b.C
+            s = sums_all[so[0]:so[0] + 2 * b.C * nseg]
+            so[0] += 2 * b.C * nseg
             return s
 
         x4 = torch.empty(B, H, W, 4, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_images_to_nhwc4(_p(images), B, H, W, _p(x4), ops._stream()), "lp_images_to_nhwc4")
+        i0 = 0
+        for p_ in parts:
+            check(self._lib.lp_images_to_nhwc4(_p(p_), p_.shape[0], H, W, _p(x4[i0:]), ops._stream()), "lp_images_to_nhwc4")
+            i0 += p_.shape[0]
         T["x4"] = x4
         def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu, bits_key=None):
             """conv -> BatchNorm(+residual)(+ReLU); in training the statistics come out of the convolution's store pass.
             ``bits_key``: keep the output's 1-bit ReLU mask on the tape (block outputs: their backward reads it instead of the
             activation itself)"""
             sums = next_sums(b)
-            zz, gg = self._conv_fwd(c, xin, B, hh, ww, sums if training else None)
+            zz, gg = self._conv_fwd(c, xin, B, hh, ww, sums if training else None, seg=seg)
             res = self._bn_fwd(b, zz, B * gg.Ho * gg.Wo, residual, relu, training, sums, have_sums=training,
-                               want_bits=bits_key is not None and training)
+                               want_bits=bits_key is not None and training, seg=seg)
             if len(res) == 4:
                 T[bits_key] = res[3]
             aa, mm, vv = res[:3]
@@ -660,15 +707,17 @@ class Engine:
         # stem: conv -> [BatchNorm -> ReLU -> max-pool] in one pass; the full-resolution activation between them is never stored
         sb = plan.stem_bn
         s_sums = next_sums(sb)
-        z, g = self._conv_fwd(plan.stem, x4, B, H, W, s_sums if training else None)
+        z, g = self._conv_fwd(plan.stem, x4, B, H, W, s_sums if training else None, seg=seg)
         h, w = g.Ho, g.Wo
-        mu, iv = self._bn_moments(sb, z, B * h * w, training, s_sums, have_sums=training)
+        mu, iv = self._bn_moments(sb, z, B * h * w, training, s_sums, have_sums=training, seg=seg)
         T["stem.z"], T["stem.mu"], T["stem.iv"] = z, mu, iv
         ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         x = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.bfloat16)
         T["pool.arg"] = torch.empty(B, ph, pw, 64, device=self.device, dtype=torch.uint8)
-        check(self._lib.lp_bn_relu_maxpool_fwd(_p(z), _p(mu), _p(iv), _p(self.param_view(sb, "weight")), _p(self.param_view(sb, "bias")), B, h, w,
-                                               64, _p(x), _p(T["pool.arg"]), ops._stream()), "lp_bn_relu_maxpool_fwd")
+        for si, (i0, n) in enumerate(self._segments(B, seg)):
+            check(self._lib.lp_bn_relu_maxpool_fwd(_p(z[i0:i0 + n]), _p(mu[si * 64:]), _p(iv[si * 64:]), _p(self.param_view(sb, "weight")),
+                                                   _p(self.param_view(sb, "bias")), n, h, w, 64, _p(x[i0:i0 + n]), _p(T["pool.arg"][i0:i0 + n]),
+                                                   ops._stream()), "lp_bn_relu_maxpool_fwd")
         h, w = ph, pw
         tp.meta["stem_hw"] = (g.Ho, g.Wo)
 
@@ -692,9 +741,9 @@ class Engine:
 
         heat = self._head_forward(x, B, h, w, T)
         T["heat"] = heat
-        tp.meta.update(B=B, H=H, W=W, training=training)
+        tp.meta.update(B=B, H=H, W=W, training=training, seg=seg)
         if training:
-            self.nbt += 1
+            self.nbt += nseg  # one count per forward call of the reference
             self._fold = None  # the running statistics moved
         return heat, tp
 
@@ -762,24 +811,39 @@ class Engine:
         return self._head_forward(x, B, h, w, {})
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None):
-        """``sums``: the (2,C) reductions [sum dy, sum dy*xhat] when the dgrad that produced ``dy`` already made them."""
+    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None, seg: int = 0):
+        """``sums``: the (segments,2,C) reductions [sum dy, sum dy*xhat] when the dgrad that produced ``dy`` already made them."""
+        B = z.shape[0]
+        rpi = M // B
+        segs = self._segments(B, seg)
+        Cn = b.C
         if sums is None:
-            sums = torch.zeros(2 * b.C, device=self.device, dtype=torch.float32)
-            check(self._lib.lp_bn_bwd_reduce(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), M, b.C, _p(sums),
-                                             _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), ops._stream()), "lp_bn_bwd_reduce")
-        count = float(M)
-        if self.sync_bn:
+            sums = torch.zeros(len(segs) * 2 * Cn, device=self.device, dtype=torch.float32)
+            for si, (i0, n) in enumerate(segs):
+                check(self._lib.lp_bn_bwd_reduce(_p(dy[i0:i0 + n]), _p(y_out[i0:i0 + n]) if y_out is not None else None, _p(z[i0:i0 + n]),
+                                                 _p(mean[si * Cn:]), _p(invstd[si * Cn:]), n * rpi, Cn, _p(sums[si * 2 * Cn:]),
+                                                 _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), ops._stream()), "lp_bn_bwd_reduce")
+        world = 1
+        if not self._bwd_training:
+            # eval-mode BatchNorm (running statistics) is a fixed per-channel affine map: dz = dy * gamma * invstd, without the
+            # batch-statistics correction terms (d gamma / d beta above are the same sums in both modes)
+            sums = torch.zeros_like(sums)
+        elif self.sync_bn:
             dist.all_reduce(sums, group=self.process_group)
-            count *= dist.get_world_size(self.process_group)
+            self.sync_bn_messages += 1
+            world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if want_dres else None
-        check(self._lib.lp_bn_bwd_apply(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), _p(self.param_view(b, "weight")), _p(sums),
-                                        count, M, b.C, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply")
+        gam = _p(self.param_view(b, "weight"))
+        for si, (i0, n) in enumerate(segs):
+            check(self._lib.lp_bn_bwd_apply(_p(dy[i0:i0 + n]), _p(y_out[i0:i0 + n]) if y_out is not None else None, _p(z[i0:i0 + n]),
+                                            _p(mean[si * Cn:]), _p(invstd[si * Cn:]), gam, _p(sums[si * 2 * Cn:]), float(n * rpi * world),
+                                            n * rpi, Cn, _p(dz[i0:i0 + n]), _p(dres[i0:i0 + n]) if want_dres else None, ops._stream()),
+                  "lp_bn_bwd_apply")
         return dz, dres
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
-                  relu_bits=None):
+                  relu_bits=None, seg: int = 0):
         """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
         ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
         for stride-2 layers only the pixels a filter tap reaches are touched.
@@ -800,7 +864,7 @@ class Engine:
             if relu_bits is not None:
                 relu_mask = None  # the 1-bit form replaces the activation tensor as the mask source
             f = self._bn_fuse(g, True, sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None,
-                              relu_bits=relu_bits)
+                              relu_bits=relu_bits, seg=seg)
             run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
                                                            C.byref(f), st), "lp_conv_dgrad_bn")
         else:
@@ -815,15 +879,18 @@ class Engine:
         ``trace`` (tests only): receives the gradient tensor at every block boundary."""
         T, plan = tp.t, self.plan
         B, H, W = tp.meta["B"], tp.meta["H"], tp.meta["W"]
+        self._bwd_training = bool(tp.meta.get("training", True))
         d = self._head_backward(T, B, g_heat)
 
+        seg = tp.meta.get("seg", 0)
+        nseg = 2 if seg else 1
         # One zeroed buffer for the reductions of every fused BatchNorm backward of this pass.
-        bsums_all = torch.zeros(sum(2 * b.C for b in plan.bns), device=self.device, dtype=torch.float32)
+        bsums_all = torch.zeros(sum(2 * b.C for b in plan.bns) * nseg, device=self.device, dtype=torch.float32)
         bo = [0]
 
         def new_sums(b: BNP) -> torch.Tensor:
-            t = bsums_all[bo[0]:bo[0] + 2 * b.C]
-            bo[0] += 2 * b.C
+            t = bsums_all[bo[0]:bo[0] + 2 * b.C * nseg]
+            bo[0] += 2 * b.C * nseg
             return t
 
         d_sums = None  # reductions of the current block's bn3 backward, when the dgrad that produced `d` already made them
@@ -843,22 +910,22 @@ class Engine:
             # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head) and the inputs of the stride-2
             # blocks (two partial writers) still run lp_bn_bwd_reduce; the stem has its own fused pair (lp_bn_pool_bwd_*).
             if last:
-                dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True)
+                dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True, seg=seg)
             else:
-                dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False, sums=d_sums)
+                dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False, sums=d_sums, seg=seg)
                 dres = d
             s2 = new_sums(blk.bn2)
             da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True,
-                                 bn=(blk.bn2, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], s2))
-            dz2, _ = self._bn_bwd(blk.bn2, da2, None, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False, sums=s2)
+                                 bn=(blk.bn2, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], s2), seg=seg)
+            dz2, _ = self._bn_bwd(blk.bn2, da2, None, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False, sums=s2, seg=seg)
             s1 = new_sums(blk.bn1)
             da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True,
-                                 bn=(blk.bn1, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], s1))
-            dz1, _ = self._bn_bwd(blk.bn1, da1, None, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False, sums=s1)
+                                 bn=(blk.bn1, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], s1), seg=seg)
+            dz1, _ = self._bn_bwd(blk.bn1, da1, None, T[f"{key}.z1"], T[f"{key}.m1"], T[f"{key}.v1"], Mi, False, sums=s1, seg=seg)
             mask_x = x if i > 0 else None  # block 0's input is the max-pool output: its ReLU is handled by the stem BN backward
             d_sums = None
             if blk.down is not None:
-                dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False)
+                dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False, seg=seg)
                 # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
                 # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x)
@@ -868,7 +935,7 @@ class Engine:
                 d_sums = new_sums(prev.bn3)
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x,
                                    bn=(prev.bn3, T[f"{pk}.z3"], T[f"{pk}.m3"], T[f"{pk}.v3"], d_sums),
-                                   relu_bits=T.get(f"{pk}.out_bits"))
+                                   relu_bits=T.get(f"{pk}.out_bits"), seg=seg)
             else:
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x)
 
@@ -878,18 +945,26 @@ class Engine:
         # max-pool, ReLU and BatchNorm backward of the stem in two passes over z (the reductions, then dz): the activation's gradient
         # is rebuilt on the fly from the pooled gradient and the arg-max bytes, the ReLU gate from z
         sb = plan.stem_bn
-        ssum = torch.zeros(2 * sb.C, device=self.device, dtype=torch.float32)
+        segs = self._segments(B, seg)
+        ssum = torch.zeros(nseg * 2 * sb.C, device=self.device, dtype=torch.float32)
         gam, bet = self.param_view(sb, "weight"), self.param_view(sb, "bias")
-        check(self._lib.lp_bn_pool_bwd_reduce(_p(T["pool.arg"]), _p(d), _p(T["stem.z"]), _p(T["stem.mu"]), _p(T["stem.iv"]), _p(gam), _p(bet), B,
-                                              sh, sw, 64, _p(ssum), _p(self.G[sb.b_off:]), _p(self.G[sb.g_off:]), ops._stream()),
-              "lp_bn_pool_bwd_reduce")
-        count = float(B * sh * sw)
-        if self.sync_bn:
+        arg, sz, smu, siv = T["pool.arg"], T["stem.z"], T["stem.mu"], T["stem.iv"]
+        for si, (i0, n) in enumerate(segs):
+            check(self._lib.lp_bn_pool_bwd_reduce(_p(arg[i0:i0 + n]), _p(d[i0:i0 + n]), _p(sz[i0:i0 + n]), _p(smu[si * sb.C:]), _p(siv[si * sb.C:]),
+                                                  _p(gam), _p(bet), n, sh, sw, 64, _p(ssum[si * 2 * sb.C:]), _p(self.G[sb.b_off:]),
+                                                  _p(self.G[sb.g_off:]), ops._stream()), "lp_bn_pool_bwd_reduce")
+        world = 1
+        if not self._bwd_training:
+            ssum = torch.zeros_like(ssum)
+        elif self.sync_bn:
             dist.all_reduce(ssum, group=self.process_group)
-            count *= dist.get_world_size(self.process_group)
+            self.sync_bn_messages += 1
+            world = dist.get_world_size(self.process_group)
         dz = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_bn_pool_bwd_apply(_p(T["pool.arg"]), _p(d), _p(T["stem.z"]), _p(T["stem.mu"]), _p(T["stem.iv"]), _p(gam), _p(bet),
-                                             _p(ssum), count, B, sh, sw, 64, _p(dz), ops._stream()), "lp_bn_pool_bwd_apply")
+        for si, (i0, n) in enumerate(segs):
+            check(self._lib.lp_bn_pool_bwd_apply(_p(arg[i0:i0 + n]), _p(d[i0:i0 + n]), _p(sz[i0:i0 + n]), _p(smu[si * sb.C:]), _p(siv[si * sb.C:]),
+                                                 _p(gam), _p(bet), _p(ssum[si * 2 * sb.C:]), float(n * sh * sw * world), n, sh, sw, 64,
+                                                 _p(dz[i0:i0 + n]), ops._stream()), "lp_bn_pool_bwd_apply")
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
                     lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True))

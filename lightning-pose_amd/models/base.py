@@ -195,8 +195,18 @@ class SemiSupervisedTrackerMixin:
             for s_ in net.branch_streams():
                 main.wait_stream(s_)
         else:
-            loss_super = self.evaluate_labeled(batch_dict=batch_dict["labeled"], stage="train", anneal_weight=unsup_importance)
-            loss_unsuper = self.evaluate_unlabeled(batch_dict=batch_dict["unlabeled"], stage="train", anneal_weight=unsup_importance)
+            # default: both batches share ONE pass through the network (two BatchNorm segments per launch - same statistics, running-
+            # statistics order and gradients as the reference's two forward calls, half the launches, fuller tile rounds); the two
+            # evaluate_* calls below then pick up their heat-maps instead of running the network
+            joint = getattr(self, "joint_forward", None)
+            try:
+                if joint is not None:
+                    joint(batch_dict["labeled"]["images"], batch_dict["unlabeled"]["frames"])
+                loss_super = self.evaluate_labeled(batch_dict=batch_dict["labeled"], stage="train", anneal_weight=unsup_importance)
+                loss_unsuper = self.evaluate_unlabeled(batch_dict=batch_dict["unlabeled"], stage="train", anneal_weight=unsup_importance)
+            finally:
+                if joint is not None:
+                    self._joint = {}
         total_loss = loss_super + loss_unsuper
         self.log("total_loss", total_loss, prog_bar=True, sync_dist=True)
         return {"loss": total_loss}

@@ -32,8 +32,9 @@ class _NetworkFn(torch.autograd.Function):
     accumulates parameter gradients straight into the flat gradient buffer (the tensors in ``param.grad`` are views of it)."""
 
     @staticmethod
-    def forward(ctx, anchor: torch.Tensor, images: torch.Tensor, net: Engine, training: bool):
-        heat, tape = net.forward(images, training=training)
+    def forward(ctx, anchor: torch.Tensor, images: torch.Tensor, net: Engine, training: bool, images2: torch.Tensor | None = None):
+        # images2: a second batch sharing the pass (joint labeled + unlabeled forward, two BatchNorm segments)
+        heat, tape = net.forward(images if images2 is None else (images, images2), training=training)
         ctx.net, ctx.tape = net, tape
         ctx.stream_key = net._stream_key() if hasattr(net, "_stream_key") else 0
         return heat
@@ -47,7 +48,7 @@ class _NetworkFn(torch.autograd.Function):
         else:
             ctx.net.backward(ctx.tape, g_heat)
         ctx.tape = None
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 def _default_device() -> torch.device:
@@ -176,8 +177,33 @@ class HeatmapTracker(BaseSupervisedTracker):
         return self.net.device
 
     # ------------------------------------------------------------------------------------------------ forward
+    def joint_forward(self, images_a: torch.Tensor, images_b: torch.Tensor) -> bool:
+        """Run the labeled and the unlabeled images of a semi-supervised step through the network in ONE pass (every layer one
+        launch over both batches, which keep their own BatchNorm statistics as in the reference's two forward calls,
+        models/base.py:682-695) and park the two heat-map stacks for the ``forward`` calls that follow.  False (nothing done) when
+        the engine cannot split the pass on tile boundaries, the image sizes differ, or LP_JOINT_FORWARD=0."""
+        if os.environ.get("LP_JOINT_FORWARD", "1") == "0" or not (self.training and torch.is_grad_enabled()):
+            return False
+        sa, sb = images_a.shape, images_b.shape
+        if sa[-3:] != sb[-3:] or not hasattr(self.net, "can_segment"):
+            return False
+        xa, xb = images_a.reshape(-1, *sa[-3:]), images_b.reshape(-1, *sb[-3:])
+        if not self.net.can_segment(xa.shape[0], sa[-2], sa[-1]):
+            return False
+        heat = _NetworkFn.apply(self._anchor, xa, self.net, True, xb)
+        ha, hb = heat[:xa.shape[0]], heat[xa.shape[0]:]
+        if len(sa) > 4:
+            ha = ha.reshape(sa[0], -1, heat.shape[-2], heat.shape[-1])
+        if len(sb) > 4:
+            hb = hb.reshape(sb[0], -1, heat.shape[-2], heat.shape[-1])
+        self._joint = {id(images_a): ha, id(images_b): hb}
+        return True
+
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) -> (B,K,h,w); (B,V,3,H,W) -> (B,K*V,h,w) (reference :107-133)."""
+        parked = getattr(self, "_joint", None)
+        if parked and id(images) in parked:
+            return parked.pop(id(images))
         shape = images.shape
         x = images.reshape(-1, shape[-3], shape[-2], shape[-1]) if len(shape) > 4 else images
         if torch.is_grad_enabled():

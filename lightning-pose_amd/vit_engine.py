@@ -306,7 +306,12 @@ class ViTEngine(Engine):
         return out
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, images: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:
+    def can_segment(self, n0: int, H: int, W: int) -> bool:
+        """no batch statistics anywhere (LayerNorm is per token): two batches of equally sized images always share one pass"""
+        return n0 > 0
+
+    def forward(self, images, training: bool = True) -> tuple[torch.Tensor, Tape]:
+        """``images``: a tensor, or a pair (labeled, unlabeled frames) that runs as one batch"""
         return self._forward(images, training, keep=True)
 
     def forward_infer(self, images: torch.Tensor) -> torch.Tensor:
@@ -314,10 +319,15 @@ class ViTEngine(Engine):
         p = NULL drops the 2 x 0.85 GB per layer the training pass stores for its backward) and no tape is kept."""
         return self._forward(images, False, keep=False)[0]
 
-    def _forward(self, images: torch.Tensor, training: bool, keep: bool) -> tuple[torch.Tensor, Tape]:
-        ops.require_device(images)
-        images = images.to(torch.float32).contiguous()
-        B, _, H, W = images.shape
+    def _forward(self, images, training: bool, keep: bool) -> tuple[torch.Tensor, Tape]:
+        parts = list(images) if isinstance(images, (list, tuple)) else [images]
+        for p_ in parts:
+            ops.require_device(p_)
+        parts = [p_.to(torch.float32).contiguous() for p_ in parts]
+        if any(p_.shape[1:] != parts[0].shape[1:] for p_ in parts):
+            raise ValueError("a joint pass takes batches of equally sized images")
+        _, _, H, W = parts[0].shape
+        B = sum(p_.shape[0] for p_ in parts)
         pl = self.plan
         D, nh, pt = pl.D, pl.heads, pl.patch
         if H % pt or W % pt:
@@ -331,7 +341,10 @@ class ViTEngine(Engine):
         self._wg_shape = (B, Tn)
 
         patches = torch.empty(B * Np, 3 * pt * pt, device=dev, dtype=torch.bfloat16)
-        check(self._lib.lp_vit_patchify(_p(images), B, H, W, pt, _p(patches), ops._stream()), "lp_vit_patchify")
+        i0 = 0
+        for p_ in parts:
+            check(self._lib.lp_vit_patchify(_p(p_), p_.shape[0], H, W, pt, _p(patches[i0 * Np:]), ops._stream()), "lp_vit_patchify")
+            i0 += p_.shape[0]
         pe = self._linear(patches, pl.patch_lin, B * Np)
         x = torch.empty(M, D, device=dev, dtype=torch.float32)
         pos = self._pos(gh, gw)  # (kept alive across the launch)

@@ -267,11 +267,13 @@ def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, 
     return ob.np(), (of.np() if of is not None else None)
 
 
-def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, want_acc=False, relu_bits=None):
-    """lp_bn_fuse + the buffers it points at (kept alive on the returned object)."""
+def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, want_acc=False, relu_bits=None, seg=0):
+    """lp_bn_fuse + the buffers it points at (kept alive on the returned object).  seg > 0: two BatchNorm segments (images [0, seg)
+    and the rest): sums is (2, 2, Cn), mean / invstd are (2, Cn)."""
     f = _lib.BnFuse()
+    f.seg_images = seg
     f.keep = dict(z=B(z), mean=B(mean, np.float32), invstd=B(invstd, np.float32), gamma=B(gamma, np.float32), beta=B(beta, np.float32),
-                  sums=Z((2, Cn)), dbeta=Z(Cn) if want_acc else None, dgamma=Z(Cn) if want_acc else None)
+                  sums=Z((2, 2, Cn) if seg else (2, Cn)), dbeta=Z(Cn) if want_acc else None, dgamma=Z(Cn) if want_acc else None)
     nws = lib().lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad))
     f.keep["ws"] = Buf(np.full(nws // 4, np.nan, np.float32))  # poisoned: every partial that is read must have been written
     k = f.keep
@@ -286,29 +288,36 @@ def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None
     return f
 
 
-def conv_fwd_bn(x_nhwc_bits, w_bits, g):
-    """-> (z bits, sums (2,Co))"""
+def conv_fwd_bn(x_nhwc_bits, w_bits, g, seg=0, rc=False):
+    """-> (z bits, sums (2,Co) or (2,2,Co) with seg); rc=True: return the status code instead of asserting it"""
     xb, wb, ob = Buf(x_nhwc_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
-    f = _bn_fuse(g, False, g.Co)
-    ok(lib().lp_conv_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
+    f = _bn_fuse(g, False, g.Co, seg=seg)
+    code = lib().lp_conv_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream())
+    if rc:
+        return code
+    ok(code)
     return ob.np(), f.keep["sums"].np()
 
 
-def stem_fwd_bn(x4_bits, w_bits, g):
+def stem_fwd_bn(x4_bits, w_bits, g, seg=0):
     xb, wb, ob = Buf(x4_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, 64), np.uint16)
-    f = _bn_fuse(g, False, 64)
+    f = _bn_fuse(g, False, 64, seg=seg)
     ok(lib().lp_stem_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
     return ob.np(), f.keep["sums"].np()
 
 
-def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None, relu_bits=None):
+def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None, relu_bits=None, seg=0,
+                  rc=False):
     """-> (dx bits, sums (2,Ci), dbeta, dgamma); the ReLU mask comes from mask_bits (bf16 activation) or relu_bits (1 bit per
-    element) if given, else is recomputed from z"""
+    element) if given, else is recomputed from z.  seg > 0: mean / invstd are (2, Ci), sums comes back (2, 2, Ci)."""
     db, wb, ab, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(mask_bits)
     ob = Z((g.B * g.Hi * g.Wi, g.Ci), np.uint16)
     f = _bn_fuse(g, True, g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None and relu_bits is None, want_acc=True,
-                 relu_bits=relu_bits)
-    ok(lib().lp_conv_dgrad_bn(db.p, wb.p, C.byref(g), ptr(ab), ptr(mb), ob.p, C.byref(f), stream()))
+                 relu_bits=relu_bits, seg=seg)
+    code = lib().lp_conv_dgrad_bn(db.p, wb.p, C.byref(g), ptr(ab), ptr(mb), ob.p, C.byref(f), stream())
+    if rc:
+        return code
+    ok(code)
     return ob.np(), f.keep["sums"].np(), f.keep["dbeta"].np(), f.keep["dgamma"].np()
 
 

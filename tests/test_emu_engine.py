@@ -25,8 +25,18 @@ def close(name, a, b, cos_min=0.995, ratio_tol=0.03):
     assert cos > cos_min and abs(ratio - 1) < ratio_tol, f"{name}: cos {cos:.5f} ratio {ratio:.4f}"
 
 
-def test_engine_forward_backward_blockwise(stack_backend):
+@pytest.mark.parametrize("joint", [None, (8, 8)], ids=["single", "joint"])
+def test_engine_forward_backward_blockwise(stack_backend, joint):
+    """``joint`` = (labeled, unlabeled) image counts: both batches share ONE pass (every layer one launch) as two BatchNorm segments with
+    their own batch statistics - what the reference's two forward calls compute (models/base.py:682-695); the oracle below then applies
+    every BatchNorm per segment."""
     dev = stack_backend
+    segs = [(0, 4)] if joint is None else [(0, joint[0]), (joint[0], sum(joint))]
+    HW = 64 if joint is None else 128      # (8 images of 128 x 128 end on a 128-row tile boundary in every layer)
+
+    def _bn_train(z, bn, residual, relu):  # noqa: F811 - BatchNorm over each segment's own rows
+        return torch.cat([O._bn_train(z[a:b], bn, None if residual is None else residual[a:b], relu) for a, b in segs])
+
     from lightning_pose_amd.engine import Engine
     from lightning_pose_amd.models.backbones._init import seeded_state_dict
 
@@ -44,8 +54,20 @@ def test_engine_forward_backward_blockwise(stack_backend):
     ref = O.OracleTracker(K, 2, torch_seed=7)
     ref.load_state_dict(sd, strict=False)
     ref.train()
-    images = torch.randn(4, 3, 64, 64, generator=gen)
-    heat, tape = eng.forward(images.to(dev), True)
+    images = torch.randn(segs[-1][1], 3, HW, HW, generator=gen)
+    if joint is not None:
+        images[joint[0]:] = images[joint[0]:] * 1.6 + 0.4     # the second batch has visibly different statistics
+        assert eng.can_segment(joint[0], HW, HW) and not eng.can_segment(3, HW, HW)
+        heat, tape = eng.forward([images[:joint[0]].to(dev), images[joint[0]:].to(dev)], True)
+        assert tape.meta["seg"] == joint[0] and int(eng.nbt) == 2
+        # running statistics: the first batch's update, then the second's (stem BatchNorm: upstream of any rounding differences)
+        z0 = tape.t["stem.z"].float().cpu().reshape(segs[-1][1], -1, 64)
+        rm = torch.zeros(64)
+        for a, b in segs:
+            rm = 0.9 * rm + 0.1 * z0[a:b].reshape(-1, 64).mean(0)
+        torch.testing.assert_close(eng.running_view(eng.plan.stem_bn, "running_mean").cpu(), rm, atol=1e-5, rtol=1e-4)
+    else:
+        heat, tape = eng.forward(images.to(dev), True)
     gh = torch.randn(heat.shape, generator=gen)
     eng.zero_grad()
     trace: dict = {}

@@ -1,0 +1,124 @@
+"""Two BatchNorm segments in ONE launch (lp_bn_fuse.seg_images): the labeled and the unlabeled frames of a semi-supervised step go through
+every layer together but keep their own batch statistics, as the reference's two forward calls do (models/base.py:682-695).  Kernel level:
+the fused reductions of a joint launch equal those of one launch per segment.  Engine level: a joint pass equals two separate passes."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.hipemu import emu
+
+bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+
+SEG_CASES = [
+    # B, seg, Hi, Wi, Ci, Co, R, stride, pad      (seg * rows per image must be a multiple of the 128-row tile in every launch)
+    (4, 2, 8, 8, 64, 64, 1, 1, 0),        # 1x1: 64 rows per image, boundary at row 128; N = 64 tiles
+    (6, 4, 8, 8, 64, 192, 3, 1, 1),       # 3x3, unequal segments (256 + 128 rows), ragged N
+    (4, 2, 16, 16, 64, 128, 3, 2, 1),     # stride 2: forward 64 rows / image; data gradient = 4 parity classes of 64 rows / image
+    (3, 1, 32, 16, 128, 64, 1, 2, 0),     # 1x1 stride 2 (projection shortcut): 3 of the 4 parity classes have no tap
+]
+
+
+@pytest.mark.parametrize("case", SEG_CASES)
+def test_fused_reductions_per_segment(case, kernel_backend):
+    B, seg, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(11 + sum(case))
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    x = emu.to_bf16_bits(torch.randn(B, Hi, Wi, Ci, generator=gen))
+    w = torch.randn(Co, R, R, Ci, generator=gen) / (Ci * R * R) ** 0.5
+    wg, wd = emu.to_bf16_bits(w), emu.to_bf16_bits(w.permute(3, 1, 2, 0))
+    # ---- forward: one joint launch vs one launch per segment
+    z, sums = emu.conv_fwd_bn(x, wg, g, seg=seg)
+    assert sums.shape == (2, 2, Co)
+    rows_o = g.Ho * g.Wo
+    for si, (i0, n) in enumerate(((0, seg), (seg, B - seg))):
+        gs = emu.geom(n, Hi, Wi, Ci, Co, R, R, st, pad)
+        zs, ss = emu.conv_fwd_bn(x[i0:i0 + n], wg, gs)
+        assert np.array_equal(z[i0 * rows_o:(i0 + n) * rows_o], zs)
+        np.testing.assert_allclose(sums[si], ss, rtol=1e-5, atol=1e-4)
+    # ---- backward: dx = gradient of relu(BN_seg(zin) + residual), each segment normalised with ITS moments
+    rows_i = Hi * Wi
+    Mi = B * rows_i
+    zin = torch.randn(Mi, Ci, generator=gen)
+    zin[seg * rows_i:] = zin[seg * rows_i:] * 1.7 + 0.4          # visibly different statistics per segment
+    zin_bits = emu.to_bf16_bits(zin)
+    gamma, beta = (torch.rand(Ci, generator=gen) + 0.5).numpy(), (torch.randn(Ci, generator=gen) * 0.3).numpy()
+    mean, invstd = np.zeros((2, Ci), np.float32), np.zeros((2, Ci), np.float32)
+    for si, (i0, n) in enumerate(((0, seg), (seg, B - seg))):
+        _, mean[si], invstd[si] = emu.bn_forward(zin_bits[i0 * rows_i:(i0 + n) * rows_i], n * rows_i, Ci, gamma, beta, relu=True)
+    dy = emu.to_bf16_bits(torch.randn(B * rows_o, Co, generator=gen))
+    add = emu.to_bf16_bits(torch.randn(Mi, Ci, generator=gen))
+    dx, bsums, dbeta, dgamma = emu.conv_dgrad_bn(dy, wd, g, zin_bits, mean, invstd, gamma, beta, addend_bits=add, seg=seg)
+    assert bsums.shape == (2, 2, Ci)
+    tot = np.zeros((2, Ci), np.float64)
+    for si, (i0, n) in enumerate(((0, seg), (seg, B - seg))):
+        gs = emu.geom(n, Hi, Wi, Ci, Co, R, R, st, pad)
+        dxs, ss, _, _ = emu.conv_dgrad_bn(dy[i0 * rows_o:(i0 + n) * rows_o], wd, gs, zin_bits[i0 * rows_i:(i0 + n) * rows_i], mean[si], invstd[si],
+                                          gamma, beta, addend_bits=add[i0 * rows_i:(i0 + n) * rows_i])
+        assert np.array_equal(dx[i0 * rows_i:(i0 + n) * rows_i], dxs)
+        np.testing.assert_allclose(bsums[si], ss, rtol=1e-4, atol=2e-3)
+        tot += ss
+    np.testing.assert_allclose(dbeta, tot[0], rtol=1e-4, atol=2e-3)      # d beta / d gamma collect both segments
+    np.testing.assert_allclose(dgamma, tot[1], rtol=1e-4, atol=2e-3)
+
+
+def test_stem_statistics_per_segment(kernel_backend):
+    """the 7x7 stem always takes the per-tile workspace + tile_stats_reduce path"""
+    gen = torch.Generator().manual_seed(5)
+    B, seg, H = 3, 1, 32                                          # 16 x 16 = 256 output rows per image
+    g = emu.geom(B, H, H, 4, 64, 7, 7, 2, 3)
+    x4 = torch.randn(B, H, H, 4, generator=gen)
+    x4[..., 3] = 0
+    x4[seg:] += 0.5
+    w = torch.zeros(64, 8, 8, 4)
+    w[:, :7, :7, :3] = torch.randn(64, 7, 7, 3, generator=gen) / 12
+    xb, wb = emu.to_bf16_bits(x4), emu.to_bf16_bits(w)
+    z, sums = emu.stem_fwd_bn(xb, wb, g, seg=seg)
+    for si, (i0, n) in enumerate(((0, seg), (seg, B - seg))):
+        zs, ss = emu.stem_fwd_bn(xb[i0:i0 + n], wb, emu.geom(n, H, H, 4, 64, 7, 7, 2, 3))
+        assert np.array_equal(z[i0 * 256:(i0 + n) * 256], zs)
+        np.testing.assert_allclose(sums[si], ss, rtol=1e-5, atol=1e-4)
+
+
+def test_workspace_reduction_path_per_segment(kernel_backend):
+    """large launches leave per-tile partial sums in a workspace that tile_stats_reduce adds up per segment (and, for a stride-2 data
+    gradient, per parity-class launch); the threshold is read once per process, so the kernel tests above re-run in a child with it at 0"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, LP_STATS_ATOMIC_TILES="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_segmented_bn.py", "tests/test_emu_conv.py", "-q", "-x", "-m",
+                        "gpu" if kernel_backend == "gpu" else "not gpu", "-k", "fused_reductions or fused_batchnorm", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_segment_boundary_must_be_tile_aligned(kernel_backend):
+    g = emu.geom(4, 6, 6, 64, 64, 1, 1, 1, 0)                    # 36 rows per image: 2 * 36 is not a multiple of 128
+    x = emu.to_bf16_bits(torch.randn(4, 6, 6, 64))
+    w = emu.to_bf16_bits(torch.randn(64, 1, 1, 64))
+    assert emu.conv_fwd_bn(x, w, g, seg=2, rc=True) == -2        # LP_ERR_UNSUPPORTED: run the segments as two calls
+    assert emu.conv_fwd_bn(x, w, g, seg=4, rc=True) == -2        # the second segment would be empty
+    z = emu.to_bf16_bits(torch.randn(4 * 36, 64))
+    m = np.zeros((2, 64), np.float32)
+    assert emu.conv_dgrad_bn(x.reshape(-1, 64), w, g, z, m, m + 1, m[0] + 1, m[0], seg=2, rc=True) == -2
+
+
+def test_finalize_two_segments_updates_running_statistics_in_order(kernel_backend):
+    import ctypes as C
+
+    Cn, gen = 24, torch.Generator().manual_seed(3)
+    xs = [torch.randn(40, Cn, generator=gen) * 2 + 1, torch.randn(72, Cn, generator=gen) * 0.5 - 2]
+    sums = np.stack([np.stack([x.sum(0).numpy(), (x * x).sum(0).numpy()]) for x in xs]).astype(np.float32)
+    rm0, rv0 = torch.randn(Cn, generator=gen).numpy(), (torch.rand(Cn, generator=gen) + 0.5).numpy()
+    sb, mean, invstd, rm, rv = emu.Buf(sums), emu.Z((2, Cn)), emu.Z((2, Cn)), emu.Buf(rm0), emu.Buf(rv0)
+    emu.ok(emu.lib().lp_bn_finalize2(sb.p, 40.0, 72.0, Cn, 1e-5, 0.1, mean.p, invstd.p, rm.p, rv.p, emu.stream()))
+    want_rm, want_rv = torch.from_numpy(rm0.copy()), torch.from_numpy(rv0.copy())
+    for si, x in enumerate(xs):                                  # what two forward calls of nn.BatchNorm2d do, in this order
+        np.testing.assert_allclose(mean.np()[si], x.mean(0).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(invstd.np()[si], (x.var(0, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-4)
+        want_rm = 0.9 * want_rm + 0.1 * x.mean(0)
+        want_rv = 0.9 * want_rv + 0.1 * x.var(0, unbiased=True)
+    np.testing.assert_allclose(rm.np(), want_rm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv.np(), want_rv.numpy(), rtol=1e-4, atol=1e-5)
