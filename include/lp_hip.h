@@ -274,6 +274,36 @@ int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom* geom, floa
                   size_t workspace_bytes, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * fp32 VALIDATION path (csrc/fp32.hip): the same layers in fp32 end to end on v_mfma_f32_32x32x2_f32, so a whole training step can
+ * be held against the reference - which trains in fp32 only (lightning_pose/train.py:411-428 passes no precision) - at the 1e-4
+ * tolerance BASELINE.json's north_star states for fp32.  Untuned (scalar operand loads, one wave per 32 x 32 tile): it exists to
+ * prove the wiring, the bf16-mixed entry points above are the product and the measured path.
+ * Tensors are dense NHWC fp32; weights are read straight from the flat fp32 parameter buffer in its [Co][KH][KW][CiS] storage
+ * (KH, KW, CiS >= R, S, Ci: the stem is stored [64][8][8][4]); dgrad needs no transposed copy.  `addend` (may alias the output) is
+ * added to the result; lp_f32_conv_wgrad accumulates into dw with fp32 atomics.
+ * ------------------------------------------------------------------------------------------------------ */
+int lp_f32_conv_fwd(const float* x, const float* w, const lp_conv_geom* geom, int KH, int KW, int CiS, const float* bias,
+                    const float* addend, float* out, lp_stream_t stream);
+int lp_f32_conv_dgrad(const float* dy, const float* w, const lp_conv_geom* geom, int KH, int KW, int CiS, const float* bias,
+                      const float* addend, float* dx, lp_stream_t stream);
+int lp_f32_conv_wgrad(const float* x, const float* dy, const lp_conv_geom* geom, int KH, int KW, int CiS, float* dw, lp_stream_t stream);
+/* fp32 forms of lp_bn_stats / lp_bn_apply / lp_bn_bwd_reduce / lp_bn_bwd_apply (lp_bn_finalize is shared), of the 3x3/2 max-pool, of the
+ * input layout conversion (NCHW -> NHWC4), of PixelShuffle(2) and of the spatial soft-max backward (fp32 gradient out) */
+int lp_f32_bn_stats(const float* x, int M, int C, float* sums, lp_stream_t stream);
+int lp_f32_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* residual,
+                    int relu, int M, int C, float* y, lp_stream_t stream);
+int lp_f32_bn_bwd_reduce(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, int M, int C,
+                         float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
+int lp_f32_bn_bwd_apply(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                        const float* sums, float count, int M, int C, float* dx, float* dres, lp_stream_t stream);
+int lp_f32_maxpool_fwd(const float* x, int B, int Hi, int Wi, int C, float* y, void* argmax_u8, lp_stream_t stream);
+int lp_f32_maxpool_bwd(const void* argmax_u8, const float* dy, int B, int Hi, int Wi, int C, float* dx, lp_stream_t stream);
+int lp_f32_images_to_nhwc4(const float* images, int B, int H, int W, float* out, lp_stream_t stream);
+int lp_f32_pixel_shuffle(const float* in, int B, int h, int w, int c_out, int ld, int inverse, float* out, lp_stream_t stream);
+int lp_f32_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, float* gin, long stride_b, long stride_i, long stride_k,
+                         lp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * HBM-bound glue of the trunk (NHWC bf16): BatchNorm2d training mode, ReLU, residual add, MaxPool2d(3,2,1),
  * PixelShuffle(2), input layout.  torchvision Bottleneck semantics; called from
  * `self.backbone(images)` (models/base.py:398) and HeatmapHead.forward (models/heads/heatmap.py:44,208).

@@ -129,6 +129,18 @@ PROTOTYPES = {
     "lp_frames_resize": (_I, [_P, _I, _I, _I, C.c_longlong, _I, _I, _I, _I, C.POINTER(FrameNorm), _P, _P]),
     "lp_frames_augment": (_I, [_P, _I, _I, _I, C.POINTER(FrameAugment), C.POINTER(FrameNorm), _P, _P]),
     "lp_labeled_keypoints": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_f32_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _P, _P]),
+    "lp_f32_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _P, _P]),
+    "lp_f32_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _I, _I, _I, _P, _P]),
+    "lp_f32_bn_stats": (_I, [_P, _I, _I, _P, _P]),
+    "lp_f32_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "lp_f32_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "lp_f32_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
+    "lp_f32_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_f32_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "lp_f32_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
+    "lp_f32_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "lp_f32_softmax2d_bwd": (_I, [_P, _P, _I, _I, _I, _P, _L, _L, _L, _P]),
     "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
     "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),
     "lp_permute_cba": (_I, [_P, _I, _I, _I, _P, _P]),

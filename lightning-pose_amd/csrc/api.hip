@@ -1,7 +1,7 @@
 // Library-level entry points of liblp_hip.so.
 #include "lp_common.h"
 
-extern "C" int lp_version(void) { return 110; }  // 0.1.1: + batch producers, inference conv / fold, temporal heat-map loss, heat-map confidence
+extern "C" int lp_version(void) { return 120; }  // 0.2.0: + two BatchNorm segments per launch (lp_bn_fuse.seg_images, lp_bn_finalize2), fp32 validation path (lp_f32_*)
 
 extern "C" const char* lp_strerror(int code) {
     if (code == LP_OK) return "ok";
