@@ -75,6 +75,11 @@ class HeatmapTracker(BaseSupervisedTracker):
         self.downsample_factor = downsample_factor
 
         device = torch.device(kwargs.get("device") or _default_device())
+        # "bf16-mixed" (the product path) or "fp32" (validation against the fp32-only reference, train.py:411-428); LP_PRECISION overrides
+        self.precision = {"32": "fp32", "32-true": "fp32", "fp32": "fp32"}.get(
+            str(os.environ.get("LP_PRECISION") or kwargs.get("precision") or "bf16-mixed"), "bf16-mixed")
+        if self.precision == "fp32" and backbone in VIT_CONFIGS:
+            raise NotImplementedError("the fp32 validation path covers the ResNet-50 trunk; ViT backbones run bf16-mixed")
         self.head = HeatmapHead(backbone_arch=backbone, in_channels=self.num_fc_input_features, out_channels=num_keypoints,
                                 downsample_factor=downsample_factor)
         self.backbone = _Holder()
@@ -102,7 +107,11 @@ class HeatmapTracker(BaseSupervisedTracker):
                     if key in init and init[key].shape == v.shape:
                         init[key] = v
         else:
-            self.net = Engine(num_keypoints, downsample_factor, device)
+            if self.precision == "fp32":  # validation mode: every activation and contraction in fp32 (engine_fp32.py)
+                from ..engine_fp32 import Fp32Engine
+                self.net = Fp32Engine(num_keypoints, downsample_factor, device)
+            else:
+                self.net = Engine(num_keypoints, downsample_factor, device)
             init = seeded_state_dict(num_keypoints, self.head.n_layers)
             if pretrained:
                 if checkpoint is None:

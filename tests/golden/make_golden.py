@@ -475,9 +475,112 @@ def gen_temporal_heatmap():
     save("temporal_heatmap", **out)
 
 
+def _train_head(model, inp, gen_hm, steps, lr):
+    """Adam on the reference head alone, over the cached trunk features of the step's own frames (the trunk stays at its seeded
+    initialisation, BatchNorm in training mode per batch, as in the measured step): after it the heat-maps are smooth peaks."""
+    cfg, batch = inp["cfg"], inp["batch"]
+    K, HW = cfg["K"], cfg["HW"]
+    h = HW // 4
+    lab = batch["labeled"] if "labeled" in batch else batch
+    sets = [(lab["images"].reshape(-1, 3, HW, HW), lab["heatmaps"].reshape(-1, K, h, h))]
+    if "unlabeled" in batch:
+        sets.append((batch["unlabeled"]["frames"].reshape(-1, 3, HW, HW), gen_hm(inp["unl_centres"].clone(), HW, HW, (h, h))))
+    model.train()
+    with torch.no_grad():
+        feats = [(model.backbone(x), t) for x, t in sets]
+    opt = torch.optim.Adam(model.head.parameters(), lr=lr)
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = 0.0
+        for f, t in feats:
+            p = model.head(f)
+            keep = t.flatten(2).sum(-1) > 0
+            loss = loss + ((p - t) ** 2)[keep].mean() * h * h
+        loss.backward()
+        opt.step()
+    model.zero_grad()
+    return float(loss)
+
+
+def gen_step_parity(names=None):
+    """End-to-end parity steps on PEAKED heat-maps at BASELINE.json's configs (tests/golden/step_inputs.py): one training step of the
+    reference's own (Semi)SupervisedHeatmapTracker - verbatim modules, fp32, torch CPU - after its head was trained on the step's frames
+    (_train_head; the trained head weights are stored so the product starts from the same model).  Stored: every logged scalar, the loss
+    inputs the losses saw (predicted keypoints in frame and model coordinates, confidences), per-map peak statistics of the heat-maps,
+    and parameter gradients (head + stem in full, a norm per convolution / BatchNorm)."""
+    from tests.golden.step_inputs import HEAD_TRAIN_LR, HEAD_TRAIN_STEPS, PCA_LOG_WEIGHT, STEP_CONFIGS, TEMPORAL, TORCH_SEED, make_step_inputs
+
+    T = R.load("models.heatmap_tracker")
+    Fa = R.load("losses.factory")
+    L = R.load("losses.losses")
+    H = R.load("data.heatmaps")
+    for name in (names or list(STEP_CONFIGS)):
+        inp = make_step_inputs(name, H.generate_heatmaps)
+        cfg, batch = inp["cfg"], inp["batch"]
+        K, V, HW = cfg["K"], cfg["V"], cfg["HW"]
+        sup = Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+        semi = cfg["S"] > 0
+        if semi:
+            unsup = Fa.LossFactory({"temporal": dict(TEMPORAL)}, None)
+            ptype = "pca_multiview" if V > 1 else "pca_singleview"
+            kpca = R.fit_keypoint_pca(ptype, inp["pca_fit"], components_to_keep=3 if V > 1 else 0.99, mirrored_column_matches=inp["mcm"],
+                                      columns_for_singleview_pca=inp["cols"])
+            loss = L.PCALoss.__new__(L.PCALoss)
+            L.Loss.__init__(loss, log_weight=PCA_LOG_WEIGHT)
+            loss.device, loss.loss_name, loss.pca = "cpu", ptype, kpca
+            loss.epsilon = kpca.parameters["epsilon"]
+            unsup.loss_instance_dict[ptype] = loss
+            model = T.SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+                                                   pretrained=False, torch_seed=TORCH_SEED, image_size=HW)
+            model.total_unsupervised_importance = torch.tensor(1.0)
+        else:
+            model = T.HeatmapTracker(num_keypoints=K, loss_factory=sup, backbone="resnet50", pretrained=False, torch_seed=TORCH_SEED,
+                                     image_size=HW)
+        fit_loss = _train_head(model, inp, H.generate_heatmaps, HEAD_TRAIN_STEPS, HEAD_TRAIN_LR)
+        seen = {}
+        for meth in ("get_loss_inputs_labeled", "get_loss_inputs_unlabeled"):
+            if hasattr(model, meth):
+                orig = getattr(model, meth)
+
+                def wrapped(batch_dict, _orig=orig, _m=meth):
+                    d = _orig(batch_dict)
+                    seen[_m] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+                    return d
+                setattr(model, meth, wrapped)
+        model.train()
+        arrs = {"head/" + n_: p_.detach().clone() for n_, p_ in model.head.named_parameters()}
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        logged = {k: float(v) for k, v in model.logged.items()}
+        arrs.update(log_names=np.array(list(logged)), log_values=np.array(list(logged.values())), loss=out["loss"].detach(),
+                    head_fit_loss=np.float32(fit_loss))
+        for meth, tag in (("get_loss_inputs_labeled", "lab"), ("get_loss_inputs_unlabeled", "unl")):
+            if meth in seen:
+                d = seen[meth]
+                for k in ("keypoints_pred", "keypoints_pred_augmented", "confidences", "keypoints_targ"):
+                    if k in d:
+                        arrs[f"{tag}_{k}"] = d[k]
+                hm = d["heatmaps_pred"]
+                flat = hm.reshape(hm.shape[0], hm.shape[1], -1)
+                arrs[f"{tag}_heat_max"], arrs[f"{tag}_heat_argmax"] = flat.max(-1).values, flat.argmax(-1)
+                if name == "s64":
+                    arrs[f"{tag}_heat"] = hm
+        if semi:
+            arrs.update(pca_mean=kpca.parameters["mean"], pca_kept=kpca.parameters["kept_eigenvectors"], pca_eps=kpca.parameters["epsilon"])
+        sd_grads = {n_: p_.grad for n_, p_ in model.named_parameters() if p_.grad is not None}
+        for n_, gr in sd_grads.items():
+            if n_.startswith("head.") or n_ == "backbone.0.weight":
+                arrs["grad/" + n_] = gr
+        names_sorted = sorted(sd_grads)
+        arrs["grad_names"] = np.array(names_sorted)
+        arrs["grad_norms"] = np.array([float(sd_grads[n_].norm()) for n_ in names_sorted])
+        save(f"step_{name}", **arrs)
+        print("   ", {k: round(v, 6) for k, v in logged.items()}, "head fit", round(fit_loss, 6))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     GENS = {"decode": gen_decode, "heatmaps": gen_heatmaps, "geometry": gen_geometry, "losses": gen_losses,
-            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions, "labeled_targets": gen_labeled_targets, "temporal_heatmap": gen_temporal_heatmap}
+            "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions, "labeled_targets": gen_labeled_targets, "temporal_heatmap": gen_temporal_heatmap, "step_parity": gen_step_parity}
     for name in (sys.argv[1:] or list(GENS)):  # `make_golden.py predictions` regenerates one fixture only
         GENS[name]()

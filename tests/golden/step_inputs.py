@@ -1,0 +1,99 @@
+"""Seeded inputs of the end-to-end parity steps (tests/golden/step_*.npz).  Imported by BOTH make_golden.py (which feeds them to the
+verbatim reference tracker) and the parity tests (which feed them to the product), so the large image tensors never have to be
+committed: torch's CPU generator reproduces them bit for bit.
+
+Configs mirror BASELINE.json's: c1 = config 1 (supervised ResNet-50 HeatmapTracker, 256x256, K=17, batch 4), c2 = configs 2/3 at a
+CPU-feasible batch (384x384, K=17, 4 labeled + 8 unlabeled frames, temporal + pca_singleview), c5 = config 5 (multiview, 256x256 views,
+temporal + pca_multiview), s64 = a 64x64 case small enough for the CPU-emulated kernels."""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+STEP_CONFIGS = {
+    "s64": dict(HW=64, K=3, Bl=4, S=6, V=1, seed=11, unsup=("temporal", "pca_singleview")),
+    "c1": dict(HW=256, K=17, Bl=4, S=0, V=1, seed=12, unsup=()),
+    "c2": dict(HW=384, K=17, Bl=4, S=8, V=1, seed=13, unsup=("temporal", "pca_singleview")),
+    "c5": dict(HW=256, K=4, Bl=2, S=4, V=2, seed=14, unsup=("temporal", "pca_multiview")),
+}
+# The head is TRAINED before the measured step (make_golden.py::_train_head: Adam on the head alone, over the cached features of the
+# step's own frames, targets = Gaussians at the blob centres): a randomly initialised head (xavier gain 0.01) gives numerically flat
+# heat-maps, on which soft-argmax(T = 1000) is an ill-conditioned function of the last bits of the trunk.  With a trained head the
+# heat-maps are what the decode sees in real training - smooth peaks of the target's shape - and keypoints are comparable across precisions.
+HEAD_TRAIN_STEPS, HEAD_TRAIN_LR = 300, 3e-3
+TORCH_SEED = 7
+TEMPORAL = {"log_weight": 2.0, "epsilon": 0.5, "prob_threshold": 0.0}
+PCA_LOG_WEIGHT = 2.0
+
+
+def _render(g, centres, size):
+    """(n, K, 2) blob centres -> (n, 3, size, size): K Gaussian blobs (sigma 6 px, amplitude 3) over N(0, 0.25) noise"""
+    n, K, _ = centres.shape
+    ys = torch.arange(size).view(1, size, 1).float()
+    xs = torch.arange(size).view(1, 1, size).float()
+    img = torch.randn(n, 3, size, size, generator=g) * 0.5
+    for k in range(K):
+        cx, cy = centres[:, k, 0].view(-1, 1, 1), centres[:, k, 1].view(-1, 1, 1)
+        img += (3.0 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 72.0)).unsqueeze(1)
+    return img
+
+
+def _affine(g, size):
+    th = math.radians(float(torch.rand(1, generator=g)) * 20 - 10)
+    sc = 0.8 + 0.4 * float(torch.rand(1, generator=g))
+    c = size / 2
+    a = torch.tensor([[sc * math.cos(th), -sc * math.sin(th), 0.0], [sc * math.sin(th), sc * math.cos(th), 0.0]])
+    a[:, 2] = torch.tensor([c, c]) - a[:, :2] @ torch.tensor([c, c])
+    return a
+
+
+def make_step_inputs(name: str, generate_heatmaps) -> dict:
+    """-> {"batch": labeled dict or {"labeled", "unlabeled"}, "pca_fit": (N, 2*K*V) or None, "mcm": list or None, "cols": list or None}.
+    ``generate_heatmaps(kp (B, K, 2), H, W, (h, w))`` builds the labeled targets (the caller passes the implementation under test's
+    oracle: the reference's own function in make_golden.py, oracle.restated's in the tests - equal to 2e-7, tests/test_oracle_golden.py)."""
+    cfg = STEP_CONFIGS[name]
+    HW, K, Bl, S, V = cfg["HW"], cfg["K"], cfg["Bl"], cfg["S"], cfg["V"]
+    g = torch.Generator().manual_seed(cfg["seed"])
+    KV = K * V
+    lab_c = (torch.rand(Bl * V, K, 2, generator=g) * 0.7 + 0.15) * HW
+    images = _render(g, lab_c, HW)
+    kp = lab_c.reshape(Bl, KV, 2).clone()
+    kp[0, 1] = float("nan")                                        # an unlabeled keypoint
+    heat = generate_heatmaps(kp.clone(), HW, HW, (HW // 4, HW // 4))
+    if V == 1:
+        bbox_l = torch.tensor([[3.0, 5.0, 2.0 * HW, 1.5 * HW]]).repeat(Bl, 1)
+        labeled = {"images": images, "keypoints": kp.reshape(Bl, 2 * KV), "heatmaps": heat, "bbox": bbox_l, "idxs": torch.arange(Bl)}
+    else:
+        box = [0.0, 0.0, float(HW), float(HW), 10.0, 20.0, 2.0 * HW, 1.5 * HW] + [0.0, 0.0, float(HW), float(HW)] * (V - 2)
+        bbox_l = torch.tensor([box]).repeat(Bl, 1)
+        labeled = {"images": images.reshape(Bl, V, 3, HW, HW), "keypoints": kp.reshape(Bl, 2 * KV), "heatmaps": heat, "bbox": bbox_l,
+                   "num_views": torch.full((Bl,), V), "idxs": torch.arange(Bl)}
+    out = {"cfg": cfg, "pca_fit": None, "mcm": None, "cols": None}
+    if S == 0:
+        out["batch"] = labeled
+        return out
+    start = (torch.rand(1, V, K, 2, generator=g) * 0.6 + 0.2) * HW
+    walk = torch.cumsum(torch.randn(S, V, K, 2, generator=g) * 3.0, dim=0) + start
+    walk = walk.clamp(8, HW - 8)
+    frames = _render(g, walk.reshape(S * V, K, 2), HW)
+    if V == 1:
+        unlabeled = {"frames": frames, "transforms": _affine(g, HW), "bbox": torch.tensor([[0.0, 0.0, float(HW), float(HW)]]).repeat(S, 1),
+                     "is_multiview": False}
+    else:
+        unlabeled = {"frames": frames.reshape(S, V, 3, HW, HW), "transforms": torch.stack([_affine(g, HW) for _ in range(V)]),
+                     "bbox": bbox_l[:1].repeat(S, 1), "is_multiview": True}
+    out["batch"] = {"labeled": labeled, "unlabeled": unlabeled}
+    out["unl_centres"] = walk.reshape(S * V, K, 2)
+    if "pca_singleview" in cfg["unsup"]:
+        basis = torch.randn(4, 2 * K, generator=g)
+        out["pca_fit"] = torch.randn(200, 4, generator=g) @ basis * (HW / 16) + HW / 2 + torch.randn(200, 2 * K, generator=g)
+        out["cols"] = [k for k in range(K) if k not in (7, 15, 16)] if K == 17 else list(range(K))
+    if "pca_multiview" in cfg["unsup"]:
+        pts = torch.randn(300, K, 3, generator=g) * (HW / 8)
+        proj = torch.randn(V, 2, 3, generator=g)
+        obs = torch.einsum("vij,nkj->nvki", proj, pts) + HW / 2 + torch.randn(300, V, K, 2, generator=g)
+        out["pca_fit"] = obs.reshape(300, V * K * 2)
+        out["mcm"] = [[v * K + k for k in range(K)] for v in range(V)]
+    return out
