@@ -508,7 +508,9 @@ def gen_step_parity(names=None):
     (_train_head; the trained head weights are stored so the product starts from the same model).  Stored: every logged scalar, the loss
     inputs the losses saw (predicted keypoints in frame and model coordinates, confidences), per-map peak statistics of the heat-maps,
     and parameter gradients (head + stem in full, a norm per convolution / BatchNorm)."""
-    from tests.golden.step_inputs import HEAD_TRAIN_LR, HEAD_TRAIN_STEPS, PCA_LOG_WEIGHT, STEP_CONFIGS, TEMPORAL, TORCH_SEED, make_step_inputs
+    from oracle import restated as O
+    from tests.golden.step_inputs import (HEAD_TRAIN_LR, HEAD_TRAIN_STEPS, PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS, TEMPORAL, TORCH_SEED,
+                                          make_step_inputs)
 
     T = R.load("models.heatmap_tracker")
     Fa = R.load("losses.factory")
@@ -536,6 +538,10 @@ def gen_step_parity(names=None):
         else:
             model = T.HeatmapTracker(num_keypoints=K, loss_factory=sup, backbone="resnet50", pretrained=False, torch_seed=TORCH_SEED,
                                      image_size=HW)
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("bn3.weight"):
+                    p_.fill_(RESIDUAL_GAIN)
         fit_loss = _train_head(model, inp, H.generate_heatmaps, HEAD_TRAIN_STEPS, HEAD_TRAIN_LR)
         seen = {}
         for meth in ("get_loss_inputs_labeled", "get_loss_inputs_unlabeled"):
@@ -549,6 +555,24 @@ def gen_step_parity(names=None):
                 setattr(model, meth, wrapped)
         model.train()
         arrs = {"head/" + n_: p_.detach().clone() for n_, p_ in model.head.named_parameters()}
+        # what the bf16-mixed POLICY itself costs on this model: the same weights through oracle.restated.forward_bf16_policy (torch
+        # CPU, rounding to bf16 where the product does) -> keypoints / confidences next to the fp32 ones below
+        orc = O.OracleTracker(K, 2, torch_seed=0)
+        orc.load_state_dict({k_: v_ for k_, v_ in model.state_dict().items()}, strict=True)
+        orc.train()
+        lab_b = batch["labeled"] if semi else batch
+        with torch.no_grad():
+            for tag, bd, key in (("lab", lab_b, "images"),) + ((("unl", batch["unlabeled"], "frames"),) if semi else ()):
+                x_ = bd[key]
+                h_ = O.forward_bf16_policy(orc, x_.reshape(-1, 3, HW, HW))
+                h_ = h_.reshape(x_.shape[0], -1, h_.shape[-2], h_.shape[-1])
+                kp_, conf_ = O.soft_argmax(h_, 2, 1000.0)
+                if tag == "unl":
+                    arrs["bf16ref_unl_keypoints_pred_augmented"] = kp_.clone()
+                    kp_ = O.undo_affine(kp_, bd["transforms"], bool(bd.get("is_multiview", False)))
+                arrs[f"bf16ref_{tag}_keypoints_pred"] = O.model_to_frame(kp_, HW, HW, bd["bbox"], V)
+                arrs[f"bf16ref_{tag}_confidences"] = conf_
+                arrs[f"bf16ref_{tag}_heat_max"] = h_.flatten(2).max(-1).values
         out = model.training_step(batch, 0)
         out["loss"].backward()
         logged = {k: float(v) for k, v in model.logged.items()}
