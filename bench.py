@@ -329,6 +329,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                     "gives the same 192 images per GPU); frames/s then counts view-images")
     ap.add_argument("--predict", action="store_true", help="secondary line: inference frames/s (eval mode, BatchNorm folded into the "
                     "convolutions, fused decode) over the same frames; the headline metric stays the training step")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("LP_HIP_GRAPH", "0")), help="1: replay the step as one captured HIP graph "
+                    "(lightning_pose_amd/graph_step.py); the capture happens in extra untimed steps before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args(argv)
@@ -354,7 +356,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
         batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     if args.predict:
         return predict_bench(args, model, batch, dev, rank, world)
-    trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True)
+    trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True, hip_graph=bool(args.graph))
     trainer.setup(model)
     model.train()
     model.total_unsupervised_importance = torch.tensor(1.0)
@@ -363,7 +365,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
+    graph_capture_steps = 3 if args.graph else 0   # 2 eager steps + the capture itself, all before the counted warm-up
+    for i in range(graph_capture_steps + args.warmup):
         trainer.training_batch(model, batch, i)
     _sync(dev)
     barrier()
@@ -413,6 +416,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
                                "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": world > 1,
+                   "hip_graph": bool(trainer._graphed is not None and trainer._graphed.replays > 0),
                    "final_loss": round(float(loss), 6)},
     }
     if rank == 0:

@@ -423,6 +423,11 @@ int lp_labeled_keypoints(const float* kp_src, const float* src_hw, const float* 
  * ------------------------------------------------------------------------------------------------------ */
 int lp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int decoupled, int step, float grad_scale, void* params_bf16, lp_stream_t stream);
+/* same update, with the scalars that change every step read from device memory: hyper_dev = [lr, 1 - beta1^step, sqrt(1 - beta2^step)]
+ * (fp32).  The launch is then identical from step to step, so the whole optimisation step can be replayed as one captured HIP graph
+ * while the host rewrites those 12 bytes (UnfreezeBackbone / MultiStepLR change lr, callbacks.py:126-148, models/base.py:427-447). */
+int lp_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, const float* hyper_dev, float beta1,
+                     float beta2, float eps, float weight_decay, int decoupled, float grad_scale, void* params_bf16, lp_stream_t stream);
 int lp_cast_bf16(const float* src, size_t n, void* dst, lp_stream_t stream);
 /* dst[c][b][a] = src[a][b][c] on bf16: weights [Co][R*S][Ci] -> data-gradient copy [Ci][R*S][Co] */
 int lp_permute_cba(const void* src, int A, int B, int C, void* dst, lp_stream_t stream);

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "lp_f32_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "lp_f32_softmax2d_bwd": (_I, [_P, _P, _I, _I, _I, _P, _L, _L, _L, _P]),
     "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
+    "lp_adam_step_dev": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _F, _P, _P]),
     "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),
     "lp_permute_cba": (_I, [_P, _I, _I, _I, _P, _P]),
 }

@@ -50,10 +50,23 @@ class BaseDataModule:
             yield self.dataset.batch(list(indices[lo:lo + batch_size]), hflip=torch.zeros(len(indices[lo:lo + batch_size]), dtype=torch.bool)
                                      if getattr(self.dataset, "imgaug_hflip", False) else None)
 
+    def _rank_world(self) -> tuple[int, int]:
+        import torch.distributed as dist
+
+        return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
     def train_dataloader(self) -> Iterator[dict]:
-        """One epoch over the training split in a fresh random order (flips, if enabled, are drawn by the dataset)."""
+        """One epoch over the training split in a fresh random order (flips, if enabled, are drawn by the dataset).  Under data
+        parallelism every rank draws the SAME permutation (same seed) and keeps its strided share, padded by wrapping around so all
+        ranks see equally many examples - torch's DistributedSampler, which Lightning installs for the reference (its
+        data/factory.py:252-255 already divides train_batch_size by the number of GPUs: pass that per-GPU size, see
+        distributed.labeled_batch_per_gpu)."""
         idx = self.train_dataset.indices
         order = torch.randperm(len(idx), generator=self._train_generator).tolist()
+        rank, world = self._rank_world()
+        if world > 1:
+            total = -(-len(order) // world) * world
+            order = (order + order[:total - len(order)])[rank:total:world]
         for lo in range(0, len(order), self.train_batch_size):
             yield self.dataset.batch([idx[i] for i in order[lo:lo + self.train_batch_size]])
 

@@ -27,9 +27,9 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("LP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available() and os.environ.get("LP_FORCE_DEVICE") is None:
+        torch.cuda.set_device(local_rank)  # every backend: kernels launch on the current device's stream (ops._stream)
     return rank, local_rank, world
 
 
@@ -68,8 +68,6 @@ class DataParallel:
         """SUM all-reduce of the flat gradient buffer in large buckets; pair with optimizer.grad_scale = 1/world."""
         if self.world == 1:
             return
-        if hasattr(self.engine, "wait_pending"):
-            self.engine.wait_pending()
         g = self.engine.G
         # backward produces the tail of the buffer (head, layer4) first: reduce from the end
         hi = g.numel()

@@ -21,8 +21,8 @@ BatchNorm per forward call with running-stat updates, SyncBatchNorm across ranks
 from __future__ import annotations
 
 import ctypes as C
-import os
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -36,44 +36,6 @@ from .ops import _p
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 CPAD = 64  # channel padding of the head's narrow tensors (K = 17 -> 64) so they are MFMA K/N operands
-
-
-# ---- two-stream mode (opt-in, LP_TWO_STREAMS=1): the labeled and the unlabeled pass of a semi-supervised step run on their own HIP
-# streams so that one pass's partially filled tile rounds and HBM-bound BatchNorm kernels overlap the other's MFMA work (DESIGN.md
-# section 10).  On a CPU device (the emulated-kernel tests) streams and events are stand-ins: the control flow below - per-stream
-# scratch, ordered running-statistics updates, the join before the optimiser - runs, sequentially.
-class _NoStream:
-    cuda_stream = 0
-
-    def wait_stream(self, other) -> None:
-        pass
-
-    def wait_event(self, event) -> None:
-        pass
-
-
-class _NoEvent:
-    def record(self, stream=None) -> None:
-        pass
-
-
-_FAKE_STREAM_KEY = [0]
-
-
-class _FakeStreamCtx:
-    def __init__(self, key: int):
-        self.key = key
-
-    def __enter__(self):
-        self.prev, _FAKE_STREAM_KEY[0] = _FAKE_STREAM_KEY[0], self.key
-
-    def __exit__(self, *exc):
-        _FAKE_STREAM_KEY[0] = self.prev
-        return False
-
-
-def two_streams_requested() -> bool:
-    return os.environ.get("LP_TWO_STREAMS", "0") == "1"
 
 
 @dataclass
@@ -256,63 +218,6 @@ class Engine:
         self._side = None                            # side stream of the weight-gradient launches (created on first use)
         self._side_busy = False
         self._fold: tuple[torch.Tensor, torch.Tensor] | None = None  # inference copies: BatchNorm folded into (bf16 weights, biases)
-        # two-stream mode (see the module header): branch streams, per-stream scratch, event bookkeeping
-        self._branches: tuple | None = None
-        self._bn_ws_by_stream: dict[int, torch.Tensor] = {}
-        self._rs_prev: list = []      # per BatchNorm layer: "running statistics updated" events of the previous training forward
-        self._rs_cur: list = []
-        self._pending: list = []      # "backward done on its stream" events the next consumer of G must wait for
-
-    # ------------------------------------------------------------------------------------------------ two-stream mode
-    def two_streams_active(self) -> bool:
-        """Opted in, not profiling (HIP events bracket single-stream launches), not synchronising BatchNorm across ranks on a shared
-        communicator from two streams, and the weight gradients on their ONE side stream (what serialises both passes' accumulation
-        into G)."""
-        return (two_streams_requested() and self.profile is None and not self.sync_bn and self.wgrad_side_stream
-                and os.environ.get("LP_WGRAD_SIDE_STREAM", "1") != "0")
-
-    def _cur_stream(self):
-        return torch.cuda.current_stream(self.device) if self.device.type == "cuda" else _NoStream()
-
-    def _stream_key(self) -> int:
-        return int(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else _FAKE_STREAM_KEY[0]
-
-    def _new_event(self):
-        return torch.cuda.Event() if self.device.type == "cuda" else _NoEvent()
-
-    def branch_streams(self) -> tuple:
-        """(labeled, unlabeled) streams, created once."""
-        if self._branches is None:
-            if self.device.type == "cuda":
-                self._branches = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
-            else:
-                self._branches = (_NoStream(), _NoStream())
-        return self._branches
-
-    def stream_ctx(self, which: int):
-        st = self.branch_streams()[which]
-        return torch.cuda.stream(st) if self.device.type == "cuda" else _FakeStreamCtx(which + 1)
-
-    def replay_ctx(self, key: int):
-        """Backward of a pass: on the device autograd already replays it on the pass's forward stream; the CPU stand-in restores the key."""
-        import contextlib
-
-        return contextlib.nullcontext() if self.device.type == "cuda" else _FakeStreamCtx(key)
-
-    def note_backward_done(self) -> None:
-        """Called at the end of a backward pass that ran on a branch stream: whoever reads G next waits for it."""
-        if self.two_streams_active():
-            ev = self._new_event()
-            ev.record(self._cur_stream())
-            self._pending.append(ev)
-
-    def wait_pending(self) -> None:
-        """Order the current stream after every branch-stream backward recorded so far (optimiser step, gradient all-reduce, zero_grad)."""
-        if self._pending:
-            cur = self._cur_stream()
-            for ev in self._pending:
-                cur.wait_event(ev)
-            self._pending = []
 
     def _timed(self, tag: str, flops: float, fn):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
@@ -450,7 +355,6 @@ class Engine:
                   "lp_permute_cba")
 
     def zero_grad(self) -> None:
-        self.wait_pending()
         self.G.zero_()
 
     # ------------------------------------------------------------------------------------------------ kernels
@@ -465,15 +369,9 @@ class Engine:
                  mask_from_z: bool = False, relu_bits=None, seg: int = 0) -> _lib.BnFuse:
         """lp_bn_fuse for one launch; the per-tile workspace is one scratch buffer reused by every launch of the stream."""
         need = int(self._lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
-        if self.two_streams_active():  # the scratch is reused by every launch of ONE stream: one buffer per stream
-            key = self._stream_key()
-            ws = self._bn_ws_by_stream.get(key)
-            if ws is None or ws.numel() < need:
-                ws = self._bn_ws_by_stream[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
-        else:
-            if self._bn_ws is None or self._bn_ws.numel() < need:
-                self._bn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
-            ws = self._bn_ws
+        if self._bn_ws is None or self._bn_ws.numel() < need:
+            self._bn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        ws = self._bn_ws
         f = _lib.BnFuse()
         f.sums, f.workspace, f.workspace_bytes = sums.data_ptr(), ws.data_ptr(), need
         f.seg_images = seg
@@ -536,11 +434,6 @@ class Engine:
                 dist.all_reduce(sums, group=self.process_group)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
-            ordered = self.two_streams_active()
-            if ordered:  # this layer's running statistics: after the previous pass's update of the same layer (labeled, then unlabeled)
-                i = len(self._rs_cur)
-                if i < len(self._rs_prev):
-                    self._cur_stream().wait_event(self._rs_prev[i])
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
             if len(segs) == 1:
                 check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
@@ -548,10 +441,6 @@ class Engine:
             else:
                 check(self._lib.lp_bn_finalize2(_p(sums), counts[0], counts[1], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv,
                                                 ops._stream()), "lp_bn_finalize2")
-            if ordered:
-                ev = self._new_event()
-                ev.record(self._cur_stream())
-                self._rs_cur.append(ev)
         else:
             mean.copy_(self.running_view(b, "running_mean"))
             invstd.copy_((self.running_view(b, "running_var") + BN_EPS).rsqrt())
@@ -627,17 +516,7 @@ class Engine:
             x_small = T[f"head.in{li}"]
             bsum = torch.zeros(2 * CPAD, device=self.device, dtype=torch.float32)
             check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
-            if self.two_streams_active() and self.device.type == "cuda":
-                # two passes may be here at once: do the add where all other non-atomic accumulations into G already run (the side stream)
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                self._side.wait_stream(torch.cuda.current_stream(self.device))
-                bsum.record_stream(self._side)
-                with torch.cuda.stream(self._side):
-                    self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
-                self._side_busy = True
-            else:
-                self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
+            self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
             self._wgrad(dcur, x_small, g, self.G[c.w_off:])
             dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
             check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
@@ -673,8 +552,6 @@ class Engine:
         tp = Tape()
         T = tp.t
         plan = self.plan
-        if training and self.two_streams_active():
-            self._rs_prev, self._rs_cur = self._rs_cur, []
         nseg = 2 if seg else 1
         n_bn = sum(2 * b.C for b in plan.bns) * nseg
         sums_all = torch.zeros(n_bn, device=self.device, dtype=torch.float32)

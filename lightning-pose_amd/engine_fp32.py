@@ -39,9 +39,6 @@ class Fp32Engine(Engine):
         """nothing is fused into tiles here: two BatchNorm segments are simply two calls of the BatchNorm kernels"""
         return n0 > 0
 
-    def two_streams_active(self) -> bool:
-        return False
-
     def _f32(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, device=self.device, dtype=torch.float32)
 

@@ -202,8 +202,12 @@ class PCALoss(Loss):
         assert keypoints_pred.device == torch.device(self.device), (keypoints_pred.device, torch.device(self.device))
         if self._index is None:
             self._index = torch.from_numpy(self.pca.index_table(keypoints_pred.shape[1] // 2)).to(keypoints_pred.device)
+        if getattr(self, "_eps_host", None) is None or self._eps_src is not self.epsilon:
+            # epsilon lives on the device (the reference's PCA parameters do): read it back ONCE - float() of a device tensor is a
+            # host synchronisation, which stalls the launch queue every step and is illegal while a HIP graph is being captured
+            self._eps_host, self._eps_src = float(self.epsilon), self.epsilon
         scalar_loss = ops.pca_loss(keypoints_pred, self._index, self.pca.parameters["mean"],
-                                   self.pca.parameters["kept_eigenvectors"], float(self.epsilon))
+                                   self.pca.parameters["kept_eigenvectors"], self._eps_host)
         return scalar_loss, self.log_loss(loss=scalar_loss, stage=stage)
 
 

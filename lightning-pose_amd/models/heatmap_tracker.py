@@ -36,17 +36,11 @@ class _NetworkFn(torch.autograd.Function):
         # images2: a second batch sharing the pass (joint labeled + unlabeled forward, two BatchNorm segments)
         heat, tape = net.forward(images if images2 is None else (images, images2), training=training)
         ctx.net, ctx.tape = net, tape
-        ctx.stream_key = net._stream_key() if hasattr(net, "_stream_key") else 0
         return heat
 
     @staticmethod
     def backward(ctx, g_heat: torch.Tensor):
-        if hasattr(ctx.net, "replay_ctx"):
-            with ctx.net.replay_ctx(ctx.stream_key):
-                ctx.net.backward(ctx.tape, g_heat)
-                ctx.net.note_backward_done()  # two-stream mode: the consumer of G waits for this stream
-        else:
-            ctx.net.backward(ctx.tape, g_heat)
+        ctx.net.backward(ctx.tape, g_heat)
         ctx.tape = None
         return None, None, None, None, None
 

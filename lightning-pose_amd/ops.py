@@ -30,6 +30,9 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
         if not t.is_cuda:
             raise LpHipUnavailable(
                 "lightning_pose_amd ops run only on a ROCm device (got a CPU tensor); there is no CPU fallback")
+        if t.device.index is not None and t.device.index != torch.cuda.current_device():
+            raise LpHipUnavailable(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: kernels launch on the "
+                                   "current device's stream - call torch.cuda.set_device (one process per GPU)")
         dev = t.device
     return dev
 
@@ -37,9 +40,14 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
 def require_device_type(device: torch.device) -> None:
     if device.type != "cuda":
         raise LpHipUnavailable(f"lightning_pose_amd needs a ROCm device (got {device}); there is no CPU fallback")
+    if device.index is not None and device.index != torch.cuda.current_device():
+        torch.cuda.set_device(device)  # the engine's device becomes the process's current device (one process per GPU)
 
 
 def _stream() -> C.c_void_p:
+    """torch's current stream on the CURRENT device.  Kernels are launched on the current device, so a model's device must be the
+    current one: Engine / ViTEngine make it so when they are built (one process per GPU, as the reference's DDP), and require_device
+    refuses tensors of another device instead of launching device-0 kernels on device-1 pointers."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -270,6 +278,26 @@ class _UnitGradFn(torch.autograd.Function):
         return (grad_unit * gout).reshape(ctx.shape), None, None
 
 
+_EPS_CACHE: dict = {}
+
+
+def _device_epsilon(epsilon: torch.Tensor, k: int, dev: torch.device) -> torch.Tensor:
+    """per-keypoint epsilon vector on the device; uploaded once per (tensor, k, device) - a host-to-device copy every step would
+    serialise the host with the launch queue and cannot be captured into a HIP graph"""
+    key = (id(epsilon), k, str(dev))
+    hit = _EPS_CACHE.get(key)
+    if hit is not None and hit[0] is epsilon and hit[1] == epsilon._version:
+        return hit[2]
+    eps = epsilon.to(device=dev, dtype=torch.float32).reshape(-1)
+    eps = eps.expand(k).contiguous() if eps.numel() == 1 else eps.contiguous()
+    if eps.numel() != k:
+        raise ValueError(f"temporal epsilon must be a scalar or have one entry per keypoint ({k}), got {eps.numel()}")
+    if len(_EPS_CACHE) > 64:
+        _EPS_CACHE.clear()
+    _EPS_CACHE[key] = (epsilon, epsilon._version, eps)
+    return eps
+
+
 def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None, epsilon: torch.Tensor, prob_threshold: float):
     """keypoints (S, 2K) -> scalar (reference losses/losses.py:674-703)."""
     require_device(keypoints)
@@ -277,10 +305,7 @@ def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None, eps
     s = kp.shape[0]
     k = kp.shape[1] // 2
     conf = _f32c(confidences) if confidences is not None else None
-    eps = epsilon.to(device=kp.device, dtype=torch.float32).reshape(-1)
-    eps = eps.expand(k).contiguous() if eps.numel() == 1 else eps.contiguous()
-    if eps.numel() != k:
-        raise ValueError(f"temporal epsilon must be a scalar or have one entry per keypoint ({k}), got {eps.numel()}")
+    eps = _device_epsilon(epsilon, k, kp.device)
     loss = torch.empty(1, device=kp.device, dtype=torch.float32)
     grad = torch.empty_like(kp)
     check(_lib.lib().lp_temporal_fwd_bwd(_p(kp), _p(conf), s, k, _p(eps), float(prob_threshold), _p(loss), _p(grad), _stream()),
@@ -335,10 +360,7 @@ def temporal_heatmap_loss(heatmaps_pred: torch.Tensor, confidences: torch.Tensor
                           kind: int) -> torch.Tensor:
     """(S, K, h, w) heat-maps, (S, K) confidences -> scalar (reference losses/losses.py:841-869); kind = HM_MSE | HM_KL."""
     k = heatmaps_pred.shape[1]
-    eps = epsilon.to(device=heatmaps_pred.device, dtype=torch.float32).reshape(-1)
-    eps = eps.expand(k).contiguous() if eps.numel() == 1 else eps.contiguous()
-    if eps.numel() != k:
-        raise ValueError(f"temporal heat-map epsilon must be a scalar or have one entry per keypoint ({k}), got {eps.numel()}")
+    eps = _device_epsilon(epsilon, k, heatmaps_pred.device)
     if tuple(confidences.shape) != tuple(heatmaps_pred.shape[:2]):
         raise ValueError(f"confidences must be {tuple(heatmaps_pred.shape[:2])}, got {tuple(confidences.shape)}")
     return _TemporalHeatmapFn.apply(heatmaps_pred, confidences, eps, float(prob_threshold), kind)

@@ -16,13 +16,16 @@ from .distributed import DataParallel
 
 class Trainer:
     def __init__(self, max_epochs: int = 1, callbacks: list | None = None, limit_train_batches: int | None = None,
-                 data_parallel: bool | None = None, sync_batchnorm: bool = True, accumulate_grad_batches: int = 1):
+                 data_parallel: bool | None = None, sync_batchnorm: bool = True, accumulate_grad_batches: int = 1,
+                 hip_graph: bool | None = None):
         self.max_epochs = max_epochs
         self.callbacks = callbacks or []
         self.limit_train_batches = limit_train_batches
         self.sync_batchnorm = sync_batchnorm
         self.accumulate_grad_batches = accumulate_grad_batches
         self._want_dp = data_parallel
+        self._want_graph = hip_graph          # None: LP_HIP_GRAPH decides (graph_step.py)
+        self._graphed = None
         self.dp: DataParallel | None = None
         self.logged_history: list[dict[str, float]] = []
         self.validation_history: list[dict[str, float]] = []
@@ -44,24 +47,64 @@ class Trainer:
         if model.optimizers() is None:
             cfg = model.configure_optimizers()
             self.scheduler = cfg["lr_scheduler"]
+        elif getattr(self, "scheduler", None) is None:  # a model whose optimiser was configured by the caller: its scheduler only
+            self.scheduler = model.get_scheduler(model.optimizers())
         opt = model.optimizers()
         if self.dp is not None:
             opt.grad_scale = 1.0 / self.dp.world
 
-    def training_batch(self, model, batch: dict, batch_idx: int) -> torch.Tensor:
-        """One optimisation step; returns the (detached) loss."""
+    def _sync_logged(self, model) -> None:
+        """``self.log(..., sync_dist=True)``: every marked scalar of the step becomes its mean over the ranks - ONE packed all-reduce"""
+        names = getattr(model, "sync_logged", None)
+        if self.dp is not None and self.dp.world > 1 and names:
+            model.logged.update(self.dp.mean_scalars({k: model.logged[k] for k in names if k in model.logged}))
+
+    def _graph_eligible(self, model) -> bool:
+        import os
+
+        from . import graph_step
+
+        want = self._want_graph if self._want_graph is not None else graph_step.requested()
+        if not want or self.accumulate_grad_batches != 1 or model.device.type != "cuda" or getattr(model.net, "profile", None) is not None:
+            return False
+        if self.dp is not None and self.dp.world > 1 and os.environ.get("LP_HIP_GRAPH_DIST", "0") != "1":
+            return False
+        return True
+
+    def training_batch(self, model, batch: dict, batch_idx: int, last_in_epoch: bool = False) -> torch.Tensor:
+        """One optimisation step; returns the (detached) loss.  With ``hip_graph`` the step is captured once and replayed as one HIP
+        graph (graph_step.GraphedStep); otherwise every kernel is enqueued from here."""
+        if self._graph_eligible(model):
+            from .graph_step import GraphedStep
+
+            if self._graphed is None or self._graphed.model is not model:
+                self._graphed = GraphedStep(self, model)
+            return self._graphed.step(batch, batch_idx)
+        return self._eager_batch(model, batch, batch_idx, last_in_epoch)
+
+    def _eager_batch(self, model, batch: dict, batch_idx: int, last_in_epoch: bool = False, count: bool = True) -> torch.Tensor:
+        """With gradient accumulation the loss is scaled by 1 / accumulate_grad_batches (Lightning's rule) and a trailing partial group is
+        stepped at the end of the epoch (``last_in_epoch``).  ``count=False`` (graph capture): hooks and step counters are the caller's."""
         opt = model.optimizers()
-        self._hook("on_train_batch_start", model, batch, batch_idx)
-        if batch_idx % self.accumulate_grad_batches == 0:
+        acc = self.accumulate_grad_batches
+        if count:
+            self._hook("on_train_batch_start", model, batch, batch_idx)
+        if batch_idx % acc == 0:
             opt.zero_grad()
         loss = model.training_step(batch, batch_idx)["loss"]
-        loss.backward()
-        if (batch_idx + 1) % self.accumulate_grad_batches == 0:
+        (loss / acc if acc > 1 else loss).backward()
+        if (batch_idx + 1) % acc == 0 or last_in_epoch:
             if self.dp is not None:
+                # the gradient buckets go out first (tail of the flat buffer = what backward finished first); the logged scalars' mean
+                # rides behind them on the same communicator, and the optimiser waits for the buckets only
                 self.dp.all_reduce_gradients()
+                self._sync_logged(model)
                 self.dp.wait()
             opt.step()
-            model.global_step += 1
+            if count:
+                model.global_step += 1
+        elif self.dp is not None:
+            self._sync_logged(model)
         return loss.detach()
 
     @torch.no_grad()
@@ -77,6 +120,7 @@ class Trainer:
             for batch_idx, batch in enumerate(batches):
                 model.logged = {}
                 getattr(model, step_name)(batch, batch_idx)
+                self._sync_logged(model)  # val_supervised_loss (the scheduler / checkpoint monitor) is the mean over ranks
                 for k, v in model.logged.items():
                     totals[k] = totals.get(k, 0.0) + float(v)
                 n += 1
@@ -94,12 +138,17 @@ class Trainer:
         for epoch in range(self.max_epochs):
             model.current_epoch = epoch
             self._hook("on_train_epoch_start", model)
-            it = batches(epoch) if callable(batches) else batches
-            for batch_idx, batch in enumerate(it):
-                if self.limit_train_batches is not None and batch_idx >= self.limit_train_batches:
-                    break
-                self.training_batch(model, batch, batch_idx)
+            it = iter(batches(epoch) if callable(batches) else batches)
+            nxt = next(it, None)
+            batch_idx = 0
+            while nxt is not None:  # one batch of look-ahead: the last batch of the epoch closes a partial accumulation group
+                batch, nxt = nxt, next(it, None)
+                last = nxt is None or (self.limit_train_batches is not None and batch_idx + 1 >= self.limit_train_batches)
+                self.training_batch(model, batch, batch_idx, last_in_epoch=last)
                 self.logged_history.append({k: float(v) for k, v in getattr(model, "logged", {}).items()})
+                batch_idx += 1
+                if last:
+                    break
             if val_batches is not None:  # check_val_every_n_epoch = 1
                 self.validate(model, val_batches(epoch))
             self.scheduler.step()

@@ -155,18 +155,14 @@ class ViTEngine(Engine):
             self.P[l.g_off:l.g_off + hidden] = 1.0
         self.nbt = torch.zeros((), dtype=torch.long)
         self.sync_bn, self.process_group = False, None   # no BatchNorm here; kept for the DataParallel wrapper
+        self.sync_bn_messages = 0
+        self._bwd_training = True
         self.profile = None
         self._wgrad_ws = None
         self._bn_ws = None
         self._side, self._side_busy = None, False
         self._fold = None
-        self._branches, self._bn_ws_by_stream, self._rs_prev, self._rs_cur, self._pending = None, {}, [], [], []
         self._interp: dict[tuple[int, int], torch.Tensor] = {}
-
-    def two_streams_active(self) -> bool:
-        """Not for this engine: its weight gradients run on the pass's own stream (no side stream), so two concurrent passes would
-        race on the accumulation into G."""
-        return False
 
     # ------------------------------------------------------------------------------------------------ params
     def _views(self, buf: torch.Tensor) -> dict[str, torch.Tensor]:

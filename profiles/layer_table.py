@@ -35,6 +35,8 @@ def main():
     dg = [x for x in launches if "dgrad" in x[0]]
     wg = [x for x in launches if "wgrad" in x[0] and "stem" not in x[0]]
     nf, nb = len(names_forward()), len(names_backward())
+    if len(fw) == nf and len(dg) == nb:              # joint labeled + unlabeled pass (round 2 default): ONE forward / backward per step
+        fw, dg, wg = fw * 2, dg * 2, wg * 2
     assert len(fw) == 2 * nf and len(dg) == 2 * nb, (len(fw), len(dg), "unexpected launch list: not a ResNet-50 step?")
     passes_f = [fw[:nf], fw[nf:]]
     passes_d = [dg[:nb], dg[nb:]]

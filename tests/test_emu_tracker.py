@@ -55,7 +55,14 @@ def test_tracker_training_step_vs_reference_golden(stack_backend, golden):
         assert got[k] == pytest.approx(float(want[k]), rel=1e-6), k
     for k in ("train_heatmap_mse_loss", "train_heatmap_mse_loss_weighted", "train_supervised_loss"):
         assert got[k] == pytest.approx(float(want[k]), rel=5e-3), k
-    assert np.isfinite(got["train_temporal_loss"]) and np.isfinite(got["train_supervised_rmse"]) and np.isfinite(got["total_loss"])
+    print("\nTRACKER_STEP", {k: (round(got[k], 6), round(float(want[k]), 6)) for k in want})
+    # keypoint-space scalars of this RANDOM-INIT step (flat heat-maps, chaotic trunk): the fixture's temporal loss is exactly 0 (every
+    # frame-to-frame move is below epsilon = 1 px) and stays 0; RMSE and the total follow the heat-map loss.  Their VALUES are pinned at
+    # 1e-4 by the fp32 path on this same fixture (tests/test_fp32_parity.py) and, for both precisions on fitted heat-maps at the
+    # BASELINE configs, by tests/test_step_parity.py
+    assert got["train_temporal_loss"] == pytest.approx(float(want["train_temporal_loss"]), abs=1e-3)
+    assert got["train_supervised_rmse"] == pytest.approx(float(want["train_supervised_rmse"]), rel=5e-2)
+    assert got["total_loss"] == pytest.approx(float(want["total_loss"]), rel=5e-3)
     # gradients reached every parameter group through the hand-written backward (their VALUES are checked block by
     # block in tests/test_emu_engine.py: a random-init 50-layer BatchNorm net at batch 4 is chaotic end to end)
     gw = getattr(model.head.upsampling_layers, "2").weight.grad
