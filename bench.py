@@ -35,6 +35,7 @@ import _lp_bootstrap  # noqa: E402,F401
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+VALU_FP32_PEAK_TFLOPS = 157.0   # fp32 vector peak, same guide
 TRAIN_GFLOP_PER_FRAME = {384: 72.4, 256: 32.2}  # 3 x 2 x (trunk + head) MACs
 VIT_S_TRAIN_GFLOP_PER_FRAME = {384: 93.1, 256: 36.9}  # SURVEY.md section 8(d), ViT-S/16
 
@@ -170,50 +171,66 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "re
 
 
 def pmc_traffic():
-    """Average HBM bytes per convolution launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, produced by profiles/summarize_pmc.py); None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return round(json.load(fh)["conv_hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    """Average HBM bytes per convolution launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
+    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r02_pmc.sh -> profiles/r02_pmc_traffic.json
+    via profiles/summarize_pmc.py); None when no profile is committed.  The counters need rocprofv3 around the process, so this is the
+    committed measurement of the same workload, not a live one; ``algorithmic_bytes_per_launch`` next to it IS computed live."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return round(json.load(fh)["conv_hbm_bytes_per_launch"]), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def hbm_rooflines(dev, size: int, K: int, frames: int, reps: int = 10) -> dict:
-    """HBM roofline of the heat-map kernels (decode and heat-map generation are HBM-bound): algorithmic bytes
-    per launch / time per launch, timed live with events on the launch stream (torch's current stream, where ops.* enqueue).
-    Bytes per frame: one K-stack of fp32 heat-maps = K*h*w*4 (626 688 B at 96x96, K = 17); decode fwd reads it once, decode bwd reads
-    and writes it once more, generation writes it once, heat-map MSE fwd+bwd reads two stacks and writes one."""
-    from lightning_pose_amd import ops
+    """HBM roofline of the heat-map kernels: algorithmic bytes per launch / time per launch, HIP events on the launch
+    stream around the C-ABI CALLS themselves (buffers allocated beforehand - no Python wrapper, autograd or allocation inside the timed
+    region).  Bytes per frame: one K-stack of fp32 heat-maps = K*h*w*4 (626 688 B at 96x96, K = 17); decode fwd reads it once, decode bwd
+    reads it and writes the gradient stack, generation writes it once, heat-map MSE fwd reads two stacks, its bwd reads two and writes one.
+    The fused decode is fp32-VALU work by construction (one pass over the map, ~9 kFLOP per heat-map pixel for the x16 up-sampled
+    soft-argmax): its VALU fraction is reported next to the HBM fraction."""
+    import ctypes as C
 
+    from lightning_pose_amd import _lib, ops
+    from lightning_pose_amd.ops import _p
+
+    lib = _lib.lib()
     h = size // 4
     stack = float(frames * K * h * h * 4)
-    heat = torch.softmax(torch.randn(frames, K, h * h, device=dev) * 4.0, -1).reshape(frames, K, h, h)
-    kp = torch.rand(frames, K, 2, device=dev) * size
+    heat = torch.softmax(torch.randn(frames, K, h * h, device=dev) * 4.0, -1).reshape(frames, K, h, h).contiguous()
+    kp = (torch.rand(frames, K, 2, device=dev) * size).contiguous()
     fm = ops.DecodeFrameMap(None, False, None, 1, size, size, K)
-    targ = ops.generate_heatmaps(kp, size, size, (h, h))
-
-    def decode_fwd_bwd():
-        x = heat.detach().requires_grad_(True)
-        _aug, kp_frame, _conf = ops.decode(x, 2, 1000.0, fm)
-        kp_frame.backward(torch.ones_like(kp_frame))
-
-    def mse_fwd_bwd():
-        x = heat.detach().requires_grad_(True)
-        ops.heatmap_mse(targ, x).backward()
+    targ = ops.generate_heatmaps(kp, size, size, (h, h)).contiguous()
+    tables, _keep = ops._device_tables(h, h, 2, heat.device)
+    kp_aug, kp_frame = torch.empty(frames, K, 2, device=dev), torch.empty(frames, K, 2, device=dev)
+    conf, stats = torch.empty(frames, K, device=dev), torch.empty(frames, K, 4, device=dev)
+    g_frame, g_heat = torch.ones(frames, K, 2, device=dev), torch.empty_like(heat)
+    out_hm = torch.empty_like(heat)
+    ws = torch.empty(int(lib.lp_heatmap_mse_workspace_bytes(frames, K)), device=dev, dtype=torch.uint8)
+    loss, go = torch.empty(1, device=dev), torch.ones(1, device=dev)
+    st = ops._stream
 
     cases = {
-        "decode_fwd": (stack, lambda: ops.decode(heat, 2, 1000.0, fm)),
-        "decode_fwd_bwd": (3 * stack, decode_fwd_bwd),
-        "heatmap_gen": (stack, lambda: ops.generate_heatmaps(kp, size, size, (h, h))),
-        "heatmap_mse_fwd_bwd": (3 * stack, mse_fwd_bwd),
+        "decode_fwd": (stack, lambda: lib.lp_decode_fwd(_p(heat), frames, K, h, h, 2, 1000.0, C.byref(tables), C.byref(fm.struct), _p(kp_aug),
+                                                        _p(kp_frame), _p(conf), _p(stats), st())),
+        "decode_bwd": (2 * stack, lambda: lib.lp_decode_bwd(_p(heat), frames, K, h, h, 2, 1000.0, C.byref(tables), C.byref(fm.struct), _p(stats),
+                                                            None, _p(g_frame), _p(g_heat), 0, st())),
+        "heatmap_gen": (stack, lambda: lib.lp_heatmap_gen(_p(kp), None, frames, K, size, size, h, h, 1.25, _p(out_hm), st())),
+        "heatmap_mse_fwd": (2 * stack, lambda: lib.lp_heatmap_loss_fwd(_lib.HM_MSE, _p(targ), _p(heat), frames, K, h, h, _p(loss), _p(ws), st())),
+        "heatmap_mse_bwd": (3 * stack, lambda: lib.lp_heatmap_loss_bwd(_lib.HM_MSE, _p(targ), _p(heat), frames, K, h, h, _p(ws), _p(go), _p(g_heat),
+                                                                       0, st())),
     }
+    # fp32 VALU work of the fused decode: per output pixel of the up-sampled (4h x 4w) map ~12 + 12 FMAs for the two separable tap passes
+    # + ~10 for the online soft-max / expectation = ~70 FLOP; x 16 pixels per heat-map pixel.  The backward recomputes it and adds the scatter.
+    valu_flop = {"decode_fwd": frames * K * (4 * h) * (4 * h) * 70.0, "decode_bwd": frames * K * (4 * h) * (4 * h) * 130.0}
     cuda = dev.type == "cuda"
     out = {}
     for name, (nbytes, fn) in cases.items():
         for _ in range(2):
-            fn()
+            rc = fn()
+            assert rc == 0, (name, rc)
         if cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -229,8 +246,13 @@ def hbm_rooflines(dev, size: int, K: int, frames: int, reps: int = 10) -> dict:
             us = 1e6 * (time.perf_counter() - t0) / reps
         gbs = nbytes / us / 1e3
         out[name] = {"us": round(us, 1), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if name in valu_flop:
+            tf = valu_flop[name] / us / 1e6
+            out[name].update(valu_tflops=round(tf, 1), valu_frac=round(tf / VALU_FP32_PEAK_TFLOPS, 3))
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frames": frames, "algorithmic_bytes_per_frame": int(stack / frames),
-            "note": "decode is fp32-VALU-bound by construction (one pass over the map, ~350 FLOP/B): HBM bytes are its floor", "kernels": out}
+            "timed": "HIP events around the C-ABI calls (lp_decode_fwd / lp_decode_bwd / lp_heatmap_gen / lp_heatmap_loss_fwd / _bwd)",
+            "note": "the fused decode is fp32-VALU-bound by construction (valu_frac: of the 157 TFLOP/s fp32 vector peak); HBM bytes are its floor",
+            "kernels": out}
 
 
 def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 3) -> dict:
@@ -250,7 +272,12 @@ def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int
                       "transforms": torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]),
                       "bbox": torch.tensor([[0.0, 0.0, size, size]]).repeat(n_unlab, 1), "is_multiview": False},
     }
-    cfg = {"temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05}, "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05}}
+    cols = [k for k in range(K) if k not in (7, 15, 16)] if K == 17 else list(range(K))
+    fit = O.fit_pca(pca_training_array(K, size)[:, sorted(c for k in cols for c in (2 * k, 2 * k + 1))].numpy(), 0.99)
+    cfg = {"temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05},
+           "pca_singleview": {"log_weight": 5.0, "mean": fit["mean"], "kept_eigenvectors": fit["kept_eigenvectors"], "epsilon": float(fit["epsilon"]),
+                              "columns": cols},
+           "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05}}
     model.train()
     times = []
     for i in range(steps + 1):  # 1 warm-up + up to `steps` timed steps, stopping early once ~25 s of timed CPU work are in (>= 2 steps)
@@ -267,10 +294,11 @@ def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int
     med = sorted(times)[len(times) // 2]
     return {"value": round((n_lab + n_unlab) / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} timed full steps (fwd+bwd+Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, fp32, "
-                      f"median {med:.2f} s/step; oracle/restated.py OracleTracker + training_step"}
+                      f"median {med:.2f} s/step; oracle/restated.py OracleTracker + training_step (kind 'port': the torch fp32 restatement "
+                      "that tests/ pin against the verbatim reference, with the bench's four losses: heatmap_mse + temporal + pca_singleview + unimodal_mse)"}
 
 
-def predict_bench(args, model, batch, dev, rank: int, world: int) -> None:
+def predict_bench(args, model, batch, dev, rank: int, world: int) -> dict:
     """Inference over the resident frames: predict_step (trunk with folded BatchNorm -> head -> fused decode incl. the bbox map)."""
     import torch.distributed as dist
 
@@ -306,48 +334,14 @@ def predict_bench(args, model, batch, dev, rank: int, world: int) -> None:
     if gf:  # forward only = a third of the training FLOPs per frame
         line["model_tflops_per_gpu"] = round(value / world * gf / 3 / 1e3, 2)
         line["mfma_frac_end_to_end"] = round(value / world * gf / 3 / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
-def main(argv: list[str] | None = None, device: torch.device | None = None) -> None:
-    """``device`` (tests only): run the whole flow on that device - the CPU with the emulated kernel library - instead of cuda:LOCAL_RANK."""
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=384)
-    ap.add_argument("--labeled", type=int, default=64)
-    ap.add_argument("--unlabeled", type=int, default=128)
-    ap.add_argument("--keypoints", type=int, default=17)
-    ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "vits_dino", "vitb_dino"],
-                    help="resnet50 = BASELINE configs C2/C3 (the headline metric); vits_dino = config C4")
-    ap.add_argument("--views", type=int, default=1, help="4 = BASELINE config C5 (multiview: --size 256 --labeled 16 --unlabeled 32 "
-                    "gives the same 192 images per GPU); frames/s then counts view-images")
-    ap.add_argument("--predict", action="store_true", help="secondary line: inference frames/s (eval mode, BatchNorm folded into the "
-                    "convolutions, fused decode) over the same frames; the headline metric stays the training step")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("LP_HIP_GRAPH", "0")), help="1: replay the step as one captured HIP graph "
-                    "(lightning_pose_amd/graph_step.py); the capture happens in extra untimed steps before the warm-up")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
-    args = ap.parse_args(argv)
-
+def train_line(args, dev, rank: int, world: int) -> dict:
+    """Build the model + batch of ``args`` and measure it: the JSON line (without printing it)."""
     import torch.distributed as dist
 
-    from lightning_pose_amd.distributed import init_process_group_from_env
     from lightning_pose_amd.trainer import Trainer
-
-    rank, local_rank, world = init_process_group_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if os.environ.get("LP_FORCE_DEVICE") is not None:  # functional multi-rank test on a 1-GPU box (with LP_DIST_BACKEND=gloo)
-        local_rank = int(os.environ["LP_FORCE_DEVICE"])
-    dev = torch.device(f"cuda:{local_rank}") if device is None else device
-    if dev.type == "cuda":
-        torch.cuda.set_device(dev)
 
     model = build_model(dev, args.keypoints, args.size, backbone=args.backbone, views=args.views)
     if args.views > 1:
@@ -398,6 +392,12 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
+    # what crosses GPUs per step: SyncBatchNorm all-reduces (one per BatchNorm layer and direction, both segments of the joint pass in one
+    # message), the gradient buckets, one packed message of logged scalars
+    n_msgs = getattr(model.net, "sync_bn_messages", 0) // max(1, graph_capture_steps + args.warmup + args.steps + 1)
+    bn_bytes = sum(2 * 2 * b.C * 4 for b in getattr(model.net.plan, "bns", [])) * 2 if getattr(model.net, "sync_bn", False) else 0
+    comm = {"sync_bn_messages": n_msgs, "sync_bn_bytes": bn_bytes, "grad_buckets": (0 if world == 1 else -(-model.net.G.numel() * 4 // (64 << 20))),
+            "grad_bytes": 0 if world == 1 else model.net.G.numel() * 4, "logged_scalar_messages": 0 if world == 1 else 1}
     frames_per_step = (args.labeled + args.unlabeled) * args.views * world
     value = frames_per_step * args.steps / elapsed
     is_vit = args.backbone != "resnet50"
@@ -415,7 +415,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                                f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
                                "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
-                   "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": world > 1,
+                   "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": bool(getattr(model.net, "sync_bn", False)),
+                   "comm_per_step": comm,
                    "hip_graph": bool(trainer._graphed is not None and trainer._graphed.replays > 0),
                    "final_loss": round(float(loss), 6)},
     }
@@ -423,49 +424,120 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
         if prof:
             by: dict[str, list[float]] = {}
             tot_ms, tot_flops = 0.0, 0.0
-            for tag, flops, e0, e1 in prof:
+            tot_bytes = 0.0
+            for tag, flops, e0, e1, nbytes in prof:
                 ms = e0.elapsed_time(e1)
-                rec = by.setdefault(tag, [0, 0.0, 0.0])
+                rec = by.setdefault(tag, [0, 0.0, 0.0, 0.0])
                 rec[0] += 1
                 rec[1] += ms
                 rec[2] += flops
+                rec[3] += nbytes
                 tot_ms += ms
                 tot_flops += flops
+                tot_bytes += nbytes
             dump = os.environ.get("LP_DUMP_LAUNCHES")
             if dump:  # per-launch (tag, GFLOP, us) of the LAST timed step, for kernel tuning
                 per_step = len(prof) // prof_steps
                 with open(dump, "w") as fh:
-                    json.dump([[t, round(f / 1e9, 3), round(1000 * a.elapsed_time(b), 1)] for t, f, a, b in prof[-per_step:]], fh)
+                    json.dump([[t, round(f / 1e9, 3), round(1000 * a.elapsed_time(b), 1), round(nb / 1e6, 2)] for t, f, a, b, nb in prof[-per_step:]], fh)
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic() if (not is_vit and args.size == 384 and args.views == 1) else (None, None)
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches)",
+                "bound": "mfma", "kernel": ("lp_gemm_nt / conv_wgrad_kernel / attn_fwd_kernel / attn_bwd_kv_kernel (all MFMA launches of the ViT)" if is_vit
+                                            else "conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches)"),
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(),
-                "launches_per_step": len(prof) // prof_steps, "conv_ms_per_step": round(tot_ms / prof_steps, 3),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(tot_bytes / len(prof)),
+                "traffic_over_algorithmic": round(traffic / (tot_bytes / len(prof)), 3) if traffic else None,
+                "hbm_gbs_algorithmic": round(tot_bytes / (tot_ms * 1e-3) / 1e9, 1),
+                "launches_per_step": len(prof) // prof_steps, "mfma_ms_per_step": round(tot_ms / prof_steps, 3),
                 "sampled_steps": prof_steps,
                 "by_kernel": {k: {"launches_per_step": v[0] // prof_steps, "avg_us": round(1000 * v[1] / v[0], 2),
-                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(by.items())},
+                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "algorithmic_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1)}
+                              for k, v in sorted(by.items())},
             }
         gf = (VIT_S_TRAIN_GFLOP_PER_FRAME if args.backbone == "vits_dino" else {} if is_vit else TRAIN_GFLOP_PER_FRAME).get(args.size)
-        if gf and is_vit:  # no per-launch events on this path yet: the roofline entry is the end-to-end model rate
-            ach = value / world * gf / 1e3
-            out["roofline"] = {"bound": "mfma", "kernel": "lp_gemm_nt + conv_wgrad_kernel (Linear layers and attention products), end to end",
-                               "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
         if gf:
             out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
             out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
-        if world == 1 and not args.no_profile and args.views == 1:
+        if world == 1 and not args.no_profile and args.views == 1 and not getattr(args, "_secondary", False):
             try:  # secondary rooflines; never allowed to cost the measured line
                 out["roofline_hbm"] = hbm_rooflines(dev, args.size, args.keypoints, args.labeled + args.unlabeled)
             except Exception as e:  # noqa: BLE001
                 out["roofline_hbm"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_cpu_baseline and not is_vit and args.views == 1:
+        if world == 1 and not args.no_cpu_baseline and not is_vit and args.views == 1 and not getattr(args, "_secondary", False):
             try:
                 out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)
             except Exception as e:  # noqa: BLE001 - the baseline must never cost the measured line
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+    return out
+
+
+def main(argv: list[str] | None = None, device: torch.device | None = None) -> None:
+    """``device`` (tests only): run the whole flow on that device - the CPU with the emulated kernel library - instead of cuda:LOCAL_RANK."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--labeled", type=int, default=64)
+    ap.add_argument("--unlabeled", type=int, default=128)
+    ap.add_argument("--keypoints", type=int, default=17)
+    ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "vits_dino", "vitb_dino"],
+                    help="resnet50 = BASELINE configs C2/C3 (the headline metric); vits_dino = config C4")
+    ap.add_argument("--views", type=int, default=1, help="4 = BASELINE config C5 (multiview: --size 256 --labeled 16 --unlabeled 32 "
+                    "gives the same 192 images per GPU); frames/s then counts view-images")
+    ap.add_argument("--predict", action="store_true", help="secondary line: inference frames/s (eval mode, BatchNorm folded into the "
+                    "convolutions, fused decode) over the same frames; the headline metric stays the training step")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("LP_HIP_GRAPH", "0")), help="1: replay the step as one captured HIP graph "
+                    "(lightning_pose_amd/graph_step.py); the capture happens in extra untimed steps before the warm-up")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip the short secondary lines (256 px, ViT-S, multiview, "
+                    "inference) the default single-GPU run appends under \"secondary\"")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    args = ap.parse_args(argv)
+
+    import torch.distributed as dist
+
+    from lightning_pose_amd.distributed import init_process_group_from_env
+    from lightning_pose_amd.trainer import Trainer
+
+    rank, local_rank, world = init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("LP_FORCE_DEVICE") is not None:  # functional multi-rank test on a 1-GPU box (with LP_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["LP_FORCE_DEVICE"])
+    dev = torch.device(f"cuda:{local_rank}") if device is None else device
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+
+    out = train_line(args, dev, rank, world)
+    if rank == 0:
+        headline = (args.size, args.labeled, args.unlabeled, args.keypoints, args.views, args.backbone) == (384, 64, 128, 17, 1, "resnet50")
+        if args.secondary and world == 1 and not args.predict and headline and dev.type == "cuda":
+            # the other BASELINE.json configs / north_star sizes in the same run (short: 3 timed steps each), so the driver's BENCH file
+            # holds them too; the headline stays `value`
+            import copy
+            sec = {}
+            for tag, over in (("resnet50_256", dict(size=256)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
+                              ("c5_multiview_4x256", dict(views=4, size=256, labeled=16, unlabeled=32)),
+                              ("predict_resnet50_384", dict(predict=True)), ("predict_vits_dino_384", dict(predict=True, backbone="vits_dino"))):
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup, a2.no_cpu_baseline, a2._secondary = 3, 2, True, True
+                for k_, v_ in over.items():
+                    setattr(a2, k_, v_)
+                try:
+                    torch.cuda.empty_cache() if dev.type == "cuda" else None
+                    r = train_line(a2, dev, rank, world)
+                    sec[tag] = {k_: r[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "model_tflops_per_gpu", "mfma_frac_end_to_end") if k_ in r}
+                    if "roofline" in r:
+                        sec[tag]["roofline"] = {k_: r["roofline"][k_] for k_ in ("achieved", "frac", "unit", "launches_per_step", "mfma_ms_per_step",
+                                                                                 "hbm_gbs_algorithmic") if k_ in r["roofline"]}
+                    sec[tag]["workload"] = r["config"]["workload"]
+                except Exception as e:  # noqa: BLE001 - never allowed to cost the headline line
+                    sec[tag] = {"error": f"{type(e).__name__}: {e}"}
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -219,15 +219,16 @@ class Engine:
         self._side_busy = False
         self._fold: tuple[torch.Tensor, torch.Tensor] | None = None  # inference copies: BatchNorm folded into (bf16 weights, biases)
 
-    def _timed(self, tag: str, flops: float, fn):
-        """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream."""
+    def _timed(self, tag: str, flops: float, fn, nbytes: float = 0.0):
+        """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream.  ``nbytes``: the launch's
+        ALGORITHMIC bytes (operands read once + result written once), the denominator the measured HBM traffic is held against."""
         if self.profile is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn()
         e1.record()
-        self.profile.append((tag, flops, e0, e1))
+        self.profile.append((tag, flops, e0, e1, nbytes))
         return out
 
     def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False, dbias: torch.Tensor | None = None) -> None:
@@ -264,6 +265,14 @@ class Engine:
         if getattr(self, "_side_busy", False):
             torch.cuda.current_stream(self.device).wait_stream(self._side)
             self._side_busy = False
+
+    @staticmethod
+    def _bytes(c: "ConvP", g, wgrad: bool = False) -> float:
+        """Algorithmic bytes of one contraction over this layer: the gathered tensor and the other activation-sized operand / result once
+        each (bf16), the weights once (bf16 operand; fp32 for the gradient a weight-gradient launch accumulates into)"""
+        kk = 8 * 8 if c.kind == "stem" else c.k * c.k
+        acts = 2.0 * g.B * (g.Hi * g.Wi * g.Ci + g.Ho * g.Wo * g.Co)
+        return acts + (4.0 if wgrad else 2.0) * c.Co * kk * c.Ci
 
     @staticmethod
     def _flops(c: "ConvP", g) -> float:
@@ -396,14 +405,14 @@ class Engine:
             else:
                 f = self._bn_fuse(g, False, sums, seg=seg)
                 run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
-            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run)
+            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run, self._bytes(c, g))
         else:
             if sums is None:
                 run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
             else:
                 f = self._bn_fuse(g, False, sums, seg=seg)
                 run = lambda: check(self._lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_conv_fwd_bn")  # noqa: E731
-            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run)
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run, self._bytes(c, g))
         return out, g
 
     @staticmethod
@@ -676,7 +685,7 @@ class Engine:
             out = torch.empty(B, g_.Ho, g_.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
             run = lambda: check(self._lib.lp_conv_fwd_act(_p(xin), _p(wf[c.w_off:]), C.byref(g_), _p(bf[b.b_off:]), _p(residual), int(relu),  # noqa: E731
                                                           _p(out), st), "lp_conv_fwd_act")
-            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},infer>", self._flops(c, g_), run)
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},infer>", self._flops(c, g_), run, self._bytes(c, g_))
             return out, g_
 
         for blk in plan.blocks:
@@ -727,7 +736,8 @@ class Engine:
         ``bn`` = (BNP, z, mean, invstd, sums): dx is the gradient of relu(BN(z) [+ residual]); the launch also leaves BatchNorm's
         two backward reductions in ``sums``.  Without ``relu_mask`` the ReLU mask is recomputed from z (no residual branch)."""
         g = self._geom(c, B, Hi, Wi)
-        self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g), lambda: self._wgrad(x, dz, g, self.G[c.w_off:]))
+        self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g), lambda: self._wgrad(x, dz, g, self.G[c.w_off:]),
+                    self._bytes(c, g, wgrad=True))
         if not need_dx:
             return None
         st = ops._stream()
@@ -747,7 +757,7 @@ class Engine:
         else:
             run = lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),  # noqa: E731
                                                         _p(dx), None, c.Ci, 0, skip, st), "lp_conv_dgrad")
-        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run)
+        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g))
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -844,5 +854,5 @@ class Engine:
                                                  _p(dz[i0:i0 + n]), ops._stream()), "lp_bn_pool_bwd_apply")
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
-                    lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True))
+                    lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True), self._bytes(plan.stem, g, wgrad=True))
         self._join_side_stream()

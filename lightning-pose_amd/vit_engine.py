@@ -245,18 +245,23 @@ class ViTEngine(Engine):
 
     def _linear(self, x: torch.Tensor, l: Lin, M: int) -> torch.Tensor:
         out = torch.empty(M, l.N, device=self.device, dtype=torch.bfloat16)
-        self._gemm(_p(x), l.K, _p(self.Wb[l.w_off:]), l.K, M, l.N, l.K, out, l.N, bias=self.P[l.b_off:l.b_off + l.N])
+        self._timed("lp_gemm_nt<linear fwd>", 2.0 * M * l.N * l.K, lambda: self._gemm(
+            _p(x), l.K, _p(self.Wb[l.w_off:]), l.K, M, l.N, l.K, out, l.N, bias=self.P[l.b_off:l.b_off + l.N]),
+            nbytes=2.0 * (M * l.K + M * l.N + l.N * l.K))
         return out
 
     def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True):
         """bias / weight gradients into G; returns dX = dY W (bf16) if wanted"""
         rows, cols = self._wg_shape
         g = _lib.ConvGeom(1, rows, cols, l.K, rows, cols, l.N, 1, 1, 1, 0) if rows * cols == M else _lib.ConvGeom(1, 1, M, l.K, 1, M, l.N, 1, 1, 1, 0)
-        self._wgrad(x, dy, g, self.G[l.w_off:], dbias=self.G[l.b_off:])  # bias gradient = column sums of dy, same pass
+        # bias gradient = column sums of dy, same pass
+        self._timed("conv_wgrad_kernel<linear wgrad+bias>", 2.0 * M * l.N * l.K,
+                    lambda: self._wgrad(x, dy, g, self.G[l.w_off:], dbias=self.G[l.b_off:]), nbytes=2.0 * (M * l.K + M * l.N) + 4.0 * l.N * l.K)
         if not need_dx:
             return None
         dx = torch.empty(M, l.K, device=self.device, dtype=torch.bfloat16)
-        self._gemm(_p(dy), l.N, _p(self.Wd[l.wd_off:]), l.N, M, l.K, l.N, dx, l.K)
+        self._timed("lp_gemm_nt<linear dgrad>", 2.0 * M * l.N * l.K, lambda: self._gemm(_p(dy), l.N, _p(self.Wd[l.wd_off:]), l.N, M, l.K, l.N, dx, l.K),
+                    nbytes=2.0 * (M * l.K + M * l.N + l.N * l.K))
         return dx
 
     def _ln(self, x, delta, l: LNP, M: int, drop_T: int = 0):
@@ -357,7 +362,10 @@ class ViTEngine(Engine):
             # the scores themselves never reach memory
             S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16) if keep else None
             attn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-            check(self._lib.lp_attn_fwd(_p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(S), Tp, _p(attn), D, ops._stream()), "lp_attn_fwd")
+            # scores + probabilities x values: 2 products of B * nh * Tn * Tn * (D / nh) MACs; the training pass computes the scores twice
+            self._timed("attn_fwd_kernel", 4.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_fwd(
+                _p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(S), Tp, _p(attn), D, ops._stream()), "lp_attn_fwd"),
+                nbytes=2.0 * (3 * B * Tn * D + B * Tn * D) + (2.0 * B * nh * Tn * Tp if S is not None else 0.0))
             proj = self._linear(attn, L["proj"], M)
             x_in = x
             y2, m2, r2, x = self._ln(x, proj, L["ln2"], M)
@@ -417,8 +425,10 @@ class ViTEngine(Engine):
             drow = torch.empty(M, nh, device=dev, dtype=torch.float32)
             check(self._lib.lp_attn_rowdot(_p(d_attn), _p(t("attn")), M, nh, D, _p(drow), ops._stream()), "lp_attn_rowdot")
             dS = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
-            check(self._lib.lp_attn_bwd_kv(_p(qkv), qs, 2 * D, _p(d_attn), D, _p(Pm), Tp, _p(drow), B, nh, Tn, scale, _p(dS), _p(dqkv), qs, D, 2 * D,
-                                           ops._stream()), "lp_attn_bwd_kv")
+            # dP = dO V^T, dV = P^T dO, dK = dS^T Q: 3 products of B * Tn * Tn * D MACs
+            self._timed("attn_bwd_kv_kernel", 6.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_bwd_kv(
+                _p(qkv), qs, 2 * D, _p(d_attn), D, _p(Pm), Tp, _p(drow), B, nh, Tn, scale, _p(dS), _p(dqkv), qs, D, 2 * D, ops._stream()),
+                "lp_attn_bwd_kv"), nbytes=2.0 * (2 * B * nh * Tn * Tp + 6 * B * Tn * D))
             # dQ = dS K
             tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
             self._transpose(qkv[:, D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)

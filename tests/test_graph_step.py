@@ -74,4 +74,4 @@ def test_graphed_steps_reproduce_eager_steps(monkeypatch):
     np.testing.assert_allclose(h1, h0, rtol=2e-2)
     np.testing.assert_allclose(l1, l0, rtol=0.2)
     a, b = m0.net.P[m0.net.plan.n_backbone:], m1.net.P[m1.net.plan.n_backbone:]
-    assert float((a - b).abs().max()) <= 6.5 * 1e-4   # Adam moves a weight by <= lr per step
+    assert float((a - b).abs().max()) <= 12.5 * 1e-4   # Adam moves a weight by <= lr per step: two runs are at most 2 x 6 x lr apart

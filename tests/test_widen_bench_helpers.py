@@ -48,7 +48,8 @@ def test_bench_predict_line(stack_backend, capsys):
 def test_hbm_rooflines_runs_the_heatmap_kernels(stack_backend):
     out = bench.hbm_rooflines(stack_backend, 64, 3, 4, reps=1)
     assert out["bound"] == "hbm" and out["algorithmic_bytes_per_frame"] == 3 * 16 * 16 * 4
-    assert set(out["kernels"]) == {"decode_fwd", "decode_fwd_bwd", "heatmap_gen", "heatmap_mse_fwd_bwd"}
+    assert set(out["kernels"]) == {"decode_fwd", "decode_bwd", "heatmap_gen", "heatmap_mse_fwd", "heatmap_mse_bwd"}
+    assert "valu_frac" in out["kernels"]["decode_fwd"] and "C-ABI" in out["timed"]
     for v in out["kernels"].values():
         assert v["us"] > 0 and v["achieved"] >= 0  # (the emulator moves kilobytes per millisecond)
 
