@@ -54,6 +54,8 @@ class DataParallel:
         engine.process_group = process_group
         engine.sync_bn = bool(sync_bn and self.world > 1)
         self._works: list = []
+        self._next_hi: int | None = None   # overlapped mode: upper end of the next bucket to send (None: no step in flight)
+        self.buckets_during_backward = 0
 
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world == 1:
@@ -64,16 +66,42 @@ class DataParallel:
             dist.broadcast(e.R, src=src, group=self.pg)
         e.refresh_weight_copies()
 
-    def all_reduce_gradients(self, async_op: bool = True) -> None:
-        """SUM all-reduce of the flat gradient buffer in large buckets; pair with optimizer.grad_scale = 1/world."""
+    def begin_step(self) -> None:
+        """Arm the overlap of the gradient exchange with backward: the engine reports how far its (single) backward pass has come
+        (Engine.grad_progress) and every bucket that is final goes out at once - the tail bucket (head, layer4, part of layer3: 64 of the
+        94 MB) is on the wire while layers 3..1 and the stem, i.e. most of backward's time, are still being computed."""
         if self.world == 1:
             return
-        g = self.engine.G
+        self._next_hi = self.engine.G.numel()
+        self.buckets_during_backward = 0
+        self.engine.grad_progress = self._on_progress
+
+    def _send(self, lo: int, hi: int, async_op: bool = True) -> None:
+        join = getattr(self.engine, "_join_side_stream", None)
+        if join is not None:
+            join()  # the weight gradients of this range run on the engine's side stream: the collective is ordered after them
+        self._works.append(dist.all_reduce(self.engine.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
+
+    def _on_progress(self, lo_done: int) -> None:
+        while self._next_hi is not None and self._next_hi > 0:
+            lo = max(0, self._next_hi - self.bucket_elems)
+            if lo < lo_done:
+                return
+            self._send(lo, self._next_hi)
+            self.buckets_during_backward += 1
+            self._next_hi = lo
+
+    def all_reduce_gradients(self, async_op: bool = True) -> None:
+        """SUM all-reduce of the flat gradient buffer in large buckets (whatever an armed backward pass has not sent yet); pair with
+        optimizer.grad_scale = 1/world."""
+        if self.world == 1:
+            return
         # backward produces the tail of the buffer (head, layer4) first: reduce from the end
-        hi = g.numel()
+        hi = self._next_hi if self._next_hi is not None else self.engine.G.numel()
+        self._next_hi = None
         while hi > 0:
             lo = max(0, hi - self.bucket_elems)
-            self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
+            self._send(lo, hi, async_op)
             hi = lo
 
     def wait(self) -> None:

@@ -208,6 +208,11 @@ class Engine:
             self.R[b.r_off + b.C:b.r_off + 2 * b.C] = 1.0
         self.nbt = torch.zeros((), dtype=torch.long)  # shared num_batches_tracked of every BatchNorm
         self.sync_bn = False          # set by the DDP wrapper when world_size > 1 (reference: train.py:427)
+        # gradient all-reduce overlapped with backward (DataParallel): called with the lowest flat offset whose gradients are FINAL, as the
+        # backward pass moves from the head towards the stem; only when the step has ONE backward pass (single_backward: the joint pass
+        # of a semi-supervised step, or a supervised step), since two passes accumulate into the same buffer
+        self.grad_progress = None
+        self.single_backward = False
         self._bwd_training = True     # mode of the forward pass whose backward is running (eval: no batch-statistics terms)
         self.sync_bn_messages = 0     # SyncBatchNorm all-reduces issued so far (bench.py reports them per step)
         self.process_group = None
@@ -768,6 +773,9 @@ class Engine:
         B, H, W = tp.meta["B"], tp.meta["H"], tp.meta["W"]
         self._bwd_training = bool(tp.meta.get("training", True))
         d = self._head_backward(T, B, g_heat)
+        progress = self.grad_progress if (self.grad_progress is not None and self.single_backward) else None
+        if progress is not None:
+            progress(plan.n_backbone)  # the head's gradients (the tail of the flat buffer) are complete
 
         seg = tp.meta.get("seg", 0)
         nseg = 2 if seg else 1
@@ -825,6 +833,8 @@ class Engine:
                                    relu_bits=T.get(f"{pk}.out_bits"), seg=seg)
             else:
                 d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dres, relu_mask=mask_x)
+            if progress is not None:
+                progress(blk.conv1.w_off)  # parameters are laid out in forward order: everything from this block on is final
 
         if trace is not None:
             trace["stem.dpool"] = d

@@ -153,6 +153,8 @@ class BaseSupervisedTracker(LightningModule):
             self.log("total_unsupervised_importance", anneal_weight, prog_bar=True)
         else:
             anneal_weight = None
+        if getattr(self, "net", None) is not None:
+            self.net.single_backward = True  # one pass, one backward: gradient buckets may leave while it runs
         return {"loss": self.evaluate_labeled(batch_dict, "train", anneal_weight=anneal_weight)}
 
     def validation_step(self, batch_dict: dict, batch_idx: int) -> None:
@@ -189,8 +191,9 @@ class SemiSupervisedTrackerMixin:
         # streams: +5.5 % on the device against +4.8 % / +14 % at 384 / 256 px for this one, which also survives SyncBatchNorm.)
         joint = getattr(self, "joint_forward", None)
         try:
-            if joint is not None:
-                joint(batch_dict["labeled"]["images"], batch_dict["unlabeled"]["frames"])
+            joined = joint is not None and bool(joint(batch_dict["labeled"]["images"], batch_dict["unlabeled"]["frames"]))
+            if getattr(self, "net", None) is not None:
+                self.net.single_backward = joined  # two separate passes accumulate into G twice: nothing may be sent before both ran
             loss_super = self.evaluate_labeled(batch_dict=batch_dict["labeled"], stage="train", anneal_weight=unsup_importance)
             loss_unsuper = self.evaluate_unlabeled(batch_dict=batch_dict["unlabeled"], stage="train", anneal_weight=unsup_importance)
         finally:

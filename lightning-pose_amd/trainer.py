@@ -92,6 +92,8 @@ class Trainer:
         if batch_idx % acc == 0:
             opt.zero_grad()
         loss = model.training_step(batch, batch_idx)["loss"]
+        if self.dp is not None and acc == 1:
+            self.dp.begin_step()  # buckets leave as soon as backward has finished their layers (single-backward steps only)
         (loss / acc if acc > 1 else loss).backward()
         if (batch_idx + 1) % acc == 0 or last_in_epoch:
             if self.dp is not None:

@@ -142,12 +142,33 @@ def _engine_worker(rank, world, port, q):
     _, tape = eng.forward(images[:2], True)
     n_fwd, calls["n"] = calls["n"], 0
     eng.zero_grad()
+    # the gradient exchange is armed before backward (DataParallel.begin_step): with 8 MB buckets the tail buckets (head, layer4) must
+    # leave WHILE backward is still running, and the result must not change
+    dp.bucket_elems = (8 << 20) // 4
+    eng.single_backward = True
+    dp.begin_step()
     eng.backward(tape, g_heat[:2])
-    n_bwd = calls["n"]
+    early = dp.buckets_during_backward
+    n_bwd = calls["n"] - early
     dp.all_reduce_gradients()
     dp.wait()
     if (n_fwd, n_bwd) != (n_bn, n_bn):
         bad.append(f"C:{n_fwd} forward / {n_bwd} backward all-reduces for {n_bn} BatchNorm layers")
+    if not (3 <= early < -(-eng.G.numel() * 4 // (8 << 20))):
+        bad.append(f"overlap: {early} gradient buckets left during backward")
+    # ---- (D) joint pass (two BatchNorm segments): ONE message carries both segments' sums; the moments are the global per-segment ones
+    calls["n"] = 0
+    b0 = eng.plan.blocks[0].bn1
+    zz = torch.randn(4, 6, 6, b0.C, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16)   # same on both ranks
+    sums = torch.zeros(2 * 2 * b0.C)
+    mu, iv = eng._bn_moments(b0, zz, 4 * 36, True, sums, have_sums=False, seg=1)
+    if calls["n"] != 1:
+        bad.append(f"D:{calls['n']} all-reduces for one two-segment BatchNorm layer")
+    zf = zz.float().reshape(4, 36, b0.C)
+    for si, sl in enumerate((slice(0, 1), slice(1, 4))):
+        want = zf[sl].reshape(-1, b0.C).mean(0)
+        if not torch.allclose(mu[si * b0.C:(si + 1) * b0.C], want, atol=1e-5, rtol=1e-4):
+            bad.append(f"D:segment {si} mean")
     if rank == 0:
         solo, _ = make(False)
         _, t_solo = solo.forward(images[:2], True)
