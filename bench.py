@@ -403,7 +403,8 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     is_vit = args.backbone != "resnet50"
     arch = {"resnet50": "ResNet-50", "vits_dino": "ViT-S/16", "vitb_dino": "ViT-B/16"}[args.backbone]
     out = {
-        "metric": f"training frames/sec (whole node), {arch} {args.size}x{args.size} {args.keypoints}-kp semi-sup",
+        "metric": (f"training view-images/sec (whole node), multiview {arch} {args.views} views x {args.size}x{args.size} {args.keypoints}-kp semi-sup"
+                   if args.views > 1 else f"training frames/sec (whole node), {arch} {args.size}x{args.size} {args.keypoints}-kp semi-sup"),
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 3), "host_enqueue_ms_per_step": round(1000 * host_enqueue / args.steps, 3),
         "host_enqueue_idle_queue_ms": round(1000 * host_idle_queue, 3),

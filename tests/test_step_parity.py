@@ -23,7 +23,7 @@ from tests.golden.step_inputs import PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS
 TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, argmax=1.0, hm_loss_rel=1e-3, px_abs=1e-4, stem_cos=0.9995,
                     head_cos=0.99999, norm_rel=5e-3, norm_worst=1e-2),
        "bf16-mixed": dict(rel=1e-2, kp_max=1.5, kp_mean=0.3, conf=0.1, peak=0.1, argmax=0.8, hm_loss_rel=0.25, px_abs=0.15, stem_cos=0.9,
-                          head_cos=0.97, norm_rel=0.12, norm_worst=0.25)}
+                          head_cos=0.97, norm_rel=0.25, norm_worst=0.3)}
 REPORT: list = []
 PEAK_MIN = 0.03   # maps the reference itself predicts with a peak below this are not fitted (the unlabeled NaN keypoint, a few of c2's
                   # 17 x 12 maps): nearly flat, so soft-argmax(T = 1000) is ill-conditioned there; they are compared in fp32 only
