@@ -57,6 +57,20 @@ class DataParallel:
         self._next_hi: int | None = None   # overlapped mode: upper end of the next bucket to send (None: no step in flight)
         self.buckets_during_backward = 0
 
+    def check_equal_batches(self, *sizes: int) -> None:
+        """SyncBatchNorm divides the all-reduced sums by (local rows x world size) and the gradient mean by world size: both assume every
+        rank holds equally many frames per step - what DistributedSampler's padding and the per-rank DALI windows give the reference.  One
+        MIN / MAX all-reduce at the first step turns a silently wrong normalisation into an error."""
+        if self.world == 1:
+            return
+        t = torch.tensor([float(v) for v in sizes] + [-float(v) for v in sizes], device=self.engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+        n = len(sizes)
+        lo, hi = t[:n].tolist(), (-t[n:]).tolist()
+        if lo != hi:
+            raise ValueError(f"ranks hold different batch sizes (min {lo}, max {hi}): SyncBatchNorm and the gradient mean need equal "
+                             "per-rank batches (pad the last batch like DistributedSampler does)")
+
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.world == 1:
             return

@@ -89,6 +89,11 @@ class Trainer:
         acc = self.accumulate_grad_batches
         if count:
             self._hook("on_train_batch_start", model, batch, batch_idx)
+        if self.dp is not None and not getattr(self, "_batches_checked", False):
+            self._batches_checked = True
+            lab = batch["labeled"] if "labeled" in batch else batch
+            sizes = [int(lab["images"].shape[0])] + ([int(batch["unlabeled"]["frames"].shape[0])] if "unlabeled" in batch else [])
+            self.dp.check_equal_batches(*sizes)
         if batch_idx % acc == 0:
             opt.zero_grad()
         loss = model.training_step(batch, batch_idx)["loss"]

@@ -47,11 +47,17 @@ def _worker(rank, world, port, q):
     dp.all_reduce_gradients()
     dp.wait()
     means = dp.mean_scalars({"b": torch.tensor(float(rank)), "a": torch.tensor(10.0 * rank)})
+    dp.check_equal_batches(4, 8)
+    try:
+        dp.check_equal_batches(4, 8 + rank)
+        unequal_caught = False
+    except ValueError:
+        unequal_caught = True
     ok = (
         bool((eng.P == 1.0).all()) and eng.refreshed == 1 and eng.sync_bn is True
         and torch.allclose(eng.G, torch.arange(n, dtype=torch.float32) * 3.0)
         and float(means["a"]) == pytest.approx(5.0) and float(means["b"]) == pytest.approx(0.5)
-        and labeled_batch_per_gpu(513, 8) == 65 and sequence_length_per_gpu(128, 8) == 16
+        and labeled_batch_per_gpu(513, 8) == 65 and sequence_length_per_gpu(128, 8) == 16 and unequal_caught
     )
     q.put((rank, ok))
     dist.destroy_process_group()
