@@ -92,6 +92,9 @@ PROTOTYPES = {
     "lp_attn_dscores": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_float, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
+    "lp_bn_affine": (_I, [_P, _P, _I, _I, _P, _P]),
+    "lp_conv_fwd_bn_norm": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P, _P, _P, _P]),
+    "lp_conv_wgrad_norm": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
     "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
     "lp_bn_fold": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),

@@ -71,6 +71,11 @@ struct ConvEpilogue {
     // straddles the boundary (host-checked: seg_images * rows per image is a multiple of the 128-row tile).  Segment s uses
     // bn_mean / bn_invstd + s * N and adds into stats_sums + s * 2 * N; 0 = one segment
     int seg_images;
+    // kModeFwdNorm: per-channel terms of the BatchNorm in front of this convolution, (segments, Ci) each: mean, scale = invstd * gamma,
+    // shift = beta (the A rows of a tile belong to one segment, like its output rows)
+    const float* norm_mean;
+    const float* norm_scale;
+    const float* norm_shift;
 };
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
@@ -86,7 +91,10 @@ struct GemmExt {
 
 // kModeAttn = kModeFwd with the soft-max backward in the store pass; kModeInfer = kModeFwd whose store pass adds a residual and
 // applies the ReLU (inference with folded BatchNorm: its own instantiation, so the training kernels' code is untouched)
-enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3, kModeInfer = 4 };
+// kModeFwdNorm = kModeFwd of a 1x1 convolution whose INPUT is a pre-normalisation tensor z: the A operand becomes
+// bf16(relu((z - mean) * scale + shift)) while it is staged (exactly what lp_bn_apply would have stored), so the activation between a
+// BatchNorm and the 1x1 convolution that consumes it is never written or read
+enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3, kModeInfer = 4, kModeFwdNorm = 5 };
 
 // One launch covers a sub-lattice of output pixels and of filter taps.  Ordinary launches use the full lattices; the data
 // gradient of a stride-2 convolution is split into its 4 output-parity classes, each of which only sees the taps of matching
@@ -234,6 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     const bool stream_a = tiles_n == 1 && lat.nr * lat.ns == 1;
 
     u16x8 ra[4], rb[BN / 32];
+    // kModeFwdNorm: this lane's 8 channels of (mean, scale, shift) for the K step held in ra
+    f32x4 nmu[2], nsc[2], nbe[2];
+    int norm_seg = 0;              // ... taken from this segment's rows of the tables (element offset)
     int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
     unsigned voff[4];              // byte offsets of the 4 A rows for the current tap (~0 where the tap is padding)
     unsigned wtap = 0;             // byte offset of the current tap inside a weight row
@@ -298,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             wrow[i] = (unsigned)(n * gx.ldw + kchunk * 8) * 2u + zw;  // row stride = the FULL filter
         }
         tir = tis = tc = 0;
+        if (MODE == kModeFwdNorm) norm_seg = (ep.seg_images > 0 && m0n >= ep.seg_images * rows_y * rows_x) ? ck : 0;
     };
 
     // `with_b = false` (the data-gradient's prefetch across its register-hungry store pass) leaves the weight rows for
@@ -332,6 +344,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 }
             }
             const unsigned tcb = (unsigned)tc * 2u;
+            if (MODE == kModeFwdNorm) {  // (1x1 only: the K offset IS the channel)
+                const int c0 = norm_seg + tc + kchunk * 8;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    nmu[h2] = *reinterpret_cast<const f32x4*>(ep.norm_mean + c0 + 4 * h2);
+                    nsc[h2] = *reinterpret_cast<const f32x4*>(ep.norm_scale + c0 + 4 * h2);
+                    nbe[h2] = *reinterpret_cast<const f32x4*>(ep.norm_shift + c0 + 4 * h2);
+                }
+            }
             if (stream_a) {  // single column of tiles and a single tap: every activation byte is fetched exactly once
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ra[i] = buf_load16_nt(rsrc_x, voff[i], tcb);
@@ -360,6 +381,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], b_deferred);
     };
     auto store_step = [&](int buf) {
+        if (MODE == kModeFwdNorm) {  // normalise + ReLU on the way into LDS, rounded to bf16 exactly as lp_bn_apply stores it
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    v[q] = fmaxf(fmaf(bf16_to_f32(ra[i][q]) - nmu[q >> 2][q & 3], nsc[q >> 2][q & 3], nbe[q >> 2][q & 3]), 0.f);
+                ra[i] = pack_bf16x8(v);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ra[i];
 #pragma unroll
@@ -640,11 +671,20 @@ struct TnExt {
 // wgrad_reduce_kernel then sums the slices in a fixed order and adds the result into dW - deterministic, and ~20x
 // cheaper than fp32 atomics (measured: 17 M atomics per launch cost 450 us, the same bytes as plain stores ~20 us).
 // ------------------------------------------------------------------------------------------------------------
-template <int BN, bool STEM, bool CS = false>
+// NORM (1x1 convolutions only): x is a PRE-normalisation tensor; the gathered operand becomes bf16(relu((x - mean) * scale + shift)) on
+// its way into LDS - the activation lp_bn_apply would have stored, which the forward pass never wrote (kModeFwdNorm)
+struct WgradNorm {
+    const float* mean;   // (segments, Ci)
+    const float* scale;  // invstd * gamma
+    const float* shift;  // beta
+    int seg_row;         // pixels [0, seg_row) are BatchNorm segment 0, the rest segment 1 (a multiple of the 64-pixel K step); 0 = one
+};
+
+template <int BN, bool STEM, bool CS = false, bool NORM = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                          unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles,
                                                          int tiles_n, int m_per_split, FastDiv div_hw, FastDiv div_wo,
-                                                         float* __restrict__ ws, TnExt tn) {
+                                                         float* __restrict__ ws, TnExt tn, WgradNorm nrm = WgradNorm{}) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
     // Operand tiles stay in their memory orientation, [pixel][channel] (K = pixel is the ROW index): the 16-B chunks go to LDS
@@ -807,7 +847,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         if (fast && (direct || mk + kBK <= m_end)) load_fast(mk);
         else load_generic(mk);
     };
-    auto store_step = [&](int buf) {
+    float nmu[8], nsc[8], nbe[8];
+    int norm_seg = -1;
+    auto store_step = [&](int buf, int mk) {
+        if (NORM) {
+            const int sg = (nrm.seg_row > 0 && mk >= nrm.seg_row) ? 1 : 0;
+            if (sg != norm_seg) {  // this lane's 8 channels of the segment's terms (a slice crosses the boundary at most once)
+                norm_seg = sg;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = sg * g.Ci + tcn + q;
+                    nmu[q] = jv ? nrm.mean[c] : 0.f;
+                    nsc[q] = jv ? nrm.scale[c] : 0.f;
+                    nbe[q] = jv ? nrm.shift[c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(fmaf(bf16_to_f32(ra[i][q]) - nmu[q], nsc[q], nbe[q]), 0.f);
+                ra[i] = pack_bf16x8(v);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(pgA * 4 + i) * LDA + jc * 8]) = ra[i];
 #pragma unroll
@@ -857,13 +919,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     const int KT = (m_end - m_begin + kBK - 1) / kBK;
     if (KT > 0) {
         load_step(m_begin);
-        store_step(0);
+        store_step(0, m_begin);
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < KT) load_step(m_begin + (kt + 1) * kBK);
             mma_step(cur);
-            if (kt + 1 < KT) store_step(cur ^ 1);
+            if (kt + 1 < KT) store_step(cur ^ 1, m_begin + (kt + 1) * kBK);
             __syncthreads();
         }
     }
@@ -1138,8 +1200,12 @@ static ConvGeom to_geom(const lp_conv_geom* c) {
 }  // namespace lp
 
 // out[b][ho][wo][co] = sum x[b][ho*st-pad+r][wo*st-pad+s][ci] * w[co][r][s][ci]  (+bias) ; x, w bf16
+struct FwdNorm {
+    const float *mean, *scale, *shift;
+};
+
 static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
-                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream) {
+                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream, const FwdNorm* norm = nullptr) {
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1162,7 +1228,13 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    if (norm) {  // the A operand is normalised on load: 1x1 / stride 1 only (the K offset is the channel, no padding taps to keep at zero)
+        LP_REQUIRE(norm->mean && norm->scale && norm->shift);
+        if (g.R != 1 || g.S != 1 || g.stride != 1 || g.pad != 0) return LP_ERR_UNSUPPORTED;
+        ep.norm_mean = norm->mean, ep.norm_scale = norm->scale, ep.norm_shift = norm->shift;
+        if (N > 64) launch_igemm<128, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
+        else launch_igemm<64, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
+    } else if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     if (bn && ep.stats_sums == nullptr) {
         const StatRanges rg{1, {0, 0, 0, 0}, {split == M ? tm : (int)(split / kBM), 0, 0, 0}, {tm, 0, 0, 0}};
@@ -1208,6 +1280,17 @@ extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* 
                               lp_stream_t stream) {
     LP_REQUIRE(bn && geom && out_bf16);
     return conv_fwd_impl(x, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream);
+}
+
+// the same for a 1x1 convolution fed with the PRE-normalisation tensor z of the BatchNorm in front of it: the A operand is
+// bf16(relu((z - mean) * scale + shift)) computed while it is staged (what lp_bn_apply would have stored, bit for bit), so that
+// activation is never written or read.  mean / scale (= invstd * gamma, lp_bn_affine) / shift (= beta) are (segments, Ci), segments as
+// in bn->seg_images (the input rows of a 1x1 / stride-1 convolution are its output rows)
+extern "C" int lp_conv_fwd_bn_norm(const void* z, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+                                   const float* norm_mean, const float* norm_scale, const float* norm_shift, lp_stream_t stream) {
+    LP_REQUIRE(bn && geom && out_bf16);
+    const FwdNorm norm{norm_mean, norm_scale, norm_shift};
+    return conv_fwd_impl(z, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream, &norm);
 }
 
 // C[z][m][n] = sum_k A[z][m][k] * B[z][n][k] (+ bias[n]): the forward kernel as a plain (batched, strided) NT GEMM
@@ -1385,7 +1468,7 @@ extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int sp
 
 // dw[co][r][s][ci] (fp32, accumulated into) += sum_m x_gather[m][(r,s,ci)] * dy[m][co]
 static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, float* dbias, int split_hint, void* workspace,
-                           size_t workspace_bytes, lp_stream_t stream) {
+                           size_t workspace_bytes, lp_stream_t stream, const lp::WgradNorm* norm = nullptr) {
     using namespace lp;
     LP_REQUIRE(x && dy && geom_ok(geom) && dw && workspace);
     ConvGeom g = to_geom(geom);
@@ -1407,6 +1490,20 @@ static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* ge
 #define LP_WGRAD_LAUNCH(BN_, CS_)                                                                                                \
     hipLaunchKernelGGL((conv_wgrad_kernel<BN_, false, CS_>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, \
                        p.per, dhw, dwo, ws, ext)
+    if (norm) {  // (1x1 / stride 1: the fast, unmasked operand path; the row index of the result IS the channel)
+        LP_REQUIRE(norm->mean && norm->scale && norm->shift && !dbias);
+        if (g.R != 1 || g.S != 1 || g.stride != 1 || g.pad != 0 || norm->seg_row % kBK != 0) return LP_ERR_UNSUPPORTED;
+        if (p.wide) {
+            hipLaunchKernelGGL((conv_wgrad_kernel<128, false, false, true>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn,
+                               p.per, dhw, dwo, ws, ext, *norm);
+            launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
+        } else {
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, false, false, true>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn,
+                               p.per, dhw, dwo, ws, ext, *norm);
+            launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
+        }
+        return launch_status();
+    }
     if (p.wide) {
         if (dbias) LP_WGRAD_LAUNCH(128, true);
         else LP_WGRAD_LAUNCH(128, false);
@@ -1423,6 +1520,16 @@ static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* ge
 extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
                              size_t workspace_bytes, lp_stream_t stream) {
     return conv_wgrad_impl(x, dy, geom, dw, nullptr, split_hint, workspace, workspace_bytes, stream);
+}
+
+// weight gradient of a 1x1 convolution whose input activation was never stored (lp_conv_fwd_bn_norm): z is the pre-normalisation
+// tensor, the gathered operand is normalised on load with the same (segments, Ci) terms; seg_images as in lp_bn_fuse
+extern "C" int lp_conv_wgrad_norm(const void* z, const void* dy, const lp_conv_geom* geom, float* dw, const float* norm_mean,
+                                  const float* norm_scale, const float* norm_shift, int seg_images, int split_hint, void* workspace,
+                                  size_t workspace_bytes, lp_stream_t stream) {
+    LP_REQUIRE(geom && seg_images >= 0 && seg_images < geom->B);
+    const lp::WgradNorm norm{norm_mean, norm_scale, norm_shift, seg_images * geom->Ho * geom->Wo};
+    return conv_wgrad_impl(z, dy, geom, dw, nullptr, split_hint, workspace, workspace_bytes, stream, &norm);
 }
 
 // same, and dbias[co] += sum_m dy[m][co] out of the same pass over dy (Linear / ConvTranspose2d layers)
