@@ -15,7 +15,7 @@ from tests.conftest import Golden  # noqa: E402
 from tests import test_step_parity as P  # noqa: E402
 
 dev = torch.device("cuda:0")
-names = ["s64", "c1", "c2", "c5"]
+names = ["s64", "c1", "c2", "c5", "c4"]
 if len(sys.argv) > 1 and sys.argv[1] == "cpu-emu":   # build container: the emulated kernels, the small case only
     from lightning_pose_amd import _lib, ops
     from tests.hipemu import emu
@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "cpu-emu":   # build container: the emul
 for name in names:
     with np.load(os.path.join(ROOT, "tests", "golden", f"step_{name}.npz"), allow_pickle=False) as z:
         g = Golden({k: z[k] for k in z.files})
-    for precision in ("fp32", "bf16-mixed"):
+    for precision in (("fp32", "bf16-mixed") if name != "c4" else ("bf16-mixed",)):
         model, out, seen, inp = P._run(name, dev, precision, g)
         rec = {"config": name, "precision": precision}
         want = dict(zip([str(n) for n in g["log_names"]], g["log_values"]))

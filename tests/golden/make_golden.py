@@ -19,6 +19,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+try:  # before any stub is installed: transformers probes torchvision with importlib and chokes on the oracle's stand-in module
+    import transformers  # noqa: E402
+    _VIT_CLASSES = (transformers.ViTModel, transformers.ViTConfig)
+except Exception:  # noqa: BLE001
+    transformers = None
+
 from oracle import ref_loader as R  # noqa: E402
 
 
@@ -510,7 +516,7 @@ def gen_step_parity(names=None):
     and parameter gradients (head + stem in full, a norm per convolution / BatchNorm)."""
     from oracle import restated as O
     from tests.golden.step_inputs import (HEAD_TRAIN_LR, HEAD_TRAIN_STEPS, PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS, TEMPORAL, TORCH_SEED,
-                                          make_step_inputs)
+                                          make_step_inputs, seeded_backbone_weights)
 
     T = R.load("models.heatmap_tracker")
     Fa = R.load("losses.factory")
@@ -520,6 +526,17 @@ def gen_step_parity(names=None):
         inp = make_step_inputs(name, H.generate_heatmaps)
         cfg, batch = inp["cfg"], inp["batch"]
         K, V, HW = cfg["K"], cfg["V"], cfg["HW"]
+        backbone = cfg.get("backbone", "resnet50")
+        if backbone != "resnet50":
+            # models/backbones/vit.py:26-27 calls ViTModel.from_pretrained("facebook/dino-vits16"): no network here, so the same architecture
+            # is constructed from its config (facebook/dino-vits16: hidden 384, 12 layers, 6 heads, MLP 1536, patch 16, 224-px position
+            # table) and its weights replaced by the seeded draw both sides share (step_inputs.seeded_backbone_weights)
+            def _from_config(model_name, add_pooling_layer=False, **kw):
+                assert model_name == "facebook/dino-vits16", model_name
+                c = transformers.ViTConfig(hidden_size=384, num_hidden_layers=12, num_attention_heads=6, intermediate_size=1536, patch_size=16,
+                                           image_size=224, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+                return transformers.ViTModel(c, add_pooling_layer=add_pooling_layer)
+            transformers.ViTModel.from_pretrained = staticmethod(_from_config)
         sup = Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
         semi = cfg["S"] > 0
         if semi:
@@ -532,7 +549,7 @@ def gen_step_parity(names=None):
             loss.device, loss.loss_name, loss.pca = "cpu", ptype, kpca
             loss.epsilon = kpca.parameters["epsilon"]
             unsup.loss_instance_dict[ptype] = loss
-            model = T.SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+            model = T.SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone=backbone,
                                                    pretrained=False, torch_seed=TORCH_SEED, image_size=HW)
             model.total_unsupervised_importance = torch.tensor(1.0)
         else:
@@ -542,6 +559,13 @@ def gen_step_parity(names=None):
             for n_, p_ in model.named_parameters():
                 if n_.endswith("bn3.weight"):
                     p_.fill_(RESIDUAL_GAIN)
+            if backbone != "resnet50":
+                sd_ = model.state_dict()
+                new = seeded_backbone_weights(sd_)
+                assert new, "no backbone tensors found"
+                sd_.update(new)
+                model.load_state_dict(sd_)
+                arrs_names = np.array(sorted(new))
         fit_loss = _train_head(model, inp, H.generate_heatmaps, HEAD_TRAIN_STEPS, HEAD_TRAIN_LR)
         seen = {}
         for meth in ("get_loss_inputs_labeled", "get_loss_inputs_unlabeled"):
@@ -557,12 +581,15 @@ def gen_step_parity(names=None):
         arrs = {"head/" + n_: p_.detach().clone() for n_, p_ in model.head.named_parameters()}
         # what the bf16-mixed POLICY itself costs on this model: the same weights through oracle.restated.forward_bf16_policy (torch
         # CPU, rounding to bf16 where the product does) -> keypoints / confidences next to the fp32 ones below
-        orc = O.OracleTracker(K, 2, torch_seed=0)
-        orc.load_state_dict({k_: v_ for k_, v_ in model.state_dict().items()}, strict=True)
-        orc.train()
         lab_b = batch["labeled"] if semi else batch
+        if backbone == "resnet50":
+            orc = O.OracleTracker(K, 2, torch_seed=0)
+            orc.load_state_dict({k_: v_ for k_, v_ in model.state_dict().items()}, strict=True)
+            orc.train()
+        else:
+            arrs["backbone_names"] = arrs_names  # the tensors both sides overwrote (name check in the test)
         with torch.no_grad():
-            for tag, bd, key in (("lab", lab_b, "images"),) + ((("unl", batch["unlabeled"], "frames"),) if semi else ()):
+            for tag, bd, key in ((("lab", lab_b, "images"),) + ((("unl", batch["unlabeled"], "frames"),) if semi else ())) if backbone == "resnet50" else ():
                 x_ = bd[key]
                 h_ = O.forward_bf16_policy(orc, x_.reshape(-1, 3, HW, HW))
                 h_ = h_.reshape(x_.shape[0], -1, h_.shape[-2], h_.shape[-1])

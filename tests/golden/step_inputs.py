@@ -17,6 +17,8 @@ STEP_CONFIGS = {
     "c1": dict(HW=256, K=17, Bl=4, S=0, V=1, seed=12, unsup=()),
     "c2": dict(HW=384, K=17, Bl=4, S=8, V=1, seed=13, unsup=("temporal", "pca_singleview")),
     "c5": dict(HW=256, K=4, Bl=2, S=4, V=2, seed=14, unsup=("temporal", "pca_multiview")),
+    # config 4: ViT-S/16 (backbone "vits_dino": HF ViTModel, interpolate_pos_encoding) at 384x384, K=17, 2 labeled + 4 unlabeled frames
+    "c4": dict(HW=384, K=17, Bl=2, S=4, V=1, seed=15, unsup=("temporal", "pca_singleview"), backbone="vits_dino"),
 }
 # The head is TRAINED before the measured step (make_golden.py::_train_head: Adam on the head alone, over the cached features of the
 # step's own frames, targets = Gaussians at the blob centres): a randomly initialised head (xavier gain 0.01) gives numerically flat
@@ -32,6 +34,24 @@ RESIDUAL_GAIN = 0.1
 TORCH_SEED = 7
 TEMPORAL = {"log_weight": 2.0, "epsilon": 0.5, "prob_threshold": 0.0}
 PCA_LOG_WEIGHT = 2.0
+
+
+def seeded_backbone_weights(state_dict: dict, seed: int = 21) -> dict:
+    """ViT configs: the DINO weights cannot be downloaded and 21.7 M parameters are too many to commit, so BOTH sides (the reference's
+    ViTModel in make_golden.py, the product's ViTEngine in the tests) overwrite their backbone with this seeded draw - one generator, tensors
+    visited in sorted-name order, HF's initialisation scale (N(0, 0.02) weights / embeddings, LayerNorm weight 1 + 0.1 N, biases 0.02 N)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(state_dict):
+        v = state_dict[k]
+        if not k.startswith("backbone.") or not torch.is_floating_point(v):
+            continue
+        r = torch.randn(v.shape, generator=g)
+        if "layernorm" in k.lower() or "layer_norm" in k.lower() or ".norm" in k.lower():
+            out[k] = (1.0 + 0.1 * r) if k.endswith("weight") else 0.02 * r
+        else:
+            out[k] = 0.02 * r
+    return out
 
 
 def _render(g, centres, size):

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import restated as O
-from tests.golden.step_inputs import PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS, TEMPORAL, TORCH_SEED, make_step_inputs
+from tests.golden.step_inputs import PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS, TEMPORAL, TORCH_SEED, make_step_inputs, seeded_backbone_weights
 
 # Tolerances.  fp32 validation path: BASELINE.json's 1e-4 (relative; keypoints 3e-3 px absolute = 1e-5 of the frame: soft-argmax multiplies
 # the up-sampled heat-map by T = 1000 before the exponential, so even fp32-vs-fp32 with another summation order moves a keypoint by ~1e-3 px).
@@ -50,8 +50,9 @@ def _build(name, dev, precision):
         else:
             pca["columns_for_singleview_pca"] = inp["cols"]
         unsup = LossFactory({"temporal": dict(TEMPORAL), ptype: pca}, None)
-        model = SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
-                                             pretrained=False, torch_seed=TORCH_SEED, device=dev, precision=precision)
+        model = SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup,
+                                             backbone=cfg.get("backbone", "resnet50"), pretrained=False, torch_seed=TORCH_SEED, device=dev,
+                                             precision=precision)
         model.total_unsupervised_importance = torch.tensor(1.0)
         batch = {"labeled": _to(inp["batch"]["labeled"], dev), "unlabeled": _to(inp["batch"]["unlabeled"], dev)}
     else:
@@ -68,6 +69,10 @@ def _run(name, dev, precision, g):
         sd["head." + k[len("head/"):]] = g.t(k).to(dev)
     for k in [k for k in sd if k.endswith("bn3.weight")]:      # damped residual branches (see step_inputs.RESIDUAL_GAIN)
         sd[k] = torch.full_like(sd[k], RESIDUAL_GAIN)
+    if "backbone_names" in g:                                  # ViT: the seeded backbone both sides draw (no DINO weights, none committed)
+        new = seeded_backbone_weights({k: v.cpu() for k, v in sd.items()})
+        assert sorted(new) == [str(n) for n in g["backbone_names"]], "backbone tensor names differ from the reference's ViTModel"
+        sd.update({k: v.to(dev) for k, v in new.items()})
     model.load_state_dict(sd)
     seen = {}
     for meth in ("get_loss_inputs_labeled", "get_loss_inputs_unlabeled"):
@@ -171,3 +176,10 @@ def test_step_parity_s64(stack_backend, golden, precision):
 @pytest.mark.parametrize("name", ["c1", "c2", "c5"])
 def test_step_parity_baseline_configs(golden, name, precision):
     _check(name, torch.device("cuda:0"), precision, golden(f"step_{name}"))
+
+
+@pytest.mark.gpu
+def test_step_parity_c4_vit(golden):
+    """config 4: ViT-S/16 (the reference's VisionEncoder over HuggingFace ViTModel, verbatim) - bf16-mixed only (the fp32 validation path
+    covers the ResNet-50 trunk); LayerNorm networks are not chaotic, so no damping is involved"""
+    _check("c4", torch.device("cuda:0"), "bf16-mixed", golden("step_c4"))
