@@ -22,6 +22,8 @@
 // G = T*p*(gx*(x-ex) + gy*(y-ey)) on the fly, scatters Uy^T G into a [h][64] LDS strip and applies Ux^T from there.
 //
 // This kernel is fp32-VALU bound by construction (about 350 FLOP per algorithmic byte): see DESIGN.md.
+#include <stdlib.h>
+
 #include "lp_common.h"
 
 namespace lp {
@@ -136,9 +138,65 @@ __device__ __forceinline__ void frame_grad_to_aug(float gxf, float gyf, int b, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact pruning at high temperature
+// ------------------------------------------------------------------------------------------------
+// A term exp(T*y - m) with T*y < m - kPruneMargin is smaller than e^-50 = 2e-22 times the largest term; all of them together (at most
+// H*W = 147 456 at 384 x 384) are below 3e-17 of the sum - nine orders of magnitude under fp32's resolution (6e-8), so skipping them moves
+// no result by more than the last bit (tests/test_emu_decode.py::test_exact_pruning_changes_nothing; parity tolerance 1e-4 px).  With the
+// reference's T = 1000 that is everything more than 0.05 below the peak of the up-sampled map - for the peaked maps of a trained network
+// (peak ~0.1) all but the few rows / columns around the peak.  The bound used to decide is
+//     |y(j, c)| <= (max_row sum_t |ty|) * (sum_t |tx_c|) * min( max |Hm| over the rows of window j , max |Hm| over the columns of c's taps )
+// from per-row / per-column maxima of the staged tile (2 * h * w LDS reads, once).  Row groups are skipped per wave (the row bound is
+// wave-uniform), whole waves / strips when none of their columns can contribute.  On flat maps (an untrained network) nothing is skipped.
+constexpr float kPruneMargin = 50.f;
+constexpr int kPruneMaxDim = 256;  // h, w up to this use pruning (LDS for the row / column maxima)
+
+struct PruneState {
+    float rmx[kPruneMaxDim];   // max |Hm[r][:]|
+    float cmx[kPruneMaxDim];   // max |Hm[:][q]|
+    float rwin[kPruneMaxDim];  // max of rmx over the input rows of output-row group j's window
+    float red[16];
+};
+
+// fills ps.rmx / cmx / rwin from the staged tile and returns Ly = max over output rows of sum_t |row tap| (block-wide)
+template <int R, int TY>
+__device__ __forceinline__ float prune_setup(PruneState& ps, const float* hs, int h, int w, const DecodeTables& tb) {
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    for (int r = tid; r < h; r += nthreads) {
+        float a = 0.f;
+        for (int q = 0; q < w; ++q) a = fmaxf(a, fabsf(hs[r * w + q]));
+        ps.rmx[r] = a;
+    }
+    for (int q = tid; q < w; q += nthreads) {
+        float a = 0.f;
+        for (int r = 0; r < h; ++r) a = fmaxf(a, fabsf(hs[r * w + q]));
+        ps.cmx[q] = a;
+    }
+    float ly = 0.f;
+    for (int i = tid; i < h * R; i += nthreads) {
+        float a = 0.f;
+        for (int t = 0; t < TY; ++t) a += fabsf(tb.row_taps[(size_t)i * TY + t]);
+        ly = fmaxf(ly, a);
+    }
+    ly = wave_max(ly);
+    if (lane == 0) ps.red[wave] = ly;
+    __syncthreads();
+    ly = ps.red[0];
+    for (int i = 1; i < nwaves; ++i) ly = fmaxf(ly, ps.red[i]);
+    for (int j = tid; j < h; j += nthreads) {
+        const int b0 = tb.row_base[j];
+        float a = 0.f;
+        for (int t = 0; t < TY; ++t) a = fmaxf(a, ps.rmx[b0 + t]);
+        ps.rwin[j] = a;
+    }
+    __syncthreads();
+    return ly;
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int R, int TY, bool FULLTX>
+template <int R, int TY, bool FULLTX, bool PRUNE>
 __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict__ heat, int K, int h, int w, float temperature,
                                                          float offset, DecodeTables tb, FrameMap fm,
                                                          float* __restrict__ kp_aug, float* __restrict__ kp_frame,
@@ -146,6 +204,10 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     HIP_DYNAMIC_SHARED(float, smem)
     float* hs = smem;                 // [h][w]
     __shared__ float red[8 * 4];
+    // (PRUNE is a template parameter so that the un-pruned instantiation stays the round-1 kernel, register for register: the pruning
+    // state costs ~20 VGPRs, i.e. one of the four resident workgroups per CU)
+    PruneState& ps = *reinterpret_cast<PruneState*>(smem + h * w);  // behind the tile (the launcher sizes the dynamic LDS for it)
+    constexpr bool prune = PRUNE;
 
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
@@ -158,19 +220,83 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
     __syncthreads();
 
+    // ---- pruning set-up: bounds from the tile, and a LOWER bound of the final maximum from the row group at the tile's largest row
+    float ly = 0.f, m_lb = -INFINITY;
+    if (prune) {
+        ly = prune_setup<R, TY>(ps, hs, h, w, tb);
+        int jstar = 0;
+        float best = -1.f;
+        for (int r = 0; r < h; ++r)
+            if (ps.rmx[r] > best) {
+                best = ps.rmx[r];
+                jstar = r;
+            }
+        float ym = -INFINITY;
+        for (int c = tid; c < W; c += nthreads) {  // (no wave collectives inside: lanes past W simply sit out)
+            float tx[kTXM];
+#pragma unroll
+            for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
+            const float* hcol = hs + tb.col_start[c];
+            const int b0 = tb.row_base[jstar];
+            float wv[TY];
+#pragma unroll
+            for (int t = 0; t < TY; ++t) wv[t] = z_value<FULLTX>(hcol, b0 + t, w, tx, tb.TX);
+            const float* taps = tb.row_taps + (size_t)jstar * R * TY;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                float y = 0.f;
+#pragma unroll
+                for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], wv[t], y);
+                ym = fmaxf(ym, y * temperature);
+            }
+        }
+        ym = wave_max(ym);
+        if (lane == 0) ps.red[8 + wave] = ym;
+        __syncthreads();
+        m_lb = ps.red[8];
+        for (int i = 1; i < nwaves; ++i) m_lb = fmaxf(m_lb, ps.red[8 + i]);
+    }
+    const float cut = (m_lb - kPruneMargin) / fmaxf(temperature, 1e-30f);  // |y| bounds below this contribute exactly 0
+
     float m = -INFINITY, s = 0.f, sx = 0.f, sy = 0.f;
-    for (int c = tid; c < W; c += nthreads) {  // one trip when the block covers the row (the host sizes it so)
+    for (int c0 = 0; c0 < W; c0 += nthreads) {  // one trip when the block covers the row (the host sizes it so)
+        // every lane takes every trip (the pruning decisions are wave collectives); lanes past W repeat the last column and add nothing
+        const bool valid = c0 + tid < W;
+        const int c = valid ? c0 + tid : W - 1;
         float tx[kTXM];
 #pragma unroll
         for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
         const float* hcol = hs + tb.col_start[c];
         const float xc = (float)c;
+        float lx = 0.f;       // wave-wide bound factor of the columns: max over the wave of sum_t |tx|, and of their column maxima
+        bool wave_live = true;
+        if (prune) {
+            float cm = 0.f;
+#pragma unroll
+            for (int t = 0; t < kTXM; ++t) {
+                lx += fabsf(tx[t]);
+                if (t < tb.TX) cm = fmaxf(cm, ps.cmx[tb.col_start[c] + t]);
+            }
+            const float colb = wave_max(ly * lx * cm);  // no column of this wave can exceed it, whatever the row
+            lx = wave_max(lx);
+            wave_live = !(colb < cut);
+        }
+        if (!wave_live) continue;  // (wave-uniform: every lane of the wave has the same colb)
         float win[TY];
         int base = tb.row_base[0];
-#pragma unroll
-        for (int t = 0; t < TY; ++t) win[t] = z_value<FULLTX>(hcol, base + t, w, tx, tb.TX);
+        bool have = false;         // is `win` the window of `base`?
         for (int j = 0; j < h; ++j) {
             const int nb = tb.row_base[j];
+            if (prune && ly * lx * ps.rwin[j] < cut) {  // the whole row group is below the cut for every column of the wave
+                have = false;
+                continue;
+            }
+            if (!have) {
+#pragma unroll
+                for (int t = 0; t < TY; ++t) win[t] = z_value<FULLTX>(hcol, nb + t, w, tx, tb.TX);
+                base = nb;
+                have = true;
+            }
             if (nb != base) {  // windows advance by exactly one input row (host asserts it)
 #pragma unroll
                 for (int t = 0; t < TY - 1; ++t) win[t] = win[t + 1];
@@ -188,6 +314,7 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
                 z[rr] = y * temperature;
                 gm = fmaxf(gm, z[rr]);
             }
+            if (!valid) continue;
             const float sc = (m == -INFINITY) ? 0.f : __expf(m - gm);
             s *= sc;
             sx *= sc;
@@ -262,7 +389,7 @@ constexpr int kBwdLd = kBwdStrip + 1;  // LDS row stride of the strip (odd: lane
 __host__ __device__ inline int bwd_tap_ld(int TC) { return TC | 1; }  // odd row stride of the staged transposed tap table
 
 // (second launch bound = waves per SIMD: two 8-wave workgroups per CU for the usual map sizes, LDS allows it)
-template <int R, int TY, int NE, bool FULLTX>
+template <int R, int TY, int NE, bool FULLTX, bool PRUNE>
 __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(const float* __restrict__ heat, int K, int h, int w,
                                                                              float temperature, DecodeTables tb, FrameMap fm,
                                                                              const float* __restrict__ stats,
@@ -270,6 +397,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                                                                              const float* __restrict__ g_frame,
                                                                              float* __restrict__ g_heat, int accumulate) {
     HIP_DYNAMIC_SHARED(float, smem)
+    constexpr bool prune = PRUNE;
     constexpr int SC = kBwdStrip, LD = kBwdLd;
     const int TCP = bwd_tap_ld(tb.TC);
     float* hs = smem;            // [h][w]   heat-map tile; reused at the end to transpose the result for coalesced stores
@@ -277,6 +405,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                                  //          has at most two contributing segments, so the sum does not depend on their order)
     float* lt = zs + h * LD;     // [w][TCP] transposed column taps
     int* lcs = reinterpret_cast<int*>(lt + w * TCP);  // [w] first output column touching input column q
+    PruneState& ps = *reinterpret_cast<PruneState*>(lcs + w);  // (PRUNE only: the launcher sizes the dynamic LDS for it)
 
     const int bk = blockIdx.x;
     const int b = bk / K, k = bk - b * K;
@@ -310,6 +439,14 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
     const float ex = stats[bk * 4 + 2], ey = stats[bk * 4 + 3];
     const float gxt = gx * temperature, gyt = gy * temperature;
 
+    // pruning (see "exact pruning at high temperature"): here the exact maximum is known from the forward pass
+    float ly = 0.f;
+    if (prune) {
+        __syncthreads();  // the staged tile is complete
+        ly = prune_setup<R, TY>(ps, hs, h, w, tb);
+    }
+    const float cut = prune ? (m - kPruneMargin) / fmaxf(temperature, 1e-30f) : -INFINITY;
+
     // this thread's elements of dH: e = tid + i * nthreads -> (q, r) = (e / h, e % h): consecutive lanes walk down one input
     // column q, so the tap reads broadcast and the strip reads are conflict-free
     float dacc[NE];
@@ -318,6 +455,20 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
     const float inv_h = 1.f / (float)h;
 
     for (int c0 = 0; c0 < W; c0 += SC) {
+        // a strip none of whose columns can reach the cut contributes nothing (every wave sees the same 64 columns: block-uniform)
+        float lx = 0.f;
+        {
+            const int cc = min(c0 + lane, W - 1);
+            float cm = 0.f;
+#pragma unroll
+            for (int t = 0; t < kTXM; ++t) {
+                lx += fabsf(tb.col_taps[cc * kTXM + t]);
+                if (prune && t < tb.TX) cm = fmaxf(cm, ps.cmx[tb.col_start[cc] + t]);
+            }
+            const float colb = wave_max(ly * lx * cm);
+            lx = wave_max(lx);
+            if (prune && colb < cut) continue;
+        }
         for (int i = tid; i < h * LD; i += nthreads) zs[i] = 0.f;
         __syncthreads();  // (first trip: also the tile / table staging)
         const int c = c0 + lane;
@@ -329,13 +480,12 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
             const float dxc = gxt * ((float)c - ex);
             float win[TY], acc[TY];
             int base = tb.row_base[j0];
+            bool have = false;  // is `win` the window of `base`? (acc always belongs to `base`)
 #pragma unroll
-            for (int t = 0; t < TY; ++t) {
-                win[t] = z_value<FULLTX>(hcol, base + t, w, tx, tb.TX);
-                acc[t] = 0.f;
-            }
+            for (int t = 0; t < TY; ++t) acc[t] = 0.f;
             for (int j = j0; j < j1; ++j) {
                 const int nb = tb.row_base[j];
+                const bool skip = prune && ly * lx * ps.rwin[j] < cut;  // wave-uniform: no row of this group reaches the cut
                 if (nb != base) {
                     atomicAdd(&zs[base * LD + lane], acc[0]);  // this segment is done with input row `base`
 #pragma unroll
@@ -343,9 +493,18 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                         win[t] = win[t + 1];
                         acc[t] = acc[t + 1];
                     }
-                    win[TY - 1] = z_value<FULLTX>(hcol, nb + TY - 1, w, tx, tb.TX);
+                    if (have && !skip) win[TY - 1] = z_value<FULLTX>(hcol, nb + TY - 1, w, tx, tb.TX);
                     acc[TY - 1] = 0.f;
                     base = nb;
+                }
+                if (skip) {
+                    have = false;
+                    continue;
+                }
+                if (!have) {
+#pragma unroll
+                    for (int t = 0; t < TY; ++t) win[t] = z_value<FULLTX>(hcol, base + t, w, tx, tb.TX);
+                    have = true;
                 }
                 const float* taps = tb.row_taps + (size_t)j * R * TY;
 #pragma unroll
@@ -428,6 +587,14 @@ static int decode_bwd_threads(int h, int TY) {
     return waves * 64;
 }
 
+// LP_DECODE_PRUNE=1 selects the pruning instantiations (read per call: tests and profiles/decode_microbench.py A/B it).  Opt-in: on the
+// FLAT maps of an untrained network nothing can be skipped and the pruning state costs one resident workgroup per CU (fwd 94 vs 71 VGPRs),
+// on the PEAKED maps of a trained one it skips most of the work - see DESIGN.md section 4.2 for the measured numbers
+static int decode_prune() {
+    const char* e = getenv("LP_DECODE_PRUNE");
+    return e != nullptr && atoi(e) != 0;
+}
+
 template <typename Kern>
 static void allow_large_lds(Kern kern, size_t bytes) {
     // opt in to > 64 KiB of dynamic LDS (gfx950 has 160 KiB per workgroup)
@@ -464,14 +631,20 @@ extern "C" int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B * K), block(decode_fwd_threads(w * R));
     const bool full = t->tx == kTXM;
-#define LP_LAUNCH_FWD2(RR, TT, FF)                                                                                      \
-    allow_large_lds(decode_fwd_kernel<RR, TT, FF>, smem);                                                               \
-    hipLaunchKernelGGL((decode_fwd_kernel<RR, TT, FF>), grid, block, smem, st, heat, K, h, w, temperature, offset, tb, fm, \
-                       kp_aug, kp_frame, conf, stats)
-#define LP_LAUNCH_FWD(RR, TT)              \
-    do {                                   \
-        if (full) { LP_LAUNCH_FWD2(RR, TT, true); } \
-        else { LP_LAUNCH_FWD2(RR, TT, false); }     \
+    const bool prune = decode_prune() && h <= kPruneMaxDim && w <= kPruneMaxDim;
+#define LP_LAUNCH_FWD2(RR, TT, FF, PP)                                                                                      \
+    allow_large_lds(decode_fwd_kernel<RR, TT, FF, PP>, smem + (PP ? sizeof(PruneState) : 0));                               \
+    hipLaunchKernelGGL((decode_fwd_kernel<RR, TT, FF, PP>), grid, block, smem + (PP ? sizeof(PruneState) : 0), st, heat, K, h, w, \
+                       temperature, offset, tb, fm, kp_aug, kp_frame, conf, stats)
+#define LP_LAUNCH_FWD(RR, TT)                                     \
+    do {                                                          \
+        if (prune) {                                              \
+            if (full) { LP_LAUNCH_FWD2(RR, TT, true, true); }     \
+            else { LP_LAUNCH_FWD2(RR, TT, false, true); }         \
+        } else {                                                  \
+            if (full) { LP_LAUNCH_FWD2(RR, TT, true, false); }    \
+            else { LP_LAUNCH_FWD2(RR, TT, false, false); }        \
+        }                                                         \
     } while (0)
     if (R == 2 && TY == 8) { LP_LAUNCH_FWD(2, 8); }
     else if (R == 4 && TY == 8) { LP_LAUNCH_FWD(4, 8); }
@@ -503,21 +676,27 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B * K), block(nthreads);
     const bool full = t->tx == kTXM;
-#define LP_LAUNCH_BWD(RR, TT, NN, FF)                                                                                   \
-    allow_large_lds(decode_bwd_kernel<RR, TT, NN, FF>, smem);                                                           \
-    hipLaunchKernelGGL((decode_bwd_kernel<RR, TT, NN, FF>), grid, block, smem, st, heat, K, h, w, temperature, tb, fm, stats, \
-                       g_aug, g_frame, g_heat, accumulate)
-#define LP_DISPATCH_NE(RR, TT)                                   \
-    do {                                                         \
-        if (full) {                                              \
-            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, true); }     \
-            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, true); } \
-            else { LP_LAUNCH_BWD(RR, TT, 64, true); }            \
-        } else {                                                 \
-            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, false); }    \
-            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, false); } \
-            else { LP_LAUNCH_BWD(RR, TT, 64, false); }           \
-        }                                                        \
+    const bool prune = decode_prune() && h <= kPruneMaxDim && w <= kPruneMaxDim;
+#define LP_LAUNCH_BWD(RR, TT, NN, FF, PP)                                                                                   \
+    allow_large_lds(decode_bwd_kernel<RR, TT, NN, FF, PP>, smem + (PP ? sizeof(PruneState) : 0));                           \
+    hipLaunchKernelGGL((decode_bwd_kernel<RR, TT, NN, FF, PP>), grid, block, smem + (PP ? sizeof(PruneState) : 0), st, heat, K, h, w, \
+                       temperature, tb, fm, stats, g_aug, g_frame, g_heat, accumulate)
+#define LP_DISPATCH_NE2(RR, TT, PP)                                  \
+    do {                                                             \
+        if (full) {                                                  \
+            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, true, PP); }     \
+            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, true, PP); } \
+            else { LP_LAUNCH_BWD(RR, TT, 64, true, PP); }            \
+        } else {                                                     \
+            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, false, PP); }    \
+            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, false, PP); } \
+            else { LP_LAUNCH_BWD(RR, TT, 64, false, PP); }           \
+        }                                                            \
+    } while (0)
+#define LP_DISPATCH_NE(RR, TT)                       \
+    do {                                             \
+        if (prune) { LP_DISPATCH_NE2(RR, TT, true); } \
+        else { LP_DISPATCH_NE2(RR, TT, false); }     \
     } while (0)
     if (R == 2 && TY == 8) { LP_DISPATCH_NE(2, 8); }
     else if (R == 4 && TY == 8) { LP_DISPATCH_NE(4, 8); }
@@ -525,6 +704,7 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
     else if (R == 8 && TY == 11) { LP_DISPATCH_NE(8, 11); }
     else return LP_ERR_UNSUPPORTED;
 #undef LP_DISPATCH_NE
+#undef LP_DISPATCH_NE2
 #undef LP_LAUNCH_BWD
     return launch_status();
 }

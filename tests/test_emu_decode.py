@@ -97,3 +97,44 @@ def test_decode_bwd_through_frame_map(golden):
                             g_frame=gf.reshape(s, k, 2).numpy(), fm=fm)
     ref = heat.grad.numpy()
     np.testing.assert_allclose(g_heat, ref, atol=2e-3 * np.abs(ref).max(), rtol=0)
+
+
+def _peaked(g, b, k, h, w, sigma=1.25, amp=1.0):
+    """maps of a trained network: a normalised Gaussian of the target's width at a random sub-pixel position (+ a little noise)"""
+    ys = torch.arange(h).view(1, 1, h, 1).float()
+    xs = torch.arange(w).view(1, 1, 1, w).float()
+    cx = torch.rand(b, k, 1, 1, generator=g) * (w - 1)
+    cy = torch.rand(b, k, 1, 1, generator=g) * (h - 1)
+    m = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * sigma ** 2))
+    m = m / m.sum(dim=(2, 3), keepdim=True) * amp
+    return m + 1e-5 * torch.rand(b, k, h, w, generator=g)
+
+
+@pytest.mark.parametrize("ds,h,w", [(2, 24, 32), (2, 96, 96), (1, 16, 16), (3, 12, 12)])
+def test_exact_pruning_changes_nothing(kernel_backend, monkeypatch, ds, h, w):
+    """At T = 1000 every term more than 104 / T below the peak is exactly 0 in fp32: the kernels skip the row groups / column waves /
+    strips whose bound says so (csrc/decode.hip, "exact pruning").  Peaked maps (a trained network's), incl. peaks on the border and a
+    two-peak map: forward outputs and the backward gradient equal the unpruned kernels' to fp32 rounding."""
+    gen = torch.Generator().manual_seed(ds * 100 + h)
+    x = _peaked(gen, 2, 5, h, w)
+    x[0, 0] = 0.5 * (_peaked(gen, 1, 1, h, w)[0, 0] + _peaked(gen, 1, 1, h, w)[0, 0])      # two peaks of equal height
+    x[1, 1] = 0.0
+    x[1, 1, 0, 0] = 0.3                                                                        # a single pixel in the corner
+    x[1, 2] = 0.0
+    x[1, 2, h - 1, w // 2] = 0.2
+    hm = x.numpy()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LP_DECODE_PRUNE", flag)
+        kp_aug, kp_frame, conf, stats = emu.decode_fwd(hm, ds)
+        g = emu.decode_bwd(hm, ds, stats, g_aug=np.ones((2, 5, 2), np.float32) * np.array([1.0, -0.5], np.float32))
+        res[flag] = (kp_aug, conf, stats, g)
+    np.testing.assert_allclose(res["1"][0], res["0"][0], atol=2e-5, rtol=0)     # keypoints, px
+    np.testing.assert_allclose(res["1"][1], res["0"][1], atol=1e-6, rtol=1e-5)  # confidences
+    np.testing.assert_allclose(res["1"][2][..., :2], res["0"][2][..., :2], rtol=1e-6)  # max and sum of exponentials
+    scale = float(np.abs(res["0"][3]).max())
+    np.testing.assert_allclose(res["1"][3], res["0"][3], atol=2e-6 * scale, rtol=0)
+    # and the pruned result is still the reference's (oracle restatement of run_subpixelmaxima)
+    want_kp, want_conf = O.soft_argmax(torch.from_numpy(hm), ds, 1000.0)
+    np.testing.assert_allclose(res["1"][0].reshape(2, -1), want_kp.numpy(), atol=2e-4)
+    np.testing.assert_allclose(res["1"][1], want_conf.numpy(), atol=2e-5)
