@@ -329,6 +329,12 @@ int lp_bn_finalize2(const float* sums, float count0, float count1, int C, float 
 /* relu_bits (optional, M*C/8 bytes): bit q of byte i = (y[8*i + q] > 0): a 16x smaller ReLU mask for the backward pass */
 int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                 int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream);
+/* both BatchNorm segments of a joint pass (lp_bn_fuse.seg_images) in ONE launch: rows [0, seg_rows) use row 0 of mean / invstd (2, C)
+ * [and of sums (2, 2, C), with count0], the other rows use row 1 [count1] */
+int lp_bn_apply_seg(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
+                    int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
+int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
+                        const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres, lp_stream_t stream);
 /* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL); dbeta/dgamma accumulate too */
 int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
                      float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);

@@ -108,6 +108,8 @@ PROTOTYPES = {
     "lp_bn_finalize": (_I, [_P, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_finalize2": (_I, [_P, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "lp_bn_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_bn_bwd_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P]),
     "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
     "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),

@@ -141,17 +141,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count0,
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
-                                                       int relu, size_t n_chunks, int C, unsigned short* __restrict__ Y,
-                                                       unsigned char* __restrict__ bits) {
+                                                       int relu, size_t n_total, int C, unsigned short* __restrict__ Y,
+                                                       unsigned char* __restrict__ bits, size_t seg_chunk) {
+    // Two BatchNorm segments in one launch (seg_chunk > 0: chunks [0, seg_chunk) use mean / invstd row 0, the rest row 1; the boundary is
+    // a whole number of rows): the walk runs once per segment with that segment's terms in registers; a lane keeps its channel chunk
+    // because every start is congruent to its global index modulo the stride.
     const int chunks = C >> 3;
     const size_t stride = (size_t)gridDim.x * 256;
-    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int c = (int)(q % chunks) * 8;
+    const size_t q0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(q0 % chunks) * 8;
+    const int nseg = seg_chunk > 0 ? 2 : 1;
+    for (int sg = 0; sg < nseg; ++sg) {
+    const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
+    size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
     float mu[8], sc[8], be[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        mu[i] = mean[c + i];
-        sc[i] = invstd[c + i] * gamma[c + i];
+        mu[i] = mean[sg * C + c + i];
+        sc[i] = invstd[sg * C + c + i] * gamma[c + i];
         be[i] = beta[c + i];
     }
     constexpr int U = 4;
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
             }
         }
     }
+    }
 }
 
 // dx = gamma * invstd * (dz - sum(dz)/N - xhat * sum(dz*xhat)/N);  dz = relu-masked dy; optionally dz is also
@@ -198,20 +206,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
                                                            const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, float inv_count, size_t n_chunks, int C,
-                                                           unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES) {
+                                                           const float* __restrict__ sums, float inv_count, size_t n_total, int C,
+                                                           unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES,
+                                                           size_t seg_chunk, float inv_count1) {
+    // (segments as in bn_apply_kernel: mean / invstd rows of C, sums rows of 2 C, one 1 / count per segment)
     const int chunks = C >> 3;
     const size_t stride = (size_t)gridDim.x * 256;
-    size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int c = (int)(q % chunks) * 8;
+    const size_t q0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(q0 % chunks) * 8;
+    const int nseg = seg_chunk > 0 ? 2 : 1;
+    for (int sg = 0; sg < nseg; ++sg) {
+    const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
+    size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
+    const float ic = sg == 0 ? inv_count : inv_count1;
     float mu[8], is[8], ga[8], k0[8], k1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        mu[i] = mean[c + i];
-        is[i] = invstd[c + i];
+        mu[i] = mean[sg * C + c + i];
+        is[i] = invstd[sg * C + c + i];
         ga[i] = gamma[c + i] * is[i];
-        k0[i] = sums[c + i] * inv_count;
-        k1[i] = sums[C + c + i] * inv_count;
+        k0[i] = sums[sg * 2 * C + c + i] * ic;
+        k1[i] = sums[sg * 2 * C + C + c + i] * ic;
     }
     constexpr int U = 2;
     for (; q < n_chunks; q += U * stride) {
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
             *reinterpret_cast<u16x8*>(DX + (q + u * stride) * 8) = pack8(o);
             if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + (q + u * stride) * 8) = pack8(dz);
         }
+    }
     }
 }
 
@@ -634,15 +650,27 @@ extern "C" int lp_bn_affine(const float* invstd, const float* gamma, int nseg, i
     return launch_status();
 }
 
-extern "C" int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                           const void* residual, int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream) {
+static int bn_apply_impl(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
+                         int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0);
+    LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0 && seg_rows >= 0 && seg_rows < M);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
-                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits);
+                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
+                       (size_t)seg_rows * (C / 8));
     return launch_status();
+}
+
+extern "C" int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const void* residual, int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream) {
+    return bn_apply_impl(x, mean, invstd, gamma, beta, residual, relu, M, C, 0, y, relu_bits, stream);
+}
+
+// two BatchNorm segments in one launch: rows [0, seg_rows) are normalised with mean / invstd row 0, the rest with row 1 ((2, C) each)
+extern "C" int lp_bn_apply_seg(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               const void* residual, int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream) {
+    return bn_apply_impl(x, mean, invstd, gamma, beta, residual, relu, M, C, seg_rows, y, relu_bits, stream);
 }
 
 extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
@@ -656,17 +684,31 @@ extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x
     return launch_status();
 }
 
-extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
-                               const float* gamma, const float* sums, float count, int M, int C, void* dx, void* dres,
-                               lp_stream_t stream) {
+static int bn_bwd_apply_impl(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
+                             lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && M > 0 && C > 0 && count > 0.f);
+    LP_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && M > 0 && C > 0 && count0 > 0.f && count1 > 0.f && seg_rows >= 0 &&
+               seg_rows < M);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
-                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count, n_chunks, C,
-                       (unsigned short*)dx, (unsigned short*)dres);
+                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count0, n_chunks, C,
+                       (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1);
     return launch_status();
+}
+
+extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
+                               const float* gamma, const float* sums, float count, int M, int C, void* dx, void* dres,
+                               lp_stream_t stream) {
+    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count, count, M, C, 0, dx, dres, stream);
+}
+
+// two segments: mean / invstd (2, C), sums (2, 2, C), one row count per segment (times the world size under SyncBatchNorm)
+extern "C" int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
+                                   const float* gamma, const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx,
+                                   void* dres, lp_stream_t stream) {
+    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count0, count1, M, C, seg_rows, dx, dres, stream);
 }
 
 extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {

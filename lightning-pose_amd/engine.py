@@ -485,10 +485,9 @@ class Engine:
         B = z.shape[0]
         rpi = M // B
         gam, bet = _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias"))
-        for si, (i0, n) in enumerate(self._segments(B, seg if training else 0)):
-            check(self._lib.lp_bn_apply(_p(z[i0:i0 + n]), _p(mean[si * b.C:]), _p(invstd[si * b.C:]), gam, bet,
-                                        _p(residual[i0:i0 + n]) if residual is not None else None, int(relu), n * rpi, b.C, _p(y[i0:i0 + n]),
-                                        _p(bits[i0 * rpi * b.C // 8:]) if want_bits else None, ops._stream()), "lp_bn_apply")
+        # both segments in ONE launch (the kernel walks each segment with that segment's terms in registers)
+        check(self._lib.lp_bn_apply_seg(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), int(relu), M, b.C,
+                                        (seg if training else 0) * rpi, _p(y), _p(bits), ops._stream()), "lp_bn_apply_seg")
         if want_bits:
             return y, mean, invstd, bits
         return y, mean, invstd
@@ -766,11 +765,9 @@ class Engine:
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if want_dres else None
         gam = _p(self.param_view(b, "weight"))
-        for si, (i0, n) in enumerate(segs):
-            check(self._lib.lp_bn_bwd_apply(_p(dy[i0:i0 + n]), _p(y_out[i0:i0 + n]) if y_out is not None else None, _p(z[i0:i0 + n]),
-                                            _p(mean[si * Cn:]), _p(invstd[si * Cn:]), gam, _p(sums[si * 2 * Cn:]), float(n * rpi * world),
-                                            n * rpi, Cn, _p(dz[i0:i0 + n]), _p(dres[i0:i0 + n]) if want_dres else None, ops._stream()),
-                  "lp_bn_bwd_apply")
+        counts = [float(n * rpi * world) for _, n in segs]
+        check(self._lib.lp_bn_bwd_apply_seg(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(sums), counts[0], counts[-1], M, Cn,
+                                            seg * rpi, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply_seg")
         return dz, dres
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,

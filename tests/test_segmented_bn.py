@@ -171,3 +171,39 @@ def test_normalise_on_load_is_for_1x1_only(kernel_backend):
     m = np.zeros((1, 64), np.float32)
     assert emu.conv_fwd_bn_norm(x, w, g, m, m + 1, m, rc=True) == -2
     assert emu.conv_wgrad_norm(x, emu.to_bf16_bits(torch.randn(2 * 64, 64)), g, m, m + 1, m, rc=True) == -2
+
+
+@pytest.mark.parametrize("M,seg_rows,Cn", [(256, 128, 64), (300, 100, 24), (5000, 1800, 256), (96, 95, 8)])
+def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_rows, Cn):
+    """lp_bn_apply_seg / lp_bn_bwd_apply_seg == the one-segment entry points called once per segment, bit for bit (one launch walks both
+    segments, each with its own per-channel terms in registers)"""
+    gen = torch.Generator().manual_seed(M + Cn)
+    bits16 = lambda t: emu.to_bf16_bits(t)  # noqa: E731
+    x, res, dy = (bits16(torch.randn(M, Cn, generator=gen)) for _ in range(3))
+    mean = (torch.randn(2, Cn, generator=gen) * 0.3).numpy()
+    invstd = (torch.rand(2, Cn, generator=gen) + 0.5).numpy()
+    gamma, beta = (torch.rand(Cn, generator=gen) + 0.5).numpy(), (torch.randn(Cn, generator=gen) * 0.2).numpy()
+    sums = torch.randn(2, 2, Cn, generator=gen).numpy()
+    counts = (float(seg_rows), float(M - seg_rows))
+    lib, st = emu.lib(), emu.stream()
+    B = emu.Buf
+    mb, ib, gb, bb, sb = B(mean), B(invstd), B(gamma), B(beta), B(sums)
+    xb, rb, db = B(x), B(res), B(dy)
+    nb = -(-M * Cn // 8)
+    # joint launches
+    y, bits, dx, dres = emu.Z((M, Cn), np.uint16), emu.Z(nb, np.uint8), emu.Z((M, Cn), np.uint16), emu.Z((M, Cn), np.uint16)
+    emu.ok(lib.lp_bn_apply_seg(xb.p, mb.p, ib.p, gb.p, bb.p, rb.p, 1, M, Cn, seg_rows, y.p, bits.p if Cn % 8 == 0 and (seg_rows * Cn) % 8 == 0 else None, st))
+    emu.ok(lib.lp_bn_bwd_apply_seg(db.p, y.p, xb.p, mb.p, ib.p, gb.p, sb.p, counts[0], counts[1], M, Cn, seg_rows, dx.p, dres.p, st))
+    got = (y.np().copy(), dx.np().copy(), dres.np().copy())
+    # one call per segment
+    want = [np.zeros((M, Cn), np.uint16) for _ in range(3)]
+    for si, (r0, n) in enumerate(((0, seg_rows), (seg_rows, M - seg_rows))):
+        ys, dxs, drs = emu.Z((n, Cn), np.uint16), emu.Z((n, Cn), np.uint16), emu.Z((n, Cn), np.uint16)
+        xs, rs, ds = B(x[r0:r0 + n]), B(res[r0:r0 + n]), B(dy[r0:r0 + n])
+        ms, is_, ss = B(mean[si]), B(invstd[si]), B(sums[si])
+        emu.ok(lib.lp_bn_apply(xs.p, ms.p, is_.p, gb.p, bb.p, rs.p, 1, n, Cn, ys.p, None, st))
+        emu.ok(lib.lp_bn_bwd_apply(ds.p, ys.p, xs.p, ms.p, is_.p, gb.p, ss.p, counts[si], n, Cn, dxs.p, drs.p, st))
+        for dst, src in zip(want, (ys, dxs, drs)):
+            dst[r0:r0 + n] = src.np()
+    for a, b_ in zip(got, want):
+        assert np.array_equal(a, b_)
