@@ -369,6 +369,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     # step (measured: 3190 vs 3330 frames/s), which would make the probe part of the result it measures.
     prof_sink: list = []
     prof_steps = 0
+    mem0 = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         sampled = not args.no_profile and i % 5 == min(2, args.steps - 1)
@@ -398,6 +399,11 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     bn_bytes = sum(2 * 2 * b.C * 4 for b in getattr(model.net.plan, "bns", [])) * 2 if getattr(model.net, "sync_bn", False) else 0
     comm = {"sync_bn_messages": n_msgs, "sync_bn_bytes": bn_bytes, "grad_buckets": (0 if world == 1 else -(-model.net.G.numel() * 4 // (64 << 20))),
             "grad_bytes": 0 if world == 1 else model.net.G.numel() * 4, "logged_scalar_messages": 0 if world == 1 else 1}
+    mem1 = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
+    memory = {"max_allocated_gb": round(mem1.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2), "max_reserved_gb": round(mem1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
+              "device_allocs_in_timed_steps": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
+              "device_frees_in_timed_steps": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0),
+              "alloc_retries": mem1.get("num_alloc_retries", 0), "ooms": mem1.get("num_ooms", 0)}
     frames_per_step = (args.labeled + args.unlabeled) * args.views * world
     value = frames_per_step * args.steps / elapsed
     is_vit = args.backbone != "resnet50"
@@ -417,7 +423,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
                                "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": bool(getattr(model.net, "sync_bn", False)),
-                   "comm_per_step": comm,
+                   "comm_per_step": comm, "memory": memory,
                    "hip_graph": bool(trainer._graphed is not None and trainer._graphed.replays > 0),
                    "final_loss": round(float(loss), 6)},
     }

@@ -15,6 +15,11 @@ from .distributed import DataParallel
 
 
 class Trainer:
+    # Nothing in a step makes the host wait for the device, so unthrottled it would enqueue steps as fast as the launch queue accepts them,
+    # each with its own ~25 GB of activations allocated ahead of time.  Two steps in flight keep the device busy across the step boundary
+    # and bound the memory the caching allocator has to hold.
+    MAX_STEPS_IN_FLIGHT = int(__import__("os").environ.get("LP_MAX_STEPS_IN_FLIGHT", "2"))
+
     def __init__(self, max_epochs: int = 1, callbacks: list | None = None, limit_train_batches: int | None = None,
                  data_parallel: bool | None = None, sync_batchnorm: bool = True, accumulate_grad_batches: int = 1,
                  hip_graph: bool | None = None):
@@ -25,6 +30,7 @@ class Trainer:
         self.accumulate_grad_batches = accumulate_grad_batches
         self._want_dp = data_parallel
         self._want_graph = hip_graph          # None: LP_HIP_GRAPH decides (graph_step.py)
+        self._inflight: list = []             # "step finished" events: the host stays at most MAX_STEPS_IN_FLIGHT steps ahead of the device
         self._graphed = None
         self.dp: DataParallel | None = None
         self.logged_history: list[dict[str, float]] = []
@@ -112,6 +118,12 @@ class Trainer:
                 model.global_step += 1
         elif self.dp is not None:
             self._sync_logged(model)
+        if count and model.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._inflight.append(ev)
+            if len(self._inflight) > self.MAX_STEPS_IN_FLIGHT:
+                self._inflight.pop(0).synchronize()
         return loss.detach()
 
     @torch.no_grad()
