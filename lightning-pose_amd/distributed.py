@@ -22,14 +22,16 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and os.environ.get("LP_FORCE_DEVICE") is None:
+        # every backend, and before the communicator exists: kernels launch on the current device's stream (ops._stream), and RCCL binds
+        # its communicator to the device that is current at its first collective
+        torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("LP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if torch.cuda.is_available() and os.environ.get("LP_FORCE_DEVICE") is None:
-        torch.cuda.set_device(local_rank)  # every backend: kernels launch on the current device's stream (ops._stream)
     return rank, local_rank, world
 
 
