@@ -1139,19 +1139,6 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
-// Opt-in tile choice (LP_CONV_TAIL_BN64=1, read per call so a process can A/B it): with 128-column tiles a launch of T tiles runs
-// ceil(T / grid) rounds of the persistent grid, and a last round that is mostly empty wastes up to half the chip;
-// 64-column tiles double T at half the work per tile.  Default off: the narrower tile has lower arithmetic intensity and the trade has
-// not been measured yet.
-static bool tail_prefers_bn64(int M, int N) {
-    const char* e = getenv("LP_CONV_TAIL_BN64");
-    if (e == nullptr || atoi(e) <= 0 || N <= 64 || N % 64 != 0) return false;
-    const long long t = (long long)((M + kBM - 1) / kBM) * ((N + 127) / 128);
-    const long long grid = igemm_max_wgs();
-    const long long rounds = (t + grid - 1) / grid;
-    return (double)t < 0.8 * (double)(rounds * grid);
-}
-
 // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue); LP_STATS_ATOMIC_TILES overrides it (tests force the
 // per-tile workspace + tile_stats_reduce path on small problems with 0)
 static int stats_atomic_tiles() {
@@ -1234,7 +1221,7 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         ep.norm_mean = norm->mean, ep.norm_scale = norm->scale, ep.norm_shift = norm->shift;
         if (N > 64) launch_igemm<128, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
         else launch_igemm<64, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
-    } else if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    } else if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     if (bn && ep.stats_sums == nullptr) {
         const StatRanges rg{1, {0, 0, 0, 0}, {split == M ? tm : (int)(split / kBM), 0, 0, 0}, {tm, 0, 0, 0}};
@@ -1263,7 +1250,7 @@ extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom*
     ep.out_bf16 = (unsigned short*)out_bf16, ep.ldo = N, ep.n_store = N, ep.bias = bias;
     ep.addend = (const unsigned short*)residual_bf16, ep.relu_fwd = relu != 0;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
+    if (N > 64) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
     else launch_igemm<64, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
     return launch_status();
 }
@@ -1413,7 +1400,7 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
             ++rg.n;
         }
         stats_rows += tm;
-        if (N > 64 && !tail_prefers_bn64(M, N)) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
         else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
     };
     if (bn && bn->seg_images > 0) {  // check every launch's segment boundary BEFORE anything is enqueued

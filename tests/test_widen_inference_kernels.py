@@ -63,32 +63,3 @@ def test_attention_forward_without_probabilities(nb, nh, T, ldp):
     none, obits_inf = emu.attn_fwd(qkv.reshape(-1), ld, D, 2 * D, nb, nh, T, scale, ldp, D, write_p=False)
     assert none is None
     np.testing.assert_array_equal(obits_inf, obits)
-
-
-# ---- opt-in tail tiling (LP_CONV_TAIL_BN64=1): launches whose 128-column tiling leaves the persistent grid's last round mostly empty run
-# on 64-column tiles instead.  Same results: the established convolution checks are re-run with the option on.
-@pytest.mark.parametrize("case", [(1, 9, 7, 64, 128, 3, 1, 1), (2, 10, 10, 128, 192, 3, 2, 1), (3, 16, 16, 64, 128, 3, 1, 1)])
-def test_tail_bn64_tiles_give_the_same_results(monkeypatch, case):
-    from tests import test_emu_conv as T
-
-    monkeypatch.setenv("LP_CONV_TAIL_BN64", "1")
-    T.test_conv_fwd_dgrad_wgrad(case)
-    T.test_conv_fused_batchnorm_reductions(case)
-    if case[6] == 1 or case[5] == 3:
-        test_conv_fwd_act_folded_batchnorm(case[:8], True, True)
-
-
-def test_tail_bn64_is_off_by_default_and_only_for_poor_rounds(monkeypatch):
-    """bit-identical outputs of a 128-column launch with the option off and on when the tiling already fills its rounds is not
-    checkable at toy sizes (every toy launch is a partial round); what is checkable: off by default = the 128-column path, and the
-    option changes nothing for N <= 64"""
-    gen = torch.Generator().manual_seed(3)
-    x = bf(torch.randn(2, 64, 8, 8, generator=gen))
-    w = bf(torch.randn(64, 64, 1, 1, generator=gen) / 8)
-    g = emu.geom(2, 8, 8, 64, 64, 1, 1, 1, 0)
-    xb, wb = emu.to_bf16_bits(nhwc(x)), emu.to_bf16_bits(w.permute(0, 2, 3, 1))
-    monkeypatch.delenv("LP_CONV_TAIL_BN64", raising=False)
-    a, _ = emu.conv_fwd(xb, wb, g)
-    monkeypatch.setenv("LP_CONV_TAIL_BN64", "1")
-    b, _ = emu.conv_fwd(xb, wb, g)
-    np.testing.assert_array_equal(a, b)
