@@ -16,7 +16,7 @@ from .distributed import DataParallel
 
 class Trainer:
     # Nothing in a step makes the host wait for the device, so unthrottled it would enqueue steps as fast as the launch queue accepts them,
-    # each with its own ~25 GB of activations allocated ahead of time.  Two steps in flight keep the device busy across the step boundary
+    # each with its own ~30 GB of activations allocated ahead of time.  Two steps in flight keep the device busy across the step boundary
     # and bound the memory the caching allocator has to hold.
     MAX_STEPS_IN_FLIGHT = int(__import__("os").environ.get("LP_MAX_STEPS_IN_FLIGHT", "2"))
 
