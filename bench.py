@@ -350,13 +350,13 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     if args.predict:
         return predict_bench(args, model, batch, dev, rank, world)
-    trainer = Trainer(max_epochs=1, data_parallel=world > 1, sync_batchnorm=True, hip_graph=bool(args.graph))
+    trainer = Trainer(max_epochs=1, data_parallel=dist.is_initialized(), sync_batchnorm=True, hip_graph=bool(args.graph))
     trainer.setup(model)
     model.train()
     model.total_unsupervised_importance = torch.tensor(1.0)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     graph_capture_steps = 3 if args.graph else 0   # 2 eager steps + the capture itself, all before the counted warm-up
@@ -388,17 +388,21 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     trainer.training_batch(model, batch, args.warmup + args.steps)
     host_idle_queue = time.perf_counter() - t1
     _sync(dev)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    solo = trainer.dp is None or not trainer.dp.active
 
     # what crosses GPUs per step: SyncBatchNorm all-reduces (one per BatchNorm layer and direction, both segments of the joint pass in one
     # message), the gradient buckets, one packed message of logged scalars
     n_msgs = getattr(model.net, "sync_bn_messages", 0) // max(1, graph_capture_steps + args.warmup + args.steps + 1)
     bn_bytes = sum(2 * 2 * b.C * 4 for b in getattr(model.net.plan, "bns", [])) * 2 if getattr(model.net, "sync_bn", False) else 0
-    comm = {"sync_bn_messages": n_msgs, "sync_bn_bytes": bn_bytes, "grad_buckets": (0 if world == 1 else -(-model.net.G.numel() * 4 // (64 << 20))),
-            "grad_bytes": 0 if world == 1 else model.net.G.numel() * 4, "logged_scalar_messages": 0 if world == 1 else 1}
+    comm = {"sync_bn_messages": n_msgs, "sync_bn_bytes": bn_bytes, "grad_buckets": (0 if solo else -(-model.net.G.numel() * 4 // (64 << 20))),
+            "grad_bytes": 0 if solo else model.net.G.numel() * 4, "logged_scalar_messages": 0 if solo else 1}
+    if not solo:
+        comm["backend"] = dist.get_backend()
+        comm["buckets_sent_during_backward"] = trainer.dp.buckets_during_backward
     mem1 = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
     memory = {"max_allocated_gb": round(mem1.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2), "max_reserved_gb": round(mem1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
               "device_allocs_in_timed_steps": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
@@ -467,12 +471,12 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         if gf:
             out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
             out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
-        if world == 1 and not args.no_profile and args.views == 1 and not getattr(args, "_secondary", False):
+        if world == 1 and not dist.is_initialized() and not args.no_profile and args.views == 1 and not getattr(args, "_secondary", False):
             try:  # secondary rooflines; never allowed to cost the measured line
                 out["roofline_hbm"] = hbm_rooflines(dev, args.size, args.keypoints, args.labeled + args.unlabeled)
             except Exception as e:  # noqa: BLE001
                 out["roofline_hbm"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_cpu_baseline and not is_vit and args.views == 1 and not getattr(args, "_secondary", False):
+        if world == 1 and not dist.is_initialized() and not args.no_cpu_baseline and not is_vit and args.views == 1 and not getattr(args, "_secondary", False):
             try:
                 out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)
             except Exception as e:  # noqa: BLE001 - the baseline must never cost the measured line
@@ -522,7 +526,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
     out = train_line(args, dev, rank, world)
     if rank == 0:
         headline = (args.size, args.labeled, args.unlabeled, args.keypoints, args.views, args.backbone) == (384, 64, 128, 17, 1, "resnet50")
-        if args.secondary and world == 1 and not args.predict and headline and dev.type == "cuda":
+        if args.secondary and world == 1 and not dist.is_initialized() and not args.predict and headline and dev.type == "cuda":
             # the other BASELINE.json configs / north_star sizes in the same run (short: 3 timed steps each), so the driver's BENCH file
             # holds them too; the headline stays `value`
             import copy
@@ -546,7 +550,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                     sec[tag] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

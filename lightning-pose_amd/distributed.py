@@ -17,6 +17,13 @@ import torch.distributed as dist
 GRAD_BUCKET_BYTES = 64 << 20  # 94 MB of fp32 gradients -> 2 buckets; large messages keep the xGMI ring bandwidth-bound
 
 
+def loopback() -> bool:
+    """``LP_DIST_LOOPBACK=1``: form the process group and issue every collective of the step even on a world of ONE rank - the whole RCCL
+    path (communicator on the right device, stream hand-offs of the buckets and SyncBatchNorm messages, the logged-scalar message) can then
+    be run on a single-GPU box; the arithmetic is unchanged (sums over one rank, divided by one)."""
+    return os.environ.get("LP_DIST_LOOPBACK", "0") == "1"
+
+
 def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract) and initialise the default group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -26,7 +33,7 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
         # every backend, and before the communicator exists: kernels launch on the current device's stream (ops._stream), and RCCL binds
         # its communicator to the device that is current at its first collective
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or loopback()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -52,9 +59,10 @@ class DataParallel:
         self.engine = engine
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (loopback() and dist.is_initialized())   # False: every method below is a no-op
         self.bucket_elems = max(1, bucket_bytes // 4)
         engine.process_group = process_group
-        engine.sync_bn = bool(sync_bn and self.world > 1)
+        engine.sync_bn = bool(sync_bn and self.active)
         self._works: list = []
         self._next_hi: int | None = None   # overlapped mode: upper end of the next bucket to send (None: no step in flight)
         self.buckets_during_backward = 0
@@ -63,7 +71,7 @@ class DataParallel:
         """SyncBatchNorm divides the all-reduced sums by (local rows x world size) and the gradient mean by world size: both assume every
         rank holds equally many frames per step - what DistributedSampler's padding and the per-rank DALI windows give the reference.  One
         MIN / MAX all-reduce at the first step turns a silently wrong normalisation into an error."""
-        if self.world == 1:
+        if not self.active:
             return
         t = torch.tensor([float(v) for v in sizes] + [-float(v) for v in sizes], device=self.engine.device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
@@ -74,7 +82,7 @@ class DataParallel:
                              "per-rank batches (pad the last batch like DistributedSampler does)")
 
     def broadcast_parameters(self, src: int = 0) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         e = self.engine
         dist.broadcast(e.P, src=src, group=self.pg)
@@ -86,7 +94,7 @@ class DataParallel:
         """Arm the overlap of the gradient exchange with backward: the engine reports how far its (single) backward pass has come
         (Engine.grad_progress) and every bucket that is final goes out at once - the tail bucket (head, layer4, part of layer3: 64 of the
         94 MB) is on the wire while layers 3..1 and the stem, i.e. most of backward's time, are still being computed."""
-        if self.world == 1:
+        if not self.active:
             return
         self._next_hi = self.engine.G.numel()
         self.buckets_during_backward = 0
@@ -110,7 +118,7 @@ class DataParallel:
     def all_reduce_gradients(self, async_op: bool = True) -> None:
         """SUM all-reduce of the flat gradient buffer in large buckets (whatever an armed backward pass has not sent yet); pair with
         optimizer.grad_scale = 1/world."""
-        if self.world == 1:
+        if not self.active:
             return
         # backward produces the tail of the buffer (head, layer4) first: reduce from the end
         hi = self._next_hi if self._next_hi is not None else self.engine.G.numel()
@@ -127,11 +135,19 @@ class DataParallel:
         self._works.clear()
 
     def mean_scalars(self, values: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
-        """``self.log(..., sync_dist=True)`` for all logged scalars in ONE all-reduce (reference base.py:535-544)."""
-        if self.world == 1 or not values:
+        """``self.log(..., sync_dist=True)`` for all logged scalars in ONE all-reduce (reference base.py:535-544).  Only device-resident
+        scalars (the losses and metrics the step computed) travel: host-side values are configuration constants (the loss weights the
+        reference logs next to each loss), identical on every rank, so their mean is themselves - and uploading a pageable host scalar
+        would block the host until the stream has drained, once per step (and is not capturable in a HIP graph)."""
+        if not self.active or not values:
             return values
-        keys = sorted(values)
-        packed = torch.stack([values[k].detach().float().reshape(()).to(self.engine.device) for k in keys])
+        dev = self.engine.device
+        keys = sorted(k for k, v in values.items() if torch.is_tensor(v) and v.device.type == dev.type)
+        if not keys:
+            return values
+        packed = torch.stack([values[k].detach().float().reshape(()) for k in keys])
         dist.all_reduce(packed, group=self.pg)
         packed /= self.world
-        return {k: packed[i] for i, k in enumerate(keys)}
+        out = dict(values)
+        out.update({k: packed[i] for i, k in enumerate(keys)})
+        return out

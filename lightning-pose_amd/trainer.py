@@ -62,7 +62,7 @@ class Trainer:
     def _sync_logged(self, model) -> None:
         """``self.log(..., sync_dist=True)``: every marked scalar of the step becomes its mean over the ranks - ONE packed all-reduce"""
         names = getattr(model, "sync_logged", None)
-        if self.dp is not None and self.dp.world > 1 and names:
+        if self.dp is not None and self.dp.active and names:
             model.logged.update(self.dp.mean_scalars({k: model.logged[k] for k in names if k in model.logged}))
 
     def _graph_eligible(self, model) -> bool:
@@ -73,7 +73,7 @@ class Trainer:
         want = self._want_graph if self._want_graph is not None else graph_step.requested()
         if not want or self.accumulate_grad_batches != 1 or model.device.type != "cuda" or getattr(model.net, "profile", None) is not None:
             return False
-        if self.dp is not None and self.dp.world > 1 and os.environ.get("LP_HIP_GRAPH_DIST", "0") != "1":
+        if self.dp is not None and self.dp.active and os.environ.get("LP_HIP_GRAPH_DIST", "0") != "1":
             return False
         return True
 

@@ -156,6 +156,7 @@ class ViTEngine(Engine):
         self.nbt = torch.zeros((), dtype=torch.long)
         self.sync_bn, self.process_group = False, None   # no BatchNorm here; kept for the DataParallel wrapper
         self.sync_bn_messages = 0
+        self.grad_progress, self.single_backward = None, False   # gradient buckets leave during backward (Engine.backward, distributed.py)
         self._bwd_training = True
         self.profile = None
         self._wgrad_ws = None
@@ -397,6 +398,9 @@ class ViTEngine(Engine):
         qs = 3 * D
 
         d_feat = self._head_backward(T, B, g_heat)                      # (B, gh, gw, D) bf16
+        progress = self.grad_progress if (self.grad_progress is not None and self.single_backward) else None
+        if progress is not None:
+            progress(pl.n_backbone)  # the head's gradients (the tail of the flat buffer) are complete
         dx = torch.zeros(M, D, device=dev, dtype=torch.float32)         # gradient of the residual stream
         # every LayerNorm backward also leaves the updated stream gradient in bf16: it is the operand of the next Linear backward
         dx16 = self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn, want_bf16=True)
@@ -437,6 +441,8 @@ class ViTEngine(Engine):
                 trace[f"l{i}.dqkv"] = dqkv
             d_y1 = self._linear_bwd(L["qkv"], t("y1"), dqkv, M)
             dx16 = self._ln_bwd(d_y1, t("x_in"), t("m1"), t("r1"), L["ln1"], M, dx, want_bf16=i > 0)
+            if progress is not None:
+                progress(L["ln1"].g_off)  # everything from this layer's first parameter to the end of G is final
         if trace is not None:
             trace["tokens.dx"] = dx
         # ---- embeddings

@@ -192,6 +192,42 @@ def _engine_worker(rank, world, port, q):
         ratio = (eng.running_view(sb, "running_var") - 0.9) / (solo.running_view(sb, "running_var") - 0.9)
         if not torch.allclose(ratio, torch.full_like(ratio, (2 * m / (2 * m - 1)) / (m / (m - 1))), rtol=1e-4):
             bad.append("B:stem running_var (global count)")
+    # ---- (E) the ViT engine: no BatchNorm messages, gradient buckets leave layer by layer during its backward, the sum is exact
+    from lightning_pose_amd.vit_engine import ViTEngine
+
+    def make_vit():
+        torch.manual_seed(11)
+        e = ViTEngine(K, 2, dev, hidden=128, depth=3, heads=2, mlp=256, patch=16, pretrain_grid=3)
+        e.P.copy_(torch.randn(e.P.shape, generator=torch.Generator().manual_seed(3)) * 0.05)
+        for l in e.plan.norms():
+            e.P[l.g_off:l.g_off + 128] = 1.0
+        e.refresh_weight_copies()
+        return e
+
+    vit = make_vit()
+    vdp = DataParallel(vit, sync_bn=True, bucket_bytes=256 << 10)
+    vdp.broadcast_parameters()
+    calls["n"] = 0
+    _, vt = vit.forward(images[:2], True)
+    vit.zero_grad()
+    vit.single_backward = True
+    vdp.begin_step()
+    vit.backward(vt, g_heat[:2])
+    v_early = vdp.buckets_during_backward
+    vdp.all_reduce_gradients()
+    vdp.wait()
+    n_buckets = -(-vit.G.numel() * 4 // (256 << 10))
+    if calls["n"] != n_buckets:
+        bad.append(f"E:{calls['n']} all-reduces for {n_buckets} gradient buckets (a ViT has no SyncBatchNorm traffic)")
+    if not (2 <= v_early < n_buckets):
+        bad.append(f"E:{v_early} of {n_buckets} ViT gradient buckets left during backward")
+    if rank == 0:
+        vsolo = make_vit()
+        _, vts = vsolo.forward(images[:2], True)
+        vsolo.zero_grad()
+        vsolo.backward(vts, g_heat[:2])
+        if not torch.equal(vit.G, 2 * vsolo.G):
+            bad.append(f"E:summed ViT gradient != 2 x single-process gradient (max diff {float((vit.G - 2 * vsolo.G).abs().max()):.3e})")
     q.put((rank, not bad, "; ".join(bad[:6])))
     dist.destroy_process_group()
 

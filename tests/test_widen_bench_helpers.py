@@ -3,6 +3,7 @@ training line, the multiview C5 workload (--views), the inference line (--predic
 
 import json
 
+import pytest
 import torch
 
 import bench
@@ -85,6 +86,62 @@ def test_bench_two_ranks_gloo():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["sync_batchnorm"] is True and out["scaling"] == "weak" and out["value"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+LOOPBACK_ARGV = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "32", "--labeled", "2", "--unlabeled", "2", "--keypoints", "3", "--no-cpu-baseline",
+                 "--no-profile", "--no-secondary"]
+
+
+def _check_loopback_line(stdout: str, backend: str) -> dict:
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    comm = out["config"]["comm_per_step"]
+    assert out["n_gpus"] == 1 and out["config"]["sync_batchnorm"] is True and comm["backend"] == backend
+    assert comm["sync_bn_messages"] > 0 and comm["grad_buckets"] >= 1 and comm["logged_scalar_messages"] == 1
+    assert out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]  # finite
+    return out
+
+
+def test_bench_loopback_gloo():
+    """LP_DIST_LOOPBACK=1: every collective of the step is issued on a world of one rank (here gloo + emulated kernels)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               LP_DIST_BACKEND="gloo", LP_DIST_LOOPBACK="1", HIPEMU_THREADS="4")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_bench_2rank_probe.py"), *LOOPBACK_ARGV], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    _check_loopback_line(p.stdout, "gloo")
+
+
+@pytest.mark.gpu
+def test_bench_loopback_rccl_on_device():
+    """The same on the device over RCCL (backend "nccl"): communicator bound to the rank's GPU, gradient buckets handed from the
+    weight-gradient side stream to RCCL's stream during backward, SyncBatchNorm messages between kernels of one stream, the packed scalar
+    message - the stream semantics the gloo tests cannot see.  One rank is all a single-GPU box offers; the arithmetic is the N = 1 step's."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               LP_DIST_LOOPBACK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LP_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *LOOPBACK_ARGV], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    _check_loopback_line(p.stdout, "nccl")
 
 
 def test_smoke_entry_point_body(stack_backend, capsys):
