@@ -350,7 +350,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     if args.predict:
         return predict_bench(args, model, batch, dev, rank, world)
-    trainer = Trainer(max_epochs=1, data_parallel=dist.is_initialized(), sync_batchnorm=True, hip_graph=bool(args.graph))
+    trainer = Trainer(max_epochs=1, data_parallel=dist.is_initialized(), sync_batchnorm=not args.no_sync_bn, hip_graph=bool(args.graph))
     trainer.setup(model)
     model.train()
     model.total_unsupervised_importance = torch.tensor(1.0)
@@ -403,6 +403,8 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     if not solo:
         comm["backend"] = dist.get_backend()
         comm["buckets_sent_during_backward"] = trainer.dp.buckets_during_backward
+        comm["sync_bn_transport"] = ("librccl ncclAllReduce on the compute stream (LP_SYNCBN_DIRECT=1)" if getattr(model.net, "direct_comm", None) is not None
+                                     else "torch.distributed all_reduce")
     mem1 = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
     memory = {"max_allocated_gb": round(mem1.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2), "max_reserved_gb": round(mem1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
               "device_allocs_in_timed_steps": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
@@ -506,6 +508,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip the short secondary lines (256 px, ViT-S, multiview, "
                     "inference) the default single-GPU run appends under \"secondary\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNorm statistics (the reference sets sync_batchnorm=True, train.py:427; A/B only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args(argv)
 

@@ -63,6 +63,11 @@ class DataParallel:
         self.bucket_elems = max(1, bucket_bytes // 4)
         engine.process_group = process_group
         engine.sync_bn = bool(sync_bn and self.active)
+        from . import rccl
+
+        if engine.sync_bn and rccl.requested() and getattr(engine, "direct_comm", None) is None and hasattr(engine, "plan") \
+                and getattr(engine.plan, "bns", None):
+            engine.direct_comm = rccl.DirectComm(engine.device, process_group)   # fails loudly: the flag asked for it
         self._works: list = []
         self._next_hi: int | None = None   # overlapped mode: upper end of the next bucket to send (None: no step in flight)
         self.buckets_during_backward = 0
@@ -101,10 +106,20 @@ class DataParallel:
         self.engine.grad_progress = self._on_progress
 
     def _send(self, lo: int, hi: int, async_op: bool = True) -> None:
-        join = getattr(self.engine, "_join_side_stream", None)
+        e = self.engine
+        side = getattr(e, "_side", None)
+        if async_op and side is not None and getattr(e, "_side_busy", False) and e.device.type == "cuda":
+            # The weight gradients of this range run on the engine's side stream.  The collective is issued FROM that stream (ordered behind
+            # the main stream's current point as well: the BatchNorm / bias gradients of the range are main-stream kernels), so RCCL's
+            # stream waits for exactly what the bucket needs and the main stream - the data-gradient chain - never waits for anything.
+            side.wait_stream(torch.cuda.current_stream(e.device))
+            with torch.cuda.stream(side):
+                self._works.append(dist.all_reduce(e.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            return
+        join = getattr(e, "_join_side_stream", None)
         if join is not None:
             join()  # the weight gradients of this range run on the engine's side stream: the collective is ordered after them
-        self._works.append(dist.all_reduce(self.engine.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
+        self._works.append(dist.all_reduce(e.G[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op))
 
     def _on_progress(self, lo_done: int) -> None:
         while self._next_hi is not None and self._next_hi > 0:

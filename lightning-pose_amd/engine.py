@@ -220,6 +220,7 @@ class Engine:
         self._bwd_training = True     # mode of the forward pass whose backward is running (eval: no batch-statistics terms)
         self.sync_bn_messages = 0     # SyncBatchNorm all-reduces issued so far (bench.py reports them per step)
         self.process_group = None
+        self.direct_comm = None       # rccl.DirectComm: SyncBatchNorm messages on the compute stream (LP_SYNCBN_DIRECT=1)
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
         self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
@@ -452,6 +453,14 @@ class Engine:
         what a parity class of the stride-2 data gradients covers) decides, every other map is 4^k times larger."""
         return n0 > 0 and H % 32 == 0 and W % 32 == 0 and (n0 * (H // 32) * (W // 32)) % 128 == 0
 
+    def _sync_stats(self, t: torch.Tensor) -> None:
+        """SUM of one SyncBatchNorm message over the ranks, in place: through torch.distributed (ProcessGroupNCCL's own stream, two event
+        hand-offs per message), or - ``direct_comm`` set by DataParallel under LP_SYNCBN_DIRECT=1 - one ncclAllReduce on the compute stream"""
+        if self.direct_comm is not None:
+            self.direct_comm.all_reduce_sum_(t, ops._stream())
+        else:
+            dist.all_reduce(t, group=self.process_group)
+
     def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False, seg: int = 0):
         """-> (mean, invstd) of this pass, each (segments, C) flattened: batch statistics (running statistics updated, segment by
         segment) in training, running statistics otherwise"""
@@ -466,7 +475,7 @@ class Engine:
                     check(self._lib.lp_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), ops._stream()), "lp_bn_stats")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:  # ONE message carries every segment's [sum, sum of squares]
-                dist.all_reduce(sums, group=self.process_group)
+                self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
@@ -764,7 +773,7 @@ class Engine:
             # batch-statistics correction terms (d gamma / d beta above are the same sums in both modes)
             sums = torch.zeros_like(sums)
         elif self.sync_bn:
-            dist.all_reduce(sums, group=self.process_group)
+            self._sync_stats(sums)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)
@@ -900,7 +909,7 @@ class Engine:
         if not self._bwd_training:
             ssum = torch.zeros_like(ssum)
         elif self.sync_bn:
-            dist.all_reduce(ssum, group=self.process_group)
+            self._sync_stats(ssum)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)

@@ -72,7 +72,7 @@ class Fp32Engine(Engine):
                 check(self._lib.lp_f32_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), ops._stream()), "lp_f32_bn_stats")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:
-                dist.all_reduce(sums, group=self.process_group)
+                self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
@@ -109,7 +109,7 @@ class Fp32Engine(Engine):
         if not self._bwd_training:
             sums = torch.zeros_like(sums)  # eval-mode BatchNorm: a fixed affine map, no batch-statistics terms
         elif self.sync_bn:
-            dist.all_reduce(sums, group=self.process_group)
+            self._sync_stats(sums)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)

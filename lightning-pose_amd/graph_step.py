@@ -13,8 +13,9 @@ data-gradient weight copies), the anneal weight of the unsupervised losses, trai
 AnnealWeight / UnfreezeBackbone / MultiStepLR - reference callbacks.py:32-196) the step is captured again.  Learning rates themselves
 and Adam's step count are NOT baked in: they are read from device memory (lp_adam_step_dev).
 
-Opt-in: ``Trainer(hip_graph=True)`` or ``LP_HIP_GRAPH=1``.  Single-process only by default (collectives inside a captured graph depend on
-the RCCL build; ``LP_HIP_GRAPH_DIST=1`` tries it), never while bench.py's per-launch events are on."""
+Opt-in: ``Trainer(hip_graph=True)`` or ``LP_HIP_GRAPH=1``.  Single-process only by default; with a process group ``LP_HIP_GRAPH_DIST=1``
+captures the collectives too (verified on RCCL 2.26 in loop-back on one MI355X; never run across GPUs).  Never while
+bench.py's per-launch events are on."""
 
 from __future__ import annotations
 
@@ -81,7 +82,10 @@ class GraphedStep:
             nbt0 = int(net.nbt) if hasattr(net, "nbt") else 0
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # with a process group alive, ProcessGroupNCCL's watchdog thread polls events while this thread captures: only THIS thread's
+            # calls are part of the capture ("thread_local"); the default mode would fail the capture on the watchdog's query
+            mode = "thread_local" if (trainer.dp is not None and trainer.dp.active) else "global"
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.loss = trainer._eager_batch(model, self.static, batch_idx, count=False)
             # the Python side of the step ran once while its kernels were only recorded: keep what it did per step, undo this instance
             if hasattr(net, "nbt"):
