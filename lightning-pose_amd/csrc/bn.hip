@@ -354,55 +354,54 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const unsigned
                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, int B, int Hi, int Wi, int C, int Ho,
                                                                   int Wo, unsigned short* __restrict__ Y, unsigned char* __restrict__ IDX) {
-    const int chunks = C >> 3;
-    const size_t total = (size_t)B * Ho * Wo * chunks;
-    int have = -1;
+    // Row walk: a workgroup takes whole output rows (b, ho); a thread keeps ONE channel chunk (chunks = C/8 divides 256) and strides over
+    // the row's pixels - no per-element index arithmetic beyond one multiply-add (the flat-index form spent three 64-bit divisions per
+    // 16 bytes: 5 - 8 % of these kernels' time).
+    const int chunks = C >> 3, ppi = 256 / chunks;
+    const int ch = threadIdx.x % chunks, pl = threadIdx.x / chunks;
     float mu[8], sc[8], be[8];
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
-        const int ch = (int)(q % chunks);
-        if (ch != have) {  // (a lane keeps its chunk whenever the grid stride is a multiple of the row length: every ResNet width)
-            have = ch;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = mean[ch * 8 + i];
+        sc[i] = invstd[ch * 8 + i] * gamma[ch * 8 + i];
+        be[i] = beta[ch * 8 + i];
+    }
+    const int rows = B * Ho;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / Ho, ho = row - b * Ho;
+        for (int wo = pl; wo < Wo; wo += ppi) {
+            float m[8];
+            unsigned char arg[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                mu[i] = mean[ch * 8 + i];
-                sc[i] = invstd[ch * 8 + i] * gamma[ch * 8 + i];
-                be[i] = beta[ch * 8 + i];
+                m[i] = -INFINITY;
+                arg[i] = 0;
             }
-        }
-        size_t p = q / chunks;
-        const int wo = (int)(p % Wo);
-        p /= Wo;
-        const int ho = (int)(p % Ho), b = (int)(p / Ho);
-        float m[8];
-        unsigned char arg[8];
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hi = ho * 2 - 1 + kh;
+                if (hi < 0 || hi >= Hi) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int wi = wo * 2 - 1 + kw;
+                    if (wi < 0 || wi >= Wi) continue;
+                    float x[8];
+                    unpack8(*reinterpret_cast<const u16x8*>(Z + (((size_t)b * Hi + hi) * Wi + wi) * C + ch * 8), x);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            m[i] = -INFINITY;
-            arg[i] = 0;
-        }
-        for (int kh = 0; kh < 3; ++kh) {
-            const int hi = ho * 2 - 1 + kh;
-            if (hi < 0 || hi >= Hi) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int wi = wo * 2 - 1 + kw;
-                if (wi < 0 || wi >= Wi) continue;
-                float x[8];
-                unpack8(*reinterpret_cast<const u16x8*>(Z + (((size_t)b * Hi + hi) * Wi + wi) * C + ch * 8), x);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float a = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(x[i] - mu[i], sc[i], be[i]), 0.f)));
-                    if (a > m[i]) {
-                        m[i] = a;
-                        arg[i] = (unsigned char)(kh * 3 + kw);
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(x[i] - mu[i], sc[i], be[i]), 0.f)));
+                        if (a > m[i]) {
+                            m[i] = a;
+                            arg[i] = (unsigned char)(kh * 3 + kw);
+                        }
                     }
                 }
             }
+            const size_t q = ((size_t)row * Wo + wo) * chunks + ch;
+            *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(m);
+            uint2 packed;
+            packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+            packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+            *reinterpret_cast<uint2*>(IDX + q * 8) = packed;
         }
-        *reinterpret_cast<u16x8*>(Y + q * 8) = pack8(m);
-        uint2 packed;
-        packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
-        packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
-        *reinterpret_cast<uint2*>(IDX + q * 8) = packed;
     }
 }
 
@@ -425,21 +424,21 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
         be[i] = beta[ch * 8 + i];
         s0[i] = s1[i] = 0.f;
     }
-    const size_t pixels = (size_t)B * Hi * Wi;
-    for (size_t p = (size_t)blockIdx.x * lanes_r + rl; p < pixels; p += (size_t)gridDim.x * lanes_r) {
-        size_t t = p;
-        const int wi = (int)(t % Wi);
-        t /= Wi;
-        const int hi = (int)(t % Hi), b = (int)(t / Hi);
-        float z[8], g[8];
-        unpack8(*reinterpret_cast<const u16x8*>(Z + p * C + ch * 8), z);
-        pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
+    const int rows = B * Hi;   // row walk as in bn_relu_maxpool_fwd_kernel: (b, hi) per workgroup step, pixels of the row over the row lanes
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / Hi, hi = row - b * Hi;
+        for (int wi = rl; wi < Wi; wi += lanes_r) {
+            const size_t p = (size_t)row * Wi + wi;
+            float z[8], g[8];
+            unpack8(load_stream8(Z + p * C + ch * 8), z);
+            pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float zc = z[i] - mu[i];
-            if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
-            s0[i] += g[i];
-            s1[i] = fmaf(g[i], zc * is[i], s1[i]);
+            for (int i = 0; i < 8; ++i) {
+                const float zc = z[i] - mu[i];
+                if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
+                s0[i] += g[i];
+                s1[i] = fmaf(g[i], zc * is[i], s1[i]);
+            }
         }
     }
 #pragma unroll
@@ -470,40 +469,36 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned c
                                                                 const float* __restrict__ beta, const float* __restrict__ sums,
                                                                 float inv_count, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                                                 unsigned short* __restrict__ DX) {
-    const int chunks = C >> 3;
-    const size_t total = (size_t)B * Hi * Wi * chunks;
-    int have = -1;
+    const int chunks = C >> 3, ppi = 256 / chunks;   // row walk as in bn_relu_maxpool_fwd_kernel
+    const int ch = threadIdx.x % chunks, pl = threadIdx.x / chunks;
     float mu[8], is[8], sc[8], be[8], ga[8], k0[8], k1[8];
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
-        const int ch = (int)(q % chunks);
-        if (ch != have) {
-            have = ch;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = ch * 8 + i;
+        mu[i] = mean[c];
+        is[i] = invstd[c];
+        ga[i] = gamma[c] * is[i];
+        sc[i] = ga[i];
+        be[i] = beta[c];
+        k0[i] = sums[c] * inv_count;
+        k1[i] = sums[C + c] * inv_count;
+    }
+    const int rows = B * Hi;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / Hi, hi = row - b * Hi;
+        for (int wi = pl; wi < Wi; wi += ppi) {
+            const size_t q = ((size_t)row * Wi + wi) * chunks + ch;
+            float z[8], g[8], o[8];
+            unpack8(load_stream8(Z + q * 8), z);
+            pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int c = ch * 8 + i;
-                mu[i] = mean[c];
-                is[i] = invstd[c];
-                ga[i] = gamma[c] * is[i];
-                sc[i] = ga[i];
-                be[i] = beta[c];
-                k0[i] = sums[c] * inv_count;
-                k1[i] = sums[C + c] * inv_count;
+                const float zc = z[i] - mu[i];
+                if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
+                o[i] = ga[i] * (g[i] - k0[i] - zc * is[i] * k1[i]);
             }
+            *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(o);
         }
-        size_t p = q / chunks;
-        const int wi = (int)(p % Wi);
-        p /= Wi;
-        const int hi = (int)(p % Hi), b = (int)(p / Hi);
-        float z[8], g[8], o[8];
-        unpack8(load_stream8(Z + q * 8), z);
-        pool_gather(IDX, DY, b, hi, wi, ch, C, Ho, Wo, g);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float zc = z[i] - mu[i];
-            if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
-            o[i] = ga[i] * (g[i] - k0[i] - zc * is[i] * k1[i]);
-        }
-        *reinterpret_cast<u16x8*>(DX + q * 8) = pack8(o);
     }
 }
 
@@ -573,6 +568,13 @@ static int bn_grid(size_t n_chunks, int chunks) {
         blocks = (blocks + m - 1) / m * m;
     }
     return (int)blocks;
+}
+
+// workgroups for the stem's row-walk kernels: one row per step, grid-stride beyond 16 workgroups per CU (4 for the reduction, whose
+// workgroups each end in 2 C atomics)
+static int pool_row_blocks(int rows, int per_cu = 16) {
+    const int cap = 256 * per_cu;
+    return rows < 1 ? 1 : (rows > cap ? cap : rows);
 }
 
 static int grid_for(size_t work_items) {
@@ -735,9 +737,9 @@ extern "C" int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const fl
                                       int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(z && mean && invstd && gamma && beta && y && argmax_u8 && B > 0 && Hi > 0 && Wi > 0 && C > 0);
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    if (C % 8 != 0 || 256 % (C / 8) != 0 || (long long)B * Hi >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
-    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(pool_row_blocks(B * Ho)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi, Wi, C, Ho, Wo, (unsigned short*)y,
                        (unsigned char*)argmax_u8);
     return launch_status();
@@ -752,7 +754,7 @@ extern "C" int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, cons
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     const long long pixels = (long long)B * Hi * Wi;
     if (pixels >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(colreduce_blocks((int)pixels, C)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pool_row_blocks(B * Hi, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi,
                        Wi, C, Ho, Wo, sums, dbeta_acc, dgamma_acc);
     return launch_status();
@@ -763,9 +765,9 @@ extern "C" int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const
                                     void* dx, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && count > 0.f);
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    if (C % 8 != 0 || 256 % (C / 8) != 0 || (long long)B * Hi >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
-    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for((size_t)B * Hi * Wi * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(pool_row_blocks(B * Hi)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
                        1.f / count, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
     return launch_status();
