@@ -18,6 +18,26 @@ def test_heatmap_gen_golden(golden):
     np.testing.assert_allclose(emu.heatmap_gen(g["kp"], None, 128, 160, 32, 40, sigma=2.0), g["hm_rect"], atol=2e-7)
 
 
+@pytest.mark.parametrize("h,w", [(24, 30), (7, 5), (96, 96), (520, 12), (3, 516)])
+def test_heatmap_gen_paths_vs_oracle(h, w):
+    """every store path of heatmap_gen_kernel against the oracle: separable profiles with 16-byte stores (w % 4 == 0), with scalar stores
+    (ragged widths), and the per-pixel form for an axis longer than the profile buffers (> 512); out-of-range, NaN and edge keypoints"""
+    gen = torch.Generator().manual_seed(h * 31 + w)
+    img_h, img_w = 4 * h, 4 * w
+    kp = torch.rand(3, 5, 2, generator=gen) * torch.tensor([img_w, img_h], dtype=torch.float32)
+    kp[0, 0] = torch.tensor([float("nan"), 3.0])
+    kp[0, 1] = torch.tensor([-30.0, 5.0])              # more than one heat-map pixel outside: zeros
+    kp[1, 0] = torch.tensor([0.0, 0.0])
+    kp[1, 1] = torch.tensor([img_w - 1e-3, img_h - 1e-3])
+    kp[2, 0] = torch.tensor([-2.0, img_h + 2.0])       # within one heat-map pixel of the border: clamped Gaussian
+    vis = torch.tensor([[2, 2, 1, 0, 2], [2, 2, 2, 1, 0], [2, 0, 1, 2, 2]], dtype=torch.int32)
+    for v in (None, vis):
+        want = O.generate_heatmaps(kp, img_h, img_w, (h, w), sigma=1.25, visibility=v).numpy()
+        got = emu.heatmap_gen(kp.numpy(), None if v is None else v.numpy(), img_h, img_w, h, w)
+        np.testing.assert_allclose(got, want, atol=2e-7)
+        np.testing.assert_allclose(got.sum((2, 3)), want.sum((2, 3)), atol=2e-6)
+
+
 def test_heatmap_mse_golden_and_grad(golden):
     g = golden("losses")
     loss, grad = emu.heatmap_mse(g["hm_targ"], g["hm_pred"], gout=0.7)
