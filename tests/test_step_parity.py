@@ -23,7 +23,10 @@ from tests.golden.step_inputs import PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS
 TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, argmax=1.0, hm_loss_rel=1e-3, px_abs=1e-4, stem_cos=0.9995,
                     head_cos=0.99999, norm_rel=5e-3, norm_worst=1e-2),
        "bf16-mixed": dict(rel=1e-2, kp_max=1.5, kp_mean=0.3, conf=0.1, peak=0.1, argmax=0.8, hm_loss_rel=0.25, px_abs=0.15, stem_cos=0.9,
-                          head_cos=0.97, norm_rel=0.25, norm_worst=0.3)}
+                          head_cos=0.97, norm_rel=0.25, norm_worst=0.35)}
+# (norm_worst: the maximum over ~160 parameter tensors of |norm ratio - 1|, reached by BatchNorm weights / biases of the deep blocks whose
+# gradients are small signed sums.  On the device it varies from run to run - small launches accumulate their BatchNorm sums with atomics -
+# over 12 runs per config: c1 0.14 .. 0.19, c2 0.06 .. 0.17, c5 0.08 .. 0.14, s64 0.05 .. 0.17, c4 0.009 (profiles/r02_flake_step_parity.log))
 REPORT: list = []
 PEAK_MIN = 0.03   # maps the reference itself predicts with a peak below this are not fitted (the unlabeled NaN keypoint, a few of c2's
                   # 17 x 12 maps): nearly flat, so soft-argmax(T = 1000) is ill-conditioned there; they are compared in fp32 only
@@ -152,17 +155,25 @@ def _check(name, dev, precision, g):
         assert float(pca.parameters["epsilon"]) == pytest.approx(float(g["pca_eps"]), rel=1e-4)
     # ---- parameter gradients: head and stem tensors in full, one norm per parameter tensor
     grads = {n_: p_.grad.detach().float().cpu() for n_, p_ in model.named_parameters() if p_.grad is not None}
+    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
     for k in [k for k in g if k.startswith("grad/")]:
         a, b = grads[k[len("grad/"):]].reshape(-1), g.t(k).reshape(-1)
         if float(b.norm()) < 1e-6:   # (the last layer's bias: soft-max is shift-invariant, its gradient is identically ~0)
             continue
         cos = float(F.cosine_similarity(a, b, dim=0))
         cos_min = t["stem_cos"] if k.startswith("grad/backbone") else t["head_cos"]
-        assert cos > cos_min and float(a.norm()) == pytest.approx(float(b.norm()), rel=t["norm_rel"]), (k, cos, float(a.norm()), float(b.norm()))
-    norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
-    worst = max(abs(float(grads[n_].norm()) / (w + 1e-30) - 1.0) for n_, w in norms.items() if w > 1e-6)
-    assert worst < t["norm_worst"], worst
-    print("\nPARITY", name, precision, REPORT[-4:])
+        ok = cos > cos_min and float(a.norm()) == pytest.approx(float(b.norm()), rel=t["norm_rel"])
+        wk = k[:-len("bias")] + "weight"
+        if not ok and k.endswith(".bias") and wk in g and float(b.norm()) < 1e-2 * float(g.t(wk).norm()):
+            # A bias gradient is a sum of signed per-pixel terms; where they cancel to < 1 % of the layer's weight gradient (c1's first
+            # deconvolution: 1.6e-5 against 4.6e-3) its DIRECTION is rounding noise amplified by the cancellation - the bf16 path sat at
+            # cos 0.967 .. 0.975 around the 0.97 bar, 2 failures in 20 runs.  Such a tensor is held to an absolute error on the scale it
+            # was summed at instead: the layer's weight gradient.
+            ok = float((a - b).norm()) <= (1e-5 if precision == "fp32" else 2e-3) * float(g.t(wk).norm())
+        assert ok, (k, cos, float(a.norm()), float(b.norm()))
+    worst, worst_name = max((abs(float(grads[n_].norm()) / (w + 1e-30) - 1.0), n_) for n_, w in norms.items() if w > 1e-6)
+    assert worst < t["norm_worst"], (worst, worst_name, norms[worst_name])
+    print("\nPARITY", name, precision, REPORT[-4:], "worst gradient-norm ratio - 1:", round(worst, 4), worst_name, "%.2e" % norms[worst_name])
     return model
 
 
