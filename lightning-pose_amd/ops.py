@@ -78,22 +78,42 @@ class DecodeFrameMap:
     def __init__(self, transforms: torch.Tensor | None, is_multiview: bool, bbox: torch.Tensor | None, num_views: int,
                  model_h: int, model_w: int, num_keypoints: int):
         self.keep = []
+        self.rows_needed: int | None = None
+        self.bbox_rows: int | None = None
         tf_mode, tf = _lib.TF_NONE, None
         if transforms is not None and transforms.shape[-1] == 3:
             tf = _f32c(transforms)
             if is_multiview:
                 tf_mode = _lib.TF_PER_VIEW
-            elif tf.dim() == 2:
+            elif tf.dim() == 2 or tf.shape[0] == 1:
+                # one matrix for the whole batch: (2, 3), or (1, 2, 3) as the DALI pipeline hands it over - the reference replicates a
+                # single inverse over the batch (data/utils.py:176-180)
                 tf_mode = _lib.TF_SINGLE
             else:
                 tf_mode = _lib.TF_PER_FRAME
+                self.rows_needed = int(tf.shape[0])   # one matrix per frame: checked against the batch where it is known (check_batch)
             self.keep.append(tf)
         bb = None
         if bbox is not None:
             bb = _f32c(bbox)
+            self.bbox_rows = int(bb.shape[0]) if bb.dim() == 2 else None
+            self._bbox = bb
             self.keep.append(bb)
         self.struct = _lib.FrameMap(_p(tf), tf_mode, _p(bb), 4 * num_views, max(1, num_keypoints // num_views),
                                     float(model_h), float(model_w))
+
+    def check_batch(self, b: int) -> None:
+        """the kernels index the per-frame tables by frame: a table shorter than the batch would be read out of bounds (the reference fails
+        in torch.bmm / broadcasting on the same inputs)"""
+        if self.rows_needed is not None and self.rows_needed != b:
+            raise ValueError(f"{self.rows_needed} affine transforms for a batch of {b} frames (one per frame, or a single (2, 3) / (1, 2, 3))")
+        if self.bbox_rows is not None and self.bbox_rows != b:
+            if self.bbox_rows != 1:
+                raise ValueError(f"{self.bbox_rows} bounding boxes for a batch of {b} frames")
+            bb = self._bbox.expand(b, -1).contiguous()   # one box for every frame: what broadcasting gives the reference (data/bboxes.py:222-288)
+            self.keep.append(bb)
+            self.struct.bbox = bb.data_ptr()
+            self.bbox_rows = b
 
 
 class _DecodeFn(torch.autograd.Function):
@@ -103,6 +123,7 @@ class _DecodeFn(torch.autograd.Function):
         ctx.in_dtype = heat.dtype
         heat = heat.to(torch.float32).contiguous()
         b, k, h, w = heat.shape
+        frame_map.check_batch(b)
         tables, keep = _device_tables(h, w, ds, heat.device)
         kp_aug = torch.empty(b, k, 2, device=heat.device, dtype=torch.float32)
         kp_frame = torch.empty_like(kp_aug)
@@ -135,6 +156,7 @@ class _FrameMapFn(torch.autograd.Function):
         require_device(kp)
         x = _f32c(kp)
         b, k = x.shape[0], x.shape[1] // 2
+        frame_map.check_batch(b)
         out = torch.empty_like(x)
         check(_lib.lib().lp_frame_map_apply(_p(x), b, k, C.byref(frame_map.struct), 0, _p(out), _stream()), "lp_frame_map_apply")
         ctx.frame_map = frame_map
