@@ -217,6 +217,8 @@ class _HeatmapLossFn(torch.autograd.Function):
         require_device(targ, pred)
         ctx.in_dtype = pred.dtype
         targ, pred = _f32c(targ), _f32c(pred)
+        if pred.dim() != 4 or targ.shape != pred.shape:   # raw pointers from here on: a shape the reference's mse_loss would refuse
+            raise ValueError(f"heat-map targets {tuple(targ.shape)} and predictions {tuple(pred.shape)} must both be (B, K, h, w)")
         b, k, h, w = pred.shape
         ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(b, k), device=pred.device, dtype=torch.uint8)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
@@ -255,6 +257,8 @@ class _UnimodalFn(torch.autograd.Function):
         ctx.in_dtype = pred.dtype
         kp, pred, conf = _f32c(kp_aug), _f32c(pred), _f32c(conf)
         s, k, h, w = pred.shape
+        if kp.numel() != s * k * 2 or tuple(conf.shape) != (s, k):
+            raise ValueError(f"unimodal_mse: keypoints {tuple(kp.shape)} / confidences {tuple(conf.shape)} do not match heat-maps {tuple(pred.shape)}")
         ws = torch.empty(_lib.lib().lp_heatmap_mse_workspace_bytes(s, k), device=pred.device, dtype=torch.uint8)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
         check(_lib.lib().lp_unimodal_mse_fwd(_p(kp), _p(pred), _p(conf), s, k, img_h, img_w, h, w, sigma, thr, _p(loss), _p(ws),
@@ -327,6 +331,8 @@ def temporal_loss(keypoints: torch.Tensor, confidences: torch.Tensor | None, eps
     s = kp.shape[0]
     k = kp.shape[1] // 2
     conf = _f32c(confidences) if confidences is not None else None
+    if kp.dim() != 2 or kp.shape[1] % 2 or (conf is not None and tuple(conf.shape) != (s, k)):
+        raise ValueError(f"temporal loss: keypoints {tuple(kp.shape)} must be (S, 2K) and confidences (S, K)")
     eps = _device_epsilon(epsilon, k, kp.device)
     loss = torch.empty(1, device=kp.device, dtype=torch.float32)
     grad = torch.empty_like(kp)
@@ -398,6 +404,9 @@ def pca_loss(keypoints: torch.Tensor, index: torch.Tensor, mean: torch.Tensor, k
     index = index.to(torch.int32).contiguous()
     s, k = kp.shape[0], kp.shape[1] // 2
     rows, pts = index.shape
+    if mean.numel() != 2 * pts or kept_eigenvectors.dim() != 2 or kept_eigenvectors.shape[1] != 2 * pts:
+        raise ValueError(f"pca loss: mean {tuple(mean.shape)} / eigenvectors {tuple(kept_eigenvectors.shape)} do not span the "
+                         f"{2 * pts} coordinates of a sample ({pts} points)")
     loss = torch.empty(1, device=kp.device, dtype=torch.float32)
     grad = torch.empty_like(kp)
     check(_lib.lib().lp_pca_fwd_bwd(_p(kp), s, k, _p(index), rows, pts, _p(mean), _p(kept_eigenvectors),
@@ -408,6 +417,8 @@ def pca_loss(keypoints: torch.Tensor, index: torch.Tensor, mean: torch.Tensor, k
 def rmse(keypoints_targ: torch.Tensor, keypoints_pred: torch.Tensor) -> torch.Tensor:
     require_device(keypoints_targ, keypoints_pred)
     t, p = _f32c(keypoints_targ), _f32c(keypoints_pred)
+    if t.shape != p.shape or t.numel() % 2:
+        raise ValueError(f"rmse: target {tuple(t.shape)} and predicted {tuple(p.shape)} keypoints must both be (B, 2K)")
     loss = torch.empty(1, device=p.device, dtype=torch.float32)
     check(_lib.lib().lp_rmse_fwd(_p(t), _p(p), t.numel() // 2, _p(loss), _stream()), "lp_rmse_fwd")
     return loss.reshape(())

@@ -91,3 +91,69 @@ def test_single_transform_shapes_and_table_lengths(stack_backend):
         torch.testing.assert_close(got, want, atol=1e-4, rtol=1e-5)
     with pytest.raises(ValueError, match="affine transforms for a batch"):
         undo_affine_transform_batch(kp, tf.unsqueeze(0).repeat(3, 1, 1).to(dev), False)
+
+
+def test_multiview_transforms_as_the_dali_wrapper_stacks_them(stack_backend):
+    """LitDaliWrapper stacks one (1, 2, 3) matrix per view (reference data/video/dali.py:311-314): transforms arrive as (V, 1, 2, 3), and
+    undo_affine_transform_batch indexes transforms[v] - a (1, 2, 3) single transform - per view (data/utils.py:219-228)"""
+    from lightning_pose_amd.data.utils import undo_affine_transform_batch
+
+    dev = stack_backend
+    g = torch.Generator().manual_seed(5)
+    V, Kv, S = 2, 3, 4
+    kp = (torch.rand(S, 2 * Kv * V, generator=g) * 60).to(dev)
+    tf = torch.tensor([[[1.0, 0.05, 1.0], [-0.05, 1.0, 0.5]], [[0.9, 0.0, 2.0], [0.0, 1.1, -1.0]]])
+    want = O.undo_affine(kp.cpu(), tf, True)
+    for form in (tf, tf.unsqueeze(1)):
+        got = undo_affine_transform_batch(kp, form.to(dev), True).cpu()
+        torch.testing.assert_close(got, want, atol=1e-4, rtol=1e-5)
+
+
+def test_predict_step_nonsquare_eval_mode(stack_backend):
+    """eval-mode prediction (folded BatchNorm, no tape) on non-square frames: keypoints land in the frame's coordinate system through the
+    non-square bbox map; compared with the oracle's eval forward + decode on the same weights"""
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import HeatmapTracker
+
+    dev = stack_backend
+    K, H, W, B = 4, 64, 96, 3
+    model = HeatmapTracker(num_keypoints=K, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
+                           pretrained=False, torch_seed=17, device=dev, precision="fp32")
+    ref = O.OracleTracker(K, 2, torch_seed=17)
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(B, 3, H, W, generator=g)
+    bbox = torch.tensor([[10.0, 20.0, 128.0, 288.0]]).repeat(B, 1)
+    batch = {"images": images.to(dev), "keypoints": torch.zeros(B, 2 * K, device=dev), "bbox": bbox.to(dev), "idxs": torch.arange(B)}
+    model.eval()
+    ref.eval()
+    with torch.no_grad():
+        kp, conf = model.predict_step(batch, 0)
+        heat = ref(images)
+        aug, want_conf = O.soft_argmax(heat, 2, 1000.0)
+        want = O.model_to_frame(aug, H, W, bbox, 1)
+    assert kp.shape == (B, 2 * K) and conf.shape == (B, K)
+    torch.testing.assert_close(conf.cpu(), want_conf, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(kp.cpu(), want, atol=0.3, rtol=0)   # (flat random-init maps: see the test above; 0.3 frame px = 0.1 model px)
+
+
+def test_loss_wrappers_refuse_mismatched_shapes(stack_backend):
+    """the C ABI takes raw pointers: every wrapper checks, on the host, the shapes the reference's own torch expressions would refuse -
+    a mismatch is an error, never an out-of-bounds read"""
+    from lightning_pose_amd import ops
+
+    dev = stack_backend
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    with pytest.raises(ValueError, match="heat-map targets"):
+        ops.heatmap_mse(z(2, 3, 8, 8), z(2, 3, 16, 16))
+    with pytest.raises(ValueError, match="temporal loss"):
+        ops.temporal_loss(z(4, 6), z(4, 2), torch.tensor(0.0), 0.0)
+    with pytest.raises(ValueError, match="temporal epsilon"):
+        ops.temporal_loss(z(4, 6), z(4, 3), torch.tensor([0.1, 0.2]), 0.0)
+    with pytest.raises(ValueError, match="unimodal_mse"):
+        ops.unimodal_mse(z(4, 6), z(4, 3, 8, 8), z(4, 2), 32, 32)
+    with pytest.raises(ValueError, match="pca loss"):
+        ops.pca_loss(z(4, 6), torch.zeros(1, 3, dtype=torch.int32, device=dev), z(4), z(2, 6), 0.0)
+    with pytest.raises(ValueError, match="rmse"):
+        ops.rmse(z(4, 6), z(4, 8))
+    with pytest.raises(ValueError, match="bounding boxes"):
+        ops.decode(torch.full((4, 3, 8, 8), 1 / 64, device=dev), 2, 1000.0, ops.DecodeFrameMap(None, False, z(3, 4) + 1, 1, 32, 32, 3))
