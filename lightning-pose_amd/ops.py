@@ -80,6 +80,7 @@ class DecodeFrameMap:
         self.keep = []
         self.rows_needed: int | None = None
         self.bbox_rows: int | None = None
+        self._tf = self._bbox = None
         tf_mode, tf = _lib.TF_NONE, None
         if transforms is not None and transforms.shape[-1] == 3:
             tf = _f32c(transforms)
@@ -92,6 +93,7 @@ class DecodeFrameMap:
             else:
                 tf_mode = _lib.TF_PER_FRAME
                 self.rows_needed = int(tf.shape[0])   # one matrix per frame: checked against the batch where it is known (check_batch)
+            self._tf = tf
             self.keep.append(tf)
         bb = None
         if bbox is not None:
@@ -102,18 +104,29 @@ class DecodeFrameMap:
         self.struct = _lib.FrameMap(_p(tf), tf_mode, _p(bb), 4 * num_views, max(1, num_keypoints // num_views),
                                     float(model_h), float(model_w))
 
-    def check_batch(self, b: int) -> None:
-        """the kernels index the per-frame tables by frame: a table shorter than the batch would be read out of bounds (the reference fails
-        in torch.bmm / broadcasting on the same inputs)"""
+    def check_batch(self, b: int, device: torch.device | None = None) -> None:
+        """Called where the batch (and its device) is known.  The kernels index the per-frame tables by frame: a table shorter than the batch
+        would be read out of bounds (the reference fails in torch.bmm / broadcasting on the same inputs); and they dereference raw pointers:
+        tables the caller left on another device (the reference moves its inverse matrices to the keypoints' device, data/utils.py:170-172)
+        are moved here."""
         if self.rows_needed is not None and self.rows_needed != b:
             raise ValueError(f"{self.rows_needed} affine transforms for a batch of {b} frames (one per frame, or a single (2, 3) / (1, 2, 3))")
         if self.bbox_rows is not None and self.bbox_rows != b:
             if self.bbox_rows != 1:
                 raise ValueError(f"{self.bbox_rows} bounding boxes for a batch of {b} frames")
-            bb = self._bbox.expand(b, -1).contiguous()   # one box for every frame: what broadcasting gives the reference (data/bboxes.py:222-288)
-            self.keep.append(bb)
-            self.struct.bbox = bb.data_ptr()
+            self._bbox = self._bbox.expand(b, -1).contiguous()   # one box for every frame: what broadcasting gives the reference (data/bboxes.py:222-288)
+            self.keep.append(self._bbox)
+            self.struct.bbox = self._bbox.data_ptr()
             self.bbox_rows = b
+        if device is not None:
+            if self._tf is not None and self._tf.device != device:
+                self._tf = self._tf.to(device)
+                self.keep.append(self._tf)
+                self.struct.transforms = self._tf.data_ptr()
+            if self._bbox is not None and self._bbox.device != device:
+                self._bbox = self._bbox.to(device)
+                self.keep.append(self._bbox)
+                self.struct.bbox = self._bbox.data_ptr()
 
 
 class _DecodeFn(torch.autograd.Function):
@@ -123,7 +136,7 @@ class _DecodeFn(torch.autograd.Function):
         ctx.in_dtype = heat.dtype
         heat = heat.to(torch.float32).contiguous()
         b, k, h, w = heat.shape
-        frame_map.check_batch(b)
+        frame_map.check_batch(b, heat.device)
         tables, keep = _device_tables(h, w, ds, heat.device)
         kp_aug = torch.empty(b, k, 2, device=heat.device, dtype=torch.float32)
         kp_frame = torch.empty_like(kp_aug)
@@ -156,7 +169,7 @@ class _FrameMapFn(torch.autograd.Function):
         require_device(kp)
         x = _f32c(kp)
         b, k = x.shape[0], x.shape[1] // 2
-        frame_map.check_batch(b)
+        frame_map.check_batch(b, x.device)
         out = torch.empty_like(x)
         check(_lib.lib().lp_frame_map_apply(_p(x), b, k, C.byref(frame_map.struct), 0, _p(out), _stream()), "lp_frame_map_apply")
         ctx.frame_map = frame_map

@@ -157,3 +157,20 @@ def test_loss_wrappers_refuse_mismatched_shapes(stack_backend):
         ops.rmse(z(4, 6), z(4, 8))
     with pytest.raises(ValueError, match="bounding boxes"):
         ops.decode(torch.full((4, 3, 8, 8), 1 / 64, device=dev), 2, 1000.0, ops.DecodeFrameMap(None, False, z(3, 4) + 1, 1, 32, 32, 3))
+
+
+@pytest.mark.gpu
+def test_frame_map_tables_left_on_the_host_are_moved():
+    """transforms / bbox handed over as CPU tensors with device heat-maps (the reference moves its inverse matrices to the keypoints' device,
+    data/utils.py:170-172): same keypoints as with device tables - not a host pointer dereferenced by a kernel"""
+    from lightning_pose_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    heat = torch.softmax(torch.randn(3, 4, 16 * 16, generator=g) * 4, -1).reshape(3, 4, 16, 16).to(dev)
+    tf = torch.tensor([[0.9, 0.1, 3.0], [-0.2, 1.1, -4.0]])
+    bbox = torch.tensor([[5.0, 6.0, 100.0, 120.0]]).repeat(3, 1)
+    want = ops.decode(heat, 2, 1000.0, ops.DecodeFrameMap(tf.to(dev), False, bbox.to(dev), 1, 64, 64, 4))
+    got = ops.decode(heat, 2, 1000.0, ops.DecodeFrameMap(tf, False, bbox, 1, 64, 64, 4))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
