@@ -583,6 +583,8 @@ class Engine:
         for p_ in parts:
             ops.require_device(p_)
         parts = [p_.to(torch.float32).contiguous() for p_ in parts]
+        if parts[0].dim() != 4 or parts[0].shape[1] != 3:
+            raise ValueError(f"images must be (B, 3, H, W), got {tuple(parts[0].shape)}")   # (raw pointers from here on)
         _, _, H, W = parts[0].shape
         if H % 32 or W % 32:
             raise ValueError(f"image size must be a multiple of 32, got {H}x{W}")
@@ -717,6 +719,8 @@ class Engine:
         passes, no pre-normalisation tensors, no tape.  images (B,3,H,W) fp32 -> heat-maps (B,K,H/2^ds,W/2^ds) fp32."""
         ops.require_device(images)
         images = images.to(torch.float32).contiguous()
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"images must be (B, 3, H, W), got {tuple(images.shape)}")
         B, _, H, W = images.shape
         if H % 32 or W % 32:
             raise ValueError(f"image size must be a multiple of 32, got {H}x{W}")

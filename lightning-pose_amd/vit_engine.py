@@ -328,6 +328,8 @@ class ViTEngine(Engine):
         parts = [p_.to(torch.float32).contiguous() for p_ in parts]
         if any(p_.shape[1:] != parts[0].shape[1:] for p_ in parts):
             raise ValueError("a joint pass takes batches of equally sized images")
+        if parts[0].dim() != 4 or parts[0].shape[1] != 3:
+            raise ValueError(f"images must be (B, 3, H, W), got {tuple(parts[0].shape)}")   # (raw pointers from here on)
         _, _, H, W = parts[0].shape
         B = sum(p_.shape[0] for p_ in parts)
         pl = self.plan

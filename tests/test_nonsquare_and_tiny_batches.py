@@ -155,6 +155,14 @@ def test_loss_wrappers_refuse_mismatched_shapes(stack_backend):
         ops.pca_loss(z(4, 6), torch.zeros(1, 3, dtype=torch.int32, device=dev), z(4), z(2, 6), 0.0)
     with pytest.raises(ValueError, match="rmse"):
         ops.rmse(z(4, 6), z(4, 8))
+    from lightning_pose_amd.engine import Engine
+
+    eng = Engine(3, 2, dev)
+    for bad in (z(2, 1, 64, 64), z(2, 3, 64)):
+        with pytest.raises(ValueError, match="images must be"):
+            eng.forward(bad, training=True)
+        with pytest.raises(ValueError, match="images must be"):
+            eng.forward_infer(bad)
     with pytest.raises(ValueError, match="bounding boxes"):
         ops.decode(torch.full((4, 3, 8, 8), 1 / 64, device=dev), 2, 1000.0, ops.DecodeFrameMap(None, False, z(3, 4) + 1, 1, 32, 32, 3))
 
