@@ -202,9 +202,15 @@ def generate_heatmaps(keypoints: torch.Tensor, height: int, width: int, output_s
                       visibility: torch.Tensor | None = None) -> torch.Tensor:
     require_device(keypoints)
     kp = _f32c(keypoints)
+    if kp.dim() != 3 or kp.shape[2] != 2:
+        raise ValueError(f"keypoints must be (B, K, 2), got {tuple(kp.shape)}")
     b, k, _ = kp.shape
     h, w = output_shape
-    vis = visibility.to(torch.int32).contiguous() if visibility is not None else None
+    vis = None
+    if visibility is not None:
+        if tuple(visibility.shape) != (b, k):
+            raise ValueError(f"visibility must be {(b, k)}, got {tuple(visibility.shape)}")
+        vis = visibility.to(device=kp.device, dtype=torch.int32).contiguous()
     out = torch.empty(b, k, h, w, device=kp.device, dtype=torch.float32)
     check(_lib.lib().lp_heatmap_gen(_p(kp), _p(vis), b, k, int(height), int(width), h, w, float(sigma), _p(out), _stream()),
           "lp_heatmap_gen")
