@@ -19,9 +19,13 @@ def nchw(t):
     return t.float().permute(0, 3, 1, 2).contiguous()
 
 
+MARGINS: list = []   # (cos, |ratio - 1|, name) of every comparison of the current test: its worst cases are printed (-s) at the end
+
+
 def close(name, a, b, cos_min=0.995, ratio_tol=0.03):
     cos = F.cosine_similarity(a.reshape(-1).float(), b.reshape(-1).float(), dim=0).item()
     ratio = (a.norm() / (b.norm() + 1e-30)).item()
+    MARGINS.append((cos, abs(ratio - 1), name))
     assert cos > cos_min and abs(ratio - 1) < ratio_tol, f"{name}: cos {cos:.5f} ratio {ratio:.4f}"
 
 
@@ -32,6 +36,7 @@ def test_engine_forward_backward_blockwise(stack_backend, joint, norm_on_load, m
     their own batch statistics - what the reference's two forward calls compute (models/base.py:682-695); the oracle below then applies
     every BatchNorm per segment."""
     dev = stack_backend
+    MARGINS.clear()
     # norm_on_load (opt-in LP_NORM_ON_LOAD=1): conv3 and its weight gradient consume z2 directly (lp_conv_fwd_bn_norm / lp_conv_wgrad_norm)
     monkeypatch.setenv("LP_NORM_ON_LOAD", "1" if norm_on_load else "0")
     segs = [(0, 4)] if joint is None else [(0, joint[0]), (joint[0], sum(joint))]
@@ -101,7 +106,17 @@ def test_engine_forward_backward_blockwise(stack_backend, joint, norm_on_load, m
         y = F.conv_transpose2d(y, _q(ct.weight), ct.bias, stride=2, padding=1, output_padding=1)
         y = _RoundGrad.apply(y) if i == len(cts) - 1 else _q(y)
     h = tp.spatial_softmax2d(y, 1.0)
-    torch.testing.assert_close(heat, h.detach(), atol=1e-6, rtol=1e-3)
+    # The head is re-run from the engine's own trunk output with the engine's roundings (bf16 storage of the first deconvolution's output).
+    # The two fp32 sums behind a stored bf16 value differ in summation order, so now and then one lands on the other side of a rounding
+    # boundary: one bf16 ulp (0.4 %) in one intermediate element, 1e-3 .. 1e-2 relative in the handful of heat-map pixels under its 3 x 3
+    # taps.  On the emulator the worst pixel sits at 0.0002 .. 0.35 of a flat 1e-3 bound depending on the case; on the device, where small
+    # launches accumulate BatchNorm sums with atomics, the trunk output itself varies from run to run and the flat bound failed once in
+    # ~120 runs.  Hence: 1e-3 on all but 0.1 % of the pixels, 2e-2 (a few ulp) on every pixel.
+    hd = h.detach()
+    over = (heat - hd).abs() > 1e-6 + 1e-3 * hd.abs()
+    print("\nHEAT max |diff| / (1e-6 + 1e-3 |want|):", float(((heat - hd).abs() / (1e-6 + 1e-3 * hd.abs())).max()), "pixels over:", int(over.sum()))
+    assert float(over.float().mean()) <= 1e-3
+    torch.testing.assert_close(heat, hd, atol=1e-6, rtol=2e-2)
     h.backward(gh)
     close("d(trunk output)", nchw(trace["b15.dout"]), x.grad)
     for i, ct in enumerate(cts):
@@ -143,3 +158,5 @@ def test_engine_forward_backward_blockwise(stack_backend, joint, norm_on_load, m
     close("backbone.0.weight", G["backbone.0.weight"], bb[0].weight.grad)
     close("backbone.1.weight", G["backbone.1.weight"], bb[1].weight.grad)
     close("backbone.1.bias", G["backbone.1.bias"], bb[1].bias.grad)
+    print("\nMARGINS lowest cos:", [(round(c, 5), n) for c, _, n in sorted(MARGINS)[:3]],
+          "largest |ratio - 1|:", [(round(r, 4), n) for _, r, n in sorted(MARGINS, key=lambda m: -m[1])[:3]])
