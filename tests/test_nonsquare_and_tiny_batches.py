@@ -9,7 +9,7 @@ import torch
 from oracle import restated as O
 
 
-@pytest.mark.parametrize("H,W,Bl,S", [(64, 96, 1, 3), (96, 64, 2, 2)])
+@pytest.mark.parametrize("H,W,Bl,S", [(64, 96, 1, 3), (96, 64, 2, 2), (32, 128, 3, 2)])
 def test_nonsquare_semisupervised_step_fp32(stack_backend, H, W, Bl, S):
     from lightning_pose_amd.losses import LossFactory
     from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
