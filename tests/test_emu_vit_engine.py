@@ -44,7 +44,7 @@ def test_vit_engine_forward_backward_vs_hf(stack_backend, hidden, depth, heads, 
     check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp)
 
 
-def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp):
+def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp, batch=2, size=64):
     """(ViT-B's width and 12 heads run this from tests/test_widen_vitb_width.py)"""
     from lightning_pose_amd.vit_engine import ViTEngine
 
@@ -61,10 +61,10 @@ def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp):
         torch.testing.assert_close(v.cpu(), sd[k].reshape(v.shape), atol=0, rtol=0)
 
     gen = torch.Generator().manual_seed(1)
-    images = torch.randn(2, 3, 64, 64, generator=gen)
+    images = torch.randn(batch, 3, size, size, generator=gen)
     heat, tape = eng.forward(images.to(dev), True)
     want = _oracle_forward(vit, head, images)
-    assert heat.shape == want.shape == (2, K, 16, 16)
+    assert heat.shape == want.shape == (batch, K, size // 4, size // 4)
     # bf16 operands vs fp32; the 768-wide head sums 192 products per logit, its sharper soft-max doubles the relative error of a peak
     torch.testing.assert_close(heat.cpu(), want.detach(), atol=2e-3, rtol=5e-2 if hidden == 128 else 1e-1)
 
@@ -85,6 +85,13 @@ def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp):
         cos = F.cosine_similarity(got.flatten(), gr.flatten(), dim=0).item()
         rel = ((got - gr).norm() / gr.norm()).item()
         assert cos > 0.999 and rel < 0.03, (k, cos, rel)  # torch.autocast(bf16) of the same model: cos 0.9999, rel 0.010-0.015
+
+
+@pytest.mark.parametrize("batch,size", [(3, 96), (1, 160)])
+def test_vit_engine_odd_batches_and_token_counts(stack_backend, batch, size):
+    """37 and 101 tokens (6 x 6 and 10 x 10 patch grids: the key axis is padded to 64 / 128 inside the attention kernels, the position table
+    is interpolated from the 3 x 3 pretraining grid), batches of 3 and 1"""
+    check_vit_engine_vs_hf(stack_backend, 128, 2, 2, 256, batch=batch, size=size)
 
 
 def test_vit_tracker_trains_through_the_reference_surface(stack_backend, monkeypatch):
