@@ -244,3 +244,88 @@ def test_sync_batchnorm_engine_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True, ""), (1, True, "")], res
+
+
+def _tracker_worker(rank, world, port, q):
+    """One supervised training step of the tracker in fp32, sharded by frame over 2 ranks (SyncBatchNorm, summed gradient, grad_scale =
+    1 / world) against the same step over all frames in one process - the definition of data parallelism the reference gets from Lightning
+    DDP + SyncBatchNorm (train.py:411-431).  fp32 so that the comparison is not limited by the bf16 policy's own noise."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import _lp_bootstrap  # noqa: F401
+    from lightning_pose_amd import _lib, ops
+    from lightning_pose_amd.distributed import DataParallel
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import HeatmapTracker
+    from oracle import restated as O
+    from tests.hipemu import emu
+
+    _lib._lib = emu.emu_lib()
+    ops.require_device = lambda *a: None
+    ops.require_device_type = lambda d: None
+    ops._stream = lambda: None
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dev, K, HW, Bper = torch.device("cpu"), 3, 64, 2
+    gen = torch.Generator().manual_seed(5)
+    images = torch.randn(world * Bper, 3, HW, HW, generator=gen)
+    kp = torch.rand(world * Bper, K, 2, generator=gen) * HW
+    heat = O.generate_heatmaps(kp, HW, HW, (HW // 4, HW // 4))
+
+    def batch(lo, hi):
+        return {"images": images[lo:hi], "keypoints": kp[lo:hi].reshape(hi - lo, 2 * K), "heatmaps": heat[lo:hi],
+                "bbox": torch.tensor([[0.0, 0.0, float(HW), float(HW)]]).repeat(hi - lo, 1), "idxs": torch.arange(lo, hi)}
+
+    def make():
+        return HeatmapTracker(num_keypoints=K, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
+                              pretrained=False, torch_seed=3, device=dev, precision="fp32")
+
+    bad = []
+    model = make()
+    dp = DataParallel(model.net, sync_bn=True)
+    dp.broadcast_parameters()
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    opt.grad_scale = 1.0 / world
+    opt.zero_grad()
+    out = model.training_step(batch(rank * Bper, (rank + 1) * Bper), 0)
+    out["loss"].backward()
+    dp.all_reduce_gradients()
+    dp.wait()
+    mean_loss = dp.mean_scalars({"loss": out["loss"].detach()})["loss"]
+    if rank == 0:
+        solo = make()
+        solo.train()
+        solo.configure_optimizers()["optimizer"].zero_grad()
+        want = solo.training_step(batch(0, world * Bper), 0)
+        want["loss"].backward()
+        # every map is labeled, so the mean over all frames is the mean of the per-rank means
+        if abs(float(mean_loss) - float(want["loss"])) > 1e-5 * abs(float(want["loss"])):
+            bad.append(f"loss: mean over ranks {float(mean_loss):.8f} vs all frames in one process {float(want['loss']):.8f}")
+        g_dp, g_solo = model.net.G / world, solo.net.G
+        n_bb = model.net.plan.n_backbone
+        for name, sl, tol in (("head", slice(n_bb, None), 2e-3), ("backbone", slice(0, n_bb), 2e-2)):
+            a, b = g_dp[sl], g_solo[sl]
+            rel = float((a - b).norm() / b.norm())
+            if not rel < tol:
+                bad.append(f"{name} gradient: |mean over ranks - single process| / |single process| = {rel:.2e}")
+        rm_dp = model.net.running_view(model.net.plan.stem_bn, "running_mean")
+        rm_solo = solo.net.running_view(solo.net.plan.stem_bn, "running_mean")
+        if not torch.allclose(rm_dp, rm_solo, atol=1e-6, rtol=1e-4):
+            bad.append("stem running_mean differs from the single-process (global batch) statistics")
+    q.put((rank, not bad, "; ".join(bad)))
+    dist.destroy_process_group()
+
+
+def test_tracker_step_sharded_over_two_ranks_equals_one_process():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tracker_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in results), [msg for _, ok, msg in results if not ok]
