@@ -1,0 +1,153 @@
+"""Differential tests: the product's drop-in functions and loss classes against the VERBATIM reference modules (executed from
+/root/reference under oracle/ref_loader's stubs) on randomly drawn inputs - the golden fixtures pin single draws, this pins the interface
+behaviour (argument shapes, masks, broadcasting rules, logged names) over many.  Build container only (the reference tree does not travel)."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import needs_reference
+
+pytestmark = [needs_reference, pytest.mark.reference]
+
+
+@pytest.fixture()
+def cpu_stack(stack_backend):
+    if stack_backend.type != "cpu":
+        pytest.skip("the reference tree exists in the build container only")
+    return stack_backend
+
+
+def _ref(name):
+    from oracle import ref_loader as R
+
+    R.install_stubs()
+    return R.load(name)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_undo_affine_transform_batch_every_shape(cpu_stack, seed):
+    from lightning_pose_amd.data.utils import undo_affine_transform_batch
+
+    U = _ref("data.utils")
+    r = np.random.default_rng(seed)
+    S, K = int(r.integers(1, 7)), int(r.integers(1, 6))
+    kp = torch.from_numpy(r.uniform(0, 80, (S, 2 * K)).astype(np.float32))
+
+    def mat():
+        a = np.eye(2) + r.normal(0, 0.2, (2, 2))
+        return torch.from_numpy(np.concatenate([a, r.normal(0, 5, (2, 1))], 1).astype(np.float32))
+
+    forms = [mat(), mat().unsqueeze(0), torch.stack([mat() for _ in range(S)]), torch.tensor([1.0]), torch.ones(S, 1)]
+    for tf in forms:
+        want = U.undo_affine_transform_batch(kp.clone(), tf.clone(), False)
+        got = undo_affine_transform_batch(kp.clone(), tf.clone(), False)
+        torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-5)
+    V = int(r.integers(2, 4))
+    kpv = torch.from_numpy(r.uniform(0, 80, (S, 2 * K * V)).astype(np.float32))
+    tfv = torch.stack([mat() for _ in range(V)])
+    for tf in (tfv, tfv.unsqueeze(1)):      # (V, 2, 3) and (V, 1, 2, 3): what the DALI wrapper stacks
+        want = U.undo_affine_transform_batch(kpv.clone(), tf.clone(), True)
+        got = undo_affine_transform_batch(kpv.clone(), tf.clone(), True)
+        torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_model_to_frame_batch(cpu_stack, seed):
+    from lightning_pose_amd.data.bboxes import model_to_frame_batch
+
+    Bx = _ref("data.bboxes")
+    r = np.random.default_rng(100 + seed)
+    B, K, V = int(r.integers(1, 6)), int(r.integers(1, 5)), int(r.integers(1, 4))
+    H, W = 32 * int(r.integers(1, 5)), 32 * int(r.integers(1, 5))
+    kp = torch.from_numpy(r.uniform(0, min(H, W), (B, 2 * K * V)).astype(np.float32))
+    bbox = torch.from_numpy(np.concatenate([r.uniform(0, 50, (B, V, 2)), r.uniform(60, 400, (B, V, 2))], 2).reshape(B, 4 * V).astype(np.float32))
+    if V == 1:
+        batches = [{"images": torch.zeros(B, 3, H, W), "bbox": bbox}, {"frames": torch.zeros(B, 3, H, W), "bbox": bbox, "is_multiview": False}]
+    else:
+        batches = [{"images": torch.zeros(B, V, 3, H, W), "bbox": bbox, "num_views": torch.full((B,), V)},
+                   {"frames": torch.zeros(B, V, 3, H, W), "bbox": bbox, "is_multiview": True}]
+    for bd in batches:
+        want = Bx.model_to_frame_batch(bd, kp.clone(), in_place=False)
+        got = model_to_frame_batch(bd, kp.clone())
+        torch.testing.assert_close(got, want, atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_heatmap_functions(cpu_stack, seed):
+    from lightning_pose_amd.data.heatmaps import evaluate_heatmaps_at_location, generate_heatmaps
+
+    Hm = _ref("data.heatmaps")
+    r = np.random.default_rng(200 + seed)
+    B, K = int(r.integers(1, 5)), int(r.integers(1, 6))
+    h, w = int(r.integers(8, 40)), int(r.integers(8, 40))
+    H, W = 4 * h, 4 * w
+    kp = torch.from_numpy(r.uniform(-20, 1.1 * max(H, W), (B, K, 2)).astype(np.float32))
+    kp[0, 0] = float("nan")
+    vis = torch.from_numpy(r.integers(0, 3, (B, K)).astype(np.int64))
+    sigma = float(r.uniform(1.0, 3.0))   # (floor(sigma * num_stds) == 0 is an error in the reference itself: an empty padded slice)
+    for v in (None, vis):
+        want = Hm.generate_heatmaps(kp.clone(), H, W, (h, w), sigma=sigma, visibility=v)
+        got = generate_heatmaps(kp.clone(), H, W, (h, w), sigma=sigma, visibility=v)
+        torch.testing.assert_close(got, want, atol=3e-7, rtol=1e-4)
+    heat = torch.softmax(torch.from_numpy(r.normal(0, 2, (B, K, h * w)).astype(np.float32)), -1).reshape(B, K, h, w)
+    # (locations inside the map: the reference indexes its padded copy directly and raises IndexError beyond it; the kernel zero-pads)
+    locs = torch.from_numpy((r.uniform(0, 1, (B, K, 2)) * np.array([w - 1e-3, h - 1e-3])).astype(np.float32))
+    for ns in (1, 2):
+        want = Hm.evaluate_heatmaps_at_location(heat, locs.clone(), sigma=sigma, num_stds=ns)
+        got = evaluate_heatmaps_at_location(heat, locs.clone(), sigma=sigma, num_stds=ns)
+        torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
+
+
+def _logs(pairs):
+    return {d["name"]: float(d["value"]) for d in pairs}
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_loss_classes_values_gradients_and_logs(cpu_stack, seed):
+    from lightning_pose_amd.losses import losses as P
+
+    L = _ref("losses.losses")
+    r = np.random.default_rng(300 + seed)
+    S, K = int(r.integers(2, 9)), int(r.integers(1, 7))
+    h, w = int(r.integers(6, 20)), int(r.integers(6, 20))
+
+    def compare(ref_loss, prod_loss, kwargs, grad_key, stage="train"):
+        a = {k: (v.clone().requires_grad_(k == grad_key) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kwargs.items()}
+        b = {k: (v.clone().requires_grad_(k == grad_key) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kwargs.items()}
+        want, want_logs = ref_loss(stage=stage, **a)
+        got, got_logs = prod_loss(stage=stage, **b)
+        assert float(got.detach()) == pytest.approx(float(want.detach()), rel=3e-5, abs=1e-8)
+        assert _logs(got_logs).keys() == _logs(want_logs).keys()
+        for k_, v_ in _logs(want_logs).items():
+            assert _logs(got_logs)[k_] == pytest.approx(v_, rel=3e-5, abs=1e-8), k_
+        if float(want) != 0.0 and torch.isfinite(want):
+            want.backward()
+            got.backward()
+            torch.testing.assert_close(b[grad_key].grad, a[grad_key].grad, atol=3e-6 * float(a[grad_key].grad.abs().max()) + 1e-12, rtol=3e-4)
+
+    # temporal: scalar / per-keypoint epsilon, with and without a confidence threshold
+    kp = torch.from_numpy(r.uniform(0, 60, (S, 2 * K)).astype(np.float32))
+    conf = torch.from_numpy(r.uniform(0, 1, (S, K)).astype(np.float32))
+    for eps in (0.0, float(r.uniform(0, 5)), [float(v) for v in r.uniform(0, 8, K)]):
+        for thr in (0.0, 0.4):
+            kw = dict(epsilon=eps, prob_threshold=thr, log_weight=float(r.uniform(-1, 3)))
+            compare(L.TemporalLoss(**kw), P.TemporalLoss(**kw), {"keypoints_pred": kp, "confidences": conf}, "keypoints_pred")
+    compare(L.TemporalLoss(epsilon=1.0), P.TemporalLoss(epsilon=1.0), {"keypoints_pred": kp}, "keypoints_pred", stage="val")
+    # heat-map losses: some maps unlabeled (all-zero targets)
+    targ = torch.softmax(torch.from_numpy(r.normal(0, 3, (S, K, h * w)).astype(np.float32)), -1).reshape(S, K, h, w)
+    drop = torch.from_numpy(r.uniform(0, 1, (S, K)) < 0.3)
+    drop[0, 0] = False
+    targ[drop] = 0.0
+    pred = torch.softmax(torch.from_numpy(r.normal(0, 1, (S, K, h * w)).astype(np.float32)), -1).reshape(S, K, h, w)
+    for name in ("HeatmapMSELoss", "HeatmapKLLoss", "HeatmapJSLoss"):
+        lw = float(r.uniform(-1, 2))
+        compare(getattr(L, name)(log_weight=lw), getattr(P, name)(log_weight=lw), {"heatmaps_targ": targ, "heatmaps_pred": pred}, "heatmaps_pred")
+    # RMSE metric: NaN pairs are unlabeled keypoints
+    kt = torch.from_numpy(r.uniform(0, 60, (S, 2 * K)).astype(np.float32))
+    miss = torch.from_numpy(r.uniform(0, 1, (S, K)) < 0.3)
+    miss[0, 0] = False
+    kt.reshape(S, K, 2)[miss] = float("nan")
+    want, _ = L.RegressionRMSELoss()(keypoints_targ=kt, keypoints_pred=kp, stage=None)
+    got, _ = P.RegressionRMSELoss()(keypoints_targ=kt, keypoints_pred=kp, stage=None)
+    assert float(got) == pytest.approx(float(want), rel=1e-5)
