@@ -100,7 +100,7 @@ def test_heatmap_functions(cpu_stack, seed):
 
 
 def _logs(pairs):
-    return {d["name"]: float(d["value"]) for d in pairs}
+    return {d["name"]: float(d["value"].detach() if torch.is_tensor(d["value"]) else d["value"]) for d in pairs}
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -151,3 +151,62 @@ def test_loss_classes_values_gradients_and_logs(cpu_stack, seed):
     want, _ = L.RegressionRMSELoss()(keypoints_targ=kt, keypoints_pred=kp, stage=None)
     got, _ = P.RegressionRMSELoss()(keypoints_targ=kt, keypoints_pred=kp, stage=None)
     assert float(got) == pytest.approx(float(want), rel=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_run_subpixelmaxima_random_maps(cpu_stack, seed):
+    """the fused decode (bicubic x2^ds upsample + 5 x 5 blur + soft-argmax at T = 1000 + confidence window) against the verbatim
+    ``run_subpixelmaxima`` on random, moderately peaked maps of random (non-square) sizes"""
+    from lightning_pose_amd import ops
+
+    hm = _ref("models.heads.heatmap")
+    r = np.random.default_rng(400 + seed)
+    ds = int(r.choice([1, 2, 3]))
+    lo = {1: 8, 2: 9, 3: 11}[ds]
+    B, K, h, w = int(r.integers(1, 4)), int(r.integers(1, 5)), int(r.integers(lo, 40)), int(r.integers(lo, 56))
+    heat = torch.softmax(torch.from_numpy(r.normal(0, float(r.uniform(2, 5)), (B, K, h * w)).astype(np.float32)), -1).reshape(B, K, h, w)
+    want_kp, want_conf = hm.run_subpixelmaxima(heat.clone(), ds, torch.tensor(1000.0))
+    fm = ops.DecodeFrameMap(None, False, None, 1, h << ds, w << ds, K)
+    kp, _, conf = ops.decode(heat, ds, 1000.0, fm)
+    torch.testing.assert_close(conf, want_conf, atol=3e-5, rtol=1e-4)
+    # soft-argmax at T = 1000 is as well conditioned as the map is peaked: 1e-3 px on these random maps, 1e-4 px on the golden (fitted) ones
+    torch.testing.assert_close(kp, want_kp, atol=2e-3, rtol=0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
+    """PCALoss (single- and multi-view) with parameters fitted by the verbatim KeypointPCA: the product's own fit (utils/pca.py) gives the
+    same parameters, and the loss class the same value, logs and gradient"""
+    from lightning_pose_amd.losses import losses as P
+    from oracle import ref_loader as R
+
+    R.install_stubs()
+    L = R.load("losses.losses")
+    r = np.random.default_rng(500 + seed)
+    K, N, S = int(r.integers(4, 9)), 60, int(r.integers(2, 7))
+    basis = r.normal(0, 1, (3, 2 * K))
+    data = torch.from_numpy((r.normal(0, 6, (N, 3)) @ basis + 40 + r.normal(0, 0.3, (N, 2 * K))).astype(np.float32))
+    cols = sorted(r.choice(K, size=int(r.integers(2, K + 1)), replace=False).tolist())
+    kp = torch.from_numpy((r.normal(0, 6, (S, 3)) @ basis + 40 + r.normal(0, 2.0, (S, 2 * K))).astype(np.float32))
+    ref_pca = R.fit_keypoint_pca("pca_singleview", data, components_to_keep=0.99, columns_for_singleview_pca=cols)
+    prod = P.PCALoss(loss_name="pca_singleview", components_to_keep=0.99, columns_for_singleview_pca=cols, data_arr=data, device="cpu",
+                     log_weight=1.0)
+    for key in ("mean", "kept_eigenvectors"):
+        a, b = prod.pca.parameters[key].float().cpu(), ref_pca.parameters[key].float().cpu()
+        if key == "kept_eigenvectors":     # principal axes are defined up to sign
+            sgn = torch.sign((a * b).sum(1, keepdim=True))
+            a = a * sgn
+        torch.testing.assert_close(a, b, atol=2e-3, rtol=1e-3)
+    assert float(prod.pca.parameters["epsilon"]) == pytest.approx(float(ref_pca.parameters["epsilon"]), rel=2e-3)
+    ref_loss = L.PCALoss.__new__(L.PCALoss)      # the reference class around the reference fit, without a data module
+    L.Loss.__init__(ref_loss, epsilon=float(ref_pca.parameters["epsilon"]), log_weight=1.0)
+    ref_loss.loss_name, ref_loss.pca, ref_loss.device = "pca_singleview", ref_pca, "cpu"
+    a, b = kp.clone().requires_grad_(True), kp.clone().requires_grad_(True)
+    want, want_logs = ref_loss(keypoints_pred=a, stage="train")
+    got, got_logs = prod(keypoints_pred=b, stage="train")
+    assert float(got.detach()) == pytest.approx(float(want.detach()), rel=5e-3, abs=1e-6)
+    assert _logs(got_logs).keys() == _logs(want_logs).keys()
+    if float(want.detach()) > 0:
+        want.backward()
+        got.backward()
+        torch.testing.assert_close(b.grad, a.grad, atol=5e-3 * float(a.grad.abs().max()), rtol=5e-2)
