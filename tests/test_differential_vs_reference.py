@@ -210,3 +210,65 @@ def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
         want.backward()
         got.backward()
         torch.testing.assert_close(b.grad, a.grad, atol=5e-3 * float(a.grad.abs().max()), rtol=5e-2)
+
+
+@pytest.mark.parametrize("K,H,W,ds,B", [(2, 96, 96, 3, 2), (5, 64, 96, 2, 3), (1, 96, 64, 2, 2), (17, 64, 64, 2, 2)])
+def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
+    """The reference's own HeatmapTracker (verbatim models/heatmap_tracker.py + heads + losses) and the product's, same seed (so the same
+    weights by construction order), one supervised step in fp32 on configurations the golden steps do not cover: downsample_factor 3 (one
+    upsampling layer less, heat-maps H / 8), non-square frames, a single keypoint, 17 keypoints.  Compared: state_dict names and values
+    before the step, heat-maps, every logged scalar that is well conditioned on a random-init net, head gradients, predict_step."""
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import HeatmapTracker
+    from oracle import ref_loader as R
+
+    R.install_stubs()
+    T, Fa, Hm = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("data.heatmaps")
+    dev = cpu_stack
+    ref = T.HeatmapTracker(num_keypoints=K, loss_factory=Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
+                           pretrained=False, torch_seed=21, downsample_factor=ds, image_size=max(H, W))
+    model = HeatmapTracker(num_keypoints=K, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
+                           pretrained=False, torch_seed=21, downsample_factor=ds, device=dev, precision="fp32")
+    sd_ref, sd = ref.state_dict(), model.state_dict()
+    assert sorted(k for k in sd_ref if "num_batches_tracked" not in k) == sorted(k for k in sd if "num_batches_tracked" not in k)
+    for k_, v_ in sd_ref.items():
+        if "num_batches_tracked" not in k_:
+            torch.testing.assert_close(sd[k_].cpu().reshape(v_.shape).float(), v_.float(), atol=0, rtol=0, msg=lambda m, k_=k_: f"{k_}: {m}")
+    g = torch.Generator().manual_seed(K * 100 + H + W)
+    kp = torch.rand(B, K, 2, generator=g) * torch.tensor([W, H], dtype=torch.float32)
+    hs, ws = H // (2 ** ds), W // (2 ** ds)
+    batch = {"images": torch.randn(B, 3, H, W, generator=g), "keypoints": kp.reshape(B, 2 * K),
+             "heatmaps": Hm.generate_heatmaps(kp, H, W, (hs, ws)), "bbox": torch.tensor([[2.0, 3.0, 3.0 * H, 2.0 * W]]).repeat(B, 1),
+             "idxs": torch.arange(B)}
+    ref.train()
+    model.train()
+    want = ref.training_step({k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+    want["loss"].backward()
+    model.configure_optimizers()["optimizer"].zero_grad()
+    got = model.training_step({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+    got["loss"].backward()
+    assert float(got["loss"].detach()) == pytest.approx(float(want["loss"].detach()), rel=1e-4)
+    assert set(model.logged) == set(ref.logged)
+    for name in ("train_heatmap_mse_loss", "train_supervised_loss", "train_heatmap_mse_loss_weighted", "heatmap_mse_weight"):
+        assert float(model.logged[name]) == pytest.approx(float(ref.logged[name]), rel=1e-4), name
+    # frame-pixel RMSE between labels and the soft-argmax of nearly flat maps: tens of pixels, conditioned like the keypoints (0.1 px)
+    assert float(model.logged["train_supervised_rmse"]) == pytest.approx(float(ref.logged["train_supervised_rmse"]), abs=0.2)
+    layers = [n_ for n_, _ in ref.head.named_parameters()]
+    for n_ in layers:
+        a = dict(model.head.named_parameters())[n_].grad.cpu()
+        b = dict(ref.head.named_parameters())[n_].grad
+        if float(b.norm()) < 1e-3 * max(float(p_.grad.norm()) for _, p_ in ref.head.named_parameters()):
+            continue  # (the last layer's bias: analytically zero under the soft-max)
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()), n_
+    with torch.no_grad():
+        heat_ref = ref(batch["images"])
+        heat = model.forward(batch["images"].to(dev)).cpu()
+    assert heat.shape == heat_ref.shape == (B, K, hs, ws)
+    torch.testing.assert_close(heat, heat_ref, atol=1e-4 * float(heat_ref.max()), rtol=1e-3)
+    ref.eval()
+    model.eval()
+    with torch.no_grad():
+        kp_ref, conf_ref = ref.predict_step({k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+        kp_got, conf_got = model.predict_step({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+    torch.testing.assert_close(conf_got.cpu(), conf_ref, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(kp_got.cpu(), kp_ref, atol=0.3, rtol=0)
