@@ -272,3 +272,11 @@ def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
         kp_got, conf_got = model.predict_step({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
     torch.testing.assert_close(conf_got.cpu(), conf_ref, atol=1e-4, rtol=1e-3)
     torch.testing.assert_close(kp_got.cpu(), kp_ref, atol=0.3, rtol=0)
+    # validation_step / test_step (Lightning runs them in eval mode under no_grad): logged names and the well-conditioned values
+    for step_name, stage in (("validation_step", "val"), ("test_step", "test")):
+        ref.logged, model.logged = {}, {}
+        with torch.no_grad():
+            getattr(ref, step_name)({k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+            getattr(model, step_name)({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+        assert set(model.logged) == set(ref.logged) and f"{stage}_supervised_loss" in ref.logged, (step_name, sorted(ref.logged))
+        assert float(model.logged[f"{stage}_supervised_loss"]) == pytest.approx(float(ref.logged[f"{stage}_supervised_loss"]), rel=1e-4)
