@@ -96,7 +96,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-LOOPBACK_ARGV = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--size", "32", "--labeled", "2", "--unlabeled", "2", "--keypoints", "3", "--no-cpu-baseline",
+LOOPBACK_ARGV = ["--gpus", "1", "--steps", "1", "--warmup", "1", "--size", "32", "--labeled", "2", "--unlabeled", "2", "--keypoints", "3", "--no-cpu-baseline",
                  "--no-profile", "--no-secondary"]
 
 
