@@ -212,7 +212,7 @@ def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
         torch.testing.assert_close(b.grad, a.grad, atol=5e-3 * float(a.grad.abs().max()), rtol=5e-2)
 
 
-@pytest.mark.parametrize("K,H,W,ds,B", [(2, 96, 96, 3, 2), (5, 64, 96, 2, 3), (1, 96, 64, 2, 2)])
+@pytest.mark.parametrize("K,H,W,ds,B", [(2, 96, 96, 3, 2), (5, 64, 96, 2, 3), (1, 96, 64, 2, 2), (3, 64, 64, 1, 2)])
 def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
     """The reference's own HeatmapTracker (verbatim models/heatmap_tracker.py + heads + losses) and the product's, same seed (so the same
     weights by construction order), one supervised step in fp32 on configurations the golden steps do not cover: downsample_factor 3 (one
@@ -257,8 +257,8 @@ def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
     for n_ in layers:
         a = dict(model.head.named_parameters())[n_].grad.cpu()
         b = dict(ref.head.named_parameters())[n_].grad
-        if float(b.norm()) < 1e-3 * max(float(p_.grad.norm()) for _, p_ in ref.head.named_parameters()):
-            continue  # (the last layer's bias: analytically zero under the soft-max)
+        if n_ == [m_ for m_ in layers if m_.endswith(".bias")][-1]:
+            continue  # (the last layer's bias: analytically zero under the soft-max - both sides hold rounding noise, 1e-9)
         assert float((a - b).norm()) <= 2e-3 * float(b.norm()), n_
     with torch.no_grad():
         heat_ref = ref(batch["images"])
