@@ -280,3 +280,45 @@ def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
             getattr(model, step_name)({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
         assert set(model.logged) == set(ref.logged) and f"{stage}_supervised_loss" in ref.logged, (step_name, sorted(ref.logged))
         assert float(model.logged[f"{stage}_supervised_loss"]) == pytest.approx(float(ref.logged[f"{stage}_supervised_loss"]), rel=1e-4)
+
+
+def test_multiview_supervised_tracker_fp32(cpu_stack):
+    """5-D (B, V, 3, H, W) labeled batches through the verbatim HeatmapTracker and the product's: heat-maps regrouped to (B, K, h, w) with
+    K = keypoints over all views, per-view bbox map in predict_step, return_heatmaps=True"""
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import HeatmapTracker
+    from oracle import ref_loader as R
+
+    R.install_stubs()
+    T, Fa, Hm = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("data.heatmaps")
+    dev = cpu_stack
+    Kv, V, HW, B = 3, 2, 64, 2      # num_keypoints is PER VIEW: the network sees B * V images and emits Kv maps for each
+    K = Kv * V
+    ref = T.HeatmapTracker(num_keypoints=Kv, loss_factory=Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
+                           pretrained=False, torch_seed=8, image_size=HW)
+    model = HeatmapTracker(num_keypoints=Kv, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
+                           pretrained=False, torch_seed=8, device=dev, precision="fp32")
+    g = torch.Generator().manual_seed(12)
+    kp = torch.rand(B, K, 2, generator=g) * HW
+    bbox = torch.tensor([[0.0, 0.0, 64.0, 64.0, 10.0, 20.0, 128.0, 96.0]]).repeat(B, 1)
+    batch = {"images": torch.randn(B, V, 3, HW, HW, generator=g), "keypoints": kp.reshape(B, 2 * K),
+             "heatmaps": Hm.generate_heatmaps(kp, HW, HW, (HW // 4, HW // 4)), "bbox": bbox, "num_views": torch.full((B,), V),
+             "idxs": torch.arange(B)}
+    clone = lambda: {k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}  # noqa: E731
+    ref.train()
+    model.train()
+    want = ref.training_step(clone(), 0)
+    model.configure_optimizers()["optimizer"].zero_grad()
+    got = model.training_step({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0)
+    assert float(got["loss"].detach()) == pytest.approx(float(want["loss"].detach()), rel=1e-4)
+    assert set(model.logged) == set(ref.logged)
+    ref.eval()
+    model.eval()
+    with torch.no_grad():
+        kp_ref, conf_ref, heat_ref = ref.predict_step(clone(), 0, return_heatmaps=True)
+        kp_got, conf_got, heat_got = model.predict_step({k_: (v_.to(dev) if torch.is_tensor(v_) else v_) for k_, v_ in batch.items()}, 0,
+                                                        return_heatmaps=True)
+    assert heat_got.shape == heat_ref.shape == (B, K, HW // 4, HW // 4)
+    torch.testing.assert_close(heat_got.cpu(), heat_ref, atol=1e-4 * float(heat_ref.max()), rtol=1e-3)
+    torch.testing.assert_close(conf_got.cpu(), conf_ref, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(kp_got.cpu(), kp_ref, atol=0.3, rtol=0)   # (frame pixels through the second view's 128 x 96 box at [10, 20])
