@@ -322,3 +322,60 @@ def test_multiview_supervised_tracker_fp32(cpu_stack):
     torch.testing.assert_close(heat_got.cpu(), heat_ref, atol=1e-4 * float(heat_ref.max()), rtol=1e-3)
     torch.testing.assert_close(conf_got.cpu(), conf_ref, atol=1e-4, rtol=1e-3)
     torch.testing.assert_close(kp_got.cpu(), kp_ref, atol=0.3, rtol=0)   # (frame pixels through the second view's 128 x 96 box at [10, 20])
+
+
+def test_semisupervised_tracker_fp32(cpu_stack):
+    """The verbatim SemiSupervisedHeatmapTracker (models/heatmap_tracker.py:208-333, models/base.py:627-701) and the product's: one step with
+    temporal + pca_singleview (the verbatim KeypointPCA fit on both sides), a transform handed over as DALI does for a single view
+    (2, 3), labeled + unlabeled batches.  Logged names identical; well-conditioned scalars at 1e-4; keypoint-space scalars of this
+    random-init net at their conditioning."""
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.losses import losses as P
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+    from oracle import ref_loader as R
+
+    R.install_stubs()
+    T, Fa, Hm, L = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("data.heatmaps"), R.load("losses.losses")
+    dev = cpu_stack
+    K, HW, Bl, S = 4, 64, 2, 3
+    g = torch.Generator().manual_seed(77)
+    fit = torch.randn(80, 3, generator=g) @ torch.randn(3, 2 * K, generator=g) * 6 + 30
+    kpca = R.fit_keypoint_pca("pca_singleview", fit, components_to_keep=0.99)
+    temporal = {"log_weight": 1.0, "epsilon": 5.0, "prob_threshold": 0.0}
+    # reference side: the factory builds TemporalLoss itself; PCALoss is placed around the in-memory fit (it would need a data module)
+    r_unsup = Fa.LossFactory({"temporal": dict(temporal)}, None)
+    r_pca = L.PCALoss.__new__(L.PCALoss)
+    L.Loss.__init__(r_pca, log_weight=2.0)
+    r_pca.device, r_pca.loss_name, r_pca.pca, r_pca.epsilon = "cpu", "pca_singleview", kpca, kpca.parameters["epsilon"]
+    r_unsup.loss_instance_dict["pca_singleview"] = r_pca
+    ref = T.SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None),
+                                         loss_factory_unsupervised=r_unsup, backbone="resnet50", pretrained=False, torch_seed=9, image_size=HW)
+    p_unsup = LossFactory({"temporal": dict(temporal),
+                           "pca_singleview": {"loss_name": "pca_singleview", "log_weight": 2.0, "components_to_keep": 0.99, "data_arr": fit,
+                                              "device": str(dev)}}, None)
+    model = SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None),
+                                         loss_factory_unsupervised=p_unsup, backbone="resnet50", pretrained=False, torch_seed=9, device=dev,
+                                         precision="fp32")
+    assert isinstance(p_unsup.loss_instance_dict["pca_singleview"], P.PCALoss)
+    ref.total_unsupervised_importance = torch.tensor(1.0)
+    model.total_unsupervised_importance = torch.tensor(1.0)
+    kp = torch.rand(Bl, K, 2, generator=g) * HW
+    tf = torch.tensor([[1.0, 0.02, 0.5], [-0.02, 1.0, -0.5]])
+    batch = {"labeled": {"images": torch.randn(Bl, 3, HW, HW, generator=g), "keypoints": kp.reshape(Bl, 2 * K),
+                         "heatmaps": Hm.generate_heatmaps(kp, HW, HW, (HW // 4, HW // 4)),
+                         "bbox": torch.tensor([[0.0, 0.0, 64.0, 64.0]]).repeat(Bl, 1), "idxs": torch.arange(Bl)},
+             "unlabeled": {"frames": torch.randn(S, 3, HW, HW, generator=g), "transforms": tf,
+                           "bbox": torch.tensor([[0.0, 0.0, 64.0, 64.0]]).repeat(S, 1), "is_multiview": False}}
+    clone = lambda d: {k_: ({kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v_.items()}) for k_, v_ in d.items()}  # noqa: E731
+    ref.train()
+    model.train()
+    want = ref.training_step(clone(batch), 0)
+    model.configure_optimizers()["optimizer"].zero_grad()
+    got = model.training_step(clone(batch), 0)
+    assert set(model.logged) == set(ref.logged), sorted(set(model.logged) ^ set(ref.logged))
+    for name in ("train_heatmap_mse_loss", "train_supervised_loss", "temporal_weight", "pca_singleview_weight", "total_unsupervised_importance"):
+        assert float(model.logged[name]) == pytest.approx(float(ref.logged[name]), rel=1e-4), name
+    assert float(model.logged["train_temporal_loss"]) == 0.0 == float(ref.logged["train_temporal_loss"])
+    # reprojection error of keypoints that sit near the map centre (flat maps) against a PCA of data around 30 px: tens of pixels
+    assert float(model.logged["train_pca_singleview_loss"]) == pytest.approx(float(ref.logged["train_pca_singleview_loss"]), rel=1e-2)
+    assert float(got["loss"].detach()) == pytest.approx(float(want["loss"].detach()), rel=1e-2)
