@@ -399,6 +399,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 
     f32x16 acc[2][NT];
 
+    // Fused BatchNorm sums on the atomic path (ep.stats_sums): thread t < 2 BN owns (component t / BN, column t % BN) and ADDS UP its
+    // column's tile sums over the tiles this persistent workgroup walks; they go out as one atomic per (workgroup, column) when the column
+    // block or the BatchNorm segment changes and at the end - at most 512 workgroups x 2 BN atomics per launch however many tiles there are
+    // (one atomic per TILE and column was 3.5 M atomics for layer1's 13 824 tiles, which is why large launches used to write per-tile rows
+    // to a workspace and run tile_stats_reduce_kernel afterwards: 45 extra launches per step)
+    float st_acc = 0.f;
+    int st_n0 = -1, st_seg_off = 0;
+    auto stats_flush = [&]() {
+        if (st_n0 >= 0 && tid < 2 * BN) {
+            const int comp = tid / BN, cl = tid % BN;
+            if (st_n0 + cl < N) {
+                atomicAdd(&ep.stats_sums[2 * st_seg_off + comp * N + st_n0 + cl], st_acc);
+                float* accp = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
+                if (accp != nullptr) atomicAdd(&accp[st_n0 + cl], st_acc);
+            }
+        }
+        st_acc = 0.f;
+    };
+
     // ---- epilogue of the tile at (m0, n0): D reg e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31 of its 32x32 tile
     auto epilogue = [&](const int m0, const int n0, const unsigned zo, const unsigned zd = 0u) {
         const int col = lane & 31, rg = lane >> 5;
@@ -553,19 +572,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     so[(1 * RPP + r0) * BN + cc * 8 + q] = s1[q];
                 }
                 __syncthreads();
+                if (ep.stats_sums != nullptr && (n0 != st_n0 || seg_off != st_seg_off)) {  // (workgroup-uniform)
+                    stats_flush();
+                    st_n0 = n0;
+                    st_seg_off = seg_off;
+                }
                 if (tid < 2 * BN) {
                     const int comp = tid / BN, cl = tid % BN;
                     float t = 0.f;
 #pragma unroll
                     for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
                     if (n0 + cl < N) {
-                        if (ep.stats_sums != nullptr) {
-                            atomicAdd(&ep.stats_sums[2 * seg_off + comp * N + n0 + cl], t);
-                            float* acc = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
-                            if (acc != nullptr) atomicAdd(&acc[n0 + cl], t);
-                        } else {
-                            ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
-                        }
+                        if (ep.stats_sums != nullptr) st_acc += t;
+                        else ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
                     }
                 }
             }
@@ -612,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             epilogue(tm_ * kBM, (tile - tm_ * tiles_n) * BN, 0u);
             __syncthreads();
         }
+        if (ep.stats_sums != nullptr) stats_flush();
         return;
     }
     setup(vt);
@@ -638,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         const unsigned zd = zdn;
         if (vt >= ntiles) {
             epilogue(m0, n0, zo, zd);
+            if (ep.stats_sums != nullptr) stats_flush();
             break;
         }
         // next tile's row descriptors and first operands: in flight while this tile is stored
@@ -1139,12 +1160,14 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
-// row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue); LP_STATS_ATOMIC_TILES overrides it (tests force the
-// per-tile workspace + tile_stats_reduce path on small problems with 0)
+// row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue): every launch since the sums are accumulated per persistent
+// workgroup (conv_igemm_kernel: stats_flush).  LP_STATS_ATOMIC_TILES overrides it: 0 selects the per-tile workspace +
+// tile_stats_reduce_kernel path, whose sums are bit-reproducible from run to run (the atomic path adds <= 512 partial sums per column in
+// arrival order); the tests run both
 static int stats_atomic_tiles() {
     static int v = [] {
         const char* e = getenv("LP_STATS_ATOMIC_TILES");
-        return e ? atoi(e) : 1152;
+        return e ? atoi(e) : 0x7fffffff;   // (per-workgroup accumulation: the atomic path costs the same for any number of tiles)
     }();
     return v;
 }
