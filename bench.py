@@ -2,6 +2,7 @@
 """bench.py - training frames/s of the MI355X-native heatmap-tracker step (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no WORLD_SIZE in the environment: spawns its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -487,6 +488,26 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     return out
 
 
+def self_launch(n: int, argv: list[str], entry: str | None = None, env: dict | None = None) -> int:
+    """``python bench.py --gpus N`` typed without a launcher: spawn the N ranks ourselves, exactly as the documented command does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py ...`, one
+    process per GPU, LOCAL_RANK -> device), the way the reference's trainer spawns its own DDP ranks from `devices=cfg.training.num_gpus`
+    (reference train.py:411-428).  The children inherit stdout, so rank 0's ONE JSON line is this process's output; returns the launcher's
+    exit code.  ``entry`` / ``env`` (tests): the script each rank runs and its environment."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), entry or os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(argv: list[str] | None = None, device: torch.device | None = None) -> None:
     """``device`` (tests only): run the whole flow on that device - the CPU with the emulated kernel library - instead of cuda:LOCAL_RANK."""
     ap = argparse.ArgumentParser()
@@ -511,15 +532,18 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
     ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNorm statistics (the reference sets sync_batchnorm=True, train.py:427; A/B only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and device is None:   # no launcher around us: be the launcher
+        raise SystemExit(self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv)))
 
     import torch.distributed as dist
 
     from lightning_pose_amd.distributed import init_process_group_from_env
     from lightning_pose_amd.trainer import Trainer
 
-    rank, local_rank, world = init_process_group_from_env()
-    if world != args.gpus:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:   # (checked before the rendezvous: a mismatched launcher must fail, not hang waiting for ranks that never come)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    rank, local_rank, world = init_process_group_from_env()
     if os.environ.get("LP_FORCE_DEVICE") is not None:  # functional multi-rank test on a 1-GPU box (with LP_DIST_BACKEND=gloo)
         local_rank = int(os.environ["LP_FORCE_DEVICE"])
     dev = torch.device(f"cuda:{local_rank}") if device is None else device

@@ -88,6 +88,46 @@ def test_bench_two_ranks_gloo():
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` typed WITHOUT a launcher (no WORLD_SIZE in the environment) spawns its own two ranks through
+    torch.distributed.run on 127.0.0.1 - here each rank is the CPU probe (gloo + emulated kernels); rank 0's line is the only JSON line."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "32", "--labeled", "2", "--unlabeled", "2", "--keypoints", "3",
+            "--no-cpu-baseline", "--no-profile"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LP_DIST_BACKEND="gloo", HIPEMU_THREADS="4")
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "raise SystemExit(bench.self_launch(2, %r, entry=%r))" % (root, argv, os.path.join(root, "tests", "_bench_2rank_probe.py")))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["sync_batchnorm"] is True and out["value"] > 0
+    assert out["config"]["comm_per_step"]["grad_buckets"] >= 1
+
+
+def test_bench_main_hands_over_to_self_launch_without_a_launcher(monkeypatch):
+    """main(--gpus N) with no WORLD_SIZE calls self_launch with the same argv and exits with its code; with WORLD_SIZE set (a launcher is
+    around us) or --gpus 1 it never does."""
+    calls = []
+    monkeypatch.setattr(bench, "self_launch", lambda n, argv, **kw: calls.append((n, list(argv))) or 7)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "4", "--steps", "3"])
+    assert e.value.code == 7 and calls == [(4, ["--gpus", "4", "--steps", "3"])]
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit) as e:   # a launcher with the wrong world size is still an error, not a second launch
+        bench.main(["--gpus", "4", "--steps", "3"], device=torch.device("cpu"))
+    assert "WORLD_SIZE=2" in str(e.value.code) and len(calls) == 1
+
+
 def _free_port() -> int:
     import socket
 
