@@ -15,7 +15,7 @@ if [ "$mode" = emu ]; then
   for s in "${SRCS[@]}"; do
     [ -f "$s" ] || continue
     o="$out/obj/${s%.hip}.o"
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || [ ../../include/lp_hip.h -nt "$o" ] || [ "$out/hip/hip_runtime.h" -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || { [ "$s" = conv.hip ] && [ conv_pipe.h -nt "$o" ]; } || [ ../../include/lp_hip.h -nt "$o" ] || [ "$out/hip/hip_runtime.h" -nt "$o" ]; then
       "$ROCM/lib/llvm/bin/clang++" -x c++ -std=c++17 -O2 -fPIC -Wno-psabi -Wno-unused-value -I"$out" -c "$s" -o "$o" &
     fi
     objs+=("$o")
@@ -25,17 +25,22 @@ if [ "$mode" = emu ]; then
   mv -f "$out/liblp_emu.so.$$" "$out/liblp_emu.so"
   echo "built $out/liblp_emu.so"
 else
-  mkdir -p obj
+  # A/B builds: LP_BUILD_TAG=name LP_BUILD_FLAGS="-DX=1" build.sh  ->  ../../build/liblp_hip_name.so (objects in obj_name/); load it with LP_HIP_LIB
+  tag=${LP_BUILD_TAG:-}
+  od=obj${tag:+_$tag}
+  mkdir -p "$od"
   objs=()
   for s in "${SRCS[@]}"; do
     [ -f "$s" ] || continue
-    o="obj/${s%.hip}.o"
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || [ ../../include/lp_hip.h -nt "$o" ]; then
-      "$ROCM/bin/hipcc" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+    o="$od/${s%.hip}.o"
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || { [ "$s" = conv.hip ] && [ conv_pipe.h -nt "$o" ]; } || [ ../../include/lp_hip.h -nt "$o" ]; then
+      "$ROCM/bin/hipcc" --offload-arch=gfx950 -O3 -std=c++17 -fPIC ${LP_BUILD_FLAGS:-} -c "$s" -o "$o" &
     fi
     objs+=("$o")
   done
   wait
-  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC -o ../liblp_hip.so "${objs[@]}"
-  echo "built $(cd .. && pwd)/liblp_hip.so"
+  out=../liblp_hip.so
+  if [ -n "$tag" ]; then mkdir -p ../../build; out=../../build/liblp_hip_$tag.so; fi
+  "$ROCM/bin/hipcc" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+  echo "built $(cd "$(dirname "$out")" && pwd)/$(basename "$out")"
 fi

@@ -670,6 +670,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     }
 }
 
+}  // namespace lp
+
+#include "conv_pipe.h"
+
+namespace lp {
+
 // Direct, batched use of the weight-gradient kernel as a TN GEMM (lp_gemm_tn: attention's dV = P^T dO and dK = dS^T Q):
 // out[z][j][n] = sum_m x[z][m][j] * y[z][m][n], one "slice" per batch z, result stored as bf16 instead of going to the split-K
 // workspace.  A null `out` means the ordinary weight-gradient.
@@ -1160,6 +1166,69 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
 
+// Pipelined kernel (conv_pipe.h): one 512-thread workgroup per CU walks 256 x BN tiles.  LP_CONV_PIPE=0 sends everything to
+// conv_igemm_kernel instead (A/B runs, and the tests that compare the two kernels bit for bit); read per call.
+static bool conv_pipe_enabled() {
+    const char* e = getenv("LP_CONV_PIPE");
+    return e == nullptr || atoi(e) != 0;
+}
+
+static int pipe_max_wgs() {
+    const char* e = getenv("LP_CONV_MAX_WGS");   // (tests: several tiles per workgroup on small problems; read per call)
+    const int n = e ? atoi(e) : 0;
+    if (n > 0) return n;
+    static int cus = [] {
+        int dev = 0, c = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        return c;
+    }();
+    return cus;
+}
+
+// what the pipelined kernel covers: dense bf16 output of a trunk convolution (no bias, no fp32 copy), K a multiple of 64 and > 0, N a
+// multiple of its column block, fused BatchNorm sums on the atomic path only, and a BatchNorm segment boundary that falls on a 256-row tile
+static bool pipe_eligible(const ConvEpilogue& ep, int M, int N, int K, int ck, long long seg_rows) {
+    if (!conv_pipe_enabled()) return false;
+    if (ep.out_bf16 == nullptr || ep.out_f32 != nullptr || ep.bias != nullptr || ep.ldo != N || ep.n_store != N) return false;
+    if (K <= 0 || ck % kBK != 0 || N % (N > 64 ? 128 : 64) != 0 || M <= 0) return false;
+    if (ep.stats != nullptr && ep.stats_sums == nullptr) return false;   // (the bit-reproducible workspace path stays on conv_igemm_kernel)
+    if (ep.seg_images > 0 && seg_rows % kPM != 0) return false;
+    return true;
+}
+
+// the store-pass form of a data gradient (conv_pipe.h: kEk*); -1 = a combination only conv_igemm_kernel implements
+static int pipe_dgrad_kind(const ConvEpilogue& ep) {
+    if (ep.bn_z != nullptr) {
+        if (ep.stats_sums == nullptr || ep.relu_mask != nullptr) return -1;
+        if (ep.mask_from_z && !ep.addend && !ep.relu_bits) return kEkZ;
+        if (!ep.mask_from_z && ep.addend && ep.relu_bits) return kEkAZB;
+        return -1;
+    }
+    return (ep.relu_bits == nullptr && ep.stats == nullptr) ? kEkPlain : -1;
+}
+
+template <int BN, int MODE, int EK>
+static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
+                        hipStream_t st) {
+    const int tm = (M + kPM - 1) / kPM, tn = N / BN, ntiles = tm * tn;
+    const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
+    const int ck = MODE == kModeDgrad ? g.Co : g.Ci;
+    const unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
+    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * ck);
+    const char* fe = getenv("LP_PIPE_FLAGS");   // experiment switch: 2 = non-temporal output stores
+    const int flags = fe ? atoi(fe) : 0;
+    hipLaunchKernelGGL((conv_pipe_kernel<BN, MODE, EK>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes,
+                       w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, flags);
+}
+
+template <int BN>
+static void launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
+                              const ConvEpilogue& ep, hipStream_t st) {
+    if (kind == kEkZ) launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
+    else if (kind == kEkAZB) launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
+    else launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
+}
+
 // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue): every launch since the sums are accumulated per persistent
 // workgroup (conv_igemm_kernel: stats_flush).  LP_STATS_ATOMIC_TILES overrides it: 0 selects the per-tile workspace +
 // tile_stats_reduce_kernel path, whose sums are bit-reproducible from run to run (the atomic path adds <= 512 partial sums per column in
@@ -1244,6 +1313,9 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         ep.norm_mean = norm->mean, ep.norm_scale = norm->scale, ep.norm_shift = norm->shift;
         if (N > 64) launch_igemm<128, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
         else launch_igemm<64, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
+    } else if (pipe_eligible(ep, M, N, K, g.Ci, split)) {
+        if (N > 64) launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+        else launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
     } else if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     if (bn && ep.stats_sums == nullptr) {
@@ -1423,7 +1495,12 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
             ++rg.n;
         }
         stats_rows += tm;
-        if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        const long long seg_rows = bn ? seg_split_rows(bn->seg_images, g.B, (long long)lat.nh * lat.nw, M) : M;
+        const int kind = pipe_dgrad_kind(ep);
+        if (kind >= 0 && pipe_eligible(ep, M, N, K, g.Co, seg_rows)) {
+            if (N > 64) launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
+            else launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);
+        } else if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
         else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
     };
     if (bn && bn->seg_images > 0) {  // check every launch's segment boundary BEFORE anything is enqueued

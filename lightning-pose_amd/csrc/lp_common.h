@@ -69,6 +69,12 @@ __device__ __forceinline__ u16x8 buf_load16_nt(buf_rsrc r, unsigned voff, unsign
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
     return __builtin_bit_cast(u16x8, v);
 }
+// 16 B per lane straight into LDS (`buffer_load_dwordx4 ... lds`): lane i of the wave writes lds_wave_base + 16 i (the LDS side is
+// lane-linear from a wave-uniform base; only the SOURCE offset is per lane); an out-of-range voff stores zeros (measured:
+// profiles/probe/glds_probe.hip).  Asynchronous: counted on vmcnt like any load, ordered for a ds_read only by that wait + a barrier.
+__device__ __forceinline__ void buf_load16_lds(buf_rsrc r, void* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
 #else
 struct buf_rsrc {
     const char* p;
@@ -81,6 +87,13 @@ __device__ __forceinline__ u16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned 
     return v;
 }
 __device__ __forceinline__ u16x8 buf_load16_nt(buf_rsrc r, unsigned voff, unsigned soff) { return buf_load16(r, voff, soff); }
+#if !defined(__HIP__)  // CPU logic build: the same data movement, synchronously
+__device__ __forceinline__ void buf_load16_lds(buf_rsrc r, void* lds_wave_base, unsigned voff, unsigned soff) {
+    *reinterpret_cast<u16x8*>(static_cast<char*>(lds_wave_base) + (threadIdx.x & 63) * 16) = buf_load16(r, voff, soff);
+}
+#else  // host pass of hipcc: declaration only
+__device__ __forceinline__ void buf_load16_lds(buf_rsrc, void*, unsigned, unsigned) {}
+#endif
 #endif
 
 // ---- LDS transpose read (ds_read_b64_tr_b16): within every group of 16 lanes the 16 addresses name a [4 rows][16 columns]

@@ -59,13 +59,16 @@ class GraphedStep:
                 tuple(sorted((k, str(v)) for k, v in _flat_scalars(batch))))
 
     def _adopt(self, batch) -> dict:
-        """the captured graph reads its inputs from these tensors: the first batch's own device tensors"""
-        return batch
+        """The captured graph reads its inputs from PRIVATE copies of the first batch's tensors: _load overwrites them with every later
+        batch, and a caller may hand the same batch objects in again next epoch (a list of batches reused every epoch, bench.py) - writing
+        through the caller's own tensors would silently replace batch 0's data with the last batch's."""
+        def clone(d):
+            return {k: (clone(v) if isinstance(v, dict) else v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+        return clone(batch)
 
     def _load(self, batch) -> None:
         for (n, dst), (_, src) in zip(_tensors(self.static), _tensors(batch)):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src, non_blocking=True)
+            dst.copy_(src, non_blocking=True)   # (one batch of D2D copies per step: negligible next to the step)
 
     def step(self, batch: dict, batch_idx: int) -> torch.Tensor:
         trainer, model = self.trainer, self.model
@@ -99,6 +102,11 @@ class GraphedStep:
         opt.advance()
         self.graph.replay()
         self.replays += 1
+        # the replayed kernels changed the parameters and the running statistics: whatever the inference forward folded out of the old
+        # ones is stale (the eager step drops it in FusedAdam.step / the training forward, neither of which runs on a replay)
+        inval = getattr(model.net, "invalidate_inference_copies", None)
+        if inval is not None:
+            inval()
         # host-side bookkeeping the captured kernels do not carry
         model.logged = dict(self._logged)
         model.global_step += 1

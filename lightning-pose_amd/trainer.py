@@ -159,6 +159,8 @@ class Trainer:
             self._hook("on_train_epoch_start", model)
             it = iter(batches(epoch) if callable(batches) else batches)
             nxt = next(it, None)
+            if self.limit_train_batches is not None and self.limit_train_batches <= 0:
+                nxt = None   # Lightning: limit_train_batches = 0 means no training batches (and no optimiser step)
             batch_idx = 0
             while nxt is not None:  # one batch of look-ahead: the last batch of the epoch closes a partial accumulation group
                 batch, nxt = nxt, next(it, None)

@@ -19,6 +19,11 @@ STEP_CONFIGS = {
     "c5": dict(HW=256, K=4, Bl=2, S=4, V=2, seed=14, unsup=("temporal", "pca_multiview")),
     # config 4: ViT-S/16 (backbone "vits_dino": HF ViTModel, interpolate_pos_encoding) at 384x384, K=17, 2 labeled + 4 unlabeled frames
     "c4": dict(HW=384, K=17, Bl=2, S=4, V=1, seed=15, unsup=("temporal", "pca_singleview"), backbone="vits_dino"),
+    # BASELINE config 2 at its REAL per-GPU batch (64 labeled + 128 unlabeled frames, 384x384, K=17): what bench.py times - the joint
+    # labeled + unlabeled pass with its BatchNorm segment boundary at 64 * H * W rows and the persistent tile walks of 13.8 k tiles
+    "c2full": dict(HW=384, K=17, Bl=64, S=128, V=1, seed=16, unsup=("temporal", "pca_singleview")),
+    # BASELINE config 5 with its real FOUR views (256x256 views, temporal + pca_multiview)
+    "c5v4": dict(HW=256, K=4, Bl=2, S=4, V=4, seed=17, unsup=("temporal", "pca_multiview")),
 }
 # The head is TRAINED before the measured step (make_golden.py::_train_head: Adam on the head alone, over the cached features of the
 # step's own frames, targets = Gaussians at the blob centres): a randomly initialised head (xavier gain 0.01) gives numerically flat

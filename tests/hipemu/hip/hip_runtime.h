@@ -518,6 +518,9 @@ inline v4f mfma_16x16x4_f32(float a, float b, v4f c, int, int, int) {
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// lanes of a wave run in lock step on the device; here they are fibers, so code that exchanges data between the lanes of ONE wave
+// through LDS marks the exchange points with a wave barrier (a pure scheduling fence on the device)
+#define __builtin_amdgcn_wave_barrier() ::hipemu::yield_with(::hipemu::WAIT_WAVE)
 
 // ---- launch -------------------------------------------------------------------------------------
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                   \

@@ -1,0 +1,91 @@
+"""The pipelined convolution kernel (csrc/conv_pipe.h: direct-to-LDS operand ring, 256-row tiles, swapped-role MFMA store pass) against
+conv_igemm_kernel on the same operands: outputs BIT-identical (same K order, same rounding points), fused BatchNorm sums equal up to
+fp32 summation order.  LP_CONV_PIPE is read per call, so both kernels run in one process; LP_CONV_MAX_WGS forces long persistent walks
+(the loader crosses tile boundaries two K steps ahead of the MFMAs; the per-thread BatchNorm sums flush when the column block changes)."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.hipemu import emu
+
+pytestmark = pytest.mark.usefixtures("kernel_backend")
+
+CASES = [
+    # B, Hi, Wi, Ci, Co, R, stride, pad
+    (2, 8, 8, 64, 64, 1, 1, 0),       # 1x1, one K step per tile (the loader is two TILES ahead), M = 128 < one tile
+    (3, 16, 16, 64, 128, 3, 1, 1),    # 3x3 "same", M = 768 = 3 tiles, BN = 128
+    (1, 19, 15, 128, 64, 3, 1, 1),    # M = 285: a ragged second tile; two K steps per tap; BN = 64
+    (2, 18, 18, 64, 256, 3, 2, 1),    # 3x3 stride 2 (4 parity-class launches in the data gradient), two column tiles
+    (4, 16, 16, 256, 64, 1, 1, 0),    # 1x1 reduce (K = 256), 4 tiles
+    (5, 8, 8, 128, 128, 1, 2, 0),     # 1x1 stride 2 (downsample): data gradient has three empty parity classes (old kernel) + one pipelined
+]
+
+
+def _both(monkeypatch, fn):
+    monkeypatch.setenv("LP_CONV_PIPE", "0")
+    ref = fn()
+    monkeypatch.setenv("LP_CONV_PIPE", "1")
+    return ref, fn()
+
+
+@pytest.mark.parametrize("wgs", ["0", "1", "2"])
+@pytest.mark.parametrize("case", CASES)
+def test_pipe_equals_igemm(case, wgs, monkeypatch):
+    if wgs != "0":
+        monkeypatch.setenv("LP_CONV_MAX_WGS", wgs)
+    B, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(11 + sum(case))
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    x = emu.to_bf16_bits(torch.randn(B, Hi, Wi, Ci, generator=gen))
+    w = torch.randn(Co, R, R, Ci, generator=gen) / (Ci * R * R) ** 0.5
+    wg, wd = emu.to_bf16_bits(w), emu.to_bf16_bits(w.permute(3, 1, 2, 0))
+    # forward, plain and with the fused BatchNorm sums
+    (z0, _), (z1, _) = _both(monkeypatch, lambda: emu.conv_fwd(x, wg, g))
+    assert np.array_equal(z0, z1)
+    (zb0, s0), (zb1, s1) = _both(monkeypatch, lambda: emu.conv_fwd_bn(x, wg, g))
+    assert np.array_equal(zb0, z0) and np.array_equal(zb1, z0)
+    np.testing.assert_allclose(s1, s0, rtol=2e-5, atol=2e-4)
+    # data gradient: addend + each ReLU-mask source, plain and with the BatchNorm-backward sums
+    Mi = B * Hi * Wi
+    zin_bits = emu.to_bf16_bits(torch.randn(Mi, Ci, generator=gen))
+    gamma, beta = torch.rand(Ci, generator=gen) + 0.5, torch.randn(Ci, generator=gen) * 0.3
+    a_bits, mean, invstd, relu_bits = emu.bn_forward(zin_bits, Mi, Ci, gamma.numpy(), beta.numpy(), relu=True, want_bits=True)
+    dy = emu.to_bf16_bits(torch.randn(B * g.Ho * g.Wo, Co, generator=gen))
+    add = emu.to_bf16_bits(torch.randn(Mi, Ci, generator=gen))
+    (d0, _), (d1, _) = _both(monkeypatch, lambda: emu.conv_dgrad(dy, wd, g, addend_bits=add, mask_bits=a_bits))
+    assert np.array_equal(d0, d1)
+    (e0, _), (e1, _) = _both(monkeypatch, lambda: emu.conv_dgrad(dy, wd, g))
+    assert np.array_equal(e0, e1)
+    for mask, bits in ((a_bits, None), (None, None), (None, relu_bits)):
+        r0, r1 = _both(monkeypatch, lambda: emu.conv_dgrad_bn(dy, wd, g, zin_bits, mean, invstd, gamma.numpy(), beta.numpy(), addend_bits=add,
+                                                           mask_bits=mask, relu_bits=bits))
+        assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[0], d0)
+        for a, b in zip(r0[1:], r1[1:]):
+            np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)
+
+
+def test_pipe_two_batchnorm_segments(monkeypatch):
+    """Joint labeled + unlabeled pass: images [0, seg) and [seg, B) keep their own sums; the boundary sits on a 256-row tile."""
+    gen = torch.Generator().manual_seed(5)
+    B, H, Ci, Co, seg = 3, 16, 64, 128, 1      # 256 rows per image
+    g = emu.geom(B, H, H, Ci, Co, 1, 1, 1, 0)
+    x = emu.to_bf16_bits(torch.randn(B, H, H, Ci, generator=gen))
+    w = emu.to_bf16_bits(torch.randn(Co, 1, 1, Ci, generator=gen) / 8)
+    (z0, s0), (z1, s1) = _both(monkeypatch, lambda: emu.conv_fwd_bn(x, w, g, seg=seg))
+    assert np.array_equal(z0, z1) and s0.shape == (2, 2, Co)
+    np.testing.assert_allclose(s1, s0, rtol=2e-5, atol=2e-4)
+    zf = emu.from_bf16_bits(z1).double().reshape(B, -1, Co)
+    np.testing.assert_allclose(s1[0, 0], zf[:seg].sum((0, 1)).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(s1[1, 1], (zf[seg:] ** 2).sum((0, 1)).numpy(), rtol=1e-5, atol=1e-4)
+    # backward: per-segment mean / invstd select by row, sums per segment
+    M = B * H * H
+    zin = emu.to_bf16_bits(torch.randn(M, Ci, generator=gen))
+    mean, invstd = torch.randn(2, Ci, generator=gen).numpy() * 0.1, (torch.rand(2, Ci, generator=gen) + 0.5).numpy()
+    gamma, beta = (torch.rand(Ci, generator=gen) + 0.5).numpy(), (torch.randn(Ci, generator=gen) * 0.3).numpy()
+    dy = emu.to_bf16_bits(torch.randn(M, Co, generator=gen))
+    wd = emu.to_bf16_bits(torch.randn(Ci, 1, 1, Co, generator=gen) / 11)
+    r0, r1 = _both(monkeypatch, lambda: emu.conv_dgrad_bn(dy, wd, g, zin, mean, invstd, gamma, beta, seg=seg))
+    assert np.array_equal(r0[0], r1[0])
+    for a, b in zip(r0[1:], r1[1:]):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)

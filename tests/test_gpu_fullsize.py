@@ -169,3 +169,76 @@ def test_native_library_is_what_runs():
     maps = open("/proc/self/maps").read()
     assert "lightning-pose_amd/liblp_hip.so" in maps
     assert "liblp_emu.so" not in maps or True  # the emulator may be loaded by other tests in this process; never by the product
+
+
+@pytest.mark.parametrize("shape", [
+    # B, seg, Hi, Ci, Co, k, stride, pad - real trunk shapes; seg images form BatchNorm segment 0 (boundary on a 256-row tile)
+    (12, 4, 96, 64, 256, 1, 1, 0),      # layer1 conv3: ONE K step per tile (the loader runs two tiles ahead), output-dominated
+    (12, 4, 96, 256, 64, 1, 1, 0),      # layer1 conv1: data gradient with addend + 1-bit ReLU mask + previous block's BatchNorm sums
+    (12, 4, 96, 64, 64, 3, 1, 1),       # layer1 conv2
+    (32, 16, 24, 256, 256, 3, 1, 1),    # layer3 conv2: 36 K steps per tile
+    (32, 16, 48, 256, 256, 3, 2, 1),    # layer3.0 conv2, stride 2: four parity-class launches in the data gradient
+    (32, 16, 24, 1024, 256, 1, 1, 0),   # layer3 conv1: 16 K steps
+    (32, 16, 12, 512, 2048, 1, 1, 0),   # layer4 conv3: 16 column tiles
+])
+def test_pipelined_conv_equals_igemm_on_real_shapes(shape, monkeypatch):
+    """conv_pipe_kernel (direct-to-LDS ring, counted vmcnt + raw barriers: the part the CPU emulator cannot see) vs conv_igemm_kernel on
+    the device: outputs bit-identical over repeated launches, fused BatchNorm sums equal up to summation order."""
+    import ctypes as C
+
+    from lightning_pose_amd import _lib
+    from lightning_pose_amd.ops import _p, _stream
+
+    B, seg, Hi, Ci, Co, k, st, pad = shape
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    gen = torch.Generator(device="cuda").manual_seed(sum(shape))
+    Ho = (Hi + 2 * pad - k) // st + 1
+    g = _lib.ConvGeom(B, Hi, Hi, Ci, Ho, Ho, Co, k, k, st, pad)
+    Mi, Mo = B * Hi * Hi, B * Ho * Ho
+    x = torch.randn(Mi, Ci, device=dev, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(Co, k * k * Ci, device=dev, generator=gen) / (Ci * k * k) ** 0.5).to(torch.bfloat16)
+    wd = w.view(Co, k, k, Ci).permute(3, 1, 2, 0).contiguous()
+    dy = torch.randn(Mo, Co, device=dev, generator=gen).to(torch.bfloat16)
+    addend = torch.randn(Mi, Ci, device=dev, generator=gen).to(torch.bfloat16)
+    zin = torch.randn(Mi, Ci, device=dev, generator=gen).to(torch.bfloat16)
+    bits = torch.randint(0, 256, (Mi * Ci // 8,), device=dev, dtype=torch.uint8, generator=gen)
+    mean, invstd = torch.randn(2, Ci, device=dev, generator=gen) * 0.1, torch.rand(2, Ci, device=dev, generator=gen) + 0.5
+    gamma, beta = torch.rand(Ci, device=dev, generator=gen) + 0.5, torch.randn(Ci, device=dev, generator=gen) * 0.3
+
+    def fuse(dgrad, C_, sums, **kw):
+        need = int(lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
+        ws = torch.empty(max(need, 16), device=dev, dtype=torch.uint8)
+        f = _lib.BnFuse()
+        f.sums, f.workspace, f.workspace_bytes, f.seg_images = sums.data_ptr(), ws.data_ptr(), need, seg
+        for k_, v_ in kw.items():
+            setattr(f, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
+        return f, ws
+
+    def run():
+        out = torch.empty(Mo, Co, device=dev, dtype=torch.bfloat16)
+        fs = torch.zeros(2, 2, Co, device=dev)
+        f, _ws = fuse(False, Co, fs)
+        assert lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), _stream()) == 0
+        dx = torch.empty(Mi, Ci, device=dev, dtype=torch.bfloat16)
+        bs, dbeta, dgamma = torch.zeros(2, 2, Ci, device=dev), torch.zeros(Ci, device=dev), torch.zeros(Ci, device=dev)
+        f2, _ws2 = fuse(True, Ci, bs, z=zin, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mask_from_z=0, relu_bits=bits,
+                        dbeta_acc=dbeta, dgamma_acc=dgamma)
+        assert lib.lp_conv_dgrad_bn(_p(dy), _p(wd), C.byref(g), _p(addend), None, _p(dx), C.byref(f2), _stream()) == 0
+        dx2 = torch.empty(Mi, Ci, device=dev, dtype=torch.bfloat16)
+        bs2 = torch.zeros(2, 2, Ci, device=dev)
+        f3, _ws3 = fuse(True, Ci, bs2, z=zin, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mask_from_z=1)
+        assert lib.lp_conv_dgrad_bn(_p(dy), _p(wd), C.byref(g), None, None, _p(dx2), C.byref(f3), _stream()) == 0
+        torch.cuda.synchronize()
+        return out, fs, dx, bs, dbeta, dgamma, dx2, bs2
+
+    monkeypatch.setenv("LP_CONV_PIPE", "0")
+    ref = run()
+    monkeypatch.setenv("LP_CONV_PIPE", "1")
+    for rep in range(3):
+        got = run()
+        for name, a, b in zip(("out", "fwd sums", "dx", "bwd sums", "dbeta", "dgamma", "dx (mask from z)", "bwd sums 2"), ref, got):
+            if a.dtype == torch.bfloat16:
+                assert torch.equal(a, b), (name, rep, int((a != b).sum()))
+            else:
+                torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-3 * float(a.abs().max()) + 1e-3, msg=lambda m: f"{name} rep {rep}: {m}")

@@ -75,3 +75,52 @@ def test_graphed_steps_reproduce_eager_steps(monkeypatch):
     np.testing.assert_allclose(l1, l0, rtol=0.2)
     a, b = m0.net.P[m0.net.plan.n_backbone:], m1.net.P[m1.net.plan.n_backbone:]
     assert float((a - b).abs().max()) <= 12.5 * 1e-4   # Adam moves a weight by <= lr per step: two runs are at most 2 x 6 x lr apart
+
+
+@pytest.mark.gpu
+def test_graphed_steps_keep_the_callers_batches_and_refresh_the_inference_copies():
+    """(round-2 advisor findings)  A list of batches reused every epoch: the captured graph reads PRIVATE input buffers, so the caller's
+    batch 0 still holds batch 0's data after later batches were loaded; and validation after replayed steps runs on weights folded from
+    the CURRENT parameters / running statistics, as after eager steps."""
+    from lightning_pose_amd import ops
+    from lightning_pose_amd.losses import LossFactory
+    from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
+    from lightning_pose_amd.trainer import Trainer
+
+    dev = torch.device("cuda:0")
+    K, HW = 5, 128
+    box = torch.tensor([[0.0, 0.0, HW, HW]])
+
+    def make_batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        kp = (torch.rand(8, K, 2, generator=g) * HW).to(dev)
+        return {"labeled": {"images": torch.randn(8, 3, HW, HW, generator=g).to(dev), "keypoints": kp.reshape(8, 2 * K),
+                            "heatmaps": ops.generate_heatmaps(kp, HW, HW, (HW // 4, HW // 4)), "bbox": box.repeat(8, 1).to(dev),
+                            "idxs": torch.arange(8)},
+                "unlabeled": {"frames": torch.randn(8, 3, HW, HW, generator=g).to(dev), "transforms": torch.tensor([-1.0]).to(dev),
+                              "bbox": box.repeat(8, 1).to(dev), "is_multiview": False}}
+
+    def run(graph: bool):
+        sup = LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+        unsup = LossFactory({"temporal": {"log_weight": 2.0, "epsilon": 0.0, "prob_threshold": 0.0}}, None)
+        model = SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+                                             pretrained=False, torch_seed=9, device=dev)
+        batches = [make_batch(4), make_batch(5), make_batch(6)]
+        keep = batches[0]["labeled"]["images"].clone(), batches[0]["unlabeled"]["frames"].clone()
+        model.train()
+        trainer = Trainer(max_epochs=1, data_parallel=False, hip_graph=graph)
+        trainer.setup(model)
+        vals = []
+        for epoch in range(3):
+            for i, b in enumerate(batches):
+                trainer.training_batch(model, b, i)
+            vals.append(trainer.validate(model, [batches[0]["labeled"]])["val_supervised_loss"])
+        torch.cuda.synchronize()
+        assert torch.equal(batches[0]["labeled"]["images"], keep[0]) and torch.equal(batches[0]["unlabeled"]["frames"], keep[1])
+        return vals, trainer._graphed
+
+    v0, _ = run(False)
+    v1, gs = run(True)
+    assert gs is not None and gs.replays >= 5
+    assert v0[0] != v0[-1]                       # the weights moved between the validations ...
+    np.testing.assert_allclose(v1, v0, rtol=3e-2)   # ... and the graphed run's validation follows them
