@@ -36,6 +36,7 @@ import _lp_bootstrap  # noqa: E402,F401
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+HBM_SUSTAINED_GBS = 6300.0      # what a streaming kernel reaches on this part (same guide): the bandwidth leg of a launch's own roof
 VALU_FP32_PEAK_TFLOPS = 157.0   # fp32 vector peak, same guide
 TRAIN_GFLOP_PER_FRAME = {384: 72.4, 256: 32.2}  # 3 x 2 x (trunk + head) MACs
 VIT_S_TRAIN_GFLOP_PER_FRAME = {384: 93.1, 256: 36.9}  # SURVEY.md section 8(d), ViT-S/16
@@ -439,16 +440,22 @@ def train_line(args, dev, rank: int, world: int) -> dict:
             by: dict[str, list[float]] = {}
             tot_ms, tot_flops = 0.0, 0.0
             tot_bytes = 0.0
+            tot_roof_ms = 0.0
             for tag, flops, e0, e1, nbytes in prof:
                 ms = e0.elapsed_time(e1)
-                rec = by.setdefault(tag, [0, 0.0, 0.0, 0.0])
+                # the launch's OWN roof: whichever of its algorithmic FLOPs at the dense bf16 MFMA peak and its algorithmic bytes at the
+                # HBM rate this part sustains (6.3 TB/s, MI355X_MICROARCH.md) takes longer
+                roof_ms = 1e3 * max(flops / (MFMA_BF16_PEAK_TFLOPS * 1e12), nbytes / (HBM_SUSTAINED_GBS * 1e9))
+                rec = by.setdefault(tag, [0, 0.0, 0.0, 0.0, 0.0])
                 rec[0] += 1
                 rec[1] += ms
                 rec[2] += flops
                 rec[3] += nbytes
+                rec[4] += roof_ms
                 tot_ms += ms
                 tot_flops += flops
                 tot_bytes += nbytes
+                tot_roof_ms += roof_ms
             dump = os.environ.get("LP_DUMP_LAUNCHES")
             if dump:  # per-launch (tag, GFLOP, us) of the LAST timed step, for kernel tuning
                 per_step = len(prof) // prof_steps
@@ -458,8 +465,11 @@ def train_line(args, dev, rank: int, world: int) -> dict:
             traffic, traffic_src = pmc_traffic() if (not is_vit and args.size == 384 and args.views == 1) else (None, None)
             out["roofline"] = {
                 "bound": "mfma", "kernel": ("lp_gemm_nt / conv_wgrad_kernel / attn_fwd_kernel / attn_bwd_kv_kernel (all MFMA launches of the ViT)" if is_vit
-                                            else "conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches)"),
+                                            else "conv_pipe_kernel / conv_wgrad_pipe_kernel / conv_igemm_kernel / conv_wgrad_kernel (all MFMA convolution launches; by_kernel splits them)"),
                 "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                # each launch against its OWN roof: sum over launches of max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s), over the
+                # measured time - 1.0 would mean every launch is either MFMA- or HBM-bound at the hardware rate
+                "attainable_frac": round(tot_roof_ms / tot_ms, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(tot_bytes / len(prof)),
                 "traffic_over_algorithmic": round(traffic / (tot_bytes / len(prof)), 3) if traffic else None,
@@ -467,7 +477,8 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                 "launches_per_step": len(prof) // prof_steps, "mfma_ms_per_step": round(tot_ms / prof_steps, 3),
                 "sampled_steps": prof_steps,
                 "by_kernel": {k: {"launches_per_step": v[0] // prof_steps, "avg_us": round(1000 * v[1] / v[0], 2),
-                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "algorithmic_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1)}
+                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "algorithmic_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                  "attainable_frac": round(v[4] / v[1], 4)}
                               for k, v in sorted(by.items())},
             }
         gf = (VIT_S_TRAIN_GFLOP_PER_FRAME if args.backbone == "vits_dino" else {} if is_vit else TRAIN_GFLOP_PER_FRAME).get(args.size)

@@ -165,6 +165,15 @@ typedef struct lp_conv_geom {
     int R, S, stride, pad;
 } lp_conv_geom;
 
+/* Which kernel family the most recent convolution entry point called from this thread launched: conv_igemm_kernel (register-staged,
+ * 128-row tiles), conv_pipe_kernel (direct-to-LDS ring, 256-row tiles; LP_CONV_PIPE=0 disables it), or the two weight-gradient kernels.
+ * Diagnostic only (bench labels, tests); replaces nothing in the reference. */
+#define LP_CONV_KERNEL_IGEMM 0
+#define LP_CONV_KERNEL_PIPE 1
+#define LP_CONV_KERNEL_WGRAD 2
+#define LP_CONV_KERNEL_WGRAD_PIPE 3
+int lp_conv_last_kernel(void);
+
 /* w: bf16 [Co][R][S][Ci] (Ci % 64 == 0).  Output row-major [B*Ho*Wo][ldo], columns < n_store written. */
 int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
                 int n_store, lp_stream_t stream);
@@ -255,16 +264,6 @@ int lp_bn_fold(const float* w, const float* gamma, const float* beta, const floa
 int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, const void* residual_bf16, int relu,
                     void* out_bf16, lp_stream_t stream);
 int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
-/* Normalise-on-load for a 1x1 / stride-1 convolution that consumes relu(BatchNorm(z)) (the bottleneck's conv3 after bn2, torchvision
- * Bottleneck semantics, reference models/backbones/factory.py:322-348): z goes in instead of the activation, and the gathered operand
- * becomes bf16(relu((z - mean) * scale + shift)) while it is staged - bit for bit what lp_bn_apply would have stored - so that
- * activation is never written (forward) nor read (forward, weight gradient).  mean, scale (= invstd * gamma: lp_bn_affine), shift
- * (= beta) are (segments, Ci) fp32; segments as in lp_bn_fuse.seg_images.  LP_ERR_UNSUPPORTED for any other filter geometry. */
-int lp_bn_affine(const float* invstd, const float* gamma, int nseg, int C, float* scale, lp_stream_t stream);
-int lp_conv_fwd_bn_norm(const void* z, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, const float* norm_mean,
-                        const float* norm_scale, const float* norm_shift, lp_stream_t stream);
-int lp_conv_wgrad_norm(const void* z, const void* dy, const lp_conv_geom* geom, float* dw, const float* norm_mean, const float* norm_scale,
-                       const float* norm_shift, int seg_images, int split_hint, void* workspace, size_t workspace_bytes, lp_stream_t stream);
 int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
 int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
                      void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream);

@@ -52,6 +52,7 @@ class GemmBatch(C.Structure):
 
 
 HM_MSE, HM_KL, HM_JS = 0, 1, 2
+CONV_KERNEL_IGEMM, CONV_KERNEL_PIPE, CONV_KERNEL_WGRAD, CONV_KERNEL_WGRAD_PIPE = 0, 1, 2, 3   # lp_conv_last_kernel()
 BORDER_RENORM, BORDER_CLAMP = 0, 1
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
@@ -92,9 +93,7 @@ PROTOTYPES = {
     "lp_attn_dscores": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_float, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
-    "lp_bn_affine": (_I, [_P, _P, _I, _I, _P, _P]),
-    "lp_conv_fwd_bn_norm": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P, _P, _P, _P]),
-    "lp_conv_wgrad_norm": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
+    "lp_conv_last_kernel": (_I, []),
     "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
     "lp_bn_fold": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),

@@ -638,19 +638,6 @@ extern "C" int lp_bn_finalize2(const float* sums, float count0, float count1, in
     return launch_status();
 }
 
-// scale[s][c] = invstd[s][c] * gamma[c]: the per-channel factor lp_bn_apply forms in registers, as a table for the convolutions that
-// normalise their operand on load (lp_conv_fwd_bn_norm / lp_conv_wgrad_norm); same fp32 product, so the results agree bit for bit
-__global__ void bn_affine_kernel(const float* __restrict__ invstd, const float* __restrict__ gamma, int nseg, int C, float* __restrict__ scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nseg * C) scale[i] = invstd[i] * gamma[i % C];
-}
-
-extern "C" int lp_bn_affine(const float* invstd, const float* gamma, int nseg, int C, float* scale, lp_stream_t stream) {
-    using namespace lp;
-    LP_REQUIRE(invstd && gamma && scale && nseg > 0 && C > 0);
-    hipLaunchKernelGGL(bn_affine_kernel, dim3((nseg * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, invstd, gamma, nseg, C, scale);
-    return launch_status();
-}
 
 static int bn_apply_impl(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                          int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream) {

@@ -71,11 +71,6 @@ struct ConvEpilogue {
     // straddles the boundary (host-checked: seg_images * rows per image is a multiple of the 128-row tile).  Segment s uses
     // bn_mean / bn_invstd + s * N and adds into stats_sums + s * 2 * N; 0 = one segment
     int seg_images;
-    // kModeFwdNorm: per-channel terms of the BatchNorm in front of this convolution, (segments, Ci) each: mean, scale = invstd * gamma,
-    // shift = beta (the A rows of a tile belong to one segment, like its output rows)
-    const float* norm_mean;
-    const float* norm_scale;
-    const float* norm_shift;
 };
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
@@ -91,10 +86,7 @@ struct GemmExt {
 
 // kModeAttn = kModeFwd with the soft-max backward in the store pass; kModeInfer = kModeFwd whose store pass adds a residual and
 // applies the ReLU (inference with folded BatchNorm: its own instantiation, so the training kernels' code is untouched)
-// kModeFwdNorm = kModeFwd of a 1x1 convolution whose INPUT is a pre-normalisation tensor z: the A operand becomes
-// bf16(relu((z - mean) * scale + shift)) while it is staged (exactly what lp_bn_apply would have stored), so the activation between a
-// BatchNorm and the 1x1 convolution that consumes it is never written or read
-enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3, kModeInfer = 4, kModeFwdNorm = 5 };
+enum { kModeFwd = 0, kModeDgrad = 1, kModeStem = 2, kModeAttn = 3, kModeInfer = 4 };
 
 // One launch covers a sub-lattice of output pixels and of filter taps.  Ordinary launches use the full lattices; the data
 // gradient of a stride-2 convolution is split into its 4 output-parity classes, each of which only sees the taps of matching
@@ -242,9 +234,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     const bool stream_a = tiles_n == 1 && lat.nr * lat.ns == 1;
 
     u16x8 ra[4], rb[BN / 32];
-    // kModeFwdNorm: this lane's 8 channels of (mean, scale, shift) for the K step held in ra
-    f32x4 nmu[2], nsc[2], nbe[2];
-    int norm_seg = 0;              // ... taken from this segment's rows of the tables (element offset)
     int tir = 0, tis = 0, tc = 0;  // filter-tap lattice index and channel offset of the NEXT K step to load
     unsigned voff[4];              // byte offsets of the 4 A rows for the current tap (~0 where the tap is padding)
     unsigned wtap = 0;             // byte offset of the current tap inside a weight row
@@ -309,7 +298,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             wrow[i] = (unsigned)(n * gx.ldw + kchunk * 8) * 2u + zw;  // row stride = the FULL filter
         }
         tir = tis = tc = 0;
-        if (MODE == kModeFwdNorm) norm_seg = (ep.seg_images > 0 && m0n >= ep.seg_images * rows_y * rows_x) ? ck : 0;
     };
 
     // `with_b = false` (the data-gradient's prefetch across its register-hungry store pass) leaves the weight rows for
@@ -344,15 +332,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                 }
             }
             const unsigned tcb = (unsigned)tc * 2u;
-            if (MODE == kModeFwdNorm) {  // (1x1 only: the K offset IS the channel)
-                const int c0 = norm_seg + tc + kchunk * 8;
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    nmu[h2] = *reinterpret_cast<const f32x4*>(ep.norm_mean + c0 + 4 * h2);
-                    nsc[h2] = *reinterpret_cast<const f32x4*>(ep.norm_scale + c0 + 4 * h2);
-                    nbe[h2] = *reinterpret_cast<const f32x4*>(ep.norm_shift + c0 + 4 * h2);
-                }
-            }
             if (stream_a) {  // single column of tiles and a single tap: every activation byte is fetched exactly once
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ra[i] = buf_load16_nt(rsrc_x, voff[i], tcb);
@@ -381,16 +360,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
         for (int i = 0; i < BN / 32; ++i) rb[i] = buf_load16(rsrc_w, wrow[i], b_deferred);
     };
     auto store_step = [&](int buf) {
-        if (MODE == kModeFwdNorm) {  // normalise + ReLU on the way into LDS, rounded to bf16 exactly as lp_bn_apply stores it
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    v[q] = fmaxf(fmaf(bf16_to_f32(ra[i][q]) - nmu[q >> 2][q & 3], nsc[q >> 2][q & 3], nbe[q >> 2][q & 3]), 0.f);
-                ra[i] = pack_bf16x8(v);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(rbase + 32 * i) * kLD + kchunk * 8]) = ra[i];
 #pragma unroll
@@ -698,20 +667,11 @@ struct TnExt {
 // wgrad_reduce_kernel then sums the slices in a fixed order and adds the result into dW - deterministic, and ~20x
 // cheaper than fp32 atomics (measured: 17 M atomics per launch cost 450 us, the same bytes as plain stores ~20 us).
 // ------------------------------------------------------------------------------------------------------------
-// NORM (1x1 convolutions only): x is a PRE-normalisation tensor; the gathered operand becomes bf16(relu((x - mean) * scale + shift)) on
-// its way into LDS - the activation lp_bn_apply would have stored, which the forward pass never wrote (kModeFwdNorm)
-struct WgradNorm {
-    const float* mean;   // (segments, Ci)
-    const float* scale;  // invstd * gamma
-    const float* shift;  // beta
-    int seg_row;         // pixels [0, seg_row) are BatchNorm segment 0, the rest segment 1 (a multiple of the 64-pixel K step); 0 = one
-};
-
-template <int BN, bool STEM, bool CS = false, bool NORM = false>
+template <int BN, bool STEM, bool CS = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                          unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles,
                                                          int tiles_n, int m_per_split, FastDiv div_hw, FastDiv div_wo,
-                                                         float* __restrict__ ws, TnExt tn, WgradNorm nrm = WgradNorm{}) {
+                                                         float* __restrict__ ws, TnExt tn) {
     constexpr int NT = BN / 64;
     constexpr int RB = BN / 32;  // dy rows (pixels) per thread per K step: 4 (BN=128) or 2 (BN=64)
     // Operand tiles stay in their memory orientation, [pixel][channel] (K = pixel is the ROW index): the 16-B chunks go to LDS
@@ -874,29 +834,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         if (fast && (direct || mk + kBK <= m_end)) load_fast(mk);
         else load_generic(mk);
     };
-    float nmu[8], nsc[8], nbe[8];
-    int norm_seg = -1;
     auto store_step = [&](int buf, int mk) {
-        if (NORM) {
-            const int sg = (nrm.seg_row > 0 && mk >= nrm.seg_row) ? 1 : 0;
-            if (sg != norm_seg) {  // this lane's 8 channels of the segment's terms (a slice crosses the boundary at most once)
-                norm_seg = sg;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int c = sg * g.Ci + tcn + q;
-                    nmu[q] = jv ? nrm.mean[c] : 0.f;
-                    nsc[q] = jv ? nrm.scale[c] : 0.f;
-                    nbe[q] = jv ? nrm.shift[c] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = fmaxf(fmaf(bf16_to_f32(ra[i][q]) - nmu[q], nsc[q], nbe[q]), 0.f);
-                ra[i] = pack_bf16x8(v);
-            }
-        }
+        (void)mk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(pgA * 4 + i) * LDA + jc * 8]) = ra[i];
 #pragma unroll
@@ -1128,6 +1067,10 @@ static long long seg_split_rows(int seg_images, int B, long long rows_per_image,
 
 static size_t bn_workspace_rows(long long m_out) { return (size_t)((m_out + kBM - 1) / kBM + 4); }
 
+// which kernel family the most recent convolution entry point of this thread launched (lp_conv_last_kernel: the bench labels its
+// per-launch timings with the kernel that actually ran; tests assert the path they mean to exercise)
+static thread_local int g_last_conv_kernel = LP_CONV_KERNEL_IGEMM;
+
 // Persistent launch of conv_igemm_kernel: at most 2 workgroups per CU (the LDS limit) x 256 CUs, a multiple of 8 so the
 // stride walk keeps every workgroup on its XCD's tile range.  LP_CONV_MAX_WGS overrides the cap (tests use it to force several
 // tiles per workgroup on small problems).
@@ -1162,6 +1105,7 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
         x_bytes = gemm_x_bytes;
         w_bytes = gemm_w_bytes;
     }
+    g_last_conv_kernel = LP_CONV_KERNEL_IGEMM;
     hipLaunchKernelGGL((conv_igemm_kernel<BN, MODE>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)w,
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
 }
@@ -1217,6 +1161,7 @@ static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const L
     const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * ck);
     const char* fe = getenv("LP_PIPE_FLAGS");   // experiment switch: 2 = non-temporal output stores
     const int flags = fe ? atoi(fe) : 0;
+    g_last_conv_kernel = LP_CONV_KERNEL_PIPE;
     hipLaunchKernelGGL((conv_pipe_kernel<BN, MODE, EK>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes,
                        w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, flags);
 }
@@ -1230,15 +1175,15 @@ static void launch_pipe_dgrad(int kind, const void* x, const void* w, const Conv
 }
 
 // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue): every launch since the sums are accumulated per persistent
-// workgroup (conv_igemm_kernel: stats_flush).  LP_STATS_ATOMIC_TILES overrides it: 0 selects the per-tile workspace +
-// tile_stats_reduce_kernel path, whose sums are bit-reproducible from run to run (the atomic path adds <= 512 partial sums per column in
-// arrival order); the tests run both
+// workgroup (conv_igemm_kernel: stats_flush; conv_pipe_kernel: per thread).  The atomic path adds <= 512 partial sums per column in
+// arrival order, so two runs differ in the last bits.  LP_DETERMINISTIC=1 (or LP_STATS_ATOMIC_TILES=0) selects the bit-reproducible form
+// instead: per-tile rows in a workspace, summed in a fixed order by tile_stats_reduce_kernel - on conv_igemm_kernel, which implements it
+// (the pipelined kernel declines such launches, pipe_eligible).  Read per call, so one process can run both (the tests do).
 static int stats_atomic_tiles() {
-    static int v = [] {
-        const char* e = getenv("LP_STATS_ATOMIC_TILES");
-        return e ? atoi(e) : 0x7fffffff;   // (per-workgroup accumulation: the atomic path costs the same for any number of tiles)
-    }();
-    return v;
+    const char* d = getenv("LP_DETERMINISTIC");
+    if (d != nullptr && atoi(d) != 0) return 0;
+    const char* e = getenv("LP_STATS_ATOMIC_TILES");
+    return e ? atoi(e) : 0x7fffffff;   // (per-workgroup accumulation: the atomic path costs the same for any number of tiles)
 }
 #define kStatsAtomicTiles stats_atomic_tiles()
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
@@ -1266,6 +1211,86 @@ static WgradPlan plan_wgrad(int M, int Kw, int Co, int split_hint, int target_wg
     return p;
 }
 
+// ---- pipelined weight gradient (conv_pipe.h): 256 x BN tiles, one (tile, pixel slice) per workgroup, ~one workgroup per CU
+struct WgradPipePlan {
+    bool ok, swap;
+    int Ka, Cb, tiles_a, tiles_b, bn, split, per;
+    size_t ws_floats;
+};
+
+// `force`: ignore the two performance rules (tile waste, HBM-bound shapes) - LP_WGRAD_PIPE=2, the tests' switch
+static WgradPipePlan plan_wgrad_pipe(const ConvGeom& g, int split_hint, bool force = false) {
+    WgradPipePlan p{};
+    const int M = g.B * g.Ho * g.Wo, Kw = g.R * g.S * g.Ci;
+    const bool one = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
+    if (g.Ci % 8 != 0 || g.Co % 64 != 0 || M < 4 * kBK) return p;
+    // a = the 256-wide side.  Ordinary: a = (r, s, ci), b = co.  A 1x1 layer with few input channels is transposed (a = co, b = ci)
+    p.swap = one && Kw % 256 != 0 && g.Co % 256 == 0 && Kw % 64 == 0;
+    p.Ka = p.swap ? g.Co : Kw;
+    p.Cb = p.swap ? Kw : g.Co;
+    p.bn = p.Cb % 128 == 0 ? 128 : 64;
+    if (p.Cb % p.bn != 0) return p;
+    p.tiles_a = (p.Ka + 255) / 256;
+    if (!force && (long long)p.tiles_a * 256 * 8 > (long long)p.Ka * 9) return p;   // a ragged last a-tile may waste an eighth at most (3x3 of 64 channels: 576 -> 768 lost, measured)
+    // HBM-bound shapes (few FLOPs per operand byte: the 1x1 layers of layer1 / layer2) gain nothing from the bigger tile and lose a few
+    // per cent to the 64-B request granularity its LDS swizzle forces on the loads (measured per layer, profiles/r03g_layer_table.txt)
+    if (!force && (long long)p.Ka * p.Cb < 120LL * (p.Ka + p.Cb)) return p;
+    p.tiles_b = p.Cb / p.bn;
+    const int tiles = p.tiles_a * p.tiles_b;
+    const int cus = pipe_max_wgs();
+    const int ksteps = (M + kBK - 1) / kBK;
+    int split = split_hint;
+    if (split <= 0) {
+        // one workgroup per CU at a time: rounds x K steps per slice, plus the partial tiles' round trip through the workspace
+        // (256 x bn fp32 written and read per (tile, slice); a K step moves about as many bytes as 6 % of one partial tile at full rate)
+        double best = 1e30;
+        for (int s = 1; s <= 2 * cus && s <= ksteps / 2; ++s) {
+            if (s != 1 && (tiles * s) % cus > 0 && (tiles * (s + 1) + cus - 1) / cus == (tiles * s + cus - 1) / cus) continue;  // not the fullest split of its round count
+            const double rounds = (double)((tiles * s + cus - 1) / cus), per = (double)((ksteps + s - 1) / s);
+            const double cost = rounds * per + 0.04 * (p.bn / 128.0) * s * tiles + 2.0 * rounds;   // (in K steps; 2 per round: ring fill)
+            if (cost < best) best = cost, split = s;
+        }
+        if (split <= 0) split = 1;
+    }
+    if (split > ksteps / 2) split = ksteps / 2;
+    if (split < 1) split = 1;
+    p.per = ((ksteps + split - 1) / split) * kBK;
+    p.split = (M + p.per - 1) / p.per;
+    p.ws_floats = (size_t)p.split * tiles * 256 * p.bn;
+    p.ok = true;
+    return p;
+}
+
+static void launch_wgrad_pipe(const WgradPipePlan& p, const void* x, const void* dy, const ConvGeom& g, float* dw, float* ws, hipStream_t st) {
+    const int M = g.B * g.Ho * g.Wo, Kw = g.R * g.S * g.Ci;
+    const unsigned x_bytes = (unsigned)(2ull * g.B * g.Hi * g.Wi * g.Ci), dy_bytes = (unsigned)(2ull * M * g.Co);
+    WgradPipeGeom wg{};
+    const void *pa = x, *qb = dy;
+    unsigned pa_bytes = x_bytes, qb_bytes = dy_bytes;
+    if (p.swap) {   // a = co (rows of dy), b = ci (rows of x): both plain
+        wg = WgradPipeGeom{g.B, g.Ho, g.Wo, g.Ho, g.Wo, g.Co, 1, 1, 1, 0, p.Ka, p.Cb, 1};
+        pa = dy, qb = x, pa_bytes = dy_bytes, qb_bytes = x_bytes;
+    } else {
+        const int plain = g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0 && g.Hi == g.Ho && g.Wi == g.Wo;
+        wg = WgradPipeGeom{g.B, g.Hi, g.Wi, g.Ho, g.Wo, g.Ci, g.R, g.S, g.stride, g.pad, p.Ka, p.Cb, plain};
+    }
+    const int tiles = p.tiles_a * p.tiles_b;
+    const FastDiv dhw = make_fastdiv(g.Ho * g.Wo), dwo = make_fastdiv(g.Wo);
+    g_last_conv_kernel = LP_CONV_KERNEL_WGRAD_PIPE;
+    const int sa = p.swap ? Kw : 1, sb = p.swap ? 1 : Kw;   // dW[co][kw]: ordinary a = kw index, b = co; swapped a = co, b = kw index
+    if (p.bn == 128) {
+        hipLaunchKernelGGL((conv_wgrad_pipe_kernel<128>), dim3(tiles * p.split), dim3(512), 0, st, (const unsigned short*)pa,
+                           (const unsigned short*)qb, pa_bytes, qb_bytes, wg, M, tiles, p.tiles_b, p.per, dhw, dwo, ws);
+        hipLaunchKernelGGL((wgrad_pipe_reduce_kernel<128>), dim3(tiles * 256 * 128 / 64), dim3(256), 0, st, ws, p.split, tiles, p.tiles_b, p.Ka,
+                           p.Cb, sa, sb, dw);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_pipe_kernel<64>), dim3(tiles * p.split), dim3(512), 0, st, (const unsigned short*)pa,
+                           (const unsigned short*)qb, pa_bytes, qb_bytes, wg, M, tiles, p.tiles_b, p.per, dhw, dwo, ws);
+        hipLaunchKernelGGL((wgrad_pipe_reduce_kernel<64>), dim3(tiles * 256 * 64 / 64), dim3(256), 0, st, ws, p.split, tiles, p.tiles_b, p.Ka,
+                           p.Cb, sa, sb, dw);
+    }
+}
+
 static bool geom_ok(const lp_conv_geom* c) {
     return c && c->B > 0 && c->Hi > 0 && c->Wi > 0 && c->Ci > 0 && c->Ho > 0 && c->Wo > 0 && c->Co > 0 && c->R > 0 && c->S > 0 &&
            c->stride > 0 && c->pad >= 0;
@@ -1279,12 +1304,8 @@ static ConvGeom to_geom(const lp_conv_geom* c) {
 }  // namespace lp
 
 // out[b][ho][wo][co] = sum x[b][ho*st-pad+r][wo*st-pad+s][ci] * w[co][r][s][ci]  (+bias) ; x, w bf16
-struct FwdNorm {
-    const float *mean, *scale, *shift;
-};
-
 static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
-                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream, const FwdNorm* norm = nullptr) {
+                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1307,13 +1328,7 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (norm) {  // the A operand is normalised on load: 1x1 / stride 1 only (the K offset is the channel, no padding taps to keep at zero)
-        LP_REQUIRE(norm->mean && norm->scale && norm->shift);
-        if (g.R != 1 || g.S != 1 || g.stride != 1 || g.pad != 0) return LP_ERR_UNSUPPORTED;
-        ep.norm_mean = norm->mean, ep.norm_scale = norm->scale, ep.norm_shift = norm->shift;
-        if (N > 64) launch_igemm<128, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
-        else launch_igemm<64, kModeFwdNorm>(x, w, g, lat, M, N, K, ep, st);
-    } else if (pipe_eligible(ep, M, N, K, g.Ci, split)) {
+    if (pipe_eligible(ep, M, N, K, g.Ci, split)) {
         if (N > 64) launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         else launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
     } else if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
@@ -1324,6 +1339,8 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     }
     return launch_status();
 }
+
+extern "C" int lp_conv_last_kernel(void) { return lp::g_last_conv_kernel; }
 
 extern "C" int lp_conv_fwd(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32,
                            int ldo, int n_store, lp_stream_t stream) {
@@ -1362,17 +1379,6 @@ extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* 
                               lp_stream_t stream) {
     LP_REQUIRE(bn && geom && out_bf16);
     return conv_fwd_impl(x, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream);
-}
-
-// the same for a 1x1 convolution fed with the PRE-normalisation tensor z of the BatchNorm in front of it: the A operand is
-// bf16(relu((z - mean) * scale + shift)) computed while it is staged (what lp_bn_apply would have stored, bit for bit), so that
-// activation is never written or read.  mean / scale (= invstd * gamma, lp_bn_affine) / shift (= beta) are (segments, Ci), segments as
-// in bn->seg_images (the input rows of a 1x1 / stride-1 convolution are its output rows)
-extern "C" int lp_conv_fwd_bn_norm(const void* z, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
-                                   const float* norm_mean, const float* norm_scale, const float* norm_shift, lp_stream_t stream) {
-    LP_REQUIRE(bn && geom && out_bf16);
-    const FwdNorm norm{norm_mean, norm_scale, norm_shift};
-    return conv_fwd_impl(z, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream, &norm);
 }
 
 // C[z][m][n] = sum_k A[z][m][k] * B[z][n][k] (+ bias[n]): the forward kernel as a plain (batched, strided) NT GEMM
@@ -1550,12 +1556,17 @@ extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int sp
     ConvGeom g = to_geom(geom);
     const bool stem = (g.Ci == 4 && g.R == 7);
     const int Kw = stem ? 256 : g.R * g.S * g.Ci;
-    return plan_wgrad(g.B * g.Ho * g.Wo, Kw, g.Co, split_hint, kWgradWgs).ws_floats * sizeof(float);
+    size_t fl = plan_wgrad(g.B * g.Ho * g.Wo, Kw, g.Co, split_hint, kWgradWgs).ws_floats;
+    if (!stem) {   // either kernel may take the launch (LP_CONV_PIPE): room for both plans
+        const WgradPipePlan pp = plan_wgrad_pipe(g, split_hint, true);   // (the forced plan is the larger one)
+        if (pp.ok && pp.ws_floats > fl) fl = pp.ws_floats;
+    }
+    return fl * sizeof(float);
 }
 
 // dw[co][r][s][ci] (fp32, accumulated into) += sum_m x_gather[m][(r,s,ci)] * dy[m][co]
 static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, float* dbias, int split_hint, void* workspace,
-                           size_t workspace_bytes, lp_stream_t stream, const lp::WgradNorm* norm = nullptr) {
+                           size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && dy && geom_ok(geom) && dw && workspace);
     ConvGeom g = to_geom(geom);
@@ -1568,6 +1579,15 @@ static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* ge
     LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    const char* wpe = getenv("LP_WGRAD_PIPE");   // (A/B: 0 keeps the weight gradients on conv_wgrad_kernel; 2 = wherever it can run)
+    if (!dbias && conv_pipe_enabled() && (wpe == nullptr || atoi(wpe) != 0)) {
+        const WgradPipePlan pp = plan_wgrad_pipe(g, split_hint, wpe != nullptr && atoi(wpe) == 2);
+        if (pp.ok && workspace_bytes >= pp.ws_floats * sizeof(float)) {
+            launch_wgrad_pipe(pp, x, dy, g, dw, ws, st);
+            return launch_status();
+        }
+    }
+    g_last_conv_kernel = LP_CONV_KERNEL_WGRAD;
     const int tiles = p.tj * p.tn;
     TnExt ext{};
     ext.col_sums = dbias;
@@ -1577,20 +1597,6 @@ static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* ge
 #define LP_WGRAD_LAUNCH(BN_, CS_)                                                                                                \
     hipLaunchKernelGGL((conv_wgrad_kernel<BN_, false, CS_>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn, \
                        p.per, dhw, dwo, ws, ext)
-    if (norm) {  // (1x1 / stride 1: the fast, unmasked operand path; the row index of the result IS the channel)
-        LP_REQUIRE(norm->mean && norm->scale && norm->shift && !dbias);
-        if (g.R != 1 || g.S != 1 || g.stride != 1 || g.pad != 0 || norm->seg_row % kBK != 0) return LP_ERR_UNSUPPORTED;
-        if (p.wide) {
-            hipLaunchKernelGGL((conv_wgrad_kernel<128, false, false, true>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn,
-                               p.per, dhw, dwo, ws, ext, *norm);
-            launch_wgrad_reduce<128>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
-        } else {
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, false, false, true>), grid, block, 0, st, xs, dys, x_bytes, dy_bytes, g, M, Kw, tiles, p.tn,
-                               p.per, dhw, dwo, ws, ext, *norm);
-            launch_wgrad_reduce<64>(ws, p.split, tiles, p.tn, Kw, g.Co, dw, st);
-        }
-        return launch_status();
-    }
     if (p.wide) {
         if (dbias) LP_WGRAD_LAUNCH(128, true);
         else LP_WGRAD_LAUNCH(128, false);
@@ -1607,16 +1613,6 @@ static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* ge
 extern "C" int lp_conv_wgrad(const void* x, const void* dy, const lp_conv_geom* geom, float* dw, int split_hint, void* workspace,
                              size_t workspace_bytes, lp_stream_t stream) {
     return conv_wgrad_impl(x, dy, geom, dw, nullptr, split_hint, workspace, workspace_bytes, stream);
-}
-
-// weight gradient of a 1x1 convolution whose input activation was never stored (lp_conv_fwd_bn_norm): z is the pre-normalisation
-// tensor, the gathered operand is normalised on load with the same (segments, Ci) terms; seg_images as in lp_bn_fuse
-extern "C" int lp_conv_wgrad_norm(const void* z, const void* dy, const lp_conv_geom* geom, float* dw, const float* norm_mean,
-                                  const float* norm_scale, const float* norm_shift, int seg_images, int split_hint, void* workspace,
-                                  size_t workspace_bytes, lp_stream_t stream) {
-    LP_REQUIRE(geom && seg_images >= 0 && seg_images < geom->B);
-    const lp::WgradNorm norm{norm_mean, norm_scale, norm_shift, seg_images * geom->Ho * geom->Wo};
-    return conv_wgrad_impl(z, dy, geom, dw, nullptr, split_hint, workspace, workspace_bytes, stream, &norm);
 }
 
 // same, and dbias[co] += sum_m dy[m][co] out of the same pass over dy (Linear / ConvTranspose2d layers)

@@ -29,6 +29,8 @@
 // of step g+2 issued right after the barrier overwrite.
 #pragma once
 
+#include <type_traits>
+
 namespace lp {
 
 #ifndef LP_PIPE_SPREAD
@@ -46,9 +48,15 @@ constexpr int kPRowB = 128;  // bytes per staged operand row (64 k x bf16)
         __builtin_amdgcn_s_barrier();      \
         asm volatile("" ::: "memory");     \
     } while (0)
+// wait until at most n LDS / scalar-memory operations of this wave are outstanding, and make the fragments named after it depend on the
+// wait (they were filled by lds_read_tr16_async: without the "+v" ties the compiler could move their first use above the wait)
+#define LP_WAIT_LGKM_TOUCH3(n, a, b, c) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c)::"memory")
+#define LP_WAIT_LGKM_TOUCH4(n, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
 #else
 #define LP_WAIT_VM(n) ((void)0)
 #define LP_RAW_BARRIER() __syncthreads()
+#define LP_WAIT_LGKM_TOUCH3(n, a, b, c) ((void)0)
+#define LP_WAIT_LGKM_TOUCH4(n, a, b, c, d) ((void)0)
 #endif
 
 // 16-B store; `stream`: non-temporal (the lines are not kept in L2, which the weight panel of the deep 1x1 layers needs)
@@ -508,6 +516,280 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     }
     if (want_stats) stats_flush(reinterpret_cast<float*>(smem + (cur == 0 ? 2 : cur - 1) * kStage));
     LP_WAIT_VM(0);   // the ring's last (empty) loads still target this workgroup's LDS
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient on the same ring:  D[a][b] = sum over pixels m of  Pa[m][a] * Qb[m][b]
+//   ordinary   a = (r, s, ci) of the gathered activations x (filter taps in the address), b = co of dy     -> dW[b][a]
+//   swapped    (1x1, few input channels) a = co of dy, b = ci of x                                            -> dW[a][b]
+// Both operands keep their memory orientation in LDS ([pixel][channel]; the contraction index is the ROW): a K step is 64 pixels,
+// the A image 64 rows x 256 channels (512-B rows), the B image 64 rows x BN channels, filled by direct-to-LDS loads; the MFMA
+// fragments (8 consecutive pixels of one channel per lane) come out of ds_read_b64_tr_b16 as in conv_wgrad_kernel.  Without row
+// padding (the LDS side of a direct load is lane-linear) the four pixel rows of a transpose read would sit on the same banks, so the
+// 16-B chunk c of pixel row r is stored at c ^ ((r & 3) << 2) (BN = 64: c ^ (((r >> 1) & 1) << 2), two 128-B rows share a bank
+// row) - applied on the source address, and arranged so that a THREAD always fetches the same chunk (its filter tap is a constant).
+// One (tile, pixel slice) per workgroup, 512 threads = 8 waves (4 along a x 2 along b, 64 x BN/2 each), tile 256 x BN: 48 KB per
+// K step for 1024 MFMA cycles (conv_wgrad_kernel: 32 KB per 512 - at the CU's 64 B/clk address path that alone caps it).  The
+// slices' partial tiles go to the workspace in accumulator order; wgrad_pipe_reduce_kernel adds them up in a fixed order.
+// ------------------------------------------------------------------------------------------------------------
+struct WgradPipeGeom {
+    int B, Hi, Wi, Ho, Wo;     // source image of the gathered operand, pixel grid of the contraction (rows m = (b, ho, wo))
+    int Ca, R, S, stride, pad; // channels per filter tap of the gathered operand, the taps
+    int Ka, Cb;                // a-extent (R * S * Ca) and b-extent (= row pitch of Qb)
+    int plain;                 // 1x1 / stride 1 / no padding: row m of Pa is pixel m
+};
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_wgrad_pipe_kernel(const unsigned short* __restrict__ Pa, const unsigned short* __restrict__ Qb,
+                                                              unsigned pa_bytes, unsigned qb_bytes, WgradPipeGeom g, int M, int tiles,
+                                                              int tiles_b, int m_per_split, FastDiv div_hw, FastDiv div_wo,
+                                                              float* __restrict__ ws) {
+    constexpr int NT = BN / 64;
+    constexpr int kRowA = 512, kRowB = BN * 2;            // bytes per pixel row of the two LDS images
+    constexpr int kStageA = kBK * kRowA, kStageB = kBK * kRowB, kStage = kStageA + kStageB;
+    constexpr int NLB = BN / 64;                           // B loads per thread and K step (4 A loads)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kStage];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int work = xcd_remap(blockIdx.x, gridDim.x);    // slice slow: an XCD owns whole slices (all tiles of a slice share its L2)
+    const int slice = work / tiles, tile = work - slice * tiles;
+    const int a0 = (tile / tiles_b) * 256, b0 = (tile % tiles_b) * BN;
+    const int m_begin = slice * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const int KT = (m_end - m_begin + kBK - 1) / kBK;
+    const buf_rsrc rsrc_a = make_buf_rsrc(Pa, pa_bytes), rsrc_b = make_buf_rsrc(Qb, qb_bytes);
+
+    // ---- loader.  A: wave instruction p covers pixel rows p*16 + wave*2 + (lane >> 5) (two 512-B rows); B (BN = 128): rows
+    // q*32 + wave*4 + (lane >> 4) (four 256-B rows); B (BN = 64): rows wave*8 + (lane >> 3) (eight 128-B rows)
+    const int arow = wave * 2 + (lane >> 5);                               // + 16 p
+    const int achunk = (lane & 31) ^ ((arow & 3) << 2);                    // the chunk this thread always fetches
+    const int ja = a0 + achunk * 8;
+    const bool ja_ok = ja < g.Ka;
+    const int tap = (ja_ok ? ja : 0) / g.Ca;
+    const int tcn = (ja_ok ? ja : 0) - tap * g.Ca;
+    const int tr = tap / g.S, ts = tap - tr * g.S;
+    const int brow = (BN == 128) ? wave * 4 + (lane >> 4) : wave * 8 + (lane >> 3);   // + 32 q
+    const int bchunk = (BN == 128) ? ((lane & 15) ^ ((brow & 3) << 2)) : ((lane & 7) ^ (((brow >> 1) & 1) << 2));
+    const unsigned boff = (unsigned)(b0 + bchunk * 8) * 2u;
+    const int hw = g.Ho * g.Wo;
+
+    unsigned is_a[4], is_b[NLB];
+    unsigned char* is_dst = smem;
+    // Stride-1 "same" convolutions (every 3x3 of the trunk but the three stride-2 ones): the source pixel of output pixel m under tap
+    // (tr, ts) is m + const, so a row's byte offset is linear in m and only the padding decision needs (ho, wo) - tracked per row and
+    // advanced by 64 pixels per K step (64 = qb images + qh rows + qw pixels) instead of two divisions per row and step.
+    const bool same = !g.plain && g.stride == 1 && g.Hi == g.Ho && g.Wi == g.Wo && hw >= kBK;
+    const int qb64 = kBK / hw, qh64 = (kBK - qb64 * hw) / g.Wo, qw64 = kBK - qb64 * hw - qh64 * g.Wo;
+    const int lo_h = max(0, g.pad - tr), span_h = min(g.Ho, g.Hi + g.pad - tr) - lo_h;   // valid output rows / columns for this thread's tap
+    const int lo_w = max(0, g.pad - ts), span_w = min(g.Wo, g.Wi + g.pad - ts) - lo_w;
+    const unsigned tap_off = (unsigned)(((tr - g.pad) * g.Wi + (ts - g.pad)) * g.Ca + tcn) * 2u;   // (may wrap: added mod 2^32)
+    int rho[4], rwo[4];
+    if (same) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m_begin + p * 16 + arow;
+            const int mm = m < M ? m : 0;
+            const int rem = mm - fdiv(mm, div_hw) * hw;
+            rho[p] = fdiv(rem, div_wo);
+            rwo[p] = rem - rho[p] * g.Wo;
+        }
+    }
+    auto prep_step = [&](int st, int kt) {
+        const int mk = m_begin + kt * kBK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = mk + p * 16 + arow;
+            unsigned off;
+            bool ok = ja_ok && m < m_end && kt < KT;
+            if (g.plain) {
+                off = (unsigned)(m * g.Ca + tcn) * 2u;
+            } else if (same) {
+                ok = ok && (unsigned)(rho[p] - lo_h) < (unsigned)span_h && (unsigned)(rwo[p] - lo_w) < (unsigned)span_w;
+                off = (unsigned)m * (unsigned)(g.Ca * 2) + tap_off;
+                rwo[p] += qw64;                       // this row's pixel of the NEXT step (prep_step is called with consecutive kt)
+                const int c = rwo[p] >= g.Wo ? 1 : 0;
+                rwo[p] -= c ? g.Wo : 0;
+                rho[p] += qh64 + c;
+                rho[p] -= rho[p] >= g.Ho ? g.Ho : 0;
+            } else {
+                const int mm = ok ? m : 0;
+                const int b = fdiv(mm, div_hw), rem = mm - b * hw;
+                const int ho = fdiv(rem, div_wo), wo = rem - ho * g.Wo;
+                const int hi = ho * g.stride - g.pad + tr, wi = wo * g.stride - g.pad + ts;
+                ok = ok && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi;
+                off = (unsigned)(((b * g.Hi + hi) * g.Wi + wi) * g.Ca + tcn) * 2u;
+            }
+            is_a[p] = ok ? off : ~0u;
+        }
+#pragma unroll
+        for (int q = 0; q < NLB; ++q) {
+            const int m = mk + q * 32 + brow;
+            is_b[q] = (m < m_end && kt < KT) ? (unsigned)m * (unsigned)(g.Cb * 2) + boff : ~0u;
+        }
+        is_dst = smem + st * kStage;
+    };
+    auto issue_load = [&](int i) {   // (compile-time i)
+        if (i < 4) buf_load16_lds(rsrc_a, is_dst + (i * 16 + wave * 2) * kRowA, is_a[i], 0u);
+        else if (BN == 128) buf_load16_lds(rsrc_b, is_dst + kStageA + ((i - 4) * 32 + wave * 4) * kRowB, is_b[i - 4], 0u);
+        else buf_load16_lds(rsrc_b, is_dst + kStageA + (wave * 8) * kRowB, is_b[0], 0u);
+    };
+
+    // ---- fragments: lane of 16-lane group fq supplies pixel row 8 (fq / 2) + (fi / 4) (+ 4 for the second read), channels
+    // 16 (fq % 2) + 4 (fi % 4) .. + 3 of a 32-channel block, and receives channel lane % 32, pixels 8 (lane / 32) .. + 7
+    const int fq = lane >> 4, fi = lane & 15;
+    const int frow = (fq >> 1) * 8 + (fi >> 2), fcol = (fq & 1) * 16 + (fi & 3) * 4;
+    const int swa = (frow & 3) << 2;                                                       // (the same for row + 4, + 8, + 16 kk)
+    const int swb = (BN == 128) ? ((frow & 3) << 2) : (((frow >> 1) & 1) << 2);
+    unsigned foa[2], fob[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int e0 = wm * 64 + mt * 32 + fcol;
+        foa[mt] = (unsigned)(frow * kRowA + (((e0 >> 3) ^ swa) << 4) + (e0 & 7) * 2);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int e0 = wn * (NT * 32) + nt * 32 + fcol;
+        fob[nt] = (unsigned)(kStageA + frow * kRowB + (((e0 >> 3) ^ swb) << 4) + (e0 & 7) * 2);
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    auto mma_stage = [&](int st) {
+        const unsigned char* sb = smem + st * kStage;
+        bf16x8 a[2][2], b[2][NT];
+        // per stage one base address per fragment column block; the k-slice and the second pixel quad ride in the instruction's offset
+        const unsigned char* pa[2];
+        const unsigned char* pb[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) pa[mt] = sb + foa[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pb[nt] = sb + fob[nt];
+        auto fetch = [&](auto kk_c, int set) {
+            constexpr int kk = decltype(kk_c)::value;
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const s16x4_t lo = lds_read_tr16_async_off<kk * 16 * kRowA>(pa[mt]), hi = lds_read_tr16_async_off<kk * 16 * kRowA + 4 * kRowA>(pa[mt]);
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[set][mt] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const s16x4_t lo = lds_read_tr16_async_off<kk * 16 * kRowB>(pb[nt]), hi = lds_read_tr16_async_off<kk * 16 * kRowB + 4 * kRowB>(pb[nt]);
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                b[set][nt] = __builtin_bit_cast(bf16x8, v);
+            }
+        };
+        // the transpose reads are asm (see lds_read_tr16_async): slice kk's 2 (2 + NT) reads must have returned before its MFMAs, slice
+        // kk + 1's (just issued) may still be in flight - LDS operations return in order
+        auto ready = [&](int set, bool last) {
+            if (NT == 2) {
+                if (last) LP_WAIT_LGKM_TOUCH4(0, a[set][0], a[set][1], b[set][0], b[set][NT - 1]);
+                else LP_WAIT_LGKM_TOUCH4(8, a[set][0], a[set][1], b[set][0], b[set][NT - 1]);
+            } else {
+                if (last) LP_WAIT_LGKM_TOUCH3(0, a[set][0], a[set][1], b[set][0]);
+                else LP_WAIT_LGKM_TOUCH3(6, a[set][0], a[set][1], b[set][0]);
+            }
+        };
+        auto slice = [&](auto kk_c) {
+            constexpr int kk = decltype(kk_c)::value;
+            if constexpr (kk + 1 < kBK / 16) fetch(std::integral_constant<int, kk + 1>{}, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ready(kk & 1, kk + 1 == kBK / 16);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk & 1][mt], b[kk & 1][nt], acc[mt][nt], 0, 0, 0);
+            constexpr int NL = 4 + NLB;   // the next-but-one step's loads, spread between the k-slices
+            if (kk == 0) {
+                issue_load(0);
+                issue_load(1);
+            } else if (kk == 1) {
+                issue_load(2);
+                if (NL == 6) issue_load(3);
+            } else if (kk == 2) {
+                issue_load(NL == 6 ? 4 : 3);
+            } else {
+                issue_load(NL - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fetch(std::integral_constant<int, 0>{}, 0);
+        slice(std::integral_constant<int, 0>{});
+        slice(std::integral_constant<int, 1>{});
+        slice(std::integral_constant<int, 2>{});
+        slice(std::integral_constant<int, 3>{});
+    };
+
+    prep_step(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4 + NLB; ++i) issue_load(i);
+    prep_step(1, 1);
+#pragma unroll
+    for (int i = 0; i < 4 + NLB; ++i) issue_load(i);
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (NLB == 2) LP_WAIT_VM(6);
+        else LP_WAIT_VM(5);
+        LP_RAW_BARRIER();
+        prep_step(cur == 0 ? 2 : cur - 1, kt + 2);   // (steps past the slice fetch nothing: the ring keeps its count)
+        mma_stage(cur);
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    LP_WAIT_VM(0);
+    // partial tile -> workspace[slice][tile][wave][mt][nt][e][lane] (accumulator order: every store is a full 256-B line per wave)
+    float* dst = ws + ((((size_t)slice * tiles + tile) * 8 + wave) * (2 * NT * 16)) * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[((mt * NT + nt) * 16 + e) * 64] = acc[mt][nt][e];
+}
+
+// dW[a * sa + b * sb] += sum over slices of the partial tiles, slices in order (deterministic).  One workgroup per 64 consecutive
+// accumulator elements of a tile; its 4 waves stride over the slices and combine through LDS.
+template <int BN>
+__global__ __launch_bounds__(256) void wgrad_pipe_reduce_kernel(const float* __restrict__ ws, int slices, int tiles, int tiles_b, int Ka, int Cb,
+                                                                int sa, int sb, float* __restrict__ dW) {
+    constexpr int NT = BN / 64;
+    constexpr int PER_TILE = 8 * 2 * NT * 16 * 64;
+    __shared__ float part[4][64];
+    const size_t total = (size_t)tiles * PER_TILE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    int sl = w;
+    for (; sl + 4 < slices; sl += 8) {
+        s0 += ws[(size_t)sl * total + i];
+        s1 += ws[(size_t)(sl + 4) * total + i];
+    }
+    for (; sl < slices; sl += 4) s0 += ws[(size_t)sl * total + i];
+    part[w][lane] = s0 + s1;
+    __syncthreads();
+    if (w == 0) {
+        const float sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        size_t t = i >> 6;
+        const int e = (int)(t & 15);
+        t >>= 4;
+        const int nt = (int)(t % NT);
+        t /= NT;
+        const int mt = (int)(t & 1);
+        t >>= 1;
+        const int wave = (int)(t & 7);
+        const int tile = (int)(t >> 3);
+        const int wm = wave & 3, wn = wave >> 2;
+        const int a = (tile / tiles_b) * 256 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int b = (tile % tiles_b) * BN + wn * (NT * 32) + nt * 32 + (lane & 31);
+        if (a < Ka && b < Cb) dW[(size_t)a * sa + (size_t)b * sb] += sum;
+    }
 }
 
 }  // namespace lp

@@ -105,8 +105,30 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
+// The same read issued WITHOUT the compiler's knowledge of its memory access (inline asm): hipcc orders the builtin form behind every
+// pending direct-to-LDS load with `s_waitcnt vmcnt(0)`, which drains a multi-stage operand ring once per k-slice (conv_wgrad_pipe_kernel
+// measured 67 % of its wave cycles parked on it).  The caller owns both orderings: the LDS-DMA data is ready by its counted vmcnt wait +
+// barrier, and the result registers may only be used after LP_WAIT_LGKM_TOUCH (the asm form is invisible to the compiler's lgkmcnt count).
+__device__ __forceinline__ s16x4_t lds_read_tr16_async(const unsigned short* p) {
+    s16x4_t v;
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+// ... with a compile-time byte offset in the instruction's offset field (no address arithmetic per read)
+template <int OFF>
+__device__ __forceinline__ s16x4_t lds_read_tr16_async_off(const unsigned char* p) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit offset field");
+    s16x4_t v;
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
 #elif defined(__HIP__)  // host pass of hipcc: declaration only, never executed
 __device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short*) { return s16x4_t{0, 0, 0, 0}; }
+__device__ __forceinline__ s16x4_t lds_read_tr16_async(const unsigned short*) { return s16x4_t{0, 0, 0, 0}; }
+template <int OFF>
+__device__ __forceinline__ s16x4_t lds_read_tr16_async_off(const unsigned char*) { return s16x4_t{0, 0, 0, 0}; }
 #else  // CPU logic build (tests/hipemu): the same lane exchange spelled with shuffles
 __device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short* p) {
     const int lane = threadIdx.x & 63, base = lane & ~15, c = lane & 15;
@@ -117,6 +139,9 @@ __device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned short* p) {
     }
     return r;
 }
+__device__ __forceinline__ s16x4_t lds_read_tr16_async(const unsigned short* p) { return lds_read_tr16(p); }
+template <int OFF>
+__device__ __forceinline__ s16x4_t lds_read_tr16_async_off(const unsigned char* p) { return lds_read_tr16(reinterpret_cast<const unsigned short*>(p + OFF)); }
 #endif
 
 // Hide a value's provenance from the optimiser (keeps it from hoisting per-element address arithmetic out of a loop into

@@ -213,10 +213,6 @@ class Engine:
         # of a semi-supervised step, or a supervised step), since two passes accumulate into the same buffer
         self.grad_progress = None
         self.single_backward = False
-        # opt-in (LP_NORM_ON_LOAD=1): normalise-on-load for the 1x1 consumers of bn2 (conv3 and its weight gradient), so a2 is never
-        # materialised.  Measured on the device: the lp_bn_apply pass it removes (0.7 ms per step of pure streaming) costs as much again as
-        # VALU work in the staging path of the two MFMA kernels - 3491 vs 3508 frames/s (profiles/r02i_bench_norm*.json.log) - so it is off
-        self.norm_on_load = os.environ.get("LP_NORM_ON_LOAD", "0") == "1"
         self._bwd_training = True     # mode of the forward pass whose backward is running (eval: no batch-statistics terms)
         self.sync_bn_messages = 0     # SyncBatchNorm all-reduces issued so far (bench.py reports them per step)
         self.process_group = None
@@ -239,10 +235,16 @@ class Engine:
         e0.record()
         out = fn()
         e1.record()
+        if tag.startswith("conv_") and hasattr(self._lib, "lp_conv_last_kernel"):   # label the launch with the kernel that actually ran
+            k = self._lib.lp_conv_last_kernel()
+            if k == _lib.CONV_KERNEL_PIPE:
+                tag = tag.replace("conv_igemm_kernel", "conv_pipe_kernel")
+            elif k == _lib.CONV_KERNEL_WGRAD_PIPE:
+                tag = tag.replace("conv_wgrad_kernel", "conv_wgrad_pipe_kernel")
         self.profile.append((tag, flops, e0, e1, nbytes))
         return out
 
-    def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False, dbias: torch.Tensor | None = None, norm: tuple | None = None) -> None:
+    def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False, dbias: torch.Tensor | None = None) -> None:
         """Weight gradient of one layer.  Nothing in the backward pass consumes it, so on the device it runs on a SIDE stream,
         ordered after the kernel that produced ``dy``: its MFMA-bound tiles fill the CUs that the data-gradient's tails and the
         HBM-bound BatchNorm kernels leave idle.  All weight gradients share that stream (and the split-K workspace);
@@ -256,11 +258,6 @@ class Engine:
         if dbias is not None:  # the layer's bias gradient (column sums of dy) rides in the same launch
             what = "lp_conv_wgrad_bias"
             fn = lambda x_, dy_, g_, dw_, split, ws, nws, st: self._lib.lp_conv_wgrad_bias(x_, dy_, g_, dw_, _p(dbias), split, ws, nws, st)  # noqa: E731
-        if norm is not None:  # x is the pre-normalisation tensor of the BatchNorm in front of this 1x1 convolution: normalised on load
-            n_mean, n_scale, n_shift, n_seg = norm
-            what = "lp_conv_wgrad_norm"
-            fn = lambda x_, dy_, g_, dw_, split, ws, nws, st: self._lib.lp_conv_wgrad_norm(  # noqa: E731
-                x_, dy_, g_, dw_, _p(n_mean), _p(n_scale), _p(n_shift), n_seg, split, ws, nws, st)
         # (while bench.py's per-launch events are on, the launch stays on the main stream: an event pair there brackets exactly this
         # kernel, as rocprofv3's serialised kernel trace does; on the side stream it would bracket nothing)
         if (self.device.type != "cuda" or not self.wgrad_side_stream or self.profile is not None
@@ -412,8 +409,7 @@ class Engine:
             f.dbeta_acc, f.dgamma_acc = self.G[b.b_off:].data_ptr(), self.G[b.g_off:].data_ptr()
         return f
 
-    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None, seg: int = 0,
-                  norm: tuple | None = None):
+    def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None, seg: int = 0):
         """``sums`` (segments,2,Co): also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics pass, fused);
         ``seg`` > 0: images [0, seg) and [seg, B) are two BatchNorm segments with their own sums."""
         g = self._geom(c, B, Hi, Wi)
@@ -428,13 +424,7 @@ class Engine:
                 run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
             self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run, self._bytes(c, g))
         else:
-            if norm is not None:  # x is a pre-normalisation tensor: (mean, scale, shift) of the BatchNorm in front, applied on load
-                if sums is None:  # eval mode: no statistics wanted, the entry point still takes a (scratch) sums buffer
-                    sums = torch.zeros(2 * c.Co, device=self.device, dtype=torch.float32)
-                f = self._bn_fuse(g, False, sums, seg=seg)
-                run = lambda: check(self._lib.lp_conv_fwd_bn_norm(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), _p(norm[0]), _p(norm[1]),  # noqa: E731
-                                                                  _p(norm[2]), st), "lp_conv_fwd_bn_norm")
-            elif sums is None:
+            if sums is None:
                 run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
             else:
                 f = self._bn_fuse(g, False, sums, seg=seg)
@@ -648,37 +638,14 @@ class Engine:
             T[f"{key}.x"] = x
             tp.meta[f"{key}.hw"] = (h, w)
             z1, a1, m1, v1, _ = conv_bn(blk.conv1, blk.bn1, x, h, w, None, True)
-            if self.norm_on_load:
-                # bn2's activation is consumed by conv3 (1x1) and by conv3's weight gradient only: both normalise z2 on load
-                # (lp_conv_fwd_bn_norm / lp_conv_wgrad_norm), so a2 is never written or read - only the moments are taken here
-                s2 = next_sums(blk.bn2)
-                z2, g2 = self._conv_fwd(blk.conv2, a1, B, h, w, s2 if training else None, seg=seg)
-                m2, v2 = self._bn_moments(blk.bn2, z2, B * g2.Ho * g2.Wo, training, s2, have_sums=training, seg=seg)
-                sc2 = torch.empty_like(v2)
-                check(self._lib.lp_bn_affine(_p(v2), _p(self.param_view(blk.bn2, "weight")), v2.numel() // blk.bn2.C, blk.bn2.C, _p(sc2),
-                                             ops._stream()), "lp_bn_affine")
-                a2 = None
-                T[f"{key}.sc2"] = sc2
-            else:
-                z2, a2, m2, v2, g2 = conv_bn(blk.conv2, blk.bn2, a1, h, w, None, True)
+            z2, a2, m2, v2, g2 = conv_bn(blk.conv2, blk.bn2, a1, h, w, None, True)
             ho, wo = g2.Ho, g2.Wo
             if blk.down is not None:
                 zd, idt, md, vd, _ = conv_bn(blk.down, blk.dbn, x, h, w, None, False)
                 T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"] = zd, md, vd
             else:
                 idt = x
-            if a2 is None:
-                s3 = next_sums(blk.bn3)
-                nseg_rows = v2.numel() // blk.bn2.C
-                shift2 = self.param_view(blk.bn2, "bias") if nseg_rows == 1 else self.param_view(blk.bn2, "bias").repeat(nseg_rows)
-                T[f"{key}.sh2"] = shift2
-                z3, g3 = self._conv_fwd(blk.conv3, z2, B, ho, wo, s3 if training else None, seg=seg, norm=(m2, sc2, shift2))
-                res3 = self._bn_fwd(blk.bn3, z3, B * g3.Ho * g3.Wo, idt, True, training, s3, have_sums=training, want_bits=training, seg=seg)
-                if len(res3) == 4:
-                    T[f"{key}.out_bits"] = res3[3]
-                out, m3, v3 = res3[:3]
-            else:
-                z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits")
+            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits")
             for nm, val in (("z1", z1), ("a1", a1), ("m1", m1), ("v1", v1), ("z2", z2), ("a2", a2), ("m2", m2), ("v2", v2),
                             ("z3", z3), ("m3", m3), ("v3", v3), ("out", out)):
                 if val is not None:
@@ -789,7 +756,7 @@ class Engine:
         return dz, dres
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
-                  relu_bits=None, seg: int = 0, x_norm: tuple | None = None):
+                  relu_bits=None, seg: int = 0):
         """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
         ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
         for stride-2 layers only the pixels a filter tap reaches are touched.
@@ -797,7 +764,7 @@ class Engine:
         two backward reductions in ``sums``.  Without ``relu_mask`` the ReLU mask is recomputed from z (no residual branch)."""
         g = self._geom(c, B, Hi, Wi)
         self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g),
-                    lambda: self._wgrad(x, dz, g, self.G[c.w_off:], norm=x_norm), self._bytes(c, g, wgrad=True))
+                    lambda: self._wgrad(x, dz, g, self.G[c.w_off:]), self._bytes(c, g, wgrad=True))
         if not need_dx:
             return None
         st = ops._stream()
@@ -817,7 +784,12 @@ class Engine:
         else:
             run = lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),  # noqa: E731
                                                         _p(dx), None, c.Ci, 0, skip, st), "lp_conv_dgrad")
-        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g))
+        # algorithmic bytes of the launch: the contraction's operands / result plus what its fused store pass reads back (the gradient arriving
+        # over the residual branch, the pre-normalisation tensor of the fused BatchNorm backward, the ReLU mask as activation or 1 bit each)
+        dx_bytes = 2.0 * B * Hi * Wi * c.Ci
+        extra = (dx_bytes if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
+                (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0)
+        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -865,12 +837,8 @@ class Engine:
                 dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False, sums=d_sums, seg=seg)
                 dres = d
             s2 = new_sums(blk.bn2)
-            if f"{key}.a2" in T:
-                x3, x3n = T[f"{key}.a2"], None
-            else:  # the forward pass never stored a2: conv3's weight gradient normalises z2 on load, like conv3 itself did
-                x3, x3n = T[f"{key}.z2"], (T[f"{key}.m2"], T[f"{key}.sc2"], T[f"{key}.sh2"], seg)
-            da2 = self._conv_bwd(blk.conv3, x3, dz3, B, ho, wo, True,
-                                 bn=(blk.bn2, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], s2), seg=seg, x_norm=x3n)
+            da2 = self._conv_bwd(blk.conv3, T[f"{key}.a2"], dz3, B, ho, wo, True,
+                                 bn=(blk.bn2, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], s2), seg=seg)
             dz2, _ = self._bn_bwd(blk.bn2, da2, None, T[f"{key}.z2"], T[f"{key}.m2"], T[f"{key}.v2"], Mo, False, sums=s2, seg=seg)
             s1 = new_sums(blk.bn1)
             da1 = self._conv_bwd(blk.conv2, T[f"{key}.a1"], dz2, B, hi, wi, True,

@@ -566,7 +566,7 @@ def gen_step_parity(names=None):
                 sd_.update(new)
                 model.load_state_dict(sd_)
                 arrs_names = np.array(sorted(new))
-        fit_loss = _train_head(model, inp, H.generate_heatmaps, HEAD_TRAIN_STEPS, HEAD_TRAIN_LR)
+        fit_loss = _train_head(model, inp, H.generate_heatmaps, cfg.get("head_steps", HEAD_TRAIN_STEPS), HEAD_TRAIN_LR)
         seen = {}
         for meth in ("get_loss_inputs_labeled", "get_loss_inputs_unlabeled"):
             if hasattr(model, meth):

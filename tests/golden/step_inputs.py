@@ -21,7 +21,9 @@ STEP_CONFIGS = {
     "c4": dict(HW=384, K=17, Bl=2, S=4, V=1, seed=15, unsup=("temporal", "pca_singleview"), backbone="vits_dino"),
     # BASELINE config 2 at its REAL per-GPU batch (64 labeled + 128 unlabeled frames, 384x384, K=17): what bench.py times - the joint
     # labeled + unlabeled pass with its BatchNorm segment boundary at 64 * H * W rows and the persistent tile walks of 13.8 k tiles
-    "c2full": dict(HW=384, K=17, Bl=64, S=128, V=1, seed=16, unsup=("temporal", "pca_singleview")),
+    # (192 frames are too many for 300 head steps to memorise when all blobs look alike: the K blobs get a seeded colour each, so the head
+    # can tell the keypoints apart from the trunk's features, and the head trains longer - the heat-maps are then single peaks as in c2)
+    "c2full": dict(HW=384, K=17, Bl=64, S=128, V=1, seed=16, unsup=("temporal", "pca_singleview"), colored=True, head_steps=1000),
     # BASELINE config 5 with its real FOUR views (256x256 views, temporal + pca_multiview)
     "c5v4": dict(HW=256, K=4, Bl=2, S=4, V=4, seed=17, unsup=("temporal", "pca_multiview")),
 }
@@ -59,15 +61,17 @@ def seeded_backbone_weights(state_dict: dict, seed: int = 21) -> dict:
     return out
 
 
-def _render(g, centres, size):
-    """(n, K, 2) blob centres -> (n, 3, size, size): K Gaussian blobs (sigma 6 px, amplitude 3) over N(0, 0.25) noise"""
+def _render(g, centres, size, colors=None):
+    """(n, K, 2) blob centres -> (n, 3, size, size): K Gaussian blobs (sigma 6 px, amplitude 3) over N(0, 0.25) noise; ``colors`` (K, 3):
+    per-keypoint channel weights (default: every blob white)"""
     n, K, _ = centres.shape
     ys = torch.arange(size).view(1, size, 1).float()
     xs = torch.arange(size).view(1, 1, size).float()
     img = torch.randn(n, 3, size, size, generator=g) * 0.5
     for k in range(K):
         cx, cy = centres[:, k, 0].view(-1, 1, 1), centres[:, k, 1].view(-1, 1, 1)
-        img += (3.0 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 72.0)).unsqueeze(1)
+        blob = (3.0 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 72.0)).unsqueeze(1)
+        img += blob if colors is None else blob * colors[k].view(1, 3, 1, 1)
     return img
 
 
@@ -88,8 +92,9 @@ def make_step_inputs(name: str, generate_heatmaps) -> dict:
     HW, K, Bl, S, V = cfg["HW"], cfg["K"], cfg["Bl"], cfg["S"], cfg["V"]
     g = torch.Generator().manual_seed(cfg["seed"])
     KV = K * V
+    colors = (torch.rand(K, 3, generator=torch.Generator().manual_seed(1000 + cfg["seed"])) * 2.0 - 0.5) if cfg.get("colored") else None
     lab_c = (torch.rand(Bl * V, K, 2, generator=g) * 0.7 + 0.15) * HW
-    images = _render(g, lab_c, HW)
+    images = _render(g, lab_c, HW, colors)
     kp = lab_c.reshape(Bl, KV, 2).clone()
     kp[0, 1] = float("nan")                                        # an unlabeled keypoint
     heat = generate_heatmaps(kp.clone(), HW, HW, (HW // 4, HW // 4))
@@ -108,7 +113,7 @@ def make_step_inputs(name: str, generate_heatmaps) -> dict:
     start = (torch.rand(1, V, K, 2, generator=g) * 0.6 + 0.2) * HW
     walk = torch.cumsum(torch.randn(S, V, K, 2, generator=g) * 3.0, dim=0) + start
     walk = walk.clamp(8, HW - 8)
-    frames = _render(g, walk.reshape(S * V, K, 2), HW)
+    frames = _render(g, walk.reshape(S * V, K, 2), HW, colors)
     if V == 1:
         unlabeled = {"frames": frames, "transforms": _affine(g, HW), "bbox": torch.tensor([[0.0, 0.0, float(HW), float(HW)]]).repeat(S, 1),
                      "is_multiview": False}

@@ -299,38 +299,6 @@ def conv_fwd_bn(x_nhwc_bits, w_bits, g, seg=0, rc=False):
     return ob.np(), f.keep["sums"].np()
 
 
-def bn_affine(invstd, gamma):
-    """(segments, C) invstd, (C,) gamma -> scale = invstd * gamma"""
-    iv = np.atleast_2d(f32(invstd))
-    ib, gb, out = Buf(iv), Buf(f32(gamma)), Z(iv.shape)
-    ok(lib().lp_bn_affine(ib.p, gb.p, iv.shape[0], iv.shape[1], out.p, stream()))
-    return out.np()
-
-
-def conv_fwd_bn_norm(z_bits, w_bits, g, mean, scale, shift, seg=0, rc=False):
-    """1x1 convolution of relu(BatchNorm(z)) with the normalisation done on load -> (out bits, sums of the output)"""
-    zb, wb, ob = Buf(z_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
-    f = _bn_fuse(g, False, g.Co, seg=seg)
-    mb, sb, hb = Buf(f32(mean)), Buf(f32(scale)), Buf(f32(shift))
-    code = lib().lp_conv_fwd_bn_norm(zb.p, wb.p, C.byref(g), ob.p, C.byref(f), mb.p, sb.p, hb.p, stream())
-    if rc:
-        return code
-    ok(code)
-    return ob.np(), f.keep["sums"].np()
-
-
-def conv_wgrad_norm(z_bits, dy_bits, g, mean, scale, shift, seg=0, split=0, rc=False):
-    zb, db, dw = Buf(z_bits), Buf(dy_bits), Z((g.Co, g.R * g.S * g.Ci))
-    nws = lib().lp_conv_wgrad_workspace_bytes(C.byref(g), split)
-    ws = Z(nws, np.uint8)
-    mb, sb, hb = Buf(f32(mean)), Buf(f32(scale)), Buf(f32(shift))
-    code = lib().lp_conv_wgrad_norm(zb.p, db.p, C.byref(g), dw.p, mb.p, sb.p, hb.p, seg, split, ws.p, nws, stream())
-    if rc:
-        return code
-    ok(code)
-    return dw.np()
-
-
 def stem_fwd_bn(x4_bits, w_bits, g, seg=0):
     xb, wb, ob = Buf(x4_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, 64), np.uint16)
     f = _bn_fuse(g, False, 64, seg=seg)

@@ -42,7 +42,7 @@ def test_pipe_equals_igemm(case, wgs, monkeypatch):
     wg, wd = emu.to_bf16_bits(w), emu.to_bf16_bits(w.permute(3, 1, 2, 0))
     # forward, plain and with the fused BatchNorm sums
     (z0, _), (z1, _) = _both(monkeypatch, lambda: emu.conv_fwd(x, wg, g))
-    assert np.array_equal(z0, z1)
+    assert np.array_equal(z0, z1) and emu.lib().lp_conv_last_kernel() == 1   # LP_CONV_KERNEL_PIPE
     (zb0, s0), (zb1, s1) = _both(monkeypatch, lambda: emu.conv_fwd_bn(x, wg, g))
     assert np.array_equal(zb0, z0) and np.array_equal(zb1, z0)
     np.testing.assert_allclose(s1, s0, rtol=2e-5, atol=2e-4)
@@ -89,3 +89,41 @@ def test_pipe_two_batchnorm_segments(monkeypatch):
     assert np.array_equal(r0[0], r1[0])
     for a, b in zip(r0[1:], r1[1:]):
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)
+
+
+WG_CASES = [
+    (3, 16, 16, 64, 128, 3, 1, 1),    # 3x3, Ka = 576 (a ragged third a-tile), BN = 128
+    (1, 19, 15, 128, 64, 3, 1, 1),    # M = 285 (a ragged last K step), Ka = 1152 (5 a-tiles), BN = 64
+    (4, 18, 18, 64, 256, 3, 2, 1),    # 3x3 stride 2: gathered rows jump by two pixels
+    (4, 16, 16, 64, 256, 1, 1, 0),    # 1x1 with 64 input channels: transposed (a = co, b = ci)
+    (4, 16, 16, 256, 64, 1, 1, 0),    # 1x1 reduce, plain addressing, BN = 64
+    (6, 16, 16, 256, 128, 1, 2, 0),   # 1x1 stride 2 (projection shortcut)
+    (2, 12, 12, 128, 128, 3, 1, 1),   # 3x3 "same" with 144-pixel images: the tracked (row, column) walk crosses images within a K step
+]
+
+
+@pytest.mark.parametrize("split", [0, 3])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_pipelined_weight_gradient(case, split, monkeypatch):
+    """conv_wgrad_pipe_kernel (+ its reduction) vs torch's weight gradient of the same bf16-rounded operands, and vs conv_wgrad_kernel"""
+    import torch.nn.functional as F
+
+    B, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(3 + sum(case))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x = bf(torch.randn(B, Ci, Hi, Wi, generator=gen))
+    w = bf(torch.randn(Co, Ci, R, R, generator=gen) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=st, padding=pad)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    xb, dyb = emu.to_bf16_bits(x.permute(0, 2, 3, 1).contiguous()), emu.to_bf16_bits(dy.permute(0, 2, 3, 1).contiguous())
+    want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    monkeypatch.setenv("LP_CONV_PIPE", "0")
+    old = emu.conv_wgrad(xb, dyb, g, split=split)
+    monkeypatch.setenv("LP_CONV_PIPE", "1")
+    monkeypatch.setenv("LP_WGRAD_PIPE", "2")      # wherever the kernel can run (the default leaves HBM-bound shapes to conv_wgrad_kernel)
+    new = emu.conv_wgrad(xb, dyb, g, split=split)
+    assert emu.lib().lp_conv_last_kernel() == 3   # LP_CONV_KERNEL_WGRAD_PIPE
+    torch.testing.assert_close(torch.from_numpy(new), want, atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(torch.from_numpy(new), torch.from_numpy(old), atol=1e-3, rtol=1e-3)

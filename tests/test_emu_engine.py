@@ -29,16 +29,13 @@ def close(name, a, b, cos_min=0.995, ratio_tol=0.03):
     assert cos > cos_min and abs(ratio - 1) < ratio_tol, f"{name}: cos {cos:.5f} ratio {ratio:.4f}"
 
 
-@pytest.mark.parametrize("joint,norm_on_load", [(None, False), ((8, 8), False), (None, True), ((8, 8), True)],
-                         ids=["single", "joint", "single-norm-on-load", "joint-norm-on-load"])
-def test_engine_forward_backward_blockwise(stack_backend, joint, norm_on_load, monkeypatch):
+@pytest.mark.parametrize("joint", [None, (8, 8)], ids=["single", "joint"])
+def test_engine_forward_backward_blockwise(stack_backend, joint, monkeypatch):
     """``joint`` = (labeled, unlabeled) image counts: both batches share ONE pass (every layer one launch) as two BatchNorm segments with
     their own batch statistics - what the reference's two forward calls compute (models/base.py:682-695); the oracle below then applies
     every BatchNorm per segment."""
     dev = stack_backend
     MARGINS.clear()
-    # norm_on_load (opt-in LP_NORM_ON_LOAD=1): conv3 and its weight gradient consume z2 directly (lp_conv_fwd_bn_norm / lp_conv_wgrad_norm)
-    monkeypatch.setenv("LP_NORM_ON_LOAD", "1" if norm_on_load else "0")
     segs = [(0, 4)] if joint is None else [(0, joint[0]), (joint[0], sum(joint))]
     HW = 64 if joint is None else 128      # (8 images of 128 x 128 end on a 128-row tile boundary in every layer)
 
@@ -58,7 +55,6 @@ def test_engine_forward_backward_blockwise(stack_backend, joint, norm_on_load, m
         if k.startswith("head") and k.endswith("bias"):
             sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.1
     eng = Engine(K, 2, dev)
-    assert eng.norm_on_load == norm_on_load
     eng.load_state_dict(sd, strict=False)
     ref = O.OracleTracker(K, 2, torch_seed=7)
     ref.load_state_dict(sd, strict=False)

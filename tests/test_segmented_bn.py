@@ -133,46 +133,6 @@ NORM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", NORM_CASES)
-def test_normalise_on_load_equals_bn_apply_then_conv(case, kernel_backend):
-    """lp_conv_fwd_bn_norm(z) == lp_conv_fwd_bn(lp_bn_apply(z)) and lp_conv_wgrad_norm(z, dy) == lp_conv_wgrad(lp_bn_apply(z), dy), bit for
-    bit on the convolution output (the activation between BatchNorm and the 1x1 convolution is what lp_bn_apply would have stored)."""
-    B, seg, H, W, Ci, Co = case
-    gen = torch.Generator().manual_seed(3 + sum(case))
-    g = emu.geom(B, H, W, Ci, Co, 1, 1, 1, 0)
-    rows = H * W
-    z = torch.randn(B * rows, Ci, generator=gen) * 1.5 + 0.3
-    if seg:
-        z[seg * rows:] = z[seg * rows:] * 0.6 - 0.5
-    zb = emu.to_bf16_bits(z)
-    gamma, beta = (torch.rand(Ci, generator=gen) + 0.5).numpy(), (torch.randn(Ci, generator=gen) * 0.3).numpy()
-    w = emu.to_bf16_bits(torch.randn(Co, 1, 1, Ci, generator=gen) / Ci ** 0.5)
-    segs = ((0, B),) if not seg else ((0, seg), (seg, B - seg))
-    mean, invstd = np.zeros((len(segs), Ci), np.float32), np.zeros((len(segs), Ci), np.float32)
-    a = np.zeros_like(zb)
-    for si, (i0, n) in enumerate(segs):
-        a[i0 * rows:(i0 + n) * rows], mean[si], invstd[si] = emu.bn_forward(zb[i0 * rows:(i0 + n) * rows], n * rows, Ci, gamma, beta, relu=True)
-    scale = emu.bn_affine(invstd, gamma)
-    np.testing.assert_array_equal(scale, invstd * gamma[None])
-    want_out, want_sums = emu.conv_fwd_bn(a, w, g, seg=seg)
-    got_out, got_sums = emu.conv_fwd_bn_norm(zb, w, g, mean, scale, np.tile(beta, (len(segs), 1)), seg=seg)
-    assert np.array_equal(got_out, want_out)
-    np.testing.assert_allclose(got_sums, want_sums, rtol=1e-5, atol=1e-4)
-    dy = emu.to_bf16_bits(torch.randn(B * rows, Co, generator=gen))
-    want_dw = emu.conv_wgrad(a, dy, g)
-    got_dw = emu.conv_wgrad_norm(zb, dy, g, mean, scale, np.tile(beta, (len(segs), 1)), seg=seg)
-    np.testing.assert_allclose(got_dw, want_dw, rtol=1e-5, atol=1e-5)
-
-
-def test_normalise_on_load_is_for_1x1_only(kernel_backend):
-    g = emu.geom(2, 8, 8, 64, 64, 3, 3, 1, 1)
-    x = emu.to_bf16_bits(torch.randn(2, 8, 8, 64))
-    w = emu.to_bf16_bits(torch.randn(64, 3, 3, 64))
-    m = np.zeros((1, 64), np.float32)
-    assert emu.conv_fwd_bn_norm(x, w, g, m, m + 1, m, rc=True) == -2
-    assert emu.conv_wgrad_norm(x, emu.to_bf16_bits(torch.randn(2 * 64, 64)), g, m, m + 1, m, rc=True) == -2
-
-
 @pytest.mark.parametrize("M,seg_rows,Cn", [(256, 128, 64), (300, 100, 24), (5000, 1800, 256), (96, 95, 8)])
 def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_rows, Cn):
     """lp_bn_apply_seg / lp_bn_bwd_apply_seg == the one-segment entry points called once per segment, bit for bit (one launch walks both
