@@ -405,8 +405,8 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     if not solo:
         comm["backend"] = dist.get_backend()
         comm["buckets_sent_during_backward"] = trainer.dp.buckets_during_backward
-        comm["sync_bn_transport"] = ("librccl ncclAllReduce on the compute stream (LP_SYNCBN_DIRECT=1)" if getattr(model.net, "direct_comm", None) is not None
-                                     else "torch.distributed all_reduce")
+        comm["sync_bn_transport"] = ("all_gather + local add in rank order (LP_SYNCBN_GATHER=1)" if getattr(model.net, "sync_bn_gather", False)
+                                     else "all_reduce")
     mem1 = torch.cuda.memory_stats(dev) if dev.type == "cuda" else {}
     memory = {"max_allocated_gb": round(mem1.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2), "max_reserved_gb": round(mem1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
               "device_allocs_in_timed_steps": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),

@@ -37,6 +37,10 @@ namespace lp {
 #define LP_PIPE_SPREAD 1   // (A/B builds: 0 issues a K step's loads in one burst after the barrier)
 #endif
 constexpr bool kSpread = LP_PIPE_SPREAD != 0;
+#ifndef LP_PIPE_STAGGER
+#define LP_PIPE_STAGGER 1  // (A/B builds: 0 = all eight waves do a K step's address arithmetic at the same point)
+#endif
+constexpr bool kStagger = LP_PIPE_STAGGER != 0;
 constexpr int kPM = 256;   // tile rows (pixels)
 constexpr int kPRowB = 128;  // bytes per staged operand row (64 k x bf16)
 
@@ -202,6 +206,9 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         }
     };
     auto issue_load = [&](int i) {   // (i is a compile-time constant at every call site)
+#ifdef LP_PIPE_EXP_NOLOAD   // (timing experiment, wrong results: how fast is the MFMA + LDS-read loop alone?)
+        if (M < 0)
+#endif
         if (i < 4) buf_load16_lds(rsrc_x, is_dst + i * (64 * kPRowB), voff[i], is_soff_a);
         else buf_load16_lds(rsrc_w, is_dst + kStageA + (i - 4) * (64 * kPRowB), is_w[i - 4], is_soff_b);
     };
@@ -230,10 +237,22 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 
     f32x16 acc[2][NT];
     // `spread`: issue the prepared step's loads between the k-slices (2 after the first slice's MFMAs have been queued, then 2, 1, 1)
-    auto mma_stage = [&](int st, const bool spread) {
+    // `spread`: issue the prepared step's loads between the k-slices.  `late` (the waves of the second column half, wn = 1): the step's
+    // address arithmetic (prep_step: ~40 VALU / SALU instructions) runs after the second k-slice instead of before the first and the
+    // loads go out in slices 2 and 3 - the two waves that share a SIMD (w and w + 4) then do their scalar work at different times, so one
+    // wave's MFMAs cover the other's arithmetic instead of both leaving the matrix pipe idle right after the barrier.
+    auto mma_stage = [&](int st, const bool spread, const bool late, const int nxt) {
         const unsigned char* sb = smem + st * kStage;
         bf16x8 a[2][2], b[2][NT];
         auto fetch = [&](int kk, int set) {
+#ifdef LP_PIPE_EXP_NOLDSREAD   // (timing experiment, wrong results: fragments are read once per K step instead of once per k-slice)
+            if (kk != 0) {
+                a[set][0] = a[set ^ 1][0], a[set][1] = a[set ^ 1][1];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[set][nt] = b[set ^ 1][nt];
+                return;
+            }
+#endif
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 a[set][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + a_row + mt * (32 * kPRowB) + koff[kk]));
@@ -253,16 +272,30 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk & 1][nt], a[kk & 1][mt], acc[mt][nt], 0, 0, 0);
             if (spread) {
                 constexpr int NL = 4 + NBL;
-                if (kk == 0) {
-                    issue_load(0);
-                    issue_load(1);
-                } else if (kk == 1) {
-                    issue_load(2);
-                    if (NL == 6) issue_load(3);
-                } else if (kk == 2) {
-                    issue_load(NL == 6 ? 4 : 3);
+                if (!late) {
+                    if (kk == 0) {
+                        issue_load(0);
+                        issue_load(1);
+                    } else if (kk == 1) {
+                        issue_load(2);
+                        if (NL == 6) issue_load(3);
+                    } else if (kk == 2) {
+                        issue_load(NL == 6 ? 4 : 3);
+                    } else {
+                        issue_load(NL - 1);
+                    }
                 } else {
-                    issue_load(NL - 1);
+                    if (kk == 1) {
+                        prep_step(nxt);
+                    } else if (kk == 2) {
+                        issue_load(0);
+                        issue_load(1);
+                        issue_load(2);
+                    } else if (kk == 3) {
+                        issue_load(3);
+                        issue_load(4);
+                        if (NL == 6) issue_load(5);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -491,16 +524,22 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         for (int kt = 0; kt < KT; ++kt) {
             if (NBL == 2) LP_WAIT_VM(6);   // this wave's loads of the current step have landed; the next step's 4 + NBL stay in flight
             else LP_WAIT_VM(5);
+#ifndef LP_PIPE_EXP_NOBARRIER   // (timing experiment, racy: what do the per-K-step barriers cost?)
             LP_RAW_BARRIER();              // ... everyone's have, and everyone is done reading the stage refilled next
+#endif
             if (!kFwd && kt == KT - 1) rb_issue(rb0, 0, m0, n0);   // the first chunk's read-backs travel under the last K step
             const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
             if (kSpread) {
-                prep_step(nxt);
-                mma_stage(cur, true);
+                if (kStagger && MODE == kModeFwd && wn == 1) {   // (wave-uniform; the data-gradient instantiations have no registers to spare for a second loop body)
+                    mma_stage(cur, true, true, nxt);
+                } else {
+                    prep_step(nxt);
+                    mma_stage(cur, true, false, nxt);
+                }
                 advance_tile();
             } else {
                 load_step(nxt);
-                mma_stage(cur, false);
+                mma_stage(cur, false, false, nxt);
             }
             cur = cur == 2 ? 0 : cur + 1;
         }

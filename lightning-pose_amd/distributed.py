@@ -65,11 +65,6 @@ class DataParallel:
         self.bucket_elems = max(1, bucket_bytes // 4)
         engine.process_group = process_group
         engine.sync_bn = bool(sync_bn and self.active)
-        from . import rccl
-
-        if engine.sync_bn and rccl.requested() and getattr(engine, "direct_comm", None) is None and hasattr(engine, "plan") \
-                and getattr(engine.plan, "bns", None):
-            engine.direct_comm = rccl.DirectComm(engine.device, process_group)   # fails loudly: the flag asked for it
         self._works: list = []
         self._next_hi: int | None = None   # overlapped mode: upper end of the next bucket to send (None: no step in flight)
         self.buckets_during_backward = 0

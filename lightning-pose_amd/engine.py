@@ -216,7 +216,11 @@ class Engine:
         self._bwd_training = True     # mode of the forward pass whose backward is running (eval: no batch-statistics terms)
         self.sync_bn_messages = 0     # SyncBatchNorm all-reduces issued so far (bench.py reports them per step)
         self.process_group = None
-        self.direct_comm = None       # rccl.DirectComm: SyncBatchNorm messages on the compute stream (LP_SYNCBN_DIRECT=1)
+        # SyncBatchNorm transport.  Default: one SUM all-reduce per message.  LP_SYNCBN_GATHER=1: one-shot exchange - every rank's
+        # [segments][2][C] sums are all-gathered (over xGMI each rank writes its 4 - 16 KB straight into every peer's slot: one hop, no
+        # ring) and added locally in RANK ORDER, so every rank holds the same bits whatever the collective's internal order
+        self.sync_bn_gather = os.environ.get("LP_SYNCBN_GATHER", "0") == "1"
+        self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
         self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
@@ -444,10 +448,19 @@ class Engine:
         return n0 > 0 and H % 32 == 0 and W % 32 == 0 and (n0 * (H // 32) * (W // 32)) % 128 == 0
 
     def _sync_stats(self, t: torch.Tensor) -> None:
-        """SUM of one SyncBatchNorm message over the ranks, in place: through torch.distributed (ProcessGroupNCCL's own stream, two event
-        hand-offs per message), or - ``direct_comm`` set by DataParallel under LP_SYNCBN_DIRECT=1 - one ncclAllReduce on the compute stream"""
-        if self.direct_comm is not None:
-            self.direct_comm.all_reduce_sum_(t, ops._stream())
+        """SUM of one SyncBatchNorm message over the ranks, in place (reference: ``sync_batchnorm=True``, train.py:427): an all-reduce, or -
+        LP_SYNCBN_GATHER=1 - the one-shot form: all-gather the ranks' sums into per-rank slots, then add the slots in rank order."""
+        if self.sync_bn_gather:
+            world, n = dist.get_world_size(self.process_group), t.numel()
+            if self._gather_buf is None or self._gather_buf.numel() < world * n:
+                self._gather_buf = torch.empty(world * max(n, 8192), device=t.device, dtype=t.dtype)
+            flat = self._gather_buf[:world * n]
+            dist.all_gather_into_tensor(flat, t.reshape(-1), group=self.process_group)   # (flat output: the form gloo and RCCL both take)
+            slots = flat.view(world, n)
+            acc = slots[0].clone()
+            for r in range(1, world):   # fixed order: bit-identical on every rank
+                acc += slots[r]
+            t.reshape(-1).copy_(acc)
         else:
             dist.all_reduce(t, group=self.process_group)
 

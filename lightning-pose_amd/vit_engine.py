@@ -154,7 +154,7 @@ class ViTEngine(Engine):
         for l in self.plan.norms():
             self.P[l.g_off:l.g_off + hidden] = 1.0
         self.nbt = torch.zeros((), dtype=torch.long)
-        self.sync_bn, self.process_group, self.direct_comm = False, None, None   # no BatchNorm here; kept for the DataParallel wrapper
+        self.sync_bn, self.process_group = False, None   # no BatchNorm here; kept for the DataParallel wrapper
         self.sync_bn_messages = 0
         self.grad_progress, self.single_backward = None, False   # gradient buckets leave during backward (Engine.backward, distributed.py)
         self._bwd_training = True

@@ -633,35 +633,42 @@ class _RoundGrad(torch.autograd.Function):
         return g.to(torch.bfloat16).float()
 
 
-def _bn_train(z: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor | None, relu: bool) -> torch.Tensor:
+def _bn_train(z: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor | None, relu: bool, q=None) -> torch.Tensor:
     y = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, training=True, momentum=bn.momentum, eps=bn.eps)
     if residual is not None:
         y = y + residual
     if relu:
         y = F.relu(y)
-    return _q(y)
+    return (_q if q is None else q)(y)
 
 
-def forward_bf16_policy(model: OracleTracker, images: torch.Tensor) -> torch.Tensor:
-    """Training-mode forward of `model` under the bf16-mixed policy (updates BN running statistics like train())."""
+def forward_bf16_policy(model: OracleTracker, images: torch.Tensor, rounding: tuple[str, ...] = ("trunk", "head")) -> torch.Tensor:
+    """Training-mode forward of `model` under the bf16-mixed policy (updates BN running statistics like train()).
+
+    ``rounding`` (profiles/rounding_ablation.py): which of the policy's rounding points are ON - "trunk" = every convolution operand and
+    output of the ResNet trunk, "head" = the operands of the two transposed convolutions and the activation between them.  Both = the
+    policy the product implements; () = the fp32 reference itself."""
+    qt = _q if "trunk" in rounding else (lambda t: t)
+    qh = _q if "head" in rounding else (lambda t: t)
     bb = model.backbone
-    x = _q(images)
-    x = _q(F.conv2d(x, _q(bb[0].weight), stride=2, padding=3))
-    x = _bn_train(x, bb[1], None, True)
+    x = qt(images)
+    x = qt(F.conv2d(x, qt(bb[0].weight), stride=2, padding=3))
+    x = _bn_train(x, bb[1], None, True, q=qt)
     x = F.max_pool2d(x, 3, 2, 1)
     for layer in (bb[4], bb[5], bb[6], bb[7]):
         for blk in layer:
             idt = x
-            o = _bn_train(_q(F.conv2d(x, _q(blk.conv1.weight))), blk.bn1, None, True)
-            o = _bn_train(_q(F.conv2d(o, _q(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True)
-            z3 = _q(F.conv2d(o, _q(blk.conv3.weight)))
+            o = _bn_train(qt(F.conv2d(x, qt(blk.conv1.weight))), blk.bn1, None, True, q=qt)
+            o = _bn_train(qt(F.conv2d(o, qt(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True, q=qt)
+            z3 = qt(F.conv2d(o, qt(blk.conv3.weight)))
             if blk.downsample is not None:
-                zd = _q(F.conv2d(x, _q(blk.downsample[0].weight), stride=blk.stride))
-                idt = _bn_train(zd, blk.downsample[1], None, False)
-            x = _bn_train(z3, blk.bn3, idt, True)
+                zd = qt(F.conv2d(x, qt(blk.downsample[0].weight), stride=blk.stride))
+                idt = _bn_train(zd, blk.downsample[1], None, False, q=qt)
+            x = _bn_train(z3, blk.bn3, idt, True, q=qt)
     x = F.pixel_shuffle(x, 2)
     cts = [m for m in model.head.upsampling_layers if isinstance(m, nn.ConvTranspose2d)]
     for i, ct in enumerate(cts):
-        x = F.conv_transpose2d(x, _q(ct.weight), ct.bias, stride=2, padding=1, output_padding=1)
-        x = _RoundGrad.apply(x) if i == len(cts) - 1 else _q(x)
+        x = F.conv_transpose2d(qh(x), qh(ct.weight), ct.bias, stride=2, padding=1, output_padding=1)
+        if "head" in rounding:
+            x = _RoundGrad.apply(x) if i == len(cts) - 1 else _q(x)
     return tp.spatial_softmax2d(x, 1.0)

@@ -76,7 +76,7 @@ def test_data_parallel_gloo_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
-def _engine_worker(rank, world, port, q):
+def _engine_worker(rank, world, port, q, gather=False):
     """one rank of 2-rank data-parallel steps of the REAL engine on the emulated kernels: SyncBatchNorm (statistics from the conv store
     passes, the fused stem, every BatchNorm backward) + bucketed gradient all-reduce, against single-process runs on rank 0.
 
@@ -90,6 +90,7 @@ def _engine_worker(rank, world, port, q):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ["HIPEMU_THREADS"] = "1"  # one emulator thread: workgroups (and their fp32 atomics) run in a fixed order, so (B) can be exact
+    os.environ["LP_SYNCBN_GATHER"] = "1" if gather else "0"   # the one-shot exchange (all-gather + local add in rank order) or an all-reduce
     import _lp_bootstrap  # noqa: F401
     from lightning_pose_amd import _lib, ops
     from lightning_pose_amd.distributed import DataParallel
@@ -112,6 +113,13 @@ def _engine_worker(rank, world, port, q):
         return real_all_reduce(*a, **k)
 
     dist.all_reduce = counting_all_reduce
+    real_all_gather = dist.all_gather_into_tensor
+
+    def counting_all_gather(*a, **k):   # (a SyncBatchNorm message in gather mode: counted like an all-reduce)
+        calls["n"] += 1
+        return real_all_gather(*a, **k)
+
+    dist.all_gather_into_tensor = counting_all_gather
     K, dev = 3, torch.device("cpu")
     torch.manual_seed(7)
     sd = seeded_state_dict(K, 2)
@@ -232,12 +240,15 @@ def _engine_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sync_batchnorm_engine_gloo_world2():
-    """SyncBatchNorm + summed gradients of the real engine across 2 gloo ranks (see _engine_worker)"""
+@pytest.mark.parametrize("gather", [False, True], ids=["all_reduce", "one_shot_gather"])
+def test_sync_batchnorm_engine_gloo_world2(gather):
+    """SyncBatchNorm + summed gradients of the real engine across 2 gloo ranks (see _engine_worker), with the messages as all-reduces and as
+    the one-shot exchange (LP_SYNCBN_GATHER=1: all-gather into per-rank slots + add in rank order - the same bits on every rank, and at
+    world 2 the same bits as the all-reduce, so part (B)'s exact comparisons hold for both)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, gather)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

@@ -182,14 +182,14 @@ def test_bench_loopback_rccl_on_device():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *LOOPBACK_ARGV], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     out = _check_loopback_line(p.stdout, "nccl")
-    assert out["config"]["comm_per_step"]["sync_bn_transport"].startswith("torch.distributed")
-    # ... and with the SyncBatchNorm messages on a second communicator driven through librccl on the compute stream (rccl.DirectComm)
-    env.update(LP_SYNCBN_DIRECT="1", MASTER_PORT=str(_free_port()))
+    assert out["config"]["comm_per_step"]["sync_bn_transport"] == "all_reduce"
+    # ... and with the SyncBatchNorm messages as the one-shot exchange (RCCL all-gather into per-rank slots + local add in rank order)
+    env.update(LP_SYNCBN_GATHER="1", MASTER_PORT=str(_free_port()))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *LOOPBACK_ARGV], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    direct = _check_loopback_line(p.stdout, "nccl")
-    assert direct["config"]["comm_per_step"]["sync_bn_transport"].startswith("librccl")
-    assert direct["config"]["final_loss"] == pytest.approx(out["config"]["final_loss"], rel=1e-3)   # sums over one rank: the same step
+    gather = _check_loopback_line(p.stdout, "nccl")
+    assert gather["config"]["comm_per_step"]["sync_bn_transport"].startswith("all_gather")
+    assert gather["config"]["final_loss"] == pytest.approx(out["config"]["final_loss"], rel=1e-3)   # sums over one rank: the same step
 
 
 def test_smoke_entry_point_body(stack_backend, capsys):
