@@ -352,8 +352,20 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     if args.predict:
         return predict_bench(args, model, batch, dev, rank, world)
+    if getattr(args, "peaked", False):
+        # the maps of a TRAINED head are single peaks; a random-init head (xavier gain 0.01) gives numerically flat ones.  Scaling the head's
+        # weights makes the soft-max outputs peaked (at arbitrary places - enough for the decode kernels, whose cost depends on how many
+        # pixels carry weight, not on where): what the decode costs in a real run, and whether the pruned kernels get chosen
+        sd = model.state_dict()
+        for k_ in sd:
+            if k_.startswith("head") and k_.endswith("weight"):
+                sd[k_] = sd[k_] * 200
+        model.load_state_dict(sd)
     trainer = Trainer(max_epochs=1, data_parallel=dist.is_initialized(), sync_batchnorm=not args.no_sync_bn, hip_graph=bool(args.graph))
     trainer.setup(model)
+    if getattr(args, "unfrozen", False):   # the regime after UnfreezeBackbone fired (reference callbacks.py:126-148): every group trains,
+        for g_ in model.optimizers().param_groups:   # so the transposed weight copies of the data gradients are refreshed every step
+            g_["lr"] = g_["lr"] if g_["lr"] > 0 else 1e-4
     model.train()
     model.total_unsupervised_importance = torch.tensor(1.0)
 
@@ -429,10 +441,14 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                                 "temporal + pca_multiview, Adam (backbone lr=0 as at step 0), bf16-mixed; value counts view-images") if args.views > 1 else
                                f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
-                               "pca_singleview + unimodal_mse, Adam (backbone lr=0 as at step 0), bf16-mixed",
+                               "pca_singleview + unimodal_mse, Adam (" + ("every group trains: backbone unfrozen" if getattr(args, "unfrozen", False)
+                                                                          else "backbone lr=0 as at step 0") + "), bf16-mixed"
+                               + (", head weights x200 (peaked heat-maps: ~4 of 147 456 up-sampled pixels carry weight, as with a trained head)" if getattr(args, "peaked", False) else ""),
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": bool(getattr(model.net, "sync_bn", False)),
                    "comm_per_step": comm, "memory": memory,
                    "hip_graph": bool(trainer._graphed is not None and trainer._graphed.replays > 0),
+                   "decode_prune": {-2: "unset", -1: "environment", 0: "plain kernels", 1: "pruned kernels (chosen from the maps)"}.get(
+                       __import__("lightning_pose_amd.ops", fromlist=["x"])._decode_prune_auto.state, "?"),
                    "final_loss": round(float(loss), 6)},
     }
     if rank == 0:
@@ -539,6 +555,9 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                     "(lightning_pose_amd/graph_step.py); the capture happens in extra untimed steps before the warm-up")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip the short secondary lines (256 px, ViT-S, multiview, "
                     "inference) the default single-GPU run appends under \"secondary\"")
+    ap.add_argument("--unfrozen", action="store_true", help="secondary line: the backbone group trains too (lr > 0), as after UnfreezeBackbone")
+    ap.add_argument("--peaked", action="store_true", help="secondary line: head weights x200 -> peaked heat-maps as a trained head gives them "
+                    "(the decode then picks its pruned kernels by itself, ops._DecodePruneAuto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNorm statistics (the reference sets sync_batchnorm=True, train.py:427; A/B only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
@@ -569,7 +588,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
             # holds them too; the headline stays `value`
             import copy
             sec = {}
-            for tag, over in (("resnet50_256", dict(size=256)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
+            for tag, over in (("resnet50_256", dict(size=256)), ("resnet50_384_unfrozen_backbone", dict(unfrozen=True)),
+                              ("resnet50_384_peaked_maps", dict(peaked=True)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
                               ("c5_multiview_4x256", dict(views=4, size=256, labeled=16, unlabeled=32)),
                               ("predict_resnet50_384", dict(predict=True)), ("predict_vits_dino_384", dict(predict=True, backbone="vits_dino"))):
                 a2 = copy.copy(args)
@@ -584,6 +604,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                         sec[tag]["roofline"] = {k_: r["roofline"][k_] for k_ in ("achieved", "frac", "unit", "launches_per_step", "mfma_ms_per_step",
                                                                                  "hbm_gbs_algorithmic") if k_ in r["roofline"]}
                     sec[tag]["workload"] = r["config"]["workload"]
+                    if "decode_prune" in r["config"]:
+                        sec[tag]["decode_prune"] = r["config"]["decode_prune"]
                 except Exception as e:  # noqa: BLE001 - never allowed to cost the headline line
                     sec[tag] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec

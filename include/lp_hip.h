@@ -70,6 +70,12 @@ typedef struct lp_frame_map {
 
 int lp_decode_window(int downsample_factor, int n);
 
+/* Which instantiation of the decode kernels runs: 1 = the exactly-pruned ones (terms below e^-50 of the largest are skipped: results equal
+ * to the last bit or two, 1.4x / 1.8x faster on the peaked maps of a trained head, slower on flat maps), 0 = the plain ones, -1 = follow the
+ * environment (LP_DECODE_PRUNE=1).  Process-wide; the product sets it from the decode's own sumexp output (ops.py).  Replaces nothing in the
+ * reference (models/heads/heatmap.py:103-144 has one code path). */
+int lp_decode_set_prune(int mode);
+
 /* heat (B,K,h,w) -> kp_aug (B,K,2) model px, kp_frame (B,K,2) frame px, conf (B,K), stats (B,K,4)={max,sumexp,ex,ey} */
 int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
                   const lp_decode_tables* tables, const lp_frame_map* frame_map, float* kp_aug, float* kp_frame, float* conf,

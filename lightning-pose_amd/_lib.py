@@ -94,6 +94,7 @@ PROTOTYPES = {
     "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_last_kernel": (_I, []),
+    "lp_decode_set_prune": (_I, [_I]),
     "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
     "lp_bn_fold": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),

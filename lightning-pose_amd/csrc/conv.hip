@@ -1175,13 +1175,11 @@ static void launch_pipe_dgrad(int kind, const void* x, const void* w, const Conv
 }
 
 // row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue): every launch since the sums are accumulated per persistent
-// workgroup (conv_igemm_kernel: stats_flush; conv_pipe_kernel: per thread).  The atomic path adds <= 512 partial sums per column in
-// arrival order, so two runs differ in the last bits.  LP_DETERMINISTIC=1 (or LP_STATS_ATOMIC_TILES=0) selects the bit-reproducible form
-// instead: per-tile rows in a workspace, summed in a fixed order by tile_stats_reduce_kernel - on conv_igemm_kernel, which implements it
-// (the pipelined kernel declines such launches, pipe_eligible).  Read per call, so one process can run both (the tests do).
+// workgroup (conv_igemm_kernel: stats_flush; conv_pipe_kernel: per thread).  LP_STATS_ATOMIC_TILES=0 selects the other form - per-tile rows
+// in a workspace, summed by tile_stats_reduce_kernel - on conv_igemm_kernel, which implements it (the pipelined kernel declines such
+// launches, pipe_eligible).  Neither makes a whole step bit-reproducible: the stand-alone BatchNorm reductions (bn.hip) and the second
+// stage of tile_stats_reduce_kernel add their partial sums with fp32 atomics too.  Read per call, so one process can run both (tests).
 static int stats_atomic_tiles() {
-    const char* d = getenv("LP_DETERMINISTIC");
-    if (d != nullptr && atoi(d) != 0) return 0;
     const char* e = getenv("LP_STATS_ATOMIC_TILES");
     return e ? atoi(e) : 0x7fffffff;   // (per-workgroup accumulation: the atomic path costs the same for any number of tiles)
 }

@@ -37,10 +37,6 @@ namespace lp {
 #define LP_PIPE_SPREAD 1   // (A/B builds: 0 issues a K step's loads in one burst after the barrier)
 #endif
 constexpr bool kSpread = LP_PIPE_SPREAD != 0;
-#ifndef LP_PIPE_STAGGER
-#define LP_PIPE_STAGGER 1  // (A/B builds: 0 = all eight waves do a K step's address arithmetic at the same point)
-#endif
-constexpr bool kStagger = LP_PIPE_STAGGER != 0;
 constexpr int kPM = 256;   // tile rows (pixels)
 constexpr int kPRowB = 128;  // bytes per staged operand row (64 k x bf16)
 
@@ -237,19 +233,24 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 
     f32x16 acc[2][NT];
     // `spread`: issue the prepared step's loads between the k-slices (2 after the first slice's MFMAs have been queued, then 2, 1, 1)
-    // `spread`: issue the prepared step's loads between the k-slices.  `late` (the waves of the second column half, wn = 1): the step's
-    // address arithmetic (prep_step: ~40 VALU / SALU instructions) runs after the second k-slice instead of before the first and the
-    // loads go out in slices 2 and 3 - the two waves that share a SIMD (w and w + 4) then do their scalar work at different times, so one
-    // wave's MFMAs cover the other's arithmetic instead of both leaving the matrix pipe idle right after the barrier.
-    auto mma_stage = [&](int st, const bool spread, const bool late, const int nxt) {
+    // `spread`: issue the prepared step's loads between the k-slices (2 after the first slice's MFMAs have been queued, then 2, 1, 1).
+    // (Measured and dropped, profiles/r03k_stagger.txt: letting the two waves of a SIMD do their per-step address arithmetic at different
+    // points - one before slice 0, the other after slice 1 with its loads in slices 2 - 3 - made every forward layer 15 - 25 % slower.)
+    // fragment sets in flight: the forward kernel reads TWO k-slices ahead of its MFMAs (3 register sets; 16 more VGPRs it has), the data
+    // gradient - at the register cap because of its read-back batches - one slice ahead (2 sets)
+#ifndef LP_PIPE_FRAG_SETS
+#define LP_PIPE_FRAG_SETS 2   // (3 = two slices ahead: measured equal within noise, profiles/r03n_fragsets.txt, at 16 more VGPRs)
+#endif
+    constexpr int NS = (MODE == kModeFwd) ? LP_PIPE_FRAG_SETS : 2;
+    auto mma_stage = [&](int st, const bool spread) {
         const unsigned char* sb = smem + st * kStage;
-        bf16x8 a[2][2], b[2][NT];
+        bf16x8 a[NS][2], b[NS][NT];
         auto fetch = [&](int kk, int set) {
 #ifdef LP_PIPE_EXP_NOLDSREAD   // (timing experiment, wrong results: fragments are read once per K step instead of once per k-slice)
             if (kk != 0) {
-                a[set][0] = a[set ^ 1][0], a[set][1] = a[set ^ 1][1];
+                a[set][0] = a[0][0], a[set][1] = a[0][1];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b[set][nt] = b[set ^ 1][nt];
+                for (int nt = 0; nt < NT; ++nt) b[set][nt] = b[0][nt];
                 return;
             }
 #endif
@@ -260,42 +261,29 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             for (int nt = 0; nt < NT; ++nt)
                 b[set][nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + b_row + nt * (32 * kPRowB) + koff[kk]));
         };
-        fetch(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NS - 1; ++kk) fetch(kk, kk);
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
-            if (kk + 1 < kBK / 16) fetch(kk + 1, (kk + 1) & 1);
+            if (kk + NS - 1 < kBK / 16) fetch(kk + NS - 1, (kk + NS - 1) % NS);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)   // roles swapped: D[channel][pixel]
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk & 1][nt], a[kk & 1][mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk % NS][nt], a[kk % NS][mt], acc[mt][nt], 0, 0, 0);
             if (spread) {
                 constexpr int NL = 4 + NBL;
-                if (!late) {
-                    if (kk == 0) {
-                        issue_load(0);
-                        issue_load(1);
-                    } else if (kk == 1) {
-                        issue_load(2);
-                        if (NL == 6) issue_load(3);
-                    } else if (kk == 2) {
-                        issue_load(NL == 6 ? 4 : 3);
-                    } else {
-                        issue_load(NL - 1);
-                    }
+                if (kk == 0) {
+                    issue_load(0);
+                    issue_load(1);
+                } else if (kk == 1) {
+                    issue_load(2);
+                    if (NL == 6) issue_load(3);
+                } else if (kk == 2) {
+                    issue_load(NL == 6 ? 4 : 3);
                 } else {
-                    if (kk == 1) {
-                        prep_step(nxt);
-                    } else if (kk == 2) {
-                        issue_load(0);
-                        issue_load(1);
-                        issue_load(2);
-                    } else if (kk == 3) {
-                        issue_load(3);
-                        issue_load(4);
-                        if (NL == 6) issue_load(5);
-                    }
+                    issue_load(NL - 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -530,16 +518,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             if (!kFwd && kt == KT - 1) rb_issue(rb0, 0, m0, n0);   // the first chunk's read-backs travel under the last K step
             const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
             if (kSpread) {
-                if (kStagger && MODE == kModeFwd && wn == 1) {   // (wave-uniform; the data-gradient instantiations have no registers to spare for a second loop body)
-                    mma_stage(cur, true, true, nxt);
-                } else {
-                    prep_step(nxt);
-                    mma_stage(cur, true, false, nxt);
-                }
+                prep_step(nxt);
+                mma_stage(cur, true);
                 advance_tile();
             } else {
                 load_step(nxt);
-                mma_stage(cur, false, false, nxt);
+                mma_stage(cur, false);
             }
             cur = cur == 2 ? 0 : cur + 1;
         }

@@ -590,9 +590,19 @@ static int decode_bwd_threads(int h, int TY) {
 // LP_DECODE_PRUNE=1 selects the pruning instantiations (read per call: tests and profiles/decode_microbench.py A/B it).  Opt-in: on the
 // FLAT maps of an untrained network nothing can be skipped and the pruning state costs one resident workgroup per CU (fwd 94 vs 71 VGPRs),
 // on the PEAKED maps of a trained one it skips most of the work - see DESIGN.md section 4.2 for the measured numbers
+// Exact pruning of the T = 1000 soft-argmax (kernels above): pays on the peaked maps of a trained head (forward 1.4x, backward 1.8x),
+// costs on flat ones.  The host decides: lp_decode_set_prune(0 / 1) - the product's default is automatic (ops.py watches the decode's own
+// sum-of-exponentials output, a direct measure of how many pixels carry weight) - or, while nothing was set, LP_DECODE_PRUNE=1.
+static int g_decode_prune = -1;
 static int decode_prune() {
+    if (g_decode_prune >= 0) return g_decode_prune;
     const char* e = getenv("LP_DECODE_PRUNE");
-    return e != nullptr && atoi(e) != 0;
+    return e != nullptr && atoi(e) == 1;
+}
+
+extern "C" int lp_decode_set_prune(int mode) {
+    g_decode_prune = mode < 0 ? -1 : (mode != 0);
+    return LP_OK;
 }
 
 template <typename Kern>

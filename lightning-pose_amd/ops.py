@@ -8,6 +8,7 @@ device, otherwise ``LpHipUnavailable`` is raised.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import functools
 
 import numpy as np
@@ -129,6 +130,60 @@ class DecodeFrameMap:
                 self.struct.bbox = self._bbox.data_ptr()
 
 
+class _DecodePruneAuto:
+    """Chooses between the plain and the exactly-pruned decode kernels (lp_decode_set_prune) from what the decode itself reports.
+
+    stats[..., 1] of lp_decode_fwd is sum exp(T (y - max y)) over the up-sampled map = the number of pixels that carry weight in the
+    soft-argmax: ~2 - 10 on the peaked maps of a trained head (T = 1000), ~all 147 456 on the flat maps of an untrained one.  Pruning pays
+    (forward 1.4x, backward 1.8x, profiles/r02k_decode_microbench.jsonl) when most maps are peaked and costs when they are flat, and which
+    regime a run is in changes once, early in training.  So every PERIOD-th call (and the FIRST-th) the fraction of peaked maps is reduced
+    on the device and copied to pinned host memory WITHOUT a synchronisation; a later call picks the value up once its event has
+    completed and flips the switch if needed.  LP_DECODE_PRUNE=0 / 1 pins the choice instead (read per call)."""
+
+    PERIOD, FIRST, PEAKED_FRACTION_OF_PIXELS, PEAKED_MAPS = 32, 2, 0.01, 0.5
+
+    def __init__(self) -> None:
+        self.calls, self.pending, self.state = 0, None, -2   # state: what lp_decode_set_prune was last given (-2: nothing yet)
+
+    def _set(self, mode: int) -> None:
+        if mode != self.state:
+            _lib.lib().lp_decode_set_prune(mode)
+            self.state = mode
+
+    def before(self) -> None:
+        env = os.environ.get("LP_DECODE_PRUNE", "auto")
+        if env != "auto":          # pinned by the environment: the library follows it
+            self._set(-1)
+            self.pending = None
+            return
+        if self.state in (-2, -1):
+            self._set(0)
+        if self.pending is not None:
+            host, ev = self.pending
+            if ev is None or ev.query():
+                self._set(1 if float(host[0]) >= self.PEAKED_MAPS else 0)
+                self.pending = None
+
+    def after(self, stats: torch.Tensor, n_up: int) -> None:
+        if os.environ.get("LP_DECODE_PRUNE", "auto") != "auto":
+            return
+        self.calls += 1
+        if self.pending is not None or not (self.calls == self.FIRST or self.calls % self.PERIOD == 0):
+            return
+        frac = (stats[..., 1] < self.PEAKED_FRACTION_OF_PIXELS * n_up).float().mean().reshape(1)
+        if stats.device.type == "cuda":
+            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(frac, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending = (host, ev)
+        else:
+            self.pending = (frac.detach().clone(), None)
+
+
+_decode_prune_auto = _DecodePruneAuto()
+
+
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, heat, ds, temperature, frame_map):
@@ -142,9 +197,11 @@ class _DecodeFn(torch.autograd.Function):
         kp_frame = torch.empty_like(kp_aug)
         conf = torch.empty(b, k, device=heat.device, dtype=torch.float32)
         stats = torch.empty(b, k, 4, device=heat.device, dtype=torch.float32)
+        _decode_prune_auto.before()
         check(_lib.lib().lp_decode_fwd(_p(heat), b, k, h, w, ds, float(temperature), C.byref(tables),
                                        C.byref(frame_map.struct), _p(kp_aug), _p(kp_frame), _p(conf), _p(stats), _stream()),
               "lp_decode_fwd")
+        _decode_prune_auto.after(stats, h * w * (4 ** int(ds)))
         ctx.save_for_backward(heat, stats)
         ctx.args = (ds, float(temperature), frame_map, tables, keep)
         ctx.mark_non_differentiable(conf)

@@ -124,6 +124,7 @@ def test_exact_pruning_changes_nothing(kernel_backend, monkeypatch, ds, h, w):
     x[1, 2, h - 1, w // 2] = 0.2
     hm = x.numpy()
     res = {}
+    emu.lib().lp_decode_set_prune(-1)      # follow the environment (an earlier ops.decode in this process may have pinned the choice)
     for flag in ("0", "1"):
         monkeypatch.setenv("LP_DECODE_PRUNE", flag)
         kp_aug, kp_frame, conf, stats = emu.decode_fwd(hm, ds)
@@ -138,3 +139,38 @@ def test_exact_pruning_changes_nothing(kernel_backend, monkeypatch, ds, h, w):
     want_kp, want_conf = O.soft_argmax(torch.from_numpy(hm), ds, 1000.0)
     np.testing.assert_allclose(res["1"][0].reshape(2, -1), want_kp.numpy(), atol=2e-4)
     np.testing.assert_allclose(res["1"][1], want_conf.numpy(), atol=2e-5)
+
+
+def test_decode_pruning_is_chosen_from_the_maps(stack_backend, monkeypatch):
+    """ops.decode watches its own sum-of-exponentials output and switches to the pruned kernels once most maps are peaked (and back on flat
+    maps); LP_DECODE_PRUNE=0 / 1 pins the choice.  Keypoints do not depend on which kernels ran."""
+    from lightning_pose_amd import ops
+
+    dev = stack_backend
+    monkeypatch.delenv("LP_DECODE_PRUNE", raising=False)
+    auto = ops._decode_prune_auto
+    auto.calls, auto.pending = 0, None
+    gen = torch.Generator().manual_seed(3)
+    peaked = _peaked(gen, 2, 4, 24, 24).to(dev)
+    flat = torch.softmax(torch.randn(2, 4, 24 * 24, generator=gen) * 0.1, -1).reshape(2, 4, 24, 24).to(dev)
+    fm = ops.DecodeFrameMap(None, False, None, 1, 96, 96, 4)
+    first = ops.decode(peaked, 2, 1000.0, fm)[0].clone()
+    assert auto.state == 0                                  # nothing observed yet: the plain kernels
+    for _ in range(3):
+        out = ops.decode(peaked, 2, 1000.0, fm)[0]
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+    assert auto.state == 1                                  # observed at the 2nd call, picked up by a later one
+    torch.testing.assert_close(out, first, atol=2e-5, rtol=0)
+    auto.calls = auto.PERIOD - 1
+    for _ in range(3):
+        ops.decode(flat, 2, 1000.0, fm)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+    assert auto.state == 0
+    monkeypatch.setenv("LP_DECODE_PRUNE", "1")
+    ops.decode(flat, 2, 1000.0, fm)
+    assert auto.state == -1                                 # the library follows the environment
+    monkeypatch.delenv("LP_DECODE_PRUNE")
+    emu.lib().lp_decode_set_prune(-1)
+    auto.state = -2
