@@ -178,6 +178,7 @@ typedef struct lp_conv_geom {
 #define LP_CONV_KERNEL_PIPE 1
 #define LP_CONV_KERNEL_WGRAD 2
 #define LP_CONV_KERNEL_WGRAD_PIPE 3
+#define LP_CONV_KERNEL_PIPE_HALO 4 /* conv_pipe_kernel<..., HALO>: 3x3 / stride 1, the input neighbourhood staged once (LP_CONV_HALO=0 disables) */
 int lp_conv_last_kernel(void);
 
 /* w: bf16 [Co][R][S][Ci] (Ci % 64 == 0).  Output row-major [B*Ho*Wo][ldo], columns < n_store written. */
@@ -317,6 +318,23 @@ int lp_f32_images_to_nhwc4(const float* images, int B, int H, int W, float* out,
 int lp_f32_pixel_shuffle(const float* in, int B, int h, int w, int c_out, int ld, int inverse, float* out, lp_stream_t stream);
 int lp_f32_softmax2d_bwd(const float* prob, const float* gprob, int B, int K, int n, float* gin, long stride_b, long stride_i, long stride_k,
                          lp_stream_t stream);
+/* fp32 forms of the ViT-S/16 glue (csrc/vit_f32.hip) - patch rows, token assembly, LayerNorm (+ residual add in front, [CLS] rows dropped
+ * with drop_T), exact GELU - and of the attention over the fused qkv tensor (head dimension 64; p [B][nh][T][T] keeps the probabilities,
+ * ds_workspace the same size): config C4 (lightning_pose/models/backbones/vit.py:16-49 over HuggingFace ViTModel) at the reference's own
+ * precision.  The Linear layers of that path are lp_f32_conv_fwd / _dgrad / _wgrad with a 1x1 geometry. */
+int lp_f32_vit_patchify(const float* images, int B, int H, int W, int patch, float* out, lp_stream_t stream);
+int lp_f32_vit_tokens_fwd(const float* patch, const float* cls, const float* pos, int B, int Np, int D, float* x, lp_stream_t stream);
+int lp_f32_vit_tokens_bwd(const float* dx, int B, int Np, int D, float* dpatch, float* dpos, lp_stream_t stream);
+int lp_f32_layernorm_fwd(const float* x, const float* delta, float* x_out, const float* gamma, const float* beta, float eps, int M, int D,
+                         int drop_T, float* y, float* mean, float* rstd, lp_stream_t stream);
+int lp_f32_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D, int drop_T,
+                         float* dx_acc, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
+int lp_f32_gelu_fwd(const float* x, size_t n, float* y, lp_stream_t stream);
+int lp_f32_gelu_bwd(const float* x, const float* dy, size_t n, float* dx, lp_stream_t stream);
+int lp_f32_attn_fwd(const float* qkv, int ld, int k_off, int v_off, int B, int nh, int T, float scale, float* p, float* o, int ldo,
+                    lp_stream_t stream);
+int lp_f32_attn_bwd(const float* qkv, int ld, int k_off, int v_off, const float* dout, int ldo, const float* p, int B, int nh, int T,
+                    float scale, float* ds_workspace, float* dqkv, int ldd, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * HBM-bound glue of the trunk (NHWC bf16): BatchNorm2d training mode, ReLU, residual add, MaxPool2d(3,2,1),

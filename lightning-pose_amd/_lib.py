@@ -52,7 +52,7 @@ class GemmBatch(C.Structure):
 
 
 HM_MSE, HM_KL, HM_JS = 0, 1, 2
-CONV_KERNEL_IGEMM, CONV_KERNEL_PIPE, CONV_KERNEL_WGRAD, CONV_KERNEL_WGRAD_PIPE = 0, 1, 2, 3   # lp_conv_last_kernel()
+CONV_KERNEL_IGEMM, CONV_KERNEL_PIPE, CONV_KERNEL_WGRAD, CONV_KERNEL_WGRAD_PIPE, CONV_KERNEL_PIPE_HALO = 0, 1, 2, 3, 4   # lp_conv_last_kernel()
 BORDER_RENORM, BORDER_CLAMP = 0, 1
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
@@ -146,6 +146,15 @@ PROTOTYPES = {
     "lp_f32_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
     "lp_f32_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "lp_f32_softmax2d_bwd": (_I, [_P, _P, _I, _I, _I, _P, _L, _L, _L, _P]),
+    "lp_f32_vit_patchify": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "lp_f32_vit_tokens_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "lp_f32_vit_tokens_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "lp_f32_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P]),
+    "lp_f32_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "lp_f32_gelu_fwd": (_I, [_P, _Z, _P, _P]),
+    "lp_f32_gelu_bwd": (_I, [_P, _P, _Z, _P, _P]),
+    "lp_f32_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
+    "lp_f32_attn_bwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P]),
     "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
     "lp_adam_step_dev": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _F, _P, _P]),
     "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),

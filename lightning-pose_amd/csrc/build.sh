@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 ROCM=${ROCM_PATH:-/opt/rocm}
-SRCS=(api.hip decode.hip heatmap.hip kploss.hip conv.hip bn.hip optim.hip vit.hip attn.hip frames.hip fp32.hip)
+SRCS=(api.hip decode.hip heatmap.hip kploss.hip conv.hip bn.hip optim.hip vit.hip attn.hip frames.hip fp32.hip vit_f32.hip)
 mode=${1:-hip}
 if [ "$mode" = emu ]; then
   out=../../tests/hipemu

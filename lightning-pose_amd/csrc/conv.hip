@@ -1129,11 +1129,12 @@ static int pipe_max_wgs() {
     return cus;
 }
 
-// what the pipelined kernel covers: dense bf16 output of a trunk convolution (no bias, no fp32 copy), K a multiple of 64 and > 0, N a
+// what the pipelined kernel covers: dense bf16 output of a trunk convolution (no fp32 copy; a bias only in the forward store pass, which
+// the Linear layers of lp_gemm_nt use), K a multiple of 64 and > 0, N a
 // multiple of its column block, fused BatchNorm sums on the atomic path only, and a BatchNorm segment boundary that falls on a 256-row tile
-static bool pipe_eligible(const ConvEpilogue& ep, int M, int N, int K, int ck, long long seg_rows) {
+static bool pipe_eligible(const ConvEpilogue& ep, int M, int N, int K, int ck, long long seg_rows, bool bias_ok = false) {
     if (!conv_pipe_enabled()) return false;
-    if (ep.out_bf16 == nullptr || ep.out_f32 != nullptr || ep.bias != nullptr || ep.ldo != N || ep.n_store != N) return false;
+    if (ep.out_bf16 == nullptr || ep.out_f32 != nullptr || (ep.bias != nullptr && !bias_ok) || ep.ldo != N || ep.n_store != N) return false;
     if (K <= 0 || ck % kBK != 0 || N % (N > 64 ? 128 : 64) != 0 || M <= 0) return false;
     if (ep.stats != nullptr && ep.stats_sums == nullptr) return false;   // (the bit-reproducible workspace path stays on conv_igemm_kernel)
     if (ep.seg_images > 0 && seg_rows % kPM != 0) return false;
@@ -1151,7 +1152,33 @@ static int pipe_dgrad_kind(const ConvEpilogue& ep) {
     return (ep.relu_bits == nullptr && ep.stats == nullptr) ? kEkPlain : -1;
 }
 
-template <int BN, int MODE, int EK>
+// HALO form (conv_pipe.h): 3x3 / stride 1 / pad 1 with the tile's input neighbourhood staged once per 64-channel slice.  Eligible when the
+// neighbourhood of every 256-pixel tile (in padded raster coordinates) fits the kernel's halo image: `cap_rows` = 512 (BN = 64) or 384.
+// LP_CONV_HALO=0 keeps those layers on the per-tap ring (A/B runs, bit-identity tests); read per call.
+static bool pipe_halo_ok(const ConvGeom& g, int M, int ck, int cap_rows) {
+    const char* e = getenv("LP_CONV_HALO");
+    if (e != nullptr && atoi(e) == 0) return false;
+    if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || g.Hi != g.Ho || g.Wi != g.Wo || ck % kBK != 0) return false;
+    struct Memo { int B, H, W, cap; bool ok; };
+    static thread_local Memo memo[8];
+    static thread_local int memo_n = 0;
+    for (int i = 0; i < memo_n; ++i)
+        if (memo[i].B == g.B && memo[i].H == g.Hi && memo[i].W == g.Wi && memo[i].cap == cap_rows) return memo[i].ok;
+    const long long W = g.Wi, H = g.Hi, Wp = W + 2;
+    auto padded = [&](long long m) {
+        const long long r = m / W, b = r / H;
+        return (r + 1 + 2 * b) * Wp + (m - r * W) + 1;
+    };
+    bool ok = true;
+    for (long long m0 = 0; m0 < M && ok; m0 += kPM) {
+        const long long last = m0 + kPM - 1 < M ? m0 + kPM - 1 : M - 1;
+        ok = padded(last) - padded(m0) + 2 * (W + 3) + 1 <= cap_rows;
+    }
+    if (memo_n < 8) memo[memo_n++] = Memo{g.B, g.Hi, g.Wi, cap_rows, ok};
+    return ok;
+}
+
+template <int BN, int MODE, int EK, bool HALO = false>
 static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
                         hipStream_t st) {
     const int tm = (M + kPM - 1) / kPM, tn = N / BN, ntiles = tm * tn;
@@ -1161,15 +1188,17 @@ static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const L
     const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * ck);
     const char* fe = getenv("LP_PIPE_FLAGS");   // experiment switch: 2 = non-temporal output stores
     const int flags = fe ? atoi(fe) : 0;
-    g_last_conv_kernel = LP_CONV_KERNEL_PIPE;
-    hipLaunchKernelGGL((conv_pipe_kernel<BN, MODE, EK>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes,
-                       w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, flags);
+    g_last_conv_kernel = HALO ? LP_CONV_KERNEL_PIPE_HALO : LP_CONV_KERNEL_PIPE;
+    const HaloDivs hd{make_fastdiv(g.Hi), make_fastdiv(g.Wi + 2), make_fastdiv(g.Hi + 2)};
+    hipLaunchKernelGGL((conv_pipe_kernel<BN, MODE, EK, HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w,
+                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, flags, hd);
 }
 
 template <int BN>
 static void launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
                               const ConvEpilogue& ep, hipStream_t st) {
-    if (kind == kEkZ) launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
+    if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
+    else if (kind == kEkZ) launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
     else if (kind == kEkAZB) launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
     else launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
 }
@@ -1326,9 +1355,15 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (pipe_eligible(ep, M, N, K, g.Ci, split)) {
-        if (N > 64) launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
-        else launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+    if (pipe_eligible(ep, M, N, K, g.Ci, split, true)) {
+        if (N > 64) {
+            if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+        } else if (pipe_halo_ok(g, M, g.Ci, 512)) {
+            launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+        } else {
+            launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+        }
     } else if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     if (bn && ep.stats_sums == nullptr) {
@@ -1403,6 +1438,13 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
     hipStream_t st = (hipStream_t)stream;
     const int nstore = ep.n_store;
+    // a dense, unbatched product (every Linear layer of the ViT, forward and data gradient) is a 1x1 convolution: the pipelined kernel
+    const char* gpe = getenv("LP_GEMM_PIPE");   // (A/B: 0 keeps the Linear layers on conv_igemm_kernel; read per call)
+    if ((gpe == nullptr || atoi(gpe) != 0) && nb * nh == 1 && lda == K && ldb == K && ldc == N && pipe_eligible(ep, M, N, K, K, M, true)) {
+        if (N > 64) launch_pipe<128, kModeFwd, kEkNone>(a, b, g, lat, M, N, K, ep, st);
+        else launch_pipe<64, kModeFwd, kEkNone>(a, b, g, lat, M, N, K, ep, st);
+        return launch_status();
+    }
     if (nstore > 64) launch_igemm<128, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
     else launch_igemm<64, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
     return launch_status();

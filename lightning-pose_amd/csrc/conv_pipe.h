@@ -79,15 +79,32 @@ __device__ __forceinline__ void store8(unsigned short* p, u16x8 v, bool stream) 
 //            block of a layer, whose input gradient has two writers)
 enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3 };
 
-template <int BN, int MODE, int EK>
+// HALO (3x3, stride 1, pad 1 - conv2 of every identity-stride block, forward and data gradient): the pixel operand is not fetched per
+// filter tap.  The ring above re-reads every activation row 9 times from L2 (once per tap: 27.7 us per tap on layer1's 64-channel layers,
+// DESIGN.md section 10.6); here a tile's input neighbourhood - its 256 pixels plus one image row and one pixel either side, in PADDED
+// raster coordinates P = ((b (H + 2) + y + 1) (W + 2) + x + 1), so that the zero border is part of the image and a tap is a constant row
+// offset - is staged ONCE per 64-channel slice ("halo image", kHaloRows x 128 B, two of them: the next slice / the next tile's first slice
+// loads while this one is consumed) and the 9 taps read it at row offsets (r - 1) (W + 2) + (s - 1).  Only the weights still ride the
+// 3-stage ring (BN x 128 B per K step).  The K loop runs slice-major (all 9 taps of a channel slice, then the next slice): for more than
+// 64 channels the fp32 accumulation order differs from conv_igemm_kernel's tap-major order (outputs agree to fp32 reassociation, not
+// bit for bit; with 64 channels they are bit-identical).
+struct HaloDivs {
+    FastDiv h, wp, hp;   // image height, padded width W + 2, padded height H + 2
+};
+
+template <int BN, int MODE, int EK, bool HALO = false>
 __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
-                                                        FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep, int flags) {
+                                                        FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep, int flags,
+                                                        HaloDivs hd) {
     static_assert((MODE == kModeFwd && EK == kEkNone) || (MODE == kModeDgrad && EK != kEkNone), "trunk convolutions only");
     constexpr int NT = BN / 64;                  // 32-channel MFMA blocks per wave along N (wave tile 64 pixels x NT*32 channels)
     constexpr int NBL = BN / 64;                 // weight rows each thread stages per K step
-    constexpr int kStageA = kPM * kPRowB, kStageB = BN * kPRowB, kStage = kStageA + kStageB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kStage];
+    constexpr int kStageA = HALO ? 0 : kPM * kPRowB, kStageB = BN * kPRowB, kStage = kStageA + kStageB;
+    constexpr int kHaloRows = BN == 64 ? 512 : 384;   // rows of a halo image (host-checked against the geometry: pipe_halo_rows)
+    constexpr int kHaloB = kHaloRows * kPRowB, NA = kHaloRows / 64;   // bytes; direct-to-LDS loads per thread and halo image
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kStage + (HALO ? 2 * kHaloB : 0)];
+    unsigned char* const halo0 = smem + 3 * kStage;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         const int tm_ = tile / tiles_n;
         const int m0 = tm_ * kPM, n0 = (tile - tm_ * tiles_n) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < (HALO ? 0 : 4); ++i) {   // (HALO: the pixel operand comes from the halo image, halo_setup below)
             const int m = m0 + lrow + 64 * i;
             const bool pv = m < M;
             const int mm = pv ? m : 0;
@@ -175,6 +192,15 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     unsigned is_soff_a = 0, is_soff_b = 0, is_w[NBL];
     unsigned char* is_dst = smem;
     auto prep_step = [&](int st) {
+        if (HALO) {      // slice-major K order: tir = tap (0 .. 8), tc = first channel of the slice; only the weights are fetched per step
+            const int tr = tir / 3, ts = tir - tr * 3;
+            is_soff_b = (unsigned)(((tr * g.S + ts) * ck + tc) * 2);
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) is_w[i] = wrow[i];
+            is_dst = smem + st * kStage + wave * (8 * kPRowB);
+            if (++tir == 9) tir = 0, tc += kBK;
+            return;
+        }
         if (tc == 0) {   // entering a filter tap: its per-row offsets (an invalid tap gets ~0 -> the range check returns zeros)
             const int tr = lat.r0 + lat.rstep * tir, ts = lat.s0 + lat.sstep * tis;
             const int qr = halved ? (tr >> 1) : tr, qs = halved ? (ts >> 1) : ts;
@@ -205,7 +231,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #ifdef LP_PIPE_EXP_NOLOAD   // (timing experiment, wrong results: how fast is the MFMA + LDS-read loop alone?)
         if (M < 0)
 #endif
-        if (i < 4) buf_load16_lds(rsrc_x, is_dst + i * (64 * kPRowB), voff[i], is_soff_a);
+        if (HALO) buf_load16_lds(rsrc_w, is_dst + (i % NBL) * (64 * kPRowB), is_w[i % NBL], is_soff_b);
+        else if (i < 4) buf_load16_lds(rsrc_x, is_dst + i * (64 * kPRowB), voff[i], is_soff_a);
         else buf_load16_lds(rsrc_w, is_dst + kStageA + (i - 4) * (64 * kPRowB), is_w[i - 4], is_soff_b);
     };
     auto advance_tile = [&]() {      // after the step's last load has been issued: the loader may cross into the next tile of the walk
@@ -218,8 +245,51 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     auto load_step = [&](int st) {
         prep_step(st);
 #pragma unroll
-        for (int i = 0; i < 4 + NBL; ++i) issue_load(i);
+        for (int i = 0; i < (HALO ? NBL : 4 + NBL); ++i) issue_load(i);
         advance_tile();
+    };
+
+    // ---- HALO loader: one halo image (a tile's padded-raster neighbourhood x one 64-channel slice) ahead of the MFMAs
+    const int hW = g.Wi, hH = g.Hi, hWp = g.Wi + 2, hHp = g.Hi + 2;   // (stride 1, "same": input and output grids coincide)
+    unsigned hvoff[HALO ? NA : 1];
+    int hl_vt = blockIdx.x, hl_slice = 0, hl_buf = 0;
+    auto padded = [&](int m) {   // padded raster coordinate of pixel row m
+        const int rm = fdiv(m, div_row), bm = fdiv(rm, hd.h);
+        return (rm + 1 + 2 * bm) * hWp + (m - rm * hW) + 1;
+    };
+    auto halo_setup = [&](int vt) {
+        if (vt >= ntiles) {
+#pragma unroll
+            for (int i = 0; i < (HALO ? NA : 0); ++i) hvoff[i] = ~0u;
+            return;
+        }
+        const int tile = xcd_remap(vt, ntiles);
+        const int pbase = padded((tile / tiles_n) * kPM) - (hW + 3);
+#pragma unroll
+        for (int i = 0; i < (HALO ? NA : 0); ++i) {
+            const int j = i * 64 + lrow, pp = pbase + j, pc = pp < 0 ? 0 : pp;
+            const int rr = fdiv(pc, hd.wp), xx = pc - rr * hWp;
+            const int bb = fdiv(rr, hd.hp), yy = rr - bb * hHp;
+            const bool ok = pp >= 0 && xx >= 1 && xx <= hW && yy >= 1 && yy <= hH && bb < g.B;
+            const int chunk = slot ^ ((j >> 1) & 7);
+            hvoff[i] = ok ? (unsigned)((((bb * hH + yy - 1) * hW + xx - 1) * ck + chunk * 8) * 2) : ~0u;   // border / beyond the batch: zeros
+        }
+    };
+    auto halo_issue = [&](int i) {   // (i is a compile-time constant at every call site)
+#ifdef LP_PIPE_EXP_NOLOAD
+        if (M < 0)
+#endif
+        buf_load16_lds(rsrc_x, halo0 + hl_buf * kHaloB + i * (64 * kPRowB) + wave * (8 * kPRowB), hvoff[HALO ? i : 0], (unsigned)(hl_slice * (kBK * 2)));
+    };
+    auto halo_advance = [&]() {      // the next slice of the tile, or the first slice of the workgroup's next tile
+        hl_buf ^= 1;
+        if ((hl_slice + 1) * kBK >= ck) {
+            hl_slice = 0;
+            hl_vt += gridDim.x;
+            halo_setup(hl_vt);
+        } else {
+            ++hl_slice;
+        }
     };
 
     // ---- MFMA side: fragment addresses inside a stage (16-B chunk (2 kk + g) of row r sits at position chunk ^ ((r >> 1) & 7))
@@ -242,9 +312,26 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #define LP_PIPE_FRAG_SETS 2   // (3 = two slices ahead: measured equal within noise, profiles/r03n_fragsets.txt, at 16 more VGPRs)
 #endif
     constexpr int NS = (MODE == kModeFwd) ? LP_PIPE_FRAG_SETS : 2;
+    // HALO: rows of the tile's pixels inside the halo image (per tile), the halo image the MFMAs read, its tap, and whether the
+    // loader still has pieces of the next halo image to issue during this K step
+    int ploc[2] = {0, 0}, mh_buf = 0, mh_tap = 0;
     auto mma_stage = [&](int st, const bool spread) {
         const unsigned char* sb = smem + st * kStage;
         bf16x8 a[NS][2], b[NS][NT];
+        const unsigned char* ha[2] = {smem, smem};
+        unsigned hk[2][4] = {};
+        if (HALO) {   // tap (r, s) of the slice: a constant row offset in padded raster coordinates (the zero border is part of the image)
+            const int tr = mh_tap / 3, ts = mh_tap - tr * 3;
+            const int dp = (tr - 1) * hWp + (ts - 1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = ploc[mt] + (MODE == kModeDgrad ? -dp : dp);
+                const int sw = (row >> 1) & 7;
+                ha[mt] = halo0 + mh_buf * kHaloB + row * kPRowB;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) hk[mt][kk] = (unsigned)(((kk * 2 + fg) ^ sw) * 16);
+            }
+        }
         auto fetch = [&](int kk, int set) {
 #ifdef LP_PIPE_EXP_NOLDSREAD   // (timing experiment, wrong results: fragments are read once per K step instead of once per k-slice)
             if (kk != 0) {
@@ -255,8 +342,10 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             }
 #endif
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                a[set][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + a_row + mt * (32 * kPRowB) + koff[kk]));
+            for (int mt = 0; mt < 2; ++mt) {
+                if (HALO) a[set][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(ha[mt] + hk[mt][kk]));
+                else a[set][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + a_row + mt * (32 * kPRowB) + koff[kk]));
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 b[set][nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + b_row + nt * (32 * kPRowB) + koff[kk]));
@@ -272,7 +361,25 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)   // roles swapped: D[channel][pixel]
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kk % NS][nt], a[kk % NS][mt], acc[mt][nt], 0, 0, 0);
-            if (spread) {
+            if (spread && HALO) {   // one piece of the next halo image (taps 0 .. NA - 1 of a slice), then this step's weight rows
+                if (kk == 0) {
+                    switch (mh_tap) {   // (workgroup-uniform)
+                    case 0: halo_issue(0); break;
+                    case 1: halo_issue(1); break;
+                    case 2: halo_issue(2); break;
+                    case 3: halo_issue(3); break;
+                    case 4: halo_issue(4); break;
+                    case 5: halo_issue(5); break;
+                    case 6: if (NA > 6) halo_issue(NA > 6 ? 6 : 0); break;
+                    case 7: if (NA > 7) halo_issue(NA > 7 ? 7 : 0); break;
+                    default: break;
+                    }
+                } else if (kk == 1) {
+                    issue_load(0);
+                } else if (kk == 2) {
+                    if (NBL == 2) issue_load(1);
+                }
+            } else if (spread) {
                 constexpr int NL = 4 + NBL;
                 if (kk == 0) {
                     issue_load(0);
@@ -345,6 +452,18 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         const int nbase = n0 + wn * (NT * 32);   // first channel of this wave
         constexpr int ROWB = NT * 64 + 16;       // bf16 chunk row + pad (16-B aligned)
         unsigned char* stg = stg_all + wave * (32 * ROWB);
+        if (ep.bias != nullptr) {   // (workgroup-uniform; Linear layers through lp_gemm_nt - the trunk's convolutions carry no bias)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + nbase + nt * 32 + 8 * j + 4 * fg);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[mt][nt][4 * j + e] += bv[e];
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -476,19 +595,35 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     };
 
     // ---- the walk: loader two K steps ahead of the MFMAs, across tile boundaries; the ring never drains
+    if (HALO) {   // the first halo image, whole; the loader then stays one image ahead
+        halo_setup(hl_vt);
+#pragma unroll
+        for (int i = 0; i < (HALO ? NA : 0); ++i) halo_issue(i);
+        halo_advance();
+    }
     setup(ld_vt);
     load_step(0);
     load_step(1);
     int cur = 0;   // stage of the K step the MFMAs are about to consume
     ReadBack rb0, rb1;
+    // LDS nobody else touches between a tile's last K step and the next tile's first barrier: the stage (HALO: the halo image) consumed last
+    auto free_lds = [&]() -> unsigned char* { return HALO ? halo0 + (mh_buf ^ 1) * kHaloB : smem + (cur == 0 ? 2 : cur - 1) * kStage; };
     for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
         const int tile = xcd_remap(vt, ntiles);
         const int tm_ = tile / tiles_n;
         const int m0 = tm_ * kPM, n0 = (tile - tm_ * tiles_n) * BN;
         const int seg_off = (ep.seg_images > 0 && m0 >= ep.seg_images * rows_y * rows_x) ? N : 0;
+        if (HALO) {
+            const int pbase = padded(m0) - (hW + 3);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + wm * 64 + mt * 32 + fr;
+                ploc[mt] = padded(m < M ? m : M - 1) - pbase;   // (rows past M: any staged row, the result is not stored)
+            }
+        }
         if (n0 != st_n0 || seg_off != st_seg_off) {   // (workgroup-uniform) new column block / BatchNorm segment
             // the stage the previous tile consumed last is free until this tile's first K step has passed its barrier
-            if (want_stats) stats_flush(reinterpret_cast<float*>(smem + (cur == 0 ? 2 : cur - 1) * kStage));
+            if (want_stats) stats_flush(reinterpret_cast<float*>(free_lds()));
             st_n0 = n0;
             st_seg_off = seg_off;
             if (bwd) {
@@ -510,14 +645,21 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
         for (int kt = 0; kt < KT; ++kt) {
-            if (NBL == 2) LP_WAIT_VM(6);   // this wave's loads of the current step have landed; the next step's 4 + NBL stay in flight
+            // this wave's loads of the current step have landed; the next step's (4 + NBL; HALO: its NBL weight pieces - the halo piece
+            // issued before them is the oldest of that step and is waited for a step early, which costs nothing: it has 8 steps to land) stay in flight
+            // (Measured and dropped, profiles/r03p_vmcnt_layers.txt: right behind a tile boundary the needed loads are OLDER than the
+            // previous tile's output stores, so the count could leave those stores in flight instead of waiting for them to reach
+            // memory - every layer came out 0 - 7 % SLOWER, forward and data gradient: the wait paces the workgroups' store bursts.)
+            if (HALO && NBL == 2) LP_WAIT_VM(2);
+            else if (HALO) LP_WAIT_VM(1);
+            else if (NBL == 2) LP_WAIT_VM(6);
             else LP_WAIT_VM(5);
 #ifndef LP_PIPE_EXP_NOBARRIER   // (timing experiment, racy: what do the per-K-step barriers cost?)
             LP_RAW_BARRIER();              // ... everyone's have, and everyone is done reading the stage refilled next
 #endif
             if (!kFwd && kt == KT - 1) rb_issue(rb0, 0, m0, n0);   // the first chunk's read-backs travel under the last K step
             const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
-            if (kSpread) {
+            if (kSpread || HALO) {
                 prep_step(nxt);
                 mma_stage(cur, true);
                 advance_tile();
@@ -526,8 +668,13 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                 mma_stage(cur, false);
             }
             cur = cur == 2 ? 0 : cur + 1;
+            if (HALO && ++mh_tap == 9) {   // the slice is consumed: the MFMAs move to the other halo image, the loader to the one after it
+                mh_tap = 0;
+                mh_buf ^= 1;
+                halo_advance();
+            }
         }
-        unsigned char* stg_all = smem + (cur == 0 ? 2 : cur - 1) * kStage;   // the stage consumed last: free until the next K step's barrier
+        unsigned char* stg_all = free_lds();   // the stage consumed last: free until the next K step's barrier
         LP_RAW_BARRIER();                  // every wave is done reading its fragments
         if (kFwd) {
             epilogue_fwd(m0, n0, stg_all);
@@ -537,7 +684,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             rb_process(rb1, 1, stg_all);
         }
     }
-    if (want_stats) stats_flush(reinterpret_cast<float*>(smem + (cur == 0 ? 2 : cur - 1) * kStage));
+    if (want_stats) stats_flush(reinterpret_cast<float*>(free_lds()));
     LP_WAIT_VM(0);   // the ring's last (empty) loads still target this workgroup's LDS
 }
 

@@ -243,6 +243,8 @@ class Engine:
             k = self._lib.lp_conv_last_kernel()
             if k == _lib.CONV_KERNEL_PIPE:
                 tag = tag.replace("conv_igemm_kernel", "conv_pipe_kernel")
+            elif k == _lib.CONV_KERNEL_PIPE_HALO:
+                tag = tag.replace("conv_igemm_kernel", "conv_pipe_kernel").replace(">", ",halo>")
             elif k == _lib.CONV_KERNEL_WGRAD_PIPE:
                 tag = tag.replace("conv_wgrad_kernel", "conv_wgrad_pipe_kernel")
         self.profile.append((tag, flops, e0, e1, nbytes))

@@ -280,3 +280,4 @@ class Fp32Engine(Engine):
         check(self._lib.lp_f32_maxpool_bwd(_p(T["pool.arg"]), _p(d), B, sh, sw, 64, _p(da), ops._stream()), "lp_f32_maxpool_bwd")
         dz, _ = self._bn_back(plan.stem_bn, da, T["stem.a"], T["stem.z"], T["stem.mu"], T["stem.iv"], False, seg)
         self._wg(plan.stem, T["x4"], dz, self._geom(plan.stem, B, H, W))
+

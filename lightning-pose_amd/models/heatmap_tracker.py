@@ -72,8 +72,6 @@ class HeatmapTracker(BaseSupervisedTracker):
         # "bf16-mixed" (the product path) or "fp32" (validation against the fp32-only reference, train.py:411-428); LP_PRECISION overrides
         self.precision = {"32": "fp32", "32-true": "fp32", "fp32": "fp32"}.get(
             str(os.environ.get("LP_PRECISION") or kwargs.get("precision") or "bf16-mixed"), "bf16-mixed")
-        if self.precision == "fp32" and backbone in VIT_CONFIGS:
-            raise NotImplementedError("the fp32 validation path covers the ResNet-50 trunk; ViT backbones run bf16-mixed")
         self.head = HeatmapHead(backbone_arch=backbone, in_channels=self.num_fc_input_features, out_channels=num_keypoints,
                                 downsample_factor=downsample_factor)
         self.backbone = _Holder()
@@ -81,7 +79,10 @@ class HeatmapTracker(BaseSupervisedTracker):
         if backbone in VIT_CONFIGS:
             from ..vit_engine import ViTEngine
             hidden, depth, heads, mlp, patch, grid = VIT_CONFIGS[backbone]
-            self.net = ViTEngine(num_keypoints, downsample_factor, device, hidden=hidden, depth=depth, heads=heads, mlp=mlp, patch=patch,
+            engine_cls = ViTEngine
+            if self.precision == "fp32":  # validation mode (vit_engine_fp32.py)
+                from ..vit_engine_fp32 import Fp32ViTEngine as engine_cls
+            self.net = engine_cls(num_keypoints, downsample_factor, device, hidden=hidden, depth=depth, heads=heads, mlp=mlp, patch=patch,
                                  pretrain_grid=grid)
             init = vit_seeded_state_dict(hidden, depth, heads, mlp, patch, grid)
             init.update(head_state_dict(self.num_fc_input_features, num_keypoints, self.head.n_layers))

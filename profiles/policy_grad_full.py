@@ -30,9 +30,20 @@ for k in list(sd):
 for k in g.files:
     if k.startswith("head/"):
         sd["head." + k[len("head/"):]] = torch.from_numpy(g[k])
+dev = torch.device(os.environ.get("DEVICE", "cpu"))   # (the full-batch fixtures need ~80 GB of fp32 autograd state: DEVICE=cuda:0 on the GPU box)
 model = O.OracleTracker(K, 2, torch_seed=0)
 model.load_state_dict(sd, strict=True)
 model.train()
+model.to(dev)
+
+
+def _to(d):
+    return {k: (_to(v) if isinstance(v, dict) else v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+batch = _to(batch)
+if dev.type != "cpu":
+    torch.set_default_device(dev)   # the oracle's index grids / constants are created where the data lives
 
 
 class Policy:
@@ -44,7 +55,8 @@ class Policy:
 
 
 unsup = {"temporal": dict(TEMPORAL),
-         "pca_singleview": {"log_weight": PCA_LOG_WEIGHT, "mean": g["pca_mean"], "kept_eigenvectors": g["pca_kept"], "epsilon": float(g["pca_eps"]),
+         "pca_singleview": {"log_weight": PCA_LOG_WEIGHT, "mean": torch.from_numpy(g["pca_mean"]).to(dev),
+                            "kept_eigenvectors": torch.from_numpy(g["pca_kept"]).to(dev), "epsilon": float(g["pca_eps"]),
                             "columns": inp["cols"]}}
 loss, logs = O.training_step(Policy(), batch, unsup, 1.0)
 loss.backward()
@@ -53,7 +65,7 @@ out = {"config": name, "scalars_rel_vs_fp32": {}}
 for k, v in logs.items():
     if k in want and abs(float(want[k])) > 0 and "weight" not in k.replace("_weighted", ""):
         out["scalars_rel_vs_fp32"][k] = round(abs(float(v) / float(want[k]) - 1), 6)
-grads = {n_: p_.grad for n_, p_ in model.named_parameters() if p_.grad is not None}
+grads = {n_: p_.grad.float().cpu() for n_, p_ in model.named_parameters() if p_.grad is not None}
 for k in g.files:
     if k.startswith("grad/"):
         a, b = grads[k[len("grad/"):]].reshape(-1), torch.from_numpy(g[k]).reshape(-1)

@@ -32,6 +32,7 @@ def _both(monkeypatch, fn):
 @pytest.mark.parametrize("wgs", ["0", "1", "2"])
 @pytest.mark.parametrize("case", CASES)
 def test_pipe_equals_igemm(case, wgs, monkeypatch):
+    monkeypatch.setenv("LP_CONV_HALO", "0")   # the per-tap ring (the HALO form of the 3x3 layers has its own test below)
     if wgs != "0":
         monkeypatch.setenv("LP_CONV_MAX_WGS", wgs)
     B, Hi, Wi, Ci, Co, R, st, pad = case
@@ -127,3 +128,68 @@ def test_pipelined_weight_gradient(case, split, monkeypatch):
     assert emu.lib().lp_conv_last_kernel() == 3   # LP_CONV_KERNEL_WGRAD_PIPE
     torch.testing.assert_close(torch.from_numpy(new), want, atol=2e-3, rtol=2e-3)
     torch.testing.assert_close(torch.from_numpy(new), torch.from_numpy(old), atol=1e-3, rtol=1e-3)
+
+
+HALO_CASES = [
+    # B, Hi, Wi, Ci, Co   (3x3, stride 1, pad 1)
+    (3, 16, 16, 64, 64),      # one slice per tile, BN = 64, tiles = whole images (256 pixels)
+    (2, 16, 24, 64, 128),     # 384-pixel images: tiles start mid-row and cross images; BN = 128
+    (1, 19, 15, 128, 64),     # M = 285: a ragged second tile; two slices per tile (K order differs from conv_igemm_kernel's)
+    (4, 16, 8, 256, 128),     # 128-pixel images: every tile spans two images (a zero border between them); four slices
+    (2, 8, 32, 64, 256),      # wide rows, two column tiles (the halo image is staged once per column tile)
+]
+
+
+@pytest.mark.parametrize("wgs", ["0", "1", "3"])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_halo_form_equals_the_per_tap_ring(case, wgs, monkeypatch):
+    """conv_pipe_kernel<..., HALO> (the tile's padded-raster neighbourhood staged once per 64-channel slice, 9 taps read from it) against the
+    per-tap ring and conv_igemm_kernel: bit-identical with 64 channels (same K order), equal to fp32 reassociation otherwise; forward and
+    the data gradient with the fused BatchNorm-backward sums (the only store-pass form a 3x3 layer of the trunk uses)."""
+    if wgs != "0":
+        monkeypatch.setenv("LP_CONV_MAX_WGS", wgs)
+    B, Hi, Wi, Ci, Co = case
+    gen = torch.Generator().manual_seed(23 + sum(case))
+    g = emu.geom(B, Hi, Wi, Ci, Co, 3, 3, 1, 1)
+    x = emu.to_bf16_bits(torch.randn(B, Hi, Wi, Ci, generator=gen))
+    w = torch.randn(Co, 3, 3, Ci, generator=gen) / (Ci * 9) ** 0.5
+    wg, wd = emu.to_bf16_bits(w), emu.to_bf16_bits(w.permute(3, 1, 2, 0))
+
+    def both(fn):
+        monkeypatch.setenv("LP_CONV_HALO", "0")
+        ref = fn()
+        assert emu.lib().lp_conv_last_kernel() == 1      # LP_CONV_KERNEL_PIPE
+        monkeypatch.setenv("LP_CONV_HALO", "1")
+        out = fn()
+        assert emu.lib().lp_conv_last_kernel() == 4      # LP_CONV_KERNEL_PIPE_HALO
+        return ref, out
+
+    def same(a, b, exact):
+        if exact:
+            assert np.array_equal(a, b)
+        else:   # bf16 results of two fp32 summation orders: at most one unit in the last place, on a small fraction of the elements
+            fa, fb = emu.from_bf16_bits(a).float(), emu.from_bf16_bits(b).float()
+            torch.testing.assert_close(fb, fa, atol=2e-2, rtol=1e-2)
+            assert float((fa != fb).float().mean()) < 0.2
+
+    (z0, _), (z1, _) = both(lambda: emu.conv_fwd(x, wg, g))
+    same(z0, z1, Ci == 64)
+    (zb0, s0), (zb1, s1) = both(lambda: emu.conv_fwd_bn(x, wg, g))
+    assert np.array_equal(zb1, z1)
+    np.testing.assert_allclose(s1, s0, rtol=1e-3, atol=2e-2)
+    # forward against fp32 convolution of the same bf16 operands
+    import torch.nn.functional as F
+    xf = emu.from_bf16_bits(x).float().reshape(B, Hi, Wi, Ci).permute(0, 3, 1, 2)
+    wf = emu.from_bf16_bits(wg).float().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    want = F.conv2d(xf, wf, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    torch.testing.assert_close(emu.from_bf16_bits(z1).float().reshape(-1, Co), want, atol=2e-2, rtol=1e-2)
+    # data gradient: mask recomputed from z, BatchNorm-backward sums fused
+    Mi = B * Hi * Wi
+    zin_bits = emu.to_bf16_bits(torch.randn(Mi, Ci, generator=gen))
+    gamma, beta = torch.rand(Ci, generator=gen) + 0.5, torch.randn(Ci, generator=gen) * 0.3
+    _, mean, invstd, _ = emu.bn_forward(zin_bits, Mi, Ci, gamma.numpy(), beta.numpy(), relu=True, want_bits=True)
+    dy = emu.to_bf16_bits(torch.randn(Mi, Co, generator=gen))
+    r0, r1 = both(lambda: emu.conv_dgrad_bn(dy, wd, g, zin_bits, mean, invstd, gamma.numpy(), beta.numpy()))
+    same(r0[0], r1[0], Co == 64)
+    for a, b in zip(r0[1:], r1[1:]):
+        np.testing.assert_allclose(b, a, rtol=2e-3, atol=3e-2)

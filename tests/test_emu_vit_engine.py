@@ -44,9 +44,17 @@ def test_vit_engine_forward_backward_vs_hf(stack_backend, hidden, depth, heads, 
     check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp)
 
 
-def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp, batch=2, size=64):
+@pytest.mark.parametrize("batch,size", [(2, 64), (3, 96)])
+def test_fp32_vit_engine_vs_hf(stack_backend, batch, size):
+    """the fp32 VALIDATION executor (vit_engine_fp32.Fp32ViTEngine on csrc/vit_f32.hip + lp_f32_conv_*): the same comparison at fp32 bars"""
+    check_vit_engine_vs_hf(stack_backend, 128, 2, 2, 256, batch=batch, size=size, fp32=True)
+
+
+def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp, batch=2, size=64, fp32=False):
     """(ViT-B's width and 12 heads run this from tests/test_widen_vitb_width.py)"""
     from lightning_pose_amd.vit_engine import ViTEngine
+    if fp32:
+        from lightning_pose_amd.vit_engine_fp32 import Fp32ViTEngine as ViTEngine  # noqa: F811
 
     dev = stack_backend
     K, grid0 = 5, 3
@@ -66,7 +74,10 @@ def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp, batch=2, si
     want = _oracle_forward(vit, head, images)
     assert heat.shape == want.shape == (batch, K, size // 4, size // 4)
     # bf16 operands vs fp32; the 768-wide head sums 192 products per logit, its sharper soft-max doubles the relative error of a peak
-    torch.testing.assert_close(heat.cpu(), want.detach(), atol=2e-3, rtol=5e-2 if hidden == 128 else 1e-1)
+    if fp32:
+        torch.testing.assert_close(heat.cpu(), want.detach(), atol=1e-6, rtol=1e-4)
+    else:
+        torch.testing.assert_close(heat.cpu(), want.detach(), atol=2e-3, rtol=5e-2 if hidden == 128 else 1e-1)
 
     g = torch.randn(want.shape, generator=gen)
     (want * g).sum().backward()
@@ -80,11 +91,14 @@ def check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp, batch=2, si
         got = grads[k].cpu().reshape(gr.shape)
         if gr.norm() < 1e-5:
             # analytically zero (soft-max is invariant to the key bias and to the head's per-channel bias): only rounding noise
-            assert got.norm() < 5e-3, (k, got.norm().item())
+            assert got.norm() < (1e-5 if fp32 else 5e-3), (k, got.norm().item())
             continue
         cos = F.cosine_similarity(got.flatten(), gr.flatten(), dim=0).item()
         rel = ((got - gr).norm() / gr.norm()).item()
-        assert cos > 0.999 and rel < 0.03, (k, cos, rel)  # torch.autocast(bf16) of the same model: cos 0.9999, rel 0.010-0.015
+        if fp32:
+            assert rel < 1e-4, (k, cos, rel)
+        else:
+            assert cos > 0.999 and rel < 0.03, (k, cos, rel)  # torch.autocast(bf16) of the same model: cos 0.9999, rel 0.010-0.015
 
 
 @pytest.mark.parametrize("batch,size", [(3, 96), (1, 160)])

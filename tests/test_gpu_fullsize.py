@@ -177,6 +177,8 @@ def test_native_library_is_what_runs():
     (12, 4, 96, 256, 64, 1, 1, 0),      # layer1 conv1: data gradient with addend + 1-bit ReLU mask + previous block's BatchNorm sums
     (12, 4, 96, 64, 64, 3, 1, 1),       # layer1 conv2
     (32, 16, 24, 256, 256, 3, 1, 1),    # layer3 conv2: 36 K steps per tile
+    (32, 16, 48, 128, 128, 3, 1, 1),    # layer2 conv2 (HALO form: two slices per tile)
+    (32, 16, 12, 512, 512, 3, 1, 1),    # layer4 conv2 (HALO form: a tile spans up to three 144-pixel images; four column tiles)
     (32, 16, 48, 256, 256, 3, 2, 1),    # layer3.0 conv2, stride 2: four parity-class launches in the data gradient
     (32, 16, 24, 1024, 256, 1, 1, 0),   # layer3 conv1: 16 K steps
     (32, 16, 12, 512, 2048, 1, 1, 0),   # layer4 conv3: 16 column tiles
@@ -235,10 +237,28 @@ def test_pipelined_conv_equals_igemm_on_real_shapes(shape, monkeypatch):
     monkeypatch.setenv("LP_CONV_PIPE", "0")
     ref = run()
     monkeypatch.setenv("LP_CONV_PIPE", "1")
+    names = ("out", "fwd sums", "dx", "bwd sums", "dbeta", "dgamma", "dx (mask from z)", "bwd sums 2")
+    monkeypatch.setenv("LP_CONV_HALO", "0")   # the per-tap ring: same K order as conv_igemm_kernel
     for rep in range(3):
         got = run()
-        for name, a, b in zip(("out", "fwd sums", "dx", "bwd sums", "dbeta", "dgamma", "dx (mask from z)", "bwd sums 2"), ref, got):
+        for name, a, b in zip(names, ref, got):
             if a.dtype == torch.bfloat16:
                 assert torch.equal(a, b), (name, rep, int((a != b).sum()))
             else:
                 torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-3 * float(a.abs().max()) + 1e-3, msg=lambda m: f"{name} rep {rep}: {m}")
+    if k == 3 and st == 1:
+        # the HALO form (the tile's neighbourhood staged once per 64-channel slice, slice-major K order): bit-identical with 64 channels,
+        # equal to fp32 reassociation (one bf16 unit in the last place on a small fraction of the elements) with more
+        monkeypatch.setenv("LP_CONV_HALO", "1")
+        for rep in range(3):
+            got = run()
+            assert lib.lp_conv_last_kernel() == _lib.CONV_KERNEL_PIPE_HALO   # (the last launch: the mask-from-z data gradient)
+            for name, a, b in zip(names, ref, got):
+                if a.dtype == torch.bfloat16 and ((Ci == 64 and name == "out") or (Co == 64 and name == "dx (mask from z)") or name == "dx"):
+                    assert torch.equal(a, b), (name, rep, int((a != b).sum()))   # ("dx": the addend + bit-mask form stays on the ring)
+                elif a.dtype == torch.bfloat16:
+                    af, bf = a.float(), b.float()
+                    torch.testing.assert_close(bf, af, rtol=1e-2, atol=1e-2 * float(af.abs().max()), msg=lambda m: f"{name} rep {rep}: {m}")
+                    assert float((af != bf).float().mean()) < 0.2, (name, rep)
+                else:
+                    torch.testing.assert_close(b, a, rtol=2e-3, atol=2e-3 * float(a.abs().max()) + 1e-3, msg=lambda m: f"{name} rep {rep}: {m}")
