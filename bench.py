@@ -174,16 +174,28 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "re
 
 def pmc_traffic():
     """Average HBM bytes per convolution launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
-    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r02_pmc.sh -> profiles/r02_pmc_traffic.json
-    via profiles/summarize_pmc.py); None when no profile is committed.  The counters need rocprofv3 around the process, so this is the
-    committed measurement of the same workload, not a live one; ``algorithmic_bytes_per_launch`` next to it IS computed live."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                return round(json.load(fh)["conv_hbm_bytes_per_launch"]), name
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r03_pmc.sh -> profiles/r03_pmc_traffic.json
+    via profiles/summarize_pmc.py).  The counters need rocprofv3 around the process, so this is the committed measurement of the same
+    workload, not a live one (``algorithmic_bytes_per_launch`` next to it IS computed live) - and it is only reported when it was taken
+    on THESE kernels: the file records a digest of the convolution sources, and a file whose digest differs from the tree's is refused
+    (``traffic`` = null, ``traffic_source`` says why).  -> (bytes | None, source note)"""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for name in ("conv.hip", "conv_pipe.h", "lp_common.h"):   # (profiles/summarize_pmc.py: KERNEL_SOURCES)
+            with open(os.path.join(ROOT, "lightning-pose_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None, "kernel sources not found"
+    name = "r03_pmc_traffic.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            rec = json.load(fh)
+        if rec.get("kernels_sha256") != h.hexdigest():
+            return None, f"{name} refused: taken on other kernel sources (digest {str(rec.get('kernels_sha256'))[:12]} != {h.hexdigest()[:12]})"
+        return round(rec["conv_hbm_bytes_per_launch"]), name
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC traffic file committed for these kernels"
 
 
 def hbm_rooflines(dev, size: int, K: int, frames: int, reps: int = 10) -> dict:

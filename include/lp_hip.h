@@ -446,6 +446,11 @@ typedef struct lp_frame_augment {
  * [0,255] (input of lp_frames_augment); else dst = fp32 (S,3,H,W) = (v/255 - mean) / std (imgaug="default": no augmentation) */
 int lp_frames_resize(const void* src_u8, int S, int Hs, int Ws, long long frame_stride, int row_stride, int H, int W, int border,
                      const lp_frame_norm* finish_norm, float* dst, lp_stream_t stream);
+/* Same layouts, bicubic interpolation without antialiasing (Keys kernel, A = -0.75, half-pixel centres, taps clamped): imgaug
+ * iaa.Resize's default (OpenCV INTER_CUBIC), the last imgaug step of every LABELED image (data/datasets.py:137-143).  round_u8 != 0:
+ * the interpolated value is rounded and saturated to [0, 255] first - imgaug returns uint8 images. */
+int lp_frames_resize_cubic(const void* src_u8, int S, int Hs, int Ws, long long frame_stride, int row_stride, int H, int W, int round_u8,
+                           const lp_frame_norm* finish_norm, float* dst, lp_stream_t stream);
 /* src fp32 (S,H,W,3) in [0,255] -> dst fp32 (S,3,H,W); one parameter set per call = per DALI sample (a whole sequence) */
 int lp_frames_augment(const float* src_hwc, int S, int H, int W, const lp_frame_augment* aug, const lp_frame_norm* norm,
                       float* dst_nchw, lp_stream_t stream);

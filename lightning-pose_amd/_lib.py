@@ -132,6 +132,7 @@ PROTOTYPES = {
     "lp_softmax_rows_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "lp_transpose_batched": (_I, [_P, _I, _I, _I, C.c_longlong, C.c_longlong, _P, _I, C.c_longlong, C.c_longlong, _I, _I, _P]),
     "lp_frames_resize": (_I, [_P, _I, _I, _I, C.c_longlong, _I, _I, _I, _I, C.POINTER(FrameNorm), _P, _P]),
+    "lp_frames_resize_cubic": (_I, [_P, _I, _I, _I, C.c_longlong, _I, _I, _I, _I, C.POINTER(FrameNorm), _P, _P]),
     "lp_frames_augment": (_I, [_P, _I, _I, _I, C.POINTER(FrameAugment), C.POINTER(FrameNorm), _P, _P]),
     "lp_labeled_keypoints": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "lp_f32_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _P, _P]),

@@ -92,6 +92,64 @@ __global__ __launch_bounds__(256) void frames_resize_kernel(const unsigned char*
     }
 }
 
+// ---- bicubic resize without antialiasing (imgaug `iaa.Resize`'s default interpolation = OpenCV INTER_CUBIC: Keys kernel with
+// A = -0.75, half-pixel centres, the 4 x 4 taps clamped to the image; reference data/datasets.py:137-143 builds
+// `iaa.Resize({"height": ..., "width": ...})` as the last imgaug step of every labeled image).  imgaug hands back a uint8 image, so
+// the interpolated value is rounded and saturated to [0, 255] before the /255 + normalise of the dataset's ToTensor / Normalize.
+__device__ __forceinline__ void cubic_taps(float c, int& i0, float (&w)[4]) {
+    const float A = -0.75f;
+    const float f = c - 0.5f;
+    const float fl = floorf(f);
+    const float t = f - fl;
+    i0 = (int)fl - 1;
+    auto k1 = [&](float u) { return ((A + 2.f) * u - (A + 3.f)) * u * u + 1.f; };          // |u| <= 1
+    auto k2 = [&](float u) { return ((A * u - 5.f * A) * u + 8.f * A) * u - 4.f * A; };    // 1 < |u| < 2
+    w[0] = k2(t + 1.f);
+    w[1] = k1(t);
+    w[2] = k1(1.f - t);
+    w[3] = k2(2.f - t);
+}
+
+template <bool FINISH>
+__global__ __launch_bounds__(256) void frames_resize_cubic_kernel(const unsigned char* __restrict__ src, ResizeSpec p, NormSpec nrm,
+                                                                  int round_u8, float* __restrict__ dst) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), s = blockIdx.z;
+    if (x >= p.W || y >= p.H) return;
+    int x0, y0;
+    float wx[4], wy[4];
+    cubic_taps(((float)x + 0.5f) * p.scale_x, x0, wx);
+    cubic_taps(((float)y + 0.5f) * p.scale_y, y0, wy);
+    const unsigned char* frame = src + (size_t)s * p.frame_stride;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned char* row = frame + (size_t)clampi(y0 + j, 0, p.Hs - 1) * p.row_stride;
+        float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned char* px = row + clampi(x0 + i, 0, p.Ws - 1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = fmaf(wx[i], (float)px[c], r[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = fmaf(wy[j], r[c], acc[c]);
+    }
+    if (round_u8) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = fminf(fmaxf(floorf(acc[c] + 0.5f), 0.f), 255.f);
+    }
+    if (FINISH) {
+        const size_t plane = (size_t)p.H * p.W;
+        float* o = dst + (size_t)s * 3 * plane + (size_t)y * p.W + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c * plane] = (acc[c] * (1.f / 255.f) - nrm.mean[c]) * nrm.inv_std[c];
+    } else {
+        float* o = dst + (((size_t)s * p.H + y) * p.W + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = acc[c];
+    }
+}
+
 // ---- counter-based random numbers (Philox4x32-10): a pixel's stream depends only on (seed, frame, pixel) ---------------
 struct Philox {  // scalar members only: nothing here is indexed dynamically, so the state stays in registers
     unsigned c0, c1, c2, k0, k1, o0, o1, o2, o3;
@@ -281,6 +339,28 @@ extern "C" int lp_frames_resize(const void* src_u8, int S, int Hs, int Ws, long 
         hipLaunchKernelGGL(frames_resize_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8, p, nrm, dst);
     } else {
         hipLaunchKernelGGL(frames_resize_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8, p, nrm, dst);
+    }
+    return launch_status();
+}
+
+extern "C" int lp_frames_resize_cubic(const void* src_u8, int S, int Hs, int Ws, long long frame_stride, int row_stride, int H, int W,
+                                      int round_u8, const lp_frame_norm* finish_norm, float* dst, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(src_u8 && dst && S > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0);
+    LP_REQUIRE(row_stride >= Ws * 3 && frame_stride >= (long long)row_stride * Hs);
+    if (S > 65535 || (H + 3) / 4 > 65535) return LP_ERR_UNSUPPORTED;
+    ResizeSpec p{};
+    p.Hs = Hs, p.Ws = Ws, p.H = H, p.W = W, p.frame_stride = frame_stride, p.row_stride = row_stride, p.border = LP_BORDER_CLAMP;
+    p.scale_y = (float)((double)Hs / H), p.scale_x = (float)((double)Ws / W);
+    NormSpec nrm{};
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, S);
+    if (finish_norm) {
+        LP_REQUIRE(norm_spec(finish_norm, nrm));
+        hipLaunchKernelGGL(frames_resize_cubic_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8, p, nrm,
+                           round_u8, dst);
+    } else {
+        hipLaunchKernelGGL(frames_resize_cubic_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8, p, nrm,
+                           round_u8, dst);
     }
     return launch_status();
 }

@@ -117,7 +117,9 @@ class LabeledBatchProducer:
 
     def __init__(self, image_resize_height: int, image_resize_width: int, downsample_factor: int = 2, uniform_heatmaps: bool = False,
                  hflip_swap_indices: Sequence[int] | None = None, normalization_mean: Sequence[float] = _IMAGENET_MEAN,
-                 normalization_std: Sequence[float] = _IMAGENET_STD, border: str = "renorm") -> None:
+                 normalization_std: Sequence[float] = _IMAGENET_STD, border: str = "renorm", interpolation: str = "cubic") -> None:
+        """``interpolation``: "cubic" = imgaug ``iaa.Resize``'s default (OpenCV INTER_CUBIC, rounded to uint8 levels), what the reference's
+        dataset applies to every labeled image (data/datasets.py:137-143); "linear" = the antialiased filter of the video pipeline."""
         if image_resize_height % 128 != 0 or image_resize_width % 128 != 0:
             raise ValueError("image dimensions (after transformation) must be repeatably divisible by 2; "
                              f"current dimensions: height={image_resize_height}, width={image_resize_width}")
@@ -128,6 +130,7 @@ class LabeledBatchProducer:
         self.swap = None if hflip_swap_indices is None else torch.as_tensor(list(hflip_swap_indices), dtype=torch.int32)
         self.mean, self.std = list(normalization_mean), list(normalization_std)
         self.border = border
+        self.interpolation = interpolation
 
     @property
     def output_shape(self) -> tuple[int, int]:
@@ -149,9 +152,10 @@ class LabeledBatchProducer:
                                               visibility=visibility, uniform_heatmaps=self.uniform_heatmaps)
         heatmaps = ops.generate_heatmaps(kp_model, self.height, self.width, self.output_shape, self.output_sigma, vis)
         if affine is None and hflip is None:
-            images = ops.frames_resize(images_u8, self.height, self.width, self.border, mean=self.mean, std=self.std)
+            images = ops.frames_resize(images_u8, self.height, self.width, self.border, mean=self.mean, std=self.std,
+                                       interpolation=self.interpolation)
         else:
-            raw = ops.frames_resize(images_u8, self.height, self.width, self.border)
+            raw = ops.frames_resize(images_u8, self.height, self.width, self.border, interpolation=self.interpolation)
             sx, sy = self.width / ws, self.height / hs
             to_model = np.array([[sx, 0.0, 0.0], [0.0, sy, 0.0], [0.0, 0.0, 1.0]])
             flips = None if hflip is None else hflip.cpu().numpy().astype(bool)

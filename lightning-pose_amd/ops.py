@@ -508,10 +508,15 @@ def _frame_norm(mean, std) -> _lib.FrameNorm:
     return _lib.FrameNorm((C.c_float * 3)(*[float(m) for m in mean]), (C.c_float * 3)(*[float(v) for v in std]))
 
 
-def frames_resize(frames_u8: torch.Tensor, height: int, width: int, border: str = "clamp", mean=None, std=None) -> torch.Tensor:
-    """(S, Hs, Ws, 3) uint8 device frames -> antialiased linear resize.  Without mean/std: fp32 (S, height, width, 3) in
-    [0, 255] (input of ``frames_augment``); with them: fp32 (S, 3, height, width) normalised planes in one launch."""
+def frames_resize(frames_u8: torch.Tensor, height: int, width: int, border: str = "clamp", mean=None, std=None,
+                  interpolation: str = "linear") -> torch.Tensor:
+    """(S, Hs, Ws, 3) uint8 device frames -> resized frames.  Without mean/std: fp32 (S, height, width, 3) in [0, 255] (input of
+    ``frames_augment``); with them: fp32 (S, 3, height, width) normalised planes in one launch.
+    ``interpolation``: "linear" = antialiased triangle filter (DALI ``fn.resize``, the video pipeline); "cubic" = bicubic without
+    antialiasing, rounded to uint8 levels (imgaug ``iaa.Resize``'s default = OpenCV INTER_CUBIC, the labeled images)."""
     require_device(frames_u8)
+    if interpolation not in ("linear", "cubic"):
+        raise ValueError(f"interpolation must be 'linear' or 'cubic', got {interpolation!r}")
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
         raise ValueError(f"frames must be uint8 (S, H, W, 3), got {frames_u8.dtype} {tuple(frames_u8.shape)}")
     if border not in ("clamp", "renorm"):
@@ -522,6 +527,10 @@ def frames_resize(frames_u8: torch.Tensor, height: int, width: int, border: str 
     finish = mean is not None
     out = torch.empty((s, 3, height, width) if finish else (s, height, width, 3), device=frames_u8.device, dtype=torch.float32)
     norm = _frame_norm(mean, std) if finish else None
+    if interpolation == "cubic":
+        check(_lib.lib().lp_frames_resize_cubic(_p(frames_u8), s, hs, ws, frames_u8.stride(0), frames_u8.stride(1), int(height), int(width), 1,
+                                                C.byref(norm) if finish else None, _p(out), _stream()), "lp_frames_resize_cubic")
+        return out
     check(_lib.lib().lp_frames_resize(_p(frames_u8), s, hs, ws, frames_u8.stride(0), frames_u8.stride(1), int(height), int(width),
                                       _lib.BORDER_CLAMP if border == "clamp" else _lib.BORDER_RENORM,
                                       C.byref(norm) if finish else None, _p(out), _stream()), "lp_frames_resize")

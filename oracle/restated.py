@@ -249,6 +249,19 @@ def frames_resize(frames_u8: torch.Tensor, height: int, width: int, border: str 
     return y.permute(0, 2, 3, 1).to(torch.float32)
 
 
+def frames_resize_cubic(frames_u8: torch.Tensor, height: int, width: int, round_u8: bool = True) -> torch.Tensor:
+    """(S, Hs, Ws, 3) uint8 -> (S, height, width, 3) fp32: bicubic without antialiasing (Keys kernel A = -0.75, half-pixel centres, taps
+    clamped) = imgaug ``iaa.Resize``'s default interpolation "cubic" = OpenCV INTER_CUBIC, the last imgaug step the reference's dataset
+    applies to every labeled image (data/datasets.py:137-143).  torch's bicubic uses the same kernel, centres and clamping; imgaug returns a
+    uint8 image, hence ``round_u8`` (OpenCV's 8-bit path evaluates the same polynomial with 11-bit fixed-point weights, so single levels
+    may differ from it - imgaug / OpenCV are not installed here: parity unpinned against them, pinned against torch's bicubic)."""
+    x = frames_u8.permute(0, 3, 1, 2).to(torch.float64)
+    y = F.interpolate(x, size=(height, width), mode="bicubic", align_corners=False)
+    if round_u8:
+        y = torch.floor(y + 0.5).clamp(0, 255)
+    return y.permute(0, 2, 3, 1).to(torch.float32)
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)  # data/__init__.py:46-47
 IMAGENET_STD = (0.229, 0.224, 0.225)
 

@@ -6,9 +6,23 @@ Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE t
 at HALF its bytes, so reads are doubled; WRITE_SIZE matched the known output bytes of the conv micro-benchmark exactly
 (profiles/conv_microbench.py: 604 MB written -> 589 824 KiB reported).
 """
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("conv.hip", "conv_pipe.h", "lp_common.h")   # what the measured kernels are compiled from (bench.py checks the same digest)
+
+
+def kernels_sha256():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lightning-pose_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
 
 
 def per_kernel(db, counter):
@@ -27,5 +41,5 @@ for k in sorted(fetch):
     out[k] = {"launches": n, "fetch_kib_reported": f, "write_kib_reported": w, "hbm_bytes_per_launch": hbm / n}
     tot_b += hbm
     tot_n += n
-print(json.dumps({"conv_hbm_bytes_per_launch": tot_b / max(tot_n, 1), "conv_launches": tot_n,
+print(json.dumps({"conv_hbm_bytes_per_launch": tot_b / max(tot_n, 1), "conv_launches": tot_n, "kernels_sha256": kernels_sha256(),
                   "correction": "reads = 2 x FETCH_SIZE (gfx950 16-B/lane streams), writes = WRITE_SIZE", "by_kernel": out}, indent=1))

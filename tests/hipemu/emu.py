@@ -591,6 +591,16 @@ def frames_resize(src_u8, H, W, border=_lib.BORDER_RENORM, norm=None):
     return out.np()
 
 
+def frames_resize_cubic(src_u8, H, W, round_u8=1, norm=None):
+    src = np.ascontiguousarray(src_u8, dtype=np.uint8)
+    S, Hs, Ws, _ = src.shape
+    sb = Buf(src)
+    out = Z((S, 3, H, W) if norm is not None else (S, H, W, 3))
+    ok(lib().lp_frames_resize_cubic(sb.p, S, Hs, Ws, Hs * Ws * 3, Ws * 3, H, W, round_u8, C.byref(norm) if norm is not None else None, out.p,
+                                    stream()))
+    return out.np()
+
+
 def frames_augment(src_hwc, matrix=None, brightness=1.0, contrast=1.0, contrast_center=0.5, shot_factor=0.0, seed=0, norm=None):
     src = f32(src_hwc)
     S, H, W, _ = src.shape

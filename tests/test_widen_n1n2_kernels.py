@@ -26,6 +26,21 @@ def _frames(seed, s, h, w):
 
 
 @pytest.mark.parametrize("hs,ws,h,w", [(50, 70, 16, 24), (37, 41, 64, 64), (64, 64, 64, 64), (203, 198, 64, 48), (30, 200, 32, 40)])
+def test_cubic_resize_matches_torch_bicubic(hs, ws, h, w):
+    """the labeled images' resize (imgaug iaa.Resize default = OpenCV INTER_CUBIC): Keys A = -0.75, half-pixel centres, clamped taps, no
+    antialiasing - the same definition torch's bicubic implements; then the uint8 rounding of the image imgaug hands back"""
+    src = _frames(11, 2, hs, ws)
+    raw = emu.frames_resize_cubic(src.numpy(), h, w, round_u8=0)
+    np.testing.assert_allclose(raw, O.frames_resize_cubic(src, h, w, round_u8=False).numpy(), atol=2e-3)
+    got = emu.frames_resize_cubic(src.numpy(), h, w, round_u8=1)
+    want = O.frames_resize_cubic(src, h, w).numpy()
+    assert got.min() >= 0 and got.max() <= 255 and np.array_equal(got, np.round(got))
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 2e-3     # fp32 vs fp64 at an exact .5: a level, rarely
+    fin = emu.frames_resize_cubic(src.numpy(), h, w, round_u8=1, norm=emu.frame_norm())
+    np.testing.assert_allclose(fin, O.frames_finish(torch.from_numpy(got)).numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("hs,ws,h,w", [(50, 70, 16, 24), (37, 41, 64, 64), (64, 64, 64, 64), (203, 198, 64, 48), (30, 200, 32, 40)])
 def test_resize_renorm_matches_torch_antialias(hs, ws, h, w):
     src = _frames(1, 2, hs, ws)
     got = emu.frames_resize(src.numpy(), h, w, _lib.BORDER_RENORM)

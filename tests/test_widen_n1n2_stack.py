@@ -102,8 +102,9 @@ def test_labeled_producer_matches_verbatim_dataset_targets(stack_backend, golden
     np.testing.assert_allclose(np.nan_to_num(kp), np.nan_to_num(g["u1_kp_model_nan"]), atol=5e-5)
     np.testing.assert_allclose(batch["heatmaps"].cpu().numpy(), g["u1_heatmaps"], atol=2e-6)
     # sample 0 has the identity affine: its image is the plain resize
-    want0 = O.frames_finish(O.frames_resize(imgs[:1], 256, 256, "renorm"))
-    torch.testing.assert_close(batch["images"][:1].cpu(), want0, atol=3e-4, rtol=0)
+    want0 = O.frames_finish(O.frames_resize_cubic(imgs[:1], 256, 256))   # imgaug's Resize default: cubic, uint8 levels
+    diff = (batch["images"][:1].cpu() - want0).abs()
+    assert float(diff.max()) <= 1.01 / 255 / 0.224 and float((diff > 3e-4).float().mean()) < 2e-3   # (one level at an exact .5, rarely)
     with pytest.raises(ValueError):
         LabeledBatchProducer(250, 256)
 
@@ -112,7 +113,7 @@ def test_labeled_producer_flip_moves_image_and_labels_together(stack_backend):
     from lightning_pose_amd.data.producers import LabeledBatchProducer
 
     dev = stack_backend
-    prod = LabeledBatchProducer(128, 128, hflip_swap_indices=[1, 0, 2])
+    prod = LabeledBatchProducer(128, 128, hflip_swap_indices=[1, 0, 2], interpolation="linear")
     imgs = _u8(6, 2, 128, 128)
     kp = torch.tensor([[10.0, 20.0, 100.0, 30.0, 64.0, 64.0]] * 2)
     batch = prod(imgs.to(dev), kp.to(dev), hflip=torch.tensor([1, 0]))
