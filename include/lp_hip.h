@@ -158,6 +158,11 @@ int lp_pca_fwd_bwd(const float* kp, int S, int K, const int* index, int rows, in
 
 /* losses/losses.py:880-996 RegressionRMSELoss (always-on diagnostic, models/base.py:528). */
 int lp_rmse_fwd(const float* kp_targ, const float* kp_pred, int n_points, float* loss, lp_stream_t stream);
+/* LossFactory.__call__ (reference losses/factory.py:229-285) in one launch: weighted[i] = w[i] * x[i][0] (logged as "<stage>_<name>_loss_weighted"),
+ * total = sum_i a[i] * weighted[i] in registry order (a = the anneal value for the unsupervised terms, 1 for the heat-map losses).  x: HOST array of
+ * n <= 8 DEVICE scalars; w, a: host arrays.  _bwd: gx[i] = w[i] * (g_weighted[i] + a[i] * g_total[0]); either gradient may be NULL. */
+int lp_loss_combine(const float* const* x, const float* w, const float* a, int n, float* weighted, float* total, lp_stream_t stream);
+int lp_loss_combine_bwd(const float* w, const float* a, int n, const float* g_weighted, const float* g_total, float* gx, lp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Backbone / head contractions on the matrix cores (bf16 NHWC activations, fp32 accumulate).

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "lp_temporal_fwd_bwd": (_I, [_P, _P, _I, _I, _P, _F, _P, _P, _P]),
     "lp_pca_fwd_bwd": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "lp_rmse_fwd": (_I, [_P, _P, _I, _P, _P]),
+    "lp_loss_combine": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "lp_loss_combine_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "lp_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _I, _P]),
     "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lp_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(GemmBatch), _P]),

@@ -131,7 +131,63 @@ __global__ __launch_bounds__(256) void rmse_kernel(const float* __restrict__ tar
     if (threadIdx.x == 0) loss[0] = s / c;
 }
 
+// LossFactory's sum (reference losses/factory.py:229-285): weighted[i] = w[i] * x[i] (what gets logged as <name>_loss_weighted),
+// total = sum_i a[i] * weighted[i] (a = the anneal value for the unsupervised terms, 1 for the heat-map losses) - one launch instead of a
+// multiply per loss and an add per pair.  The loss scalars live in separate 0-dim tensors: their addresses ride in the kernel
+// arguments.  Backward: d x[i] = w[i] * (g_weighted[i] + a[i] * g_total).
+constexpr int kMaxCombine = 8;
+struct CombineArgs {
+    const float* x[kMaxCombine];
+    float w[kMaxCombine], a[kMaxCombine];
+    int n;
+};
+
+__global__ void loss_combine_kernel(CombineArgs p, float* __restrict__ weighted, float* __restrict__ total) {
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < p.n; ++i) {   // (sequential: the reference adds the terms in registry order)
+            const float v = p.w[i] * p.x[i][0];
+            weighted[i] = v;
+            t += p.a[i] * v;
+        }
+        total[0] = t;
+    }
+}
+
+__global__ void loss_combine_bwd_kernel(CombineArgs p, const float* __restrict__ g_weighted, const float* __restrict__ g_total,
+                                        float* __restrict__ gx) {
+    const int i = threadIdx.x;
+    if (i < p.n) gx[i] = p.w[i] * ((g_weighted ? g_weighted[i] : 0.f) + (g_total ? p.a[i] * g_total[0] : 0.f));
+}
+
 }  // namespace lp
+
+extern "C" int lp_loss_combine(const float* const* x, const float* w, const float* a, int n, float* weighted, float* total,
+                               lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && w && a && weighted && total && n > 0);
+    if (n > kMaxCombine) return LP_ERR_UNSUPPORTED;
+    CombineArgs p{};
+    p.n = n;
+    for (int i = 0; i < n; ++i) {
+        LP_REQUIRE(x[i]);
+        p.x[i] = x[i], p.w[i] = w[i], p.a[i] = a[i];
+    }
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, weighted, total);
+    return launch_status();
+}
+
+extern "C" int lp_loss_combine_bwd(const float* w, const float* a, int n, const float* g_weighted, const float* g_total, float* gx,
+                                   lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(w && a && gx && n > 0 && (g_weighted || g_total));
+    if (n > kMaxCombine) return LP_ERR_UNSUPPORTED;
+    CombineArgs p{};
+    p.n = n;
+    for (int i = 0; i < n; ++i) p.w[i] = w[i], p.a[i] = a[i];
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, g_weighted, g_total, gx);
+    return launch_status();
+}
 
 extern "C" int lp_temporal_fwd_bwd(const float* kp, const float* conf, int S, int K, const float* eps_per_kp, float prob_threshold,
                                    float* loss, float* grad_unit, lp_stream_t stream) {

@@ -230,6 +230,16 @@ class Engine:
         self._side_keep: list = []                   # operands of the side-stream launches in flight (released at the join)
         self._fold: tuple[torch.Tensor, torch.Tensor] | None = None  # inference copies: BatchNorm folded into (bf16 weights, biases)
 
+    def _zeros_f32(self, n: int) -> torch.Tensor:
+        """n zeroed fp32 words for a reduction target.  Inside backward() they are carved from ONE arena zeroed with a single fill (the
+        step had ~25 separate fills for its BatchNorm / bias sums); outside, an ordinary allocation."""
+        ar = getattr(self, "_zero_arena", None)
+        if ar is not None and self._zero_off + n <= ar.numel():
+            t = ar[self._zero_off:self._zero_off + n]
+            self._zero_off += (n + 3) // 4 * 4   # (16-B aligned pieces)
+            return t
+        return torch.zeros(n, device=self.device, dtype=torch.float32)
+
     def _timed(self, tag: str, flops: float, fn, nbytes: float = 0.0):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream.  ``nbytes``: the launch's
         ALGORITHMIC bytes (operands read once + result written once), the denominator the measured HBM traffic is held against."""
@@ -562,7 +572,7 @@ class Engine:
             hs, ws = h // 2, w // 2
             g = self._geom(c, B, hs, ws)
             x_small = T[f"head.in{li}"]
-            bsum = torch.zeros(2 * CPAD, device=self.device, dtype=torch.float32)
+            bsum = self._zeros_f32(2 * CPAD)
             check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
             self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
             self._wgrad(dcur, x_small, g, self.G[c.w_off:])
@@ -748,7 +758,7 @@ class Engine:
         segs = self._segments(B, seg)
         Cn = b.C
         if sums is None:
-            sums = torch.zeros(len(segs) * 2 * Cn, device=self.device, dtype=torch.float32)
+            sums = self._zeros_f32(len(segs) * 2 * Cn)
             for si, (i0, n) in enumerate(segs):
                 check(self._lib.lp_bn_bwd_reduce(_p(dy[i0:i0 + n]), _p(y_out[i0:i0 + n]) if y_out is not None else None, _p(z[i0:i0 + n]),
                                                  _p(mean[si * Cn:]), _p(invstd[si * Cn:]), n * rpi, Cn, _p(sums[si * 2 * Cn:]),
@@ -814,21 +824,28 @@ class Engine:
         T, plan = tp.t, self.plan
         B, H, W = tp.meta["B"], tp.meta["H"], tp.meta["W"]
         self._bwd_training = bool(tp.meta.get("training", True))
+        seg = tp.meta.get("seg", 0)
+        nseg = 2 if seg else 1
+        # One zeroed arena for every reduction target of this pass: the sums of each BatchNorm backward (fused into a data gradient or
+        # not), the head's bias sums, the stem's.
+        self._zero_arena = torch.zeros((sum(2 * b.C for b in plan.bns) + 2 * plan.stem_bn.C) * nseg + 2 * CPAD * len(plan.head) + 64,
+                                       device=self.device, dtype=torch.float32)
+        self._zero_off = 0
+        try:
+            self._backward(tp, g_heat, trace, seg, nseg)
+        finally:
+            self._zero_arena = None
+
+    def _backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None, seg: int, nseg: int) -> None:
+        T, plan = tp.t, self.plan
+        B, H, W = tp.meta["B"], tp.meta["H"], tp.meta["W"]
         d = self._head_backward(T, B, g_heat)
         progress = self.grad_progress if (self.grad_progress is not None and self.single_backward) else None
         if progress is not None:
             progress(plan.n_backbone)  # the head's gradients (the tail of the flat buffer) are complete
 
-        seg = tp.meta.get("seg", 0)
-        nseg = 2 if seg else 1
-        # One zeroed buffer for the reductions of every fused BatchNorm backward of this pass.
-        bsums_all = torch.zeros(sum(2 * b.C for b in plan.bns) * nseg, device=self.device, dtype=torch.float32)
-        bo = [0]
-
         def new_sums(b: BNP) -> torch.Tensor:
-            t = bsums_all[bo[0]:bo[0] + 2 * b.C * nseg]
-            bo[0] += 2 * b.C * nseg
-            return t
+            return self._zeros_f32(2 * b.C * nseg)
 
         d_sums = None  # reductions of the current block's bn3 backward, when the dgrad that produced `d` already made them
         for i in range(len(plan.blocks) - 1, -1, -1):
@@ -885,7 +902,7 @@ class Engine:
         # is rebuilt on the fly from the pooled gradient and the arg-max bytes, the ReLU gate from z
         sb = plan.stem_bn
         segs = self._segments(B, seg)
-        ssum = torch.zeros(nseg * 2 * sb.C, device=self.device, dtype=torch.float32)
+        ssum = self._zeros_f32(nseg * 2 * sb.C)
         gam, bet = self.param_view(sb, "weight"), self.param_view(sb, "bias")
         arg, sz, smu, siv = T["pool.arg"], T["stem.z"], T["stem.mu"], T["stem.iv"]
         for si, (i0, n) in enumerate(segs):

@@ -7,6 +7,7 @@ from typing import Any, Literal
 import numpy as np
 import torch
 
+from .. import ops
 from .losses import HeatmapJSLoss, HeatmapKLLoss, HeatmapMSELoss, Loss, PCALoss, TemporalHeatmapLoss, TemporalLoss, UnimodalLoss
 
 _HEATMAP_LOSSES = ("heatmap_mse", "heatmap_kl", "heatmap_js")
@@ -44,20 +45,21 @@ class LossFactory:
 
     def __call__(self, stage: Literal["train", "val", "test"] | None = None, anneal_weight: float | torch.Tensor | None = 1.0,
                  **kwargs: Any) -> tuple[torch.Tensor, list[dict]]:
-        tot_loss: torch.Tensor | float = 0.0
         log_list_all: list[dict] = []
+        names, values, weights, anneals, logs = [], [], [], [], []
         for loss_name, loss_instance in self.loss_instance_dict.items():
             curr_loss, log_list = loss_instance(stage=stage, **kwargs)
-            current_weighted_loss = float(loss_instance.weight) * curr_loss
-            if anneal_weight is None or loss_name in _HEATMAP_LOSSES:
-                scaled = current_weighted_loss
-            else:
-                scaled = float(anneal_weight) * current_weighted_loss
-            tot_loss = scaled if isinstance(tot_loss, float) else tot_loss + scaled
-            log_list += [{"name": f"{stage}_{loss_name}_loss_weighted", "value": current_weighted_loss}]
-            log_list_all += log_list
-        if isinstance(tot_loss, float):
-            tot_loss = torch.tensor(tot_loss)
+            names.append(loss_name)
+            values.append(curr_loss)
+            weights.append(float(loss_instance.weight))
+            anneals.append(1.0 if (anneal_weight is None or loss_name in _HEATMAP_LOSSES) else float(anneal_weight))
+            logs.append(log_list)
+        if not values:
+            return torch.tensor(0.0), log_list_all
+        # weighted[i] = weight_i * loss_i (logged), total = sum anneal_i * weighted[i] in registry order: ONE launch (ops.loss_combine)
+        weighted, tot_loss = ops.loss_combine(values, weights, anneals)
+        for i, (loss_name, log_list) in enumerate(zip(names, logs)):
+            log_list_all += log_list + [{"name": f"{stage}_{loss_name}_loss_weighted", "value": weighted[i]}]
         return tot_loss, log_list_all
 
 

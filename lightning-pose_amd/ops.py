@@ -500,6 +500,45 @@ def rmse(keypoints_targ: torch.Tensor, keypoints_pred: torch.Tensor) -> torch.Te
     return loss.reshape(())
 
 
+class _LossCombineFn(torch.autograd.Function):
+    """weighted[i] = w[i] * x[i];  total = sum_i a[i] * weighted[i]  (csrc/kploss.hip: lp_loss_combine, one launch each way)"""
+
+    @staticmethod
+    def forward(ctx, w, a, *xs):
+        n = len(xs)
+        dev = xs[0].device
+        weighted = torch.empty(n, device=dev, dtype=torch.float32)
+        total = torch.empty((), device=dev, dtype=torch.float32)
+        keep = [x.detach().reshape(1) for x in xs]   # (views of the callers' scalars: alive for the launch)
+        ptrs = (C.c_void_p * n)(*[_p(x) for x in keep])
+        wa, aa = (C.c_float * n)(*w), (C.c_float * n)(*a)
+        check(_lib.lib().lp_loss_combine(ptrs, wa, aa, n, _p(weighted), _p(total), _stream()), "lp_loss_combine")
+        ctx.w, ctx.a, ctx.n = tuple(w), tuple(a), n
+        return weighted, total
+
+    @staticmethod
+    def backward(ctx, g_weighted, g_total):
+        n = ctx.n
+        dev = g_total.device if g_total is not None else g_weighted.device
+        gx = torch.empty(n, device=dev, dtype=torch.float32)
+        gw = None if g_weighted is None else _f32c(g_weighted)
+        gt = None if g_total is None else _f32c(g_total)
+        check(_lib.lib().lp_loss_combine_bwd((C.c_float * n)(*ctx.w), (C.c_float * n)(*ctx.a), n, _p(gw), _p(gt), _p(gx), _stream()),
+              "lp_loss_combine_bwd")
+        return (None, None) + tuple(gx[i] for i in range(n))
+
+
+def loss_combine(losses: list[torch.Tensor], weights: list[float], anneal: list[float]) -> tuple[torch.Tensor, torch.Tensor]:
+    """LossFactory's weighted sum of up to 8 device scalars in one launch -> ((n,) weighted values, 0-dim total); differentiable."""
+    require_device(*losses)
+    if not 0 < len(losses) <= 8:
+        raise ValueError(f"a LossFactory sums between 1 and 8 losses in one launch, got {len(losses)}")
+    if any(x.numel() != 1 for x in losses):
+        raise ValueError("every loss must be a scalar")
+    xs = [x if x.dtype == torch.float32 else x.to(torch.float32) for x in losses]
+    return _LossCombineFn.apply([float(v) for v in weights], [float(v) for v in anneal], *xs)
+
+
 # --------------------------------------------------------------------------------------------------------
 # batch producers (csrc/frames.hip; SURVEY.md 8f N1 / N2)
 # --------------------------------------------------------------------------------------------------------
