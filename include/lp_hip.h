@@ -184,6 +184,7 @@ typedef struct lp_conv_geom {
 #define LP_CONV_KERNEL_WGRAD 2
 #define LP_CONV_KERNEL_WGRAD_PIPE 3
 #define LP_CONV_KERNEL_PIPE_HALO 4 /* conv_pipe_kernel<..., HALO>: 3x3 / stride 1, the input neighbourhood staged once (LP_CONV_HALO=0 disables) */
+#define LP_CONV_KERNEL_RES2D 5     /* conv_res2d_kernel: 3x3 / stride 1, 64 -> 64 channels, 16 x 16 tiles, filter resident in LDS (LP_CONV_RES2D=0 disables) */
 int lp_conv_last_kernel(void);
 
 /* w: bf16 [Co][R][S][Ci] (Ci % 64 == 0).  Output row-major [B*Ho*Wo][ldo], columns < n_store written. */

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 }  // namespace lp
 
 #include "conv_pipe.h"
+#include "conv_res2d.h"
 
 namespace lp {
 
@@ -1178,6 +1179,25 @@ static bool pipe_halo_ok(const ConvGeom& g, int M, int ck, int cap_rows) {
     return ok;
 }
 
+// conv_res2d_kernel (conv_res2d.h): 3x3 / stride 1 / pad 1 with 64 channels in and out on 16 x 16 pixel tiles, the whole filter resident
+// in LDS.  LP_CONV_RES2D=0 leaves those layers to conv_pipe_kernel's HALO form (A/B runs, bit-identity tests); read per call.
+static bool res2d_ok(const ConvGeom& g, int ck, int N, const ConvEpilogue& ep) {
+    const char* e = getenv("LP_CONV_RES2D");
+    if (e != nullptr && atoi(e) == 0) return false;
+    return g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.Hi == g.Ho && g.Wi == g.Wo && ck == 64 && N == 64 && g.Hi % 16 == 0 &&
+           g.Wi % 16 == 0 && ep.bias == nullptr;
+}
+
+template <int MODE>
+static void launch_res2d(const void* x, const void* w, const ConvGeom& g, const ConvEpilogue& ep, hipStream_t st) {
+    const int ntiles = g.B * (g.Hi / 16) * (g.Wi / 16);
+    const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
+    const unsigned x_bytes = (unsigned)(2ull * g.B * g.Hi * g.Wi * 64), w_bytes = (unsigned)(2ull * 64 * 9 * 64);
+    g_last_conv_kernel = LP_CONV_KERNEL_RES2D;
+    hipLaunchKernelGGL((conv_res2d_kernel<MODE>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes, w_bytes,
+                       g.B, g.Hi, g.Wi, ntiles, ep);
+}
+
 template <int BN, int MODE, int EK, bool HALO = false>
 static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
                         hipStream_t st) {
@@ -1197,7 +1217,8 @@ static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const L
 template <int BN>
 static void launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
                               const ConvEpilogue& ep, hipStream_t st) {
-    if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
+    if (kind == kEkZ && BN == 64 && res2d_ok(g, g.Co, N, ep)) launch_res2d<kModeDgrad>(x, w, g, ep, st);
+    else if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
     else if (kind == kEkZ) launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
     else if (kind == kEkAZB) launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
     else launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
@@ -1359,6 +1380,8 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         if (N > 64) {
             if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
             else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+        } else if (res2d_ok(g, g.Ci, N, ep)) {
+            launch_res2d<kModeFwd>(x, w, g, ep, st);
         } else if (pipe_halo_ok(g, M, g.Ci, 512)) {
             launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
         } else {

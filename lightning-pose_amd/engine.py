@@ -255,6 +255,8 @@ class Engine:
                 tag = tag.replace("conv_igemm_kernel", "conv_pipe_kernel")
             elif k == _lib.CONV_KERNEL_PIPE_HALO:
                 tag = tag.replace("conv_igemm_kernel", "conv_pipe_kernel").replace(">", ",halo>")
+            elif k == _lib.CONV_KERNEL_RES2D:
+                tag = tag.replace("conv_igemm_kernel<64,", "conv_res2d_kernel<").replace("conv_igemm_kernel<64>", "conv_res2d_kernel<fwd>")
             elif k == _lib.CONV_KERNEL_WGRAD_PIPE:
                 tag = tag.replace("conv_wgrad_kernel", "conv_wgrad_pipe_kernel")
         self.profile.append((tag, flops, e0, e1, nbytes))

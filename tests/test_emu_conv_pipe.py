@@ -146,6 +146,7 @@ def test_halo_form_equals_the_per_tap_ring(case, wgs, monkeypatch):
     """conv_pipe_kernel<..., HALO> (the tile's padded-raster neighbourhood staged once per 64-channel slice, 9 taps read from it) against the
     per-tap ring and conv_igemm_kernel: bit-identical with 64 channels (same K order), equal to fp32 reassociation otherwise; forward and
     the data gradient with the fused BatchNorm-backward sums (the only store-pass form a 3x3 layer of the trunk uses)."""
+    monkeypatch.setenv("LP_CONV_RES2D", "0")   # (64 -> 64 channels on 16-aligned images would go to conv_res2d_kernel: its own test below)
     if wgs != "0":
         monkeypatch.setenv("LP_CONV_MAX_WGS", wgs)
     B, Hi, Wi, Ci, Co = case
@@ -193,3 +194,56 @@ def test_halo_form_equals_the_per_tap_ring(case, wgs, monkeypatch):
     same(r0[0], r1[0], Co == 64)
     for a, b in zip(r0[1:], r1[1:]):
         np.testing.assert_allclose(b, a, rtol=2e-3, atol=3e-2)
+
+
+RES2D_CASES = [
+    # B, H, W, seg   (3x3, stride 1, pad 1, 64 -> 64 channels; H and W multiples of 16)
+    (3, 16, 16, 0),       # one tile per image
+    (2, 32, 48, 0),       # 6 tiles per image: interior / edge / corner neighbourhoods
+    (3, 16, 32, 1),       # two BatchNorm segments (image 0 | images 1 - 2)
+]
+
+
+@pytest.mark.parametrize("wgs", ["0", "1", "2"])
+@pytest.mark.parametrize("case", RES2D_CASES)
+def test_res2d_kernel_equals_igemm(case, wgs, monkeypatch):
+    """conv_res2d_kernel (16 x 16 tiles, the 3 x 3 x 64 x 64 filter resident in LDS, no barrier inside a tile) against conv_igemm_kernel: same K
+    order and rounding points, so outputs are BIT-identical; the fused BatchNorm sums agree to fp32 summation order.  Forward (+ sums) and the
+    data gradient with the ReLU mask recomputed from z and the BatchNorm-backward sums."""
+    if wgs != "0":
+        monkeypatch.setenv("LP_CONV_MAX_WGS", wgs)
+    B, H, W, seg = case
+    Ci = Co = 64
+    gen = torch.Generator().manual_seed(31 + sum(case))
+    g = emu.geom(B, H, W, Ci, Co, 3, 3, 1, 1)
+    x = emu.to_bf16_bits(torch.randn(B, H, W, Ci, generator=gen))
+    w = torch.randn(Co, 3, 3, Ci, generator=gen) / (Ci * 9) ** 0.5
+    wg, wd = emu.to_bf16_bits(w), emu.to_bf16_bits(w.permute(3, 1, 2, 0))
+
+    def both(fn):
+        monkeypatch.setenv("LP_CONV_PIPE", "0")
+        ref = fn()
+        monkeypatch.setenv("LP_CONV_PIPE", "1")
+        out = fn()
+        assert emu.lib().lp_conv_last_kernel() == 5      # LP_CONV_KERNEL_RES2D
+        monkeypatch.setenv("LP_CONV_RES2D", "0")
+        fn()
+        assert emu.lib().lp_conv_last_kernel() == 4      # ... and without it the HALO form of conv_pipe_kernel takes the layer
+        monkeypatch.delenv("LP_CONV_RES2D")
+        return ref, out
+
+    (z0, _), (z1, _) = both(lambda: emu.conv_fwd(x, wg, g))
+    assert np.array_equal(z0, z1)
+    (zb0, s0), (zb1, s1) = both(lambda: emu.conv_fwd_bn(x, wg, g, seg=seg))
+    assert np.array_equal(zb1, z0) and s1.shape == s0.shape
+    np.testing.assert_allclose(s1, s0, rtol=2e-5, atol=2e-4)
+    M = B * H * W
+    zin = emu.to_bf16_bits(torch.randn(M, Ci, generator=gen))
+    nseg = 2 if seg else 1
+    mean, invstd = torch.randn(nseg, Ci, generator=gen).numpy() * 0.1, (torch.rand(nseg, Ci, generator=gen) + 0.5).numpy()
+    gamma, beta = (torch.rand(Ci, generator=gen) + 0.5).numpy(), (torch.randn(Ci, generator=gen) * 0.3).numpy()
+    dy = emu.to_bf16_bits(torch.randn(M, Co, generator=gen))
+    r0, r1 = both(lambda: emu.conv_dgrad_bn(dy, wd, g, zin, mean if seg else mean[0], invstd if seg else invstd[0], gamma, beta, seg=seg))
+    assert np.array_equal(r0[0], r1[0])
+    for a, b in zip(r0[1:], r1[1:]):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)

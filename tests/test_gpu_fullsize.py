@@ -239,6 +239,7 @@ def test_pipelined_conv_equals_igemm_on_real_shapes(shape, monkeypatch):
     monkeypatch.setenv("LP_CONV_PIPE", "1")
     names = ("out", "fwd sums", "dx", "bwd sums", "dbeta", "dgamma", "dx (mask from z)", "bwd sums 2")
     monkeypatch.setenv("LP_CONV_HALO", "0")   # the per-tap ring: same K order as conv_igemm_kernel
+    monkeypatch.setenv("LP_CONV_RES2D", "0")
     for rep in range(3):
         got = run()
         for name, a, b in zip(names, ref, got):
@@ -250,9 +251,11 @@ def test_pipelined_conv_equals_igemm_on_real_shapes(shape, monkeypatch):
         # the HALO form (the tile's neighbourhood staged once per 64-channel slice, slice-major K order): bit-identical with 64 channels,
         # equal to fp32 reassociation (one bf16 unit in the last place on a small fraction of the elements) with more
         monkeypatch.setenv("LP_CONV_HALO", "1")
+        monkeypatch.delenv("LP_CONV_RES2D")
         for rep in range(3):
             got = run()
-            assert lib.lp_conv_last_kernel() == _lib.CONV_KERNEL_PIPE_HALO   # (the last launch: the mask-from-z data gradient)
+            # (the last launch: the mask-from-z data gradient; 64 -> 64 channels go to conv_res2d_kernel - 16 x 16 tiles, resident filter)
+            assert lib.lp_conv_last_kernel() == (_lib.CONV_KERNEL_RES2D if Ci == Co == 64 else _lib.CONV_KERNEL_PIPE_HALO)
             for name, a, b in zip(names, ref, got):
                 if a.dtype == torch.bfloat16 and ((Ci == 64 and name == "out") or (Co == 64 and name == "dx (mask from z)") or name == "dx"):
                     assert torch.equal(a, b), (name, rep, int((a != b).sum()))   # ("dx": the addend + bit-mask form stays on the ring)
