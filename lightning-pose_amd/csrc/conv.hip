@@ -1742,6 +1742,22 @@ static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom
         ep.seg_images = bn->seg_images;
         ep.stats = (float*)bn->workspace;
     }
+    // conv_stem2d_kernel (conv_res2d.h): 16 x 16 output tiles, filter resident in LDS, fused sums by atomics.  LP_STEM_2D=0 (A/B runs,
+    // bit-identity tests) and the bit-reproducible sums (LP_STATS_ATOMIC_TILES=0) keep conv_igemm_kernel<64, stem>
+    const char* s2 = getenv("LP_STEM_2D");
+    if (conv_pipe_enabled() && (s2 == nullptr || atoi(s2) != 0) && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo &&
+        (!bn || tm <= kStatsAtomicTiles)) {
+        if (bn) {
+            ep.stats = nullptr;
+            ep.stats_sums = bn->sums;
+        }
+        const int ntiles = g.B * (g.Ho / 16) * (g.Wo / 16);
+        const int grid = ntiles < 2 * pipe_max_wgs() ? ntiles : 2 * pipe_max_wgs();
+        g_last_conv_kernel = LP_CONV_KERNEL_RES2D;
+        hipLaunchKernelGGL(conv_stem2d_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const unsigned short*)x4, (const unsigned short*)w,
+                           (unsigned)(2ull * g.B * g.Hi * g.Wi * 4), g.B, g.Ho, g.Wo, ntiles, ep);
+        return launch_status();
+    }
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
     if (bn) {

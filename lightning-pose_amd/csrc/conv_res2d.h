@@ -289,4 +289,181 @@ __global__ __launch_bounds__(512) void conv_res2d_kernel(const unsigned short* _
     (void)M;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The 7x7 / stride 2 / pad 3 stem (NHWC4 bf16 input, 64 output channels, K = 8 x 8 x 4 = 256 with the 8th row / column of taps zero) in the
+// same style: 16 x 16 output tiles, the [64][256] filter resident in LDS, the 38 x 40-pixel input neighbourhood of a tile (12 KB) staged by
+// direct-to-LDS loads while the previous tile is consumed, 32 MFMAs per wave and tile without a barrier or counted wait.  The im2col row of
+// an output pixel under filter row r is 64 contiguous bytes of input (8 taps x 4 channels), so the pixel operand of k-slice (r, half) is
+// 16 B at input pixel (2 y - 3 + r, 2 x - 3 + 4 half + 2 fg): read straight from the staged image as two 8-B pieces (the image starts at the
+// EVEN column 2 x0 - 4 so that the global 16-B chunks are whole pixel pairs inside or outside the frame; the fragments then start on odd
+// pixels).  K order and rounding points are conv_igemm_kernel<64, stem>'s: bit-identical outputs.  The weights sit in LDS as one
+// [64 rows][32 B] image per k-slice (a [64][512 B] image would put a wave's 32 rows on the same banks).
+constexpr int kS2RowPx = 40, kS2Rows = 38;
+constexpr int kS2ImgB = 768 * 16;   // 38 x 40 x 8 B = 12 160 B, staged as 12 wave pieces of 1 KB
+constexpr int kS2WB = 64 * 512;
+
+__global__ __launch_bounds__(512, 2) void conv_stem2d_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
+                                                          unsigned x_bytes, int B, int Ho, int Wo, int ntiles, ConvEpilogue ep) {
+    constexpr int kScratchB = 8 * 32 * (64 + 16);   // the 8 waves' store-pass corners (20 KB): 76 KB in all, two workgroups per CU
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kS2WB + 2 * kS2ImgB + kScratchB];
+    unsigned char* const wlds = smem;
+    unsigned char* const img0 = smem + kS2WB;
+    unsigned char* const scratch = smem + kS2WB + 2 * kS2ImgB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int Hi = 2 * Ho, Wi = 2 * Wo;
+    const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_w = make_buf_rsrc(Wt, (unsigned)kS2WB);
+    const int tiles_x = Wo >> 4, tiles_img = tiles_x * (Ho >> 4);
+
+    // chunk q (16 B = 2 pixels) of the staged image: row q / 20, pixel pair q % 20; this thread stages q = tid and (waves 0 - 3) 512 + tid
+    int crow[2], ccol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        crow[i] = q / 20;
+        ccol[i] = (q - crow[i] * 20) * 2;
+    }
+    auto img_load = [&](int vt, int buf) {
+        if (vt >= ntiles) return;
+        const int tile = xcd_remap(vt, ntiles);
+        const int b = tile / tiles_img, t2 = tile - b * tiles_img;
+        const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+        const int iy0 = 32 * ty - 3, ix0 = 32 * tx - 4;
+        unsigned char* dst = img0 + buf * kS2ImgB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && wave >= 4) break;
+            const int iy = iy0 + crow[i], ix = ix0 + ccol[i];
+            const bool ok = crow[i] < kS2Rows && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+            const unsigned voff = ok ? (unsigned)(((b * Hi + iy) * Wi + ix) * 8) : ~0u;
+            buf_load16_lds(rsrc_x, dst + i * (512 * 16) + wave * 1024, voff, 0u);
+        }
+    };
+    // the filter, once: wave instruction (kk, rows n0 .. n0 + 31): lane -> (n = n0 + lane / 2, fg = lane % 2), source chunk 2 kk + fg of row n
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i, kk = piece >> 1, n = (piece & 1) * 32 + (lane >> 1), fgl = lane & 1;
+        buf_load16_lds(rsrc_w, wlds + piece * 1024, (unsigned)(n * 512 + (kk * 2 + fgl) * 16), 0u);
+    }
+    img_load(blockIdx.x, 0);
+
+    const int fr = lane & 31, fg = lane >> 5;
+    unsigned abase[2];   // byte offset of input pixel (2 py, 2 px + 2 fg + 1) in the staged image, per mt
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int p = wm * 64 + mt * 32 + fr;
+        abase[mt] = (unsigned)(((2 * (p >> 4)) * kS2RowPx + 2 * (p & 15) + 2 * fg + 1) * 8);
+    }
+    const unsigned wbase = (unsigned)((wn * 32 + fr) * 32 + fg * 16);
+
+    constexpr int CP = 4, RP = 16, N = 64;
+    const int pc = lane % CP, prow = lane / CP;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.f;
+    int st_seg_off = -1;
+    const bool want_stats = ep.stats_sums != nullptr;
+    auto stats_flush = [&](float* red) {
+        if (st_seg_off >= 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int msk = CP; msk < 64; msk <<= 1) {
+                    s0[q] += __shfl_xor(s0[q], msk, 64);
+                    s1[q] += __shfl_xor(s1[q], msk, 64);
+                }
+            }
+            __syncthreads();
+            if (lane < CP) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    red[(wave * 2 + 0) * 32 + lane * 8 + q] = s0[q];
+                    red[(wave * 2 + 1) * 32 + lane * 8 + q] = s1[q];
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * N) {
+                const int comp = tid / N, cl = tid % N;
+                const int wn_ = cl / 32, c = cl % 32;
+                float t = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) t += red[((wn_ * 4 + w4) * 2 + comp) * 32 + c];
+                atomicAdd(&ep.stats_sums[2 * st_seg_off + comp * N + cl], t);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.f;
+    };
+
+    f32x16 acc[2];
+    int buf = 0;
+    for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+        const int tile = xcd_remap(vt, ntiles);
+        const int b = tile / tiles_img, t2 = tile - b * tiles_img;
+        const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+        const int m_tile = (b * Ho + ty * 16) * Wo + tx * 16;
+        const int seg_off = (ep.seg_images > 0 && b >= ep.seg_images) ? N : 0;
+        if (seg_off != st_seg_off) {
+            if (want_stats) stats_flush(reinterpret_cast<float*>(scratch));   // (the waves' store-pass corners are idle between tiles)
+            st_seg_off = seg_off;
+        }
+        LP_WAIT_VM(0);        // the filter and this tile's image have landed (and the previous tile's stores have left)
+        LP_RAW_BARRIER();     // ... everyone's have, and everyone is done with the other image
+        img_load(vt + gridDim.x, buf ^ 1);
+        const unsigned char* ib = img0 + buf * kS2ImgB;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {   // k-slice (r, half): taps 4 half .. 4 half + 3 of filter row r
+            const int r = kk >> 1, half = kk & 1;
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(wlds + kk * 2048 + wbase));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned char* ap = ib + abase[mt] + (r * kS2RowPx + 4 * half) * 8;
+                const u16x4 lo = *reinterpret_cast<const u16x4*>(ap), hi = *reinterpret_cast<const u16x4*>(ap + 8);
+                const u16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, av), acc[mt], 0, 0, 0);
+            }
+        }
+        // store pass: per wave through its private corner (no barrier: the images are only refilled behind the NEXT tile's barrier)
+        constexpr int ROWB = 64 + 16;
+        unsigned char* stg = scratch + wave * (32 * ROWB);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t pk = {pack_bf16x2(acc[mt][4 * j], acc[mt][4 * j + 1]), pack_bf16x2(acc[mt][4 * j + 2], acc[mt][4 * j + 3])};
+                *reinterpret_cast<u32x2_t*>(stg + fr * ROWB + (8 * j + 4 * fg) * 2) = pk;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 32 / RP; ++ps) {
+                const int row = ps * RP + prow;
+                const u16x8 w = *reinterpret_cast<const u16x8*>(stg + row * ROWB + pc * 16);
+                const int p = wm * 64 + mt * 32 + row;
+                const unsigned off = (unsigned)(m_tile + (p >> 4) * Wo + (p & 15)) * 64u + (unsigned)(wn * 32 + pc * 8);
+                *reinterpret_cast<u16x8*>(ep.out_bf16 + off) = w;
+                if (want_stats) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float vr = bf16_to_f32(w[q]);
+                        s0[q] += vr;
+                        s1[q] = fmaf(vr, vr, s1[q]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        buf ^= 1;
+    }
+    LP_WAIT_VM(0);
+    LP_RAW_BARRIER();
+    if (want_stats) stats_flush(reinterpret_cast<float*>(scratch));
+}
+
 }  // namespace lp

@@ -247,3 +247,30 @@ def test_res2d_kernel_equals_igemm(case, wgs, monkeypatch):
     assert np.array_equal(r0[0], r1[0])
     for a, b in zip(r0[1:], r1[1:]):
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("wgs", ["0", "1", "3"])
+@pytest.mark.parametrize("B,H,W,seg", [(2, 32, 32, 0), (3, 64, 32, 1), (1, 32, 96, 0)])
+def test_stem_2d_kernel_equals_igemm(B, H, W, seg, wgs, monkeypatch):
+    """conv_stem2d_kernel (16 x 16 output tiles, the [64][256] filter resident in LDS, the input neighbourhood staged by direct loads, fragments
+    read from the staged image) against conv_igemm_kernel<64, stem>: same k-slices in the same order, so outputs are BIT-identical; the fused
+    BatchNorm sums (atomics here, the per-tile workspace there) agree to fp32 summation order."""
+    if wgs != "0":
+        monkeypatch.setenv("LP_CONV_MAX_WGS", wgs)
+    gen = torch.Generator().manual_seed(41 + B + H + W)
+    x4 = torch.zeros(B, H, W, 4)
+    x4[..., :3] = torch.randn(B, H, W, 3, generator=gen)
+    wp = torch.zeros(64, 8, 8, 4)
+    wp[:, :7, :7, :3] = torch.randn(64, 7, 7, 3, generator=gen) / 12
+    g = emu.geom(B, H, W, 4, 64, 7, 7, 2, 3)
+    xb, wb = emu.to_bf16_bits(x4), emu.to_bf16_bits(wp)
+    monkeypatch.setenv("LP_STEM_2D", "0")
+    ref = emu.stem_fwd(xb, wb, g)
+    ref_bn, ref_s = emu.stem_fwd_bn(xb, wb, g, seg=seg)
+    assert emu.lib().lp_conv_last_kernel() == 0      # LP_CONV_KERNEL_IGEMM
+    monkeypatch.setenv("LP_STEM_2D", "1")
+    got = emu.stem_fwd(xb, wb, g)
+    assert emu.lib().lp_conv_last_kernel() == 5      # LP_CONV_KERNEL_RES2D
+    got_bn, got_s = emu.stem_fwd_bn(xb, wb, g, seg=seg)
+    assert np.array_equal(ref, got) and np.array_equal(ref_bn, got_bn) and np.array_equal(ref, ref_bn)
+    np.testing.assert_allclose(got_s, ref_s, rtol=2e-5, atol=2e-4)
