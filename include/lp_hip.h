@@ -98,6 +98,10 @@ int lp_frame_map_apply(const float* kp_in, int B, int K, const lp_frame_map* fra
 /* data/heatmaps.py:11-87 generate_heatmaps.  keypoints (B,K,2) image px; visibility int32 (B,K) or NULL. */
 int lp_heatmap_gen(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w, float sigma,
                    float* out, lp_stream_t stream);
+/* ... and its gradient with respect to the keypoints (keep_gradients=True, data/heatmaps.py:37-40): grad_keypoints (B,K,2); zero / uniform maps
+ * (NaN, out of bounds, visibility < 2) contribute zeros.  Heat-map axes up to 512. */
+int lp_heatmap_gen_bwd(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w, float sigma,
+                       const float* grad_out, float* grad_keypoints, lp_stream_t stream);
 
 /* losses/losses.py:706-869 TemporalHeatmapLoss ("temporal_heatmap_mse" = LP_HM_MSE, "temporal_heatmap_kl" = LP_HM_KL): distance
  * between the heat-maps of consecutive frames per keypoint, zeroed where either frame's confidence < prob_threshold, relu(. - epsilon[k]),

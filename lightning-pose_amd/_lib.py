@@ -67,6 +67,7 @@ PROTOTYPES = {
     "lp_decode_bwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _I, _P]),
     "lp_frame_map_apply": (_I, [_P, _I, _I, C.POINTER(FrameMap), _I, _P, _P]),
     "lp_heatmap_gen": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "lp_heatmap_gen_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
     "lp_temporal_heatmap_workspace_bytes": (_Z, [_I, _I]),
     "lp_temporal_heatmap_fwd": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P]),
     "lp_temporal_heatmap_bwd": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),

@@ -95,6 +95,57 @@ __global__ __launch_bounds__(256) void heatmap_gen_kernel(const float* __restric
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = gauss_at(i, cx, cy, g) / total;
 }
 
+// ---- generate_heatmaps, backward (keep_gradients=True with a live graph: data/heatmaps.py:37-40 keeps the keypoints attached) -----------
+// H = E / S with E[r][c] = exp(-((c - cx)^2 + (r - cy)^2) / (2 sigma^2)):  dH/dcx = H ((c - cx) - m_x) / sigma^2, m_x = sum_c ex[c] (c - cx) / sum ex.
+// d loss / d keypoint = (that contracted with the incoming gradient) * heat-map px per image px.  Zero / uniform maps (NaN, out of bounds,
+// visibility < 2) are constants; inside [-1, w + 1] the reference's clamp is the identity.
+__global__ __launch_bounds__(256) void heatmap_gen_bwd_kernel(const float* __restrict__ kp, const int* __restrict__ vis, GaussSpec g,
+                                                              const float* __restrict__ gout, float* __restrict__ gkp) {
+    __shared__ float red[4];
+    __shared__ float ex[kGaussAxisMax], ey[kGaussAxisMax];
+    const int bk = blockIdx.x, n = g.h * g.w;
+    float cx, cy;
+    const bool ok = gauss_centre(kp[bk * 2], kp[bk * 2 + 1], g, cx, cy);
+    const bool gaussian = ok && (vis == nullptr || vis[bk] == 2);
+    if (!gaussian) {   // (workgroup-uniform)
+        if (threadIdx.x < 2) gkp[bk * 2 + threadIdx.x] = 0.f;
+        return;
+    }
+    float px = 0.f, py = 0.f, qx = 0.f, qy = 0.f;
+    for (int i = threadIdx.x; i < g.w; i += 256) {
+        const float d = (float)i - cx, e = expf(-(d * d) * g.inv_two_var);
+        ex[i] = e;
+        px += e;
+        qx = fmaf(e, d, qx);
+    }
+    for (int i = threadIdx.x; i < g.h; i += 256) {
+        const float d = (float)i - cy, e = expf(-(d * d) * g.inv_two_var);
+        ey[i] = e;
+        py += e;
+        qy = fmaf(e, d, qy);
+    }
+    const float sx = block_sum<4>(px, red), sy = block_sum<4>(py, red);
+    const float mx = block_sum<4>(qx, red) / sx, my = block_sum<4>(qy, red) / sy;
+    const float inv = 1.f / (sx * sy);
+    const float* gsrc = gout + (size_t)bk * n;
+    float a = 0.f, b = 0.f, t = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / g.w, c = i - r * g.w;
+        const float gh = gsrc[i] * ex[c] * (ey[r] * inv);
+        t += gh;
+        a = fmaf(gh, (float)c - cx, a);
+        b = fmaf(gh, (float)r - cy, b);
+    }
+    a = block_sum<4>(a, red);
+    b = block_sum<4>(b, red);
+    t = block_sum<4>(t, red);
+    if (threadIdx.x == 0) {
+        const float k2 = 2.f * g.inv_two_var;   // 1 / sigma^2
+        gkp[bk * 2] = (a - mx * t) * k2 * g.sx;
+        gkp[bk * 2 + 1] = (b - my * t) * k2 * g.sy;
+    }
+}
+
 // ---- masked heat-map losses (MSE / KL / JS) -----------------------------------------------------------
 // per-pixel term of the three supervised heat-map losses (reference losses/losses.py:293-423; the divergences are kornia's
 // kl_div_loss_2d / js_div_loss_2d on t + 1e-10, p + 1e-10, summed per map) and its derivative with respect to p
@@ -481,6 +532,17 @@ extern "C" int lp_heatmap_gen(const float* keypoints, const int* visibility, int
     if (B == 0) return LP_OK;
     hipLaunchKernelGGL(heatmap_gen_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, keypoints, visibility,
                        make_spec(img_h, img_w, h, w, sigma), out);
+    return launch_status();
+}
+
+extern "C" int lp_heatmap_gen_bwd(const float* keypoints, const int* visibility, int B, int K, int img_h, int img_w, int h, int w,
+                                  float sigma, const float* grad_out, float* grad_keypoints, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(keypoints && grad_out && grad_keypoints && B >= 0 && K > 0 && h > 0 && w > 0 && img_h > 0 && img_w > 0 && sigma > 0.f);
+    if (h > kGaussAxisMax || w > kGaussAxisMax) return LP_ERR_UNSUPPORTED;
+    if (B == 0) return LP_OK;
+    hipLaunchKernelGGL(heatmap_gen_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, keypoints, visibility,
+                       make_spec(img_h, img_w, h, w, sigma), grad_out, grad_keypoints);
     return launch_status();
 }
 

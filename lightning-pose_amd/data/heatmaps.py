@@ -26,10 +26,8 @@ def generate_heatmaps(
     """2-D Gaussian targets, (B, K, 2) image-px keypoints -> (B, K, h, w).  Same semantics as the reference:
     sigma in heat-map px, maps normalised to sum 1, NaN / out-of-bounds -> zeros, visibility 0 -> zeros,
     1 -> uniform, 2 -> Gaussian."""
-    if keep_gradients and keypoints.requires_grad:
-        raise NotImplementedError(
-            "generate_heatmaps(keep_gradients=True) is only needed by the 3-D reprojection losses, which are outside the "
-            "heatmap-tracker hot path implemented here")
+    if keep_gradients and keypoints.requires_grad:   # reference :37-40: the keypoints stay attached (lp_heatmap_gen_bwd)
+        return ops.generate_heatmaps_with_grad(keypoints, height, width, tuple(output_shape), sigma, visibility)
     return ops.generate_heatmaps(keypoints, height, width, tuple(output_shape), sigma, visibility)
 
 

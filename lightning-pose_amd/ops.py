@@ -255,6 +255,34 @@ def decode(heatmaps: torch.Tensor, downsample_factor: int, temperature: float, f
 # heat-map targets / losses
 # --------------------------------------------------------------------------------------------------------
 
+class _HeatmapGenFn(torch.autograd.Function):
+    """generate_heatmaps with the keypoints attached (keep_gradients=True): lp_heatmap_gen forward, lp_heatmap_gen_bwd backward"""
+
+    @staticmethod
+    def forward(ctx, keypoints, height, width, output_shape, sigma, visibility):
+        out = generate_heatmaps(keypoints.detach(), height, width, output_shape, sigma, visibility)
+        ctx.save_for_backward(_f32c(keypoints))
+        ctx.args = (int(height), int(width), tuple(output_shape), float(sigma),
+                    None if visibility is None else visibility.to(device=keypoints.device, dtype=torch.int32).contiguous())
+        ctx.in_dtype = keypoints.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (kp,) = ctx.saved_tensors
+        height, width, (h, w), sigma, vis = ctx.args
+        b, k, _ = kp.shape
+        gkp = torch.empty_like(kp)
+        check(_lib.lib().lp_heatmap_gen_bwd(_p(kp), _p(vis), b, k, height, width, h, w, sigma, _p(_f32c(g)), _p(gkp), _stream()),
+              "lp_heatmap_gen_bwd")
+        return gkp.to(ctx.in_dtype), None, None, None, None, None
+
+
+def generate_heatmaps_with_grad(keypoints: torch.Tensor, height: int, width: int, output_shape: tuple[int, int], sigma: float = 1.25,
+                                visibility: torch.Tensor | None = None) -> torch.Tensor:
+    return _HeatmapGenFn.apply(keypoints, height, width, tuple(output_shape), sigma, visibility)
+
+
 def generate_heatmaps(keypoints: torch.Tensor, height: int, width: int, output_shape: tuple[int, int], sigma: float = 1.25,
                       visibility: torch.Tensor | None = None) -> torch.Tensor:
     require_device(keypoints)

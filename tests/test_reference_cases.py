@@ -232,16 +232,31 @@ def test_generate_heatmaps_extreme_coordinates_stay_finite(dev):
     assert not _gen(dev, kp, torch.full((1, 4), 2, dtype=torch.long)).any()
 
 
-def test_generate_heatmaps_detaches(dev):
-    """TestGenerateHeatmaps::test_keep_gradients, the keep_gradients=False half (the True half belongs to the 3-D reprojection losses,
-    outside this path: it raises instead of silently dropping the gradient)"""
+def test_generate_heatmaps_keep_gradients(dev):
+    """TestGenerateHeatmaps::test_keep_gradients: detached by default; with keep_gradients=True the keypoints stay attached (lp_heatmap_gen_bwd)
+    and the gradient equals autograd's through the restated reference expression - including the maps that carry none (NaN, out of bounds,
+    visibility 0 / 1)."""
     from lightning_pose_amd.data.heatmaps import generate_heatmaps
 
     kp = torch.tensor([[[32.0, 64.0], [128.0, 96.0]]], device=dev, requires_grad=True)
     h = generate_heatmaps(kp, height=256, width=256, output_shape=(64, 64), keep_gradients=False)
     assert not h.requires_grad and kp.grad is None
-    with pytest.raises(NotImplementedError):
-        generate_heatmaps(kp, height=256, width=256, output_shape=(64, 64), keep_gradients=True)
+    gen = torch.Generator().manual_seed(3)
+    base = torch.tensor([[[32.0, 64.0], [128.0, 96.0], [200.0, 150.0], [100.0, 200.0]], [[64.0, 32.0], [160.0, 120.0], [3.5, 250.2], [float("nan"), 5.0]],
+                         [[-3.0, 10.0], [300.0, 40.0], [255.9, 0.1], [17.3, 41.9]]])
+    weights = torch.randn(3, 4, 48, 64, generator=gen)   # a loss that is not invariant to the map (sum(H) = 1 has zero gradient)
+    for vis in (None, torch.tensor([[2, 2, 1, 2], [2, 0, 2, 2], [2, 2, 2, 2]])):
+        a = base.clone().to(dev).requires_grad_(True)
+        b = base.clone().requires_grad_(True)
+        got = generate_heatmaps(a, height=192, width=256, output_shape=(48, 64), keep_gradients=True, visibility=None if vis is None else vis.to(dev))
+        from oracle import restated as O
+        want = O.generate_heatmaps(b, 192, 256, (48, 64), 1.25, vis, keep_gradients=True)
+        torch.testing.assert_close(got.detach().cpu(), want.detach(), atol=2e-7, rtol=1e-5)
+        (got * weights.to(dev)).sum().backward()
+        (want * weights).sum().backward()
+        assert a.grad is not None and torch.isfinite(a.grad).all()
+        torch.testing.assert_close(a.grad.cpu(), torch.nan_to_num(b.grad), atol=2e-6, rtol=2e-4)
+        assert float(a.grad[1, 3].abs().sum()) == 0 and float(a.grad[2, 1].abs().sum()) == 0   # NaN / out of bounds: constant maps
 
 
 # --------------------------------------------------------------------------------------------------------------- data/test_utils.py
