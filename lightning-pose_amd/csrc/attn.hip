@@ -35,6 +35,8 @@ struct AttnArgs {
     int ldp;
     unsigned short* out;        // [B*T][ldo] bf16, head h at column h*64
     int ldo;
+    float* stats;               // [B*nh][T][2] = (row maximum of the scaled scores, 1 / exp-sum) per query, or nullptr: what a backward pass
+                                // that RECOMPUTES the probabilities needs instead of the T x T tensor (lp_attn_fwd_lse / lp_attn_bwd_kv_lse)
 };
 
 // WRITE_P = false (inference: a.p == nullptr): the probabilities are used for O and dropped - nothing of size T x T is written.
@@ -216,6 +218,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     // O[q][h*64 + d]: reg e of block db is d = db*32 + (e&3) + 8*(e>>2) + 4*half -> 4 consecutive d per store
     const int q = q0 + wave * 32 + col;
+    if (a.stats != nullptr && active && q < T && half == 0) {
+        float* st = a.stats + ((size_t)z * T + q) * 2;
+        st[0] = m;
+        st[1] = inv_l;
+    }
     if (active && q < T) {
         unsigned short* orow = a.out + ((size_t)b * T + q) * a.ldo + h * kAD;
 #pragma unroll
@@ -258,13 +265,21 @@ struct AttnBwdArgs {
     unsigned short* ds;          // [B*nh][T][ldp] (pad columns zeroed)
     unsigned short* dqkv;        // token rows of pitch ld_dqkv: dK at dk_off + h*64, dV at dv_off + h*64
     int ld_dqkv, dk_off, dv_off;
+    const float* stats;          // RECOMPUTE: [B*nh][T][2] = (m, 1 / l) of lp_attn_fwd_lse; p is unused
+    int k_off;                   // RECOMPUTE: K at k_off + h*64
 };
 
+// RECOMPUTE: the probabilities are not read from memory but rebuilt per tile as exp(scale * Q K^T - m) / l - 8 more MFMAs per tile and wave on
+// the Q tile that is staged anyway - exactly the expression (and k-slice order) of the forward kernel, so the bf16 values are the ones it
+// would have stored.  The T x T tensor P (0.85 GB per layer at C4) is then neither written by the forward pass nor read here.
+template <bool RECOMPUTE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sDO[kBQ * kLDT];
     __shared__ __attribute__((aligned(16))) unsigned short sQ[kBQ * kLDT];
     __shared__ __attribute__((aligned(16))) unsigned short sP[kBQ * kLDP2];
     __shared__ __attribute__((aligned(16))) float sD[kBQ];
+    __shared__ __attribute__((aligned(16))) float sM[RECOMPUTE ? kBQ : 4], sIL[RECOMPUTE ? kBQ : 4];
+    __shared__ __attribute__((aligned(16))) unsigned short sKk[RECOMPUTE ? kBK2 * kLDK : 8];   // this workgroup's 128 key rows (RECOMPUTE)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,8 +291,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     const unsigned short* Qp = a.qkv + (size_t)b * T * a.ld + h * kAD;
     const unsigned short* Vp = Qp + a.v_off;
     const unsigned short* DOp = a.d_out + (size_t)b * T * a.ld_do + h * kAD;
-    const unsigned short* Pp = a.p + (size_t)z * T * a.ldp;
+    const unsigned short* Pp = RECOMPUTE ? nullptr : a.p + (size_t)z * T * a.ldp;
     const bool active = kv0 + wave * 32 < T;
+    const bool key_ok = kv0 + wave * 32 + col < T;   // RECOMPUTE: this lane's key exists (a stored P has zeros in its pad columns)
 
     // this lane's key row of V as the B operand of dP = dO V^T (rows past T alias the last row: their P is zero)
     bf16x8 vf[kAD / 16];
@@ -287,6 +303,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
         const unsigned short* vr = Vp + (size_t)kv * a.ld + half * 8;
 #pragma unroll
         for (int kk = 0; kk < kAD / 16; ++kk) vf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(vr + kk * 16));
+    }
+    // ... and of K, the B operand of S = Q K^T: staged once in LDS (the register file is full: 254 VGPRs without it), read per k-slice
+    if (RECOMPUTE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // 128 keys x 8 chunks of 16 B: thread -> chunk (tid & 7) of rows (tid >> 3) + 32 i
+            int kv = kv0 + (tid >> 3) + 32 * i;
+            if (kv >= T) kv = T - 1;
+            *reinterpret_cast<u16x8*>(&sKk[((tid >> 3) + 32 * i) * kLDK + (tid & 7) * 8]) =
+                *reinterpret_cast<const u16x8*>(Qp + a.k_off + (size_t)kv * a.ld + (tid & 7) * 8);
+        }
     }
 
     // staging: dO / Q tiles -> thread owns chunk (tid & 7) of rows (tid >> 3) + 32 i; P tile -> chunk (tid & 15) of rows (tid >> 4) + 16 i
@@ -302,25 +328,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
             rdo[i] = q < T ? *reinterpret_cast<const u16x8*>(DOp + (size_t)q * a.ld_do + schunk * 8) : zero;
             rq[i] = q < T ? *reinterpret_cast<const u16x8*>(Qp + (size_t)q * a.ld + schunk * 8) : zero;
         }
+        if (!RECOMPUTE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = t * kBQ + prow + 16 * i;
-            rp[i] = (q < T && pcol_ok) ? *reinterpret_cast<const u16x8*>(Pp + (size_t)q * a.ldp + kv0 + pchunk * 8) : zero;
+            for (int i = 0; i < 4; ++i) {
+                const int q = t * kBQ + prow + 16 * i;
+                rp[i] = (q < T && pcol_ok) ? *reinterpret_cast<const u16x8*>(Pp + (size_t)q * a.ldp + kv0 + pchunk * 8) : zero;
+            }
         }
         if (tid < kBQ) {
             const int q = t * kBQ + tid;
             rd = q < T ? a.d_rows[((size_t)b * T + q) * a.nh + h] : 0.f;
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<u16x8*>(&sDO[(srow + 32 * i) * kLDT + schunk * 8]) = rdo[i];
             *reinterpret_cast<u16x8*>(&sQ[(srow + 32 * i) * kLDT + schunk * 8]) = rq[i];
         }
+        if (!RECOMPUTE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sP[(prow + 16 * i) * kLDP2 + pchunk * 8]) = rp[i];
-        if (tid < kBQ) sD[tid] = rd;
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sP[(prow + 16 * i) * kLDP2 + pchunk * 8]) = rp[i];
+        }
+        if (tid < kBQ) {
+            sD[tid] = rd;
+            if (RECOMPUTE) {   // (not prefetched: the register file is full.)  Rows past T: 1 / l = 0 makes their probabilities zero
+                const int q = t * kBQ + tid;
+                const float2 st = q < T ? *reinterpret_cast<const float2*>(a.stats + ((size_t)z * T + q) * 2) : make_float2(0.f, 0.f);
+                sM[tid] = st.x;
+                sIL[tid] = st.y;
+            }
+        }
     };
 
     f32x16 dv[2], dk[2];  // dV^T, dK^T: [d = db*32 + rows][key = this lane's]
@@ -334,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     const int n_q = (T + kBQ - 1) / kBQ;
     fetch(0);
     for (int t = 0; t < n_q; ++t) {
-        stage();
+        stage(t);
         __syncthreads();
         if (t + 1 < n_q) fetch(t + 1);
         if (active) {
@@ -352,10 +390,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
                     const bf16x8 of = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(&sDO[(blk * 32 + col) * kLDT + kk * 16 + half * 8]));
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[kk], dp, 0, 0, 0);
                 }
+                f32x16 sc;
+                if (RECOMPUTE) {   // S = Q K^T for this block of 32 queries: the forward kernel's k-slice order
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sc[e] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < kAD / 16; ++kk) {
+                        const bf16x8 qf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(&sQ[(blk * 32 + col) * kLDT + kk * 16 + half * 8]));
+                        const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(&sKk[(wave * 32 + col) * kLDK + kk * 16 + half * 8]));
+                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sc, 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int q0 = blk * 32 + 8 * g4;  // + 4 * half + (0..3)
-                    pr[blk][g4] = lds_read_tr16(&sP[(q0 + trow) * kLDP2 + wave * 32 + tcol]);
+                    if (RECOMPUTE) {
+                        const f32x4 m4 = *reinterpret_cast<const f32x4*>(&sM[q0 + 4 * half]), il4 = *reinterpret_cast<const f32x4*>(&sIL[q0 + 4 * half]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            pr[blk][g4][i] = (short)f32_to_bf16(key_ok ? __expf(sc[4 * g4 + i] * a.scale - m4[i]) * il4[i] : 0.f);
+                    } else {
+                        pr[blk][g4] = lds_read_tr16(&sP[(q0 + trow) * kLDP2 + wave * 32 + tcol]);
+                    }
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[q0 + 4 * half]);
                     float s4[4];
 #pragma unroll
@@ -460,6 +516,38 @@ extern "C" int lp_attn_bwd_kv(const void* qkv_bf16, int ld_qkv, int v_off, const
     if (wgs >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     AttnBwdArgs a{(const unsigned short*)qkv_bf16, ld_qkv, v_off, (const unsigned short*)d_out_bf16, ld_do, (const unsigned short*)p_bf16, ldp,
                   d_rows, nh, T, ktiles, scale, (unsigned short*)ds_bf16, (unsigned short*)dqkv_bf16, ld_dqkv, dk_off, dv_off};
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+// Training forward WITHOUT the T x T tensor: O as lp_attn_fwd, plus (row maximum, 1 / exp-sum) per query for lp_attn_bwd_kv_lse
+extern "C" int lp_attn_fwd_lse(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, float* stats,
+                               void* out_bf16, int ldo, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(qkv_bf16 && out_bf16 && stats && B > 0 && nh > 0 && T > 0 && ldo >= nh * kAD && k_off >= 0 && v_off >= 0 && ld_qkv >= nh * kAD);
+    if (ld_qkv % 8 != 0 || k_off % 8 != 0 || v_off % 8 != 0 || ldo % 4 != 0) return LP_ERR_UNSUPPORTED;
+    const int qtiles = (T + kAQ - 1) / kAQ;
+    const long long wgs = (long long)B * nh * qtiles;
+    if (wgs >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    AttnArgs a{(const unsigned short*)qkv_bf16, ld_qkv, k_off, v_off, nh, T, qtiles, scale, nullptr, 8, (unsigned short*)out_bf16, ldo, stats};
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+// lp_attn_bwd_kv with the probabilities recomputed from Q, K and the forward's per-query statistics instead of read from memory
+extern "C" int lp_attn_bwd_kv_lse(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, const void* d_out_bf16, int ld_do, const float* stats,
+                                  const float* d_rows, int B, int nh, int T, float scale, void* ds_bf16, int ldp, void* dqkv_bf16, int ld_dqkv,
+                                  int dk_off, int dv_off, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(qkv_bf16 && d_out_bf16 && stats && d_rows && ds_bf16 && dqkv_bf16 && B > 0 && nh > 0 && T > 0 && ldp >= T && ld_qkv >= nh * kAD &&
+               ld_do >= nh * kAD && ld_dqkv >= nh * kAD && k_off >= 0 && v_off >= 0 && dk_off >= 0 && dv_off >= 0);
+    if (ld_qkv % 8 != 0 || k_off % 8 != 0 || v_off % 8 != 0 || ld_do % 8 != 0 || ldp % 8 != 0 || ld_dqkv % 4 != 0 || dk_off % 4 != 0 || dv_off % 4 != 0)
+        return LP_ERR_UNSUPPORTED;
+    const int ktiles = (ldp + kBK2 - 1) / kBK2;
+    const long long wgs = (long long)B * nh * ktiles;
+    if (wgs >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    AttnBwdArgs a{(const unsigned short*)qkv_bf16, ld_qkv, v_off, (const unsigned short*)d_out_bf16, ld_do, nullptr, ldp, d_rows, nh, T, ktiles, scale,
+                  (unsigned short*)ds_bf16, (unsigned short*)dqkv_bf16, ld_dqkv, dk_off, dv_off, stats, k_off};
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a);
     return launch_status();
 }
