@@ -428,6 +428,12 @@ int lp_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* mean
                           int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream);
 int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream);                       /* exact (erf) GELU */
 int lp_gelu_bwd(const void* x_bf16, const void* dy_bf16, size_t n, void* dx_bf16, lp_stream_t stream);
+/* The two producers of a Linear layer's dy in the ViT backward, leaving that layer's BIAS gradient (the column sums of the bf16 tensor they
+ * write, accumulated into colsum_acc) on the way: the weight gradient then needs no bias pass (lp_conv_wgrad instead of lp_conv_wgrad_bias). */
+int lp_gelu_bwd_colsum(const void* x_bf16, const void* dy_bf16, int rows, int cols, void* dx_bf16, float* colsum_acc, lp_stream_t stream);
+int lp_layernorm_bwd_bf16_colsum(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
+                                 int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, float* colsum_acc,
+                                 lp_stream_t stream);
 /* in place: s[r][:n] = softmax(scale * s[r][:n]), s[r][n:ld] = 0   /   dp <- scale * p * (dp - sum(dp * p)) */
 int lp_softmax_rows_fwd(void* s_bf16, int rows, int n, int ld, float scale, lp_stream_t stream);
 int lp_softmax_rows_bwd(const void* p_bf16, void* dp_bf16, int rows, int n, int ld, float scale, lp_stream_t stream);

@@ -133,6 +133,8 @@ PROTOTYPES = {
     "lp_layernorm_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "lp_gelu_fwd": (_I, [_P, _Z, _P, _P]),
     "lp_gelu_bwd": (_I, [_P, _P, _Z, _P, _P]),
+    "lp_gelu_bwd_colsum": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "lp_layernorm_bwd_bf16_colsum": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "lp_softmax_rows_fwd": (_I, [_P, _I, _I, _I, _F, _P]),
     "lp_softmax_rows_bwd": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "lp_transpose_batched": (_I, [_P, _I, _I, _I, C.c_longlong, C.c_longlong, _P, _I, C.c_longlong, C.c_longlong, _I, _I, _P]),

@@ -185,21 +185,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-workgroup partial d gamma / d beta -> atomics
+// COLSUM (round 3): also the column sums of the bf16 stream gradient it writes - that tensor is the dy of the NEXT Linear backward, and its
+// column sums are that layer's bias gradient: taken here, the weight gradient needs no bias pass and may run on the pipelined kernel.
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int M, int D, int drop_T,
                                                             float* __restrict__ dx, unsigned short* __restrict__ dx_bf16,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[2][4][256];  // [gamma|beta][wave][column of the current pass]
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ colsum) {
+    __shared__ float red[COLSUM ? 3 : 2][4][256];  // [gamma|beta|column sum][wave][column of the current pass]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pieces = D >> 2;
-    float ag[kLnPass][4], ab[kLnPass][4], gm[kLnPass][4];
+    float ag[kLnPass][4], ab[kLnPass][4], gm[kLnPass][4], ac[COLSUM ? kLnPass : 1][4];
 #pragma unroll
     for (int p = 0; p < kLnPass; ++p) {
         const int pc = lane + 64 * p;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             ag[p][e] = ab[p][e] = 0.f;
+            ac[COLSUM ? p : 0][e] = 0.f;
             gm[p][e] = pc < pieces ? gamma[pc * 4 + e] : 0.f;
         }
     }
@@ -249,6 +253,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
                     const u32x2_t w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                     *reinterpret_cast<u32x2_t*>(dx_bf16 + (size_t)row * D + pc * 4) = w;
+                    if (COLSUM) {   // of the values as stored (what a weight-gradient kernel summing dy would add up)
+                        ac[COLSUM ? p : 0][0] += bf16_to_f32((unsigned short)(w[0] & 0xffffu));
+                        ac[COLSUM ? p : 0][1] += bf16_to_f32((unsigned short)(w[0] >> 16));
+                        ac[COLSUM ? p : 0][2] += bf16_to_f32((unsigned short)(w[1] & 0xffffu));
+                        ac[COLSUM ? p : 0][3] += bf16_to_f32((unsigned short)(w[1] >> 16));
+                    }
                 }
             }
         }
@@ -262,6 +272,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
         for (int e = 0; e < 4; ++e) {
             red[0][wave][lane * 4 + e] = ag[p][e];
             red[1][wave][lane * 4 + e] = ab[p][e];
+            if (COLSUM) red[COLSUM ? 2 : 0][wave][lane * 4 + e] = ac[COLSUM ? p : 0][e];
         }
         __syncthreads();
         const int cl = threadIdx.x;            // column within this pass
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             const float tb = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
             atomicAdd(&dgamma[c], tg);
             atomicAdd(&dbeta[c], tb);
+            if (COLSUM) atomicAdd(&colsum[c], (red[COLSUM ? 2 : 0][0][cl] + red[COLSUM ? 2 : 0][1][cl]) + (red[COLSUM ? 2 : 0][2][cl] + red[COLSUM ? 2 : 0][3][cl]));
         }
     }
 }
@@ -300,6 +312,40 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const unsigned short* __r
 #pragma unroll
         for (int i = 0; i < 8; ++i) d[i] *= gelu_df(v[i]);
         *reinterpret_cast<u16x8*>(dx + q * 8) = pack_bf16x8(d);
+    }
+}
+
+// GELU backward of a [rows][cols] tensor that also leaves the column sums of what it writes (= the bias gradient of the Linear layer in front
+// of the activation).  grid = (column groups of 64 chunks, row blocks); a thread keeps ONE 8-column chunk and walks rows 4 apart.
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, int rows,
+                                                              int chunks, unsigned short* __restrict__ dx, float* __restrict__ colsum) {
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + lane;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (ch < chunks) {
+        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) {
+            const size_t q = (size_t)r * chunks + ch;
+            float v[8], d[8];
+            unpack8v(*reinterpret_cast<const u16x8*>(x + q * 8), v);
+            unpack8v(*reinterpret_cast<const u16x8*>(dy + q * 8), d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] *= gelu_df(v[i]);
+            const u16x8 w = pack_bf16x8(d);
+            *reinterpret_cast<u16x8*>(dx + q * 8) = w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += bf16_to_f32(w[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][lane][i] = acc[i];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 64 * 8; t += 256) {
+        const int l = t >> 3, i = t & 7;
+        const int c = (blockIdx.x * 64 + l) * 8 + i;
+        if (blockIdx.x * 64 + l < chunks) atomicAdd(&colsum[c], (red[0][l][i] + red[1][l][i]) + (red[2][l][i] + red[3][l][i]));
     }
 }
 
@@ -540,14 +586,19 @@ extern "C" int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x
 }
 
 static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M, int D,
-                              int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
+                              int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream,
+                              float* colsum_acc = nullptr) {
     using namespace lp;
     LP_REQUIRE(dy_bf16 && x && mean && rstd && gamma && dx_acc && dgamma_acc && dbeta_acc && M > 0 && D > 0 && drop_T >= 0);
     if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;  // 8 waves per SIMD; also bounds the d gamma / d beta atomics per column
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, rstd,
-                       gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc);
+    if (colsum_acc != nullptr)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean,
+                           rstd, gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc, colsum_acc);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean,
+                           rstd, gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc, nullptr);
     return launch_status();
 }
 
@@ -561,6 +612,14 @@ extern "C" int lp_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const 
                                      int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc, lp_stream_t stream) {
     LP_REQUIRE(dx_bf16);
     return layernorm_bwd_impl(dy_bf16, x, mean, rstd, gamma, M, D, drop_T, dx_acc, dx_bf16, dgamma_acc, dbeta_acc, stream);
+}
+
+// ... and the column sums of dx_bf16 accumulated into colsum_acc[D]: the bias gradient of the Linear layer whose dy that tensor is
+extern "C" int lp_layernorm_bwd_bf16_colsum(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma, int M,
+                                            int D, int drop_T, float* dx_acc, void* dx_bf16, float* dgamma_acc, float* dbeta_acc,
+                                            float* colsum_acc, lp_stream_t stream) {
+    LP_REQUIRE(dx_bf16 && colsum_acc);
+    return layernorm_bwd_impl(dy_bf16, x, mean, rstd, gamma, M, D, drop_T, dx_acc, dx_bf16, dgamma_acc, dbeta_acc, stream, colsum_acc);
 }
 
 extern "C" int lp_gelu_fwd(const void* x_bf16, size_t n, void* y_bf16, lp_stream_t stream) {
@@ -578,6 +637,19 @@ extern "C" int lp_gelu_bwd(const void* x_bf16, const void* dy_bf16, size_t n, vo
     if (n % 8 != 0) return LP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(vit_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16,
                        (const unsigned short*)dy_bf16, n / 8, (unsigned short*)dx_bf16);
+    return launch_status();
+}
+
+extern "C" int lp_gelu_bwd_colsum(const void* x_bf16, const void* dy_bf16, int rows, int cols, void* dx_bf16, float* colsum_acc, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x_bf16 && dy_bf16 && dx_bf16 && colsum_acc && rows > 0 && cols > 0);
+    if (cols % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const int chunks = cols / 8, gx = (chunks + 63) / 64;
+    int gy = (rows + 3) / 4;
+    const int cap = (256 * 8 + gx - 1) / gx;   // ~8 workgroups per CU; bounds the atomics per column
+    if (gy > cap) gy = cap;
+    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x_bf16,
+                       (const unsigned short*)dy_bf16, rows, chunks, (unsigned short*)dx_bf16, colsum_acc);
     return launch_status();
 }
 

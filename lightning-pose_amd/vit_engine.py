@@ -252,13 +252,16 @@ class ViTEngine(Engine):
             nbytes=2.0 * (M * l.K + M * l.N + l.N * l.K))
         return out
 
-    def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True):
-        """bias / weight gradients into G; returns dX = dY W (bf16) if wanted"""
+    def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True, bias_done: bool = False):
+        """bias / weight gradients into G; returns dX = dY W (bf16) if wanted.  ``bias_done``: the kernel that produced ``dy`` already left its
+        column sums in G (lp_gelu_bwd_colsum / lp_layernorm_bwd_bf16_colsum), so the weight gradient runs without the bias pass - which lets the
+        pipelined weight-gradient kernel take it."""
         rows, cols = self._wg_shape
         g = _lib.ConvGeom(1, rows, cols, l.K, rows, cols, l.N, 1, 1, 1, 0) if rows * cols == M else _lib.ConvGeom(1, 1, M, l.K, 1, M, l.N, 1, 1, 1, 0)
         # bias gradient = column sums of dy, same pass
-        self._timed("conv_wgrad_kernel<linear wgrad+bias>", 2.0 * M * l.N * l.K,
-                    lambda: self._wgrad(x, dy, g, self.G[l.w_off:], dbias=self.G[l.b_off:]), nbytes=2.0 * (M * l.K + M * l.N) + 4.0 * l.N * l.K)
+        self._timed("conv_wgrad_kernel<linear wgrad" + ("" if bias_done else "+bias") + ">", 2.0 * M * l.N * l.K,
+                    lambda: self._wgrad(x, dy, g, self.G[l.w_off:], dbias=None if bias_done else self.G[l.b_off:]),
+                    nbytes=2.0 * (M * l.K + M * l.N) + 4.0 * l.N * l.K)
         if not need_dx:
             return None
         dx = torch.empty(M, l.K, device=self.device, dtype=torch.bfloat16)
@@ -277,8 +280,15 @@ class ViTEngine(Engine):
                                          _p(mean), _p(rstd), ops._stream()), "lp_layernorm_fwd")
         return y, mean, rstd, (xo if xo is not None else x)
 
-    def _ln_bwd(self, dy, x, mean, rstd, l: LNP, M: int, dx, drop_T: int = 0, want_bf16: bool = False):
-        """dx (fp32, the residual stream's gradient) += LayerNorm backward of dy; ``want_bf16``: also return the updated dx in bf16"""
+    def _ln_bwd(self, dy, x, mean, rstd, l: LNP, M: int, dx, drop_T: int = 0, want_bf16: bool = False, colsum: torch.Tensor | None = None):
+        """dx (fp32, the residual stream's gradient) += LayerNorm backward of dy; ``want_bf16``: also return the updated dx in bf16;
+        ``colsum``: accumulate that bf16 tensor's column sums there (the bias gradient of the Linear layer it is the dy of)"""
+        if want_bf16 and colsum is not None:
+            out = torch.empty(M, self.plan.D, device=self.device, dtype=torch.bfloat16)
+            check(self._lib.lp_layernorm_bwd_bf16_colsum(_p(dy), _p(x), _p(mean), _p(rstd), _p(self.P[l.g_off:]), M, self.plan.D, drop_T, _p(dx),
+                                                         _p(out), _p(self.G[l.g_off:]), _p(self.G[l.b_off:]), _p(colsum), ops._stream()),
+                  "lp_layernorm_bwd_bf16_colsum")
+            return out
         if not want_bf16:
             check(self._lib.lp_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(self.P[l.g_off:]), M, self.plan.D, drop_T, _p(dx),
                                              _p(self.G[l.g_off:]), _p(self.G[l.b_off:]), ops._stream()), "lp_layernorm_bwd")
@@ -418,7 +428,10 @@ class ViTEngine(Engine):
             progress(pl.n_backbone)  # the head's gradients (the tail of the flat buffer) are complete
         dx = torch.zeros(M, D, device=dev, dtype=torch.float32)         # gradient of the residual stream
         # every LayerNorm backward also leaves the updated stream gradient in bf16: it is the operand of the next Linear backward
-        dx16 = self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn, want_bf16=True)
+        # ... and its column sums are the bias gradient of that layer (fc2 of the last block here), so no weight gradient needs a bias pass
+        fuse_bias = os.environ.get("LP_VIT_BIAS_FUSED", "1") != "0"
+        bsum = (lambda lin: self.G[lin.b_off:lin.b_off + lin.N]) if fuse_bias else (lambda lin: None)
+        dx16 = self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn, want_bf16=True, colsum=bsum(pl.layers[-1]["fc2"]))
 
         for i in range(pl.depth - 1, -1, -1):
             L = pl.layers[i]
@@ -427,14 +440,17 @@ class ViTEngine(Engine):
                 trace[f"l{i}.dout"] = dx.clone()
             # ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             dmlp = dx16
-            d_a1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M)
+            d_a1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M, bias_done=fuse_bias)
             d_h1 = torch.empty_like(d_a1)
-            check(self._lib.lp_gelu_bwd(_p(t("h1")), _p(d_a1), d_a1.numel(), _p(d_h1), ops._stream()), "lp_gelu_bwd")
-            d_y2 = self._linear_bwd(L["fc1"], t("y2"), d_h1, M)
-            dx16 = self._ln_bwd(d_y2, t("x_mid"), t("m2"), t("r2"), L["ln2"], M, dx, want_bf16=True)
+            if fuse_bias:
+                check(self._lib.lp_gelu_bwd_colsum(_p(t("h1")), _p(d_a1), M, pl.mlp, _p(d_h1), _p(bsum(L["fc1"])), ops._stream()), "lp_gelu_bwd_colsum")
+            else:
+                check(self._lib.lp_gelu_bwd(_p(t("h1")), _p(d_a1), d_a1.numel(), _p(d_h1), ops._stream()), "lp_gelu_bwd")
+            d_y2 = self._linear_bwd(L["fc1"], t("y2"), d_h1, M, bias_done=fuse_bias)
+            dx16 = self._ln_bwd(d_y2, t("x_mid"), t("m2"), t("r2"), L["ln2"], M, dx, want_bf16=True, colsum=bsum(L["proj"]))
             # ---- attention branch: x_mid = x_in + proj(softmax(Q K^T / 8) V)
             dproj = dx16
-            d_attn = self._linear_bwd(L["proj"], t("attn"), dproj, M)
+            d_attn = self._linear_bwd(L["proj"], t("attn"), dproj, M, bias_done=fuse_bias)
             qkv, Pm = t("qkv"), t("P")
             dqkv = torch.empty(M, qs, device=dev, dtype=torch.bfloat16)
             zP = (nh * Tn * Tp, Tn * Tp)       # batch strides of a [B][nh][Tn][Tp] tensor
@@ -461,7 +477,8 @@ class ViTEngine(Engine):
             if trace is not None:
                 trace[f"l{i}.dqkv"] = dqkv
             d_y1 = self._linear_bwd(L["qkv"], t("y1"), dqkv, M)
-            dx16 = self._ln_bwd(d_y1, t("x_in"), t("m1"), t("r1"), L["ln1"], M, dx, want_bf16=i > 0)
+            dx16 = self._ln_bwd(d_y1, t("x_in"), t("m1"), t("r1"), L["ln1"], M, dx, want_bf16=i > 0,
+                                colsum=bsum(pl.layers[i - 1]["fc2"]) if i > 0 else None)
             if progress is not None:
                 progress(L["ln1"].g_off)  # everything from this layer's first parameter to the end of G is final
         if trace is not None:
