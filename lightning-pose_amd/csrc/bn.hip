@@ -9,6 +9,8 @@
 //
 // Every kernel moves 16 B per lane (8 bf16 channels), keeps per-channel scale/shift in registers and reduces in
 // fp32.  Roofline: HBM; algorithmic bytes are listed per kernel in DESIGN.md.
+#include <stdlib.h>
+
 #include "lp_common.h"
 
 namespace lp {
@@ -502,6 +504,150 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned c
     }
 }
 
+// ---- round 3: the two backward passes with the pooled gradient and the arg-max bytes staged in LDS ---------------------------------
+// bn_pool_bwd_reduce_kernel / _apply_kernel gather dy and the arg-max byte of up to 4 windows per input pixel straight from global memory:
+// nine dependent-address loads per 16 B of z, 2.0 / 3.1 TB/s at any grid size (profiles/r03ab_pool.txt).  Here a workgroup walks a band of
+// output rows of one image; per output row ho it handles the input rows 2 ho and 2 ho + 1, whose windows lie in the output rows ho and ho + 1:
+// those two rows of dy (96 x 128 B) and of arg-max bytes (96 x 64 B) sit in LDS (row ho + 1 is loaded while row ho is still there: each is
+// read from memory once per band), the z loads of a step are 12 independent 16-B streams per thread, and the gather reads LDS.  C = 64 only
+// (the stem); other shapes keep the kernels above.  APPLY = false: the two reductions; true: dz.
+constexpr int kPbW = 96;   // widest pooled row staged (Wo <= 96: 384-px frames)
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
+                                                             const unsigned short* __restrict__ Z, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ sums_in, float inv_count,
+                                                             int B, int Hi, int Wi, int Ho, int Wo, int band, float* __restrict__ sums,
+                                                             float* __restrict__ acc0, float* __restrict__ acc1, unsigned short* __restrict__ DX) {
+    constexpr int C = 64, chunks = 8;
+    __shared__ __attribute__((aligned(16))) unsigned short sdy[2][kPbW * C];
+    __shared__ __attribute__((aligned(16))) unsigned char sidx[2][kPbW * C];
+    __shared__ float red[APPLY ? 1 : 2][APPLY ? 1 : 256][8];
+    const int ch = threadIdx.x % chunks, pl = threadIdx.x / chunks;   // 32 pixel lanes
+    float mu[8], is[8], sc[8], be[8], k0[8], k1[8], s0[8], s1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = ch * 8 + i;
+        mu[i] = mean[c];
+        is[i] = invstd[c];
+        sc[i] = is[i] * gamma[c];
+        be[i] = beta[c];
+        k0[i] = APPLY ? sums_in[c] * inv_count : 0.f;
+        k1[i] = APPLY ? sums_in[C + c] * inv_count : 0.f;
+        s0[i] = s1[i] = 0.f;
+    }
+    const int bands = (Ho + band - 1) / band;
+    auto stage_row = [&](int b, int ho, int slot) {   // pooled row ho of image b -> LDS slot (rows past the image: never read)
+        if (ho >= Ho) return;
+        const size_t base = ((size_t)b * Ho + ho) * Wo * C;
+        for (int q = threadIdx.x; q < Wo * chunks; q += 256) {
+            *reinterpret_cast<u16x8*>(&sdy[slot][q * 8]) = *reinterpret_cast<const u16x8*>(DY + base + (size_t)q * 8);
+            *reinterpret_cast<uint2*>(&sidx[slot][q * 8]) = *reinterpret_cast<const uint2*>(IDX + base + (size_t)q * 8);
+        }
+    };
+    for (int wgi = blockIdx.x; wgi < B * bands; wgi += gridDim.x) {
+        const int b = wgi / bands, ho0 = (wgi - b * bands) * band;
+        const int ho1 = ho0 + band < Ho ? ho0 + band : Ho;
+        __syncthreads();   // the previous band's rows are dead
+        stage_row(b, ho0, ho0 & 1);
+        for (int ho = ho0; ho < ho1; ++ho) {
+            stage_row(b, ho + 1, (ho + 1) & 1);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int hi = 2 * ho + r;
+                if (hi >= Hi) break;
+                const size_t rowbase = ((size_t)b * Hi + hi) * Wi;
+                for (int wi0 = 0; wi0 < Wi; wi0 += 32 * 6) {
+                    u16x8 zv[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int wi = wi0 + pl + 32 * k;
+                        if (wi < Wi) zv[k] = load_stream8(Z + (rowbase + wi) * C + ch * 8);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int wi = wi0 + pl + 32 * k;
+                        if (wi >= Wi) break;
+                        float z[8], g[8];
+                        unpack8(zv[k], z);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) g[i] = 0.f;
+                        // the (<= 4) windows that contain this pixel (a loop over the valid ones: reading all four unconditionally was slower -
+                        // these passes are VALU-bound, ~350 instructions per 16 B of z, profiles/r03ac_pool_v2.txt)
+                        const int hlo = ho, hhi = (r == 1 && ho + 1 < Ho) ? ho + 1 : ho;   // rows hi / 2 .. min(Ho - 1, (hi + 1) / 2)
+                        const int wlo = wi >> 1, whi = ((wi + 1) >> 1) < Wo ? ((wi + 1) >> 1) : Wo - 1;
+                        for (int hh = hlo; hh <= hhi; ++hh)
+                            for (int ww = wlo; ww <= whi; ++ww) {
+                                const unsigned mine = (unsigned)((hi - (hh * 2 - 1)) * 3 + (wi - (ww * 2 - 1)));
+                                const int o = (ww * chunks + ch) * 8;
+                                const uint2 packed = *reinterpret_cast<const uint2*>(&sidx[hh & 1][o]);
+                                float d[8];
+                                unpack8(*reinterpret_cast<const u16x8*>(&sdy[hh & 1][o]), d);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const unsigned a = ((i < 4 ? packed.x : packed.y) >> (8 * (i & 3))) & 0xffu;
+                                    if (a == mine) g[i] += d[i];
+                                }
+                            }
+                        if (APPLY) {
+                            float o8[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const float zc = z[i] - mu[i];
+                                if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
+                                o8[i] = sc[i] * (g[i] - k0[i] - zc * is[i] * k1[i]);
+                            }
+                            *reinterpret_cast<u16x8*>(DX + (rowbase + wi) * C + ch * 8) = pack8(o8);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const float zc = z[i] - mu[i];
+                                if (!(fmaf(zc, sc[i], be[i]) > 0x1p-134f)) g[i] = 0.f;
+                                s0[i] += g[i];
+                                s1[i] = fmaf(g[i], zc * is[i], s1[i]);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // row ho is dead: the next step's staging may overwrite its slot
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[0][threadIdx.x][i] = s0[i];
+            red[APPLY ? 0 : 1][threadIdx.x][i] = s1[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const int pc = threadIdx.x >> 3, pi = threadIdx.x & 7;
+            float t0 = 0.f, t1 = 0.f;
+            for (int q = 0; q < 32; ++q) {
+                t0 += red[0][q * chunks + pc][pi];
+                t1 += red[APPLY ? 0 : 1][q * chunks + pc][pi];
+            }
+            atomicAdd(&sums[threadIdx.x], t0);
+            atomicAdd(&sums[C + threadIdx.x], t1);
+            if (acc0) atomicAdd(&acc0[threadIdx.x], t0);  // d beta
+            if (acc1) atomicAdd(&acc1[threadIdx.x], t1);  // d gamma
+        }
+    }
+}
+
+static int pool_v2_band() {   // output rows per workgroup: 6 -> 16 bands per 96-row map, 1024 / 2048 workgroups for 64 / 128 frames = whole rounds
+    const char* e = getenv("LP_POOL_BAND");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 6;
+}
+
+static bool pool_v2_ok(int C, int Hi, int Wi, int Ho, int Wo) {
+    const char* e = getenv("LP_POOL_V2");
+    if (e != nullptr && atoi(e) == 0) return false;
+    return C == 64 && Wo <= kPbW && Hi <= 2 * Ho && Wi <= 2 * Wo;
+}
+
 // ---- images (B,3,H,W) fp32 NCHW -> (B,H,W,4) bf16, channel 3 = 0 ----------------------------------------------
 __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ X, int B, int HW, unsigned short* __restrict__ Y) {
     const size_t total = (size_t)B * HW;
@@ -741,6 +887,13 @@ extern "C" int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, cons
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     const long long pixels = (long long)B * Hi * Wi;
     if (pixels >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
+    if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) {
+        const int band = pool_v2_band(), wgs = B * ((Ho + band - 1) / band);   // one band per workgroup (4 resident per CU)
+        hipLaunchKernelGGL(bn_pool_bwd_v2_kernel<false>, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, nullptr,
+                           0.f, B, Hi, Wi, Ho, Wo, band, sums, dbeta_acc, dgamma_acc, nullptr);
+        return launch_status();
+    }
     hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pool_row_blocks(B * Hi, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi,
                        Wi, C, Ho, Wo, sums, dbeta_acc, dgamma_acc);
@@ -754,6 +907,13 @@ extern "C" int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const
     LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && count > 0.f);
     if (C % 8 != 0 || 256 % (C / 8) != 0 || (long long)B * Hi >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) {
+        const int band = pool_v2_band(), wgs = B * ((Ho + band - 1) / band);
+        hipLaunchKernelGGL(bn_pool_bwd_v2_kernel<true>, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
+                           1.f / count, B, Hi, Wi, Ho, Wo, band, nullptr, nullptr, nullptr, (unsigned short*)dx);
+        return launch_status();
+    }
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(pool_row_blocks(B * Hi)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
                        1.f / count, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
