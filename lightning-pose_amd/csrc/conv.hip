@@ -1566,7 +1566,8 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         stats_rows += tm;
         const long long seg_rows = bn ? seg_split_rows(bn->seg_images, g.B, (long long)lat.nh * lat.nw, M) : M;
         const int kind = pipe_dgrad_kind(ep);
-        if (kind >= 0 && pipe_eligible(ep, M, N, K, g.Co, seg_rows)) {
+        const bool full_lattice = lat.hstep == 1 && lat.wstep == 1;   // (kEkAZB recomputes its output offsets from the row index)
+        if (kind >= 0 && (kind != kEkAZB || full_lattice) && pipe_eligible(ep, M, N, K, g.Co, seg_rows)) {
             if (N > 64) launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
             else launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);
         } else if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);

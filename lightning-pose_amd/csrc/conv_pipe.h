@@ -507,8 +507,11 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     constexpr int PH = 16 / RP;          // read-back passes per 16-pixel half
     constexpr int NPC = 2 * PH;          // pieces (8 channels of one row) per lane and 32-pixel chunk
     constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain), kLz = (EK != kEkNone), kLb = (EK == kEkAZB);
+    // (kEkAZB - the hottest data gradient, at the register cap - does not keep the output offsets of its pieces: its launches cover the full
+    //  pixel lattice (host-checked), so an offset is two multiply-adds away and is recomputed in rb_process: 8 VGPRs, the 7 it used to spill)
+    constexpr bool kKeepOff = EK != kEkAZB;
     struct ReadBack {
-        unsigned off[NPC];
+        unsigned off[kKeepOff ? NPC : 1];
         u16x8 la[kLa ? NPC : 1];   // addend
         u16x8 lz[kLz ? NPC : 1];   // z (kEkZ, kEkAZB) or the activation used as ReLU mask (kEkPlain)
         unsigned lb[kLb ? NPC : 1];
@@ -520,15 +523,16 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         for (int p = 0; p < NPC; ++p) {
             const int m = m0 + wm * 64 + mt * 32 + (p / PH) * 16 + (p % PH) * RP + prow;
             const bool rv = m < M;
-            rb.off[p] = rv ? (unsigned)out_row(m, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8) : ~0u;
-            const unsigned o = rv ? rb.off[p] : (unsigned)(nbase + pc * 8);   // (rows past M: any valid address, the result is not stored)
+            const unsigned off_p = rv ? (unsigned)(kKeepOff ? out_row(m, lat, div_img, div_row, full_h, full_w) : m) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8) : ~0u;
+            if (kKeepOff) rb.off[kKeepOff ? p : 0] = off_p;
+            const unsigned o = rv ? off_p : (unsigned)(nbase + pc * 8);   // (rows past M: any valid address, the result is not stored)
             if (EK == kEkAZB || (EK == kEkPlain && ep.addend)) rb.la[kLa ? p : 0] = load8_stream(ep.addend + o);
             if (bwd) rb.lz[p] = load8(ep.bn_z + o);
             if (EK == kEkPlain && ep.relu_mask) rb.lz[p] = load8_stream(ep.relu_mask + o);
             if (EK == kEkAZB) rb.lb[kLb ? p : 0] = ep.relu_bits[o >> 3];
         }
     };
-    auto rb_process = [&](const ReadBack& rb, const int mt, unsigned char* stg_all) {
+    auto rb_process = [&](const ReadBack& rb, const int mt, unsigned char* stg_all, const int m0, const int n0) {
         constexpr int ROWF = NT * 128 + 16;   // fp32 row of the wave's channels + pad
         unsigned char* stg = stg_all + wave * (16 * ROWF);
 #pragma unroll
@@ -553,7 +557,14 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #pragma unroll
             for (int ps = 0; ps < PH; ++ps) {
                 const int p = h * PH + ps;
-                if (rb.off[p] != ~0u) {
+                unsigned off_p;
+                if (kKeepOff) {
+                    off_p = rb.off[kKeepOff ? p : 0];
+                } else {
+                    const int m = m0 + wm * 64 + mt * 32 + h * 16 + ps * RP + prow;
+                    off_p = m < M ? (unsigned)m * (unsigned)ep.ldo + (unsigned)(n0 + wn * (NT * 32) + pc * 8) : ~0u;
+                }
+                if (off_p != ~0u) {
                     float v[8] = {lo_[ps][0], lo_[ps][1], lo_[ps][2], lo_[ps][3], hi_[ps][0], hi_[ps][1], hi_[ps][2], hi_[ps][3]};
                     if (EK == kEkAZB || (EK == kEkPlain && ep.addend)) {
 #pragma unroll
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                             if (!((rb.lb[kLb ? p : 0] >> q) & 1u)) v[q] = 0.f;
                     }
                     const u16x8 w = pack_bf16x8(v);
-                    store8(ep.out_bf16 + rb.off[p], w, (flags & 2) != 0);
+                    store8(ep.out_bf16 + off_p, w, (flags & 2) != 0);
                     if (want_stats) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -680,8 +691,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             epilogue_fwd(m0, n0, stg_all);
         } else {
             rb_issue(rb1, 1, m0, n0);
-            rb_process(rb0, 0, stg_all);
-            rb_process(rb1, 1, stg_all);
+            rb_process(rb0, 0, stg_all, m0, n0);
+            rb_process(rb1, 1, stg_all, m0, n0);
         }
     }
     if (want_stats) stats_flush(reinterpret_cast<float*>(free_lds()));
