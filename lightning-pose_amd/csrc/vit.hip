@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-workgroup partial d gamma / d beta -> atomics
 // COLSUM (round 3): also the column sums of the bf16 stream gradient it writes - that tensor is the dy of the NEXT Linear backward, and its
 // column sums are that layer's bias gradient: taken here, the weight gradient needs no bias pass and may run on the pipelined kernel.
-template <bool COLSUM>
+// NP = passes of 64 lanes x 4 columns that cover D (2 for ViT-S: the accumulators of unused passes would cost a wave of occupancy per SIMD)
+template <bool COLSUM, int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int M, int D, int drop_T,
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     __shared__ float red[COLSUM ? 3 : 2][4][256];  // [gamma|beta|column sum][wave][column of the current pass]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pieces = D >> 2;
-    float ag[kLnPass][4], ab[kLnPass][4], gm[kLnPass][4], ac[COLSUM ? kLnPass : 1][4];
+    float ag[NP][4], ab[NP][4], gm[NP][4], ac[COLSUM ? NP : 1][4];
 #pragma unroll
-    for (int p = 0; p < kLnPass; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int pc = lane + 64 * p;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -216,10 +217,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             yrow = b * (drop_T - 1) + t - 1;
         }
         const float mu = mean[row], rs = rstd[row];
-        float g[kLnPass][4], xh[kLnPass][4];
+        float g[NP][4], xh[NP][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int p = 0; p < kLnPass; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int pc = lane + 64 * p;
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[p][e] = xh[p][e] = 0.f;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int p = 0; p < kLnPass; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int pc = lane + 64 * p;
             if (pc < pieces) {
                 f32x4* dst = reinterpret_cast<f32x4*>(dx + (size_t)row * D + pc * 4);
@@ -253,11 +254,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
                     const u32x2_t w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                     *reinterpret_cast<u32x2_t*>(dx_bf16 + (size_t)row * D + pc * 4) = w;
-                    if (COLSUM) {   // of the values as stored (what a weight-gradient kernel summing dy would add up)
-                        ac[COLSUM ? p : 0][0] += bf16_to_f32((unsigned short)(w[0] & 0xffffu));
-                        ac[COLSUM ? p : 0][1] += bf16_to_f32((unsigned short)(w[0] >> 16));
-                        ac[COLSUM ? p : 0][2] += bf16_to_f32((unsigned short)(w[1] & 0xffffu));
-                        ac[COLSUM ? p : 0][3] += bf16_to_f32((unsigned short)(w[1] >> 16));
+                    if (COLSUM) {   // (of the fp32 values: the reference's bias gradient sums the unrounded dy)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ac[COLSUM ? p : 0][e] += o[e];
                     }
                 }
             }
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     }
     // column sums of this workgroup: 4 waves -> LDS -> one atomic per column, one 256-column pass at a time
 #pragma unroll
-    for (int p = 0; p < kLnPass; ++p) {
+    for (int p = 0; p < NP; ++p) {
         if (64 * p >= pieces) break;
         __syncthreads();
 #pragma unroll
@@ -333,10 +332,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const unsigned sho
             unpack8v(*reinterpret_cast<const u16x8*>(dy + q * 8), d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) d[i] *= gelu_df(v[i]);
-            const u16x8 w = pack_bf16x8(d);
-            *reinterpret_cast<u16x8*>(dx + q * 8) = w;
+            *reinterpret_cast<u16x8*>(dx + q * 8) = pack_bf16x8(d);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += bf16_to_f32(w[i]);
+            for (int i = 0; i < 8; ++i) acc[i] += d[i];   // (fp32: the reference's bias gradient sums the unrounded dy)
         }
     }
 #pragma unroll
@@ -593,12 +591,22 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* 
     if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;  // 8 waves per SIMD; also bounds the d gamma / d beta atomics per column
-    if (colsum_acc != nullptr)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean,
-                           rstd, gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc, colsum_acc);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean,
-                           rstd, gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc, nullptr);
+#define LP_LN_BWD(CS_, NP_)                                                                                                                   \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<CS_, NP_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, \
+                       rstd, gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc, colsum_acc)
+    const int np = (D + 255) / 256;
+    if (colsum_acc != nullptr) {
+        if (np == 1) LP_LN_BWD(true, 1);
+        else if (np == 2) LP_LN_BWD(true, 2);
+        else if (np == 3) LP_LN_BWD(true, 3);
+        else LP_LN_BWD(true, 4);
+    } else {
+        if (np == 1) LP_LN_BWD(false, 1);
+        else if (np == 2) LP_LN_BWD(false, 2);
+        else if (np == 3) LP_LN_BWD(false, 3);
+        else LP_LN_BWD(false, 4);
+    }
+#undef LP_LN_BWD
     return launch_status();
 }
 
