@@ -509,9 +509,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned c
 // nine dependent-address loads per 16 B of z, 2.0 / 3.1 TB/s at any grid size (profiles/r03ab_pool.txt).  Here a workgroup walks a band of
 // output rows of one image; per output row ho it handles the input rows 2 ho and 2 ho + 1, whose windows lie in the output rows ho and ho + 1:
 // those two rows of dy (96 x 128 B) and of arg-max bytes (96 x 64 B) sit in LDS (row ho + 1 is loaded while row ho is still there: each is
-// read from memory once per band), the z loads of a step are 12 independent 16-B streams per thread, and the gather reads LDS.  C = 64 only
+// read from memory once per band), and the gather reads LDS.  z is fetched LP_POOL_ZU = 2 chunks ahead per thread: with 6 in flight the
+// kernel needed 195 VGPRs (2 waves per SIMD) and ran at 2.3 / 3.4 TB/s, with 2 it needs 115 and runs at 3.2 / 4.6 (profiles/r03ag_pool_zu.txt:
+// reduce 418 -> 260 us, apply 452 -> 314 us per 128 frames against the gather-from-memory kernels).  C = 64 only
 // (the stem); other shapes keep the kernels above.  APPLY = false: the two reductions; true: dz.
 constexpr int kPbW = 96;   // widest pooled row staged (Wo <= 96: 384-px frames)
+#ifndef LP_POOL_ZU
+#define LP_POOL_ZU 2
+#endif
 template <bool APPLY>
 __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
                                                              const unsigned short* __restrict__ Z, const float* __restrict__ mean,
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
                                                              int B, int Hi, int Wi, int Ho, int Wo, int band, float* __restrict__ sums,
                                                              float* __restrict__ acc0, float* __restrict__ acc1, unsigned short* __restrict__ DX) {
     constexpr int C = 64, chunks = 8;
+    constexpr int kZU = LP_POOL_ZU;   // z chunks in flight per thread
     __shared__ __attribute__((aligned(16))) unsigned short sdy[2][kPbW * C];
     __shared__ __attribute__((aligned(16))) unsigned char sidx[2][kPbW * C];
     __shared__ float red[APPLY ? 1 : 2][APPLY ? 1 : 256][8];
@@ -558,15 +564,15 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
                 const int hi = 2 * ho + r;
                 if (hi >= Hi) break;
                 const size_t rowbase = ((size_t)b * Hi + hi) * Wi;
-                for (int wi0 = 0; wi0 < Wi; wi0 += 32 * 6) {
-                    u16x8 zv[6];
+                for (int wi0 = 0; wi0 < Wi; wi0 += 32 * kZU) {
+                    u16x8 zv[kZU];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
+                    for (int k = 0; k < kZU; ++k) {
                         const int wi = wi0 + pl + 32 * k;
                         if (wi < Wi) zv[k] = load_stream8(Z + (rowbase + wi) * C + ch * 8);
                     }
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
+                    for (int k = 0; k < kZU; ++k) {
                         const int wi = wi0 + pl + 32 * k;
                         if (wi >= Wi) break;
                         float z[8], g[8];
