@@ -668,6 +668,11 @@ struct TnExt {
 // wgrad_reduce_kernel then sums the slices in a fixed order and adds the result into dW - deterministic, and ~20x
 // cheaper than fp32 atomics (measured: 17 M atomics per launch cost 450 us, the same bytes as plain stores ~20 us).
 // ------------------------------------------------------------------------------------------------------------
+#ifndef LP_WGRAD_DEEP
+#define LP_WGRAD_DEEP 1
+#endif
+constexpr bool kWgradDeep = LP_WGRAD_DEEP != 0;   // (build-time A/B switch)
+
 template <int BN, bool STEM, bool CS = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                          unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int Kw, int tiles,
@@ -730,7 +735,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
-    u16x8 ra[4], rb[RB];
+    u16x8 ra[4], rb[RB];     // the K step in flight ...
+    u16x8 ra2[4], rb2[RB];   // ... and, on the two-deep path below, the one after it
     const int hw = g.Ho * g.Wo;
     const bool want_cs = CS && j0 == 0;  // workgroup-uniform (CS: the instantiation that also takes dy's column sums)
     float cs[8];
@@ -765,10 +771,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     }
     const unsigned jinv = jv ? 0u : ~0u;
 
-    auto load_fast = [&](int mk) {  // whole K step inside [m_begin, m_end)
+    // (NM = nomask as a compile-time constant: with both forms in one loop body the two register sets of the two-deep path below
+    // meet in phi copies and every store waits for all loads)
+    auto load_fast = [&](auto nm_c, int mk, u16x8 (&ra)[4], u16x8 (&rb)[RB]) {  // whole K step inside [m_begin, m_end)
+        constexpr bool NM = decltype(nm_c)::value;
         const unsigned step = (unsigned)(mk - m_begin);
         const unsigned soffA = step * ci2, soffB = step * (unsigned)pitch_y * 2u;
-        if (nomask) {
+        if (NM) {
             // (TN-GEMM mode takes its ragged last step here too: rows >= m_end get the offset ~0 and read zeros)
             const bool ragged = mk + kBK > m_end;
 #pragma unroll
@@ -776,10 +785,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
                 const unsigned rinv = (ragged && mk + pgA * 4 + i >= m_end) ? ~0u : 0u;
                 ra[i] = buf_load16(rsrc_x, (voffA + i * ci2) | jinv | rinv, soffA);
             }
-            if (ragged) {
 #pragma unroll
-                for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rsrc_dy, voffB[i] | ((mk + pgB * RB + i >= m_end) ? ~0u : 0u), soffB);
-                return;
+            for (int i = 0; i < RB; ++i) {
+                const unsigned rinv = (ragged && mk + pgB * RB + i >= m_end) ? ~0u : 0u;
+                rb[i] = buf_load16(rsrc_dy, voffB[i] | rinv, soffB);
             }
         } else {
 #pragma unroll
@@ -802,12 +811,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
             }
             if (fho >= g.Ho) fho -= g.Ho;
             if (fho >= g.Ho) fho -= g.Ho;
-        }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rsrc_dy, voffB[i], soffB);
+            for (int i = 0; i < RB; ++i) rb[i] = buf_load16(rsrc_dy, voffB[i], soffB);
+        }
     };
 
-    auto load_generic = [&](int mk) {
+    auto load_generic = [&](int mk, u16x8 (&ra)[4], u16x8 (&rb)[RB]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mk + pgA * 4 + i;
@@ -832,11 +841,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
         }
     };
     auto load_step = [&](int mk) {
-        if (fast && (direct || mk + kBK <= m_end)) load_fast(mk);
-        else load_generic(mk);
+        if (fast && (direct || mk + kBK <= m_end)) {
+            if (nomask) load_fast(std::true_type{}, mk, ra, rb);
+            else load_fast(std::false_type{}, mk, ra, rb);
+        } else load_generic(mk, ra, rb);
     };
-    auto store_step = [&](int buf, int mk) {
-        (void)mk;
+    auto store_step = [&](int buf, const u16x8 (&ra)[4], const u16x8 (&rb)[RB]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(&sA[buf][(pgA * 4 + i) * LDA + jc * 8]) = ra[i];
 #pragma unroll
@@ -884,15 +894,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const unsigned short* _
     };
 
     const int KT = (m_end - m_begin + kBK - 1) / kBK;
-    if (KT > 0) {
+    // Two K steps in flight (register sets ra / ra2) where every step takes the fast loads: the HBM-bound shapes (the 1x1 layers of
+    // layer1 / layer2: 25 KB per step against 512 MFMA cycles) are bound by the bytes a CU keeps in flight, and with one step per
+    // workgroup that is 2 x 25 KB.  The loop is unrolled by two so that each set is a fixed array (a store of one set waits with a counted
+    // vmcnt while the other set's loads stay in flight).
+    const bool deep = kWgradDeep && fast && KT >= 2 && (direct || (m_end - m_begin) % kBK == 0);
+    auto deep_loop = [&](auto nm) {
+        load_fast(nm, m_begin, ra, rb);
+        load_fast(nm, m_begin + kBK, ra2, rb2);
+        store_step(0, ra, rb);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 3 < KT; kt += 2) {   // buffer 0 holds step kt, set 2 step kt + 1
+            load_fast(nm, m_begin + (kt + 2) * kBK, ra, rb);
+            mma_step(0);
+            store_step(1, ra2, rb2);
+            __syncthreads();
+            load_fast(nm, m_begin + (kt + 3) * kBK, ra2, rb2);
+            mma_step(1);
+            store_step(0, ra, rb);
+            __syncthreads();
+        }
+        const bool three = kt + 2 < KT;   // two or three steps left
+        if (three) load_fast(nm, m_begin + (kt + 2) * kBK, ra, rb);
+        mma_step(0);
+        store_step(1, ra2, rb2);
+        __syncthreads();
+        mma_step(1);
+        if (three) {
+            store_step(0, ra, rb);
+            __syncthreads();
+            mma_step(0);
+        }
+        __syncthreads();
+    };
+    if (deep) {
+        if (nomask) deep_loop(std::true_type{});
+        else deep_loop(std::false_type{});
+    } else if (KT > 0) {
         load_step(m_begin);
-        store_step(0, m_begin);
+        store_step(0, ra, rb);
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < KT) load_step(m_begin + (kt + 1) * kBK);
             mma_step(cur);
-            if (kt + 1 < KT) store_step(cur ^ 1, m_begin + (kt + 1) * kBK);
+            if (kt + 1 < KT) store_step(cur ^ 1, ra, rb);
             __syncthreads();
         }
     }
