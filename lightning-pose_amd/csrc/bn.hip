@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
                         unpack8(zv[k], z);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) g[i] = 0.f;
-                        // the (<= 4) windows that contain this pixel (a loop over the valid ones: reading all four unconditionally was slower -
-                        // these passes are VALU-bound, ~350 instructions per 16 B of z, profiles/r03ac_pool_v2.txt)
+                        // the (<= 4) windows that contain this pixel (a loop over the valid ones: reading all four unconditionally was slower,
+                        // ~350 instructions per 16 B of z, profiles/r03ac_pool_v2.txt)
                         const int hlo = ho, hhi = (r == 1 && ho + 1 < Ho) ? ho + 1 : ho;   // rows hi / 2 .. min(Ho - 1, (hi + 1) / 2)
                         const int wlo = wi >> 1, whi = ((wi + 1) >> 1) < Wo ? ((wi + 1) >> 1) : Wo - 1;
                         for (int hh = hlo; hh <= hhi; ++hh)
