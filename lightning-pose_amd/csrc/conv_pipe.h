@@ -448,7 +448,16 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 
     // ---- forward store pass of the tile at (m0, n0): per wave, 2 chunks of 32 pixels through a private bf16 corner; lane (pixel fr,
     // half fg) holds for block nt the channels nt*32 + 8 j + 4 fg + (0..3) in acc[mt][nt][4 j .. 4 j + 3]
+    // (Measured and dropped, profiles/r03al_store_pass_cost.txt + r03am_lazy_layers.txt.  In the open this pass costs ~1600 cycles per wave
+    // and tile whatever K is: 45 % on top of a K = 256 tile (timing builds LP_EXP_SKIP_FWD_*: 7.32 ms of forward launches per step, 6.53
+    // without the global stores, 7.08 without the sums, 5.74 without the pass).  Converting the accumulators at the end of a tile and running
+    // the rest - a 2-KB corner per wave outside the ring, 16 units: write / read / store + sums twice per 16-pixel chunk - one unit after
+    // the MFMAs of each k-slice of the NEXT tile came out SLOWER in every layer (l3.c3 106 -> 123..132 us, l1.c3 246 -> 355, step 44.6 ->
+    // 45.4 ms): two waves' units are ~400 VALU cycles per k-slice against 256 cycles of matrix pipe, and they share the issue port.)
     auto epilogue_fwd = [&](const int m0, const int n0, unsigned char* stg_all) {
+#ifdef LP_EXP_SKIP_FWD_STORE   // (timing experiment only: what the forward store pass costs - results are not written)
+        if (ep.ldo > 0) return;
+#endif
         const int nbase = n0 + wn * (NT * 32);   // first channel of this wave
         constexpr int ROWB = NT * 64 + 16;       // bf16 chunk row + pad (16-B aligned)
         unsigned char* stg = stg_all + wave * (32 * ROWB);
@@ -483,7 +492,13 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                 const int m = m0 + wm * 64 + mt * 32 + row;
                 if (m < M) {
                     const unsigned off = (unsigned)out_row(m, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8);
+#ifdef LP_EXP_SKIP_FWD_GSTORE
+                    if (ep.ldo < 0)
+#endif
                     store8(ep.out_bf16 + off, w, (flags & 2) != 0);
+#ifdef LP_EXP_SKIP_FWD_STATS
+                    if (ep.ldo < 0)
+#endif
                     if (want_stats) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
