@@ -11,10 +11,15 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 python profiles/summarize_pmc.py /tmp/r03_pmc_fetch/fetch_results.db /tmp/r03_pmc_write/write_results.db > gpurun_out/r03_pmc_traffic.json 2> gpurun_out/r03_pmc_traffic.err; head -4 gpurun_out/r03_pmc_traffic.json
 python profiles/summarize_pmc_sq.py /tmp/r03_pmc_sq/sq_results.db > gpurun_out/r03_pmc_mfma.json 2> gpurun_out/r03_pmc_mfma.err; tail -2 gpurun_out/r03_pmc_mfma.err
 cp gpurun_out/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
-LP_DUMP_LAUNCHES=gpurun_out/r03_final_launches.json timeout 900 python bench.py > gpurun_out/r03_final_bench_n1.json.log 2>&1; tail -1 gpurun_out/r03_final_bench_n1.json.log | cut -c1-330
+timeout 900 python bench.py > gpurun_out/r03_final_bench_n1.json.log 2>&1; tail -1 gpurun_out/r03_final_bench_n1.json.log | cut -c1-330
+# (the per-layer table from a headline-only run: the default run's secondary configurations overwrite the launch dump)
+LP_DUMP_LAUNCHES=gpurun_out/r03_final_launches.json timeout 300 python bench.py --no-cpu-baseline --no-secondary --steps 5 > gpurun_out/r03_final_bench_layers.json.log 2>&1
 python profiles/layer_table.py gpurun_out/r03_final_launches.json > gpurun_out/r03_final_layer_table.txt 2>&1; tail -1 gpurun_out/r03_final_layer_table.txt
 timeout 300 python bench.py --no-cpu-baseline --no-profile --no-secondary --steps 12 > gpurun_out/r03_final_bench_noprofile.json.log 2>&1; tail -1 gpurun_out/r03_final_bench_noprofile.json.log | cut -c80-160
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r03_final_prof -o dflt -- python bench.py --no-cpu-baseline --no-profile --no-secondary --steps 8 --warmup 2 > gpurun_out/r03_final_prof.log 2>&1
 python profiles/summarize_rocpd.py /tmp/r03_final_prof/dflt_results.db > gpurun_out/r03_final_kernel_stats.txt 2>&1
 LP_WGRAD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r03_final_prof_serial -o serial -- python bench.py --no-cpu-baseline --no-profile --no-secondary --steps 8 --warmup 2 > gpurun_out/r03_final_prof_serial.log 2>&1
 python profiles/summarize_rocpd.py /tmp/r03_final_prof_serial/serial_results.db > gpurun_out/r03_final_kernel_stats_serial.txt 2>&1; head -12 gpurun_out/r03_final_kernel_stats_serial.txt | cut -c1-60,110-160
+python profiles/gap_analysis.py /tmp/r03_final_prof/dflt_results.db > gpurun_out/r03_final_gap_analysis.txt 2>&1; head -9 gpurun_out/r03_final_gap_analysis.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r03_final_vit -o vit -- python bench.py --backbone vits_dino --no-cpu-baseline --no-profile --no-secondary --steps 6 --warmup 2 > gpurun_out/r03_final_vit_prof.log 2>&1
+python profiles/summarize_rocpd.py /tmp/r03_final_vit/vit_results.db > gpurun_out/r03_final_vit_kernel_stats.txt 2>&1; head -3 gpurun_out/r03_final_vit_kernel_stats.txt | cut -c1-60,110-160
