@@ -32,8 +32,11 @@ TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, a
 # maps whose peak is < 0.05); c2full bf16-mixed - mean 0.17 / 0.11 px = the policy's own 0.18 / 0.11, 99 % within 0.9 px, and the same handful
 # of two-peak maps on which the reference's arithmetic under the policy jumps too (policy max 67 px, product 66 px on the same map).  Those few
 # jumps are what moves the temporal loss (a mean of frame-to-frame distances) by 1.7 % at full batch.
+# Run to run on the device (BatchNorm sums through fp32 atomics, in both executors) the 99.9th percentile of c2full fp32 was 1.9e-3, 3.1e-3 and
+# 4.8e-3 px (profiles/r03_flake4.log, r03m_parity_dist.jsonl) - the six worst of ~6000 coordinates, on maps whose peak is just above PEAK_MIN -
+# so the bulk bar sits at the 99th percentile and the 99.9th is bounded separately (1.5e-2 px = 4e-5 of the frame).
 BIG = 500                                  # keypoints per fixture from which the tail rules apply
-TAIL = {"fp32": dict(q=0.999, max=0.05), "bf16-mixed": dict(q=0.99, frac_over=0.005)}
+TAIL = {"fp32": dict(q=0.99, q_hi=(0.999, 1.5e-2), max=0.05), "bf16-mixed": dict(q=0.99, frac_over=0.005)}
 SCALAR_REL = {"c2full": 3e-2}              # temporal / pca / total of the bf16-mixed path (default 1.5e-2)
 # Parameter gradients at BASELINE's real batch under the bf16-mixed POLICY itself - the reference's arithmetic rounded where the product rounds,
 # torch autograd on the device (profiles/policy_grad_full.py -> profiles/r03_policy_grad_c2full.json): the stem's weight gradient (the end of a
@@ -169,6 +172,8 @@ def _check(name, dev, precision, g):
                 tail = TAIL[precision] if err.numel() >= BIG else None
                 bulk = float(err.quantile(tail["q"])) if tail else float(err.max())
                 assert bulk <= t["kp_max"] and float(err.mean()) <= t["kp_mean"], (tag, key, bulk, float(err.max()), float(err.mean()))
+                if tail and "q_hi" in tail:
+                    assert float(err.quantile(tail["q_hi"][0])) <= tail["q_hi"][1], (tag, key, float(err.quantile(tail["q_hi"][0])))
                 if tail and "max" in tail:
                     assert float(err.max()) <= tail["max"], (tag, key, float(err.max()))
                 if tail and "frac_over" in tail:
@@ -210,7 +215,14 @@ def _check(name, dev, precision, g):
             # was summed at instead: the layer's weight gradient.
             ok = float((a - b).norm()) <= (1e-5 if precision == "fp32" else 2e-3) * float(g.t(wk).norm())
         assert ok, (k, cos, float(a.norm()), float(b.norm()))
-    worst, worst_name = max((abs(float(grads[n_].norm()) / (w + 1e-30) - 1.0), n_) for n_, w in norms.items() if w > 1e-6)
+    def cancels(n_):   # a bias gradient below 1 % of its layer's weight gradient (see above): held to an absolute error on that scale instead
+        wk_ = n_[:-len("bias")] + "weight"
+        return n_.endswith(".bias") and wk_ in norms and norms[n_] < 1e-2 * norms[wk_]
+    for n_, w in norms.items():
+        if w > 1e-6 and cancels(n_):   # (c2full's first deconvolution bias: 0.012 against 4.27 - its norm ratio wandered 0.2 .. 0.36 over runs)
+            dn = abs(float(grads[n_].norm()) - w)
+            assert dn < t["norm_worst"] * w or dn <= (1e-5 if precision == "fp32" else 2e-3) * norms[n_[:-len("bias")] + "weight"], (n_, dn, w)
+    worst, worst_name = max((abs(float(grads[n_].norm()) / (w + 1e-30) - 1.0), n_) for n_, w in norms.items() if w > 1e-6 and not cancels(n_))
     assert worst < t["norm_worst"], (worst, worst_name, norms[worst_name])
     print("\nPARITY", name, precision, REPORT[-4:], "worst gradient-norm ratio - 1:", round(worst, 4), worst_name, "%.2e" % norms[worst_name])
     return model
