@@ -284,7 +284,8 @@ size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad);
  * after a convolution is folded into it once per set of weights - lp_bn_fold: w_bf16[co][:] = bf16(w[co][:] * a[co]),
  * bias[co] = beta[co] - running_mean[co] * a[co], a = gamma / sqrt(running_var + eps) - and the layer becomes ONE launch,
  * lp_conv_fwd_act: out = [relu](conv(x, w_bf16) + bias + residual), residual = the block's identity / shortcut (bf16, layout of out)
- * or NULL.  No BatchNorm pass, no pre-normalisation tensor, nothing kept for a backward pass. */
+ * or NULL.  No BatchNorm pass, no pre-normalisation tensor, nothing kept for a backward pass.  Runs on conv_pipe_kernel<.., kEkInfer> where
+ * the training forward would (LP_INFER_PIPE=0: conv_igemm_kernel<infer>); there the residual and the ReLU act on bf16(accumulator + bias). */
 int lp_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                int Co, int per_co, void* w_bf16, float* bias, lp_stream_t stream);
 int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, const void* residual_bf16, int relu,

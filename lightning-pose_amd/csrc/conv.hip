@@ -1465,8 +1465,23 @@ extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom*
     ep.out_bf16 = (unsigned short*)out_bf16, ep.ldo = N, ep.n_store = N, ep.bias = bias;
     ep.addend = (const unsigned short*)residual_bf16, ep.relu_fwd = relu != 0;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    if (N > 64) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
-    else launch_igemm<64, kModeInfer>(x, w, g, lat, M, N, K, ep, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    // the pipelined forward kernel with the residual and the ReLU in its store pass (LP_INFER_PIPE=0: A/B runs keep conv_igemm_kernel<infer>)
+    const char* ip = getenv("LP_INFER_PIPE");
+    if ((ip == nullptr || atoi(ip) != 0) && pipe_eligible(ep, M, N, K, g.Ci, M, true)) {
+        if (N > 64) {
+            if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkInfer, true>(x, w, g, lat, M, N, K, ep, st);
+            else launch_pipe<128, kModeFwd, kEkInfer>(x, w, g, lat, M, N, K, ep, st);
+        } else if (pipe_halo_ok(g, M, g.Ci, 512)) {
+            launch_pipe<64, kModeFwd, kEkInfer, true>(x, w, g, lat, M, N, K, ep, st);
+        } else {
+            launch_pipe<64, kModeFwd, kEkInfer>(x, w, g, lat, M, N, K, ep, st);
+        }
+        return launch_status();
+    }
+    g_last_conv_kernel = LP_CONV_KERNEL_IGEMM;
+    if (N > 64) launch_igemm<128, kModeInfer>(x, w, g, lat, M, N, K, ep, st);
+    else launch_igemm<64, kModeInfer>(x, w, g, lat, M, N, K, ep, st);
     return launch_status();
 }
 

@@ -77,7 +77,8 @@ __device__ __forceinline__ void store8(unsigned short* p, u16x8 v, bool stream) 
 //   kEkAZB   addend + z (sums) + 1-bit ReLU mask (conv1 of the blocks behind an identity shortcut)
 //   kEkPlain no BatchNorm fused: optional addend, optional bf16 activation as the ReLU mask (conv1 / projection shortcut of the first
 //            block of a layer, whose input gradient has two writers)
-enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3 };
+//   kEkInfer forward with + residual and ReLU in the store pass (inference, BatchNorm folded into weights and bias: lp_conv_fwd_act)
+enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4 };
 
 // HALO (3x3, stride 1, pad 1 - conv2 of every identity-stride block, forward and data gradient): the pixel operand is not fetched per
 // filter tap.  The ring above re-reads every activation row 9 times from L2 (once per tap: 27.7 us per tap on layer1's 64-channel layers,
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
                                                         FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep, int flags,
                                                         HaloDivs hd) {
-    static_assert((MODE == kModeFwd && EK == kEkNone) || (MODE == kModeDgrad && EK != kEkNone), "trunk convolutions only");
+    static_assert((MODE == kModeFwd && (EK == kEkNone || EK == kEkInfer)) || (MODE == kModeDgrad && EK != kEkNone && EK != kEkInfer),
+                  "trunk convolutions only");
     constexpr int NT = BN / 64;                  // 32-channel MFMA blocks per wave along N (wave tile 64 pixels x NT*32 channels)
     constexpr int NBL = BN / 64;                 // weight rows each thread stages per K step
     constexpr int kStageA = HALO ? 0 : kPM * kPRowB, kStageB = BN * kPRowB, kStage = kStageA + kStageB;
@@ -459,9 +461,22 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         if (ep.ldo > 0) return;
 #endif
         const int nbase = n0 + wn * (NT * 32);   // first channel of this wave
+        constexpr bool infer = EK == kEkInfer;   // lp_conv_fwd_act: its own instantiations, so the training kernels' store pass carries none of it
         constexpr int ROWB = NT * 64 + 16;       // bf16 chunk row + pad (16-B aligned)
         unsigned char* stg = stg_all + wave * (32 * ROWB);
-        if (ep.bias != nullptr) {   // (workgroup-uniform; Linear layers through lp_gemm_nt - the trunk's convolutions carry no bias)
+        u16x8 radd[2][32 / RP] = {};   // inference: this lane's pieces of the residual, all 8 requested before the conversion / staging work
+        if (infer && ep.addend != nullptr) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int ps = 0; ps < 32 / RP; ++ps) {
+                    const int m = m0 + wm * 64 + mt * 32 + ps * RP + prow;
+                    if (m < M)
+                        radd[mt][ps] = load8(ep.addend + (unsigned)out_row(m, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo +
+                                             (unsigned)(nbase + pc * 8));
+                }
+        }
+        if (ep.bias != nullptr) {   // (workgroup-uniform; Linear layers through lp_gemm_nt, inference with the BatchNorm folded)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -488,10 +503,24 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #pragma unroll
             for (int ps = 0; ps < 32 / RP; ++ps) {
                 const int row = ps * RP + prow;
-                const u16x8 w = *reinterpret_cast<const u16x8*>(stg + row * ROWB + pc * 16);
+                u16x8 w = *reinterpret_cast<const u16x8*>(stg + row * ROWB + pc * 16);
                 const int m = m0 + wm * 64 + mt * 32 + row;
                 if (m < M) {
                     const unsigned off = (unsigned)out_row(m, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8);
+                    if (infer) {   // lp_conv_fwd_act: + residual, ReLU (on the bf16 value of accumulator + bias: one more rounding than kModeInfer)
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = bf16_to_f32(w[q]);
+                        if (ep.addend != nullptr) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(radd[mt][ps][q]);
+                        }
+                        if (ep.relu_fwd) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        w = pack_bf16x8(v);
+                    }
 #ifdef LP_EXP_SKIP_FWD_GSTORE
                     if (ep.ldo < 0)
 #endif
@@ -521,7 +550,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     // everything is applied before the single rounding to bf16, as in conv_igemm_kernel.
     constexpr int PH = 16 / RP;          // read-back passes per 16-pixel half
     constexpr int NPC = 2 * PH;          // pieces (8 channels of one row) per lane and 32-pixel chunk
-    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain), kLz = (EK != kEkNone), kLb = (EK == kEkAZB);
+    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain), kLz = (EK != kEkNone && EK != kEkInfer), kLb = (EK == kEkAZB);
     // (kEkAZB - the hottest data gradient, at the register cap - does not keep the output offsets of its pieces: its launches cover the full
     //  pixel lattice (host-checked), so an offset is two multiply-adds away and is recomputed in rb_process: 8 VGPRs, the 7 it used to spill)
     constexpr bool kKeepOff = EK != kEkAZB;

@@ -51,6 +51,33 @@ def test_conv_fwd_act_folded_batchnorm(case, residual, relu):
     assert float((got - ref).abs().max()) < 0.06 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("case,kernel", [((2, 16, 16, 64, 128, 1, 1, 0), 1), ((1, 20, 12, 128, 128, 3, 1, 1), 4), ((2, 17, 16, 128, 256, 1, 2, 0), 1),
+                                         ((2, 12, 12, 64, 64, 3, 2, 1), 1), ((1, 9, 9, 64, 192, 1, 1, 0), 0)])
+def test_conv_fwd_act_on_the_pipelined_kernel(case, kernel, monkeypatch):
+    """round 3: lp_conv_fwd_act takes conv_pipe_kernel (plain / HALO form) where the shape allows, the residual and the ReLU applied in its store
+    pass to the bf16 value of accumulator + bias - at most one bf16 rounding away from conv_igemm_kernel<infer> (LP_INFER_PIPE=0), which adds
+    in fp32 before its only rounding"""
+    B, Hi, Wi, Ci, Co, R, st, pad = case
+    gen = torch.Generator().manual_seed(sum(case) + 11)
+    x = emu.to_bf16_bits(nhwc(torch.randn(B, Ci, Hi, Wi, generator=gen)))
+    w = emu.to_bf16_bits(torch.randn(Co, R * R * Ci, generator=gen) / (Ci * R * R) ** 0.5)
+    bias = torch.randn(Co, generator=gen).numpy()
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, st, pad)
+    res = emu.to_bf16_bits(torch.randn(B * g.Ho * g.Wo, Co, generator=gen))
+    for residual, relu in ((True, True), (False, True), (True, False)):
+        got = emu.from_bf16_bits(emu.conv_fwd_act(x, w, g, bias=bias, residual_bits=res if residual else None, relu=relu))
+        assert emu.lib().lp_conv_last_kernel() == kernel
+        monkeypatch.setenv("LP_INFER_PIPE", "0")
+        want = emu.from_bf16_bits(emu.conv_fwd_act(x, w, g, bias=bias, residual_bits=res if residual else None, relu=relu))
+        assert emu.lib().lp_conv_last_kernel() == 0
+        monkeypatch.delenv("LP_INFER_PIPE")
+        if not residual and Ci * R * R <= 64:
+            assert torch.equal(got, want)        # same K order, no second rounding
+        # two roundings of values up to |a| + |r|: 2^-8 relative of the larger of the sum and its terms
+        scale = torch.maximum(want.abs(), emu.from_bf16_bits(res).abs() if residual else want.abs())
+        assert float(((got - want).abs() / (scale + 1e-3)).max()) <= 2.0 ** -7
+
+
 @pytest.mark.parametrize("nb,nh,T,ldp", [(2, 2, 77, 80), (1, 3, 130, 192), (1, 1, 64, 64), (1, 2, 5, 8)])
 def test_attention_forward_without_probabilities(nb, nh, T, ldp):
     """inference form (p = NULL): the same O as the training form bit for bit, nothing of size T x T written"""
