@@ -110,19 +110,22 @@ def test_graphed_steps_keep_the_callers_batches_and_refresh_the_inference_copies
         model.train()
         trainer = Trainer(max_epochs=1, data_parallel=False, hip_graph=graph)
         trainer.setup(model)
-        vals = []
+        vals, psums = [], []
         for epoch in range(3):
             for i, b in enumerate(batches):
                 trainer.training_batch(model, b, i)
             vals.append(trainer.validate(model, [batches[0]["labeled"]])["val_supervised_loss"])
+            psums.append(float(model.net.P.double().abs().sum()))
         torch.cuda.synchronize()
         assert torch.equal(batches[0]["labeled"]["images"], keep[0]) and torch.equal(batches[0]["unlabeled"]["frames"], keep[1])
+        # the weights moved between the validations (checked on the master parameters: the validation loss of this random-init network
+        # repeated to the last digit across epochs in 1 of 14 device runs, profiles/r03_flake6.log - a saturated soft-max does not see small updates)
+        assert psums[0] != psums[-1]
         return vals, trainer._graphed
 
     v0, _ = run(False)
     v1, gs = run(True)
     assert gs is not None and gs.replays >= 5
-    assert v0[0] != v0[-1]                       # the weights moved between the validations ...
     # ... and the graphed run's validation follows them.  (Two runs of the SAME eager code differ too - BatchNorm sums go through fp32 atomics and a
     # random-init ResNet at batch 8 amplifies that over 9 steps: 1 - 2 % usually, 3 % exceeded once in ~10 device runs, profiles/r03_final_pytest_gpu_run4.log.)
     np.testing.assert_allclose(v1, v0, rtol=1e-1)
