@@ -326,6 +326,10 @@ int lp_f32_conv_wgrad(const float* x, const float* dy, const lp_conv_geom* geom,
 /* fp32 forms of lp_bn_stats / lp_bn_apply / lp_bn_bwd_reduce / lp_bn_bwd_apply (lp_bn_finalize is shared), of the 3x3/2 max-pool, of the
  * input layout conversion (NCHW -> NHWC4), of PixelShuffle(2) and of the spatial soft-max backward (fp32 gradient out) */
 int lp_f32_bn_stats(const float* x, int M, int C, float* sums, lp_stream_t stream);
+/* the same sums through per-stripe partials in `workspace`, added in a fixed order (no atomics): the validation executor's forward statistics,
+ * so that its outputs repeat bit for bit from run to run */
+size_t lp_f32_bn_stats_workspace_bytes(int M, int C);
+int lp_f32_bn_stats_ordered(const float* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
 int lp_f32_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* residual,
                     int relu, int M, int C, float* y, lp_stream_t stream);
 int lp_f32_bn_bwd_reduce(const float* dy, const float* y_out, const float* x, const float* mean, const float* invstd, int M, int C,

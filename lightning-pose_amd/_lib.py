@@ -146,6 +146,8 @@ PROTOTYPES = {
     "lp_f32_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _P, _P]),
     "lp_f32_conv_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _I, _I, _I, _P, _P]),
     "lp_f32_bn_stats": (_I, [_P, _I, _I, _P, _P]),
+    "lp_f32_bn_stats_workspace_bytes": (C.c_size_t, [_I, _I]),
+    "lp_f32_bn_stats_ordered": (_I, [_P, _I, _I, _P, _P, C.c_size_t, _P]),
     "lp_f32_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "lp_f32_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "lp_f32_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),

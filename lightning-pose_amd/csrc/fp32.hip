@@ -163,6 +163,32 @@ __global__ __launch_bounds__(256) void f32_bn_stats_kernel(const float* __restri
     atomicAdd(&sums[C + c], s1);
 }
 
+// the same sums without atomics: every (row stripe, row lane) writes its partial pair to part[stripe * 4 + lane][2][C] and
+// f32_bn_stats_fold_kernel adds them up in index order - the validation executor's forward is then reproducible bit for bit from run to run
+// (its keypoints are compared with the reference at 3e-3 px, and soft-argmax multiplies by T = 1000: the summation order showed)
+__global__ __launch_bounds__(256) void f32_bn_stats_part_kernel(const float* __restrict__ X, int M, int C, float* __restrict__ part) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = blockIdx.y * 4 + rl; r < M; r += gridDim.y * 4) {
+        const float v = X[(size_t)r * C + c];
+        s0 += v;
+        s1 = fmaf(v, v, s1);
+    }
+    float* dst = part + (size_t)(blockIdx.y * 4 + rl) * 2 * C;
+    dst[c] = s0;
+    dst[C + c] = s1;
+}
+
+__global__ __launch_bounds__(256) void f32_bn_stats_fold_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // over 2 C
+    if (i >= 2 * C) return;
+    float t = 0.f;
+    for (int p = 0; p < nparts; ++p) t += part[(size_t)p * 2 * C + i];
+    sums[i] += t;
+}
+
 __global__ __launch_bounds__(256) void f32_bn_apply_kernel(const float* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ residual, int relu,
@@ -382,6 +408,26 @@ extern "C" int lp_f32_bn_stats(const float* x, int M, int C, float* sums, lp_str
     int gy = M / 64;
     gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
     hipLaunchKernelGGL(f32_bn_stats_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, x, M, C, sums);
+    return launch_status();
+}
+
+static int f32_stats_stripes(int M) {
+    int gy = M / 64;
+    return gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+}
+
+extern "C" size_t lp_f32_bn_stats_workspace_bytes(int M, int C) {
+    return M > 0 && C > 0 ? (size_t)f32_stats_stripes(M) * 4 * 2 * (size_t)C * sizeof(float) : 0;
+}
+
+// sums += [sum x, sum x^2] as lp_f32_bn_stats, through per-stripe partial sums in `workspace` added in a fixed order: reproducible
+extern "C" int lp_f32_bn_stats_ordered(const float* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && sums && workspace && M > 0 && C > 0 && workspace_bytes >= lp_f32_bn_stats_workspace_bytes(M, C));
+    const int gy = f32_stats_stripes(M);
+    hipLaunchKernelGGL(f32_bn_stats_part_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, (hipStream_t)stream, x, M, C, (float*)workspace);
+    hipLaunchKernelGGL(f32_bn_stats_fold_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, gy * 4, C,
+                       sums);
     return launch_status();
 }
 

@@ -68,8 +68,12 @@ class Fp32Engine(Engine):
         invstd = torch.empty_like(mean)
         if training:
             sums = torch.zeros(len(segs) * 2 * b.C, device=self.device, dtype=torch.float32)
-            for si, (i0, n) in enumerate(segs):
-                check(self._lib.lp_f32_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), ops._stream()), "lp_f32_bn_stats")
+            for si, (i0, n) in enumerate(segs):   # ordered partial sums (no atomics): the validation forward repeats bit for bit
+                need = int(self._lib.lp_f32_bn_stats_workspace_bytes(n * rpi, b.C))
+                if getattr(self, "_stats_ws", None) is None or self._stats_ws.numel() < need:
+                    self._stats_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+                check(self._lib.lp_f32_bn_stats_ordered(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), _p(self._stats_ws),
+                                                        self._stats_ws.numel(), ops._stream()), "lp_f32_bn_stats_ordered")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:
                 self._sync_stats(sums)

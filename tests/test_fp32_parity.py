@@ -53,3 +53,28 @@ def test_fp32_training_step_vs_reference_golden(stack_backend, golden):
     with torch.no_grad():
         heat = model.forward(_batch(g, dev)["labeled"]["images"]).cpu()
     torch.testing.assert_close(heat, g.t("heat_after_step_train_mode"), atol=FP32_TOL * float(g.t("heat_after_step_train_mode").max()), rtol=1e-3)
+
+
+@pytest.mark.parametrize("M,C_", [(300, 72), (64, 64), (5000, 256), (1, 8)])
+def test_fp32_ordered_batchnorm_sums(stack_backend, M, C_):
+    """lp_f32_bn_stats_ordered (the validation executor's forward statistics): the sums of lp_f32_bn_stats without atomics - the same values
+    up to summation order, and the same bits every time"""
+    from lightning_pose_amd import _lib
+    from lightning_pose_amd.ops import _p, _stream
+
+    dev = stack_backend
+    lib = _lib.lib()
+    x = torch.randn(M, C_, generator=torch.Generator().manual_seed(M + C_)).to(dev)
+    ref = torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)]).reshape(-1)
+    ws = torch.empty(int(lib.lp_f32_bn_stats_workspace_bytes(M, C_)), device=dev, dtype=torch.uint8)
+    outs = []
+    for _ in range(2):
+        s = torch.full((2 * C_,), 0.5, device=dev)   # (accumulated into)
+        assert lib.lp_f32_bn_stats_ordered(_p(x), M, C_, _p(s), _p(ws), ws.numel(), _stream()) == 0
+        outs.append(s.cpu())
+    assert torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[0].double() - 0.5, ref.cpu(), rtol=1e-5, atol=5e-4)   # fp32 sums of up to 5000 terms
+    a = torch.zeros(2 * C_, device=dev)
+    assert lib.lp_f32_bn_stats(_p(x), M, C_, _p(a), _stream()) == 0
+    torch.testing.assert_close(a.cpu(), outs[0] - 0.5, rtol=1e-5, atol=5e-4)
+    assert lib.lp_f32_bn_stats_ordered(_p(x), M, C_, _p(a), _p(ws), max(ws.numel() - 1, 0), _stream()) != 0   # workspace too small
