@@ -67,6 +67,29 @@ def test_conv_fwd_dgrad_wgrad(case):
     torch.testing.assert_close(torch.from_numpy(db), nhwc(dy).reshape(-1, Co).sum(0), atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("R", [1, 3])
+@pytest.mark.parametrize("B", [2, 3, 4, 5, 6])
+def test_weight_gradient_two_steps_in_flight(B, R, monkeypatch):
+    """conv_wgrad_kernel keeps two K steps in flight where every step takes the fixed-offset loads (round 3): pixel slices of 2 .. 6 K steps
+    (even and odd tails of the loop unrolled by two), with and without the padding walk, one slice and several (a one-step slice takes the
+    old loop), against autograd on the same bf16 operands"""
+    monkeypatch.setenv("LP_WGRAD_PIPE", "0")
+    Hi = Wi = 8
+    Ci, Co, pad = 64, 128, R // 2
+    gen = torch.Generator().manual_seed(100 * B + R)
+    x = bf(torch.randn(B, Ci, Hi, Wi, generator=gen))
+    w = bf(torch.randn(Co, Ci, R, R, generator=gen) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, padding=pad)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    g = emu.geom(B, Hi, Wi, Ci, Co, R, R, 1, pad)
+    want = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    for split in (1, 2, B):
+        dw = emu.conv_wgrad(emu.to_bf16_bits(nhwc(x)), emu.to_bf16_bits(nhwc(dy)), g, split=split)
+        assert emu.lib().lp_conv_last_kernel() == 2   # LP_CONV_KERNEL_WGRAD
+        torch.testing.assert_close(torch.from_numpy(dw), want, atol=2e-3, rtol=2e-3)
+
+
 def test_conv_bias_and_column_mask():
     gen = torch.Generator().manual_seed(3)
     x = bf(torch.randn(1, 64, 6, 6, generator=gen))
