@@ -181,6 +181,48 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void tile_probe(con
     if (t0 == 12345.678f) sums[tid] = t0;
 }
 
+// ---- LDS read rate per CU: ds_read_b128 (forward / data-gradient fragments) against 2 x ds_read_b64_tr_b16 (weight-gradient fragments) -----------
+// 8 waves, every lane reads ITER fragments of 16 B from a 32-KB image with the kernels' row swizzle; bytes / cycle / CU = 8 x 64 x 16 x ITER / cycles.
+// conv_wgrad_pipe_kernel issues 128 KB of transpose reads per 1024 MFMA cycles and K step: if this probe shows ~128 B/clk for the transpose
+// form, that kernel is LDS-bound at half the matrix rate and only a bigger wave tile (fewer fragments per MFMA) can lift it.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <int MODE>
+__global__ __launch_bounds__(512) void lds_rate(unsigned* out, long long* cycles, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char img[32 * 1024];
+    for (int i = threadIdx.x; i < 32 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(img)[i] = i * 2654435761u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned acc = 0;
+    const long long t0 = clock64();
+    if (MODE == 0) {   // fragment of 32 rows x 16 B: lane -> (row fr, half fg), chunk (2 kk + fg) ^ ((row >> 1) & 7), 128-B rows
+        const int fr = lane & 31, fg = lane >> 5;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int row = wave * 32 + fr;
+                const u16x8 v = *reinterpret_cast<const volatile u16x8*>(img + row * 128 + (((kk * 2 + fg) ^ ((row >> 1) & 7)) << 4));
+                acc ^= v[0] ^ v[7];
+            }
+        }
+    } else {           // transpose fragment: 2 reads of 8 B per lane, rows of 512 B (the weight gradient's [pixel][256 channels] image)
+        const int fq = lane >> 4, fi = lane & 15;
+        const int frow = (fq >> 1) * 8 + (fi >> 2), fcol = (fq & 1) * 16 + (fi & 3) * 4;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int e0 = (wave & 3) * 64 + fcol;
+                const unsigned char* pa = img + (kk * 16 + frow) * 512 + (((e0 >> 3) ^ ((frow & 3) << 2)) << 4) + (e0 & 7) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * 512));
+                acc ^= (unsigned)lo[0] ^ (unsigned)hi[3];
+            }
+        }
+    }
+    const long long t1 = clock64();
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 #define CK(x)                                                                     \
     do {                                                                          \
         hipError_t e_ = (x);                                                      \
@@ -241,6 +283,29 @@ int main() {
                 printf("%-34s %6d %6d %10.2f %10.2f %9.0f %9.0f\n", "B: 4 waves x 128x64, kstep 32, 2 WG", K, reuse, u0 / tiles_a, u1 / tiles_a,
                        flop_tile * tiles_a * cus / u0 * 1e-6, flop_tile * tiles_a * cus / u1 * 1e-6);
             }
+        }
+    }
+    // LDS read rates (one workgroup of 8 waves per CU; HIP events around the second launch)
+    {
+        long long* cyc;
+        CK(hipMalloc(&cyc, cus * sizeof(long long)));
+        const int iters = 16384;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        for (int mode = 0; mode < 2; ++mode) {
+            float ms = 0.f;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                if (mode == 0) hipLaunchKernelGGL(lds_rate<0>, dim3(cus), dim3(512), 0, 0, (unsigned*)sums, cyc, iters);
+                else hipLaunchKernelGGL(lds_rate<1>, dim3(cus), dim3(512), 0, 0, (unsigned*)sums, cyc, iters);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            const double bytes_cu = 512.0 * 16 * 4 * iters;
+            printf("LDS %-26s %7.1f GB/s per CU = %6.1f B/clk at 2.4 GHz (%.1f us)\n", mode == 0 ? "ds_read_b128 fragments" : "2 x ds_read_b64_tr_b16",
+                   bytes_cu / (ms * 1e-3) * 1e-9, bytes_cu / (ms * 1e-3) / 2.4e9, ms * 1e3);
         }
     }
     return 0;
