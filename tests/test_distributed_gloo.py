@@ -332,11 +332,13 @@ def _tracker_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_tracker_step_sharded_over_two_ranks_equals_one_process():
+@pytest.mark.parametrize("world", [2, 4])
+def test_tracker_step_sharded_over_ranks_equals_one_process(world):
+    """(world 4: the SCALE runs go to 8 ranks - bucketed gradient sum, SyncBatchNorm counts and the 1 / world scale beyond two ranks)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_tracker_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tracker_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in procs]
