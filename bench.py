@@ -269,7 +269,57 @@ def hbm_rooflines(dev, size: int, K: int, frames: int, reps: int = 10) -> dict:
             "kernels": out}
 
 
-def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 3) -> dict:
+def cpu_baseline_reference(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 2) -> dict:
+    """The reference's OWN SemiSupervisedHeatmapTracker (verbatim modules, executed by oracle/ref_loader.py from /root/reference or from the
+    copy oracle/make_ref.py shipped to oracle/_ref/; torch fp32 on the host cores - the reference trains fp32 only, train.py:411-428) timed
+    over full optimisation steps: training_step -> backward -> Adam.step on a bounded sample of the bench's workload.  Its losses are the
+    three of the bench's four that exist in the reference snapshot (heatmap_mse + temporal + pca_singleview; unimodal_mse does not)."""
+    from oracle import ref_loader as R
+
+    T, Fa, L, H = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("losses.losses"), R.load("data.heatmaps")
+    torch.manual_seed(0)
+    cols = [k for k in range(K) if k not in (7, 15, 16)] if K == 17 else list(range(K))
+    sup = Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None)
+    unsup = Fa.LossFactory({"temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05}}, None)
+    kpca = R.fit_keypoint_pca("pca_singleview", pca_training_array(K, size), components_to_keep=0.99, columns_for_singleview_pca=cols)
+    pl = L.PCALoss.__new__(L.PCALoss)
+    L.Loss.__init__(pl, log_weight=5.0)
+    pl.device, pl.loss_name, pl.pca, pl.epsilon = "cpu", "pca_singleview", kpca, kpca.parameters["epsilon"]
+    unsup.loss_instance_dict["pca_singleview"] = pl
+    model = T.SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone="resnet50",
+                                           pretrained=False, torch_seed=0, image_size=size)
+    model.total_unsupervised_importance = torch.tensor(1.0)
+    opt = model.configure_optimizers()["optimizer"]
+    g = torch.Generator().manual_seed(5)
+    kp = torch.rand(n_lab, 2 * K, generator=g) * size
+    batch = {
+        "labeled": {"images": torch.randn(n_lab, 3, size, size, generator=g), "keypoints": kp,
+                    "heatmaps": H.generate_heatmaps(kp.reshape(n_lab, K, 2), size, size, (size // 4, size // 4)),
+                    "bbox": torch.tensor([[0.0, 0.0, size, size]]).repeat(n_lab, 1), "idxs": torch.arange(n_lab)},
+        "unlabeled": {"frames": torch.randn(n_unlab, 3, size, size, generator=g),
+                      "transforms": torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]),
+                      "bbox": torch.tensor([[0.0, 0.0, size, size]]).repeat(n_unlab, 1), "is_multiview": False},
+    }
+    model.train()
+    times = []
+    for i in range(steps + 1):   # 1 warm-up + `steps` timed steps
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = model.training_step(batch, i)["loss"]
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round((n_lab + n_unlab) / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "reference",
+            "sample": f"{len(times)} timed full steps (training_step + backward + Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, "
+                      f"fp32, median {med:.2f} s/step; the reference's own SemiSupervisedHeatmapTracker / LossFactory / losses (verbatim modules from "
+                      f"{'/root/reference' if R.REFERENCE_ROOT.startswith('/root/reference') else 'oracle/_ref (oracle/make_ref.py)'}; kornia / "
+                      "torchvision restated by oracle/thirdparty.py) with heatmap_mse + temporal + pca_singleview (unimodal_mse is not in the "
+                      "reference snapshot), final loss %.5f" % float(loss.detach())}
+
+
+def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int = 2) -> dict:
     """Oracle (fp32 torch CPU restatement of the reference path) timed on the host cores for a bounded sample."""
     from oracle import restated as O
 
@@ -294,7 +344,7 @@ def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int
            "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05}}
     model.train()
     times = []
-    for i in range(steps + 1):  # 1 warm-up + up to `steps` timed steps, stopping early once ~25 s of timed CPU work are in (>= 2 steps)
+    for i in range(steps + 1):  # 1 warm-up + `steps` timed steps (2 by default: the driver's lease should not be mostly CPU work)
         t0 = time.perf_counter()
         opt.zero_grad()
         loss, _ = O.training_step(model, batch, cfg, 1.0)
@@ -351,12 +401,78 @@ def predict_bench(args, model, batch, dev, rank: int, world: int) -> dict:
     return line
 
 
+def _decode_prune_label(model) -> str:
+    """which decode kernels THIS model's chooser (ops._DecodePruneAuto, one per tracker) ended on"""
+    if os.environ.get("LP_DECODE_PRUNE", "auto").strip().lower() not in ("", "auto"):
+        return "environment (LP_DECODE_PRUNE=%s)" % os.environ["LP_DECODE_PRUNE"]
+    st = getattr(model, "_decode_prune", None)
+    if st is None:
+        return "unset"
+    return "pruned kernels (chosen from the maps)" if st.want == 1 else "plain kernels (chosen from the maps)" if st.calls >= st.FIRST else "plain kernels"
+
+
+def fit_line(args, dev, rank: int, world: int) -> dict:
+    """What a user's training loop gets: Trainer.fit over the device-side producers - decoded uint8 frames on the HOST (a video of
+    `unlabeled`-frame windows, a labeled set of uint8 images + stored keypoints, both at the bundled example's 406 x 396 source size) ->
+    FrameWindowSource (pinned copy on a side stream, one window ahead) -> VideoFramePipeline (antialiased resize + normalise) /
+    LabeledBatchProducer (bicubic resize, keypoint projection, heat-map targets, all on the device) -> the same step as the headline line.
+    PCIe-inclusive by construction (56 MB of video frames + 31 MB of labeled images per step); the logged scalars reach the host every
+    `log_every_n_steps` only.  Timed: one fit() of `steps` batches after a warm-up fit() of `warmup`."""
+    from lightning_pose_amd.data.producers import FrameWindowSource, LabeledBatchProducer, VideoFramePipeline
+    from lightning_pose_amd.trainer import Trainer
+
+    Hs, Ws, K, size = 406, 396, args.keypoints, args.size
+    model = build_model(dev, K, size, backbone=args.backbone)
+    g = torch.Generator().manual_seed(77 + rank)
+    n_win = args.warmup + args.steps
+    video = torch.randint(0, 256, (n_win * args.unlabeled, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    lab_u8 = torch.randint(0, 256, (args.labeled, Hs, Ws, 3), generator=g, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else \
+        torch.randint(0, 256, (args.labeled, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    kp = torch.rand(args.labeled, K, 2, generator=g) * torch.tensor([Ws, Hs])
+    kp[torch.rand(args.labeled, K, generator=g) < 0.088] = float("nan")
+    src = FrameWindowSource(video, args.unlabeled, random_shuffle=False, pad_sequences=False, device=dev)
+    pipe = VideoFramePipeline([size, size], imgaug="default")
+    prod = LabeledBatchProducer(size, size, uniform_heatmaps=True)
+
+    def batches(first: int, n: int):
+        it = iter(src)
+        for i, frames_u8 in enumerate(it):
+            if i < first:
+                continue
+            if i >= first + n:
+                break
+            labeled = prod(lab_u8.to(dev, non_blocking=True), kp.to(dev))
+            yield {"labeled": labeled, "unlabeled": pipe(frames_u8)}
+
+    trainer = Trainer(max_epochs=1, data_parallel=False, log_every_n_steps=50)
+    model.total_unsupervised_importance = torch.tensor(1.0)
+    if args.warmup > 0:
+        trainer.fit(model, lambda epoch: batches(0, args.warmup))
+    _sync(dev)
+    t0 = time.perf_counter()
+    trainer.fit(model, lambda epoch: batches(args.warmup, args.steps))
+    _sync(dev)
+    elapsed = time.perf_counter() - t0
+    frames = (args.labeled + args.unlabeled) * args.steps
+    rec = trainer.logged_history[-1] if trainer.logged_history else {}
+    return {"metric": f"training frames/sec through Trainer.fit + device-side producers, ResNet-50 {size}x{size} {K}-kp semi-sup",
+            "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Trainer.fit: {args.labeled} labeled uint8 images + a window of {args.unlabeled} uint8 video frames per step, "
+                                   f"{Hs}x{Ws} on the host -> pinned copy -> LabeledBatchProducer / VideoFramePipeline on the device -> the headline step "
+                                   "(PCIe-inclusive; scalars logged every 50 steps + at the end of the epoch)",
+                       "host_records": len(trainer.logged_history), "final_loss": round(float(rec.get("total_loss", float("nan"))), 6)}}
+
+
 def train_line(args, dev, rank: int, world: int) -> dict:
     """Build the model + batch of ``args`` and measure it: the JSON line (without printing it)."""
     import torch.distributed as dist
 
     from lightning_pose_amd.trainer import Trainer
 
+    if getattr(args, "fit", False):
+        return fit_line(args, dev, rank, world)
     model = build_model(dev, args.keypoints, args.size, backbone=args.backbone, views=args.views)
     if args.views > 1:
         batch = synth_multiview_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints, args.views)
@@ -364,6 +480,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         batch = synth_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints)
     if args.predict:
         return predict_bench(args, model, batch, dev, rank, world)
+
     if getattr(args, "peaked", False):
         # the maps of a TRAINED head are single peaks; a random-init head (xavier gain 0.01) gives numerically flat ones.  Scaling the head's
         # weights makes the soft-max outputs peaked (at arbitrary places - enough for the decode kernels, whose cost depends on how many
@@ -459,8 +576,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": bool(getattr(model.net, "sync_bn", False)),
                    "comm_per_step": comm, "memory": memory,
                    "hip_graph": bool(trainer._graphed is not None and trainer._graphed.replays > 0),
-                   "decode_prune": {-2: "unset", -1: "environment", 0: "plain kernels", 1: "pruned kernels (chosen from the maps)"}.get(
-                       __import__("lightning_pose_amd.ops", fromlist=["x"])._decode_prune_auto.state, "?"),
+                   "decode_prune": _decode_prune_label(model),
                    "final_loss": round(float(loss), 6)},
     }
     if rank == 0:
@@ -520,7 +636,8 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                 out["roofline_hbm"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not dist.is_initialized() and not args.no_cpu_baseline and not is_vit and args.views == 1 and not getattr(args, "_secondary", False):
             try:
-                out["cpu_baseline"] = cpu_baseline(args.size, args.keypoints)
+                from oracle import ref_loader as _R
+                out["cpu_baseline"] = (cpu_baseline_reference if _R.available() else cpu_baseline)(args.size, args.keypoints, steps=args.cpu_baseline_steps)
             except Exception as e:  # noqa: BLE001 - the baseline must never cost the measured line
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
@@ -571,6 +688,9 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
     ap.add_argument("--peaked", action="store_true", help="secondary line: head weights x200 -> peaked heat-maps as a trained head gives them "
                     "(the decode then picks its pruned kernels by itself, ops._DecodePruneAuto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=2, help="timed CPU steps of the baseline leg (after 1 warm-up step)")
+    ap.add_argument("--fit", action="store_true", help="secondary line: Trainer.fit over the device-side producers (uint8 host frames -> "
+                    "FrameWindowSource / LabeledBatchProducer / VideoFramePipeline -> step), i.e. what a user's training loop gets")
     ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNorm statistics (the reference sets sync_batchnorm=True, train.py:427; A/B only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args(argv)
@@ -601,7 +721,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
             import copy
             sec = {}
             for tag, over in (("resnet50_256", dict(size=256)), ("resnet50_384_unfrozen_backbone", dict(unfrozen=True)),
-                              ("resnet50_384_peaked_maps", dict(peaked=True)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
+                              ("resnet50_384_peaked_maps", dict(peaked=True, warmup=4, steps=5)),
+                              ("resnet50_384_trainer_fit", dict(fit=True, warmup=2, steps=6)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
                               ("c5_multiview_4x256", dict(views=4, size=256, labeled=16, unlabeled=32)),
                               ("predict_resnet50_384", dict(predict=True)), ("predict_vits_dino_384", dict(predict=True, backbone="vits_dino"))):
                 a2 = copy.copy(args)
@@ -611,7 +732,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                 try:
                     torch.cuda.empty_cache() if dev.type == "cuda" else None
                     r = train_line(a2, dev, rank, world)
-                    sec[tag] = {k_: r[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "model_tflops_per_gpu", "mfma_frac_end_to_end") if k_ in r}
+                    sec[tag] = {k_: r[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "steps", "model_tflops_per_gpu", "mfma_frac_end_to_end") if k_ in r}
                     if "roofline" in r:
                         sec[tag]["roofline"] = {k_: r["roofline"][k_] for k_ in ("achieved", "frac", "unit", "launches_per_step", "mfma_ms_per_step",
                                                                                  "hbm_gbs_algorithmic") if k_ in r["roofline"]}

@@ -251,8 +251,9 @@ int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int ldv, const 
                     long long d_b, long long d_h, float scale, void* ds_bf16, int ldc, int M, int N, int K, const lp_gemm_batch* batch,
                     lp_stream_t stream);
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
- * for them (torch.nn.BatchNorm2d training forward / backward).  Every 128-row output tile leaves its
- * column sums in `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds them into `sums`.
+ * for them (torch.nn.BatchNorm2d training forward / backward).  Every persistent workgroup leaves the
+ * column sums of the tiles it walked in one row of `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds the rows
+ * into `sums` in workgroup order (bit-reproducible; see lp_bn_fuse.defer_reduce).
  *   lp_conv_fwd_bn / lp_stem_fwd_bn:  sums (2,Co) += [sum z, sum z^2] of the bf16 output z  (== lp_bn_stats on it);
  *                                     only sums / workspace / workspace_bytes are read.
  *   lp_conv_dgrad_bn:                 dx is the gradient of a = relu(BN(z) [+ residual]); sums (2,Ci) += [sum dx, sum dx*xhat]
@@ -278,6 +279,13 @@ typedef struct lp_bn_fuse {
      * Then sums is (2 segments, 2, C), mean / invstd are (2, C); dbeta_acc / dgamma_acc receive both segments.  seg_images times the
      * launch's rows per image must be a multiple of 128 (LP_ERR_UNSUPPORTED otherwise: run the segments as two calls).  0 = one segment. */
     int seg_images;
+    /* Bit-reproducible sums (round 4).  The store passes do not add their sums into `sums` with atomics: every persistent workgroup leaves
+     * ONE row of partial sums in `workspace` ([slot_rows][segments][2][C]) and an ordered reduction (stats_slots_reduce_kernel) adds the
+     * rows in workgroup order into sums / dbeta_acc / dgamma_acc before the call returns its stream.  defer_reduce = 1 (forward entry
+     * points): skip that reduction - the caller hands `workspace` and the `slot_rows` the call reports back (OUT field) to
+     * lp_bn_finalize_slots, which reduces and finalizes in one launch.  LP_STATS_ATOMIC=1 (A/B timing only) brings the atomics back. */
+    int defer_reduce;
+    int slot_rows;        /* OUT: rows of partial sums the call left in workspace (0 in the atomic form) */
 } lp_bn_fuse;
 size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad);
 /* Inference (predict_step, models/heatmap_tracker.py:155-191; eval-mode nn.BatchNorm2d uses its running statistics): the BatchNorm
@@ -290,10 +298,10 @@ int lp_bn_fold(const float* w, const float* gamma, const float* beta, const floa
                int Co, int per_co, void* w_bf16, float* bias, lp_stream_t stream);
 int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, const void* residual_bf16, int relu,
                     void* out_bf16, lp_stream_t stream);
-int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
-int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
+int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn, lp_stream_t stream);
+int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn, lp_stream_t stream);
 int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
-                     void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
+                     void* dx_bf16, lp_bn_fuse* bn, lp_stream_t stream);
 /* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split.  The pixel slices leave
  * partial tiles in `workspace` (lp_conv_wgrad_workspace_bytes) and a second kernel sums them in a fixed order: deterministic. */
 size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);
@@ -365,8 +373,17 @@ int lp_f32_attn_bwd(const float* qkv, int ld, int k_off, int v_off, const float*
  * PixelShuffle(2), input layout.  torchvision Bottleneck semantics; called from
  * `self.backbone(images)` (models/base.py:398) and HeatmapHead.forward (models/heads/heatmap.py:44,208).
  * ------------------------------------------------------------------------------------------------------ */
-/* sums (2,C) fp32, accumulated into (zero first): [sum x, sum x^2] over the M rows.  SyncBatchNorm = all-reduce it. */
-int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream);
+/* sums (2,C) fp32, accumulated into (zero first): [sum x, sum x^2] over the M rows.  SyncBatchNorm = all-reduce it.
+ * The reductions over rows (this one, lp_bn_bwd_reduce, lp_bn_pool_bwd_reduce) are bit-reproducible since round 4: every workgroup leaves
+ * its partial sums in one row of `workspace` (lp_bn_reduce_workspace_bytes / lp_bn_pool_bwd_workspace_bytes) and a second launch adds the
+ * rows in workgroup order - no fp32 atomics. */
+size_t lp_bn_reduce_workspace_bytes(int M, int C);
+int lp_bn_stats(const void* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
+/* mean / invstd (and the running-statistics update, segment by segment) straight from the per-workgroup rows a fused forward entry point
+ * left with lp_bn_fuse.defer_reduce = 1 (`slots` = its workspace, `slot_rows` as it reported): the ordered reduction and lp_bn_finalize[2]
+ * in ONE launch.  nseg = 1 or 2 (count1 ignored for 1); sums_out (optional) receives the raw (nseg, 2, C) totals. */
+int lp_bn_finalize_slots(const void* slots, int slot_rows, int nseg, float count0, float count1, int C, float eps, float momentum, float* mean,
+                         float* invstd, float* running_mean, float* running_var, float* sums_out, lp_stream_t stream);
 int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, lp_stream_t stream);
 /* two segments at once: sums (2,2,C), mean / invstd (2,C); the running statistics take segment 0's update, then segment 1's - the
@@ -384,7 +401,7 @@ int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const 
                         const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres, lp_stream_t stream);
 /* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL); dbeta/dgamma accumulate too */
 int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
-                     float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
+                     float* sums, float* dbeta_acc, float* dgamma_acc, void* workspace, size_t workspace_bytes, lp_stream_t stream);
 int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
                     const float* sums, float count, int M, int C, void* dx, void* dres, lp_stream_t stream);
 /* 3x3 / stride 2 / pad 1; argmax_u8 (B,Ho,Wo,C) records the winning tap (first maximum, ATen tie rule) for the backward gather */
@@ -397,9 +414,10 @@ int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi,
  * in sums[2][C] (+= d beta / d gamma), lp_bn_pool_bwd_apply writes d z. */
 int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int B, int Hi, int Wi,
                            int C, void* y, void* argmax_u8, lp_stream_t stream);
+size_t lp_bn_pool_bwd_workspace_bytes(int B, int Hi, int Wi, int C);
 int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, int B, int Hi, int Wi, int C, float* sums, float* dbeta_acc, float* dgamma_acc,
-                          lp_stream_t stream);
+                          void* workspace, size_t workspace_bytes, lp_stream_t stream);
 int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* sums, float count, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
 int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_bf16, lp_stream_t stream);

@@ -34,14 +34,16 @@ __device__ __forceinline__ u16x8 load_stream8(const unsigned short* p) {
 // ---- per-channel sums over rows: sums[0][c] += sum a, sums[1][c] += sum a*b -------------------------------------
 // MODE 0: plain statistics (sum x, sum x^2)
 // MODE 1: BN backward reductions: dz = relu-masked dy;  sum dz, sum dz * xhat
-// Grid-stride over rows with register accumulators (4 independent 16-B loads in flight per lane), ONE LDS reduction and
-// 2*C atomics per workgroup; the grid is capped so that at most a few hundred workgroups contend on a channel.
+// Grid-stride over rows with register accumulators (4 independent 16-B loads in flight per lane), ONE LDS reduction; every workgroup
+// leaves its 2 C partial sums in ITS row of `slots` ([gridDim.x][2][C]) and stats_slots_reduce_kernel adds the rows in workgroup order:
+// bit-reproducible totals (round 4; before, 2 C fp32 atomics per workgroup in arrival order).
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Yout,
                                                         const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int M, int C,
-                                                        float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
+                                                        float* __restrict__ slots) {
     __shared__ float red[2][256][8];
+    float* const row = slots + (size_t)blockIdx.x * 2 * C;
     const int chunks = C >> 3;                       // 16-B chunks per row
     const int cpb = chunks < 256 ? chunks : 256;     // chunks handled per block pass
     const int lanes_r = 256 / cpb;                   // row lanes
@@ -104,10 +106,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
                     t1 += red[1][q * cpb + pc][pi];
                 }
                 const int cc = (cbase + pc) * 8 + pi;
-                atomicAdd(&sums[cc], t0);
-                atomicAdd(&sums[C + cc], t1);
-                if (acc0) atomicAdd(&acc0[cc], t0);  // d beta
-                if (acc1) atomicAdd(&acc1[cc], t1);  // d gamma
+                row[cc] = t0;
+                row[C + cc] = t1;
             }
         }
         __syncthreads();
@@ -133,6 +133,49 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count0,
             const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+}
+
+// sums[pair][c] += the slot rows' totals (lp_common.h: slots_totals); d beta / d gamma accumulators += component 0 / 1 over the segments.
+// One thread per address for every read-modify-write: deterministic.
+__global__ __launch_bounds__(256) void stats_slots_reduce_kernel(const float* __restrict__ slots, int rows, int C, int nseg,
+                                                                 float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
+    __shared__ float red[32][64];
+    const int npairs = nseg * 2, c0 = blockIdx.x * 16, tid = threadIdx.x;
+    slots_totals(slots, rows, C, npairs, c0, red);
+    if (tid < npairs * 16 && c0 + (tid & 15) < C) sums[(size_t)(tid >> 4) * C + c0 + (tid & 15)] += red[0][tid];
+    if (tid < 32 && c0 + (tid & 15) < C) {
+        const int comp = tid >> 4, c = tid & 15;
+        float* accp = comp == 0 ? acc0 : acc1;
+        if (accp != nullptr) accp[c0 + c] += nseg == 2 ? red[0][comp * 16 + c] + red[0][(2 + comp) * 16 + c] : red[0][comp * 16 + c];
+    }
+}
+
+// bn_finalize_kernel fed by the slot rows directly (the forward pass without SyncBatchNorm: no separate reduction launch); `sums_out`
+// (optional) receives the raw [segment][2][C] totals
+__global__ __launch_bounds__(256) void bn_finalize_slots_kernel(const float* __restrict__ slots, int rows, float count0, float count1, int nseg,
+                                                                int C, float eps, float momentum, float* __restrict__ mean,
+                                                                float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float* __restrict__ sums_out) {
+    __shared__ float red[32][64];
+    const int npairs = nseg * 2, c0 = blockIdx.x * 16, tid = threadIdx.x;
+    slots_totals(slots, rows, C, npairs, c0, red);
+    if (sums_out != nullptr && tid < npairs * 16 && c0 + (tid & 15) < C) sums_out[(size_t)(tid >> 4) * C + c0 + (tid & 15)] = red[0][tid];
+    if (tid < 16 && c0 + tid < C) {
+        const int c = c0 + tid;
+        for (int sg = 0; sg < nseg; ++sg) {   // (the arithmetic of bn_finalize_kernel, expression for expression)
+            const float count = sg == 0 ? count0 : count1;
+            const float mu = red[0][(2 * sg) * 16 + tid] / count;
+            float var = red[0][(2 * sg + 1) * 16 + tid] / count - mu * mu;
+            var = fmaxf(var, 0.f);
+            mean[sg * C + c] = mu;
+            invstd[sg * C + c] = 1.f / sqrtf(var + eps);
+            if (running_mean != nullptr) {
+                const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
         }
     }
 }
@@ -413,8 +456,9 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
                                                                  const unsigned short* __restrict__ Z, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                                                                 float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
+                                                                 float* __restrict__ slots) {
     __shared__ float red[2][256][8];
+    float* const srow = slots + (size_t)blockIdx.x * 2 * C;   // this workgroup's partial sums (added in workgroup order afterwards)
     const int chunks = C >> 3, lanes_r = 256 / chunks;
     const int ch = threadIdx.x % chunks, rl = threadIdx.x / chunks;
     float mu[8], is[8], sc[8], be[8], s0[8], s1[8];
@@ -457,10 +501,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
             t1 += red[1][q * chunks + pc][pi];
         }
         const int cc = pc * 8 + pi;
-        atomicAdd(&sums[cc], t0);
-        atomicAdd(&sums[C + cc], t1);
-        if (acc0) atomicAdd(&acc0[cc], t0);  // d beta
-        if (acc1) atomicAdd(&acc1[cc], t1);  // d gamma
+        srow[cc] = t0;
+        srow[C + cc] = t1;
     }
 }
 
@@ -523,7 +565,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ sums_in, float inv_count,
                                                              int B, int Hi, int Wi, int Ho, int Wo, int band, float* __restrict__ sums,
-                                                             float* __restrict__ acc0, float* __restrict__ acc1, unsigned short* __restrict__ DX) {
+                                                             unsigned short* __restrict__ DX) {
     constexpr int C = 64, chunks = 8;
     constexpr int kZU = LP_POOL_ZU;   // z chunks in flight per thread
     __shared__ __attribute__((aligned(16))) unsigned short sdy[2][kPbW * C];
@@ -634,10 +676,9 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
                 t0 += red[0][q * chunks + pc][pi];
                 t1 += red[APPLY ? 0 : 1][q * chunks + pc][pi];
             }
-            atomicAdd(&sums[threadIdx.x], t0);
-            atomicAdd(&sums[C + threadIdx.x], t1);
-            if (acc0) atomicAdd(&acc0[threadIdx.x], t0);  // d beta
-            if (acc1) atomicAdd(&acc1[threadIdx.x], t1);  // d gamma
+            float* const srow = sums + (size_t)blockIdx.x * 2 * C;   // (reduce form: `sums` = the per-workgroup slot rows)
+            srow[threadIdx.x] = t0;
+            srow[C + threadIdx.x] = t1;
         }
     }
 }
@@ -750,16 +791,41 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) bias_out[co] = beta[co] - rmean[co] * a;
 }
 
+void launch_stats_slots_reduce(const float* slots, int rows, int nseg, int C, float* sums, float* acc0, float* acc1, hipStream_t st) {
+    hipLaunchKernelGGL(stats_slots_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, slots, rows, C, nseg, sums, acc0, acc1);
+}
+
 }  // namespace lp
 
-extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, lp_stream_t stream) {
+// workspace of the stand-alone reductions below: one [2][C] row of partial sums per workgroup
+extern "C" size_t lp_bn_reduce_workspace_bytes(int M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)lp::colreduce_blocks(M, C) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(x && sums && M > 0 && C > 0);
+    LP_REQUIRE(x && sums && workspace && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     dim3 grid(colreduce_blocks(M, C), 1);
+    LP_REQUIRE(workspace_bytes >= (size_t)grid.x * 2 * C * sizeof(float));
     hipLaunchKernelGGL((colreduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr, (const float*)nullptr, M,
-                       C, sums, (float*)nullptr, (float*)nullptr);
+                       C, (float*)workspace);
+    launch_stats_slots_reduce((const float*)workspace, (int)grid.x, 1, C, sums, nullptr, nullptr, (hipStream_t)stream);
+    return launch_status();
+}
+
+// mean / invstd (+ running statistics) straight from the per-workgroup rows a deferred lp_conv_fwd_bn / lp_stem_fwd_bn left
+// (lp_bn_fuse.defer_reduce, .slot_rows): reduction and finalize in ONE launch
+extern "C" int lp_bn_finalize_slots(const void* slots, int slot_rows, int nseg, float count0, float count1, int C, float eps, float momentum,
+                                    float* mean, float* invstd, float* running_mean, float* running_var, float* sums_out,
+                                    lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(slots && mean && invstd && slot_rows > 0 && (nseg == 1 || nseg == 2) && C > 0 && count0 > 0.f && (nseg == 1 || count1 > 0.f));
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)slots, slot_rows, count0,
+                       nseg == 2 ? count1 : count0, nseg, C, eps, momentum, mean, invstd, running_mean, running_var, sums_out);
     return launch_status();
 }
 
@@ -815,13 +881,15 @@ extern "C" int lp_bn_apply_seg(const void* x, const float* mean, const float* in
 }
 
 extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
-                                float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
+                                float* sums, float* dbeta_acc, float* dgamma_acc, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(dy && x && mean && invstd && sums && M > 0 && C > 0);
+    LP_REQUIRE(dy && x && mean && invstd && sums && workspace && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     dim3 grid(colreduce_blocks(M, C), 1);
+    LP_REQUIRE(workspace_bytes >= (size_t)grid.x * 2 * C * sizeof(float));
     hipLaunchKernelGGL((colreduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
-                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, M, C, sums, dbeta_acc, dgamma_acc);
+                       (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, M, C, (float*)workspace);
+    launch_stats_slots_reduce((const float*)workspace, (int)grid.x, 1, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -884,25 +952,42 @@ extern "C" int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const fl
     return launch_status();
 }
 
+static int pool_reduce_wgs(int B, int Hi, int Wi, int C) {
+    using namespace lp;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) return B * ((Ho + pool_v2_band() - 1) / pool_v2_band());   // one band per workgroup (4 resident per CU)
+    return pool_row_blocks(B * Hi, 4);
+}
+
+extern "C" size_t lp_bn_pool_bwd_workspace_bytes(int B, int Hi, int Wi, int C) {
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) return 0;
+    return (size_t)pool_reduce_wgs(B, Hi, Wi, C) * 2 * (size_t)C * sizeof(float);
+}
+
 extern "C" int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, int B, int Hi, int Wi, int C, float* sums, float* dbeta_acc,
-                                     float* dgamma_acc, lp_stream_t stream) {
+                                     float* dgamma_acc, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && workspace && B > 0 && Hi > 0 && Wi > 0 && C > 0);
     if (C % 8 != 0 || 256 % (C / 8) != 0) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     const long long pixels = (long long)B * Hi * Wi;
     if (pixels >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) {
-        const int band = pool_v2_band(), wgs = B * ((Ho + band - 1) / band);   // one band per workgroup (4 resident per CU)
+        const int band = pool_v2_band(), wgs = pool_reduce_wgs(B, Hi, Wi, C);
+        LP_REQUIRE(workspace_bytes >= (size_t)wgs * 2 * C * sizeof(float));
         hipLaunchKernelGGL(bn_pool_bwd_v2_kernel<false>, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, nullptr,
-                           0.f, B, Hi, Wi, Ho, Wo, band, sums, dbeta_acc, dgamma_acc, nullptr);
+                           0.f, B, Hi, Wi, Ho, Wo, band, (float*)workspace, nullptr);
+        launch_stats_slots_reduce((const float*)workspace, wgs, 1, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
         return launch_status();
     }
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pool_row_blocks(B * Hi, 4)), dim3(256), 0, (hipStream_t)stream,
+    const int wgs = pool_row_blocks(B * Hi, 4);
+    LP_REQUIRE(workspace_bytes >= (size_t)wgs * 2 * C * sizeof(float));
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi,
-                       Wi, C, Ho, Wo, sums, dbeta_acc, dgamma_acc);
+                       Wi, C, Ho, Wo, (float*)workspace);
+    launch_stats_slots_reduce((const float*)workspace, wgs, 1, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -917,7 +1002,7 @@ extern "C" int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const
         const int band = pool_v2_band(), wgs = B * ((Ho + band - 1) / band);
         hipLaunchKernelGGL(bn_pool_bwd_v2_kernel<true>, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
-                           1.f / count, B, Hi, Wi, Ho, Wo, band, nullptr, nullptr, nullptr, (unsigned short*)dx);
+                           1.f / count, B, Hi, Wi, Ho, Wo, band, nullptr, (unsigned short*)dx);
         return launch_status();
     }
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(pool_row_blocks(B * Hi)), dim3(256), 0, (hipStream_t)stream,

@@ -42,14 +42,16 @@ struct ConvEpilogue {
     const unsigned short* addend;  // [M][ldo] bf16 added before the store (gradient accumulation), or nullptr
     const unsigned short* relu_mask;  // [M][ldo] bf16 activation; outputs where it is <= 0 are zeroed (ReLU backward), or nullptr
     const unsigned char* relu_bits;   // same mask at 1 bit per element ([M][ldo/8] bytes, written by lp_bn_apply), or nullptr
-    // BatchNorm reductions fused into the store pass (bf16 outputs only).  `stats` receives, per 128-row tile, the column
-    // sums of the values actually stored (after rounding): [tile][0][c] = sum v, [tile][1][c] = sum v^2 (forward: the
-    // statistics of the next BatchNorm) or, with bn_z, sum v * xhat (backward: the two reductions of BatchNorm's gradient).
-    float* stats;                  // [stats_row0 + tile_m][2][N] or nullptr
-    int stats_row0;
-    // few row tiles (<= kStatsAtomicTiles): the tile sums are added straight into these (2, N) totals with atomics instead of
-    // going through `stats` and a second kernel (contention per address = number of row tiles); acc0 / acc1 receive them too
-    float* stats_sums;
+    // BatchNorm reductions fused into the store pass (bf16 outputs only; `stats` != nullptr switches them on): the column sums of the
+    // values actually stored (after rounding) - sum v and sum v^2 (forward: the statistics of the next BatchNorm) or, with bn_z,
+    // sum v * xhat (backward: the two reductions of BatchNorm's gradient).  Every persistent workgroup adds up its tiles' sums in a fixed
+    // order and leaves them in ITS OWN row of `stats_slots` ([workgroup][segment][2][N], zeroed by the workgroup itself at the start of
+    // the launch); stats_slots_reduce_kernel / bn_finalize_slots_kernel then add the rows in workgroup order: the totals repeat bit for
+    // bit from run to run (round 4; rounds 2 - 3 added the workgroups' sums into `stats_sums` with fp32 atomics, in arrival order -
+    // that form remains behind LP_STATS_ATOMIC=1 for A/B timing: stats_slots == nullptr, acc0 / acc1 receive the totals too).
+    float* stats;                  // non-null = take the sums
+    int stats_pad;
+    float* stats_sums;             // [segment][2][N] totals (always set with `stats`; written by the kernel only in the atomic form)
     float* stats_acc0;
     float* stats_acc1;
     const unsigned short* bn_z;    // [M][ldo] bf16 pre-normalisation tensor the gradient belongs to, or nullptr
@@ -71,7 +73,34 @@ struct ConvEpilogue {
     // straddles the boundary (host-checked: seg_images * rows per image is a multiple of the 128-row tile).  Segment s uses
     // bn_mean / bn_invstd + s * N and adds into stats_sums + s * 2 * N; 0 = one segment
     int seg_images;
+    float* stats_slots;            // this launch's [gridDim.x][segments][2][N] partial-sum rows (see `stats`), or nullptr = atomic form
 };
+
+// one workgroup's contribution to a fused BatchNorm sum (`idx` = 2 * segment offset + component * N + column): its own slot row, or - the
+// atomic A/B form - straight into the totals
+__device__ __forceinline__ void stats_emit(const ConvEpilogue& ep, int N, int idx, int comp, int col, float t) {
+    if (ep.stats_slots != nullptr) {
+        float* p = ep.stats_slots + (size_t)blockIdx.x * ((ep.seg_images > 0 ? 4 : 2) * N) + idx;
+        *p += t;   // (always the same thread of the same workgroup for a given address: program order)
+    } else {
+        atomicAdd(&ep.stats_sums[idx], t);
+        float* accp = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
+        if (accp != nullptr) atomicAdd(&accp[col], t);
+    }
+}
+
+// every workgroup zeroes ITS row of stats_slots before its walk (nobody else touches the row; the stores are acknowledged before the first
+// barrier of the K loop, which every flush is behind)
+__device__ __forceinline__ void stats_slots_zero(const ConvEpilogue& ep, int N, int tid, int nthreads) {
+    if (ep.stats_slots == nullptr) return;
+    const int n = (ep.seg_images > 0 ? 4 : 2) * N;
+    float* row = ep.stats_slots + (size_t)blockIdx.x * n;
+    for (int i = tid; i < n; i += nthreads) row[i] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+}
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
 // per-(image, head) products).  A convolution is the special case ldx = channels, ldw = filter length, one batch.
@@ -207,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int kchunk = tid & 7, rbase = tid >> 3;  // 8 x 16-B chunks per 64-wide K row; 32 rows per pass
+    stats_slots_zero(ep, N, tid, 256);
 
     // Workgroups are persistent: each walks the tile list with stride gridDim.x, and the operands of the NEXT tile's first K
     // step are already in flight (in registers) while the current tile's epilogue runs, so the store pass of one tile overlaps
@@ -368,21 +398,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 
     f32x16 acc[2][NT];
 
-    // Fused BatchNorm sums on the atomic path (ep.stats_sums): thread t < 2 BN owns (component t / BN, column t % BN) and ADDS UP its
-    // column's tile sums over the tiles this persistent workgroup walks; they go out as one atomic per (workgroup, column) when the column
-    // block or the BatchNorm segment changes and at the end - at most 512 workgroups x 2 BN atomics per launch however many tiles there are
-    // (one atomic per TILE and column was 3.5 M atomics for layer1's 13 824 tiles, which is why large launches used to write per-tile rows
-    // to a workspace and run tile_stats_reduce_kernel afterwards: 45 extra launches per step)
+    // Fused BatchNorm sums: thread t < 2 BN owns (component t / BN, column t % BN) and ADDS UP its column's tile sums over the tiles this
+    // persistent workgroup walks (a fixed order); they leave - into the workgroup's slot row, stats_emit - when the column block or the
+    // BatchNorm segment changes and at the end: at most 512 workgroups x 2 BN values per launch however many tiles there are
     float st_acc = 0.f;
     int st_n0 = -1, st_seg_off = 0;
     auto stats_flush = [&]() {
         if (st_n0 >= 0 && tid < 2 * BN) {
             const int comp = tid / BN, cl = tid % BN;
-            if (st_n0 + cl < N) {
-                atomicAdd(&ep.stats_sums[2 * st_seg_off + comp * N + st_n0 + cl], st_acc);
-                float* accp = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
-                if (accp != nullptr) atomicAdd(&accp[st_n0 + cl], st_acc);
-            }
+            if (st_n0 + cl < N) stats_emit(ep, N, 2 * st_seg_off + comp * N + st_n0 + cl, comp, st_n0 + cl, st_acc);
         }
         st_acc = 0.f;
     };
@@ -551,10 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                     float t = 0.f;
 #pragma unroll
                     for (int r = 0; r < RPP; ++r) t += so[(comp * RPP + r) * BN + cl];
-                    if (n0 + cl < N) {
-                        if (ep.stats_sums != nullptr) st_acc += t;
-                        else ep.stats[((size_t)(ep.stats_row0 + m0 / kBM) * 2 + comp) * N + n0 + cl] = t;
-                    }
+                    if (n0 + cl < N) st_acc += t;
                 }
             }
             return;
@@ -1060,50 +1081,6 @@ static void launch_wgrad_reduce(const float* ws, int slices, int tiles, int tile
     }
 }
 
-// sums[seg][(2,C)] += column sums of the per-tile partials written by the fused epilogues ([rows][2][C] fp32); the optional
-// accumulators receive the totals of all segments (d beta, d gamma of the BatchNorm backward).  The partial rows of one call are up
-// to 4 ranges (the parity-class launches of a stride-2 data gradient), each split at `mid` into the rows of BatchNorm segment 0 and
-// of segment 1 (mid == end: one segment); blockIdx.z = segment.
-struct StatRanges {
-    int n;
-    int begin[4], mid[4], end[4];
-};
-
-__global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __restrict__ partial, StatRanges rg, int C,
-                                                                float* __restrict__ sums, float* __restrict__ acc0,
-                                                                float* __restrict__ acc1) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const int seg = blockIdx.z;
-    float s = 0.f;
-    if (col < 2 * C)
-        for (int i = 0; i < rg.n; ++i) {
-            const int lo = seg == 0 ? rg.begin[i] : rg.mid[i], hi = seg == 0 ? rg.mid[i] : rg.end[i];
-            for (int r = lo + blockIdx.y * 4 + rl; r < hi; r += gridDim.y * 4) s += partial[(size_t)r * 2 * C + col];
-        }
-    red[rl][lane] = s;
-    __syncthreads();
-    if (rl == 0 && col < 2 * C) {
-        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        atomicAdd(&sums[(size_t)seg * 2 * C + col], t);
-        if (col < C) {
-            if (acc0) atomicAdd(&acc0[col], t);
-        } else if (acc1) {
-            atomicAdd(&acc1[col - C], t);
-        }
-    }
-}
-
-static void launch_tile_stats_reduce(const float* partial, const StatRanges& rg, int nseg, int C, float* sums, float* acc0, float* acc1,
-                                     hipStream_t st) {
-    int rows = 0;
-    for (int i = 0; i < rg.n; ++i) rows += rg.end[i] - rg.begin[i];
-    int gy = rows / 64 / nseg;
-    gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
-    hipLaunchKernelGGL(tile_stats_reduce_kernel, dim3((2 * C + 63) / 64, gy, nseg), dim3(256), 0, st, partial, rg, C, sums, acc0, acc1);
-}
-
 // rows of BatchNorm segment 0 in a launch whose images have `rows_per_image` output rows each; -1 if a 128-row tile would straddle
 // the boundary (unsupported), `M` itself for a single segment
 static long long seg_split_rows(int seg_images, int B, long long rows_per_image, long long M) {
@@ -1113,7 +1090,37 @@ static long long seg_split_rows(int seg_images, int B, long long rows_per_image,
     return (r % kBM == 0) ? r : -1;
 }
 
-static size_t bn_workspace_rows(long long m_out) { return (size_t)((m_out + kBM - 1) / kBM + 4); }
+// workspace of a fused launch: one [segments][2][N] row of partial sums per workgroup, at most 4 launches per call (the parity classes of a
+// stride-2 data gradient) of at most 2 workgroups per CU each
+static int bn_max_wgs();
+static size_t bn_workspace_floats(int N) { return (size_t)4 * (size_t)bn_max_wgs() * 4 * (size_t)N; }
+// the fused sums leave through per-workgroup rows and an ordered reduction (bit-reproducible); LP_STATS_ATOMIC=1 selects rounds 2 - 3's
+// fp32 atomics in arrival order (A/B timing only).  Read per call, so one process can run both.
+static bool stats_atomic() {
+    const char* e = getenv("LP_STATS_ATOMIC");
+    return e != nullptr && atoi(e) != 0;
+}
+// what every fused entry point does with its lp_bn_fuse: the epilogue's targets before the launches ...
+static void bn_fuse_begin(ConvEpilogue& ep, lp_bn_fuse* bn, bool bwd) {
+    ep.stats = (float*)bn->workspace;
+    ep.stats_sums = bn->sums;
+    ep.seg_images = bn->seg_images;
+    ep.stats_slots = stats_atomic() ? nullptr : (float*)bn->workspace;
+    if (bwd && ep.stats_slots == nullptr) ep.stats_acc0 = bn->dbeta_acc, ep.stats_acc1 = bn->dgamma_acc;
+    bn->slot_rows = 0;
+}
+// ... the rows one launch of `grid` workgroups takes ...
+static void bn_fuse_launched(ConvEpilogue& ep, lp_bn_fuse* bn, int N, int grid) {
+    if (ep.stats_slots == nullptr) return;
+    bn->slot_rows += grid;
+    ep.stats_slots += (size_t)grid * (bn->seg_images > 0 ? 4 : 2) * N;
+}
+// ... and the ordered reduction afterwards (unless the caller feeds the rows to lp_bn_finalize_slots itself: defer_reduce)
+static void bn_fuse_end(const ConvEpilogue& ep, lp_bn_fuse* bn, int N, bool bwd, hipStream_t st) {
+    if (ep.stats_slots == nullptr || bn->defer_reduce) return;
+    launch_stats_slots_reduce((const float*)bn->workspace, bn->slot_rows, bn->seg_images > 0 ? 2 : 1, N, bn->sums, bwd ? bn->dbeta_acc : nullptr,
+                              bwd ? bn->dgamma_acc : nullptr, st);
+}
 
 // which kernel family the most recent convolution entry point of this thread launched (lp_conv_last_kernel: the bench labels its
 // per-launch timings with the kernel that actually ran; tests assert the path they mean to exercise)
@@ -1137,7 +1144,7 @@ static int igemm_max_wgs() {
 
 // `gemm` (lp_gemm_nt only): operand pitches, batch strides and explicit operand sizes; nz = number of batched GEMMs
 template <int BN, int MODE>
-static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
+static int launch_igemm(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
                          hipStream_t st, const GemmExt* gemm = nullptr, int nz = 1, unsigned gemm_x_bytes = 0,
                          unsigned gemm_w_bytes = 0) {
     const int tm = (M + kBM - 1) / kBM, tn = (N + BN - 1) / BN, per_z = tm * tn, ntiles = per_z * nz;
@@ -1156,6 +1163,7 @@ static void launch_igemm(const void* x, const void* w, const ConvGeom& g, const 
     g_last_conv_kernel = LP_CONV_KERNEL_IGEMM;
     hipLaunchKernelGGL((conv_igemm_kernel<BN, MODE>), dim3(grid), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)w,
                        x_bytes, w_bytes, g, lat, gx, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep);
+    return grid;
 }
 
 // Pipelined kernel (conv_pipe.h): one 512-thread workgroup per CU walks 256 x BN tiles.  LP_CONV_PIPE=0 sends everything to
@@ -1177,6 +1185,8 @@ static int pipe_max_wgs() {
     return cus;
 }
 
+static int bn_max_wgs() { return igemm_max_wgs() > 2 * pipe_max_wgs() ? igemm_max_wgs() : 2 * pipe_max_wgs(); }
+
 // what the pipelined kernel covers: dense bf16 output of a trunk convolution (no fp32 copy; a bias only in the forward store pass, which
 // the Linear layers of lp_gemm_nt use), K a multiple of 64 and > 0, N a
 // multiple of its column block, fused BatchNorm sums on the atomic path only, and a BatchNorm segment boundary that falls on a 256-row tile
@@ -1184,7 +1194,6 @@ static bool pipe_eligible(const ConvEpilogue& ep, int M, int N, int K, int ck, l
     if (!conv_pipe_enabled()) return false;
     if (ep.out_bf16 == nullptr || ep.out_f32 != nullptr || (ep.bias != nullptr && !bias_ok) || ep.ldo != N || ep.n_store != N) return false;
     if (K <= 0 || ck % kBK != 0 || N % (N > 64 ? 128 : 64) != 0 || M <= 0) return false;
-    if (ep.stats != nullptr && ep.stats_sums == nullptr) return false;   // (the bit-reproducible workspace path stays on conv_igemm_kernel)
     if (ep.seg_images > 0 && seg_rows % kPM != 0) return false;
     return true;
 }
@@ -1236,17 +1245,18 @@ static bool res2d_ok(const ConvGeom& g, int ck, int N, const ConvEpilogue& ep) {
 }
 
 template <int MODE>
-static void launch_res2d(const void* x, const void* w, const ConvGeom& g, const ConvEpilogue& ep, hipStream_t st) {
+static int launch_res2d(const void* x, const void* w, const ConvGeom& g, const ConvEpilogue& ep, hipStream_t st) {
     const int ntiles = g.B * (g.Hi / 16) * (g.Wi / 16);
     const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
     const unsigned x_bytes = (unsigned)(2ull * g.B * g.Hi * g.Wi * 64), w_bytes = (unsigned)(2ull * 64 * 9 * 64);
     g_last_conv_kernel = LP_CONV_KERNEL_RES2D;
     hipLaunchKernelGGL((conv_res2d_kernel<MODE>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes, w_bytes,
                        g.B, g.Hi, g.Wi, ntiles, ep);
+    return grid;
 }
 
 template <int BN, int MODE, int EK, bool HALO = false>
-static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
+static int launch_pipe(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
                         hipStream_t st) {
     const int tm = (M + kPM - 1) / kPM, tn = N / BN, ntiles = tm * tn;
     const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
@@ -1259,28 +1269,19 @@ static void launch_pipe(const void* x, const void* w, const ConvGeom& g, const L
     const HaloDivs hd{make_fastdiv(g.Hi), make_fastdiv(g.Wi + 2), make_fastdiv(g.Hi + 2)};
     hipLaunchKernelGGL((conv_pipe_kernel<BN, MODE, EK, HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w,
                        x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, flags, hd);
+    return grid;
 }
 
 template <int BN>
-static void launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
-                              const ConvEpilogue& ep, hipStream_t st) {
-    if (kind == kEkZ && BN == 64 && res2d_ok(g, g.Co, N, ep)) launch_res2d<kModeDgrad>(x, w, g, ep, st);
-    else if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
-    else if (kind == kEkZ) launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
-    else if (kind == kEkAZB) launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
-    else launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
+static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
+                             const ConvEpilogue& ep, hipStream_t st) {
+    if (kind == kEkZ && BN == 64 && res2d_ok(g, g.Co, N, ep)) return launch_res2d<kModeDgrad>(x, w, g, ep, st);
+    if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) return launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
+    if (kind == kEkZ) return launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
+    if (kind == kEkAZB) return launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
+    return launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
 }
 
-// row tiles up to which the fused BatchNorm sums use atomics (see ConvEpilogue): every launch since the sums are accumulated per persistent
-// workgroup (conv_igemm_kernel: stats_flush; conv_pipe_kernel: per thread).  LP_STATS_ATOMIC_TILES=0 selects the other form - per-tile rows
-// in a workspace, summed by tile_stats_reduce_kernel - on conv_igemm_kernel, which implements it (the pipelined kernel declines such
-// launches, pipe_eligible).  Neither makes a whole step bit-reproducible: the stand-alone BatchNorm reductions (bn.hip) and the second
-// stage of tile_stats_reduce_kernel add their partial sums with fp32 atomics too.  Read per call, so one process can run both (tests).
-static int stats_atomic_tiles() {
-    const char* e = getenv("LP_STATS_ATOMIC_TILES");
-    return e ? atoi(e) : 0x7fffffff;   // (per-workgroup accumulation: the atomic path costs the same for any number of tiles)
-}
-#define kStatsAtomicTiles stats_atomic_tiles()
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
 
 struct WgradPlan {
@@ -1400,7 +1401,7 @@ static ConvGeom to_geom(const lp_conv_geom* c) {
 
 // out[b][ho][wo][co] = sum x[b][ho*st-pad+r][wo*st-pad+s][ci] * w[co][r][s][ci]  (+bias) ; x, w bf16
 static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
-                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream) {
+                         int n_store, lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1410,35 +1411,33 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
     ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    const int tm = (M + kBM - 1) / kBM;
     long long split = M;
     if (bn) {
-        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * N * sizeof(float) && bn->seg_images >= 0);
+        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_floats(N) * sizeof(float) && bn->seg_images >= 0);
         if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
         split = seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M);
         if (split < 0) return LP_ERR_UNSUPPORTED;
-        ep.seg_images = bn->seg_images;
-        ep.stats = (float*)bn->workspace;
-        if (tm <= kStatsAtomicTiles) ep.stats_sums = bn->sums;
+        bn_fuse_begin(ep, bn, false);
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
+    int grid = 0;
     if (pipe_eligible(ep, M, N, K, g.Ci, split, true)) {
         if (N > 64) {
-            if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
-            else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+            if (pipe_halo_ok(g, M, g.Ci, 384)) grid = launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            else grid = launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         } else if (res2d_ok(g, g.Ci, N, ep)) {
-            launch_res2d<kModeFwd>(x, w, g, ep, st);
+            grid = launch_res2d<kModeFwd>(x, w, g, ep, st);
         } else if (pipe_halo_ok(g, M, g.Ci, 512)) {
-            launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            grid = launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
         } else {
-            launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+            grid = launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         }
-    } else if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
-    else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
-    if (bn && ep.stats_sums == nullptr) {
-        const StatRanges rg{1, {0, 0, 0, 0}, {split == M ? tm : (int)(split / kBM), 0, 0, 0}, {tm, 0, 0, 0}};
-        launch_tile_stats_reduce(ep.stats, rg, bn->seg_images > 0 ? 2 : 1, N, bn->sums, nullptr, nullptr, st);
+    } else if (N > 64) grid = launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    else grid = launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    if (bn) {
+        bn_fuse_launched(ep, bn, N, grid);
+        bn_fuse_end(ep, bn, N, false, st);
     }
     return launch_status();
 }
@@ -1489,11 +1488,12 @@ extern "C" size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad
     using namespace lp;
     if (!geom_ok(geom)) return 0;
     const long long rows = (long long)geom->B * (dgrad ? geom->Hi * geom->Wi : geom->Ho * geom->Wo);
-    return bn_workspace_rows(rows) * 2 * (size_t)(dgrad ? geom->Ci : geom->Co) * sizeof(float);
+    (void)rows;
+    return bn_workspace_floats(dgrad ? geom->Ci : geom->Co) * sizeof(float);
 }
 
 // conv + the [sum, sum of squares] of its (bf16-rounded) output per channel: the statistics pass of the BatchNorm that follows
-extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn,
                               lp_stream_t stream) {
     LP_REQUIRE(bn && geom && out_bf16);
     return conv_fwd_impl(x, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream);
@@ -1572,7 +1572,7 @@ extern "C" int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int 
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
 static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
                            const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
-                           const lp_bn_fuse* bn, lp_stream_t stream) {
+                           lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1587,9 +1587,10 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         // the reductions cover every pixel exactly once, so no class may be skipped and the output must be the dense bf16 tensor
         LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && bn->workspace && dx_bf16 && !dx_f32 && !skip_empty_classes &&
                    ldo == N && ep.n_store == N && (!bn->mask_from_z || (bn->gamma && bn->beta)) &&
-                   bn->workspace_bytes >= bn_workspace_rows((long long)g.B * g.Hi * g.Wi) * 2 * N * sizeof(float));
+                   bn->workspace_bytes >= bn_workspace_floats(N) * sizeof(float));
         if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
-        ep.stats = (float*)bn->workspace;
+        LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)) && bn->seg_images >= 0);
+        bn_fuse_begin(ep, bn, true);
         ep.bn_z = (const unsigned short*)bn->z;
         ep.bn_mean = bn->mean;
         ep.bn_invstd = bn->invstd;
@@ -1597,43 +1598,27 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         ep.bn_beta = bn->beta;
         ep.mask_from_z = bn->mask_from_z;
         ep.relu_bits = (const unsigned char*)bn->relu_bits;
-        if (((long long)g.B * g.Hi * g.Wi + kBM - 1) / kBM <= kStatsAtomicTiles) {
-            ep.stats_sums = bn->sums;
-            ep.stats_acc0 = bn->dbeta_acc;
-            ep.stats_acc1 = bn->dgamma_acc;
-        }
-        LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)) && bn->seg_images >= 0);
-        ep.seg_images = bn->seg_images;
     }
     hipStream_t st = (hipStream_t)stream;
-    int stats_rows = 0;
-    StatRanges rg{};
+    int n_launches = 0;
     bool seg_ok = true;
     auto launch = [&](const Lattice& lat) {
         const int M = g.B * lat.nh * lat.nw, K = lat.nr * lat.ns * g.Co;
         if (M <= 0) return;
-        const int tm = (M + kBM - 1) / kBM;
-        ep.stats_row0 = stats_rows;
-        if (bn) {
-            const long long split = seg_split_rows(bn->seg_images, g.B, (long long)lat.nh * lat.nw, M);
-            if (split < 0 || rg.n >= 4) {
-                seg_ok = false;
-                return;
-            }
-            rg.begin[rg.n] = stats_rows;
-            rg.mid[rg.n] = stats_rows + (split == M ? tm : (int)(split / kBM));
-            rg.end[rg.n] = stats_rows + tm;
-            ++rg.n;
-        }
-        stats_rows += tm;
         const long long seg_rows = bn ? seg_split_rows(bn->seg_images, g.B, (long long)lat.nh * lat.nw, M) : M;
+        if (seg_rows < 0 || ++n_launches > 4) {
+            seg_ok = false;
+            return;
+        }
         const int kind = pipe_dgrad_kind(ep);
         const bool full_lattice = lat.hstep == 1 && lat.wstep == 1;   // (kEkAZB recomputes its output offsets from the row index)
+        int grid;
         if (kind >= 0 && (kind != kEkAZB || full_lattice) && pipe_eligible(ep, M, N, K, g.Co, seg_rows)) {
-            if (N > 64) launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
-            else launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);
-        } else if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
-        else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+            if (N > 64) grid = launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
+            else grid = launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);
+        } else if (N > 64) grid = launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        else grid = launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        if (bn) bn_fuse_launched(ep, bn, N, grid);
     };
     if (bn && bn->seg_images > 0) {  // check every launch's segment boundary BEFORE anything is enqueued
         if (bn->seg_images >= g.B) return LP_ERR_UNSUPPORTED;
@@ -1658,8 +1643,7 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
             }
     }
     if (!seg_ok) return LP_ERR_UNSUPPORTED;
-    if (bn && ep.stats_sums == nullptr)
-        launch_tile_stats_reduce(ep.stats, rg, bn->seg_images > 0 ? 2 : 1, N, bn->sums, bn->dbeta_acc, bn->dgamma_acc, st);
+    if (bn) bn_fuse_end(ep, bn, N, true, st);
     return launch_status();
 }
 
@@ -1671,7 +1655,7 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
 
 // data gradient + ReLU backward + the two reductions of the BatchNorm backward that consumes dx (sum dx, sum dx * xhat)
 extern "C" int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
-                                void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream) {
+                                void* dx_bf16, lp_bn_fuse* bn, lp_stream_t stream) {
     LP_REQUIRE(bn && geom);
     return conv_dgrad_impl(dy, wd, geom, nullptr, addend, relu_mask, dx_bf16, nullptr, geom->Ci, 0, 0, bn, stream);
 }
@@ -1787,45 +1771,37 @@ extern "C" int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* 
 }
 
 // 7x7/2 stem on NHWC4 bf16 input (channel 3 = 0): weights [64][7+1][8][4] zero padded (K = 256)
-static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn,
                          lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x4 && w && geom_ok(geom) && out_bf16);
     ConvGeom g = to_geom(geom);
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo;
-    const int tm = (M + kBM - 1) / kBM;
     ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr, nullptr,
                     nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    long long split = M;
     if (bn) {
-        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_rows(M) * 2 * 64 * sizeof(float) && bn->seg_images >= 0);
-        split = seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M);
-        if (split < 0) return LP_ERR_UNSUPPORTED;
-        ep.seg_images = bn->seg_images;
-        ep.stats = (float*)bn->workspace;
+        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_floats(64) * sizeof(float) && bn->seg_images >= 0);
+        if (seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M) < 0) return LP_ERR_UNSUPPORTED;
+        bn_fuse_begin(ep, bn, false);
     }
-    // conv_stem2d_kernel (conv_res2d.h): 16 x 16 output tiles, filter resident in LDS, fused sums by atomics.  LP_STEM_2D=0 (A/B runs,
-    // bit-identity tests) and the bit-reproducible sums (LP_STATS_ATOMIC_TILES=0) keep conv_igemm_kernel<64, stem>
+    // conv_stem2d_kernel (conv_res2d.h): 16 x 16 output tiles, filter resident in LDS.  LP_STEM_2D=0 (A/B runs, bit-identity tests) keeps
+    // conv_igemm_kernel<64, stem>
     const char* s2 = getenv("LP_STEM_2D");
-    if (conv_pipe_enabled() && (s2 == nullptr || atoi(s2) != 0) && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo &&
-        (!bn || tm <= kStatsAtomicTiles)) {
-        if (bn) {
-            ep.stats = nullptr;
-            ep.stats_sums = bn->sums;
-        }
+    int grid;
+    if (conv_pipe_enabled() && (s2 == nullptr || atoi(s2) != 0) && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo) {
         const int ntiles = g.B * (g.Ho / 16) * (g.Wo / 16);
-        const int grid = ntiles < 2 * pipe_max_wgs() ? ntiles : 2 * pipe_max_wgs();
+        grid = ntiles < 2 * pipe_max_wgs() ? ntiles : 2 * pipe_max_wgs();
         g_last_conv_kernel = LP_CONV_KERNEL_RES2D;
         hipLaunchKernelGGL(conv_stem2d_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const unsigned short*)x4, (const unsigned short*)w,
                            (unsigned)(2ull * g.B * g.Hi * g.Wi * 4), g.B, g.Ho, g.Wo, ntiles, ep);
-        return launch_status();
+    } else {
+        const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
+        grid = launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
     }
-    const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
     if (bn) {
-        const StatRanges rg{1, {0, 0, 0, 0}, {split == M ? tm : (int)(split / kBM), 0, 0, 0}, {tm, 0, 0, 0}};
-        launch_tile_stats_reduce(ep.stats, rg, bn->seg_images > 0 ? 2 : 1, 64, bn->sums, nullptr, nullptr, (hipStream_t)stream);
+        bn_fuse_launched(ep, bn, 64, grid);
+        bn_fuse_end(ep, bn, 64, false, (hipStream_t)stream);
     }
     return launch_status();
 }
@@ -1834,7 +1810,7 @@ extern "C" int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* ge
     return stem_fwd_impl(x4, w, geom, out_bf16, nullptr, stream);
 }
 
-extern "C" int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
+extern "C" int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn,
                               lp_stream_t stream) {
     LP_REQUIRE(bn);
     return stem_fwd_impl(x4, w, geom, out_bf16, bn, stream);

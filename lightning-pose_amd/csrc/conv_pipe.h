@@ -111,6 +111,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
+    stats_slots_zero(ep, N, tid, 512);
 
     const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_w = make_buf_rsrc(Wt, w_bytes);
     const int rows_y = lat.nh, rows_x = lat.nw;
@@ -438,9 +439,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) t += scratch[((wn_ * 4 + w4) * 2 + comp) * (NT * 32) + c];
                 if (bwd && comp == 1) t *= ep.bn_invstd[st_seg_off + st_n0 + cl];   // sum dy (z - mean)  ->  sum dy xhat
-                atomicAdd(&ep.stats_sums[2 * st_seg_off + comp * N + st_n0 + cl], t);
-                float* accp = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
-                if (accp != nullptr) atomicAdd(&accp[st_n0 + cl], t);
+                stats_emit(ep, N, 2 * st_seg_off + comp * N + st_n0 + cl, comp, st_n0 + cl, t);
             }
             __syncthreads();
         }

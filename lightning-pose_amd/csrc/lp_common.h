@@ -193,6 +193,44 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return t;
 }
 
+// ---- bit-reproducible cross-workgroup sums (round 4) ---------------------------------------------------------------------
+// Kernels that reduce over rows spread across workgroups (the fused BatchNorm sums of the convolution store passes, colreduce_kernel, the
+// stem's pool reduction) leave ONE row of partial sums per workgroup in a workspace - `slots`, [rows][npairs][C], a pair = (segment,
+// component) - instead of adding them into the totals with fp32 atomics in arrival order.  slots_totals adds the rows up in an order that
+// depends on nothing but (rows, npairs): RG = 16 (npairs 4) or 32 (npairs 2) interleaved chains (rows rg, rg + RG, ...) per element, joined
+// by a fixed pairwise tree.  One 256-thread workgroup covers the 16 channels [c0, c0 + 16) of every pair with float4 loads; on return
+// red[0][pair * 16 + c] holds the total of (pair, c0 + c).  `red` = float[32][64] of LDS.
+__device__ __forceinline__ void slots_totals(const float* __restrict__ slots, int rows, int C, int npairs, int c0, float (*red)[64]) {
+    const int P4 = npairs * 4, RG = 256 / P4;
+    const int pq = (int)threadIdx.x % P4, rg = (int)threadIdx.x / P4;
+    const int n = npairs * C;
+    const float* src = slots + (pq >> 2) * C + c0 + (pq & 3) * 4;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (c0 + (pq & 3) * 4 < C)   // (C is a multiple of 8: the last workgroup may cover 8 channels only)
+    for (int r = rg; r < rows; r += RG) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * n);
+        t0 += v[0], t1 += v[1], t2 += v[2], t3 += v[3];
+    }
+    red[rg][pq * 4 + 0] = t0, red[rg][pq * 4 + 1] = t1, red[rg][pq * 4 + 2] = t2, red[rg][pq * 4 + 3] = t3;
+    __syncthreads();
+    float tot = 0.f;
+    if ((int)threadIdx.x < npairs * 16) {
+        float u[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) u[i] = i < RG ? red[i][threadIdx.x] : 0.f;
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) u[i] += u[i + w];
+        tot = u[0];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < npairs * 16) red[0][threadIdx.x] = tot;
+    __syncthreads();
+}
+// sums[pair][c] += total of the slot rows; acc0 / acc1 (optional) += the totals of component 0 / 1 over all segments (bn.hip)
+void launch_stats_slots_reduce(const float* slots, int rows, int nseg, int C, float* sums, float* acc0, float* acc1, hipStream_t st);
+
 // ---- host-side launch epilogue ------------------------------------------------------------------
 inline int launch_status() {
     hipError_t e = hipGetLastError();

@@ -224,7 +224,8 @@ class Engine:
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
         self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
-        self._bn_ws: torch.Tensor | None = None     # per-tile column sums of the fused BatchNorm reductions
+        self._bn_ws: torch.Tensor | None = None     # per-workgroup rows of the fused BatchNorm reductions (summed in workgroup order)
+        self._red_ws: torch.Tensor | None = None    # the same for the stand-alone reductions
         self._side = None                            # side stream of the weight-gradient launches (created on first use)
         self._side_busy = False
         self._side_keep: list = []                   # operands of the side-stream launches in flight (released at the join)
@@ -409,9 +410,18 @@ class Engine:
         Wo = (Wi + 2 * c.pad - c.k) // c.stride + 1
         return _lib.ConvGeom(B, Hi, Wi, c.Ci, Ho, Wo, c.Co, c.k, c.k, c.stride, c.pad)
 
+    def _reduce_ws(self, nbytes: int) -> torch.Tensor:
+        """Scratch rows of the stand-alone reductions (lp_bn_stats, lp_bn_bwd_reduce, lp_bn_pool_bwd_reduce): one buffer, reused in
+        stream order like the fused launches' workspace."""
+        if self._red_ws is None or self._red_ws.numel() < nbytes:
+            self._red_ws = torch.empty(max(nbytes, 4 << 20), device=self.device, dtype=torch.uint8)
+        return self._red_ws
+
     def _bn_fuse(self, g: _lib.ConvGeom, dgrad: bool, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None,
-                 mask_from_z: bool = False, relu_bits=None, seg: int = 0) -> _lib.BnFuse:
-        """lp_bn_fuse for one launch; the per-tile workspace is one scratch buffer reused by every launch of the stream."""
+                 mask_from_z: bool = False, relu_bits=None, seg: int = 0, defer: bool = False) -> _lib.BnFuse:
+        """lp_bn_fuse for one launch; the workspace (one row of partial sums per workgroup) is one scratch buffer reused by every launch
+        of the stream.  ``defer``: leave the rows for lp_bn_finalize_slots (forward without SyncBatchNorm: reduction + finalize in one
+        launch) instead of reducing them into ``sums`` inside the call."""
         need = int(self._lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
         if self._bn_ws is None or self._bn_ws.numel() < need:
             self._bn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
@@ -419,6 +429,7 @@ class Engine:
         f = _lib.BnFuse()
         f.sums, f.workspace, f.workspace_bytes = sums.data_ptr(), ws.data_ptr(), need
         f.seg_images = seg
+        f.defer_reduce = int(defer)
         if dgrad:
             f.z, f.mean, f.invstd = z.data_ptr(), mean.data_ptr(), invstd.data_ptr()
             f.gamma, f.beta = self.param_view(b, "weight").data_ptr(), self.param_view(b, "bias").data_ptr()
@@ -429,8 +440,11 @@ class Engine:
 
     def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None, seg: int = 0):
         """``sums`` (segments,2,Co): also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics pass, fused);
-        ``seg`` > 0: images [0, seg) and [seg, B) are two BatchNorm segments with their own sums."""
+        ``seg`` > 0: images [0, seg) and [seg, B) are two BatchNorm segments with their own sums.  Without SyncBatchNorm the sums stay
+        in the launch's per-workgroup rows (``self._slots`` = (workspace, rows) for the _bn_moments call that follows)."""
         g = self._geom(c, B, Hi, Wi)
+        self._slots = None
+        defer = sums is not None and not self.sync_bn
         out = torch.empty(B, g.Ho, g.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
         w = self.Wb[c.w_off:]
         st = ops._stream()
@@ -438,16 +452,18 @@ class Engine:
             if sums is None:
                 run = lambda: check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), st), "lp_stem_fwd")  # noqa: E731
             else:
-                f = self._bn_fuse(g, False, sums, seg=seg)
+                f = self._bn_fuse(g, False, sums, seg=seg, defer=defer)
                 run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
             self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run, self._bytes(c, g))
         else:
             if sums is None:
                 run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
             else:
-                f = self._bn_fuse(g, False, sums, seg=seg)
+                f = self._bn_fuse(g, False, sums, seg=seg, defer=defer)
                 run = lambda: check(self._lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_conv_fwd_bn")  # noqa: E731
             self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run, self._bytes(c, g))
+        if defer and f.slot_rows > 0:
+            self._slots = (self._bn_ws, int(f.slot_rows))
         return out, g
 
     @staticmethod
@@ -487,16 +503,23 @@ class Engine:
         mean = torch.empty(len(segs) * b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         if training:
+            slots = getattr(self, "_slots", None) if have_sums else None
+            self._slots = None
             if not have_sums:
+                ws = self._reduce_ws(int(self._lib.lp_bn_reduce_workspace_bytes(M, b.C)))
                 for si, (i0, n) in enumerate(segs):
-                    check(self._lib.lp_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), ops._stream()), "lp_bn_stats")
+                    check(self._lib.lp_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), _p(ws), ws.numel(), ops._stream()),
+                          "lp_bn_stats")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:  # ONE message carries every segment's [sum, sum of squares]
                 self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
-            if len(segs) == 1:
+            if slots is not None:   # the convolution left per-workgroup rows: ordered reduction + finalize in ONE launch
+                check(self._lib.lp_bn_finalize_slots(_p(slots[0]), slots[1], len(segs), counts[0], counts[-1], b.C, BN_EPS, BN_MOMENTUM,
+                                                     _p(mean), _p(invstd), rm, rv, None, ops._stream()), "lp_bn_finalize_slots")
+            elif len(segs) == 1:
                 check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
                       "lp_bn_finalize")
             else:
@@ -575,7 +598,8 @@ class Engine:
             g = self._geom(c, B, hs, ws)
             x_small = T[f"head.in{li}"]
             bsum = self._zeros_f32(2 * CPAD)
-            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), ops._stream()), "lp_bn_stats(bias)")
+            rws = self._reduce_ws(int(self._lib.lp_bn_reduce_workspace_bytes(B * h * w, CPAD)))
+            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), _p(rws), rws.numel(), ops._stream()), "lp_bn_stats(bias)")
             self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
             self._wgrad(dcur, x_small, g, self.G[c.w_off:])
             dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
@@ -761,10 +785,11 @@ class Engine:
         Cn = b.C
         if sums is None:
             sums = self._zeros_f32(len(segs) * 2 * Cn)
+            ws = self._reduce_ws(int(self._lib.lp_bn_reduce_workspace_bytes(M, Cn)))
             for si, (i0, n) in enumerate(segs):
                 check(self._lib.lp_bn_bwd_reduce(_p(dy[i0:i0 + n]), _p(y_out[i0:i0 + n]) if y_out is not None else None, _p(z[i0:i0 + n]),
                                                  _p(mean[si * Cn:]), _p(invstd[si * Cn:]), n * rpi, Cn, _p(sums[si * 2 * Cn:]),
-                                                 _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), ops._stream()), "lp_bn_bwd_reduce")
+                                                 _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), _p(ws), ws.numel(), ops._stream()), "lp_bn_bwd_reduce")
         world = 1
         if not self._bwd_training:
             # eval-mode BatchNorm (running statistics) is a fixed per-channel affine map: dz = dy * gamma * invstd, without the
@@ -907,10 +932,11 @@ class Engine:
         ssum = self._zeros_f32(nseg * 2 * sb.C)
         gam, bet = self.param_view(sb, "weight"), self.param_view(sb, "bias")
         arg, sz, smu, siv = T["pool.arg"], T["stem.z"], T["stem.mu"], T["stem.iv"]
+        ws = self._reduce_ws(int(self._lib.lp_bn_pool_bwd_workspace_bytes(B, sh, sw, 64)))
         for si, (i0, n) in enumerate(segs):
             check(self._lib.lp_bn_pool_bwd_reduce(_p(arg[i0:i0 + n]), _p(d[i0:i0 + n]), _p(sz[i0:i0 + n]), _p(smu[si * sb.C:]), _p(siv[si * sb.C:]),
                                                   _p(gam), _p(bet), n, sh, sw, 64, _p(ssum[si * 2 * sb.C:]), _p(self.G[sb.b_off:]),
-                                                  _p(self.G[sb.g_off:]), ops._stream()), "lp_bn_pool_bwd_reduce")
+                                                  _p(self.G[sb.g_off:]), _p(ws), ws.numel(), ops._stream()), "lp_bn_pool_bwd_reduce")
         world = 1
         if not self._bwd_training:
             ssum = torch.zeros_like(ssum)

@@ -224,7 +224,9 @@ class HeatmapTracker(BaseSupervisedTracker):
         mh, mw = model_dims(batch_dict)
         views = batch_num_views(batch_dict)
         fm = ops.DecodeFrameMap(transforms, is_multiview, batch_dict["bbox"], views, mh, mw, heat.shape[1])
-        return ops.decode(heat, self.downsample_factor, float(self.head.temperature), fm)
+        if getattr(self, "_decode_prune", None) is None:
+            self._decode_prune = ops._DecodePruneAuto()   # this model's own plain / pruned decode choice (made from ITS maps)
+        return ops.decode(heat, self.downsample_factor, float(self.head.temperature), fm, self._decode_prune)
 
     def get_loss_inputs_labeled(self, batch_dict: dict) -> HeatmapTrackerLabeledOutputsDict:
         predicted_heatmaps = self.forward(batch_dict["images"])

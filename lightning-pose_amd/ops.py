@@ -130,6 +130,16 @@ class DecodeFrameMap:
                 self.struct.bbox = self._bbox.data_ptr()
 
 
+def _prune_env() -> str:
+    """LP_DECODE_PRUNE: "auto" (default / unset / empty), "0" or "1" - anything else is a configuration error, not a silent default"""
+    v = os.environ.get("LP_DECODE_PRUNE", "").strip().lower()
+    if v in ("", "auto"):
+        return "auto"
+    if v in ("0", "1"):
+        return v
+    raise ValueError(f"LP_DECODE_PRUNE must be auto, 0 or 1 (got {v!r})")
+
+
 class _DecodePruneAuto:
     """Chooses between the plain and the exactly-pruned decode kernels (lp_decode_set_prune) from what the decode itself reports.
 
@@ -138,34 +148,54 @@ class _DecodePruneAuto:
     (forward 1.4x, backward 1.8x, profiles/r02k_decode_microbench.jsonl) when most maps are peaked and costs when they are flat, and which
     regime a run is in changes once, early in training.  So every PERIOD-th call (and the FIRST-th) the fraction of peaked maps is reduced
     on the device and copied to pinned host memory WITHOUT a synchronisation; a later call picks the value up once its event has
-    completed and flips the switch if needed.  LP_DECODE_PRUNE=0 / 1 pins the choice instead (read per call)."""
+    completed and flips the switch if needed.  LP_DECODE_PRUNE=0 / 1 pins the choice instead (read per call).
+
+    One instance per OWNER (a tracker: HeatmapTracker._decode passes its own; stand-alone ops.decode calls share `_decode_prune_default`),
+    so one model's maps never steer another's kernels and a fresh model starts from the plain kernels (round 3 kept one process-wide
+    object: ADVICE r3).  The library's switch is process-wide, so every call states what its owner wants (`_lib_mode` caches what the
+    library was last given).  While the current stream is being captured into a HIP graph nothing here runs - no event query, no pinned
+    allocation, no copy, no counter: a replayed graph keeps the kernels it was captured with, and the eager steps around captures (the
+    warm-up steps, every re-capture at an epoch boundary) are where the choice is re-evaluated."""
 
     PERIOD, FIRST, PEAKED_FRACTION_OF_PIXELS, PEAKED_MAPS = 32, 2, 0.01, 0.5
+    _lib_mode = -2   # what lp_decode_set_prune was last given by anyone (-2: nothing yet, -1: "follow the environment")
 
     def __init__(self) -> None:
-        self.calls, self.pending, self.state = 0, None, -2   # state: what lp_decode_set_prune was last given (-2: nothing yet)
+        self.calls, self.pending, self.want = 0, None, 0   # want: this owner's current choice (0 plain, 1 pruned)
 
-    def _set(self, mode: int) -> None:
-        if mode != self.state:
+    @property
+    def state(self) -> int:
+        """what the library is set to right now (tests, bench): -1 environment, 0 plain, 1 pruned, -2 nothing set yet"""
+        return _DecodePruneAuto._lib_mode
+
+    @staticmethod
+    def _set(mode: int) -> None:
+        if mode != _DecodePruneAuto._lib_mode:
             _lib.lib().lp_decode_set_prune(mode)
-            self.state = mode
+            _DecodePruneAuto._lib_mode = mode
+
+    @staticmethod
+    def _capturing() -> bool:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
     def before(self) -> None:
-        env = os.environ.get("LP_DECODE_PRUNE", "auto")
+        env = _prune_env()
         if env != "auto":          # pinned by the environment: the library follows it
             self._set(-1)
             self.pending = None
             return
-        if self.state in (-2, -1):
-            self._set(0)
+        if self._capturing():
+            self._set(self.want)   # (a host-side switch: harmless inside a capture)
+            return
         if self.pending is not None:
             host, ev = self.pending
             if ev is None or ev.query():
-                self._set(1 if float(host[0]) >= self.PEAKED_MAPS else 0)
+                self.want = 1 if float(host[0]) >= self.PEAKED_MAPS else 0
                 self.pending = None
+        self._set(self.want)
 
     def after(self, stats: torch.Tensor, n_up: int) -> None:
-        if os.environ.get("LP_DECODE_PRUNE", "auto") != "auto":
+        if _prune_env() != "auto" or self._capturing():
             return
         self.calls += 1
         if self.pending is not None or not (self.calls == self.FIRST or self.calls % self.PERIOD == 0):
@@ -181,12 +211,13 @@ class _DecodePruneAuto:
             self.pending = (frac.detach().clone(), None)
 
 
-_decode_prune_auto = _DecodePruneAuto()
+_decode_prune_default = _DecodePruneAuto()
+_decode_prune_auto = _decode_prune_default   # (the name round 3's tests and bench read)
 
 
 class _DecodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, heat, ds, temperature, frame_map):
+    def forward(ctx, heat, ds, temperature, frame_map, prune):
         require_device(heat)
         ctx.in_dtype = heat.dtype
         heat = heat.to(torch.float32).contiguous()
@@ -197,11 +228,11 @@ class _DecodeFn(torch.autograd.Function):
         kp_frame = torch.empty_like(kp_aug)
         conf = torch.empty(b, k, device=heat.device, dtype=torch.float32)
         stats = torch.empty(b, k, 4, device=heat.device, dtype=torch.float32)
-        _decode_prune_auto.before()
+        prune.before()
         check(_lib.lib().lp_decode_fwd(_p(heat), b, k, h, w, ds, float(temperature), C.byref(tables),
                                        C.byref(frame_map.struct), _p(kp_aug), _p(kp_frame), _p(conf), _p(stats), _stream()),
               "lp_decode_fwd")
-        _decode_prune_auto.after(stats, h * w * (4 ** int(ds)))
+        prune.after(stats, h * w * (4 ** int(ds)))
         ctx.save_for_backward(heat, stats)
         ctx.args = (ds, float(temperature), frame_map, tables, keep)
         ctx.mark_non_differentiable(conf)
@@ -217,7 +248,7 @@ class _DecodeFn(torch.autograd.Function):
         g_heat = torch.empty_like(heat)
         check(_lib.lib().lp_decode_bwd(_p(heat), b, k, h, w, ds, temperature, C.byref(tables), C.byref(frame_map.struct),
                                        _p(stats), _p(ga), _p(gf), _p(g_heat), 0, _stream()), "lp_decode_bwd")
-        return g_heat.to(ctx.in_dtype), None, None, None
+        return g_heat.to(ctx.in_dtype), None, None, None, None
 
 
 class _FrameMapFn(torch.autograd.Function):
@@ -246,9 +277,11 @@ def frame_map_apply(keypoints: torch.Tensor, frame_map: DecodeFrameMap) -> torch
     return _FrameMapFn.apply(keypoints, frame_map)
 
 
-def decode(heatmaps: torch.Tensor, downsample_factor: int, temperature: float, frame_map: DecodeFrameMap):
-    """heatmaps (B,K,h,w) -> keypoints in model px (B,2K), keypoints in frame px (B,2K), confidences (B,K)."""
-    return _DecodeFn.apply(heatmaps, int(downsample_factor), float(temperature), frame_map)
+def decode(heatmaps: torch.Tensor, downsample_factor: int, temperature: float, frame_map: DecodeFrameMap,
+           prune: "_DecodePruneAuto | None" = None):
+    """heatmaps (B,K,h,w) -> keypoints in model px (B,2K), keypoints in frame px (B,2K), confidences (B,K).
+    ``prune``: the caller's own plain / pruned-kernel chooser (a tracker passes its own, see _DecodePruneAuto); default: a shared one."""
+    return _DecodeFn.apply(heatmaps, int(downsample_factor), float(temperature), frame_map, prune or _decode_prune_default)
 
 
 # --------------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 1, callbacks: list | None = None, limit_train_batches: int | None = None,
                  data_parallel: bool | None = None, sync_batchnorm: bool = True, accumulate_grad_batches: int = 1,
-                 hip_graph: bool | None = None):
+                 hip_graph: bool | None = None, log_every_n_steps: int = 50):
         self.max_epochs = max_epochs
         self.callbacks = callbacks or []
         self.limit_train_batches = limit_train_batches
@@ -30,6 +30,11 @@ class Trainer:
         self.accumulate_grad_batches = accumulate_grad_batches
         self._want_dp = data_parallel
         self._want_graph = hip_graph          # None: LP_HIP_GRAPH decides (graph_step.py)
+        # The step's logged scalars stay ON THE DEVICE; they reach the host every log_every_n_steps optimiser steps (Lightning's default 50;
+        # the reference passes cfg.training.log_every_n_steps, train.py:420) and at the end of every epoch, as ONE packed copy.  Round 3
+        # called float() on each of ~15 scalars after every batch: a full host <-> device synchronisation per step, which made
+        # MAX_STEPS_IN_FLIGHT meaningless for anyone who trained through fit() instead of training_batch().
+        self.log_every_n_steps = max(1, int(log_every_n_steps))
         self._inflight: list = []             # "step finished" events: the host stays at most MAX_STEPS_IN_FLIGHT steps ahead of the device
         self._graphed = None
         self.dp: DataParallel | None = None
@@ -149,6 +154,19 @@ class Trainer:
         self.validation_history.append(means)
         return means
 
+    def _flush_logged(self, model) -> None:
+        """the current step's logged values -> one host record: device scalars travel as ONE stacked copy (the only synchronisation)"""
+        logged = getattr(model, "logged", {})
+        if not logged:
+            return
+        dev_keys = [k for k, v in logged.items() if torch.is_tensor(v) and v.device.type != "cpu"]
+        rec = {k: float(v) for k, v in logged.items() if k not in dev_keys}
+        if dev_keys:
+            vals = torch.stack([logged[k].detach().float().reshape(()) for k in dev_keys]).tolist()
+            rec.update(zip(dev_keys, vals))
+        rec["step"] = float(model.global_step)
+        self.logged_history.append({k: rec[k] for k in list(logged) + ["step"]})
+
     def fit(self, model, batches: Callable[[int], Iterable[dict]] | Iterable[dict],
             val_batches: Callable[[int], Iterable[dict]] | None = None) -> None:
         self.setup(model)
@@ -166,7 +184,8 @@ class Trainer:
                 batch, nxt = nxt, next(it, None)
                 last = nxt is None or (self.limit_train_batches is not None and batch_idx + 1 >= self.limit_train_batches)
                 self.training_batch(model, batch, batch_idx, last_in_epoch=last)
-                self.logged_history.append({k: float(v) for k, v in getattr(model, "logged", {}).items()})
+                if last or model.global_step % self.log_every_n_steps == 0:
+                    self._flush_logged(model)
                 batch_idx += 1
                 if last:
                     break

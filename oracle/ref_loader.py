@@ -1,9 +1,11 @@
 """Import the reference's OWN hot-path modules, verbatim, from /root/reference under stubs.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Works only in the build container:
-``/root/reference`` does not exist on the GPU box, so nothing that runs there may call this.
-Used by ``tests/golden/make_golden.py`` (fixture generation) and by the CPU tests that pin
-``oracle.restated`` directly against the reference (skipped when the tree is absent).
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  ``/root/reference`` exists in the build container
+only; on the GPU box the loader falls back to ``oracle/_ref/`` - the same hot-path files, copied
+verbatim by ``oracle/make_ref.py`` (git-ignored, shipped with the snapshot).  Used by
+``tests/golden/make_golden.py`` (fixture generation), by the tests that pin ``oracle.restated`` and the
+product directly against the reference (skipped when neither tree is present) and by ``bench.py``'s
+``cpu_baseline`` leg (the reference's own training step timed on the host cores).
 
 Recipe: the reference package cannot be imported as a package here
 (omegaconf, lightning, kornia, torchvision, jaxtyping are not installed).  Its hot-path
@@ -27,7 +29,10 @@ import torch.nn as nn
 
 from . import thirdparty as tp
 
-REFERENCE_ROOT = os.environ.get("LP_REFERENCE_ROOT", "/root/reference")
+# /root/reference in the build container; on the GPU box the verbatim copy oracle/make_ref.py shipped (oracle/_ref/: git-ignored, travels
+# with the snapshot) - the hot-path modules only, which is all this loader executes
+_SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+REFERENCE_ROOT = os.environ.get("LP_REFERENCE_ROOT") or ("/root/reference" if os.path.isdir("/root/reference/lightning_pose") else _SHIPPED)
 _PKG = os.path.join(REFERENCE_ROOT, "lightning_pose")
 
 

@@ -660,24 +660,33 @@ def forward_bf16_policy(model: OracleTracker, images: torch.Tensor, rounding: tu
 
     ``rounding`` (profiles/rounding_ablation.py): which of the policy's rounding points are ON - "trunk" = every convolution operand and
     output of the ResNet trunk, "head" = the operands of the two transposed convolutions and the activation between them.  Both = the
-    policy the product implements; () = the fp32 reference itself."""
-    qt = _q if "trunk" in rounding else (lambda t: t)
-    qh = _q if "head" in rounding else (lambda t: t)
+    policy the product implements; () = the fp32 reference itself.  Finer tags switch on parts of "trunk" only (the per-stage ablation,
+    profiles/r04_rounding_stages.json): a STAGE - "stem", "layer1" .. "layer4" = every rounding point inside it - or a KIND across all
+    stages - "trunk:w" weights, "trunk:z" convolution outputs (the pre-normalisation tensors), "trunk:a" the activations inside a block
+    (outputs of bn1 / bn2, the stem's pooled activation), "trunk:res" the residual stream (block outputs, shortcut projections)."""
+    ident = lambda t: t  # noqa: E731
+
+    def qt(stage: str, kind: str):
+        return _q if ("trunk" in rounding or stage in rounding or f"trunk:{kind}" in rounding) else ident
+
+    qh = _q if "head" in rounding else ident
     bb = model.backbone
-    x = qt(images)
-    x = qt(F.conv2d(x, qt(bb[0].weight), stride=2, padding=3))
-    x = _bn_train(x, bb[1], None, True, q=qt)
+    x = qt("stem", "a")(images)
+    x = qt("stem", "z")(F.conv2d(x, qt("stem", "w")(bb[0].weight), stride=2, padding=3))
+    x = _bn_train(x, bb[1], None, True, q=qt("stem", "a"))
     x = F.max_pool2d(x, 3, 2, 1)
-    for layer in (bb[4], bb[5], bb[6], bb[7]):
+    for li, layer in enumerate((bb[4], bb[5], bb[6], bb[7])):
+        st = f"layer{li + 1}"
+        qw, qz, qa, qr = qt(st, "w"), qt(st, "z"), qt(st, "a"), qt(st, "res")
         for blk in layer:
             idt = x
-            o = _bn_train(qt(F.conv2d(x, qt(blk.conv1.weight))), blk.bn1, None, True, q=qt)
-            o = _bn_train(qt(F.conv2d(o, qt(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True, q=qt)
-            z3 = qt(F.conv2d(o, qt(blk.conv3.weight)))
+            o = _bn_train(qz(F.conv2d(x, qw(blk.conv1.weight))), blk.bn1, None, True, q=qa)
+            o = _bn_train(qz(F.conv2d(o, qw(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True, q=qa)
+            z3 = qz(F.conv2d(o, qw(blk.conv3.weight)))
             if blk.downsample is not None:
-                zd = qt(F.conv2d(x, qt(blk.downsample[0].weight), stride=blk.stride))
-                idt = _bn_train(zd, blk.downsample[1], None, False, q=qt)
-            x = _bn_train(z3, blk.bn3, idt, True, q=qt)
+                zd = qz(F.conv2d(x, qw(blk.downsample[0].weight), stride=blk.stride))
+                idt = _bn_train(zd, blk.downsample[1], None, False, q=qr)
+            x = _bn_train(z3, blk.bn3, idt, True, q=qr)
     x = F.pixel_shuffle(x, 2)
     cts = [m for m in model.head.upsampling_layers if isinstance(m, nn.ConvTranspose2d)]
     for i, ct in enumerate(cts):

@@ -1,0 +1,379 @@
+// Round 4 follow-up to tile_probe.hip (which said NO-GO on the two-workgroup tile: profiles/r04a_tile_probe.txt).  Same synthetic 256 x 128 x K
+// tile loop as conv_pipe_kernel's forward (shape A: 8 waves of 64 x 64, K steps of 64, 3-stage direct-to-LDS ring, one workgroup per CU), now
+// taken apart to see WHAT bounds it:
+//   loop parts      LOADS on/off (direct-to-LDS operand loads), LDSRD on/off (fragment reads; off = fragments stay in registers)
+//   store pass      EPI 0 none | 1 staged through LDS (today's epilogue_fwd) | 2 direct: v_permlane32_swap pairs -> 16-B global stores (guide T21)
+//   phase stagger   workgroup w sleeps (w % P) * sleeps x 1024 cycles before its walk: are the chip-wide store bursts (all CUs in phase) the cost?
+//   static priority waves 4-7 at s_setprio 1 (guide T5, static form)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o loop_probe profiles/probe/loop_probe.hip && ./loop_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+#define RAW_BARRIER()                      \
+    do {                                   \
+        asm volatile("" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();      \
+        asm volatile("" ::: "memory");     \
+    } while (0)
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+enum { kEpiNone = 0, kEpiLds = 1, kEpiDirect = 2 };
+// load modes (call C: is the loop bound by BYTES through the L2 -> LDS path, by the load INSTRUCTIONS, or by their latency against the ring depth?)
+//   0 none | 1 full (pixels + weights, direct to LDS, swizzled source) | 2 pixel rows only (2/3 of the bytes) | 3 weight rows only (1/3)
+//   4 full, into REGISTERS (buffer_load_dwordx4 -> VGPR, results dropped: no LDS write) | 5 full, lane-linear source (every wave instruction reads 1 KB
+//   contiguous instead of 8 rows x 128 B)  | 6 pixel rows only with the ring one step DEEPER (4 stages of 32 KB, three K steps in flight)
+enum { kLdNone = 0, kLdFull = 1, kLdA = 2, kLdB = 3, kLdReg = 4, kLdLinear = 5, kLdADeep = 6 };
+
+template <int LOADS, bool LDSRD, int EPI, bool PRIO>
+__global__ __launch_bounds__(512, 1) void loop_probe(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, unsigned short* __restrict__ Y,
+                                                     float* __restrict__ sums, int K, int tiles, int reuse, unsigned x_rows, int phases, int sleeps) {
+    constexpr int WAVES = 8, KB = 64, MT = 2, NT = 2, ROWB = 128, kStageA = 256 * ROWB, kStage = (256 + 128) * ROWB;
+    constexpr int NST = LOADS == kLdADeep ? 4 : 3;            // ring stages (kLdADeep: 4 x 32 KB of pixel rows only - fragments then read stage-relative garbage, fine)
+    constexpr int kStep = LOADS == kLdADeep ? kStageA : kStage;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LOADS == kLdADeep ? 4 * kStageA + 128 * ROWB : 3 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const unsigned x_bytes = x_rows * (unsigned)K * 2u, w_bytes = 128u * (unsigned)K * 2u;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, w_bytes, 0x00020000);
+    const int KT = K / KB;
+    if (PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (phases > 1) {
+        const int n = (int)(blockIdx.x % (unsigned)phases) * sleeps;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles
+    }
+
+    const int lrow = lane >> 3, slot = lane & 7;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    int ld_tile = 0, ld_kt = 0;
+    u32x4 regsink = {0, 0, 0, 0}, pend[6] = {};   // kLdReg: a load's result is consumed one K step later (no wait at the issue)
+    auto issue = [&](int st) {
+        if (LOADS == kLdNone) return;
+        if (LOADS == kLdReg) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) regsink ^= pend[i];
+        }
+        unsigned char* dst = smem + st * kStep;
+        const bool live = ld_tile < tiles;
+        const unsigned a_row0 = live ? (unsigned)((((blockIdx.x * tiles + ld_tile) / reuse) * 256) % x_rows) : 0u;
+        if (LOADS != kLdB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (i * WAVES + wave) * 8 + lrow;
+                unsigned voff = live ? ((a_row0 + r) * (unsigned)K + (unsigned)((slot ^ swz(r)) * 8 + ld_kt * KB)) * 2u : ~0u;
+                if (LOADS == kLdLinear) voff = live ? ((a_row0 + (unsigned)(i * WAVES + wave) * 8u) * (unsigned)K + (unsigned)(ld_kt * 4096 + lane * 8)) * 2u % x_bytes : ~0u;
+                if (LOADS == kLdReg) {
+                    pend[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0u, 0));
+                } else {
+                    glds16(rx, dst + (i * WAVES + wave) * 1024, voff, 0u);
+                }
+            }
+        }
+        if (LOADS != kLdA && LOADS != kLdADeep) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = (i * WAVES + wave) * 8 + lrow;
+                unsigned voff = live ? ((unsigned)r * (unsigned)K + (unsigned)((slot ^ swz(r)) * 8 + ld_kt * KB)) * 2u : ~0u;
+                if (LOADS == kLdLinear) voff = live ? (((unsigned)(i * WAVES + wave) * 8u) * (unsigned)K + (unsigned)(ld_kt * 4096 + lane * 8)) * 2u % w_bytes : ~0u;
+                if (LOADS == kLdReg) {
+                    pend[4 + i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff, 0u, 0));
+                } else {
+                    glds16(rw, dst + kStageA + (i * WAVES + wave) * 1024, voff, 0u);
+                }
+            }
+        }
+        if (++ld_kt == KT) ld_kt = 0, ++ld_tile;
+    };
+
+    const int fr = lane & 31, fg = lane >> 5;
+    f32x16 acc[MT][NT];
+    bf16x8 ra[MT], rb[NT];   // LDSRD off: the fragments every MFMA uses
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ra[i] = __builtin_bit_cast(bf16x8, u16x8{0x3c3c, 0x3c3c, 0x3c3c, 0x3c3c, 0x3c3c, 0x3c3c, 0x3c3c, (unsigned short)(0x3c00 + lane)});
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rb[i] = ra[0];
+    auto mma_stage = [&](int st) {
+        const unsigned char* sb = smem + st * kStep;
+        const int kOffB = LOADS == kLdADeep ? (NST - st) * kStageA : kStageA;   // (kLdADeep: one fixed 16-KB weight image behind the ring)
+#pragma unroll
+        for (int kk = 0; kk < KB / 16; ++kk) {
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wm * (MT * 32) + mt * 32 + fr;
+                a[mt] = LDSRD ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + row * ROWB + (((kk * 2 + fg) ^ swz(row)) << 4))) : ra[mt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int row = wn * (NT * 32) + nt * 32 + fr;
+                b[nt] = LDSRD ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(sb + kOffB + row * ROWB + (((kk * 2 + fg) ^ swz(row)) << 4))) : rb[nt];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    // ---- store pass, staged through LDS (conv_pipe_kernel's epilogue_fwd): 8 running sums per thread
+    const int pc = lane & 7, prow = lane >> 3;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.f;
+    auto store_lds = [&](int tile_row0, unsigned char* stg_all) {
+        constexpr int SROW = NT * 64 + 16;
+        unsigned char* stg = stg_all + wave * (32 * SROW);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x2 p = {pack2(acc[mt][nt][4 * j], acc[mt][nt][4 * j + 1]), pack2(acc[mt][nt][4 * j + 2], acc[mt][nt][4 * j + 3])};
+                    *reinterpret_cast<u32x2*>(stg + fr * SROW + (nt * 32 + 8 * j + 4 * fg) * 2) = p;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + prow;
+                const u16x8 w = *reinterpret_cast<const u16x8*>(stg + row * SROW + pc * 16);
+                const unsigned m = (unsigned)tile_row0 + (unsigned)(wm * (MT * 32) + mt * 32 + row);
+                *reinterpret_cast<u16x8*>(Y + (size_t)m * 128 + wn * 64 + pc * 8) = w;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = __uint_as_float(((unsigned)w[q]) << 16);
+                    s0[q] += v;
+                    s1[q] = fmaf(v, v, s1[q]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // ---- store pass, direct (guide T21): lane (pixel fr, half fg) holds for block nt the channels nt*32 + 8 j + 4 fg + (0..3) in acc[..][4 j ..];
+    // one v_permlane32_swap per dword and j pair leaves lanes 0-31 with channels nt*32 + 16 jp + (0..7) and lanes 32-63 with + 8 + (0..7):
+    // ONE 16-B store per (mt, nt, jp), no LDS; the running sums are per (nt, jp, 8 channels): 32 + 32 registers
+    float d0[NT][2][8], d1[NT][2][8];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d0[nt][jp][q] = d1[nt][jp][q] = 0.f;
+    auto store_direct = [&](int tile_row0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned m = (unsigned)tile_row0 + (unsigned)(wm * (MT * 32) + mt * 32 + fr);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    unsigned lo0 = pack2(acc[mt][nt][8 * jp], acc[mt][nt][8 * jp + 1]), lo1 = pack2(acc[mt][nt][8 * jp + 2], acc[mt][nt][8 * jp + 3]);
+                    unsigned hi0 = pack2(acc[mt][nt][8 * jp + 4], acc[mt][nt][8 * jp + 5]), hi1 = pack2(acc[mt][nt][8 * jp + 6], acc[mt][nt][8 * jp + 7]);
+                    // swap: lanes 32-63 of (lo) <-> lanes 0-31 of (hi)
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
+                    const u32x4 v = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                    *reinterpret_cast<u32x4*>(Y + (size_t)m * 128 + wn * 64 + nt * 32 + jp * 16 + fg * 8) = v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned wq = v[q];
+                        const float v0 = __uint_as_float(wq << 16), v1 = __uint_as_float(wq & 0xffff0000u);
+                        d0[nt][jp][2 * q] += v0;
+                        d1[nt][jp][2 * q] = fmaf(v0, v0, d1[nt][jp][2 * q]);
+                        d0[nt][jp][2 * q + 1] += v1;
+                        d1[nt][jp][2 * q + 1] = fmaf(v1, v1, d1[nt][jp][2 * q + 1]);
+                    }
+                }
+        }
+    };
+
+    issue(0);
+    issue(1);
+    if (NST == 4) issue(2);
+    int cur = 0;
+    for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (LOADS == kLdFull || LOADS == kLdLinear) WAIT_VM(6);
+            else if (LOADS == kLdA) WAIT_VM(4);
+            else if (LOADS == kLdB) WAIT_VM(2);
+            else if (LOADS == kLdADeep) WAIT_VM(8);
+            RAW_BARRIER();
+            issue(cur == 0 ? NST - 1 : cur - 1);
+            mma_stage(cur);
+            cur = cur == NST - 1 ? 0 : cur + 1;
+        }
+        if (EPI == kEpiLds) {
+            RAW_BARRIER();
+            store_lds((blockIdx.x * tiles + t) * 256, smem + (cur == 0 ? NST - 1 : cur - 1) * kStep);
+        } else if (EPI == kEpiDirect) {
+            store_direct((blockIdx.x * tiles + t) * 256);
+        }
+    }
+    WAIT_VM(0);
+    float t0 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t0 += s0[q] + s1[q];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t0 += d0[nt][jp][q] + d1[nt][jp][q];
+    if (EPI == kEpiNone) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) t0 += acc[mt][nt][lane & 15];
+    }
+    if (t0 == 12345.678f || regsink[0] == 0x12345678u) sums[tid] = t0 + (float)regsink[1];
+}
+
+// ---- LDS read rate per CU for the forward's fragment pattern (the rate tile_probe printed was an artefact: its `volatile` reads compiled to
+// one flat_load + full wait each).  8 waves, 4 ds_read_b128 in flight per lane and trip, the kernels' swizzle.
+__global__ __launch_bounds__(512) void lds_rate_b128(unsigned* out, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char img[48 * 1024];
+    for (int i = threadIdx.x; i < 48 * 1024 / 4; i += 512) reinterpret_cast<unsigned*>(img)[i] = i * 2654435761u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 31, fg = lane >> 5;
+    const int row = wave * 32 + fr;
+    u32x4 acc = {0, 0, 0, 0};
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)img;
+    unsigned a[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a[kk] = base + row * 128 + (((kk * 2 + fg) ^ ((row >> 1) & 7)) << 4);
+    for (int it = 0; it < iters; ++it) {
+        u32x4 v0, v1, v2, v3;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+                     : "memory");
+        acc ^= v0 ^ v1 ^ v2 ^ v3;
+    }
+    if (acc[0] == 0x12345678u) out[threadIdx.x] = acc[1];
+}
+
+#define CK(x)                                                                     \
+    do {                                                                          \
+        hipError_t e_ = (x);                                                      \
+        if (e_ != hipSuccess) {                                                   \
+            printf("%s failed: %s\n", #x, hipGetErrorString(e_));                 \
+            exit(1);                                                              \
+        }                                                                         \
+    } while (0)
+
+struct Args {
+    const unsigned short *X, *W;
+    unsigned short* Y;
+    float* sums;
+    int K, tiles, reuse;
+    unsigned x_rows;
+    int grid, phases, sleeps;
+};
+
+template <int LOADS, bool LDSRD, int EPI, bool PRIO>
+static double run(const Args& a) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((loop_probe<LOADS, LDSRD, EPI, PRIO>), dim3(a.grid), dim3(512), 0, 0, a.X, a.W, a.Y, a.sums, a.K, a.tiles, a.reuse, a.x_rows,
+                           a.phases, a.sleeps);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3 / a.tiles;   // us per tile and CU
+}
+
+int main() {
+    int cus = 0;
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    const size_t x_bytes = 1536ull << 20, y_rows = (size_t)cus * 64 * 256;
+    unsigned short *X, *W, *Y;
+    float* sums;
+    CK(hipMalloc(&X, x_bytes));
+    CK(hipMalloc(&W, 128 * 2048 * 2));
+    CK(hipMalloc(&Y, y_rows * 128 * 2));
+    CK(hipMalloc(&sums, 4096));
+    CK(hipMemset(X, 0x3c, x_bytes));
+    CK(hipMemset(W, 0x3c, 128 * 2048 * 2));
+    printf("%d CUs; us per 256 x 128 x K tile and CU (TFLOP/s over the chip)\n", cus);
+    const bool call_b = getenv("LOOP_PROBE_CALL_B") != nullptr;   // the first set of questions (profiles/r04b_loop_probe.txt)
+    const int Ks[4] = {128, 256, 576, 1024};
+    for (int ki = 0; ki < 4; ++ki) {
+        const int K = Ks[ki];
+        for (int reuse = 1; reuse <= 8; reuse *= 8) {
+            Args a{X, W, Y, sums, K, K >= 1024 ? 16 : 48, reuse, (unsigned)(x_bytes / ((size_t)K * 2)), cus, 1, 0};
+            const double ft = 2.0 * 256 * 128 * K * cus * 1e-6;   // TFLOP/s = ft / us
+            if (call_b) {
+                const double full = run<1, true, kEpiNone, false>(a), noload = run<0, true, kEpiNone, false>(a), nolds = run<1, false, kEpiNone, false>(a),
+                             mfma = run<0, false, kEpiNone, false>(a), prio = run<1, true, kEpiNone, true>(a);
+                printf("K %4d reuse %d | loop: full %6.2f (%4.0f)  no loads %6.2f (%4.0f)  no LDS reads %6.2f (%4.0f)  MFMA+barrier only %6.2f (%4.0f)  prio %6.2f\n", K,
+                       reuse, full, ft / full, noload, ft / noload, nolds, ft / nolds, mfma, ft / mfma, prio);
+                const double e1 = run<1, true, kEpiLds, false>(a), e2 = run<1, true, kEpiDirect, false>(a), e2p = run<1, true, kEpiDirect, true>(a);
+                printf("              | store pass: LDS-staged %6.2f (%4.0f)  direct 16-B %6.2f (%4.0f)  direct + prio %6.2f\n", e1, ft / e1, e2, ft / e2, e2p);
+                for (int P = 2; P <= 4; P *= 2) {   // stagger: P phase groups, the walk of group p delayed by p / P of a tile
+                    Args b = a;
+                    b.phases = P;
+                    b.sleeps = (int)(e1 * 2400.0 / 1024.0 / P + 0.5);
+                    Args c = b;
+                    c.sleeps = (int)(e2 * 2400.0 / 1024.0 / P + 0.5);
+                    const double s1 = run<1, true, kEpiLds, false>(b), s2 = run<1, true, kEpiDirect, false>(c);
+                    printf("              | %d phase groups: LDS-staged %6.2f  direct %6.2f   (incl. the start delay, %d tiles)\n", P, s1, s2, a.tiles);
+                }
+            } else {
+                const double none = run<kLdNone, true, kEpiNone, false>(a), full = run<kLdFull, true, kEpiNone, false>(a), la = run<kLdA, true, kEpiNone, false>(a),
+                             lb = run<kLdB, true, kEpiNone, false>(a), reg = run<kLdReg, true, kEpiNone, false>(a), lin = run<kLdLinear, true, kEpiNone, false>(a),
+                             deep = run<kLdADeep, true, kEpiNone, false>(a);
+                printf("K %4d reuse %d | us per tile: no loads %6.2f | full %6.2f | pixel rows only (2/3) %6.2f | weight rows only (1/3) %6.2f | into registers %6.2f | "
+                       "lane-linear source %6.2f | pixel rows only, 3 steps in flight %6.2f\n", K, reuse, none, full, la, lb, reg, lin, deep);
+            }
+        }
+    }
+    {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const int iters = 1 << 16;
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(lds_rate_b128, dim3(cus), dim3(512), 0, 0, (unsigned*)sums, iters);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        const double bytes_cu = 512.0 * 16 * 4 * iters;
+        printf("LDS ds_read_b128 fragments (4 in flight per lane, 8 waves): %.1f GB/s per CU = %.1f B/clk at 2.4 GHz\n", bytes_cu / (ms * 1e-3) * 1e-9,
+               bytes_cu / (ms * 1e-3) / 2.4e9);
+    }
+    return 0;
+}

@@ -28,7 +28,7 @@ def pytest_collection_modifyitems(config, items):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "reference: executes the reference's own modules (/root/reference, or oracle/_ref on the GPU box)")
 
 
 class Golden(dict):
@@ -45,10 +45,14 @@ def golden():
 
 
 def has_reference() -> bool:
-    return os.path.isdir("/root/reference/lightning_pose")
+    """the reference's hot-path modules can be executed: /root/reference (build container) or the verbatim copy oracle/make_ref.py shipped
+    to oracle/_ref/ (GPU box); tests that need the reference's DATA files check for /root/reference themselves"""
+    from oracle import ref_loader
+
+    return ref_loader.available()
 
 
-needs_reference = pytest.mark.skipif(not has_reference(), reason="/root/reference not present")
+needs_reference = pytest.mark.skipif(not has_reference(), reason="neither /root/reference nor oracle/_ref present")
 
 
 @pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])

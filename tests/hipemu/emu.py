@@ -288,6 +288,25 @@ def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None
     return f
 
 
+def conv_fwd_bn_deferred(x_nhwc_bits, w_bits, g, seg=0):
+    """lp_conv_fwd_bn with lp_bn_fuse.defer_reduce = 1 -> (z bits, the fuse object: .slot_rows rows of partial sums in .keep["ws"])"""
+    xb, wb, ob = Buf(x_nhwc_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
+    f = _bn_fuse(g, False, g.Co, seg=seg)
+    f.defer_reduce = 1
+    ok(lib().lp_conv_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
+    return ob.np(), f
+
+
+def bn_finalize_slots(f, counts, Cn, running, eps=1e-5, momentum=0.1):
+    """lp_bn_finalize_slots on the rows a deferred launch left -> (mean, invstd, running_mean, running_var, raw sums), each per segment"""
+    nseg = len(counts)
+    mean, invstd, sums = Z((nseg, Cn)), Z((nseg, Cn)), Z((nseg, 2, Cn))
+    rm, rv = Buf(running[0]), Buf(running[1])
+    ok(lib().lp_bn_finalize_slots(f.keep["ws"].p, int(f.slot_rows), nseg, float(counts[0]), float(counts[-1]), Cn, eps, momentum, mean.p,
+                                  invstd.p, rm.p, rv.p, sums.p, stream()))
+    return mean.np(), invstd.np(), rm.np(), rv.np(), sums.np()
+
+
 def conv_fwd_bn(x_nhwc_bits, w_bits, g, seg=0, rc=False):
     """-> (z bits, sums (2,Co) or (2,2,Co) with seg); rc=True: return the status code instead of asserting it"""
     xb, wb, ob = Buf(x_nhwc_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
@@ -422,7 +441,9 @@ def stem_wgrad(x4_bits, dy_bits, g, split=0):
 def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False):
     xb, rb = Buf(x_bits), B(residual_bits)
     sums, mean, invstd = Z((2, Cn)), Z(Cn), Z(Cn)
-    ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, stream()))
+    nws = lib().lp_bn_reduce_workspace_bytes(M, Cn)
+    ws = Buf(np.full(nws // 4, np.nan, np.float32))  # poisoned: every partial that is read must have been written
+    ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, ws.p, nws, stream()))
     rm = Buf(running[0]) if running is not None else None
     rv = Buf(running[1]) if running is not None else None
     ok(lib().lp_bn_finalize(sums.p, float(M), Cn, eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), stream()))
@@ -440,7 +461,9 @@ def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e
 def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False):
     db, yb, xb, mb, vb, gb = Buf(dy_bits), B(y_bits), Buf(x_bits), Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma))
     sums, dbeta, dgamma = Z((2, Cn)), Z(Cn), Z(Cn)
-    ok(lib().lp_bn_bwd_reduce(db.p, ptr(yb), xb.p, mb.p, vb.p, M, Cn, sums.p, dbeta.p, dgamma.p, stream()))
+    nws = lib().lp_bn_reduce_workspace_bytes(M, Cn)
+    ws = Buf(np.full(nws // 4, np.nan, np.float32))
+    ok(lib().lp_bn_bwd_reduce(db.p, ptr(yb), xb.p, mb.p, vb.p, M, Cn, sums.p, dbeta.p, dgamma.p, ws.p, nws, stream()))
     dx = Z((M, Cn), np.uint16)
     dres = Z((M, Cn), np.uint16) if want_dres else None
     ok(lib().lp_bn_bwd_apply(db.p, ptr(yb), xb.p, mb.p, vb.p, gb.p, sums.p, float(M), M, Cn, dx.p, ptr(dres), stream()))
@@ -473,7 +496,9 @@ def bn_pool_backward(arg_u8, dy_bits, z_bits, mean, invstd, gamma, beta, Bn, Hi,
     ab, db, zb = Buf(arg_u8), Buf(dy_bits), Buf(z_bits)
     mb, vb, gb, bb = Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma)), Buf(f32(beta))
     sums, dbeta, dgamma = Z((2, Cn)), Z(Cn), Z(Cn)
-    ok(lib().lp_bn_pool_bwd_reduce(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, Bn, Hi, Wi, Cn, sums.p, dbeta.p, dgamma.p, stream()))
+    nws = lib().lp_bn_pool_bwd_workspace_bytes(Bn, Hi, Wi, Cn)
+    ws = Buf(np.full(nws // 4, np.nan, np.float32))
+    ok(lib().lp_bn_pool_bwd_reduce(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, Bn, Hi, Wi, Cn, sums.p, dbeta.p, dgamma.p, ws.p, nws, stream()))
     dz = Z((Bn * Hi * Wi, Cn), np.uint16)
     ok(lib().lp_bn_pool_bwd_apply(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, sums.p, float(Bn * Hi * Wi), Bn, Hi, Wi, Cn, dz.p, stream()))
     return dz.np(), dgamma.np(), dbeta.np(), sums.np()

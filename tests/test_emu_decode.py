@@ -148,29 +148,37 @@ def test_decode_pruning_is_chosen_from_the_maps(stack_backend, monkeypatch):
 
     dev = stack_backend
     monkeypatch.delenv("LP_DECODE_PRUNE", raising=False)
-    auto = ops._decode_prune_auto
-    auto.calls, auto.pending = 0, None
+    auto = ops._DecodePruneAuto()                           # an owner's own chooser (a tracker holds one; ops.decode's default is shared)
+    ops._DecodePruneAuto._lib_mode = -2
     gen = torch.Generator().manual_seed(3)
     peaked = _peaked(gen, 2, 4, 24, 24).to(dev)
     flat = torch.softmax(torch.randn(2, 4, 24 * 24, generator=gen) * 0.1, -1).reshape(2, 4, 24, 24).to(dev)
     fm = ops.DecodeFrameMap(None, False, None, 1, 96, 96, 4)
-    first = ops.decode(peaked, 2, 1000.0, fm)[0].clone()
+    first = ops.decode(peaked, 2, 1000.0, fm, auto)[0].clone()
     assert auto.state == 0                                  # nothing observed yet: the plain kernels
     for _ in range(3):
-        out = ops.decode(peaked, 2, 1000.0, fm)[0]
+        out = ops.decode(peaked, 2, 1000.0, fm, auto)[0]
         if dev.type == "cuda":
             torch.cuda.synchronize()
     assert auto.state == 1                                  # observed at the 2nd call, picked up by a later one
     torch.testing.assert_close(out, first, atol=2e-5, rtol=0)
+    other = ops._DecodePruneAuto()                          # a second owner (another model) starts from the plain kernels and is
+    ops.decode(flat, 2, 1000.0, fm, other)                  # not steered by the first one's peaked maps ...
+    assert auto.want == 1 and other.want == 0 and other.state == 0
+    ops.decode(peaked, 2, 1000.0, fm, auto)                 # ... and the first one gets its own choice back on its next call
+    assert auto.state == 1
     auto.calls = auto.PERIOD - 1
     for _ in range(3):
-        ops.decode(flat, 2, 1000.0, fm)
+        ops.decode(flat, 2, 1000.0, fm, auto)
         if dev.type == "cuda":
             torch.cuda.synchronize()
-    assert auto.state == 0
+    assert auto.state == 0 and auto.want == 0
     monkeypatch.setenv("LP_DECODE_PRUNE", "1")
-    ops.decode(flat, 2, 1000.0, fm)
+    ops.decode(flat, 2, 1000.0, fm, auto)
     assert auto.state == -1                                 # the library follows the environment
+    monkeypatch.setenv("LP_DECODE_PRUNE", "yes")
+    with pytest.raises(ValueError):                         # auto / 0 / 1 only: a typo is an error, not a silent default
+        ops.decode(flat, 2, 1000.0, fm, auto)
     monkeypatch.delenv("LP_DECODE_PRUNE")
     emu.lib().lp_decode_set_prune(-1)
-    auto.state = -2
+    ops._DecodePruneAuto._lib_mode = -2

@@ -63,7 +63,7 @@ def test_fused_reductions_per_segment(case, kernel_backend):
 
 
 def test_stem_statistics_per_segment(kernel_backend):
-    """the 7x7 stem always takes the per-tile workspace + tile_stats_reduce path"""
+    """the 7x7 stem's fused sums (conv_stem2d_kernel / conv_igemm_kernel<64, stem>), per segment"""
     gen = torch.Generator().manual_seed(5)
     B, seg, H = 3, 1, 32                                          # 16 x 16 = 256 output rows per image
     g = emu.geom(B, H, H, 4, 64, 7, 7, 2, 3)
@@ -80,18 +80,72 @@ def test_stem_statistics_per_segment(kernel_backend):
         np.testing.assert_allclose(sums[si], ss, rtol=1e-5, atol=1e-4)
 
 
-def test_workspace_reduction_path_per_segment(kernel_backend):
-    """large launches leave per-tile partial sums in a workspace that tile_stats_reduce adds up per segment (and, for a stride-2 data
-    gradient, per parity-class launch); the threshold is read once per process, so the kernel tests above re-run in a child with it at 0"""
+def test_atomic_form_of_the_fused_sums_still_agrees(kernel_backend):
+    """LP_STATS_ATOMIC=1 (A/B timing only since round 4: the store passes add their sums into the totals with fp32 atomics instead of leaving
+    per-workgroup rows for the ordered reduction) is read per call; the kernel tests above re-run in a child with it set"""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, LP_STATS_ATOMIC_TILES="0")
+    env = dict(os.environ, LP_STATS_ATOMIC="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_segmented_bn.py", "tests/test_emu_conv.py", "-q", "-x", "-m",
                         "gpu" if kernel_backend == "gpu" else "not gpu", "-k", "fused_reductions or fused_batchnorm", "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _sums_case(kernel_backend, gen):
+    """a launch with several tiles per workgroup AND several workgroups (LP_CONV_MAX_WGS is read per call)"""
+    B, H, Ci, Co = (32, 32, 64, 256) if kernel_backend == "gpu" else (4, 16, 64, 128)
+    g = emu.geom(B, H, H, Ci, Co, 1, 1, 1, 0)
+    x = emu.to_bf16_bits(torch.randn(B, H, H, Ci, generator=gen))
+    w = emu.to_bf16_bits(torch.randn(Co, 1, 1, Ci, generator=gen) / 8)
+    return g, x, w, B, H, Co
+
+
+def test_fused_sums_repeat_bit_for_bit_and_finalize_from_the_rows(kernel_backend, monkeypatch):
+    """Round 4: every persistent workgroup leaves its sums in its own row of the workspace and the rows are added in workgroup order.
+    (a) two runs give the same BITS (on the device the old atomics did not); (b) lp_bn_finalize_slots on the rows of a deferred launch ==
+    lp_bn_finalize2 on the reduced sums, bit for bit - moments, running statistics and the raw totals."""
+    gen = torch.Generator().manual_seed(11)
+    g, x, w, B, H, Co = _sums_case(kernel_backend, gen)
+    if kernel_backend != "gpu":
+        monkeypatch.setenv("LP_CONV_MAX_WGS", "3")            # 4 tiles of 256 rows over 3 workgroups: one of them walks two
+    seg = B // 4                                                  # two BatchNorm segments, boundary on a tile boundary
+    z1, s1 = emu.conv_fwd_bn(x, w, g, seg=seg)
+    z2, s2 = emu.conv_fwd_bn(x, w, g, seg=seg)
+    assert np.array_equal(z1, z2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+    zf = emu.from_bf16_bits(z1).reshape(B, H * H, Co)
+    np.testing.assert_allclose(s1[0][0], zf[:seg].sum((0, 1)).numpy(), rtol=2e-4, atol=2e-2)
+    np.testing.assert_allclose(s1[1][1], (zf[seg:] ** 2).sum((0, 1)).numpy(), rtol=2e-4, atol=2e-2)
+    # (b) deferred rows -> one launch
+    z3, f = emu.conv_fwd_bn_deferred(x, w, g, seg=seg)
+    assert np.array_equal(z1, z3) and f.slot_rows > 1
+    counts = (seg * H * H, (B - seg) * H * H)
+    rm0, rv0 = torch.randn(Co, generator=gen).numpy(), (torch.rand(Co, generator=gen) + 0.5).numpy()
+    mean, invstd, rm, rv, raw = emu.bn_finalize_slots(f, counts, Co, (rm0, rv0))
+    assert np.array_equal(raw.view(np.uint32), s1.view(np.uint32))
+    sb, m2, v2, rm2, rv2 = emu.Buf(s1), emu.Z((2, Co)), emu.Z((2, Co)), emu.Buf(rm0), emu.Buf(rv0)
+    emu.ok(emu.lib().lp_bn_finalize2(sb.p, float(counts[0]), float(counts[1]), Co, 1e-5, 0.1, m2.p, v2.p, rm2.p, rv2.p, emu.stream()))
+    for a, b in ((mean, m2.np()), (invstd, v2.np()), (rm, rm2.np()), (rv, rv2.np())):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_standalone_reductions_repeat_bit_for_bit(kernel_backend):
+    """lp_bn_stats / lp_bn_bwd_reduce: per-workgroup rows + ordered reduction (no atomics): same bits twice, d beta / d gamma = the sums"""
+    gen = torch.Generator().manual_seed(12)
+    M, Cn = (200_000, 256) if kernel_backend == "gpu" else (3000, 40)
+    x = torch.randn(M, Cn, generator=gen)
+    dy = torch.randn(M, Cn, generator=gen)
+    xb, db = emu.to_bf16_bits(x), emu.to_bf16_bits(dy)
+    mean, invstd = x.mean(0).numpy(), (x.var(0, unbiased=False) + 1e-5).rsqrt().numpy()
+    gamma = np.ones(Cn, np.float32)
+    outs = [emu.bn_backward(db, None, xb, mean, invstd, gamma, M, Cn) for _ in range(2)]
+    for a, b in zip(outs[0], outs[1]):
+        if a is not None:
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    dyf = emu.from_bf16_bits(db)
+    np.testing.assert_allclose(outs[0][3], dyf.sum(0).numpy(), rtol=1e-4, atol=5e-2)      # d beta
 
 
 def test_segment_boundary_must_be_tile_aligned(kernel_backend):

@@ -46,6 +46,26 @@ def test_bench_predict_line(stack_backend, capsys):
     assert out["metric"].startswith("inference frames/sec") and out["config"]["global_batch"] == 5 and out["config"]["finite"] is True
 
 
+def test_bench_fit_line(stack_backend, capsys):
+    """--fit: Trainer.fit over FrameWindowSource / VideoFramePipeline / LabeledBatchProducer (uint8 host frames in, the step out); the
+    logged scalars reach the host once (end of the epoch), not per step"""
+    out = _run(capsys, stack_backend, "--fit", "--steps", "1", "--warmup", "0", "--size", "128", "--labeled", "1", "--unlabeled", "2",
+               "--keypoints", "3", "--no-cpu-baseline", "--no-profile")
+    assert out["metric"].startswith("training frames/sec through Trainer.fit") and out["config"]["host_records"] == 1
+    assert torch.isfinite(torch.tensor(out["config"]["final_loss"]))
+
+
+def test_cpu_baseline_is_the_reference_itself_when_its_modules_are_there():
+    """bench.py's cpu_baseline leg times the reference's OWN tracker step (kind "reference": /root/reference, or oracle/_ref on the GPU
+    box) and falls back to the restated port (kind "port") only when neither tree exists"""
+    from oracle import ref_loader as R
+
+    if not R.available():
+        pytest.skip("neither /root/reference nor oracle/_ref present")
+    out = bench.cpu_baseline_reference(64, 17, n_lab=2, n_unlab=3, steps=1)
+    assert out["kind"] == "reference" and out["value"] > 0 and out["unit"] == "frames/s" and "verbatim" in out["sample"]
+
+
 def test_hbm_rooflines_runs_the_heatmap_kernels(stack_backend):
     out = bench.hbm_rooflines(stack_backend, 64, 3, 4, reps=1)
     assert out["bound"] == "hbm" and out["algorithmic_bytes_per_frame"] == 3 * 16 * 16 * 4

@@ -7,7 +7,7 @@ import torch
 
 from tests.test_widen_n2_dataset import _write_project
 
-needs_reference = pytest.mark.skipif(not os.path.isdir("/root/reference/lightning_pose"), reason="/root/reference not present")
+from tests.conftest import needs_reference  # noqa: E402
 
 # (n, train, val, test) -> the verbatim function's answer (generated with the reference in the build container; re-checked below when present)
 SPLIT_CASES = {
