@@ -379,6 +379,10 @@ int lp_f32_attn_bwd(const float* qkv, int ld, int k_off, int v_off, const float*
  * rows in workgroup order - no fp32 atomics. */
 size_t lp_bn_reduce_workspace_bytes(int M, int C);
 int lp_bn_stats(const void* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
+/* sums (nseg, 2, C) += the rows of slots ([rows][nseg][2][C] fp32) added in row order; dbeta_acc / dgamma_acc (optional) += component
+ * 0 / 1 over the segments.  The ordered reduction the fused and stand-alone entry points run internally; SyncBatchNorm's one-shot
+ * exchange (every rank's sums all-gathered into per-rank rows) adds the ranks in rank order with it. */
+int lp_bn_slots_reduce(const void* slots, int rows, int nseg, int C, float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
 /* mean / invstd (and the running-statistics update, segment by segment) straight from the per-workgroup rows a fused forward entry point
  * left with lp_bn_fuse.defer_reduce = 1 (`slots` = its workspace, `slot_rows` as it reported): the ordered reduction and lp_bn_finalize[2]
  * in ONE launch.  nseg = 1 or 2 (count1 ignored for 1); sums_out (optional) receives the raw (nseg, 2, C) totals. */

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "lp_stem_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
     "lp_bn_reduce_workspace_bytes": (_Z, [_I, _I]),
     "lp_bn_stats": (_I, [_P, _I, _I, _P, _P, _Z, _P]),
+    "lp_bn_slots_reduce": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "lp_bn_finalize_slots": (_I, [_P, _I, _I, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "lp_bn_finalize": (_I, [_P, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_finalize2": (_I, [_P, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P]),

@@ -816,6 +816,18 @@ extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, void* works
     return launch_status();
 }
 
+// sums (nseg, 2, C) += the rows of `slots` ([rows][nseg][2][C]) added in ROW order (fixed chains + tree, lp_common.h: slots_totals); the
+// optional accumulators += component 0 / 1 summed over the segments.  The reduction every fused / stand-alone entry point runs internally,
+// exported for callers that hold rows of their own - SyncBatchNorm's one-shot exchange adds the ranks' sums in rank order with it.
+extern "C" int lp_bn_slots_reduce(const void* slots, int rows, int nseg, int C, float* sums, float* dbeta_acc, float* dgamma_acc,
+                                  lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(slots && sums && rows > 0 && (nseg == 1 || nseg == 2) && C > 0);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    launch_stats_slots_reduce((const float*)slots, rows, nseg, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
+    return launch_status();
+}
+
 // mean / invstd (+ running statistics) straight from the per-workgroup rows a deferred lp_conv_fwd_bn / lp_stem_fwd_bn left
 // (lp_bn_fuse.defer_reduce, .slot_rows): reduction and finalize in ONE launch
 extern "C" int lp_bn_finalize_slots(const void* slots, int slot_rows, int nseg, float count0, float count1, int C, float eps, float momentum,

@@ -413,7 +413,7 @@ class Engine:
     def _reduce_ws(self, nbytes: int) -> torch.Tensor:
         """Scratch rows of the stand-alone reductions (lp_bn_stats, lp_bn_bwd_reduce, lp_bn_pool_bwd_reduce): one buffer, reused in
         stream order like the fused launches' workspace."""
-        if self._red_ws is None or self._red_ws.numel() < nbytes:
+        if getattr(self, "_red_ws", None) is None or self._red_ws.numel() < nbytes:   # (ViTEngine shares this head code with its own __init__)
             self._red_ws = torch.empty(max(nbytes, 4 << 20), device=self.device, dtype=torch.uint8)
         return self._red_ws
 
@@ -477,20 +477,22 @@ class Engine:
         what a parity class of the stride-2 data gradients covers) decides, every other map is 4^k times larger."""
         return n0 > 0 and H % 32 == 0 and W % 32 == 0 and (n0 * (H // 32) * (W // 32)) % 128 == 0
 
-    def _sync_stats(self, t: torch.Tensor) -> None:
-        """SUM of one SyncBatchNorm message over the ranks, in place (reference: ``sync_batchnorm=True``, train.py:427): an all-reduce, or -
-        LP_SYNCBN_GATHER=1 - the one-shot form: all-gather the ranks' sums into per-rank slots, then add the slots in rank order."""
+    def _sync_stats(self, t: torch.Tensor, C_: int) -> None:
+        """SUM of one SyncBatchNorm message ((segments, 2, C) fp32) over the ranks, in place (reference: ``sync_batchnorm=True``,
+        train.py:427): an all-reduce, or - LP_SYNCBN_GATHER=1 - the one-shot form: all-gather the ranks' sums into per-rank rows, then add
+        the rows in RANK order with the library's ordered reduction (lp_bn_slots_reduce: one launch, the same bits on every rank whatever
+        the collective's internal order)."""
         if self.sync_bn_gather:
+            if not t.is_contiguous():
+                raise ValueError("a SyncBatchNorm message must be a contiguous buffer (the reduction writes through its pointer)")
             world, n = dist.get_world_size(self.process_group), t.numel()
-            if self._gather_buf is None or self._gather_buf.numel() < world * n:
-                self._gather_buf = torch.empty(world * max(n, 8192), device=t.device, dtype=t.dtype)
+            if self._gather_buf is None or self._gather_buf.numel() < world * n:   # sized once for the widest layer, two segments
+                widest = max([2 * b.C for b in self.plan.bns] + [2 * self.plan.stem_bn.C]) * 2
+                self._gather_buf = torch.empty(world * max(n, widest), device=t.device, dtype=t.dtype)
             flat = self._gather_buf[:world * n]
             dist.all_gather_into_tensor(flat, t.reshape(-1), group=self.process_group)   # (flat output: the form gloo and RCCL both take)
-            slots = flat.view(world, n)
-            acc = slots[0].clone()
-            for r in range(1, world):   # fixed order: bit-identical on every rank
-                acc += slots[r]
-            t.reshape(-1).copy_(acc)
+            t.zero_()
+            check(self._lib.lp_bn_slots_reduce(_p(flat), world, n // (2 * C_), C_, _p(t), None, None, ops._stream()), "lp_bn_slots_reduce")
         else:
             dist.all_reduce(t, group=self.process_group)
 
@@ -512,7 +514,7 @@ class Engine:
                           "lp_bn_stats")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:  # ONE message carries every segment's [sum, sum of squares]
-                self._sync_stats(sums)
+                self._sync_stats(sums, b.C)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
@@ -796,7 +798,7 @@ class Engine:
             # batch-statistics correction terms (d gamma / d beta above are the same sums in both modes)
             sums = torch.zeros_like(sums)
         elif self.sync_bn:
-            self._sync_stats(sums)
+            self._sync_stats(sums, Cn)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)
@@ -941,7 +943,7 @@ class Engine:
         if not self._bwd_training:
             ssum = torch.zeros_like(ssum)
         elif self.sync_bn:
-            self._sync_stats(ssum)
+            self._sync_stats(ssum, sb.C)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)

@@ -76,7 +76,7 @@ class Fp32Engine(Engine):
                                                         self._stats_ws.numel(), ops._stream()), "lp_f32_bn_stats_ordered")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:
-                self._sync_stats(sums)
+                self._sync_stats(sums, b.C)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
@@ -113,7 +113,7 @@ class Fp32Engine(Engine):
         if not self._bwd_training:
             sums = torch.zeros_like(sums)  # eval-mode BatchNorm: a fixed affine map, no batch-statistics terms
         elif self.sync_bn:
-            self._sync_stats(sums)
+            self._sync_stats(sums, Cn)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)

@@ -600,8 +600,13 @@ def gen_step_parity(names=None):
                 arrs[f"bf16ref_{tag}_keypoints_pred"] = O.model_to_frame(kp_, HW, HW, bd["bbox"], V)
                 arrs[f"bf16ref_{tag}_confidences"] = conf_
                 arrs[f"bf16ref_{tag}_heat_max"] = h_.flatten(2).max(-1).values
-        out = model.training_step(batch, 0)
-        out["loss"].backward()
+        outputs_only = bool(cfg.get("outputs_only"))
+        if outputs_only:   # (c4full: the forward quantities only - see step_inputs.STEP_CONFIGS)
+            with torch.no_grad():
+                out = model.training_step(batch, 0)
+        else:
+            out = model.training_step(batch, 0)
+            out["loss"].backward()
         logged = {k: float(v) for k, v in model.logged.items()}
         arrs.update(log_names=np.array(list(logged)), log_values=np.array(list(logged.values())), loss=out["loss"].detach(),
                     head_fit_loss=np.float32(fit_loss))
@@ -618,13 +623,14 @@ def gen_step_parity(names=None):
                     arrs[f"{tag}_heat"] = hm
         if semi:
             arrs.update(pca_mean=kpca.parameters["mean"], pca_kept=kpca.parameters["kept_eigenvectors"], pca_eps=kpca.parameters["epsilon"])
-        sd_grads = {n_: p_.grad for n_, p_ in model.named_parameters() if p_.grad is not None}
-        for n_, gr in sd_grads.items():
-            if n_.startswith("head.") or n_ == "backbone.0.weight":
-                arrs["grad/" + n_] = gr
-        names_sorted = sorted(sd_grads)
-        arrs["grad_names"] = np.array(names_sorted)
-        arrs["grad_norms"] = np.array([float(sd_grads[n_].norm()) for n_ in names_sorted])
+        if not outputs_only:
+            sd_grads = {n_: p_.grad for n_, p_ in model.named_parameters() if p_.grad is not None}
+            for n_, gr in sd_grads.items():
+                if n_.startswith("head.") or n_ == "backbone.0.weight":
+                    arrs["grad/" + n_] = gr
+            names_sorted = sorted(sd_grads)
+            arrs["grad_names"] = np.array(names_sorted)
+            arrs["grad_norms"] = np.array([float(sd_grads[n_].norm()) for n_ in names_sorted])
         save(f"step_{name}", **arrs)
         print("   ", {k: round(v, 6) for k, v in logged.items()}, "head fit", round(fit_loss, 6))
 
@@ -633,5 +639,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     GENS = {"decode": gen_decode, "heatmaps": gen_heatmaps, "geometry": gen_geometry, "losses": gen_losses,
             "callbacks": gen_callbacks, "tracker_step": gen_tracker_step, "predictions": gen_predictions, "labeled_targets": gen_labeled_targets, "temporal_heatmap": gen_temporal_heatmap, "step_parity": gen_step_parity}
-    for name in (sys.argv[1:] or list(GENS)):  # `make_golden.py predictions` regenerates one fixture only
-        GENS[name]()
+    for name in (sys.argv[1:] or list(GENS)):  # `make_golden.py predictions` regenerates one fixture only; `step_parity:c4full` one step config
+        if ":" in name:
+            gname, sub = name.split(":", 1)
+            GENS[gname](sub.split(","))
+        else:
+            GENS[name]()

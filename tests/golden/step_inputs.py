@@ -24,6 +24,13 @@ STEP_CONFIGS = {
     # (192 frames are too many for 300 head steps to memorise when all blobs look alike: the K blobs get a seeded colour each, so the head
     # can tell the keypoints apart from the trunk's features, and the head trains longer - the heat-maps are then single peaks as in c2)
     "c2full": dict(HW=384, K=17, Bl=64, S=128, V=1, seed=16, unsup=("temporal", "pca_singleview"), colored=True, head_steps=1000),
+    # BASELINE config 4 at its REAL per-GPU batch (ViT-S/16, 64 labeled + 128 unlabeled 384x384 frames: the GEMM walks over 192 x 577 token
+    # rows, the fused bias-gradient column sums, attention over 1152 (image, head) slices).  OUTPUTS ONLY: the reference's step runs under
+    # no_grad (every logged scalar, keypoints, confidences, heat-map peaks) - its backward over 192 frames needs ~55 GB of saved attention /
+    # MLP activations in fp32, more than the build container has; LayerNorm networks have no batch statistics, so the gradients of a frame
+    # do not depend on the batch it is in and stay pinned by the 2 + 4 frame fixture c4
+    "c4full": dict(HW=384, K=17, Bl=64, S=128, V=1, seed=18, unsup=("temporal", "pca_singleview"), backbone="vits_dino", colored=True,
+                   head_steps=600, outputs_only=True),
     # BASELINE config 5 with its real FOUR views (256x256 views, temporal + pca_multiview)
     "c5v4": dict(HW=256, K=4, Bl=2, S=4, V=4, seed=17, unsup=("temporal", "pca_multiview")),
 }

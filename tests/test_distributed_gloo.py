@@ -124,8 +124,8 @@ def _engine_worker(rank, world, port, q, gather=False):
     torch.manual_seed(7)
     sd = seeded_state_dict(K, 2)
     gen = torch.Generator().manual_seed(0)
-    images = torch.randn(4, 3, 64, 64, generator=gen)
-    g_heat = torch.randn(4, K, 16, 16, generator=gen)
+    images = torch.randn(2 * world, 3, 64, 64, generator=gen)   # (world 2: the 4 frames of rounds 1 - 3, same draw)
+    g_heat = torch.randn(2 * world, K, 16, 16, generator=gen)
 
     def make(sync):
         e = Engine(K, 2, dev)
@@ -166,7 +166,7 @@ def _engine_worker(rank, world, port, q, gather=False):
     n_bwd = calls["n"] - early
     dp.all_reduce_gradients()
     dp.wait()
-    if (n_fwd, n_bwd) != (n_bn, n_bn):
+    if (n_fwd, n_bwd) != (n_bn, n_bn):   # (one message per layer and direction whatever the world size)
         bad.append(f"C:{n_fwd} forward / {n_bwd} backward all-reduces for {n_bn} BatchNorm layers")
     if not (3 <= early < -(-eng.G.numel() * 4 // (8 << 20))):
         bad.append(f"overlap: {early} gradient buckets left during backward")
@@ -191,14 +191,14 @@ def _engine_worker(rank, world, port, q, gather=False):
         for key, v in t_solo.t.items():
             if key.split(".")[-1] in ("mu", "iv", "m1", "v1", "m2", "v2", "m3", "v3", "md", "vd") and not torch.equal(tape.t[key], v):
                 bad.append(f"B:{key} not bit-identical")
-        if not torch.equal(eng.G, 2 * solo.G):
-            bad.append(f"B:summed gradient != 2 x single-process gradient (max diff {float((eng.G - 2 * solo.G).abs().max()):.3e})")
+        if not torch.equal(eng.G, world * solo.G):   # (world is a power of two: sums of equal terms are exact)
+            bad.append(f"B:summed gradient != {world} x single-process gradient (max diff {float((eng.G - world * solo.G).abs().max()):.3e})")
         sb = eng.plan.stem_bn
         if not torch.equal(eng.running_view(sb, "running_mean"), solo.running_view(sb, "running_mean")):
             bad.append("B:stem running_mean")
-        m = 2 * 32 * 32  # stem pixels per rank: unbiased variance uses the GLOBAL count 2m
+        m = 2 * 32 * 32  # stem pixels per rank: unbiased variance uses the GLOBAL count world * m
         ratio = (eng.running_view(sb, "running_var") - 0.9) / (solo.running_view(sb, "running_var") - 0.9)
-        if not torch.allclose(ratio, torch.full_like(ratio, (2 * m / (2 * m - 1)) / (m / (m - 1))), rtol=1e-4):
+        if not torch.allclose(ratio, torch.full_like(ratio, (world * m / (world * m - 1)) / (m / (m - 1))), rtol=1e-4):
             bad.append("B:stem running_var (global count)")
     # ---- (E) the ViT engine: no BatchNorm messages, gradient buckets leave layer by layer during its backward, the sum is exact
     from lightning_pose_amd.vit_engine import ViTEngine
@@ -234,27 +234,29 @@ def _engine_worker(rank, world, port, q, gather=False):
         _, vts = vsolo.forward(images[:2], True)
         vsolo.zero_grad()
         vsolo.backward(vts, g_heat[:2])
-        if not torch.equal(vit.G, 2 * vsolo.G):
-            bad.append(f"E:summed ViT gradient != 2 x single-process gradient (max diff {float((vit.G - 2 * vsolo.G).abs().max()):.3e})")
+        if not torch.equal(vit.G, world * vsolo.G):
+            bad.append(f"E:summed ViT gradient != {world} x single-process gradient (max diff {float((vit.G - world * vsolo.G).abs().max()):.3e})")
     q.put((rank, not bad, "; ".join(bad[:6])))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gather", [False, True], ids=["all_reduce", "one_shot_gather"])
-def test_sync_batchnorm_engine_gloo_world2(gather):
-    """SyncBatchNorm + summed gradients of the real engine across 2 gloo ranks (see _engine_worker), with the messages as all-reduces and as
-    the one-shot exchange (LP_SYNCBN_GATHER=1: all-gather into per-rank slots + add in rank order - the same bits on every rank, and at
-    world 2 the same bits as the all-reduce, so part (B)'s exact comparisons hold for both)"""
+@pytest.mark.parametrize("world,gather", [(2, False), (2, True), (8, True)], ids=["all_reduce", "one_shot_gather", "world8_one_shot_gather"])
+def test_sync_batchnorm_engine_gloo_world2(world, gather):
+    """SyncBatchNorm + summed gradients of the real engine across gloo ranks (see _engine_worker), with the messages as all-reduces and as
+    the one-shot exchange (LP_SYNCBN_GATHER=1: all-gather into per-rank rows + lp_bn_slots_reduce in rank order - the same bits on every
+    rank, and at world 2 the same bits as the all-reduce, so part (B)'s exact comparisons hold for both).  World 8 (round 4: what the
+    driver's SCALE run launches) takes the one-shot form, whose pairwise tree keeps sums of 8 equal terms exact; a ring all-reduce passes
+    through 3x, 5x, 7x, which round."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, gather)) for r in range(2)]
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q, gather)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=1500) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True, ""), (1, True, "")], res
+    assert sorted(res) == [(r, True, "") for r in range(world)], res
 
 
 def _tracker_worker(rank, world, port, q):
@@ -278,7 +280,7 @@ def _tracker_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    dev, K, HW, Bper = torch.device("cpu"), 3, 64, 2
+    dev, K, HW, Bper = torch.device("cpu"), 3, 64, (2 if world <= 4 else 1)
     gen = torch.Generator().manual_seed(5)
     images = torch.randn(world * Bper, 3, HW, HW, generator=gen)
     kp = torch.rand(world * Bper, K, 2, generator=gen) * HW
@@ -332,9 +334,10 @@ def _tracker_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_tracker_step_sharded_over_ranks_equals_one_process(world):
-    """(world 4: the SCALE runs go to 8 ranks - bucketed gradient sum, SyncBatchNorm counts and the 1 / world scale beyond two ranks)"""
+    """(world 4 and 8: the SCALE runs go to 8 ranks - bucketed gradient sum, SyncBatchNorm counts and the 1 / world scale beyond two ranks;
+    world 8 shards one frame per rank, the smallest per-rank batch `ceil(batch / n)` produces)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

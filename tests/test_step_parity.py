@@ -22,11 +22,17 @@ from tests.golden.step_inputs import PCA_LOG_WEIGHT, RESIDUAL_GAIN, STEP_CONFIGS
 # confidences <= 0.06, peak heights 5 %.  The product must stay within 2x of that policy noise (asserted below per fixture).
 TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, argmax=1.0, hm_loss_rel=1e-3, px_abs=1e-4, stem_cos=0.9995,
                     head_cos=0.99999, norm_rel=5e-3, norm_worst=1e-2),
-       "bf16-mixed": dict(rel=1e-2, kp_max=1.5, kp_mean=0.3, conf=0.1, peak=0.15, argmax=0.8, hm_loss_rel=0.25, px_abs=0.15, stem_cos=0.9,
-                          head_cos=0.97, norm_rel=0.25, norm_worst=0.35)}
+       # Round 4: every bf16-mixed bar is <= 2x the WORST value measured on the device over c1 / c2 / c5 / c5v4 / c4 (profiles/
+       # r04e_parity_device.jsonl - the step is bit-reproducible now, two runs gave identical records, so nothing is left for run-to-run
+       # spread): keypoints 0.61 px max / 0.124 px mean; confidences 7.8e-3; peak heights 0.117; arg-max agreement 0.906; heat-map loss of
+       # the fitted head 1.45e-2 (c5; 1.1e-2 c1, 2.4e-3 c2, 5.9e-3 c5v4); RMSE 0.022 px where it is a fraction of a pixel (c5: 0.178 px);
+       # stem cosine 0.915 .. 0.973, head 0.9755 .. 0.9996; norm ratios of the compared tensors 0.98 .. 1.126.  (Round 3's bars were
+       # 1.5 / 0.3 / 0.1 / 0.15 / 0.8 / 0.25 / 0.15 px and 0.35: VERDICT r3 "a regression that triples the heat-map-loss error passes".)
+       "bf16-mixed": dict(rel=1e-2, kp_max=1.0, kp_mean=0.25, conf=0.03, peak=0.15, argmax=0.85, hm_loss_rel=0.03, px_abs=0.05, stem_cos=0.9,
+                          head_cos=0.97, norm_rel=0.2, norm_worst=0.25)}
 # (norm_worst: the maximum over ~160 parameter tensors of |norm ratio - 1|, reached by BatchNorm weights / biases of the deep blocks whose
-# gradients are small signed sums.  On the device it varies from run to run - small launches accumulate their BatchNorm sums with atomics -
-# over 12 runs per config: c1 0.14 .. 0.19, c2 0.06 .. 0.17, c5 0.08 .. 0.14, s64 0.05 .. 0.17, c4 0.009 (profiles/r02_flake_step_parity.log))
+# gradients are small signed sums: c1 0.17, c5 0.125, c5v4 0.10, c2 0.09, c4 0.009 on the device (r04e); until round 3 it also varied from
+# run to run - the BatchNorm sums went through fp32 atomics - between 0.05 and 0.19)
 # Full-batch fixtures (thousands of keypoints): the bulk is held to the bars above and the tail is bounded.  Measured on the device
 # (profiles/r03m_parity_dist.jsonl): c2full fp32 - keypoints mean 7e-5 px, 99.9 % within 1.9e-3 px, max 7e-3 px (2 - 3 of ~3000 keypoints, on
 # maps whose peak is < 0.05); c2full bf16-mixed - mean 0.17 / 0.11 px = the policy's own 0.18 / 0.11, 99 % within 0.9 px, and the same handful
@@ -36,8 +42,11 @@ TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, a
 # 4.8e-3 px (profiles/r03_flake4.log, r03m_parity_dist.jsonl) - the six worst of ~6000 coordinates, on maps whose peak is just above PEAK_MIN -
 # so the bulk bar sits at the 99th percentile and the 99.9th is bounded separately (1.5e-2 px = 4e-5 of the frame).
 BIG = 500                                  # keypoints per fixture from which the tail rules apply
-TAIL = {"fp32": dict(q=0.99, q_hi=(0.999, 1.5e-2), max=0.05), "bf16-mixed": dict(q=0.99, frac_over=0.005)}
-SCALAR_REL = {"c2full": 3e-2}              # temporal / pca / total of the bf16-mixed path (default 1.5e-2)
+TAIL = {"fp32": dict(q=0.99, q_hi=(0.999, 1.5e-2), max=0.05), "bf16-mixed": dict(q=0.99, kp_max=1.5, frac_over=0.005)}
+# (bf16-mixed at the full batch: 99 % of the ~3000 labeled keypoints within 0.965 px, ~6000 unlabeled ones within 0.52 px - r04e - against a
+# bulk bar of 1.5 px; at most 0.5 % beyond it)
+SCALAR_REL = {"c2full": 2.5e-2}            # temporal / pca / total of the bf16-mixed path (default 1.2e-2): measured 1.27e-2 (temporal: the handful
+                                           # of two-peak maps, see above; the policy oracle itself: 2.8e-2, profiles/r04_rounding_stages.json)
 # Parameter gradients at BASELINE's real batch under the bf16-mixed POLICY itself - the reference's arithmetic rounded where the product rounds,
 # torch autograd on the device (profiles/policy_grad_full.py -> profiles/r03_policy_grad_c2full.json): the stem's weight gradient (the end of a
 # 53-layer bf16 backward chain summed over 7 M pixels x 192 frames) has cosine 0.888 against the fp32 fixture, the head's 0.90 - 0.94 (sums of
@@ -58,7 +67,7 @@ def _policy_cos(name):
 
 
 POLICY_COS = {"c2full": _policy_cos("c2full")}
-POLICY_COS_MARGIN = 0.06
+POLICY_COS_MARGIN = 0.045   # (measured gap to the policy's own cosine: 0.033 first head layer, 0.011 stem - r04e; round 3: 0.06)
 REPORT: list = []
 PEAK_MIN = 0.03   # maps the reference itself predicts with a peak below this are not fitted (the unlabeled NaN keypoint, a few of c2's
                   # 17 x 12 maps): nearly flat, so soft-argmax(T = 1000) is ill-conditioned there; they are compared in fp32 only
@@ -146,7 +155,7 @@ def _check(name, dev, precision, g):
             # magnified by target / residual
             assert got[k] == pytest.approx(v, rel=t["hm_loss_rel"]), (k, got[k], v)
         else:                                                                                  # temporal, pca, total: the bar itself
-            assert got[k] == pytest.approx(v, rel=max(t["rel"], SCALAR_REL.get(name, 1.5e-2) if precision != "fp32" else 0)), (k, got[k], v)
+            assert got[k] == pytest.approx(v, rel=max(t["rel"], SCALAR_REL.get(name, 1.2e-2) if precision != "fp32" else 0)), (k, got[k], v)
     # (the supervised tracker's loss IS the heat-map loss of the fitted head: see above)
     assert float(out["loss"].detach()) == pytest.approx(float(g["loss"]), rel=t["rel"] if cfg["S"] > 0 else t["hm_loss_rel"])
     # ---- what the losses saw: keypoints (frame px and model px), confidences - on the maps the reference itself localises
@@ -171,13 +180,14 @@ def _check(name, dev, precision, g):
                 REPORT.append((name, precision, tag, key, round(float(err.max()), 5), round(float(err.mean()), 5)))
                 tail = TAIL[precision] if err.numel() >= BIG else None
                 bulk = float(err.quantile(tail["q"])) if tail else float(err.max())
-                assert bulk <= t["kp_max"] and float(err.mean()) <= t["kp_mean"], (tag, key, bulk, float(err.max()), float(err.mean()))
+                kp_max = tail.get("kp_max", t["kp_max"]) if tail else t["kp_max"]
+                assert bulk <= kp_max and float(err.mean()) <= t["kp_mean"], (tag, key, bulk, float(err.max()), float(err.mean()))
                 if tail and "q_hi" in tail:
                     assert float(err.quantile(tail["q_hi"][0])) <= tail["q_hi"][1], (tag, key, float(err.quantile(tail["q_hi"][0])))
                 if tail and "max" in tail:
                     assert float(err.max()) <= tail["max"], (tag, key, float(err.max()))
                 if tail and "frac_over" in tail:
-                    assert float((err > t["kp_max"]).float().mean()) <= tail["frac_over"], (tag, key, int((err > t["kp_max"]).sum()))
+                    assert float((err > kp_max).float().mean()) <= tail["frac_over"], (tag, key, int((err > kp_max).sum()))
                 if precision != "fp32" and f"bf16ref_{tag}_{key}" in g:   # no worse than 2x the precision policy's own noise
                     pol = (g.t(f"bf16ref_{tag}_{key}") - w).abs()[ok2]
                     assert float(err.mean()) <= 2.0 * float(pol.mean()) + 0.02, (tag, key, float(err.mean()), float(pol.mean()))
@@ -195,6 +205,10 @@ def _check(name, dev, precision, g):
         pca = model.loss_factory_unsup.loss_instance_dict[ptype].pca
         torch.testing.assert_close(pca.parameters["mean"].cpu().float(), g.t("pca_mean").float(), atol=1e-3, rtol=1e-5)
         assert float(pca.parameters["epsilon"]) == pytest.approx(float(g["pca_eps"]), rel=1e-4)
+    if "grad_names" not in g:   # an outputs-only fixture (c4full: the reference's backward over 192 ViT frames does not fit the build container)
+        assert any(p_.grad is not None and float(p_.grad.abs().sum()) > 0 for p_ in model.parameters())
+        print("\nPARITY", name, precision, REPORT[-4:], "(outputs only)")
+        return model
     # ---- parameter gradients: head and stem tensors in full, one norm per parameter tensor
     grads = {n_: p_.grad.detach().float().cpu() for n_, p_ in model.named_parameters() if p_.grad is not None}
     norms = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
@@ -274,7 +288,13 @@ def test_step_repeats_bit_for_bit(golden, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16-mixed"])
-def test_step_parity_c4_vit(golden, precision):
+@pytest.mark.parametrize("name", ["c4", "c4full"])
+def test_step_parity_c4_vit(golden, name, precision):
     """config 4: ViT-S/16 (the reference's VisionEncoder over HuggingFace ViTModel, verbatim) in both precisions (fp32 = the validation
-    executor vit_engine_fp32.Fp32ViTEngine); LayerNorm networks are not chaotic, so no damping is involved"""
-    _check("c4", torch.device("cuda:0"), precision, golden("step_c4"))
+    executor vit_engine_fp32.Fp32ViTEngine); LayerNorm networks are not chaotic, so no damping is involved.  c4full = the same at BASELINE's
+    real per-GPU batch, 64 + 128 frames (round 4: the GEMM walks over 192 x 577 token rows, 1152 (image, head) attention slices, the fused
+    bias-gradient column sums) - forward quantities only, see tests/golden/step_inputs.py"""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"step_{name}.npz")):
+        pytest.skip(f"step_{name}.npz not generated")
+    _check(name, torch.device("cuda:0"), precision, golden(f"step_{name}"))
