@@ -362,6 +362,20 @@ def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int
                       "that tests/ pin against the verbatim reference, with the bench's four losses: heatmap_mse + temporal + pca_singleview + unimodal_mse)"}
 
 
+def cpu_baseline_in_subprocess(size: int, K: int, steps: int) -> dict:
+    """The baseline leg in its OWN process (`bench.py --cpu-baseline-only`): executing the reference's modules installs stand-ins for
+    torchvision / kornia / lightning in sys.modules (oracle/ref_loader.py) - test infrastructure that must not leak into the process that
+    measures the product (the ViT secondary lines import transformers, which probes for the real torchvision)."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(size), "--keypoints", str(K),
+                        "--cpu-baseline-steps", str(steps)], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu baseline process failed (rc {r.returncode}): {r.stderr[-300:]}")
+    return json.loads(lines[-1])
+
+
 def predict_bench(args, model, batch, dev, rank: int, world: int) -> dict:
     """Inference over the resident frames: predict_step (trunk with folded BatchNorm -> head -> fused decode incl. the bbox map)."""
     import torch.distributed as dist
@@ -426,6 +440,8 @@ def fit_line(args, dev, rank: int, world: int) -> dict:
     g = torch.Generator().manual_seed(77 + rank)
     n_win = args.warmup + args.steps
     video = torch.randint(0, 256, (n_win * args.unlabeled, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    if dev.type == "cuda":
+        video = video.pin_memory()   # (a decoder writes into pinned buffers; FrameWindowSource copies windows of a pinned video as they are)
     lab_u8 = torch.randint(0, 256, (args.labeled, Hs, Ws, 3), generator=g, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else \
         torch.randint(0, 256, (args.labeled, Hs, Ws, 3), generator=g, dtype=torch.uint8)
     kp = torch.rand(args.labeled, K, 2, generator=g) * torch.tensor([Ws, Hs])
@@ -490,7 +506,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
             if k_.startswith("head") and k_.endswith("weight"):
                 sd[k_] = sd[k_] * 200
         model.load_state_dict(sd)
-    trainer = Trainer(max_epochs=1, data_parallel=dist.is_initialized(), sync_batchnorm=not args.no_sync_bn, hip_graph=bool(args.graph))
+    trainer = Trainer(max_epochs=1, data_parallel=dist.is_initialized(), sync_batchnorm=not args.no_sync_bn)
     trainer.setup(model)
     if getattr(args, "unfrozen", False):   # the regime after UnfreezeBackbone fired (reference callbacks.py:126-148): every group trains,
         for g_ in model.optimizers().param_groups:   # so the transposed weight copies of the data gradients are refreshed every step
@@ -502,8 +518,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         if dist.is_initialized():
             dist.barrier()
 
-    graph_capture_steps = 3 if args.graph else 0   # 2 eager steps + the capture itself, all before the counted warm-up
-    for i in range(graph_capture_steps + args.warmup):
+    for i in range(args.warmup):
         trainer.training_batch(model, batch, i)
     _sync(dev)
     barrier()
@@ -539,7 +554,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
 
     # what crosses GPUs per step: SyncBatchNorm all-reduces (one per BatchNorm layer and direction, both segments of the joint pass in one
     # message), the gradient buckets, one packed message of logged scalars
-    n_msgs = getattr(model.net, "sync_bn_messages", 0) // max(1, graph_capture_steps + args.warmup + args.steps + 1)
+    n_msgs = getattr(model.net, "sync_bn_messages", 0) // max(1, args.warmup + args.steps + 1)
     bn_bytes = sum(2 * 2 * b.C * 4 for b in getattr(model.net.plan, "bns", [])) * 2 if getattr(model.net, "sync_bn", False) else 0
     comm = {"sync_bn_messages": n_msgs, "sync_bn_bytes": bn_bytes, "grad_buckets": (0 if solo else -(-model.net.G.numel() * 4 // (64 << 20))),
             "grad_bytes": 0 if solo else model.net.G.numel() * 4, "logged_scalar_messages": 0 if solo else 1}
@@ -575,7 +590,6 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                                + (", head weights x200 (peaked heat-maps: ~4 of 147 456 up-sampled pixels carry weight, as with a trained head)" if getattr(args, "peaked", False) else ""),
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": bool(getattr(model.net, "sync_bn", False)),
                    "comm_per_step": comm, "memory": memory,
-                   "hip_graph": bool(trainer._graphed is not None and trainer._graphed.replays > 0),
                    "decode_prune": _decode_prune_label(model),
                    "final_loss": round(float(loss), 6)},
     }
@@ -636,8 +650,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                 out["roofline_hbm"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not dist.is_initialized() and not args.no_cpu_baseline and not is_vit and args.views == 1 and not getattr(args, "_secondary", False):
             try:
-                from oracle import ref_loader as _R
-                out["cpu_baseline"] = (cpu_baseline_reference if _R.available() else cpu_baseline)(args.size, args.keypoints, steps=args.cpu_baseline_steps)
+                out["cpu_baseline"] = cpu_baseline_in_subprocess(args.size, args.keypoints, args.cpu_baseline_steps)
             except Exception as e:  # noqa: BLE001 - the baseline must never cost the measured line
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
@@ -661,6 +674,9 @@ def self_launch(n: int, argv: list[str], entry: str | None = None, env: dict | N
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), entry or os.path.abspath(__file__), *argv]
+    if os.environ.get("LP_BENCH_DRY_RUN") == "1":   # (tests: the launcher command and the environment its ranks would get, nothing started)
+        print(json.dumps({"cmd": cmd, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS", "LP_SYNCBN_GATHER") if k in env}}))
+        return 0
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -680,8 +696,6 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                     "gives the same 192 images per GPU); frames/s then counts view-images")
     ap.add_argument("--predict", action="store_true", help="secondary line: inference frames/s (eval mode, BatchNorm folded into the "
                     "convolutions, fused decode) over the same frames; the headline metric stays the training step")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("LP_HIP_GRAPH", "0")), help="1: replay the step as one captured HIP graph "
-                    "(lightning_pose_amd/graph_step.py); the capture happens in extra untimed steps before the warm-up")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip the short secondary lines (256 px, ViT-S, multiview, "
                     "inference) the default single-GPU run appends under \"secondary\"")
     ap.add_argument("--unfrozen", action="store_true", help="secondary line: the backbone group trains too (lr > 0), as after UnfreezeBackbone")
@@ -693,7 +707,18 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                     "FrameWindowSource / LabeledBatchProducer / VideoFramePipeline -> step), i.e. what a user's training loop gets")
     ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNorm statistics (the reference sets sync_batchnorm=True, train.py:427; A/B only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--syncbn-gather", action="store_true", help="N > 1: SyncBatchNorm messages as ONE all-gather + an ordered add of the ranks' rows "
+                    "(lp_bn_slots_reduce) instead of an all-reduce (= LP_SYNCBN_GATHER=1; the A/B the first 8-GPU call decides)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit: the reference's own "
+                    "step when its modules are present (/root/reference, or oracle/_ref on the GPU box), the restated port otherwise")
     args = ap.parse_args(argv)
+    if args.syncbn_gather:
+        os.environ["LP_SYNCBN_GATHER"] = "1"   # (read by Engine.__init__; self_launch's children inherit it)
+    if args.cpu_baseline_only:
+        from oracle import ref_loader as _R
+        print(json.dumps((cpu_baseline_reference if _R.available() else cpu_baseline)(args.size, args.keypoints, steps=args.cpu_baseline_steps)),
+              flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and device is None:   # no launcher around us: be the launcher
         raise SystemExit(self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv)))
 

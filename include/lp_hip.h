@@ -232,15 +232,6 @@ int lp_attn_fwd(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, i
  * Q / V come from the token rows of lp_attn_fwd, dO from d_out_bf16[(b*T + q)*ld_do + h*64 ..], D = lp_attn_rowdot's [B*T][nh]. */
 int lp_attn_bwd_kv(const void* qkv_bf16, int ld_qkv, int v_off, const void* d_out_bf16, int ld_do, const void* p_bf16, int ldp, const float* d_rows,
                    int B, int nh, int T, float scale, void* ds_bf16, void* dqkv_bf16, int ld_dqkv, int dk_off, int dv_off, lp_stream_t stream);
-/* The same pair WITHOUT the T x T tensor: the training forward leaves (row maximum of the scaled scores, 1 / exp-sum) per query in `stats`
- * ([B*nh][T][2] fp32) instead of P, and the key / value backward rebuilds each tile's probabilities as exp(scale Q K^T - m) / l - the forward's
- * own expression and k-slice order - from the Q tile it stages anyway.  dS ([B*nh][T][ldp] bf16, pad columns zeroed) is still written: the dQ
- * product (lp_gemm_nt) reads it.  Replaces the eager attention of HuggingFace ViTSelfAttention (reference models/backbones/vit.py:38-43). */
-int lp_attn_fwd_lse(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, int B, int nh, int T, float scale, float* stats, void* out_bf16,
-                    int ldo, lp_stream_t stream);
-int lp_attn_bwd_kv_lse(const void* qkv_bf16, int ld_qkv, int k_off, int v_off, const void* d_out_bf16, int ld_do, const float* stats,
-                       const float* d_rows, int B, int nh, int T, float scale, void* ds_bf16, int ldp, void* dqkv_bf16, int ld_dqkv, int dk_off,
-                       int dv_off, lp_stream_t stream);
 /* Attention backward without materialising dP (replaces lp_gemm_nt + lp_softmax_rows_bwd of the composition; the reference's
  * arithmetic is HF ViTSelfAttention's eager soft-max attention, models/backbones/vit.py:38-43):
  *   lp_attn_rowdot   D[row][h] = sum_d a[row][h*64+d] * b[row][h*64+d]   (a = dO, b = O, head dimension 64)
@@ -519,11 +510,6 @@ int lp_labeled_keypoints(const float* kp_src, const float* src_hw, const float* 
  * ------------------------------------------------------------------------------------------------------ */
 int lp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int decoupled, int step, float grad_scale, void* params_bf16, lp_stream_t stream);
-/* same update, with the scalars that change every step read from device memory: hyper_dev = [lr, 1 - beta1^step, sqrt(1 - beta2^step)]
- * (fp32).  The launch is then identical from step to step, so the whole optimisation step can be replayed as one captured HIP graph
- * while the host rewrites those 12 bytes (UnfreezeBackbone / MultiStepLR change lr, callbacks.py:126-148, models/base.py:427-447). */
-int lp_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, const float* hyper_dev, float beta1,
-                     float beta2, float eps, float weight_decay, int decoupled, float grad_scale, void* params_bf16, lp_stream_t stream);
 int lp_cast_bf16(const float* src, size_t n, void* dst, lp_stream_t stream);
 /* dst[c][b][a] = src[a][b][c] on bf16: weights [Co][R*S][Ci] -> data-gradient copy [Ci][R*S][Co] */
 int lp_permute_cba(const void* src, int A, int B, int C, void* dst, lp_stream_t stream);

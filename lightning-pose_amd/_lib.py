@@ -93,8 +93,6 @@ PROTOTYPES = {
     "lp_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P, _I, _P]),
     "lp_attn_bwd_kv": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, C.c_float, _P, _P, _I, _I, _I, _P]),
-    "lp_attn_fwd_lse": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
-    "lp_attn_bwd_kv_lse": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _F, _P, _I, _P, _I, _I, _I, _P]),
     "lp_attn_rowdot": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "lp_attn_dscores": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_float, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
@@ -171,7 +169,6 @@ PROTOTYPES = {
     "lp_f32_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
     "lp_f32_attn_bwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _I, _P]),
     "lp_adam_step": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _I, _F, _P, _P]),
-    "lp_adam_step_dev": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _F, _P, _P]),
     "lp_cast_bf16": (_I, [_P, _Z, _P, _P]),
     "lp_permute_cba": (_I, [_P, _I, _I, _I, _P, _P]),
 }

@@ -89,17 +89,15 @@ __device__ __forceinline__ void stats_emit(const ConvEpilogue& ep, int N, int id
     }
 }
 
-// every workgroup zeroes ITS row of stats_slots before its walk (nobody else touches the row; the stores are acknowledged before the first
-// barrier of the K loop, which every flush is behind)
+// every workgroup zeroes ITS row of stats_slots before its walk (nobody else touches the row).  No wait here: the first read-modify-write
+// of the row is in a stats flush, behind that flush's __syncthreads() - which every wave enters only after ITS outstanding stores are
+// acknowledged (hipcc's __syncthreads is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier) - and at least one whole tile later.  (With an
+// explicit wait + barrier at the start every launch began ~3 us later: forward launches 7.55 -> 7.80 ms per step, profiles/r04h_*.)
 __device__ __forceinline__ void stats_slots_zero(const ConvEpilogue& ep, int N, int tid, int nthreads) {
     if (ep.stats_slots == nullptr) return;
     const int n = (ep.seg_images > 0 ? 4 : 2) * N;
     float* row = ep.stats_slots + (size_t)blockIdx.x * n;
     for (int i = tid; i < n; i += nthreads) row[i] = 0.f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    __syncthreads();
 }
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's

@@ -33,6 +33,9 @@
 
 namespace lp {
 
+#ifndef LP_HALO_KEY_ROW
+#define LP_HALO_KEY_ROW 0   // (A/B builds: 1 = round 3's swizzle key of the HALO form, the halo row itself)
+#endif
 #ifndef LP_PIPE_SPREAD
 #define LP_PIPE_SPREAD 1   // (A/B builds: 0 issues a K step's loads in one burst after the barrier)
 #endif
@@ -231,9 +234,6 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         }
     };
     auto issue_load = [&](int i) {   // (i is a compile-time constant at every call site)
-#ifdef LP_PIPE_EXP_NOLOAD   // (timing experiment, wrong results: how fast is the MFMA + LDS-read loop alone?)
-        if (M < 0)
-#endif
         if (HALO) buf_load16_lds(rsrc_w, is_dst + (i % NBL) * (64 * kPRowB), is_w[i % NBL], is_soff_b);
         else if (i < 4) buf_load16_lds(rsrc_x, is_dst + i * (64 * kPRowB), voff[i], is_soff_a);
         else buf_load16_lds(rsrc_w, is_dst + kStageA + (i - 4) * (64 * kPRowB), is_w[i - 4], is_soff_b);
@@ -260,6 +260,16 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         const int rm = fdiv(m, div_row), bm = fdiv(rm, hd.h);
         return (rm + 1 + 2 * bm) * hWp + (m - rm * hW) + 1;
     };
+    auto padded_row = [&](int m) {   // ... and the padded image row it lies in
+        const int rm = fdiv(m, div_row), bm = fdiv(rm, hd.h);
+        return rm + 1 + 2 * bm;
+    };
+    // Swizzle key of a halo row (round 4).  A wave's 32-pixel fragment window crosses an image-row end every W pixels, where the padded
+    // raster skips the two border columns (+3 instead of +1): keyed on the halo row itself - (row >> 1) & 7, conflict-free for CONSECUTIVE
+    // rows - the ds_read_b128 lane groups {0-3, 12-15, 20-27} ... then meet 2-way bank conflicts after every jump (W = 24 / 12: one to three
+    // per window; SQ_LDS_BANK_CONFLICT was 8 - 10 % of the HALO launches' cycles, profiles/r03_pmc_mfma.json).  Keyed on
+    // u = row - 2 x (padded image rows since the tile's first), u advances by exactly 1 from pixel to pixel across row ends, and row - u is
+    // even, so (bank half, chunk position) = u mod 16 stays distinct over any 16 pixels in a row.  A tap (r, s) moves u by (r - 1) W + (s - 1).
     auto halo_setup = [&](int vt) {
         if (vt >= ntiles) {
 #pragma unroll
@@ -267,21 +277,20 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             return;
         }
         const int tile = xcd_remap(vt, ntiles);
-        const int pbase = padded((tile / tiles_n) * kPM) - (hW + 3);
+        const int m0h = (tile / tiles_n) * kPM;
+        const int pbase = padded(m0h) - (hW + 3), rr0 = padded_row(m0h) - 1;   // (pbase lies in the padded row above the tile's first pixel)
 #pragma unroll
         for (int i = 0; i < (HALO ? NA : 0); ++i) {
             const int j = i * 64 + lrow, pp = pbase + j, pc = pp < 0 ? 0 : pp;
             const int rr = fdiv(pc, hd.wp), xx = pc - rr * hWp;
             const int bb = fdiv(rr, hd.hp), yy = rr - bb * hHp;
             const bool ok = pp >= 0 && xx >= 1 && xx <= hW && yy >= 1 && yy <= hH && bb < g.B;
-            const int chunk = slot ^ ((j >> 1) & 7);
+            const int u = LP_HALO_KEY_ROW ? j : j - 2 * (rr - rr0);
+            const int chunk = slot ^ ((u >> 1) & 7);
             hvoff[i] = ok ? (unsigned)((((bb * hH + yy - 1) * hW + xx - 1) * ck + chunk * 8) * 2) : ~0u;   // border / beyond the batch: zeros
         }
     };
     auto halo_issue = [&](int i) {   // (i is a compile-time constant at every call site)
-#ifdef LP_PIPE_EXP_NOLOAD
-        if (M < 0)
-#endif
         buf_load16_lds(rsrc_x, halo0 + hl_buf * kHaloB + i * (64 * kPRowB) + wave * (8 * kPRowB), hvoff[HALO ? i : 0], (unsigned)(hl_slice * (kBK * 2)));
     };
     auto halo_advance = [&]() {      // the next slice of the tile, or the first slice of the workgroup's next tile
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     constexpr int NS = (MODE == kModeFwd) ? LP_PIPE_FRAG_SETS : 2;
     // HALO: rows of the tile's pixels inside the halo image (per tile), the halo image the MFMAs read, its tap, and whether the
     // loader still has pieces of the next halo image to issue during this K step
-    int ploc[2] = {0, 0}, mh_buf = 0, mh_tap = 0;
+    int ploc[2] = {0, 0}, uloc[2] = {0, 0}, mh_buf = 0, mh_tap = 0;
     auto mma_stage = [&](int st, const bool spread) {
         const unsigned char* sb = smem + st * kStage;
         bf16x8 a[NS][2], b[NS][NT];
@@ -325,25 +334,17 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         unsigned hk[2][4] = {};
         if (HALO) {   // tap (r, s) of the slice: a constant row offset in padded raster coordinates (the zero border is part of the image)
             const int tr = mh_tap / 3, ts = mh_tap - tr * 3;
-            const int dp = (tr - 1) * hWp + (ts - 1);
+            const int dp = (tr - 1) * hWp + (ts - 1), du = (tr - 1) * hW + (ts - 1);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = ploc[mt] + (MODE == kModeDgrad ? -dp : dp);
-                const int sw = (row >> 1) & 7;
+                const int sw = LP_HALO_KEY_ROW ? (row >> 1) & 7 : ((uloc[mt] + (MODE == kModeDgrad ? -du : du)) >> 1) & 7;
                 ha[mt] = halo0 + mh_buf * kHaloB + row * kPRowB;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) hk[mt][kk] = (unsigned)(((kk * 2 + fg) ^ sw) * 16);
             }
         }
         auto fetch = [&](int kk, int set) {
-#ifdef LP_PIPE_EXP_NOLDSREAD   // (timing experiment, wrong results: fragments are read once per K step instead of once per k-slice)
-            if (kk != 0) {
-                a[set][0] = a[0][0], a[set][1] = a[0][1];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b[set][nt] = b[0][nt];
-                return;
-            }
-#endif
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 if (HALO) a[set][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8*>(ha[mt] + hk[mt][kk]));
@@ -450,15 +451,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     // ---- forward store pass of the tile at (m0, n0): per wave, 2 chunks of 32 pixels through a private bf16 corner; lane (pixel fr,
     // half fg) holds for block nt the channels nt*32 + 8 j + 4 fg + (0..3) in acc[mt][nt][4 j .. 4 j + 3]
     // (Measured and dropped, profiles/r03al_store_pass_cost.txt + r03am_lazy_layers.txt.  In the open this pass costs ~1600 cycles per wave
-    // and tile whatever K is: 45 % on top of a K = 256 tile (timing builds LP_EXP_SKIP_FWD_*: 7.32 ms of forward launches per step, 6.53
+    // and tile whatever K is: 45 % on top of a K = 256 tile (timing builds, hooks kept in profiles/retired/r04_conv_pipe_timing_hooks.txt: 7.32 ms of forward launches per step, 6.53
     // without the global stores, 7.08 without the sums, 5.74 without the pass).  Converting the accumulators at the end of a tile and running
     // the rest - a 2-KB corner per wave outside the ring, 16 units: write / read / store + sums twice per 16-pixel chunk - one unit after
     // the MFMAs of each k-slice of the NEXT tile came out SLOWER in every layer (l3.c3 106 -> 123..132 us, l1.c3 246 -> 355, step 44.6 ->
     // 45.4 ms): two waves' units are ~400 VALU cycles per k-slice against 256 cycles of matrix pipe, and they share the issue port.)
     auto epilogue_fwd = [&](const int m0, const int n0, unsigned char* stg_all) {
-#ifdef LP_EXP_SKIP_FWD_STORE   // (timing experiment only: what the forward store pass costs - results are not written)
-        if (ep.ldo > 0) return;
-#endif
         const int nbase = n0 + wn * (NT * 32);   // first channel of this wave
         constexpr bool infer = EK == kEkInfer;   // lp_conv_fwd_act: its own instantiations, so the training kernels' store pass carries none of it
         constexpr int ROWB = NT * 64 + 16;       // bf16 chunk row + pad (16-B aligned)
@@ -520,13 +518,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                         }
                         w = pack_bf16x8(v);
                     }
-#ifdef LP_EXP_SKIP_FWD_GSTORE
-                    if (ep.ldo < 0)
-#endif
                     store8(ep.out_bf16 + off, w, (flags & 2) != 0);
-#ifdef LP_EXP_SKIP_FWD_STATS
-                    if (ep.ldo < 0)
-#endif
                     if (want_stats) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -668,11 +660,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         const int m0 = tm_ * kPM, n0 = (tile - tm_ * tiles_n) * BN;
         const int seg_off = (ep.seg_images > 0 && m0 >= ep.seg_images * rows_y * rows_x) ? N : 0;
         if (HALO) {
-            const int pbase = padded(m0) - (hW + 3);
+            const int pbase = padded(m0) - (hW + 3), rr0 = padded_row(m0) - 1;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const int m = m0 + wm * 64 + mt * 32 + fr;
-                ploc[mt] = padded(m < M ? m : M - 1) - pbase;   // (rows past M: any staged row, the result is not stored)
+                const int m = m0 + wm * 64 + mt * 32 + fr, mc = m < M ? m : M - 1;   // (rows past M: any staged row, the result is not stored)
+                ploc[mt] = padded(mc) - pbase;
+                uloc[mt] = ploc[mt] - 2 * (padded_row(mc) - rr0);
             }
         }
         if (n0 != st_n0 || seg_off != st_seg_off) {   // (workgroup-uniform) new column block / BatchNorm segment
@@ -708,9 +701,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             else if (HALO) LP_WAIT_VM(1);
             else if (NBL == 2) LP_WAIT_VM(6);
             else LP_WAIT_VM(5);
-#ifndef LP_PIPE_EXP_NOBARRIER   // (timing experiment, racy: what do the per-K-step barriers cost?)
             LP_RAW_BARRIER();              // ... everyone's have, and everyone is done reading the stage refilled next
-#endif
             if (!kFwd && kt == KT - 1) rb_issue(rb0, 0, m0, n0);   // the first chunk's read-backs travel under the last K step
             const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
             if (kSpread || HALO) {

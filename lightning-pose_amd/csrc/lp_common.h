@@ -206,10 +206,20 @@ __device__ __forceinline__ void slots_totals(const float* __restrict__ slots, in
     const int n = npairs * C;
     const float* src = slots + (pq >> 2) * C + c0 + (pq & 3) * 4;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    if (c0 + (pq & 3) * 4 < C)   // (C is a multiple of 8: the last workgroup may cover 8 channels only)
-    for (int r = rg; r < rows; r += RG) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * n);
-        t0 += v[0], t1 += v[1], t2 += v[2], t3 += v[3];
+    if (c0 + (pq & 3) * 4 < C) {   // (C is a multiple of 8: the last workgroup may cover 8 channels only)
+        // 8 row loads in flight per thread (the rows were written by workgroups all over the chip: every load is an L2 miss, and this kernel
+        // sits between a convolution and the BatchNorm pass that waits for it), added in row order
+        constexpr int U = 8;
+        for (int r = rg; r < rows; r += RG * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ru = r + u * RG;
+                v[u] = ru < rows ? *reinterpret_cast<const f32x4*>(src + (size_t)ru * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) t0 += v[u][0], t1 += v[u][1], t2 += v[u][2], t3 += v[u][3];
+        }
     }
     red[rg][pq * 4 + 0] = t0, red[rg][pq * 4 + 1] = t1, red[rg][pq * 4 + 2] = t2, red[rg][pq * 4 + 3] = t3;
     __syncthreads();

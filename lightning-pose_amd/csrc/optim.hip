@@ -34,31 +34,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-// same update with the per-step scalars read from DEVICE memory (hyper = [lr, 1 - beta1^t, sqrt(1 - beta2^t)]): the launch itself is
-// then identical every step, so it can sit in a captured HIP graph while the host only rewrites 12 bytes before each replay
-__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                       float* __restrict__ v, size_t n, const float* __restrict__ hyper, float beta1,
-                                                       float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
-                                                       unsigned short* __restrict__ p_bf16) {
-    const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2];
-    const float step_size = lr / bc1;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float pv = p[i];
-        float gv = g[i] * grad_scale;
-        if (weight_decay != 0.f) {
-            if (decoupled) pv *= 1.f - lr * weight_decay;
-            else gv = fmaf(weight_decay, pv, gv);
-        }
-        const float mv = beta1 * m[i] + (1.f - beta1) * gv;
-        const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
-        m[i] = mv;
-        v[i] = vv;
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        pv -= step_size * (mv / denom);
-        p[i] = pv;
-        if (p_bf16 != nullptr) p_bf16[i] = f32_to_bf16(pv);
-    }
-}
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, size_t n, unsigned short* __restrict__ dst) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = f32_to_bf16(src[i]);
@@ -94,17 +69,6 @@ extern "C" int lp_adam_step(float* params, const float* grads, float* exp_avg, f
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for_n(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, weight_decay, decoupled, bc1, bc2_sqrt, grad_scale, (unsigned short*)params_bf16);
-    return launch_status();
-}
-
-extern "C" int lp_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, const float* hyper_dev,
-                                float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale, void* params_bf16,
-                                lp_stream_t stream) {
-    using namespace lp;
-    LP_REQUIRE(params && grads && exp_avg && exp_avg_sq && hyper_dev);
-    if (n == 0) return LP_OK;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for_n(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, hyper_dev,
-                       beta1, beta2, eps, weight_decay, decoupled, grad_scale, (unsigned short*)params_bf16);
     return launch_status();
 }
 

@@ -832,7 +832,7 @@ class Engine:
             if relu_bits is not None:
                 relu_mask = None  # the 1-bit form replaces the activation tensor as the mask source
             f = self._bn_fuse(g, True, sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None,
-                              relu_bits=relu_bits, seg=seg)
+                              relu_bits=relu_bits, seg=seg, defer=True)
             run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
                                                            C.byref(f), st), "lp_conv_dgrad_bn")
         else:
@@ -844,6 +844,11 @@ class Engine:
         extra = (dx_bytes if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
                 (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0)
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
+        if bn is not None and f.slot_rows > 0:
+            # the store passes left one row of partial sums per workgroup: the ordered reduction into `sums` (and d beta / d gamma) is
+            # BatchNorm's launch, issued here - outside the convolution's timed bracket - right in front of the lp_bn_bwd_apply that reads it
+            check(self._lib.lp_bn_slots_reduce(_p(self._bn_ws), int(f.slot_rows), 2 if seg else 1, b.C, _p(sums), _p(self.G[b.b_off:]),
+                                               _p(self.G[b.g_off:]), st), "lp_bn_slots_reduce")
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:

@@ -590,14 +590,21 @@ class _LossCombineFn(torch.autograd.Function):
 
 
 def loss_combine(losses: list[torch.Tensor], weights: list[float], anneal: list[float]) -> tuple[torch.Tensor, torch.Tensor]:
-    """LossFactory's weighted sum of up to 8 device scalars in one launch -> ((n,) weighted values, 0-dim total); differentiable."""
+    """LossFactory's weighted sum of device scalars -> ((n,) weighted values a_l w_l x_l, 0-dim total); differentiable.  Up to 8 losses are
+    one launch each way (lp_loss_combine); more - the reference's registry holds more than 8 loss classes and its factory sums any number,
+    losses/factory.py:229-285 - go through groups of 8 whose totals are combined the same way."""
     require_device(*losses)
-    if not 0 < len(losses) <= 8:
-        raise ValueError(f"a LossFactory sums between 1 and 8 losses in one launch, got {len(losses)}")
+    if len(losses) == 0:
+        raise ValueError("a LossFactory needs at least one loss")
     if any(x.numel() != 1 for x in losses):
         raise ValueError("every loss must be a scalar")
     xs = [x if x.dtype == torch.float32 else x.to(torch.float32) for x in losses]
-    return _LossCombineFn.apply([float(v) for v in weights], [float(v) for v in anneal], *xs)
+    w, a = [float(v) for v in weights], [float(v) for v in anneal]
+    if len(xs) <= 8:
+        return _LossCombineFn.apply(w, a, *xs)
+    parts = [_LossCombineFn.apply(w[i:i + 8], a[i:i + 8], *xs[i:i + 8]) for i in range(0, len(xs), 8)]
+    _, total = loss_combine([p[1] for p in parts], [1.0] * len(parts), [1.0] * len(parts))
+    return torch.cat([p[0] for p in parts]), total
 
 
 # --------------------------------------------------------------------------------------------------------

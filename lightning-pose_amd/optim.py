@@ -35,46 +35,15 @@ class FusedAdam(torch.optim.Optimizer):
                 raise ValueError('FusedAdam expects the reference\'s parameter groups named "backbone" and "head"')
             g.setdefault("step", 0)
         self.grad_scale = 1.0  # e.g. 1 / world_size after a SUM all-reduce
-        # graph mode (graph_step.GraphedStep): lr and the bias corrections come from this device buffer ([group][lr, 1-b1^t, sqrt(1-b2^t), 0]),
-        # written by advance() before each replay, so the captured launches never change
-        self.hyper_dev: torch.Tensor | None = None
-        self._hyper_host: torch.Tensor | None = None
-
-    def enable_device_hyper(self) -> None:
-        if self.hyper_dev is None:
-            self.hyper_dev = torch.zeros(len(self.param_groups), 4, device=self.engine.device, dtype=torch.float32)
-            self._hyper_host = torch.zeros(len(self.param_groups), 4, dtype=torch.float32).pin_memory()
-
-    def advance(self) -> None:
-        """graph mode: count the step and upload this step's [lr, bias corrections] per group (one 32-byte copy on the current stream)"""
-        for i, g in enumerate(self.param_groups):
-            g["step"] += 1
-            b1, b2 = g["betas"]
-            self._hyper_host[i, 0] = float(g["lr"])
-            self._hyper_host[i, 1] = 1.0 - b1 ** g["step"]
-            self._hyper_host[i, 2] = (1.0 - b2 ** g["step"]) ** 0.5
-        self.hyper_dev.copy_(self._hyper_host, non_blocking=True)
-
-    def refresh_signature(self) -> tuple:
-        """which groups refresh their data-gradient weight copies after a step (decided on the host from lr): part of a captured graph's key"""
-        return tuple(float(g["lr"]) != 0.0 or (float(g["weight_decay"]) != 0.0 and bool(g["decoupled"])) for g in self.param_groups)
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         e = self.engine
         lib = _lib.lib()
-        dev_hyper = self.hyper_dev is not None and e.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        for gi, g in enumerate(self.param_groups):
+        for g in self.param_groups:
             lo, hi = self._ranges[g["name"]]
             b1, b2 = g["betas"]
-            if dev_hyper:  # being captured: the step count / lr of each replay arrive through hyper_dev (advance())
-                check(lib.lp_adam_step_dev(_p(e.P[lo:hi]), _p(e.G[lo:hi]), _p(self.exp_avg[lo:hi]), _p(self.exp_avg_sq[lo:hi]), hi - lo,
-                                           _p(self.hyper_dev[gi]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                           int(bool(g["decoupled"])), float(self.grad_scale), _p(e.Wb[lo:hi]), ops._stream()), "lp_adam_step_dev")
-                if float(g["lr"]) != 0.0 or (float(g["weight_decay"]) != 0.0 and g["decoupled"]):
-                    e.refresh_dgrad_copies(lo, hi)
-                continue
             g["step"] += 1
             check(lib.lp_adam_step(_p(e.P[lo:hi]), _p(e.G[lo:hi]), _p(self.exp_avg[lo:hi]), _p(self.exp_avg_sq[lo:hi]), hi - lo,
                                    float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),

@@ -22,21 +22,19 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 1, callbacks: list | None = None, limit_train_batches: int | None = None,
                  data_parallel: bool | None = None, sync_batchnorm: bool = True, accumulate_grad_batches: int = 1,
-                 hip_graph: bool | None = None, log_every_n_steps: int = 50):
+                 log_every_n_steps: int = 50):
         self.max_epochs = max_epochs
         self.callbacks = callbacks or []
         self.limit_train_batches = limit_train_batches
         self.sync_batchnorm = sync_batchnorm
         self.accumulate_grad_batches = accumulate_grad_batches
         self._want_dp = data_parallel
-        self._want_graph = hip_graph          # None: LP_HIP_GRAPH decides (graph_step.py)
         # The step's logged scalars stay ON THE DEVICE; they reach the host every log_every_n_steps optimiser steps (Lightning's default 50;
         # the reference passes cfg.training.log_every_n_steps, train.py:420) and at the end of every epoch, as ONE packed copy.  Round 3
         # called float() on each of ~15 scalars after every batch: a full host <-> device synchronisation per step, which made
         # MAX_STEPS_IN_FLIGHT meaningless for anyone who trained through fit() instead of training_batch().
         self.log_every_n_steps = max(1, int(log_every_n_steps))
         self._inflight: list = []             # "step finished" events: the host stays at most MAX_STEPS_IN_FLIGHT steps ahead of the device
-        self._graphed = None
         self.dp: DataParallel | None = None
         self.logged_history: list[dict[str, float]] = []
         self.validation_history: list[dict[str, float]] = []
@@ -70,32 +68,16 @@ class Trainer:
         if self.dp is not None and self.dp.active and names:
             model.logged.update(self.dp.mean_scalars({k: model.logged[k] for k in names if k in model.logged}))
 
-    def _graph_eligible(self, model) -> bool:
-        import os
-
-        from . import graph_step
-
-        want = self._want_graph if self._want_graph is not None else graph_step.requested()
-        if not want or self.accumulate_grad_batches != 1 or model.device.type != "cuda" or getattr(model.net, "profile", None) is not None:
-            return False
-        if self.dp is not None and self.dp.active and os.environ.get("LP_HIP_GRAPH_DIST", "0") != "1":
-            return False
-        return True
-
     def training_batch(self, model, batch: dict, batch_idx: int, last_in_epoch: bool = False) -> torch.Tensor:
-        """One optimisation step; returns the (detached) loss.  With ``hip_graph`` the step is captured once and replayed as one HIP
-        graph (graph_step.GraphedStep); otherwise every kernel is enqueued from here."""
-        if self._graph_eligible(model):
-            from .graph_step import GraphedStep
-
-            if self._graphed is None or self._graphed.model is not model:
-                self._graphed = GraphedStep(self, model)
-            return self._graphed.step(batch, batch_idx)
+        """One optimisation step; returns the (detached) loss.  Every kernel is enqueued from here; nothing in it makes the host wait for the
+        device.  (Rounds 2 - 3 could also replay the step as one captured HIP graph: host 0.2 instead of 10 - 26 ms per step, but the replay
+        was ~3 ms SLOWER on the device than stream launches and the device bounds the step - measured in profiles/r02d_*, removed in round 4,
+        profiles/retired/r04_graph_step.py.txt.)"""
         return self._eager_batch(model, batch, batch_idx, last_in_epoch)
 
     def _eager_batch(self, model, batch: dict, batch_idx: int, last_in_epoch: bool = False, count: bool = True) -> torch.Tensor:
         """With gradient accumulation the loss is scaled by 1 / accumulate_grad_batches (Lightning's rule) and a trailing partial group is
-        stepped at the end of the epoch (``last_in_epoch``).  ``count=False`` (graph capture): hooks and step counters are the caller's."""
+        stepped at the end of the epoch (``last_in_epoch``).  ``count=False``: hooks and step counters are the caller's."""
         opt = model.optimizers()
         acc = self.accumulate_grad_batches
         if count:

@@ -374,24 +374,12 @@ class ViTEngine(Engine):
             qkv = self._linear(y1, L["qkv"], M)
             # P = softmax(Q K^T / 8) (bf16, row pitch Tp, pad columns zero; kept for the backward pass) and attn = P V in one kernel:
             # the scores themselves never reach memory
-            # LP_ATTN_RECOMPUTE=1 (round 3, opt-in): the training pass keeps (row maximum, 1 / exp-sum) per query instead of the T x T
-            # probabilities and the backward pass rebuilds them tile by tile (lp_attn_bwd_kv_lse): 10 GB less memory at C4's batch, the
-            # forward 433 -> 361 us per layer - but the key / value backward 476 -> 571 us (8 more MFMAs and 32 exponentials per tile and
-            # wave in a kernel that is already at 256 VGPRs), 3790 vs 3745 frames/s in one call (profiles/r03x_*): the stored-P pair stays
-            # the default, the pair without the tensor is for batches that do not fit.
-            recompute = keep and os.environ.get("LP_ATTN_RECOMPUTE", "0") == "1"
-            S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16) if (keep and not recompute) else None
-            st = torch.empty(B * nh * Tn, 2, device=dev, dtype=torch.float32) if recompute else None
+            S = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16) if keep else None
             attn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             # scores + probabilities x values: 2 products of B * nh * Tn * Tn * (D / nh) MACs; the training pass computes the scores twice
-            if recompute:
-                self._timed("attn_fwd_kernel", 4.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_fwd_lse(
-                    _p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(st), _p(attn), D, ops._stream()), "lp_attn_fwd_lse"),
-                    nbytes=2.0 * (3 * B * Tn * D + B * Tn * D))
-            else:
-                self._timed("attn_fwd_kernel", 4.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_fwd(
-                    _p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(S), Tp, _p(attn), D, ops._stream()), "lp_attn_fwd"),
-                    nbytes=2.0 * (3 * B * Tn * D + B * Tn * D) + (2.0 * B * nh * Tn * Tp if S is not None else 0.0))
+            self._timed("attn_fwd_kernel", 4.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_fwd(
+                _p(qkv), qs, D, 2 * D, B, nh, Tn, scale, _p(S), Tp, _p(attn), D, ops._stream()), "lp_attn_fwd"),
+                nbytes=2.0 * (3 * B * Tn * D + B * Tn * D) + (2.0 * B * nh * Tn * Tp if S is not None else 0.0))
             proj = self._linear(attn, L["proj"], M)
             x_in = x
             y2, m2, r2, x = self._ln(x, proj, L["ln2"], M)
@@ -400,7 +388,7 @@ class ViTEngine(Engine):
             check(self._lib.lp_gelu_fwd(_p(h1), h1.numel(), _p(a1), ops._stream()), "lp_gelu_fwd")
             delta = self._linear(a1, L["fc2"], M)
             if keep:
-                for nm, v in (("x_in", x_in), ("m1", m1), ("r1", r1), ("y1", y1), ("qkv", qkv), ("P", S), ("pstats", st), ("attn", attn), ("x_mid", x),
+                for nm, v in (("x_in", x_in), ("m1", m1), ("r1", r1), ("y1", y1), ("qkv", qkv), ("P", S), ("attn", attn), ("x_mid", x),
                               ("m2", m2), ("r2", r2), ("y2", y2), ("h1", h1), ("a1", a1)):
                     T[f"l{i}.{nm}"] = v
         feat, mf, rf, x = self._ln(x, delta, pl.lnf, M, drop_T=Tn)
@@ -463,15 +451,9 @@ class ViTEngine(Engine):
             check(self._lib.lp_attn_rowdot(_p(d_attn), _p(t("attn")), M, nh, D, _p(drow), ops._stream()), "lp_attn_rowdot")
             dS = torch.empty(B * nh * Tn, Tp, device=dev, dtype=torch.bfloat16)
             # dP = dO V^T, dV = P^T dO, dK = dS^T Q: 3 products of B * Tn * Tn * D MACs
-            if Pm is None:   # probabilities rebuilt from Q, K and the forward's per-query statistics: + 2 B Tn Tn D FLOP, - one pass over P
-                pst = t("pstats")
-                self._timed("attn_bwd_kv_kernel", 8.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_bwd_kv_lse(
-                    _p(qkv), qs, D, 2 * D, _p(d_attn), D, _p(pst), _p(drow), B, nh, Tn, scale, _p(dS), Tp, _p(dqkv), qs, D, 2 * D, ops._stream()),
-                    "lp_attn_bwd_kv_lse"), nbytes=2.0 * (B * nh * Tn * Tp + 6 * B * Tn * D))
-            else:
-                self._timed("attn_bwd_kv_kernel", 6.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_bwd_kv(
-                    _p(qkv), qs, 2 * D, _p(d_attn), D, _p(Pm), Tp, _p(drow), B, nh, Tn, scale, _p(dS), _p(dqkv), qs, D, 2 * D, ops._stream()),
-                    "lp_attn_bwd_kv"), nbytes=2.0 * (2 * B * nh * Tn * Tp + 6 * B * Tn * D))
+            self._timed("attn_bwd_kv_kernel", 6.0 * B * Tn * Tn * D, lambda: check(self._lib.lp_attn_bwd_kv(
+                _p(qkv), qs, 2 * D, _p(d_attn), D, _p(Pm), Tp, _p(drow), B, nh, Tn, scale, _p(dS), _p(dqkv), qs, D, 2 * D, ops._stream()),
+                "lp_attn_bwd_kv"), nbytes=2.0 * (2 * B * nh * Tn * Tp + 6 * B * Tn * D))
             # dQ = dS K
             tmpT = torch.empty(B * nh * 64, Tp, device=dev, dtype=torch.bfloat16)      # a transposed [64][Tp] head slice
             self._transpose(qkv[:, D:].data_ptr(), Tn, 64, qs, Tn * qs, 64, tmpT, Tp, *zT, B, nh)

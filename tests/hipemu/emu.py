@@ -377,22 +377,6 @@ def attn_bwd_kv(qkv_bits, ld, v_off, do_bits, ld_do, p_bits, ldp, d_rows, nb, nh
     return ds.np(), dq.np()
 
 
-def attn_fwd_lse(qkv_bits, ld, k_off, v_off, nb, nh, T, scale, ldo):
-    """-> (stats [nb*nh*T][2] = (row maximum, 1 / exp-sum), O bits [nb*T][ldo]): the training forward without the T x T tensor"""
-    qb, ob, st = Buf(qkv_bits), Z((nb * T, ldo), np.uint16), Z((nb * nh * T, 2))
-    ok(lib().lp_attn_fwd_lse(qb.p, ld, k_off, v_off, nb, nh, T, scale, st.p, ob.p, ldo, stream()))
-    return st.np(), ob.np()
-
-
-def attn_bwd_kv_lse(qkv_bits, ld, k_off, v_off, do_bits, ld_do, stats, ldp, d_rows, nb, nh, T, scale, ld_dqkv, dk_off, dv_off):
-    """lp_attn_bwd_kv with the probabilities rebuilt from Q, K and the forward's statistics -> (dS bits, dqkv bits)"""
-    qb, db, sb, dr = Buf(qkv_bits), Buf(do_bits), B(stats, np.float32), B(d_rows, np.float32)
-    ds, dq = Z((nb * nh * T, ldp), np.uint16), Z((nb * T, ld_dqkv), np.uint16)
-    ok(lib().lp_attn_bwd_kv_lse(qb.p, ld, k_off, v_off, db.p, ld_do, sb.p, dr.p, nb, nh, T, scale, ds.p, ldp, dq.p, ld_dqkv, dk_off, dv_off,
-                                stream()))
-    return ds.np(), dq.np()
-
-
 def attn_rowdot(a_bits, b_bits, rows, nh, ld):
     ab, bb, o = Buf(a_bits), Buf(b_bits), Z((rows, nh))
     ok(lib().lp_attn_rowdot(ab.p, bb.p, rows, nh, ld, o.p, stream()))

@@ -14,7 +14,7 @@ pytestmark = [needs_reference, pytest.mark.reference]
 @pytest.fixture()
 def cpu_stack(stack_backend):
     if stack_backend.type != "cpu":
-        pytest.skip("the reference tree exists in the build container only")
+        pytest.skip("host-tensor test: the product runs on the emulated kernels next to the reference's CPU modules")
     return stack_backend
 
 

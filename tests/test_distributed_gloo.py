@@ -191,7 +191,10 @@ def _engine_worker(rank, world, port, q, gather=False):
         for key, v in t_solo.t.items():
             if key.split(".")[-1] in ("mu", "iv", "m1", "v1", "m2", "v2", "m3", "v3", "md", "vd") and not torch.equal(tape.t[key], v):
                 bad.append(f"B:{key} not bit-identical")
-        if not torch.equal(eng.G, world * solo.G):   # (world is a power of two: sums of equal terms are exact)
+        # world 2: x + x is exact.  Beyond it the gradient buckets go through gloo's / RCCL's ring, whose partial sums 3x, 5x, 7x of equal
+        # terms round (the SyncBatchNorm sums above do not: lp_bn_slots_reduce adds the ranks' rows pairwise) - equal to fp32 rounding then
+        same = torch.equal(eng.G, world * solo.G) if world == 2 else torch.allclose(eng.G, world * solo.G, rtol=2e-6, atol=1e-7 * float(solo.G.abs().max()))
+        if not same:
             bad.append(f"B:summed gradient != {world} x single-process gradient (max diff {float((eng.G - world * solo.G).abs().max()):.3e})")
         sb = eng.plan.stem_bn
         if not torch.equal(eng.running_view(sb, "running_mean"), solo.running_view(sb, "running_mean")):
@@ -234,7 +237,7 @@ def _engine_worker(rank, world, port, q, gather=False):
         _, vts = vsolo.forward(images[:2], True)
         vsolo.zero_grad()
         vsolo.backward(vts, g_heat[:2])
-        if not torch.equal(vit.G, world * vsolo.G):
+        if not (torch.equal(vit.G, world * vsolo.G) if world == 2 else torch.allclose(vit.G, world * vsolo.G, rtol=2e-6, atol=1e-7 * float(vsolo.G.abs().max()))):
             bad.append(f"E:summed ViT gradient != {world} x single-process gradient (max diff {float((vit.G - world * vsolo.G).abs().max()):.3e})")
     q.put((rank, not bad, "; ".join(bad[:6])))
     dist.destroy_process_group()

@@ -44,13 +44,6 @@ def test_vit_engine_forward_backward_vs_hf(stack_backend, hidden, depth, heads, 
     check_vit_engine_vs_hf(stack_backend, hidden, depth, heads, mlp)
 
 
-def test_vit_engine_without_stored_probabilities(stack_backend, monkeypatch):
-    """LP_ATTN_RECOMPUTE=1: the training pass keeps per-query soft-max statistics instead of the T x T tensor (lp_attn_fwd_lse /
-    lp_attn_bwd_kv_lse) - the same comparison against HuggingFace ViTModel, forward and every parameter gradient"""
-    monkeypatch.setenv("LP_ATTN_RECOMPUTE", "1")
-    check_vit_engine_vs_hf(stack_backend, 128, 2, 2, 256, batch=3, size=96)
-
-
 @pytest.mark.parametrize("batch,size", [(2, 64), (3, 96)])
 def test_fp32_vit_engine_vs_hf(stack_backend, batch, size):
     """the fp32 VALIDATION executor (vit_engine_fp32.Fp32ViTEngine on csrc/vit_f32.hip + lp_f32_conv_*): the same comparison at fp32 bars"""

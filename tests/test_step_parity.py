@@ -45,6 +45,15 @@ BIG = 500                                  # keypoints per fixture from which th
 TAIL = {"fp32": dict(q=0.99, q_hi=(0.999, 1.5e-2), max=0.05), "bf16-mixed": dict(q=0.99, kp_max=1.5, frac_over=0.005)}
 # (bf16-mixed at the full batch: 99 % of the ~3000 labeled keypoints within 0.965 px, ~6000 unlabeled ones within 0.52 px - r04e - against a
 # bulk bar of 1.5 px; at most 0.5 % beyond it)
+# c4full (ViT-S at the full batch; its head had 600 Adam steps on 192 frames and fits them less tightly than c2full's - fit loss 0.060): the
+# fp32 executor localises 99 % of the keypoints within 4.6e-3 px (max 0.025 px, every scalar <= 1e-5); under bf16-mixed every scalar is
+# within 6.3e-3, the mean keypoint error is 0.18 / 0.11 px like c2full's, but ~2 % of the maps carry a second mode close enough in height
+# for bf16 to flip the soft-argmax between them (1.99 % / 1.93 % beyond 1 px, 1.75 % / 1.41 % beyond 1.5 px, max 54 px;
+# profiles/r04f_parity_device.jsonl), and a flipped map also moves its confidence (99th percentile 0.071)
+TAIL_BY_FIXTURE = {("c4full", "fp32"): dict(q=0.99, kp_max=1e-2, q_hi=(0.999, 4e-2), max=0.06),
+                   ("c4full", "bf16-mixed"): dict(q=0.95, kp_max=1.5, frac_over=0.035, conf=0.15)}
+HM_LOSS_REL = {"s64": 0.25}                # the 64 x 64 emulator-size fixture: a heat-map loss of 5.7e-5 (the head fits 10 frames almost exactly), so the
+                                           # same absolute heat-map error is 9 % (emulator) / 12 % (device) of it - r04g; every other fixture: TOL
 SCALAR_REL = {"c2full": 2.5e-2}            # temporal / pca / total of the bf16-mixed path (default 1.2e-2): measured 1.27e-2 (temporal: the handful
                                            # of two-peak maps, see above; the policy oracle itself: 2.8e-2, profiles/r04_rounding_stages.json)
 # Parameter gradients at BASELINE's real batch under the bf16-mixed POLICY itself - the reference's arithmetic rounded where the product rounds,
@@ -153,11 +162,11 @@ def _check(name, dev, precision, g):
         elif "heatmap_mse" in k or "supervised_loss" in k:
             # (target - prediction)^2 of a FITTED head: a difference of nearly equal numbers, so relative errors of the heat-map appear
             # magnified by target / residual
-            assert got[k] == pytest.approx(v, rel=t["hm_loss_rel"]), (k, got[k], v)
+            assert got[k] == pytest.approx(v, rel=t["hm_loss_rel"] if precision == "fp32" else HM_LOSS_REL.get(name, t["hm_loss_rel"])), (k, got[k], v)
         else:                                                                                  # temporal, pca, total: the bar itself
             assert got[k] == pytest.approx(v, rel=max(t["rel"], SCALAR_REL.get(name, 1.2e-2) if precision != "fp32" else 0)), (k, got[k], v)
     # (the supervised tracker's loss IS the heat-map loss of the fitted head: see above)
-    assert float(out["loss"].detach()) == pytest.approx(float(g["loss"]), rel=t["rel"] if cfg["S"] > 0 else t["hm_loss_rel"])
+    assert float(out["loss"].detach()) == pytest.approx(float(g["loss"]), rel=t["rel"] if cfg["S"] > 0 else HM_LOSS_REL.get(name, t["hm_loss_rel"]))
     # ---- what the losses saw: keypoints (frame px and model px), confidences - on the maps the reference itself localises
     for meth, tag in (("get_loss_inputs_labeled", "lab"), ("get_loss_inputs_unlabeled", "unl")):
         if meth not in seen:
@@ -178,7 +187,7 @@ def _check(name, dev, precision, g):
                     assert float((d[key] - w).abs().max()) <= 0.3, (tag, key)
                 err = (d[key] - w).abs()[ok2]
                 REPORT.append((name, precision, tag, key, round(float(err.max()), 5), round(float(err.mean()), 5)))
-                tail = TAIL[precision] if err.numel() >= BIG else None
+                tail = TAIL_BY_FIXTURE.get((name, precision), TAIL[precision]) if err.numel() >= BIG else None
                 bulk = float(err.quantile(tail["q"])) if tail else float(err.max())
                 kp_max = tail.get("kp_max", t["kp_max"]) if tail else t["kp_max"]
                 assert bulk <= kp_max and float(err.mean()) <= t["kp_mean"], (tag, key, bulk, float(err.max()), float(err.mean()))
@@ -192,7 +201,8 @@ def _check(name, dev, precision, g):
                     pol = (g.t(f"bf16ref_{tag}_{key}") - w).abs()[ok2]
                     assert float(err.mean()) <= 2.0 * float(pol.mean()) + 0.02, (tag, key, float(err.mean()), float(pol.mean()))
         cerr = (d["confidences"] - g.t(f"{tag}_confidences")).abs()[ok] - t["rel"] * g.t(f"{tag}_confidences").abs()[ok]
-        assert float(cerr.quantile(0.99) if cerr.numel() >= BIG // 2 else cerr.max()) <= t["conf"], (tag, "confidences", float(cerr.max()))
+        conf_bar = TAIL_BY_FIXTURE.get((name, precision), {}).get("conf", t["conf"])
+        assert float(cerr.quantile(0.99) if cerr.numel() >= BIG // 2 else cerr.max()) <= conf_bar, (tag, "confidences", float(cerr.max()))
         flat = d["heatmaps_pred"].reshape(peak.shape[0], peak.shape[1], -1)
         prel = ((flat.max(-1).values - peak).abs() / peak)[ok]
         assert float(prel.quantile(0.99) if prel.numel() >= BIG // 2 else prel.max()) <= t["peak"], (tag, "peak height", float(prel.max()))

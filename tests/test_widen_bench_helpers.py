@@ -148,6 +148,30 @@ def test_bench_main_hands_over_to_self_launch_without_a_launcher(monkeypatch):
     assert "WORLD_SIZE=2" in str(e.value.code) and len(calls) == 1
 
 
+def test_bench_gpus_8_launcher_command(monkeypatch, capsys):
+    """`python bench.py --gpus 8 --syncbn-gather` with no launcher around it (what the driver's SCALE run may type): the command it would run -
+    torch.distributed.run, one node, 8 processes, rendezvous on 127.0.0.1, this script with the same flags - and the environment of its
+    ranks (dmabuf IPC for RCCL, a thread budget per rank, the SyncBatchNorm transport), checked without starting anything"""
+    import os
+    import sys
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LP_SYNCBN_GATHER", "OMP_NUM_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LP_BENCH_DRY_RUN", "1")
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "3", "--syncbn-gather"]
+    with pytest.raises(SystemExit) as e:
+        bench.main(argv)
+    assert e.value.code == 0
+    rec = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    cmd = rec["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv) - 1:] == [os.path.abspath(bench.__file__)] + argv
+    assert rec["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and rec["env"]["LP_SYNCBN_GATHER"] == "1"
+    assert int(rec["env"]["OMP_NUM_THREADS"]) == max(1, (os.cpu_count() or 8) // 8)
+    monkeypatch.delenv("LP_SYNCBN_GATHER", raising=False)
+
+
 def _free_port() -> int:
     import socket
 
