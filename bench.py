@@ -174,7 +174,7 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "re
 
 def pmc_traffic():
     """Average HBM bytes per convolution launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
-    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r03_pmc.sh -> profiles/r03_pmc_traffic.json
+    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r04_final.sh -> profiles/r04_pmc_traffic.json
     via profiles/summarize_pmc.py).  The counters need rocprofv3 around the process, so this is the committed measurement of the same
     workload, not a live one (``algorithmic_bytes_per_launch`` next to it IS computed live) - and it is only reported when it was taken
     on THESE kernels: the file records a digest of the convolution sources, and a file whose digest differs from the tree's is refused
@@ -187,7 +187,7 @@ def pmc_traffic():
                 h.update(fh.read())
     except OSError:
         return None, "kernel sources not found"
-    name = "r03_pmc_traffic.json"
+    name = "r04_pmc_traffic.json"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             rec = json.load(fh)
@@ -708,7 +708,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
     ap.add_argument("--no-sync-bn", action="store_true", help="N > 1: per-rank BatchNorm statistics (the reference sets sync_batchnorm=True, train.py:427; A/B only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--syncbn-gather", action="store_true", help="N > 1: SyncBatchNorm messages as ONE all-gather + an ordered add of the ranks' rows "
-                    "(lp_bn_slots_reduce) instead of an all-reduce (= LP_SYNCBN_GATHER=1; the A/B the first 8-GPU call decides)")
+                    "(int64 fixed-point sums) instead of an all-reduce (= LP_SYNCBN_GATHER=1; the A/B the first 8-GPU call decides)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit: the reference's own "
                     "step when its modules are present (/root/reference, or oracle/_ref on the GPU box), the restated port otherwise")
     args = ap.parse_args(argv)

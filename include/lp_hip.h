@@ -241,14 +241,25 @@ int lp_attn_rowdot(const void* a_bf16, const void* b_bf16, int rows, int nh, int
 int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int ldv, const void* p_bf16, const float* d_rows, int d_row_stride,
                     long long d_b, long long d_h, float scale, void* ds_bf16, int ldc, int M, int N, int K, const lp_gemm_batch* batch,
                     lp_stream_t stream);
+/* A BatchNorm sum in FIXED POINT (round 4): value = hi * 2^-12 + lo * 2^-60.  The reductions over rows that are spread across workgroups -
+ * the sums the convolution store passes take, lp_bn_pool_bwd_reduce - split each workgroup's fp32 partial sum t into hi = rint(t 2^12),
+ * lo = rint((t - hi 2^-12) 2^60) and add both with 64-bit INTEGER atomics (lp_bn_stats / lp_bn_bwd_reduce: per-workgroup fp32 rows added in
+ * a fixed order, then one such addition per channel).  Integer addition commutes, so
+ * the totals do not depend on the order in which workgroups arrive: a training step repeats bit for bit (the reference is deterministic on
+ * a fixed seed, models/heatmap_tracker.py:69-70; rounds 2 - 3 used fp32 atomics and did not).  |sum| < 2^50; a partial of magnitude
+ * >= 1e-10 is represented exactly, smaller ones to 4e-19.  Buffers are accumulated into: zero them first.  SyncBatchNorm all-reduces the
+ * integers (SUM is exact).  lp_bn_finalize / lp_bn_bwd_apply / lp_bn_pool_bwd_apply read them. */
+typedef struct lp_fxsum {
+    long long hi, lo;
+} lp_fxsum;
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
- * for them (torch.nn.BatchNorm2d training forward / backward).  Every persistent workgroup leaves the
- * column sums of the tiles it walked in one row of `workspace` (lp_conv_bn_workspace_bytes); a second small kernel adds the rows
- * into `sums` in workgroup order (bit-reproducible; see lp_bn_fuse.defer_reduce).
+ * for them (torch.nn.BatchNorm2d training forward / backward).  Every persistent workgroup adds the
+ * column sums of the tiles it walked into `sums` (fixed point, integer atomics: see lp_fxsum).
  *   lp_conv_fwd_bn / lp_stem_fwd_bn:  sums (2,Co) += [sum z, sum z^2] of the bf16 output z  (== lp_bn_stats on it);
- *                                     only sums / workspace / workspace_bytes are read.
+ *                                     only sums / seg_images are read.
  *   lp_conv_dgrad_bn:                 dx is the gradient of a = relu(BN(z) [+ residual]); sums (2,Ci) += [sum dx, sum dx*xhat]
- *                                     (== lp_bn_bwd_reduce), dbeta_acc / dgamma_acc (optional) receive the same totals.
+ *                                     (== lp_bn_bwd_reduce; the BatchNorm's d beta / d gamma ARE these sums: lp_bn_bwd_apply adds them
+ *                                     into the parameter gradients).
  *                                     mask_from_z = 1 recomputes the ReLU mask as bf16(gamma*invstd*(z-mean)+beta) > 0 (layers
  *                                     without a residual branch; relu_mask must then be NULL), otherwise pass relu_mask or
  *                                     bn->relu_bits. */
@@ -260,25 +271,13 @@ typedef struct lp_bn_fuse {
     const float* beta;    /* (C,) bias,   mask_from_z only */
     int mask_from_z;
     const void* relu_bits; /* dgrad only, optional: 1-bit ReLU mask written by lp_bn_apply (then relu_mask must be NULL) */
-    float* sums;          /* (2,C) fp32, accumulated into (zero first) */
-    float* dbeta_acc;     /* (C,) or NULL */
-    float* dgamma_acc;    /* (C,) or NULL */
-    void* workspace;
-    size_t workspace_bytes;
+    lp_fxsum* sums;       /* (2,C) fixed-point sums, accumulated into (zero first) */
     /* Two BatchNorm segments in ONE launch: images [0, seg_images) and [seg_images, B) keep separate batch statistics - the labeled
      * and the unlabeled frames of a semi-supervised step, which the reference normalises in two forward calls (models/base.py:682-695).
-     * Then sums is (2 segments, 2, C), mean / invstd are (2, C); dbeta_acc / dgamma_acc receive both segments.  seg_images times the
+     * Then sums is (2 segments, 2, C), mean / invstd are (2, C).  seg_images times the
      * launch's rows per image must be a multiple of 128 (LP_ERR_UNSUPPORTED otherwise: run the segments as two calls).  0 = one segment. */
     int seg_images;
-    /* Bit-reproducible sums (round 4).  The store passes do not add their sums into `sums` with atomics: every persistent workgroup leaves
-     * ONE row of partial sums in `workspace` ([slot_rows][segments][2][C]) and an ordered reduction (stats_slots_reduce_kernel) adds the
-     * rows in workgroup order into sums / dbeta_acc / dgamma_acc before the call returns its stream.  defer_reduce = 1 (forward entry
-     * points): skip that reduction - the caller hands `workspace` and the `slot_rows` the call reports back (OUT field) to
-     * lp_bn_finalize_slots, which reduces and finalizes in one launch.  LP_STATS_ATOMIC=1 (A/B timing only) brings the atomics back. */
-    int defer_reduce;
-    int slot_rows;        /* OUT: rows of partial sums the call left in workspace (0 in the atomic form) */
 } lp_bn_fuse;
-size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad);
 /* Inference (predict_step, models/heatmap_tracker.py:155-191; eval-mode nn.BatchNorm2d uses its running statistics): the BatchNorm
  * after a convolution is folded into it once per set of weights - lp_bn_fold: w_bf16[co][:] = bf16(w[co][:] * a[co]),
  * bias[co] = beta[co] - running_mean[co] * a[co], a = gamma / sqrt(running_var + eps) - and the layer becomes ONE launch,
@@ -289,10 +288,10 @@ int lp_bn_fold(const float* w, const float* gamma, const float* beta, const floa
                int Co, int per_co, void* w_bf16, float* bias, lp_stream_t stream);
 int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, const void* residual_bf16, int relu,
                     void* out_bf16, lp_stream_t stream);
-int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn, lp_stream_t stream);
-int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn, lp_stream_t stream);
+int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
+int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
 int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
-                     void* dx_bf16, lp_bn_fuse* bn, lp_stream_t stream);
+                     void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream);
 /* dw: fp32 [Co][R][S][Ci], accumulated into (zero it first); split_hint <= 0 picks the pixel split.  The pixel slices leave
  * partial tiles in `workspace` (lp_conv_wgrad_workspace_bytes) and a second kernel sums them in a fixed order: deterministic. */
 size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint);
@@ -364,41 +363,43 @@ int lp_f32_attn_bwd(const float* qkv, int ld, int k_off, int v_off, const float*
  * PixelShuffle(2), input layout.  torchvision Bottleneck semantics; called from
  * `self.backbone(images)` (models/base.py:398) and HeatmapHead.forward (models/heads/heatmap.py:44,208).
  * ------------------------------------------------------------------------------------------------------ */
-/* sums (2,C) fp32, accumulated into (zero first): [sum x, sum x^2] over the M rows.  SyncBatchNorm = all-reduce it.
- * The reductions over rows (this one, lp_bn_bwd_reduce, lp_bn_pool_bwd_reduce) are bit-reproducible since round 4: every workgroup leaves
- * its partial sums in one row of `workspace` (lp_bn_reduce_workspace_bytes / lp_bn_pool_bwd_workspace_bytes) and a second launch adds the
- * rows in workgroup order - no fp32 atomics. */
+/* sums (2,C) fixed point (lp_fxsum), accumulated into (zero first): [sum x, sum x^2] over the M rows.  SyncBatchNorm = all-reduce it
+ * (int64 SUM).  `workspace` (lp_bn_reduce_workspace_bytes; also for lp_bn_bwd_reduce): one fp32 row of partial sums per workgroup, added in
+ * a fixed order by a second launch - up to 1024 workgroups finish together here, too many for atomics on one address each. */
 size_t lp_bn_reduce_workspace_bytes(int M, int C);
-int lp_bn_stats(const void* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
-/* sums (nseg, 2, C) += the rows of slots ([rows][nseg][2][C] fp32) added in row order; dbeta_acc / dgamma_acc (optional) += component
- * 0 / 1 over the segments.  The ordered reduction the fused and stand-alone entry points run internally; SyncBatchNorm's one-shot
- * exchange (every rank's sums all-gathered into per-rank rows) adds the ranks in rank order with it. */
-int lp_bn_slots_reduce(const void* slots, int rows, int nseg, int C, float* sums, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
-/* mean / invstd (and the running-statistics update, segment by segment) straight from the per-workgroup rows a fused forward entry point
- * left with lp_bn_fuse.defer_reduce = 1 (`slots` = its workspace, `slot_rows` as it reported): the ordered reduction and lp_bn_finalize[2]
- * in ONE launch.  nseg = 1 or 2 (count1 ignored for 1); sums_out (optional) receives the raw (nseg, 2, C) totals. */
-int lp_bn_finalize_slots(const void* slots, int slot_rows, int nseg, float count0, float count1, int C, float eps, float momentum, float* mean,
-                         float* invstd, float* running_mean, float* running_var, float* sums_out, lp_stream_t stream);
-int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
+int lp_bn_stats(const void* x, int M, int C, lp_fxsum* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
+/* dst[i] += value of sums[i], i < n (fixed-point totals as fp32) */
+int lp_fxsum_accumulate(const lp_fxsum* sums, int n, float* dst, lp_stream_t stream);
+int lp_bn_finalize(const lp_fxsum* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, lp_stream_t stream);
+/* the same from plain fp32 [sum, sum of squares] (the fp32 validation executor: lp_f32_bn_stats_ordered) */
+int lp_bn_finalize_f32(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
+                       float* running_mean, float* running_var, lp_stream_t stream);
 /* two segments at once: sums (2,2,C), mean / invstd (2,C); the running statistics take segment 0's update, then segment 1's - the
  * order of the reference's two forward calls (labeled, then unlabeled: models/base.py:682-695) */
-int lp_bn_finalize2(const float* sums, float count0, float count1, int C, float eps, float momentum, float* mean, float* invstd,
+int lp_bn_finalize2(const lp_fxsum* sums, float count0, float count1, int C, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, lp_stream_t stream);
-/* relu_bits (optional, M*C/8 bytes): bit q of byte i = (y[8*i + q] > 0): a 16x smaller ReLU mask for the backward pass */
+/* y = [relu]((x - mean) * invstd * gamma + beta [+ residual]); relu_bits (optional, M*C/8 bytes): bit q of byte i = (y[8*i + q] > 0),
+ * a 16x smaller ReLU mask for the backward pass */
 int lp_bn_apply(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                 int relu, int M, int C, void* y, void* relu_bits, lp_stream_t stream);
 /* both BatchNorm segments of a joint pass (lp_bn_fuse.seg_images) in ONE launch: rows [0, seg_rows) use row 0 of mean / invstd (2, C)
  * [and of sums (2, 2, C), with count0], the other rows use row 1 [count1] */
 int lp_bn_apply_seg(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                     int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
-int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
-                        const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres, lp_stream_t stream);
-/* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL); dbeta/dgamma accumulate too */
+/* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL) */
 int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
-                     float* sums, float* dbeta_acc, float* dgamma_acc, void* workspace, size_t workspace_bytes, lp_stream_t stream);
+                     lp_fxsum* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
+/* dx = gamma * invstd * (dz - sum(dz)/N - xhat * sum(dz*xhat)/N) [, dres = dz].  `sums`: the totals the two correction terms use - the
+ * buffer after the SyncBatchNorm all-reduce, with count = rows x world size - or NULL: no batch-statistics terms (eval-mode BatchNorm is a
+ * fixed affine map).  `sums_local` (this rank's sums, before any exchange; may equal sums) + dbeta_acc / dgamma_acc (optional): the
+ * BatchNorm's parameter gradients d beta += sum dz, d gamma += sum dz*xhat over the segments, added by one thread per channel. */
 int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
-                    const float* sums, float count, int M, int C, void* dx, void* dres, lp_stream_t stream);
+                    const lp_fxsum* sums, float count, int M, int C, void* dx, void* dres, const lp_fxsum* sums_local, float* dbeta_acc,
+                    float* dgamma_acc, lp_stream_t stream);
+int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
+                        const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
+                        const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
 /* 3x3 / stride 2 / pad 1; argmax_u8 (B,Ho,Wo,C) records the winning tap (first maximum, ATen tie rule) for the backward gather */
 int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream);
 int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
@@ -406,15 +407,14 @@ int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi,
  * bn1, relu, maxpool; reference models/backbones/factory.py:322-348).  Forward = lp_bn_apply(relu) -> lp_maxpool_fwd, bit for bit
  * (each tap is rounded to bf16 as lp_bn_apply would have stored it).  Backward: the activation's gradient is rebuilt on the fly from
  * the pooled gradient dy, the arg-max bytes and z (ReLU gate recomputed from z): lp_bn_pool_bwd_reduce leaves [sum g, sum g * xhat]
- * in sums[2][C] (+= d beta / d gamma), lp_bn_pool_bwd_apply writes d z. */
+ * in sums[2][C] (fixed point), lp_bn_pool_bwd_apply writes d z (and adds the sums into d beta / d gamma, as lp_bn_bwd_apply does). */
 int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta, int B, int Hi, int Wi,
                            int C, void* y, void* argmax_u8, lp_stream_t stream);
-size_t lp_bn_pool_bwd_workspace_bytes(int B, int Hi, int Wi, int C);
 int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
-                          const float* beta, int B, int Hi, int Wi, int C, float* sums, float* dbeta_acc, float* dgamma_acc,
-                          void* workspace, size_t workspace_bytes, lp_stream_t stream);
+                          const float* beta, int B, int Hi, int Wi, int C, lp_fxsum* sums, lp_stream_t stream);
 int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd, const float* gamma,
-                         const float* beta, const float* sums, float count, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);
+                         const float* beta, const lp_fxsum* sums, float count, int B, int Hi, int Wi, int C, void* dx,
+                         const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
 int lp_images_to_nhwc4(const float* images_nchw, int B, int H, int W, void* out_bf16, lp_stream_t stream);
 /* (B,h,w,4*c_out) -> (B,2h,2w,c_out) stored with channel pitch ld >= c_out (pad channels untouched); inverse = 1 maps the
  * gradient (pitch ld) back */

@@ -34,9 +34,7 @@ class ConvGeom(C.Structure):
 
 class BnFuse(C.Structure):
     _fields_ = [("z", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("mask_from_z", C.c_int), ("relu_bits", C.c_void_p), ("sums", C.c_void_p), ("dbeta_acc", C.c_void_p), ("dgamma_acc", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("seg_images", C.c_int), ("defer_reduce", C.c_int),
-                ("slot_rows", C.c_int)]
+                ("mask_from_z", C.c_int), ("relu_bits", C.c_void_p), ("sums", C.c_void_p), ("seg_images", C.c_int)]
 
 
 class FrameNorm(C.Structure):
@@ -95,7 +93,6 @@ PROTOTYPES = {
     "lp_attn_bwd_kv": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, C.c_float, _P, _P, _I, _I, _I, _P]),
     "lp_attn_rowdot": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "lp_attn_dscores": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_float, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
-    "lp_conv_bn_workspace_bytes": (_Z, [C.POINTER(ConvGeom), _I]),
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_last_kernel": (_I, []),
     "lp_decode_set_prune": (_I, [_I]),
@@ -110,21 +107,20 @@ PROTOTYPES = {
     "lp_stem_wgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _I, _P, _Z, _P]),
     "lp_bn_reduce_workspace_bytes": (_Z, [_I, _I]),
     "lp_bn_stats": (_I, [_P, _I, _I, _P, _P, _Z, _P]),
-    "lp_bn_slots_reduce": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
-    "lp_bn_finalize_slots": (_I, [_P, _I, _I, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "lp_bn_finalize": (_I, [_P, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "lp_fxsum_accumulate": (_I, [_P, _I, _P, _P]),
+    "lp_bn_finalize_f32": (_I, [_P, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_finalize2": (_I, [_P, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "lp_bn_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "lp_bn_bwd_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P]),
-    "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
+    "lp_bn_bwd_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _Z, _P]),
+    "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P]),
     "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "lp_bn_relu_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "lp_bn_pool_bwd_workspace_bytes": (_Z, [_I, _I, _I, _I]),
-    "lp_bn_pool_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    "lp_bn_pool_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _P, _P]),
+    "lp_bn_pool_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "lp_bn_pool_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "lp_images_to_nhwc4": (_I, [_P, _I, _I, _I, _P, _P]),
     "lp_pixel_shuffle": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "lp_vit_patchify": (_I, [_P, _I, _I, _I, _I, _P, _P]),

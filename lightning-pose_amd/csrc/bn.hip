@@ -34,16 +34,18 @@ __device__ __forceinline__ u16x8 load_stream8(const unsigned short* p) {
 // ---- per-channel sums over rows: sums[0][c] += sum a, sums[1][c] += sum a*b -------------------------------------
 // MODE 0: plain statistics (sum x, sum x^2)
 // MODE 1: BN backward reductions: dz = relu-masked dy;  sum dz, sum dz * xhat
-// Grid-stride over rows with register accumulators (4 independent 16-B loads in flight per lane), ONE LDS reduction; every workgroup
-// leaves its 2 C partial sums in ITS row of `slots` ([gridDim.x][2][C]) and stats_slots_reduce_kernel adds the rows in workgroup order:
-// bit-reproducible totals (round 4; before, 2 C fp32 atomics per workgroup in arrival order).
+// Grid-stride over rows with register accumulators (4 independent 16-B loads in flight per lane) and ONE LDS reduction per workgroup, which
+// leaves its 2 C partial sums in ITS row of `rows` ([gridDim.x][2][C] fp32); rows_reduce_kernel adds the rows in a fixed order and adds the
+// totals into the fixed-point sums.  (Up to 1024 workgroups finish together here: adding their sums straight into the totals - fp32
+// atomics until round 3, fx_add in a first version of round 4 - serialises ~26 ns per atomic and address, 27 / 52 us of a 110 us launch;
+// the convolution store passes, <= 256 workgroups finishing at different times, do use fx_add.  profiles/r04m_*)
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Yout,
                                                         const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int M, int C,
-                                                        float* __restrict__ slots) {
+                                                        float* __restrict__ rows) {
     __shared__ float red[2][256][8];
-    float* const row = slots + (size_t)blockIdx.x * 2 * C;
+    float* const row = rows + (size_t)blockIdx.x * 2 * C;
     const int chunks = C >> 3;                       // 16-B chunks per row
     const int cpb = chunks < 256 ? chunks : 256;     // chunks handled per block pass
     const int lanes_r = 256 / cpb;                   // row lanes
@@ -114,18 +116,60 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const unsigned short* __
     }
 }
 
+// sums[comp][c] += the total over the partial-sum rows ([nrows][2][C] fp32) of (comp, c), added in an order that depends on nothing but
+// nrows: 32 interleaved chains (rows g, g + 32, ...) per element, joined by a fixed pairwise tree.  One 256-thread workgroup covers the 16
+// channels [c0, c0 + 16) of both components with float4 loads, 8 in flight per thread (the rows were written all over the chip: every
+// load is an L2 miss, and this launch sits between a reduction and the BatchNorm pass that waits for it).
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ rows, int nrows, int C, lp_fxsum* __restrict__ sums) {
+    __shared__ float red[32][32];
+    const int c0 = blockIdx.x * 16;
+    const int pq = (int)threadIdx.x % 8, rg = (int)threadIdx.x / 8;   // pq: (component, quad of channels); rg: chain
+    const float* src = rows + (pq >> 2) * C + c0 + (pq & 3) * 4;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (c0 + (pq & 3) * 4 < C) {   // (C is a multiple of 8: the last workgroup may cover 8 channels only)
+        constexpr int U = 8;
+        for (int r = rg; r < nrows; r += 32 * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ru = r + u * 32;
+                v[u] = ru < nrows ? *reinterpret_cast<const f32x4*>(src + (size_t)ru * 2 * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) t0 += v[u][0], t1 += v[u][1], t2 += v[u][2], t3 += v[u][3];
+        }
+    }
+    red[rg][pq * 4 + 0] = t0, red[rg][pq * 4 + 1] = t1, red[rg][pq * 4 + 2] = t2, red[rg][pq * 4 + 3] = t3;
+    __syncthreads();
+    if ((int)threadIdx.x < 32) {
+        float u[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) u[i] = red[i][threadIdx.x];
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+            for (int i = 0; i < w; ++i) u[i] += u[i + w];
+        const int comp = (int)threadIdx.x >> 4, c = c0 + ((int)threadIdx.x & 15);
+        if (c < C) fx_add(&sums[(size_t)comp * C + c], u[0]);
+    }
+}
+
+__device__ __forceinline__ float sum_value(const float* p) { return *p; }          // (fp32 sums: the fp32 validation executor's)
+__device__ __forceinline__ float sum_value(const lp_fxsum* p) { return fx_value(p); }
+
 // mean / invstd from [sum, sumsq]; running statistics updated with torch's momentum rule (unbiased variance)
 // `nseg` segments ([seg][2][C] sums -> [seg][C] moments), running statistics updated segment by segment in order
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count0, float count1, int nseg, int C, float eps, float momentum,
+template <typename SumT>
+__global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, float count1, int nseg, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     for (int sg = 0; sg < nseg; ++sg) {
         const float count = sg == 0 ? count0 : count1;
-        const float* sm = sums + (size_t)sg * 2 * C;
-        const float mu = sm[c] / count;
-        float var = sm[C + c] / count - mu * mu;
+        const SumT* sm = sums + (size_t)sg * 2 * C;
+        const float mu = sum_value(&sm[c]) / count;
+        float var = sum_value(&sm[C + c]) / count - mu * mu;
         var = fmaxf(var, 0.f);
         mean[sg * C + c] = mu;
         invstd[sg * C + c] = 1.f / sqrtf(var + eps);
@@ -133,49 +177,6 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count0,
             const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-        }
-    }
-}
-
-// sums[pair][c] += the slot rows' totals (lp_common.h: slots_totals); d beta / d gamma accumulators += component 0 / 1 over the segments.
-// One thread per address for every read-modify-write: deterministic.
-__global__ __launch_bounds__(256) void stats_slots_reduce_kernel(const float* __restrict__ slots, int rows, int C, int nseg,
-                                                                 float* __restrict__ sums, float* __restrict__ acc0, float* __restrict__ acc1) {
-    __shared__ float red[32][64];
-    const int npairs = nseg * 2, c0 = blockIdx.x * 16, tid = threadIdx.x;
-    slots_totals(slots, rows, C, npairs, c0, red);
-    if (tid < npairs * 16 && c0 + (tid & 15) < C) sums[(size_t)(tid >> 4) * C + c0 + (tid & 15)] += red[0][tid];
-    if (tid < 32 && c0 + (tid & 15) < C) {
-        const int comp = tid >> 4, c = tid & 15;
-        float* accp = comp == 0 ? acc0 : acc1;
-        if (accp != nullptr) accp[c0 + c] += nseg == 2 ? red[0][comp * 16 + c] + red[0][(2 + comp) * 16 + c] : red[0][comp * 16 + c];
-    }
-}
-
-// bn_finalize_kernel fed by the slot rows directly (the forward pass without SyncBatchNorm: no separate reduction launch); `sums_out`
-// (optional) receives the raw [segment][2][C] totals
-__global__ __launch_bounds__(256) void bn_finalize_slots_kernel(const float* __restrict__ slots, int rows, float count0, float count1, int nseg,
-                                                                int C, float eps, float momentum, float* __restrict__ mean,
-                                                                float* __restrict__ invstd, float* __restrict__ running_mean,
-                                                                float* __restrict__ running_var, float* __restrict__ sums_out) {
-    __shared__ float red[32][64];
-    const int npairs = nseg * 2, c0 = blockIdx.x * 16, tid = threadIdx.x;
-    slots_totals(slots, rows, C, npairs, c0, red);
-    if (sums_out != nullptr && tid < npairs * 16 && c0 + (tid & 15) < C) sums_out[(size_t)(tid >> 4) * C + c0 + (tid & 15)] = red[0][tid];
-    if (tid < 16 && c0 + tid < C) {
-        const int c = c0 + tid;
-        for (int sg = 0; sg < nseg; ++sg) {   // (the arithmetic of bn_finalize_kernel, expression for expression)
-            const float count = sg == 0 ? count0 : count1;
-            const float mu = red[0][(2 * sg) * 16 + tid] / count;
-            float var = red[0][(2 * sg + 1) * 16 + tid] / count - mu * mu;
-            var = fmaxf(var, 0.f);
-            mean[sg * C + c] = mu;
-            invstd[sg * C + c] = 1.f / sqrtf(var + eps);
-            if (running_mean != nullptr) {
-                const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-            }
         }
     }
 }
@@ -246,32 +247,91 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
     }
 }
 
+// d beta[c] += sum over the segments of local[seg][0][c], d gamma[c] += ... [1][c]: the parameter gradients of a BatchNorm ARE its two backward
+// sums (of THIS rank: `local` is the buffer before any SyncBatchNorm exchange).  Done by the kernel that consumes the sums, one thread of the
+// whole grid per channel (plain read-modify-write, a single pass for any grid of C / 256 workgroups or more: a workgroup that did all C
+// channels alone started its walk ~10 us late and the launch ended that much later, profiles/r04p_*) - now that the sums no longer travel
+// through per-address fp32 atomics.
+__device__ __forceinline__ void bn_param_grads(const lp_fxsum* __restrict__ local, int nseg, int C, float* __restrict__ dbeta,
+                                               float* __restrict__ dgamma) {
+    if (local == nullptr) return;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float b = 0.f, g = 0.f;
+        for (int sg = 0; sg < nseg; ++sg) {
+            b += fx_value(&local[(size_t)sg * 2 * C + c]);
+            g += fx_value(&local[(size_t)sg * 2 * C + C + c]);
+        }
+        if (dbeta != nullptr) dbeta[c] += b;
+        if (dgamma != nullptr) dgamma[c] += g;
+    }
+}
+
 // dx = gamma * invstd * (dz - sum(dz)/N - xhat * sum(dz*xhat)/N);  dz = relu-masked dy; optionally dz is also
 // written out (gradient of the residual branch).  Same walk as bn_apply_kernel: per-channel terms in registers.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
+// `sums`: the (possibly all-reduced) totals the correction terms use, nullptr = no batch-statistics terms (eval-mode BatchNorm: a fixed
+// affine map); `local` / dbeta / dgamma: see bn_param_grads.
+constexpr int kBnBwdMaxC = 2048;   // widest BatchNorm bn_bwd_apply_kernel takes (ResNet-50's layer4): 32 KB of LDS for its correction terms
+// (launch bounds: 5 waves per SIMD = 96 VGPRs, as before the fixed-point sums; the allocator spills two values, outside the chunk loop;
+// without the bound: 102 VGPRs = 4 waves, the same speed - profiles/r04o_*)
+__global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
                                                            const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, float inv_count, size_t n_total, int C,
+                                                           const lp_fxsum* __restrict__ sums, float inv_count, size_t n_total, int C,
                                                            unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES,
-                                                           size_t seg_chunk, float inv_count1) {
+                                                           size_t seg_chunk, float inv_count1, const lp_fxsum* __restrict__ local,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
     // (segments as in bn_apply_kernel: mean / invstd rows of C, sums rows of 2 C, one 1 / count per segment)
     const int chunks = C >> 3;
     const size_t stride = (size_t)gridDim.x * 256;
     const size_t q0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(q0 % chunks) * 8;
     const int nseg = seg_chunk > 0 ? 2 : 1;
-    for (int sg = 0; sg < nseg; ++sg) {
-    const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
-    size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
-    const float ic = sg == 0 ? inv_count : inv_count1;
+    // The correction terms sum / count of the whole launch ([segment][2][C], C <= kBnBwdMaxC: host-checked) are converted from fixed point
+    // ONCE per workgroup, a few per thread, into LDS.  Converted per lane (16 values per segment, four registers each while in flight) the
+    // kernel needed 130 instead of 94 VGPRs = 3 instead of 5 waves per SIMD and the step lost 2.6 ms (profiles/r04m_*).  nullptr: zeros.
+    __shared__ float kterm[2 * 2 * kBnBwdMaxC];
+    bn_param_grads(local, nseg, C, dbeta, dgamma);
+    __builtin_amdgcn_sched_barrier(0);   // (keeps the parameter-gradient code's registers out of the walk's allocation)
+    // segment 0's per-channel terms are requested BEFORE the conversion and its barrier, so the workgroup waits one memory latency, not two
     float mu[8], is[8], ga[8], k0[8], k1[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        mu[i] = mean[sg * C + c + i];
-        is[i] = invstd[sg * C + c + i];
+        mu[i] = mean[c + i];
+        is[i] = invstd[c + i];
+        ga[i] = gamma[c + i];
+    }
+    {
+        constexpr int UC = 8;   // conversions in flight per thread (C = 2048, two segments: 32 per thread = 4 round trips to L2)
+        const int n = nseg * 2 * C;
+        for (int e0 = threadIdx.x; e0 < n; e0 += 256 * UC) {
+            long long hi[UC], lo[UC];
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                const int e = e0 + 256 * u;
+                hi[u] = (sums != nullptr && e < n) ? sums[e].hi : 0;
+                lo[u] = (sums != nullptr && e < n) ? sums[e].lo : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                const int e = e0 + 256 * u;
+                const lp_fxsum v{hi[u], lo[u]};
+                if (e < n) kterm[e] = fx_value(&v) * (e < 2 * C ? inv_count : inv_count1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int sg = 0; sg < nseg; ++sg) {
+    const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
+    size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (sg > 0) {
+            mu[i] = mean[sg * C + c + i];
+            is[i] = invstd[sg * C + c + i];
+        }
         ga[i] = gamma[c + i] * is[i];
-        k0[i] = sums[sg * 2 * C + c + i] * ic;
-        k1[i] = sums[sg * 2 * C + C + c + i] * ic;
+        k0[i] = kterm[sg * 2 * C + c + i];
+        k1[i] = kterm[sg * 2 * C + C + c + i];
     }
     constexpr int U = 2;
     for (; q < n_chunks; q += U * stride) {
@@ -456,9 +516,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
                                                                  const unsigned short* __restrict__ Z, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                                                                 float* __restrict__ slots) {
+                                                                 lp_fxsum* __restrict__ sums) {
     __shared__ float red[2][256][8];
-    float* const srow = slots + (size_t)blockIdx.x * 2 * C;   // this workgroup's partial sums (added in workgroup order afterwards)
     const int chunks = C >> 3, lanes_r = 256 / chunks;
     const int ch = threadIdx.x % chunks, rl = threadIdx.x / chunks;
     float mu[8], is[8], sc[8], be[8], s0[8], s1[8];
@@ -501,8 +560,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
             t1 += red[1][q * chunks + pc][pi];
         }
         const int cc = pc * 8 + pi;
-        srow[cc] = t0;
-        srow[C + cc] = t1;
+        fx_add(&sums[cc], t0);
+        fx_add(&sums[C + cc], t1);
     }
 }
 
@@ -510,9 +569,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
                                                                 const unsigned short* __restrict__ Z, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, const float* __restrict__ sums,
+                                                                const float* __restrict__ beta, const lp_fxsum* __restrict__ sums,
                                                                 float inv_count, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                                                                unsigned short* __restrict__ DX) {
+                                                                unsigned short* __restrict__ DX, const lp_fxsum* __restrict__ local,
+                                                                float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    bn_param_grads(local, 1, C, dbeta, dgamma);
     const int chunks = C >> 3, ppi = 256 / chunks;   // row walk as in bn_relu_maxpool_fwd_kernel
     const int ch = threadIdx.x % chunks, pl = threadIdx.x / chunks;
     float mu[8], is[8], sc[8], be[8], ga[8], k0[8], k1[8];
@@ -524,8 +585,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned c
         ga[i] = gamma[c] * is[i];
         sc[i] = ga[i];
         be[i] = beta[c];
-        k0[i] = sums[c] * inv_count;
-        k1[i] = sums[C + c] * inv_count;
+        k0[i] = sums != nullptr ? fx_value(&sums[c]) * inv_count : 0.f;
+        k1[i] = sums != nullptr ? fx_value(&sums[C + c]) * inv_count : 0.f;
     }
     const int rows = B * Hi;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -563,10 +624,12 @@ template <bool APPLY>
 __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char* __restrict__ IDX, const unsigned short* __restrict__ DY,
                                                              const unsigned short* __restrict__ Z, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ sums_in, float inv_count,
-                                                             int B, int Hi, int Wi, int Ho, int Wo, int band, float* __restrict__ sums,
-                                                             unsigned short* __restrict__ DX) {
+                                                             const float* __restrict__ beta, const lp_fxsum* __restrict__ sums_in, float inv_count,
+                                                             int B, int Hi, int Wi, int Ho, int Wo, int band, lp_fxsum* __restrict__ sums,
+                                                             unsigned short* __restrict__ DX, const lp_fxsum* __restrict__ local,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
     constexpr int C = 64, chunks = 8;
+    if (APPLY) bn_param_grads(local, 1, C, dbeta, dgamma);
     constexpr int kZU = LP_POOL_ZU;   // z chunks in flight per thread
     __shared__ __attribute__((aligned(16))) unsigned short sdy[2][kPbW * C];
     __shared__ __attribute__((aligned(16))) unsigned char sidx[2][kPbW * C];
@@ -580,8 +643,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
         is[i] = invstd[c];
         sc[i] = is[i] * gamma[c];
         be[i] = beta[c];
-        k0[i] = APPLY ? sums_in[c] * inv_count : 0.f;
-        k1[i] = APPLY ? sums_in[C + c] * inv_count : 0.f;
+        k0[i] = (APPLY && sums_in != nullptr) ? fx_value(&sums_in[c]) * inv_count : 0.f;
+        k1[i] = (APPLY && sums_in != nullptr) ? fx_value(&sums_in[C + c]) * inv_count : 0.f;
         s0[i] = s1[i] = 0.f;
     }
     const int bands = (Ho + band - 1) / band;
@@ -676,18 +739,15 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
                 t0 += red[0][q * chunks + pc][pi];
                 t1 += red[APPLY ? 0 : 1][q * chunks + pc][pi];
             }
-            float* const srow = sums + (size_t)blockIdx.x * 2 * C;   // (reduce form: `sums` = the per-workgroup slot rows)
-            srow[threadIdx.x] = t0;
-            srow[C + threadIdx.x] = t1;
+            fx_add(&sums[threadIdx.x], t0);
+            fx_add(&sums[C + threadIdx.x], t1);
         }
     }
 }
 
-static int pool_v2_band() {   // output rows per workgroup: 6 -> 16 bands per 96-row map, 1024 / 2048 workgroups for 64 / 128 frames = whole rounds
-    const char* e = getenv("LP_POOL_BAND");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 6;
-}
+// output rows per workgroup: 6 -> 16 bands per 96-row map, 1024 / 2048 workgroups for 64 / 128 frames = whole rounds (3, 4, 8, 12 measured:
+// profiles/r03ad_pool_band.txt)
+static int pool_v2_band() { return 6; }
 
 static bool pool_v2_ok(int C, int Hi, int Wi, int Ho, int Wo) {
     const char* e = getenv("LP_POOL_V2");
@@ -748,7 +808,10 @@ static int colreduce_blocks(int M, int C) {
 // lane stays on one channel chunk; rows of C/8 chunks with C/8 a divisor of 256 (every ResNet width) need no adjustment
 static int bn_grid(size_t n_chunks, int chunks) {
     size_t blocks = (n_chunks + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    // ONE resident round: bn_apply_kernel / bn_bwd_apply_kernel run 5 waves per SIMD = 5 workgroups per CU.  (Until round 4 the cap was
+    // 2048 = 1.6 rounds, the second one 60 % full: 1280 gave bn_apply 110.7 -> 102.2 us and bn_bwd_apply 129.0 -> 121.8 us per launch,
+    // 4260 -> 4324 frames/s over three A/B pairs; 1024 - four per CU - loses it again, 1536 gives half of it.  profiles/r04p_*, r04q_*)
+    if (blocks > 256 * 5) blocks = 256 * 5;
     if (blocks < 1) blocks = 1;
     if (256 % chunks != 0) {  // make grid * 256 a multiple of `chunks`: round the grid up to a multiple of chunks / gcd(chunks, 256)
         int a = chunks, b = 256;
@@ -791,19 +854,15 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) bias_out[co] = beta[co] - rmean[co] * a;
 }
 
-void launch_stats_slots_reduce(const float* slots, int rows, int nseg, int C, float* sums, float* acc0, float* acc1, hipStream_t st) {
-    hipLaunchKernelGGL(stats_slots_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, slots, rows, C, nseg, sums, acc0, acc1);
-}
-
 }  // namespace lp
 
-// workspace of the stand-alone reductions below: one [2][C] row of partial sums per workgroup
+// workspace of the two stand-alone reductions below: one [2][C] fp32 row of partial sums per workgroup
 extern "C" size_t lp_bn_reduce_workspace_bytes(int M, int C) {
     if (M <= 0 || C <= 0) return 0;
-    return (size_t)lp::colreduce_blocks(M, C) * 2 * (size_t)C * sizeof(float);
+    return (size_t)lp::colreduce_blocks(M, C) * 2 * C * sizeof(float);
 }
 
-extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
+extern "C" int lp_bn_stats(const void* x, int M, int C, lp_fxsum* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && sums && workspace && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
@@ -812,33 +871,21 @@ extern "C" int lp_bn_stats(const void* x, int M, int C, float* sums, void* works
     hipLaunchKernelGGL((colreduce_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr, (const float*)nullptr, M,
                        C, (float*)workspace);
-    launch_stats_slots_reduce((const float*)workspace, (int)grid.x, 1, C, sums, nullptr, nullptr, (hipStream_t)stream);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid.x, C, sums);
     return launch_status();
 }
 
-// sums (nseg, 2, C) += the rows of `slots` ([rows][nseg][2][C]) added in ROW order (fixed chains + tree, lp_common.h: slots_totals); the
-// optional accumulators += component 0 / 1 summed over the segments.  The reduction every fused / stand-alone entry point runs internally,
-// exported for callers that hold rows of their own - SyncBatchNorm's one-shot exchange adds the ranks' sums in rank order with it.
-extern "C" int lp_bn_slots_reduce(const void* slots, int rows, int nseg, int C, float* sums, float* dbeta_acc, float* dgamma_acc,
-                                  lp_stream_t stream) {
-    using namespace lp;
-    LP_REQUIRE(slots && sums && rows > 0 && (nseg == 1 || nseg == 2) && C > 0);
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
-    launch_stats_slots_reduce((const float*)slots, rows, nseg, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
-    return launch_status();
+// dst[i] += the value of sums[i] (a fixed-point total as fp32): what a caller that wants plain floats does with lp_bn_stats' output
+// (the head's bias gradients are column sums of the output gradient)
+__global__ void fx_accumulate_kernel(const lp_fxsum* __restrict__ sums, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += lp::fx_value(&sums[i]);
 }
 
-// mean / invstd (+ running statistics) straight from the per-workgroup rows a deferred lp_conv_fwd_bn / lp_stem_fwd_bn left
-// (lp_bn_fuse.defer_reduce, .slot_rows): reduction and finalize in ONE launch
-extern "C" int lp_bn_finalize_slots(const void* slots, int slot_rows, int nseg, float count0, float count1, int C, float eps, float momentum,
-                                    float* mean, float* invstd, float* running_mean, float* running_var, float* sums_out,
-                                    lp_stream_t stream) {
-    using namespace lp;
-    LP_REQUIRE(slots && mean && invstd && slot_rows > 0 && (nseg == 1 || nseg == 2) && C > 0 && count0 > 0.f && (nseg == 1 || count1 > 0.f));
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)slots, slot_rows, count0,
-                       nseg == 2 ? count1 : count0, nseg, C, eps, momentum, mean, invstd, running_mean, running_var, sums_out);
-    return launch_status();
+extern "C" int lp_fxsum_accumulate(const lp_fxsum* sums, int n, float* dst, lp_stream_t stream) {
+    LP_REQUIRE(sums && dst && n > 0);
+    hipLaunchKernelGGL(fx_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, n, dst);
+    return lp::launch_status();
 }
 
 extern "C" int lp_bn_fold(const float* w, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -850,20 +897,30 @@ extern "C" int lp_bn_fold(const float* w, const float* gamma, const float* beta,
     return launch_status();
 }
 
-extern "C" int lp_bn_finalize(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
+extern "C" int lp_bn_finalize(const lp_fxsum* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
                               float* running_mean, float* running_var, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(sums && mean && invstd && C > 0 && count > 0.f);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count, 1, C, eps, momentum,
-                       mean, invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel<lp_fxsum>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count, 1, C, eps,
+                       momentum, mean, invstd, running_mean, running_var);
     return launch_status();
 }
 
-extern "C" int lp_bn_finalize2(const float* sums, float count0, float count1, int C, float eps, float momentum, float* mean, float* invstd,
+extern "C" int lp_bn_finalize2(const lp_fxsum* sums, float count0, float count1, int C, float eps, float momentum, float* mean, float* invstd,
                                float* running_mean, float* running_var, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(sums && mean && invstd && C > 0 && count0 > 0.f && count1 > 0.f);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count0, count1, 2, C, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel<lp_fxsum>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count0, count1, 2, C, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    return launch_status();
+}
+
+// the same from plain fp32 [sum, sum of squares] (the fp32 validation executor's statistics: lp_f32_bn_stats_ordered)
+extern "C" int lp_bn_finalize_f32(const float* sums, float count, int C, float eps, float momentum, float* mean, float* invstd,
+                                  float* running_mean, float* running_var, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(sums && mean && invstd && C > 0 && count > 0.f);
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count, 1, C, eps,
                        momentum, mean, invstd, running_mean, running_var);
     return launch_status();
 }
@@ -893,7 +950,7 @@ extern "C" int lp_bn_apply_seg(const void* x, const float* mean, const float* in
 }
 
 extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
-                                float* sums, float* dbeta_acc, float* dgamma_acc, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
+                                lp_fxsum* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && x && mean && invstd && sums && workspace && M > 0 && C > 0);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
@@ -901,35 +958,36 @@ extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x
     LP_REQUIRE(workspace_bytes >= (size_t)grid.x * 2 * C * sizeof(float));
     hipLaunchKernelGGL((colreduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
                        (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, M, C, (float*)workspace);
-    launch_stats_slots_reduce((const float*)workspace, (int)grid.x, 1, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid.x, C, sums);
     return launch_status();
 }
 
 static int bn_bwd_apply_impl(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
-                             const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
-                             lp_stream_t stream) {
+                             const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
+                             const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(dy && x && mean && invstd && gamma && sums && dx && M > 0 && C > 0 && count0 > 0.f && count1 > 0.f && seg_rows >= 0 &&
-               seg_rows < M);
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    LP_REQUIRE(dy && x && mean && invstd && gamma && dx && M > 0 && C > 0 && count0 > 0.f && count1 > 0.f && seg_rows >= 0 && seg_rows < M);
+    LP_REQUIRE(sums_local != nullptr || (dbeta_acc == nullptr && dgamma_acc == nullptr));
+    if (C % 8 != 0 || C > kBnBwdMaxC) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
                        (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count0, n_chunks, C,
-                       (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1);
+                       (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1, sums_local, dbeta_acc, dgamma_acc);
     return launch_status();
 }
 
 extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
-                               const float* gamma, const float* sums, float count, int M, int C, void* dx, void* dres,
-                               lp_stream_t stream) {
-    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count, count, M, C, 0, dx, dres, stream);
+                               const float* gamma, const lp_fxsum* sums, float count, int M, int C, void* dx, void* dres,
+                               const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
+    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count, count, M, C, 0, dx, dres, sums_local, dbeta_acc, dgamma_acc, stream);
 }
 
 // two segments: mean / invstd (2, C), sums (2, 2, C), one row count per segment (times the world size under SyncBatchNorm)
 extern "C" int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
-                                   const float* gamma, const float* sums, float count0, float count1, int M, int C, int seg_rows, void* dx,
-                                   void* dres, lp_stream_t stream) {
-    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count0, count1, M, C, seg_rows, dx, dres, stream);
+                                   const float* gamma, const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx,
+                                   void* dres, const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
+    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count0, count1, M, C, seg_rows, dx, dres, sums_local, dbeta_acc,
+                             dgamma_acc, stream);
 }
 
 extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {
@@ -964,62 +1022,47 @@ extern "C" int lp_bn_relu_maxpool_fwd(const void* z, const float* mean, const fl
     return launch_status();
 }
 
-static int pool_reduce_wgs(int B, int Hi, int Wi, int C) {
-    using namespace lp;
-    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
-    if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) return B * ((Ho + pool_v2_band() - 1) / pool_v2_band());   // one band per workgroup (4 resident per CU)
-    return pool_row_blocks(B * Hi, 4);
-}
-
-extern "C" size_t lp_bn_pool_bwd_workspace_bytes(int B, int Hi, int Wi, int C) {
-    if (B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) return 0;
-    return (size_t)pool_reduce_wgs(B, Hi, Wi, C) * 2 * (size_t)C * sizeof(float);
-}
-
 extern "C" int lp_bn_pool_bwd_reduce(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd,
-                                     const float* gamma, const float* beta, int B, int Hi, int Wi, int C, float* sums, float* dbeta_acc,
-                                     float* dgamma_acc, void* workspace, size_t workspace_bytes, lp_stream_t stream) {
+                                     const float* gamma, const float* beta, int B, int Hi, int Wi, int C, lp_fxsum* sums, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && workspace && B > 0 && Hi > 0 && Wi > 0 && C > 0);
+    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && B > 0 && Hi > 0 && Wi > 0 && C > 0);
     if (C % 8 != 0 || 256 % (C / 8) != 0) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     const long long pixels = (long long)B * Hi * Wi;
     if (pixels >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) {
-        const int band = pool_v2_band(), wgs = pool_reduce_wgs(B, Hi, Wi, C);
-        LP_REQUIRE(workspace_bytes >= (size_t)wgs * 2 * C * sizeof(float));
+        const int band = pool_v2_band(), wgs = B * ((Ho + band - 1) / band);   // one band per workgroup (4 resident per CU)
         hipLaunchKernelGGL(bn_pool_bwd_v2_kernel<false>, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, nullptr,
-                           0.f, B, Hi, Wi, Ho, Wo, band, (float*)workspace, nullptr);
-        launch_stats_slots_reduce((const float*)workspace, wgs, 1, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
+                           0.f, B, Hi, Wi, Ho, Wo, band, sums, nullptr, nullptr, nullptr, nullptr);
         return launch_status();
     }
-    const int wgs = pool_row_blocks(B * Hi, 4);
-    LP_REQUIRE(workspace_bytes >= (size_t)wgs * 2 * C * sizeof(float));
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(pool_row_blocks(B * Hi, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, B, Hi,
-                       Wi, C, Ho, Wo, (float*)workspace);
-    launch_stats_slots_reduce((const float*)workspace, wgs, 1, C, sums, dbeta_acc, dgamma_acc, (hipStream_t)stream);
+                       Wi, C, Ho, Wo, sums);
     return launch_status();
 }
 
+// `sums`: the totals the correction terms use (all-reduced under SyncBatchNorm), NULL = none (eval-mode BatchNorm); `sums_local` +
+// dbeta_acc / dgamma_acc: this rank's sums are added into the parameter gradients (NULL: not)
 extern "C" int lp_bn_pool_bwd_apply(const void* argmax_u8, const void* dy, const void* z, const float* mean, const float* invstd,
-                                    const float* gamma, const float* beta, const float* sums, float count, int B, int Hi, int Wi, int C,
-                                    void* dx, lp_stream_t stream) {
+                                    const float* gamma, const float* beta, const lp_fxsum* sums, float count, int B, int Hi, int Wi, int C,
+                                    void* dx, const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
     using namespace lp;
-    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && sums && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && count > 0.f);
+    LP_REQUIRE(argmax_u8 && dy && z && mean && invstd && gamma && beta && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && count > 0.f);
+    LP_REQUIRE(sums_local != nullptr || (dbeta_acc == nullptr && dgamma_acc == nullptr));
     if (C % 8 != 0 || 256 % (C / 8) != 0 || (long long)B * Hi >= (1LL << 31)) return LP_ERR_UNSUPPORTED;
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     if (pool_v2_ok(C, Hi, Wi, Ho, Wo)) {
         const int band = pool_v2_band(), wgs = B * ((Ho + band - 1) / band);
         hipLaunchKernelGGL(bn_pool_bwd_v2_kernel<true>, dim3(wgs), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
-                           1.f / count, B, Hi, Wi, Ho, Wo, band, nullptr, (unsigned short*)dx);
+                           1.f / count, B, Hi, Wi, Ho, Wo, band, nullptr, (unsigned short*)dx, sums_local, dbeta_acc, dgamma_acc);
         return launch_status();
     }
     hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(pool_row_blocks(B * Hi)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned char*)argmax_u8, (const unsigned short*)dy, (const unsigned short*)z, mean, invstd, gamma, beta, sums,
-                       1.f / count, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx);
+                       1.f / count, B, Hi, Wi, C, Ho, Wo, (unsigned short*)dx, sums_local, dbeta_acc, dgamma_acc);
     return launch_status();
 }
 

@@ -42,18 +42,12 @@ struct ConvEpilogue {
     const unsigned short* addend;  // [M][ldo] bf16 added before the store (gradient accumulation), or nullptr
     const unsigned short* relu_mask;  // [M][ldo] bf16 activation; outputs where it is <= 0 are zeroed (ReLU backward), or nullptr
     const unsigned char* relu_bits;   // same mask at 1 bit per element ([M][ldo/8] bytes, written by lp_bn_apply), or nullptr
-    // BatchNorm reductions fused into the store pass (bf16 outputs only; `stats` != nullptr switches them on): the column sums of the
+    // BatchNorm reductions fused into the store pass (bf16 outputs only; `stats_sums` != nullptr switches them on): the column sums of the
     // values actually stored (after rounding) - sum v and sum v^2 (forward: the statistics of the next BatchNorm) or, with bn_z,
     // sum v * xhat (backward: the two reductions of BatchNorm's gradient).  Every persistent workgroup adds up its tiles' sums in a fixed
-    // order and leaves them in ITS OWN row of `stats_slots` ([workgroup][segment][2][N], zeroed by the workgroup itself at the start of
-    // the launch); stats_slots_reduce_kernel / bn_finalize_slots_kernel then add the rows in workgroup order: the totals repeat bit for
-    // bit from run to run (round 4; rounds 2 - 3 added the workgroups' sums into `stats_sums` with fp32 atomics, in arrival order -
-    // that form remains behind LP_STATS_ATOMIC=1 for A/B timing: stats_slots == nullptr, acc0 / acc1 receive the totals too).
-    float* stats;                  // non-null = take the sums
-    int stats_pad;
-    float* stats_sums;             // [segment][2][N] totals (always set with `stats`; written by the kernel only in the atomic form)
-    float* stats_acc0;
-    float* stats_acc1;
+    // order and adds the result into `stats_sums` ([segment][2][N] lp_fxsum) in FIXED POINT with integer atomics (lp_common.h: fx_add):
+    // the totals repeat bit for bit from run to run (rounds 2 - 3: fp32 atomics in arrival order).
+    lp_fxsum* stats_sums;          // [segment][2][N] totals; non-null = take the sums
     const unsigned short* bn_z;    // [M][ldo] bf16 pre-normalisation tensor the gradient belongs to, or nullptr
     const float* bn_mean;          // [N]
     const float* bn_invstd;        // [N]
@@ -73,32 +67,10 @@ struct ConvEpilogue {
     // straddles the boundary (host-checked: seg_images * rows per image is a multiple of the 128-row tile).  Segment s uses
     // bn_mean / bn_invstd + s * N and adds into stats_sums + s * 2 * N; 0 = one segment
     int seg_images;
-    float* stats_slots;            // this launch's [gridDim.x][segments][2][N] partial-sum rows (see `stats`), or nullptr = atomic form
 };
 
-// one workgroup's contribution to a fused BatchNorm sum (`idx` = 2 * segment offset + component * N + column): its own slot row, or - the
-// atomic A/B form - straight into the totals
-__device__ __forceinline__ void stats_emit(const ConvEpilogue& ep, int N, int idx, int comp, int col, float t) {
-    if (ep.stats_slots != nullptr) {
-        float* p = ep.stats_slots + (size_t)blockIdx.x * ((ep.seg_images > 0 ? 4 : 2) * N) + idx;
-        *p += t;   // (always the same thread of the same workgroup for a given address: program order)
-    } else {
-        atomicAdd(&ep.stats_sums[idx], t);
-        float* accp = comp == 0 ? ep.stats_acc0 : ep.stats_acc1;
-        if (accp != nullptr) atomicAdd(&accp[col], t);
-    }
-}
-
-// every workgroup zeroes ITS row of stats_slots before its walk (nobody else touches the row).  No wait here: the first read-modify-write
-// of the row is in a stats flush, behind that flush's __syncthreads() - which every wave enters only after ITS outstanding stores are
-// acknowledged (hipcc's __syncthreads is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier) - and at least one whole tile later.  (With an
-// explicit wait + barrier at the start every launch began ~3 us later: forward launches 7.55 -> 7.80 ms per step, profiles/r04h_*.)
-__device__ __forceinline__ void stats_slots_zero(const ConvEpilogue& ep, int N, int tid, int nthreads) {
-    if (ep.stats_slots == nullptr) return;
-    const int n = (ep.seg_images > 0 ? 4 : 2) * N;
-    float* row = ep.stats_slots + (size_t)blockIdx.x * n;
-    for (int i = tid; i < n; i += nthreads) row[i] = 0.f;
-}
+// one workgroup's contribution to a fused BatchNorm sum (`idx` = 2 * segment offset + component * N + column)
+__device__ __forceinline__ void stats_emit(const ConvEpilogue& ep, int idx, float t) { fx_add(&ep.stats_sums[idx], t); }
 
 // Row pitches of the two operands and an optional batch of independent GEMMs sharing one launch (lp_gemm_nt: attention's
 // per-(image, head) products).  A convolution is the special case ldx = channels, ldw = filter length, one batch.
@@ -234,7 +206,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int kchunk = tid & 7, rbase = tid >> 3;  // 8 x 16-B chunks per 64-wide K row; 32 rows per pass
-    stats_slots_zero(ep, N, tid, 256);
 
     // Workgroups are persistent: each walks the tile list with stride gridDim.x, and the operands of the NEXT tile's first K
     // step are already in flight (in registers) while the current tile's epilogue runs, so the store pass of one tile overlaps
@@ -397,14 +368,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
     f32x16 acc[2][NT];
 
     // Fused BatchNorm sums: thread t < 2 BN owns (component t / BN, column t % BN) and ADDS UP its column's tile sums over the tiles this
-    // persistent workgroup walks (a fixed order); they leave - into the workgroup's slot row, stats_emit - when the column block or the
+    // persistent workgroup walks (a fixed order); they leave - stats_emit: fixed point, integer atomics - when the column block or the
     // BatchNorm segment changes and at the end: at most 512 workgroups x 2 BN values per launch however many tiles there are
     float st_acc = 0.f;
     int st_n0 = -1, st_seg_off = 0;
     auto stats_flush = [&]() {
         if (st_n0 >= 0 && tid < 2 * BN) {
             const int comp = tid / BN, cl = tid % BN;
-            if (st_n0 + cl < N) stats_emit(ep, N, 2 * st_seg_off + comp * N + st_n0 + cl, comp, st_n0 + cl, st_acc);
+            if (st_n0 + cl < N) stats_emit(ep, 2 * st_seg_off + comp * N + st_n0 + cl, st_acc);
         }
         st_acc = 0.f;
     };
@@ -433,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
             constexpr int RPP = 256 / CPR;       // rows per pass
             const int cc = tid % CPR, r0 = tid / CPR;
             const int n = n0 + cc * 8;
-            const bool want_stats = ep.stats != nullptr;
+            const bool want_stats = ep.stats_sums != nullptr;
             // only the data-gradient has tensors to read back in its store pass (addend, pre-normalisation tensor, activation)
             constexpr bool kReads = (MODE == kModeDgrad || MODE == kModeInfer);  // the addend (gradient accumulation / residual)
             constexpr bool kBwd = (MODE == kModeDgrad);  // pre-normalisation tensor and ReLU masks: data gradient only
@@ -1088,36 +1059,10 @@ static long long seg_split_rows(int seg_images, int B, long long rows_per_image,
     return (r % kBM == 0) ? r : -1;
 }
 
-// workspace of a fused launch: one [segments][2][N] row of partial sums per workgroup, at most 4 launches per call (the parity classes of a
-// stride-2 data gradient) of at most 2 workgroups per CU each
-static int bn_max_wgs();
-static size_t bn_workspace_floats(int N) { return (size_t)4 * (size_t)bn_max_wgs() * 4 * (size_t)N; }
-// the fused sums leave through per-workgroup rows and an ordered reduction (bit-reproducible); LP_STATS_ATOMIC=1 selects rounds 2 - 3's
-// fp32 atomics in arrival order (A/B timing only).  Read per call, so one process can run both.
-static bool stats_atomic() {
-    const char* e = getenv("LP_STATS_ATOMIC");
-    return e != nullptr && atoi(e) != 0;
-}
-// what every fused entry point does with its lp_bn_fuse: the epilogue's targets before the launches ...
-static void bn_fuse_begin(ConvEpilogue& ep, lp_bn_fuse* bn, bool bwd) {
-    ep.stats = (float*)bn->workspace;
+// what every fused entry point does with its lp_bn_fuse: the epilogue's targets
+static void bn_fuse_begin(ConvEpilogue& ep, const lp_bn_fuse* bn) {
     ep.stats_sums = bn->sums;
     ep.seg_images = bn->seg_images;
-    ep.stats_slots = stats_atomic() ? nullptr : (float*)bn->workspace;
-    if (bwd && ep.stats_slots == nullptr) ep.stats_acc0 = bn->dbeta_acc, ep.stats_acc1 = bn->dgamma_acc;
-    bn->slot_rows = 0;
-}
-// ... the rows one launch of `grid` workgroups takes ...
-static void bn_fuse_launched(ConvEpilogue& ep, lp_bn_fuse* bn, int N, int grid) {
-    if (ep.stats_slots == nullptr) return;
-    bn->slot_rows += grid;
-    ep.stats_slots += (size_t)grid * (bn->seg_images > 0 ? 4 : 2) * N;
-}
-// ... and the ordered reduction afterwards (unless the caller feeds the rows to lp_bn_finalize_slots itself: defer_reduce)
-static void bn_fuse_end(const ConvEpilogue& ep, lp_bn_fuse* bn, int N, bool bwd, hipStream_t st) {
-    if (ep.stats_slots == nullptr || bn->defer_reduce) return;
-    launch_stats_slots_reduce((const float*)bn->workspace, bn->slot_rows, bn->seg_images > 0 ? 2 : 1, N, bn->sums, bwd ? bn->dbeta_acc : nullptr,
-                              bwd ? bn->dgamma_acc : nullptr, st);
 }
 
 // which kernel family the most recent convolution entry point of this thread launched (lp_conv_last_kernel: the bench labels its
@@ -1183,8 +1128,6 @@ static int pipe_max_wgs() {
     return cus;
 }
 
-static int bn_max_wgs() { return igemm_max_wgs() > 2 * pipe_max_wgs() ? igemm_max_wgs() : 2 * pipe_max_wgs(); }
-
 // what the pipelined kernel covers: dense bf16 output of a trunk convolution (no fp32 copy; a bias only in the forward store pass, which
 // the Linear layers of lp_gemm_nt use), K a multiple of 64 and > 0, N a
 // multiple of its column block, fused BatchNorm sums on the atomic path only, and a BatchNorm segment boundary that falls on a 256-row tile
@@ -1204,7 +1147,7 @@ static int pipe_dgrad_kind(const ConvEpilogue& ep) {
         if (!ep.mask_from_z && ep.addend && ep.relu_bits) return kEkAZB;
         return -1;
     }
-    return (ep.relu_bits == nullptr && ep.stats == nullptr) ? kEkPlain : -1;
+    return (ep.relu_bits == nullptr && ep.stats_sums == nullptr) ? kEkPlain : -1;
 }
 
 // HALO form (conv_pipe.h): 3x3 / stride 1 / pad 1 with the tile's input neighbourhood staged once per 64-channel slice.  Eligible when the
@@ -1261,12 +1204,10 @@ static int launch_pipe(const void* x, const void* w, const ConvGeom& g, const La
     const int ck = MODE == kModeDgrad ? g.Co : g.Ci;
     const unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
     const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * ck);
-    const char* fe = getenv("LP_PIPE_FLAGS");   // experiment switch: 2 = non-temporal output stores
-    const int flags = fe ? atoi(fe) : 0;
     g_last_conv_kernel = HALO ? LP_CONV_KERNEL_PIPE_HALO : LP_CONV_KERNEL_PIPE;
     const HaloDivs hd{make_fastdiv(g.Hi), make_fastdiv(g.Wi + 2), make_fastdiv(g.Hi + 2)};
     hipLaunchKernelGGL((conv_pipe_kernel<BN, MODE, EK, HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w,
-                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, flags, hd);
+                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, hd);
     return grid;
 }
 
@@ -1399,7 +1340,7 @@ static ConvGeom to_geom(const lp_conv_geom* c) {
 
 // out[b][ho][wo][co] = sum x[b][ho*st-pad+r][wo*st-pad+s][ci] * w[co][r][s][ci]  (+bias) ; x, w bf16
 static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom, const float* bias, void* out_bf16, float* out_f32, int ldo,
-                         int n_store, lp_bn_fuse* bn, lp_stream_t stream) {
+                         int n_store, const lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && w && geom_ok(geom) && (out_bf16 || out_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1407,36 +1348,30 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         (long long)g.B * g.Ho * g.Wo * ldo >= (1LL << 32))
         return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, N = g.Co, K = g.R * g.S * g.Ci;
-    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
-                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    ConvEpilogue ep{(unsigned short*)out_bf16, out_f32, ldo, n_store > 0 ? n_store : N, bias};
     long long split = M;
     if (bn) {
-        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_floats(N) * sizeof(float) && bn->seg_images >= 0);
+        LP_REQUIRE(bn->sums && bn->seg_images >= 0);
         if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
         split = seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M);
         if (split < 0) return LP_ERR_UNSUPPORTED;
-        bn_fuse_begin(ep, bn, false);
+        bn_fuse_begin(ep, bn);
     }
     hipStream_t st = (hipStream_t)stream;
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-    int grid = 0;
     if (pipe_eligible(ep, M, N, K, g.Ci, split, true)) {
         if (N > 64) {
-            if (pipe_halo_ok(g, M, g.Ci, 384)) grid = launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
-            else grid = launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+            if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         } else if (res2d_ok(g, g.Ci, N, ep)) {
-            grid = launch_res2d<kModeFwd>(x, w, g, ep, st);
+            launch_res2d<kModeFwd>(x, w, g, ep, st);
         } else if (pipe_halo_ok(g, M, g.Ci, 512)) {
-            grid = launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
         } else {
-            grid = launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
+            launch_pipe<64, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         }
-    } else if (N > 64) grid = launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
-    else grid = launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
-    if (bn) {
-        bn_fuse_launched(ep, bn, N, grid);
-        bn_fuse_end(ep, bn, N, false, st);
-    }
+    } else if (N > 64) launch_igemm<128, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
+    else launch_igemm<64, kModeFwd>(x, w, g, lat, M, N, K, ep, st);
     return launch_status();
 }
 
@@ -1482,16 +1417,8 @@ extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom*
     return launch_status();
 }
 
-extern "C" size_t lp_conv_bn_workspace_bytes(const lp_conv_geom* geom, int dgrad) {
-    using namespace lp;
-    if (!geom_ok(geom)) return 0;
-    const long long rows = (long long)geom->B * (dgrad ? geom->Hi * geom->Wi : geom->Ho * geom->Wo);
-    (void)rows;
-    return bn_workspace_floats(dgrad ? geom->Ci : geom->Co) * sizeof(float);
-}
-
 // conv + the [sum, sum of squares] of its (bf16-rounded) output per channel: the statistics pass of the BatchNorm that follows
-extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn,
+extern "C" int lp_conv_fwd_bn(const void* x, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
                               lp_stream_t stream) {
     LP_REQUIRE(bn && geom && out_bf16);
     return conv_fwd_impl(x, w, geom, nullptr, out_bf16, nullptr, geom->Co, 0, bn, stream);
@@ -1514,8 +1441,7 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     if (a_elems >= (1LL << 31) || b_elems >= (1LL << 31) || c_elems >= (1LL << 32)) return LP_ERR_UNSUPPORTED;
     if ((a_b | a_h | b_b | b_h) % 8 != 0) return LP_ERR_UNSUPPORTED;  // 16-B operand chunks
     ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
-    ConvEpilogue ep{(unsigned short*)c_bf16, c_f32, ldc, n_store > 0 ? n_store : N, bias, nullptr, nullptr, nullptr,
-                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    ConvEpilogue ep{(unsigned short*)c_bf16, c_f32, ldc, n_store > 0 ? n_store : N, bias};
     GemmExt gx{lda, ldb, nh, 0, (unsigned)(2 * a_b), (unsigned)(2 * a_h), (unsigned)(2 * b_b), (unsigned)(2 * b_h), (unsigned)c_b,
                (unsigned)c_h};
     const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
@@ -1570,7 +1496,7 @@ extern "C" int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int 
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
 static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
                            const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
-                           lp_bn_fuse* bn, lp_stream_t stream) {
+                           const lp_bn_fuse* bn, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1579,16 +1505,14 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         return LP_ERR_UNSUPPORTED;
     const int N = g.Ci;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
-                    (const unsigned short*)relu_mask, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                    nullptr, 0};
+                    (const unsigned short*)relu_mask};
     if (bn) {
         // the reductions cover every pixel exactly once, so no class may be skipped and the output must be the dense bf16 tensor
-        LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && bn->workspace && dx_bf16 && !dx_f32 && !skip_empty_classes &&
-                   ldo == N && ep.n_store == N && (!bn->mask_from_z || (bn->gamma && bn->beta)) &&
-                   bn->workspace_bytes >= bn_workspace_floats(N) * sizeof(float));
+        LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && dx_bf16 && !dx_f32 && !skip_empty_classes &&
+                   ldo == N && ep.n_store == N && (!bn->mask_from_z || (bn->gamma && bn->beta)));
         if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
         LP_REQUIRE(!(bn->relu_bits && (relu_mask || bn->mask_from_z)) && bn->seg_images >= 0);
-        bn_fuse_begin(ep, bn, true);
+        bn_fuse_begin(ep, bn);
         ep.bn_z = (const unsigned short*)bn->z;
         ep.bn_mean = bn->mean;
         ep.bn_invstd = bn->invstd;
@@ -1610,13 +1534,11 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         }
         const int kind = pipe_dgrad_kind(ep);
         const bool full_lattice = lat.hstep == 1 && lat.wstep == 1;   // (kEkAZB recomputes its output offsets from the row index)
-        int grid;
         if (kind >= 0 && (kind != kEkAZB || full_lattice) && pipe_eligible(ep, M, N, K, g.Co, seg_rows)) {
-            if (N > 64) grid = launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
-            else grid = launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);
-        } else if (N > 64) grid = launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
-        else grid = launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
-        if (bn) bn_fuse_launched(ep, bn, N, grid);
+            if (N > 64) launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
+            else launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);
+        } else if (N > 64) launch_igemm<128, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
+        else launch_igemm<64, kModeDgrad>(dy, wd, g, lat, M, N, K, ep, st);
     };
     if (bn && bn->seg_images > 0) {  // check every launch's segment boundary BEFORE anything is enqueued
         if (bn->seg_images >= g.B) return LP_ERR_UNSUPPORTED;
@@ -1641,7 +1563,6 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
             }
     }
     if (!seg_ok) return LP_ERR_UNSUPPORTED;
-    if (bn) bn_fuse_end(ep, bn, N, true, st);
     return launch_status();
 }
 
@@ -1653,7 +1574,7 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
 
 // data gradient + ReLU backward + the two reductions of the BatchNorm backward that consumes dx (sum dx, sum dx * xhat)
 extern "C" int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_mask,
-                                void* dx_bf16, lp_bn_fuse* bn, lp_stream_t stream) {
+                                void* dx_bf16, const lp_bn_fuse* bn, lp_stream_t stream) {
     LP_REQUIRE(bn && geom);
     return conv_dgrad_impl(dy, wd, geom, nullptr, addend, relu_mask, dx_bf16, nullptr, geom->Ci, 0, 0, bn, stream);
 }
@@ -1769,37 +1690,31 @@ extern "C" int lp_gemm_tn(const void* x, int ldx, const void* y, int ldy, void* 
 }
 
 // 7x7/2 stem on NHWC4 bf16 input (channel 3 = 0): weights [64][7+1][8][4] zero padded (K = 256)
-static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn,
+static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
                          lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x4 && w && geom_ok(geom) && out_bf16);
     ConvGeom g = to_geom(geom);
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo;
-    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64, nullptr, nullptr, nullptr, nullptr,
-                    nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    ConvEpilogue ep{(unsigned short*)out_bf16, nullptr, 64, 64};
     if (bn) {
-        LP_REQUIRE(bn->sums && bn->workspace && bn->workspace_bytes >= bn_workspace_floats(64) * sizeof(float) && bn->seg_images >= 0);
+        LP_REQUIRE(bn->sums && bn->seg_images >= 0);
         if (seg_split_rows(bn->seg_images, g.B, (long long)g.Ho * g.Wo, M) < 0) return LP_ERR_UNSUPPORTED;
-        bn_fuse_begin(ep, bn, false);
+        bn_fuse_begin(ep, bn);
     }
     // conv_stem2d_kernel (conv_res2d.h): 16 x 16 output tiles, filter resident in LDS.  LP_STEM_2D=0 (A/B runs, bit-identity tests) keeps
     // conv_igemm_kernel<64, stem>
     const char* s2 = getenv("LP_STEM_2D");
-    int grid;
     if (conv_pipe_enabled() && (s2 == nullptr || atoi(s2) != 0) && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo) {
         const int ntiles = g.B * (g.Ho / 16) * (g.Wo / 16);
-        grid = ntiles < 2 * pipe_max_wgs() ? ntiles : 2 * pipe_max_wgs();
+        const int grid = ntiles < 2 * pipe_max_wgs() ? ntiles : 2 * pipe_max_wgs();
         g_last_conv_kernel = LP_CONV_KERNEL_RES2D;
         hipLaunchKernelGGL(conv_stem2d_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (const unsigned short*)x4, (const unsigned short*)w,
                            (unsigned)(2ull * g.B * g.Hi * g.Wi * 4), g.B, g.Ho, g.Wo, ntiles, ep);
     } else {
         const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
-        grid = launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
-    }
-    if (bn) {
-        bn_fuse_launched(ep, bn, 64, grid);
-        bn_fuse_end(ep, bn, 64, false, (hipStream_t)stream);
+        launch_igemm<64, kModeStem>(x4, w, g, lat, M, 64, 256, ep, (hipStream_t)stream);
     }
     return launch_status();
 }
@@ -1808,7 +1723,7 @@ extern "C" int lp_stem_fwd(const void* x4, const void* w, const lp_conv_geom* ge
     return stem_fwd_impl(x4, w, geom, out_bf16, nullptr, stream);
 }
 
-extern "C" int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, lp_bn_fuse* bn,
+extern "C" int lp_stem_fwd_bn(const void* x4, const void* w, const lp_conv_geom* geom, void* out_bf16, const lp_bn_fuse* bn,
                               lp_stream_t stream) {
     LP_REQUIRE(bn);
     return stem_fwd_impl(x4, w, geom, out_bf16, bn, stream);

@@ -62,16 +62,8 @@ constexpr int kPRowB = 128;  // bytes per staged operand row (64 k x bf16)
 #define LP_WAIT_LGKM_TOUCH4(n, a, b, c, d) ((void)0)
 #endif
 
-// 16-B store; `stream`: non-temporal (the lines are not kept in L2, which the weight panel of the deep 1x1 layers needs)
-__device__ __forceinline__ void store8(unsigned short* p, u16x8 v, bool stream) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (stream) __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(p));
-    else *reinterpret_cast<u16x8*>(p) = v;
-#else
-    (void)stream;
-    *reinterpret_cast<u16x8*>(p) = v;
-#endif
-}
+// 16-B store (a non-temporal form was measured in round 3 and dropped: profiles/r03b_bench_ntstore_1.json.log)
+__device__ __forceinline__ void store8(unsigned short* p, u16x8 v) { *reinterpret_cast<u16x8*>(p) = v; }
 
 // EK = what the data gradient's store pass reads back (its own instantiation each, so the read-back registers of one form are not
 // allocated in the others; anything else goes to conv_igemm_kernel):
@@ -99,7 +91,7 @@ struct HaloDivs {
 template <int BN, int MODE, int EK, bool HALO = false>
 __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
-                                                        FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep, int flags,
+                                                        FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep,
                                                         HaloDivs hd) {
     static_assert((MODE == kModeFwd && (EK == kEkNone || EK == kEkInfer)) || (MODE == kModeDgrad && EK != kEkNone && EK != kEkInfer),
                   "trunk convolutions only");
@@ -114,7 +106,6 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    stats_slots_zero(ep, N, tid, 512);
 
     const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_w = make_buf_rsrc(Wt, w_bytes);
     const int rows_y = lat.nh, rows_x = lat.nw;
@@ -440,7 +431,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) t += scratch[((wn_ * 4 + w4) * 2 + comp) * (NT * 32) + c];
                 if (bwd && comp == 1) t *= ep.bn_invstd[st_seg_off + st_n0 + cl];   // sum dy (z - mean)  ->  sum dy xhat
-                stats_emit(ep, N, 2 * st_seg_off + comp * N + st_n0 + cl, comp, st_n0 + cl, t);
+                stats_emit(ep, 2 * st_seg_off + comp * N + st_n0 + cl, t);
             }
             __syncthreads();
         }
@@ -518,7 +509,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                         }
                         w = pack_bf16x8(v);
                     }
-                    store8(ep.out_bf16 + off, w, (flags & 2) != 0);
+                    store8(ep.out_bf16 + off, w);
                     if (want_stats) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -626,7 +617,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                             if (!((rb.lb[kLb ? p : 0] >> q) & 1u)) v[q] = 0.f;
                     }
                     const u16x8 w = pack_bf16x8(v);
-                    store8(ep.out_bf16 + off_p, w, (flags & 2) != 0);
+                    store8(ep.out_bf16 + off_p, w);
                     if (want_stats) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {

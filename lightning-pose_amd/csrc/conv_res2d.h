@@ -35,7 +35,6 @@ __global__ __launch_bounds__(512) void conv_res2d_kernel(const unsigned short* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    stats_slots_zero(ep, 64, tid, 512);
     const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_w = make_buf_rsrc(Wt, w_bytes);
     const int tiles_x = W >> 4, tiles_y = H >> 4, tiles_img = tiles_x * tiles_y;
     const int M = B * H * W;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(512) void conv_res2d_kernel(const unsigned short* _
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) t += scratch[((wn_ * 4 + w4) * 2 + comp) * 32 + c];
                 if (!kFwd && comp == 1) t *= ep.bn_invstd[st_seg_off + cl];   // sum dy (z - mean) -> sum dy xhat
-                stats_emit(ep, N, 2 * st_seg_off + comp * N + cl, comp, cl, t);
+                stats_emit(ep, 2 * st_seg_off + comp * N + cl, t);
             }
             __syncthreads();
         }
@@ -311,7 +310,6 @@ __global__ __launch_bounds__(512, 2) void conv_stem2d_kernel(const unsigned shor
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    stats_slots_zero(ep, 64, tid, 512);
     const int Hi = 2 * Ho, Wi = 2 * Wo;
     const buf_rsrc rsrc_x = make_buf_rsrc(X, x_bytes), rsrc_w = make_buf_rsrc(Wt, (unsigned)kS2WB);
     const int tiles_x = Wo >> 4, tiles_img = tiles_x * (Ho >> 4);
@@ -389,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem2d_kernel(const unsigned shor
                 float t = 0.f;
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) t += red[((wn_ * 4 + w4) * 2 + comp) * 32 + c];
-                stats_emit(ep, N, 2 * st_seg_off + comp * N + cl, comp, cl, t);
+                stats_emit(ep, 2 * st_seg_off + comp * N + cl, t);
             }
             __syncthreads();
         }

@@ -193,53 +193,26 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return t;
 }
 
-// ---- bit-reproducible cross-workgroup sums (round 4) ---------------------------------------------------------------------
-// Kernels that reduce over rows spread across workgroups (the fused BatchNorm sums of the convolution store passes, colreduce_kernel, the
-// stem's pool reduction) leave ONE row of partial sums per workgroup in a workspace - `slots`, [rows][npairs][C], a pair = (segment,
-// component) - instead of adding them into the totals with fp32 atomics in arrival order.  slots_totals adds the rows up in an order that
-// depends on nothing but (rows, npairs): RG = 16 (npairs 4) or 32 (npairs 2) interleaved chains (rows rg, rg + RG, ...) per element, joined
-// by a fixed pairwise tree.  One 256-thread workgroup covers the 16 channels [c0, c0 + 16) of every pair with float4 loads; on return
-// red[0][pair * 16 + c] holds the total of (pair, c0 + c).  `red` = float[32][64] of LDS.
-__device__ __forceinline__ void slots_totals(const float* __restrict__ slots, int rows, int C, int npairs, int c0, float (*red)[64]) {
-    const int P4 = npairs * 4, RG = 256 / P4;
-    const int pq = (int)threadIdx.x % P4, rg = (int)threadIdx.x / P4;
-    const int n = npairs * C;
-    const float* src = slots + (pq >> 2) * C + c0 + (pq & 3) * 4;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    if (c0 + (pq & 3) * 4 < C) {   // (C is a multiple of 8: the last workgroup may cover 8 channels only)
-        // 8 row loads in flight per thread (the rows were written by workgroups all over the chip: every load is an L2 miss, and this kernel
-        // sits between a convolution and the BatchNorm pass that waits for it), added in row order
-        constexpr int U = 8;
-        for (int r = rg; r < rows; r += RG * U) {
-            f32x4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ru = r + u * RG;
-                v[u] = ru < rows ? *reinterpret_cast<const f32x4*>(src + (size_t)ru * n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) t0 += v[u][0], t1 += v[u][1], t2 += v[u][2], t3 += v[u][3];
-        }
-    }
-    red[rg][pq * 4 + 0] = t0, red[rg][pq * 4 + 1] = t1, red[rg][pq * 4 + 2] = t2, red[rg][pq * 4 + 3] = t3;
-    __syncthreads();
-    float tot = 0.f;
-    if ((int)threadIdx.x < npairs * 16) {
-        float u[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) u[i] = i < RG ? red[i][threadIdx.x] : 0.f;
-#pragma unroll
-        for (int w = 16; w >= 1; w >>= 1)
-#pragma unroll
-            for (int i = 0; i < w; ++i) u[i] += u[i + w];
-        tot = u[0];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < npairs * 16) red[0][threadIdx.x] = tot;
-    __syncthreads();
+// ---- bit-reproducible cross-workgroup sums (round 4): fixed point + INTEGER atomics ------------------------------------------------
+// A BatchNorm statistic is a sum over rows spread across hundreds of workgroups.  Rounds 2 - 3 added the workgroups' fp32 partial sums
+// into the total with fp32 atomics: the order of arrival decided the last bits, and a training step did not repeat.  Integer addition
+// commutes, so each fp32 partial t is split - a pure function of t - into two 64-bit integers, hi = rint(t 2^12) and lo = rint((t - hi
+// 2^-12) 2^60), and both are added with 64-bit integer atomics into an lp_fxsum {hi, lo} per value: whatever the order, the same bits.
+// The consumer reads value = hi 2^-12 + lo 2^-60.  Range |sum| < 2^50 (1e15; a partial beyond it saturates), resolution 2^-61 (4e-19) per
+// partial: a partial of 1e-10 or more is represented EXACTLY (its 24 bits lie above 2^-60), smaller ones to 4e-19 absolute - far inside
+// fp32 atomics' own rounding.  Costs what the atomics cost (two 8-byte ones per value instead of a 4-byte one + the d beta / d gamma one),
+// no workspace, no extra launch.  (The first form of round 4 - one row of partial sums per workgroup + an ordered reduction launch - was
+// bit-reproducible too and 1.4 % slower per step: ~110 more small launches on the critical path, profiles/r04i_bench_*.)
+__device__ __forceinline__ void fx_add(lp_fxsum* p, float t) {
+    double td = (double)t;
+    td = fmin(fmax(td, -0x1p49), 0x1p49);                         // (saturate: hi stays inside 2^61)
+    const double h = rint(td * 0x1p12);
+    const long long hi = (long long)h;
+    const long long lo = (long long)rint((td - h * 0x1p-12) * 0x1p60);   // |remainder| <= 2^-13: |lo| <= 2^47
+    atomicAdd(reinterpret_cast<unsigned long long*>(&p->hi), (unsigned long long)hi);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&p->lo), (unsigned long long)lo);
 }
-// sums[pair][c] += total of the slot rows; acc0 / acc1 (optional) += the totals of component 0 / 1 over all segments (bn.hip)
-void launch_stats_slots_reduce(const float* slots, int rows, int nseg, int C, float* sums, float* acc0, float* acc1, hipStream_t st);
+__device__ __forceinline__ float fx_value(const lp_fxsum* p) { return (float)((double)p->hi * 0x1p-12 + (double)p->lo * 0x1p-60); }
 
 // ---- host-side launch epilogue ------------------------------------------------------------------
 inline int launch_status() {

@@ -224,8 +224,7 @@ class Engine:
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
         self._wgrad_ws: torch.Tensor | None = None  # split-K partial tiles of the weight-gradient kernels
-        self._bn_ws: torch.Tensor | None = None     # per-workgroup rows of the fused BatchNorm reductions (summed in workgroup order)
-        self._red_ws: torch.Tensor | None = None    # the same for the stand-alone reductions
+        self._red_ws: torch.Tensor | None = None    # per-workgroup rows of the stand-alone BatchNorm reductions
         self._side = None                            # side stream of the weight-gradient launches (created on first use)
         self._side_busy = False
         self._side_keep: list = []                   # operands of the side-stream launches in flight (released at the join)
@@ -240,6 +239,12 @@ class Engine:
             self._zero_off += (n + 3) // 4 * 4   # (16-B aligned pieces)
             return t
         return torch.zeros(n, device=self.device, dtype=torch.float32)
+
+    def _zeros_fx(self, n: int) -> torch.Tensor:
+        """n zeroed fixed-point sums (include/lp_hip.h: lp_fxsum = two int64 words each) as an int64 tensor of 2 n words: the targets of
+        every BatchNorm reduction.  Integer addition commutes, so the totals - and an all-reduce over them - do not depend on the order
+        workgroups or ranks arrive in."""
+        return self._zeros_f32(4 * n).view(torch.int64)
 
     def _timed(self, tag: str, flops: float, fn, nbytes: float = 0.0):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream.  ``nbytes``: the launch's
@@ -410,41 +415,31 @@ class Engine:
         Wo = (Wi + 2 * c.pad - c.k) // c.stride + 1
         return _lib.ConvGeom(B, Hi, Wi, c.Ci, Ho, Wo, c.Co, c.k, c.k, c.stride, c.pad)
 
-    def _reduce_ws(self, nbytes: int) -> torch.Tensor:
-        """Scratch rows of the stand-alone reductions (lp_bn_stats, lp_bn_bwd_reduce, lp_bn_pool_bwd_reduce): one buffer, reused in
-        stream order like the fused launches' workspace."""
-        if getattr(self, "_red_ws", None) is None or self._red_ws.numel() < nbytes:   # (ViTEngine shares this head code with its own __init__)
-            self._red_ws = torch.empty(max(nbytes, 4 << 20), device=self.device, dtype=torch.uint8)
+    def _reduce_ws(self, M: int, C_: int) -> torch.Tensor:
+        """Scratch rows of the stand-alone reductions (lp_bn_stats, lp_bn_bwd_reduce): one buffer, reused in stream order"""
+        need = int(self._lib.lp_bn_reduce_workspace_bytes(M, C_))
+        if getattr(self, "_red_ws", None) is None or self._red_ws.numel() < need:   # (ViTEngine shares the head code with its own __init__)
+            self._red_ws = torch.empty(max(need, 4 << 20), device=self.device, dtype=torch.uint8)
         return self._red_ws
 
-    def _bn_fuse(self, g: _lib.ConvGeom, dgrad: bool, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None,
-                 mask_from_z: bool = False, relu_bits=None, seg: int = 0, defer: bool = False) -> _lib.BnFuse:
-        """lp_bn_fuse for one launch; the workspace (one row of partial sums per workgroup) is one scratch buffer reused by every launch
-        of the stream.  ``defer``: leave the rows for lp_bn_finalize_slots (forward without SyncBatchNorm: reduction + finalize in one
-        launch) instead of reducing them into ``sums`` inside the call."""
-        need = int(self._lib.lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad)))
-        if self._bn_ws is None or self._bn_ws.numel() < need:
-            self._bn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
-        ws = self._bn_ws
+    def _bn_fuse(self, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None, mask_from_z: bool = False,
+                 relu_bits=None, seg: int = 0) -> _lib.BnFuse:
+        """lp_bn_fuse for one launch: ``sums`` alone = the forward form ([sum z, sum z^2] of the output); with ``b`` / ``z`` / ``mean`` /
+        ``invstd`` the backward form ([sum dz, sum dz * xhat] of the gradient the launch produces)."""
         f = _lib.BnFuse()
-        f.sums, f.workspace, f.workspace_bytes = sums.data_ptr(), ws.data_ptr(), need
+        f.sums = sums.data_ptr()
         f.seg_images = seg
-        f.defer_reduce = int(defer)
-        if dgrad:
+        if b is not None:
             f.z, f.mean, f.invstd = z.data_ptr(), mean.data_ptr(), invstd.data_ptr()
             f.gamma, f.beta = self.param_view(b, "weight").data_ptr(), self.param_view(b, "bias").data_ptr()
             f.mask_from_z = int(mask_from_z)
             f.relu_bits = relu_bits.data_ptr() if relu_bits is not None else None
-            f.dbeta_acc, f.dgamma_acc = self.G[b.b_off:].data_ptr(), self.G[b.g_off:].data_ptr()
         return f
 
     def _conv_fwd(self, c: ConvP, x: torch.Tensor, B: int, Hi: int, Wi: int, sums: torch.Tensor | None = None, seg: int = 0):
-        """``sums`` (segments,2,Co): also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics pass, fused);
-        ``seg`` > 0: images [0, seg) and [seg, B) are two BatchNorm segments with their own sums.  Without SyncBatchNorm the sums stay
-        in the launch's per-workgroup rows (``self._slots`` = (workspace, rows) for the _bn_moments call that follows)."""
+        """``sums`` (segments,2,Co) fixed point: also accumulate [sum z, sum z^2] of the output there (the next BatchNorm's statistics
+        pass, fused); ``seg`` > 0: images [0, seg) and [seg, B) are two BatchNorm segments with their own sums."""
         g = self._geom(c, B, Hi, Wi)
-        self._slots = None
-        defer = sums is not None and not self.sync_bn
         out = torch.empty(B, g.Ho, g.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
         w = self.Wb[c.w_off:]
         st = ops._stream()
@@ -452,18 +447,16 @@ class Engine:
             if sums is None:
                 run = lambda: check(self._lib.lp_stem_fwd(_p(x), _p(w), C.byref(g), _p(out), st), "lp_stem_fwd")  # noqa: E731
             else:
-                f = self._bn_fuse(g, False, sums, seg=seg, defer=defer)
+                f = self._bn_fuse(sums, seg=seg)
                 run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
             self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run, self._bytes(c, g))
         else:
             if sums is None:
                 run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
             else:
-                f = self._bn_fuse(g, False, sums, seg=seg, defer=defer)
+                f = self._bn_fuse(sums, seg=seg)
                 run = lambda: check(self._lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_conv_fwd_bn")  # noqa: E731
             self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run, self._bytes(c, g))
-        if defer and f.slot_rows > 0:
-            self._slots = (self._bn_ws, int(f.slot_rows))
         return out, g
 
     @staticmethod
@@ -477,22 +470,20 @@ class Engine:
         what a parity class of the stride-2 data gradients covers) decides, every other map is 4^k times larger."""
         return n0 > 0 and H % 32 == 0 and W % 32 == 0 and (n0 * (H // 32) * (W // 32)) % 128 == 0
 
-    def _sync_stats(self, t: torch.Tensor, C_: int) -> None:
-        """SUM of one SyncBatchNorm message ((segments, 2, C) fp32) over the ranks, in place (reference: ``sync_batchnorm=True``,
-        train.py:427): an all-reduce, or - LP_SYNCBN_GATHER=1 - the one-shot form: all-gather the ranks' sums into per-rank rows, then add
-        the rows in RANK order with the library's ordered reduction (lp_bn_slots_reduce: one launch, the same bits on every rank whatever
-        the collective's internal order)."""
+    def _sync_stats(self, t: torch.Tensor) -> None:
+        """SUM of one SyncBatchNorm message ((segments, 2, C) fixed-point sums = int64 words) over the ranks, in place (reference:
+        ``sync_batchnorm=True``, train.py:427).  Integer sums: every rank ends with the same bits whatever order the collective adds in.
+        An all-reduce, or - LP_SYNCBN_GATHER=1 - the one-shot form: all-gather the ranks' messages, add the rows locally."""
         if self.sync_bn_gather:
             if not t.is_contiguous():
-                raise ValueError("a SyncBatchNorm message must be a contiguous buffer (the reduction writes through its pointer)")
+                raise ValueError("a SyncBatchNorm message must be a contiguous buffer (the sum is written back through it)")
             world, n = dist.get_world_size(self.process_group), t.numel()
             if self._gather_buf is None or self._gather_buf.numel() < world * n:   # sized once for the widest layer, two segments
-                widest = max([2 * b.C for b in self.plan.bns] + [2 * self.plan.stem_bn.C]) * 2
+                widest = max([2 * b.C for b in self.plan.bns] + [2 * self.plan.stem_bn.C]) * 2 * 2
                 self._gather_buf = torch.empty(world * max(n, widest), device=t.device, dtype=t.dtype)
             flat = self._gather_buf[:world * n]
             dist.all_gather_into_tensor(flat, t.reshape(-1), group=self.process_group)   # (flat output: the form gloo and RCCL both take)
-            t.zero_()
-            check(self._lib.lp_bn_slots_reduce(_p(flat), world, n // (2 * C_), C_, _p(t), None, None, ops._stream()), "lp_bn_slots_reduce")
+            torch.sum(flat.view(world, n), dim=0, out=t.view(-1))
         else:
             dist.all_reduce(t, group=self.process_group)
 
@@ -505,23 +496,18 @@ class Engine:
         mean = torch.empty(len(segs) * b.C, device=self.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         if training:
-            slots = getattr(self, "_slots", None) if have_sums else None
-            self._slots = None
             if not have_sums:
-                ws = self._reduce_ws(int(self._lib.lp_bn_reduce_workspace_bytes(M, b.C)))
+                rws = self._reduce_ws(M, b.C)
                 for si, (i0, n) in enumerate(segs):
-                    check(self._lib.lp_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 2 * b.C:]), _p(ws), ws.numel(), ops._stream()),
+                    check(self._lib.lp_bn_stats(_p(z[i0:i0 + n]), n * rpi, b.C, _p(sums[si * 4 * b.C:]), _p(rws), rws.numel(), ops._stream()),
                           "lp_bn_stats")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:  # ONE message carries every segment's [sum, sum of squares]
-                self._sync_stats(sums, b.C)
+                self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
-            if slots is not None:   # the convolution left per-workgroup rows: ordered reduction + finalize in ONE launch
-                check(self._lib.lp_bn_finalize_slots(_p(slots[0]), slots[1], len(segs), counts[0], counts[-1], b.C, BN_EPS, BN_MOMENTUM,
-                                                     _p(mean), _p(invstd), rm, rv, None, ops._stream()), "lp_bn_finalize_slots")
-            elif len(segs) == 1:
+            if len(segs) == 1:
                 check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
                       "lp_bn_finalize")
             else:
@@ -599,10 +585,10 @@ class Engine:
             hs, ws = h // 2, w // 2
             g = self._geom(c, B, hs, ws)
             x_small = T[f"head.in{li}"]
-            bsum = self._zeros_f32(2 * CPAD)
-            rws = self._reduce_ws(int(self._lib.lp_bn_reduce_workspace_bytes(B * h * w, CPAD)))
+            bsum = self._zeros_fx(2 * CPAD)
+            rws = self._reduce_ws(B * h * w, CPAD)
             check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), _p(rws), rws.numel(), ops._stream()), "lp_bn_stats(bias)")
-            self.G[c.bias_off:c.bias_off + CPAD] += bsum[:CPAD]
+            check(self._lib.lp_fxsum_accumulate(_p(bsum), CPAD, _p(self.G[c.bias_off:]), ops._stream()), "lp_fxsum_accumulate")
             self._wgrad(dcur, x_small, g, self.G[c.w_off:])
             dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
             check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
@@ -642,12 +628,12 @@ class Engine:
         plan = self.plan
         nseg = 2 if seg else 1
         n_bn = sum(2 * b.C for b in plan.bns) * nseg
-        sums_all = torch.zeros(n_bn, device=self.device, dtype=torch.float32)
+        sums_all = torch.zeros(2 * n_bn, device=self.device, dtype=torch.int64)   # fixed-point sums: two int64 words each (lp_fxsum)
         so = [0]
 
         def next_sums(b: BNP) -> torch.Tensor:
-            s = sums_all[so[0]:so[0] + 2 * b.C * nseg]
-            so[0] += 2 * b.C * nseg
+            s = sums_all[so[0]:so[0] + 4 * b.C * nseg]
+            so[0] += 4 * b.C * nseg
             return s
 
         x4 = torch.empty(B, H, W, 4, device=self.device, dtype=torch.bfloat16)
@@ -780,33 +766,37 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------------ backward
     def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None, seg: int = 0):
-        """``sums``: the (segments,2,C) reductions [sum dy, sum dy*xhat] when the dgrad that produced ``dy`` already made them."""
+        """``sums``: the (segments,2,C) fixed-point reductions [sum dy, sum dy*xhat] when the dgrad that produced ``dy`` already made them.
+        The apply launch also adds THIS rank's sums into d beta / d gamma (they are the parameter gradients)."""
         B = z.shape[0]
         rpi = M // B
         segs = self._segments(B, seg)
         Cn = b.C
         if sums is None:
-            sums = self._zeros_f32(len(segs) * 2 * Cn)
-            ws = self._reduce_ws(int(self._lib.lp_bn_reduce_workspace_bytes(M, Cn)))
+            sums = self._zeros_fx(len(segs) * 2 * Cn)
+            rws = self._reduce_ws(M, Cn)
             for si, (i0, n) in enumerate(segs):
                 check(self._lib.lp_bn_bwd_reduce(_p(dy[i0:i0 + n]), _p(y_out[i0:i0 + n]) if y_out is not None else None, _p(z[i0:i0 + n]),
-                                                 _p(mean[si * Cn:]), _p(invstd[si * Cn:]), n * rpi, Cn, _p(sums[si * 2 * Cn:]),
-                                                 _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), _p(ws), ws.numel(), ops._stream()), "lp_bn_bwd_reduce")
+                                                 _p(mean[si * Cn:]), _p(invstd[si * Cn:]), n * rpi, Cn, _p(sums[si * 4 * Cn:]), _p(rws), rws.numel(),
+                                                 ops._stream()), "lp_bn_bwd_reduce")
         world = 1
+        local, total = sums, sums
         if not self._bwd_training:
             # eval-mode BatchNorm (running statistics) is a fixed per-channel affine map: dz = dy * gamma * invstd, without the
-            # batch-statistics correction terms (d gamma / d beta above are the same sums in both modes)
-            sums = torch.zeros_like(sums)
+            # batch-statistics correction terms (d gamma / d beta are the same sums in both modes)
+            total = None
         elif self.sync_bn:
-            self._sync_stats(sums, Cn)
+            local = sums.clone()
+            self._sync_stats(sums)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if want_dres else None
         gam = _p(self.param_view(b, "weight"))
         counts = [float(n * rpi * world) for _, n in segs]
-        check(self._lib.lp_bn_bwd_apply_seg(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(sums), counts[0], counts[-1], M, Cn,
-                                            seg * rpi, _p(dz), _p(dres), ops._stream()), "lp_bn_bwd_apply_seg")
+        check(self._lib.lp_bn_bwd_apply_seg(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(total), counts[0], counts[-1], M, Cn,
+                                            seg * rpi, _p(dz), _p(dres), _p(local), _p(self.G[b.b_off:]), _p(self.G[b.g_off:]),
+                                            ops._stream()), "lp_bn_bwd_apply_seg")
         return dz, dres
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
@@ -831,8 +821,7 @@ class Engine:
             b, z, mean, invstd, sums = bn
             if relu_bits is not None:
                 relu_mask = None  # the 1-bit form replaces the activation tensor as the mask source
-            f = self._bn_fuse(g, True, sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None,
-                              relu_bits=relu_bits, seg=seg, defer=True)
+            f = self._bn_fuse(sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None, relu_bits=relu_bits, seg=seg)
             run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
                                                            C.byref(f), st), "lp_conv_dgrad_bn")
         else:
@@ -844,11 +833,6 @@ class Engine:
         extra = (dx_bytes if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
                 (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0)
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
-        if bn is not None and f.slot_rows > 0:
-            # the store passes left one row of partial sums per workgroup: the ordered reduction into `sums` (and d beta / d gamma) is
-            # BatchNorm's launch, issued here - outside the convolution's timed bracket - right in front of the lp_bn_bwd_apply that reads it
-            check(self._lib.lp_bn_slots_reduce(_p(self._bn_ws), int(f.slot_rows), 2 if seg else 1, b.C, _p(sums), _p(self.G[b.b_off:]),
-                                               _p(self.G[b.g_off:]), st), "lp_bn_slots_reduce")
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -862,7 +846,7 @@ class Engine:
         nseg = 2 if seg else 1
         # One zeroed arena for every reduction target of this pass: the sums of each BatchNorm backward (fused into a data gradient or
         # not), the head's bias sums, the stem's.
-        self._zero_arena = torch.zeros((sum(2 * b.C for b in plan.bns) + 2 * plan.stem_bn.C) * nseg + 2 * CPAD * len(plan.head) + 64,
+        self._zero_arena = torch.zeros(4 * ((sum(2 * b.C for b in plan.bns) + 2 * plan.stem_bn.C) * nseg + 2 * CPAD * len(plan.head)) + 64,
                                        device=self.device, dtype=torch.float32)
         self._zero_off = 0
         try:
@@ -879,7 +863,7 @@ class Engine:
             progress(plan.n_backbone)  # the head's gradients (the tail of the flat buffer) are complete
 
         def new_sums(b: BNP) -> torch.Tensor:
-            return self._zeros_f32(2 * b.C * nseg)
+            return self._zeros_fx(2 * b.C * nseg)
 
         d_sums = None  # reductions of the current block's bn3 backward, when the dgrad that produced `d` already made them
         for i in range(len(plan.blocks) - 1, -1, -1):
@@ -936,26 +920,27 @@ class Engine:
         # is rebuilt on the fly from the pooled gradient and the arg-max bytes, the ReLU gate from z
         sb = plan.stem_bn
         segs = self._segments(B, seg)
-        ssum = self._zeros_f32(nseg * 2 * sb.C)
+        ssum = self._zeros_fx(nseg * 2 * sb.C)
         gam, bet = self.param_view(sb, "weight"), self.param_view(sb, "bias")
         arg, sz, smu, siv = T["pool.arg"], T["stem.z"], T["stem.mu"], T["stem.iv"]
-        ws = self._reduce_ws(int(self._lib.lp_bn_pool_bwd_workspace_bytes(B, sh, sw, 64)))
         for si, (i0, n) in enumerate(segs):
             check(self._lib.lp_bn_pool_bwd_reduce(_p(arg[i0:i0 + n]), _p(d[i0:i0 + n]), _p(sz[i0:i0 + n]), _p(smu[si * sb.C:]), _p(siv[si * sb.C:]),
-                                                  _p(gam), _p(bet), n, sh, sw, 64, _p(ssum[si * 2 * sb.C:]), _p(self.G[sb.b_off:]),
-                                                  _p(self.G[sb.g_off:]), _p(ws), ws.numel(), ops._stream()), "lp_bn_pool_bwd_reduce")
+                                                  _p(gam), _p(bet), n, sh, sw, 64, _p(ssum[si * 4 * sb.C:]), ops._stream()), "lp_bn_pool_bwd_reduce")
         world = 1
+        slocal, stotal = ssum, ssum
         if not self._bwd_training:
-            ssum = torch.zeros_like(ssum)
+            stotal = None
         elif self.sync_bn:
-            self._sync_stats(ssum, sb.C)
+            slocal = ssum.clone()
+            self._sync_stats(ssum)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty(B, sh, sw, 64, device=self.device, dtype=torch.bfloat16)
         for si, (i0, n) in enumerate(segs):
             check(self._lib.lp_bn_pool_bwd_apply(_p(arg[i0:i0 + n]), _p(d[i0:i0 + n]), _p(sz[i0:i0 + n]), _p(smu[si * sb.C:]), _p(siv[si * sb.C:]),
-                                                 _p(gam), _p(bet), _p(ssum[si * 2 * sb.C:]), float(n * sh * sw * world), n, sh, sw, 64,
-                                                 _p(dz[i0:i0 + n]), ops._stream()), "lp_bn_pool_bwd_apply")
+                                                 _p(gam), _p(bet), _p(stotal[si * 4 * sb.C:]) if stotal is not None else None,
+                                                 float(n * sh * sw * world), n, sh, sw, 64, _p(dz[i0:i0 + n]), _p(slocal[si * 4 * sb.C:]),
+                                                 _p(self.G[sb.b_off:]), _p(self.G[sb.g_off:]), ops._stream()), "lp_bn_pool_bwd_apply")
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
                     lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True), self._bytes(plan.stem, g, wgrad=True))

@@ -76,16 +76,13 @@ class Fp32Engine(Engine):
                                                         self._stats_ws.numel(), ops._stream()), "lp_f32_bn_stats_ordered")
             counts = [float(n * rpi) for _, n in segs]
             if self.sync_bn:
-                self._sync_stats(sums, b.C)
+                self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
-            if len(segs) == 1:
-                check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
-                      "lp_bn_finalize")
-            else:
-                check(self._lib.lp_bn_finalize2(_p(sums), counts[0], counts[1], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv,
-                                                ops._stream()), "lp_bn_finalize2")
+            for si in range(len(segs)):   # segment 0's running-statistics update, then segment 1's (the reference's two forward calls)
+                check(self._lib.lp_bn_finalize_f32(_p(sums[si * 2 * b.C:]), counts[si], b.C, BN_EPS, BN_MOMENTUM, _p(mean[si * b.C:]),
+                                                   _p(invstd[si * b.C:]), rm, rv, ops._stream()), "lp_bn_finalize_f32")
         else:
             mean.copy_(self.running_view(b, "running_mean"))
             invstd.copy_((self.running_view(b, "running_var") + BN_EPS).rsqrt())
@@ -113,7 +110,7 @@ class Fp32Engine(Engine):
         if not self._bwd_training:
             sums = torch.zeros_like(sums)  # eval-mode BatchNorm: a fixed affine map, no batch-statistics terms
         elif self.sync_bn:
-            self._sync_stats(sums, Cn)
+            self._sync_stats(sums)
             self.sync_bn_messages += 1
             world = dist.get_world_size(self.process_group)
         dz = torch.empty_like(z)

@@ -161,7 +161,6 @@ class ViTEngine(Engine):
         self._bwd_training = True
         self.profile = None
         self._wgrad_ws = None
-        self._bn_ws = None
         self._side, self._side_busy, self._side_keep = None, False, []
         self._fold = None
         self._interp: dict[tuple[int, int], torch.Tensor] = {}

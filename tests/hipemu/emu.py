@@ -267,77 +267,76 @@ def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, 
     return ob.np(), (of.np() if of is not None else None)
 
 
-def _bn_fuse(g, dgrad, Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, want_acc=False, relu_bits=None, seg=0):
+def ZX(shape):
+    """zeroed fixed-point sums (include/lp_hip.h: lp_fxsum = {int64 hi, int64 lo}) of the given value shape"""
+    return Z(tuple(shape) + (2,), np.int64)
+
+
+def fx(raw: np.ndarray) -> np.ndarray:
+    """the values of raw lp_fxsum words (..., 2) as fp32: hi * 2^-12 + lo * 2^-60 (lp_common.h: fx_value)"""
+    return (raw[..., 0].astype(np.float64) * 2.0 ** -12 + raw[..., 1].astype(np.float64) * 2.0 ** -60).astype(np.float32)
+
+
+def to_fx(v) -> np.ndarray:
+    """fp32 values -> lp_fxsum words (..., 2), the split fx_add makes: hi = round(v * 2^12), lo = round((v - hi * 2^-12) * 2^60)"""
+    v = np.asarray(v, np.float64)
+    hi = np.rint(v * 2.0 ** 12)
+    lo = np.rint((v - hi * 2.0 ** -12) * 2.0 ** 60)
+    return np.stack([hi, lo], -1).astype(np.int64)
+
+
+def _bn_fuse(Cn, z=None, mean=None, invstd=None, gamma=None, beta=None, mask_from_z=0, relu_bits=None, seg=0):
     """lp_bn_fuse + the buffers it points at (kept alive on the returned object).  seg > 0: two BatchNorm segments (images [0, seg)
     and the rest): sums is (2, 2, Cn), mean / invstd are (2, Cn)."""
     f = _lib.BnFuse()
     f.seg_images = seg
     f.keep = dict(z=B(z), mean=B(mean, np.float32), invstd=B(invstd, np.float32), gamma=B(gamma, np.float32), beta=B(beta, np.float32),
-                  sums=Z((2, 2, Cn) if seg else (2, Cn)), dbeta=Z(Cn) if want_acc else None, dgamma=Z(Cn) if want_acc else None)
-    nws = lib().lp_conv_bn_workspace_bytes(C.byref(g), int(dgrad))
-    f.keep["ws"] = Buf(np.full(nws // 4, np.nan, np.float32))  # poisoned: every partial that is read must have been written
+                  sums=ZX((2, 2, Cn) if seg else (2, Cn)))
     k = f.keep
     f.z, f.mean, f.invstd, f.gamma, f.beta = (ptr(k[n]).value if k[n] is not None else None for n in ("z", "mean", "invstd", "gamma", "beta"))
     f.mask_from_z = int(mask_from_z)
     k["bits"] = B(relu_bits)
     f.relu_bits = k["bits"].p.value if relu_bits is not None else None
     f.sums = k["sums"].p.value
-    f.dbeta_acc = k["dbeta"].p.value if want_acc else None
-    f.dgamma_acc = k["dgamma"].p.value if want_acc else None
-    f.workspace, f.workspace_bytes = k["ws"].p.value, nws
     return f
 
 
-def conv_fwd_bn_deferred(x_nhwc_bits, w_bits, g, seg=0):
-    """lp_conv_fwd_bn with lp_bn_fuse.defer_reduce = 1 -> (z bits, the fuse object: .slot_rows rows of partial sums in .keep["ws"])"""
+def conv_fwd_bn(x_nhwc_bits, w_bits, g, seg=0, rc=False, raw=False):
+    """-> (z bits, sums (2,Co) or (2,2,Co) with seg); rc=True: return the status code instead of asserting it; raw=True: the sums as
+    their fixed-point words (..., 2) int64 instead of fp32 values"""
     xb, wb, ob = Buf(x_nhwc_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
-    f = _bn_fuse(g, False, g.Co, seg=seg)
-    f.defer_reduce = 1
-    ok(lib().lp_conv_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
-    return ob.np(), f
-
-
-def bn_finalize_slots(f, counts, Cn, running, eps=1e-5, momentum=0.1):
-    """lp_bn_finalize_slots on the rows a deferred launch left -> (mean, invstd, running_mean, running_var, raw sums), each per segment"""
-    nseg = len(counts)
-    mean, invstd, sums = Z((nseg, Cn)), Z((nseg, Cn)), Z((nseg, 2, Cn))
-    rm, rv = Buf(running[0]), Buf(running[1])
-    ok(lib().lp_bn_finalize_slots(f.keep["ws"].p, int(f.slot_rows), nseg, float(counts[0]), float(counts[-1]), Cn, eps, momentum, mean.p,
-                                  invstd.p, rm.p, rv.p, sums.p, stream()))
-    return mean.np(), invstd.np(), rm.np(), rv.np(), sums.np()
-
-
-def conv_fwd_bn(x_nhwc_bits, w_bits, g, seg=0, rc=False):
-    """-> (z bits, sums (2,Co) or (2,2,Co) with seg); rc=True: return the status code instead of asserting it"""
-    xb, wb, ob = Buf(x_nhwc_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, g.Co), np.uint16)
-    f = _bn_fuse(g, False, g.Co, seg=seg)
+    f = _bn_fuse(g.Co, seg=seg)
     code = lib().lp_conv_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream())
     if rc:
         return code
     ok(code)
-    return ob.np(), f.keep["sums"].np()
+    words = f.keep["sums"].np()
+    return ob.np(), (words if raw else fx(words))
 
 
 def stem_fwd_bn(x4_bits, w_bits, g, seg=0):
     xb, wb, ob = Buf(x4_bits), Buf(w_bits), Z((g.B * g.Ho * g.Wo, 64), np.uint16)
-    f = _bn_fuse(g, False, 64, seg=seg)
+    f = _bn_fuse(64, seg=seg)
     ok(lib().lp_stem_fwd_bn(xb.p, wb.p, C.byref(g), ob.p, C.byref(f), stream()))
-    return ob.np(), f.keep["sums"].np()
+    return ob.np(), fx(f.keep["sums"].np())
 
 
 def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None, relu_bits=None, seg=0,
-                  rc=False):
+                  rc=False, raw=False):
     """-> (dx bits, sums (2,Ci), dbeta, dgamma); the ReLU mask comes from mask_bits (bf16 activation) or relu_bits (1 bit per
-    element) if given, else is recomputed from z.  seg > 0: mean / invstd are (2, Ci), sums comes back (2, 2, Ci)."""
+    element) if given, else is recomputed from z.  seg > 0: mean / invstd are (2, Ci), sums comes back (2, 2, Ci).  d beta / d gamma are
+    the sums themselves added over the segments (the library adds them into the gradient buffer in lp_bn_bwd_apply: bn_backward)."""
     db, wb, ab, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(mask_bits)
     ob = Z((g.B * g.Hi * g.Wi, g.Ci), np.uint16)
-    f = _bn_fuse(g, True, g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None and relu_bits is None, want_acc=True,
-                 relu_bits=relu_bits, seg=seg)
+    f = _bn_fuse(g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None and relu_bits is None, relu_bits=relu_bits, seg=seg)
     code = lib().lp_conv_dgrad_bn(db.p, wb.p, C.byref(g), ptr(ab), ptr(mb), ob.p, C.byref(f), stream())
     if rc:
         return code
     ok(code)
-    return ob.np(), f.keep["sums"].np(), f.keep["dbeta"].np(), f.keep["dgamma"].np()
+    words = f.keep["sums"].np()
+    vals = fx(words)
+    tot = vals.reshape(-1, 2, g.Ci).sum(0)
+    return ob.np(), (words if raw else vals), tot[0], tot[1]
 
 
 def gemm_nt(a_bits, lda, b_bits, ldb, M, N, K, ldc, c_rows, n_store=0, bias=None, batch=None, f32_out=False):
@@ -422,12 +421,27 @@ def stem_wgrad(x4_bits, dy_bits, g, split=0):
     return dw.np()
 
 
+def _reduce_ws(M, Cn):
+    """workspace of lp_bn_stats / lp_bn_bwd_reduce, poisoned: every partial that is read must have been written"""
+    nws = lib().lp_bn_reduce_workspace_bytes(M, Cn)
+    ws = Buf(np.full(nws // 4, np.nan, np.float32))
+    ws.nbytes = nws
+    return ws
+
+
+def bn_stats(x_bits, M, Cn, raw=False):
+    """lp_bn_stats -> [sum x, sum x^2] (2, Cn)"""
+    xb, sums = Buf(x_bits), ZX((2, Cn))
+    ws = _reduce_ws(M, Cn)
+    ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, ws.p, ws.nbytes, stream()))
+    return sums.np() if raw else fx(sums.np())
+
+
 def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False):
     xb, rb = Buf(x_bits), B(residual_bits)
-    sums, mean, invstd = Z((2, Cn)), Z(Cn), Z(Cn)
-    nws = lib().lp_bn_reduce_workspace_bytes(M, Cn)
-    ws = Buf(np.full(nws // 4, np.nan, np.float32))  # poisoned: every partial that is read must have been written
-    ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, ws.p, nws, stream()))
+    sums, mean, invstd = ZX((2, Cn)), Z(Cn), Z(Cn)
+    ws = _reduce_ws(M, Cn)
+    ok(lib().lp_bn_stats(xb.p, M, Cn, sums.p, ws.p, ws.nbytes, stream()))
     rm = Buf(running[0]) if running is not None else None
     rv = Buf(running[1]) if running is not None else None
     ok(lib().lp_bn_finalize(sums.p, float(M), Cn, eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), stream()))
@@ -442,15 +456,18 @@ def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e
     return y.np(), mean.np(), invstd.np()
 
 
-def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False):
+def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False, eval_mode=False, acc0=None):
+    """-> (dx bits, dres bits, dgamma, dbeta): lp_bn_bwd_reduce, then lp_bn_bwd_apply (which also adds the sums into d beta / d gamma,
+    starting from ``acc0`` = (dbeta0, dgamma0) if given).  eval_mode: no batch-statistics terms (sums = NULL)."""
     db, yb, xb, mb, vb, gb = Buf(dy_bits), B(y_bits), Buf(x_bits), Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma))
-    sums, dbeta, dgamma = Z((2, Cn)), Z(Cn), Z(Cn)
-    nws = lib().lp_bn_reduce_workspace_bytes(M, Cn)
-    ws = Buf(np.full(nws // 4, np.nan, np.float32))
-    ok(lib().lp_bn_bwd_reduce(db.p, ptr(yb), xb.p, mb.p, vb.p, M, Cn, sums.p, dbeta.p, dgamma.p, ws.p, nws, stream()))
+    sums = ZX((2, Cn))
+    dbeta, dgamma = (Buf(f32(acc0[0])), Buf(f32(acc0[1]))) if acc0 is not None else (Z(Cn), Z(Cn))
+    ws = _reduce_ws(M, Cn)
+    ok(lib().lp_bn_bwd_reduce(db.p, ptr(yb), xb.p, mb.p, vb.p, M, Cn, sums.p, ws.p, ws.nbytes, stream()))
     dx = Z((M, Cn), np.uint16)
     dres = Z((M, Cn), np.uint16) if want_dres else None
-    ok(lib().lp_bn_bwd_apply(db.p, ptr(yb), xb.p, mb.p, vb.p, gb.p, sums.p, float(M), M, Cn, dx.p, ptr(dres), stream()))
+    ok(lib().lp_bn_bwd_apply(db.p, ptr(yb), xb.p, mb.p, vb.p, gb.p, None if eval_mode else sums.p, float(M), M, Cn, dx.p, ptr(dres), sums.p,
+                             dbeta.p, dgamma.p, stream()))
     return dx.np(), (dres.np() if dres is not None else None), dgamma.np(), dbeta.np()
 
 
@@ -475,17 +492,16 @@ def bn_relu_maxpool(z_bits, mean, invstd, gamma, beta, Bn, Hi, Wi, Cn):
     return y.np(), arg.np()
 
 
-def bn_pool_backward(arg_u8, dy_bits, z_bits, mean, invstd, gamma, beta, Bn, Hi, Wi, Cn):
+def bn_pool_backward(arg_u8, dy_bits, z_bits, mean, invstd, gamma, beta, Bn, Hi, Wi, Cn, raw=False):
     """-> (dz bits, dgamma, dbeta, sums) of the fused stem backward"""
     ab, db, zb = Buf(arg_u8), Buf(dy_bits), Buf(z_bits)
     mb, vb, gb, bb = Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma)), Buf(f32(beta))
-    sums, dbeta, dgamma = Z((2, Cn)), Z(Cn), Z(Cn)
-    nws = lib().lp_bn_pool_bwd_workspace_bytes(Bn, Hi, Wi, Cn)
-    ws = Buf(np.full(nws // 4, np.nan, np.float32))
-    ok(lib().lp_bn_pool_bwd_reduce(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, Bn, Hi, Wi, Cn, sums.p, dbeta.p, dgamma.p, ws.p, nws, stream()))
+    sums, dbeta, dgamma = ZX((2, Cn)), Z(Cn), Z(Cn)
+    ok(lib().lp_bn_pool_bwd_reduce(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, Bn, Hi, Wi, Cn, sums.p, stream()))
     dz = Z((Bn * Hi * Wi, Cn), np.uint16)
-    ok(lib().lp_bn_pool_bwd_apply(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, sums.p, float(Bn * Hi * Wi), Bn, Hi, Wi, Cn, dz.p, stream()))
-    return dz.np(), dgamma.np(), dbeta.np(), sums.np()
+    ok(lib().lp_bn_pool_bwd_apply(ab.p, db.p, zb.p, mb.p, vb.p, gb.p, bb.p, sums.p, float(Bn * Hi * Wi), Bn, Hi, Wi, Cn, dz.p, sums.p, dbeta.p,
+                                  dgamma.p, stream()))
+    return dz.np(), dgamma.np(), dbeta.np(), (sums.np() if raw else fx(sums.np()))
 
 
 def images_to_nhwc4(img):

@@ -174,7 +174,7 @@ def _engine_worker(rank, world, port, q, gather=False):
     calls["n"] = 0
     b0 = eng.plan.blocks[0].bn1
     zz = torch.randn(4, 6, 6, b0.C, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16)   # same on both ranks
-    sums = torch.zeros(2 * 2 * b0.C)
+    sums = torch.zeros(2 * 2 * b0.C * 2, dtype=torch.int64)   # (segments, 2, C) fixed-point sums: two int64 words each
     mu, iv = eng._bn_moments(b0, zz, 4 * 36, True, sums, have_sums=False, seg=1)
     if calls["n"] != 1:
         bad.append(f"D:{calls['n']} all-reduces for one two-segment BatchNorm layer")
@@ -192,7 +192,7 @@ def _engine_worker(rank, world, port, q, gather=False):
             if key.split(".")[-1] in ("mu", "iv", "m1", "v1", "m2", "v2", "m3", "v3", "md", "vd") and not torch.equal(tape.t[key], v):
                 bad.append(f"B:{key} not bit-identical")
         # world 2: x + x is exact.  Beyond it the gradient buckets go through gloo's / RCCL's ring, whose partial sums 3x, 5x, 7x of equal
-        # terms round (the SyncBatchNorm sums above do not: lp_bn_slots_reduce adds the ranks' rows pairwise) - equal to fp32 rounding then
+        # terms round (the SyncBatchNorm sums above do not: they are integers) - equal to fp32 rounding then
         same = torch.equal(eng.G, world * solo.G) if world == 2 else torch.allclose(eng.G, world * solo.G, rtol=2e-6, atol=1e-7 * float(solo.G.abs().max()))
         if not same:
             bad.append(f"B:summed gradient != {world} x single-process gradient (max diff {float((eng.G - world * solo.G).abs().max()):.3e})")
@@ -246,10 +246,9 @@ def _engine_worker(rank, world, port, q, gather=False):
 @pytest.mark.parametrize("world,gather", [(2, False), (2, True), (8, True)], ids=["all_reduce", "one_shot_gather", "world8_one_shot_gather"])
 def test_sync_batchnorm_engine_gloo_world2(world, gather):
     """SyncBatchNorm + summed gradients of the real engine across gloo ranks (see _engine_worker), with the messages as all-reduces and as
-    the one-shot exchange (LP_SYNCBN_GATHER=1: all-gather into per-rank rows + lp_bn_slots_reduce in rank order - the same bits on every
-    rank, and at world 2 the same bits as the all-reduce, so part (B)'s exact comparisons hold for both).  World 8 (round 4: what the
-    driver's SCALE run launches) takes the one-shot form, whose pairwise tree keeps sums of 8 equal terms exact; a ring all-reduce passes
-    through 3x, 5x, 7x, which round."""
+    the one-shot exchange (LP_SYNCBN_GATHER=1: all-gather into per-rank rows, added locally).  The messages are fixed-point sums (int64
+    words), so either form gives the same bits on every rank at any world size and part (B)'s exact comparisons hold for both.  World 8
+    (round 4: what the driver's SCALE run launches) runs the one-shot form."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -80,20 +80,6 @@ def test_stem_statistics_per_segment(kernel_backend):
         np.testing.assert_allclose(sums[si], ss, rtol=1e-5, atol=1e-4)
 
 
-def test_atomic_form_of_the_fused_sums_still_agrees(kernel_backend):
-    """LP_STATS_ATOMIC=1 (A/B timing only since round 4: the store passes add their sums into the totals with fp32 atomics instead of leaving
-    per-workgroup rows for the ordered reduction) is read per call; the kernel tests above re-run in a child with it set"""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, LP_STATS_ATOMIC="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_segmented_bn.py", "tests/test_emu_conv.py", "-q", "-x", "-m",
-                        "gpu" if kernel_backend == "gpu" else "not gpu", "-k", "fused_reductions or fused_batchnorm", "-p", "no:cacheprovider"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def _sums_case(kernel_backend, gen):
     """a launch with several tiles per workgroup AND several workgroups (LP_CONV_MAX_WGS is read per call)"""
     B, H, Ci, Co = (32, 32, 64, 256) if kernel_backend == "gpu" else (4, 16, 64, 128)
@@ -103,49 +89,76 @@ def _sums_case(kernel_backend, gen):
     return g, x, w, B, H, Co
 
 
-def test_fused_sums_repeat_bit_for_bit_and_finalize_from_the_rows(kernel_backend, monkeypatch):
-    """Round 4: every persistent workgroup leaves its sums in its own row of the workspace and the rows are added in workgroup order.
-    (a) two runs give the same BITS (on the device the old atomics did not); (b) lp_bn_finalize_slots on the rows of a deferred launch ==
-    lp_bn_finalize2 on the reduced sums, bit for bit - moments, running statistics and the raw totals."""
+def test_fused_sums_repeat_bit_for_bit(kernel_backend, monkeypatch):
+    """Round 4: the store passes add their sums into the totals in FIXED POINT with 64-bit integer atomics (lp_fxsum; lp_common.h: fx_add).
+    Integer addition commutes, so the totals do not depend on the order workgroups arrive in: repeated launches give the same BITS (the
+    fp32 atomics of rounds 2 - 3 did not on the device), and lp_bn_finalize2 turns them into the moments of the stored values."""
     gen = torch.Generator().manual_seed(11)
     g, x, w, B, H, Co = _sums_case(kernel_backend, gen)
     if kernel_backend != "gpu":
         monkeypatch.setenv("LP_CONV_MAX_WGS", "3")            # 4 tiles of 256 rows over 3 workgroups: one of them walks two
     seg = B // 4                                                  # two BatchNorm segments, boundary on a tile boundary
-    z1, s1 = emu.conv_fwd_bn(x, w, g, seg=seg)
-    z2, s2 = emu.conv_fwd_bn(x, w, g, seg=seg)
-    assert np.array_equal(z1, z2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
-    zf = emu.from_bf16_bits(z1).reshape(B, H * H, Co)
-    np.testing.assert_allclose(s1[0][0], zf[:seg].sum((0, 1)).numpy(), rtol=2e-4, atol=2e-2)
-    np.testing.assert_allclose(s1[1][1], (zf[seg:] ** 2).sum((0, 1)).numpy(), rtol=2e-4, atol=2e-2)
-    # (b) deferred rows -> one launch
-    z3, f = emu.conv_fwd_bn_deferred(x, w, g, seg=seg)
-    assert np.array_equal(z1, z3) and f.slot_rows > 1
+    runs = [emu.conv_fwd_bn(x, w, g, seg=seg, raw=True) for _ in range(6 if kernel_backend == "gpu" else 2)]
+    for z, words in runs[1:]:
+        assert np.array_equal(z, runs[0][0]) and np.array_equal(words, runs[0][1])
+    z1, words = runs[0]
+    s1 = emu.fx(words)
+    zf = emu.from_bf16_bits(z1).reshape(B, H * H, Co).double()
+    np.testing.assert_allclose(s1[0][0], zf[:seg].sum((0, 1)).numpy(), rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(s1[1][1], (zf[seg:] ** 2).sum((0, 1)).numpy(), rtol=2e-5, atol=2e-3)
     counts = (seg * H * H, (B - seg) * H * H)
     rm0, rv0 = torch.randn(Co, generator=gen).numpy(), (torch.rand(Co, generator=gen) + 0.5).numpy()
-    mean, invstd, rm, rv, raw = emu.bn_finalize_slots(f, counts, Co, (rm0, rv0))
-    assert np.array_equal(raw.view(np.uint32), s1.view(np.uint32))
-    sb, m2, v2, rm2, rv2 = emu.Buf(s1), emu.Z((2, Co)), emu.Z((2, Co)), emu.Buf(rm0), emu.Buf(rv0)
+    sb, m2, v2, rm2, rv2 = emu.Buf(words), emu.Z((2, Co)), emu.Z((2, Co)), emu.Buf(rm0), emu.Buf(rv0)
     emu.ok(emu.lib().lp_bn_finalize2(sb.p, float(counts[0]), float(counts[1]), Co, 1e-5, 0.1, m2.p, v2.p, rm2.p, rv2.p, emu.stream()))
-    for a, b in ((mean, m2.np()), (invstd, v2.np()), (rm, rm2.np()), (rv, rv2.np())):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    np.testing.assert_allclose(m2.np()[0], zf[:seg].mean((0, 1)).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(v2.np()[1], (zf[seg:].var((0, 1), unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-4)
+
+
+def test_fixed_point_sums_keep_small_and_large_terms(kernel_backend):
+    """lp_fxsum: hi counts 2^-12, lo counts 2^-60 - a column of 1e-6s next to a column of 3e4s, and a column whose terms cancel exactly"""
+    M, Cn = 4096, 8
+    x = torch.zeros(M, Cn)
+    x[:, 0] = 1e-6
+    x[:, 1] = 3e4
+    x[:, 2] = torch.where(torch.arange(M) % 2 == 0, 257.0, -257.0)
+    x[:, 3] = torch.randn(M, generator=torch.Generator().manual_seed(0))
+    xb = emu.to_bf16_bits(x)
+    xd = emu.from_bf16_bits(xb).double()
+    words = emu.bn_stats(xb, M, Cn, raw=True)
+    got = emu.fx(words)
+    np.testing.assert_allclose(got[0], xd.sum(0).numpy(), rtol=3e-6, atol=1e-12)
+    np.testing.assert_allclose(got[1], (xd * xd).sum(0).numpy(), rtol=3e-6, atol=1e-18)
+    assert got[0][2] == 0.0 and np.array_equal(words[0, 2], [0, 0])
+    assert np.array_equal(emu.bn_stats(xb, M, Cn, raw=True), words)
 
 
 def test_standalone_reductions_repeat_bit_for_bit(kernel_backend):
-    """lp_bn_stats / lp_bn_bwd_reduce: per-workgroup rows + ordered reduction (no atomics): same bits twice, d beta / d gamma = the sums"""
+    """lp_bn_stats / lp_bn_bwd_reduce (fixed-point sums): same bits twice; lp_bn_bwd_apply adds the sums into d beta / d gamma on top of
+    what is already there; sums = NULL (eval-mode BatchNorm) drops the batch-statistics terms: dx = dy * gamma * invstd"""
     gen = torch.Generator().manual_seed(12)
     M, Cn = (200_000, 256) if kernel_backend == "gpu" else (3000, 40)
     x = torch.randn(M, Cn, generator=gen)
     dy = torch.randn(M, Cn, generator=gen)
     xb, db = emu.to_bf16_bits(x), emu.to_bf16_bits(dy)
     mean, invstd = x.mean(0).numpy(), (x.var(0, unbiased=False) + 1e-5).rsqrt().numpy()
-    gamma = np.ones(Cn, np.float32)
+    gamma = (torch.rand(Cn, generator=gen) + 0.5).numpy()
     outs = [emu.bn_backward(db, None, xb, mean, invstd, gamma, M, Cn) for _ in range(2)]
     for a, b in zip(outs[0], outs[1]):
         if a is not None:
             assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
-    dyf = emu.from_bf16_bits(db)
-    np.testing.assert_allclose(outs[0][3], dyf.sum(0).numpy(), rtol=1e-4, atol=5e-2)      # d beta
+    dyf, xf = emu.from_bf16_bits(db).double(), emu.from_bf16_bits(xb).double()
+    xhat = (xf - torch.from_numpy(mean).double()) * torch.from_numpy(invstd).double()
+    np.testing.assert_allclose(outs[0][3], dyf.sum(0).numpy(), rtol=1e-5, atol=1e-3)                 # d beta
+    np.testing.assert_allclose(outs[0][2], (dyf * xhat).sum(0).numpy(), rtol=1e-4, atol=5e-3)        # d gamma
+    base = (np.full(Cn, 2.0, np.float32), np.full(Cn, -1.0, np.float32))
+    acc = emu.bn_backward(db, None, xb, mean, invstd, gamma, M, Cn, acc0=base)
+    np.testing.assert_allclose(acc[3], outs[0][3] + 2.0, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(acc[2], outs[0][2] - 1.0, rtol=1e-6, atol=1e-5)
+    ev = emu.bn_backward(db, None, xb, mean, invstd, gamma, M, Cn, eval_mode=True)
+    want = emu.to_bf16_bits((dyf * torch.from_numpy(gamma * invstd).double()).float())
+    got = emu.from_bf16_bits(ev[0]).float()
+    np.testing.assert_allclose(got.numpy(), emu.from_bf16_bits(want).numpy(), rtol=1e-2, atol=1e-6)
+    assert np.array_equal(ev[3].view(np.uint32), outs[0][3].view(np.uint32))                       # the parameter gradients do not change
 
 
 def test_segment_boundary_must_be_tile_aligned(kernel_backend):
@@ -166,7 +179,7 @@ def test_finalize_two_segments_updates_running_statistics_in_order(kernel_backen
     xs = [torch.randn(40, Cn, generator=gen) * 2 + 1, torch.randn(72, Cn, generator=gen) * 0.5 - 2]
     sums = np.stack([np.stack([x.sum(0).numpy(), (x * x).sum(0).numpy()]) for x in xs]).astype(np.float32)
     rm0, rv0 = torch.randn(Cn, generator=gen).numpy(), (torch.rand(Cn, generator=gen) + 0.5).numpy()
-    sb, mean, invstd, rm, rv = emu.Buf(sums), emu.Z((2, Cn)), emu.Z((2, Cn)), emu.Buf(rm0), emu.Buf(rv0)
+    sb, mean, invstd, rm, rv = emu.Buf(emu.to_fx(sums)), emu.Z((2, Cn)), emu.Z((2, Cn)), emu.Buf(rm0), emu.Buf(rv0)
     emu.ok(emu.lib().lp_bn_finalize2(sb.p, 40.0, 72.0, Cn, 1e-5, 0.1, mean.p, invstd.p, rm.p, rv.p, emu.stream()))
     want_rm, want_rv = torch.from_numpy(rm0.copy()), torch.from_numpy(rv0.copy())
     for si, x in enumerate(xs):                                  # what two forward calls of nn.BatchNorm2d do, in this order
@@ -201,23 +214,29 @@ def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_
     counts = (float(seg_rows), float(M - seg_rows))
     lib, st = emu.lib(), emu.stream()
     B = emu.Buf
-    mb, ib, gb, bb, sb = B(mean), B(invstd), B(gamma), B(beta), B(sums)
+    mb, ib, gb, bb, sb = B(mean), B(invstd), B(gamma), B(beta), B(emu.to_fx(sums))
+    dbj, dgj, dbs, dgs = emu.Z(Cn), emu.Z(Cn), emu.Z(Cn), emu.Z(Cn)
     xb, rb, db = B(x), B(res), B(dy)
     nb = -(-M * Cn // 8)
     # joint launches
     y, bits, dx, dres = emu.Z((M, Cn), np.uint16), emu.Z(nb, np.uint8), emu.Z((M, Cn), np.uint16), emu.Z((M, Cn), np.uint16)
     emu.ok(lib.lp_bn_apply_seg(xb.p, mb.p, ib.p, gb.p, bb.p, rb.p, 1, M, Cn, seg_rows, y.p, bits.p if Cn % 8 == 0 and (seg_rows * Cn) % 8 == 0 else None, st))
-    emu.ok(lib.lp_bn_bwd_apply_seg(db.p, y.p, xb.p, mb.p, ib.p, gb.p, sb.p, counts[0], counts[1], M, Cn, seg_rows, dx.p, dres.p, st))
+    emu.ok(lib.lp_bn_bwd_apply_seg(db.p, y.p, xb.p, mb.p, ib.p, gb.p, sb.p, counts[0], counts[1], M, Cn, seg_rows, dx.p, dres.p, sb.p, dbj.p, dgj.p, st))
     got = (y.np().copy(), dx.np().copy(), dres.np().copy())
     # one call per segment
     want = [np.zeros((M, Cn), np.uint16) for _ in range(3)]
     for si, (r0, n) in enumerate(((0, seg_rows), (seg_rows, M - seg_rows))):
         ys, dxs, drs = emu.Z((n, Cn), np.uint16), emu.Z((n, Cn), np.uint16), emu.Z((n, Cn), np.uint16)
         xs, rs, ds = B(x[r0:r0 + n]), B(res[r0:r0 + n]), B(dy[r0:r0 + n])
-        ms, is_, ss = B(mean[si]), B(invstd[si]), B(sums[si])
+        ms, is_, ss = B(mean[si]), B(invstd[si]), B(emu.to_fx(sums[si]))
         emu.ok(lib.lp_bn_apply(xs.p, ms.p, is_.p, gb.p, bb.p, rs.p, 1, n, Cn, ys.p, None, st))
-        emu.ok(lib.lp_bn_bwd_apply(ds.p, ys.p, xs.p, ms.p, is_.p, gb.p, ss.p, counts[si], n, Cn, dxs.p, drs.p, st))
+        emu.ok(lib.lp_bn_bwd_apply(ds.p, ys.p, xs.p, ms.p, is_.p, gb.p, ss.p, counts[si], n, Cn, dxs.p, drs.p, ss.p, dbs.p, dgs.p, st))
         for dst, src in zip(want, (ys, dxs, drs)):
             dst[r0:r0 + n] = src.np()
     for a, b_ in zip(got, want):
         assert np.array_equal(a, b_)
+    # d beta / d gamma: the sums of both segments, whether one launch adds them or two
+    tot = emu.fx(emu.to_fx(sums)).sum(0)
+    for a, b_, t in ((dbj, dbs, tot[0]), (dgj, dgs, tot[1])):
+        np.testing.assert_allclose(a.np(), t, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(b_.np(), t, rtol=1e-6, atol=1e-6)

@@ -41,6 +41,12 @@ TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, a
 # Run to run on the device (BatchNorm sums through fp32 atomics, in both executors) the 99.9th percentile of c2full fp32 was 1.9e-3, 3.1e-3 and
 # 4.8e-3 px (profiles/r03_flake4.log, r03m_parity_dist.jsonl) - the six worst of ~6000 coordinates, on maps whose peak is just above PEAK_MIN -
 # so the bulk bar sits at the 99th percentile and the 99.9th is bounded separately (1.5e-2 px = 4e-5 of the frame).
+# s64 - the 64 x 64, K = 3 fixture small enough for the CPU-emulated kernels - is a WIRING test of the whole step, not a BASELINE config: 16 x 16
+# heat-maps whose head fits 10 frames almost exactly (heat-map loss 5.7e-5, RMSE 0.028 px), so the bf16-mixed path's absolute errors (RMSE
+# +0.07 px, heat-map loss +9 .. 12 %, confidences 0.05) are large RELATIVE to it.  It keeps round 3's bars; every BASELINE-config fixture
+# (c1, c2, c5, c5v4, c2full, c4, c4full) is held to the tightened ones above.
+TOL_S64_BF16 = dict(rel=1e-2, kp_max=1.5, kp_mean=0.3, conf=0.1, peak=0.15, argmax=0.8, hm_loss_rel=0.25, px_abs=0.15, stem_cos=0.9, head_cos=0.97,
+                    norm_rel=0.25, norm_worst=0.35)
 BIG = 500                                  # keypoints per fixture from which the tail rules apply
 TAIL = {"fp32": dict(q=0.99, q_hi=(0.999, 1.5e-2), max=0.05), "bf16-mixed": dict(q=0.99, kp_max=1.5, frac_over=0.005)}
 # (bf16-mixed at the full batch: 99 % of the ~3000 labeled keypoints within 0.965 px, ~6000 unlabeled ones within 0.52 px - r04e - against a
@@ -52,8 +58,6 @@ TAIL = {"fp32": dict(q=0.99, q_hi=(0.999, 1.5e-2), max=0.05), "bf16-mixed": dict
 # profiles/r04f_parity_device.jsonl), and a flipped map also moves its confidence (99th percentile 0.071)
 TAIL_BY_FIXTURE = {("c4full", "fp32"): dict(q=0.99, kp_max=1e-2, q_hi=(0.999, 4e-2), max=0.06),
                    ("c4full", "bf16-mixed"): dict(q=0.95, kp_max=1.5, frac_over=0.035, conf=0.15)}
-HM_LOSS_REL = {"s64": 0.25}                # the 64 x 64 emulator-size fixture: a heat-map loss of 5.7e-5 (the head fits 10 frames almost exactly), so the
-                                           # same absolute heat-map error is 9 % (emulator) / 12 % (device) of it - r04g; every other fixture: TOL
 SCALAR_REL = {"c2full": 2.5e-2}            # temporal / pca / total of the bf16-mixed path (default 1.2e-2): measured 1.27e-2 (temporal: the handful
                                            # of two-peak maps, see above; the policy oracle itself: 2.8e-2, profiles/r04_rounding_stages.json)
 # Parameter gradients at BASELINE's real batch under the bf16-mixed POLICY itself - the reference's arithmetic rounded where the product rounds,
@@ -146,7 +150,7 @@ def _run(name, dev, precision, g):
 
 
 def _check(name, dev, precision, g):
-    t = TOL[precision]
+    t = TOL_S64_BF16 if (name == "s64" and precision != "fp32") else TOL[precision]
     model, out, seen, inp = _run(name, dev, precision, g)
     cfg = inp["cfg"]
     # ---- every logged scalar
@@ -158,15 +162,15 @@ def _check(name, dev, precision, g):
         if "weight" in k.replace("_weighted", "") or k == "total_unsupervised_importance":
             assert got[k] == pytest.approx(v, rel=1e-6), k                                    # exp(-log_weight) / 2, the anneal value
         elif "rmse" in k:
-            assert got[k] == pytest.approx(v, rel=t["rel"], abs=t["px_abs"]), (k, got[k], v)    # a distance in frame pixels
+            assert got[k] == pytest.approx(v, rel=t["rel"], abs=t["px_abs"]), (k, got[k], v)   # frame px
         elif "heatmap_mse" in k or "supervised_loss" in k:
             # (target - prediction)^2 of a FITTED head: a difference of nearly equal numbers, so relative errors of the heat-map appear
             # magnified by target / residual
-            assert got[k] == pytest.approx(v, rel=t["hm_loss_rel"] if precision == "fp32" else HM_LOSS_REL.get(name, t["hm_loss_rel"])), (k, got[k], v)
+            assert got[k] == pytest.approx(v, rel=t["hm_loss_rel"]), (k, got[k], v)
         else:                                                                                  # temporal, pca, total: the bar itself
-            assert got[k] == pytest.approx(v, rel=max(t["rel"], SCALAR_REL.get(name, 1.2e-2) if precision != "fp32" else 0)), (k, got[k], v)
+            assert got[k] == pytest.approx(v, rel=max(t["rel"], SCALAR_REL.get(name, 1.5e-2 if name == "s64" else 1.2e-2) if precision != "fp32" else 0)), (k, got[k], v)
     # (the supervised tracker's loss IS the heat-map loss of the fitted head: see above)
-    assert float(out["loss"].detach()) == pytest.approx(float(g["loss"]), rel=t["rel"] if cfg["S"] > 0 else HM_LOSS_REL.get(name, t["hm_loss_rel"]))
+    assert float(out["loss"].detach()) == pytest.approx(float(g["loss"]), rel=t["rel"] if cfg["S"] > 0 else t["hm_loss_rel"])
     # ---- what the losses saw: keypoints (frame px and model px), confidences - on the maps the reference itself localises
     for meth, tag in (("get_loss_inputs_labeled", "lab"), ("get_loss_inputs_unlabeled", "unl")):
         if meth not in seen:
@@ -279,8 +283,8 @@ def test_step_parity_on_the_register_staged_kernels(golden, name, monkeypatch):
 @pytest.mark.parametrize("name", ["c2", "c2full"])
 def test_step_repeats_bit_for_bit(golden, name):
     """Round 4: the default bf16-mixed step is bit-reproducible - every cross-workgroup sum (fused BatchNorm sums of the
-    convolution store passes, the stand-alone reductions, the weight gradients' pixel slices) is added in a fixed order, none with fp32
-    atomics in arrival order.  Two runs of the same step from the same state: the flat gradient buffer, the running statistics and every
+    convolution store passes, the stand-alone reductions, the weight gradients' pixel slices) is added in a fixed order or as 64-bit integers
+    (lp_fxsum), none with fp32 atomics in arrival order.  Two runs of the same step from the same state: the flat gradient buffer, the running statistics and every
     logged scalar agree in every bit (the reference is deterministic on a fixed seed: models/heatmap_tracker.py:69-70)."""
     runs = []
     for _ in range(2):
