@@ -200,7 +200,7 @@ NORM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("M,seg_rows,Cn", [(256, 128, 64), (300, 100, 24), (5000, 1800, 256), (96, 95, 8)])
+@pytest.mark.parametrize("M,seg_rows,Cn", [(256, 128, 64), (300, 100, 24), (5000, 1800, 256), (96, 95, 8), (40, 24, 2048)])
 def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_rows, Cn):
     """lp_bn_apply_seg / lp_bn_bwd_apply_seg == the one-segment entry points called once per segment, bit for bit (one launch walks both
     segments, each with its own per-channel terms in registers)"""
@@ -240,3 +240,12 @@ def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_
     for a, b_, t in ((dbj, dbs, tot[0]), (dgj, dgs, tot[1])):
         np.testing.assert_allclose(a.np(), t, rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(b_.np(), t, rtol=1e-6, atol=1e-6)
+
+
+def test_bn_bwd_apply_refuses_more_channels_than_its_term_buffer_holds(kernel_backend):
+    """bn_bwd_apply_kernel stages the launch's correction terms in 32 KB of LDS: C <= 2048 (ResNet-50's widest BatchNorm); beyond -> LP_ERR_UNSUPPORTED"""
+    M, Cn = 8, 2056
+    z16 = emu.Z((M, Cn), np.uint16)
+    f = emu.Z(Cn)
+    sums = emu.ZX((2, Cn))
+    assert emu.lib().lp_bn_bwd_apply(z16.p, None, z16.p, f.p, f.p, f.p, sums.p, float(M), M, Cn, z16.p, None, None, None, None, emu.stream()) == -2
