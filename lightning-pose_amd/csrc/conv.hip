@@ -1182,16 +1182,16 @@ static bool res2d_ok(const ConvGeom& g, int ck, int N, const ConvEpilogue& ep) {
     const char* e = getenv("LP_CONV_RES2D");
     if (e != nullptr && atoi(e) == 0) return false;
     return g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.Hi == g.Ho && g.Wi == g.Wo && ck == 64 && N == 64 && g.Hi % 16 == 0 &&
-           g.Wi % 16 == 0 && ep.bias == nullptr;
+           g.Wi % 16 == 0;
 }
 
-template <int MODE>
+template <int MODE, bool INFER = false>
 static int launch_res2d(const void* x, const void* w, const ConvGeom& g, const ConvEpilogue& ep, hipStream_t st) {
     const int ntiles = g.B * (g.Hi / 16) * (g.Wi / 16);
     const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
     const unsigned x_bytes = (unsigned)(2ull * g.B * g.Hi * g.Wi * 64), w_bytes = (unsigned)(2ull * 64 * 9 * 64);
     g_last_conv_kernel = LP_CONV_KERNEL_RES2D;
-    hipLaunchKernelGGL((conv_res2d_kernel<MODE>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes, w_bytes,
+    hipLaunchKernelGGL((conv_res2d_kernel<MODE, INFER>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes, w_bytes,
                        g.B, g.Hi, g.Wi, ntiles, ep);
     return grid;
 }
@@ -1214,7 +1214,7 @@ static int launch_pipe(const void* x, const void* w, const ConvGeom& g, const La
 template <int BN>
 static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
                              const ConvEpilogue& ep, hipStream_t st) {
-    if (kind == kEkZ && BN == 64 && res2d_ok(g, g.Co, N, ep)) return launch_res2d<kModeDgrad>(x, w, g, ep, st);
+    if (kind == kEkZ && BN == 64 && ep.bias == nullptr && res2d_ok(g, g.Co, N, ep)) return launch_res2d<kModeDgrad>(x, w, g, ep, st);
     if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) return launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkZ) return launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkAZB) return launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
@@ -1363,7 +1363,7 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
         if (N > 64) {
             if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
             else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
-        } else if (res2d_ok(g, g.Ci, N, ep)) {
+        } else if (ep.bias == nullptr && res2d_ok(g, g.Ci, N, ep)) {
             launch_res2d<kModeFwd>(x, w, g, ep, st);
         } else if (pipe_halo_ok(g, M, g.Ci, 512)) {
             launch_pipe<64, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
@@ -1400,6 +1400,11 @@ extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom*
     hipStream_t st = (hipStream_t)stream;
     // the pipelined forward kernel with the residual and the ReLU in its store pass (LP_INFER_PIPE=0: A/B runs keep conv_igemm_kernel<infer>)
     const char* ip = getenv("LP_INFER_PIPE");
+    if ((ip == nullptr || atoi(ip) != 0) && ep.addend == nullptr && res2d_ok(g, g.Ci, N, ep)) {
+        // layer1's 64 -> 64 3x3 layers: 16 x 16 tiles, the filter resident in LDS (round 4: the inference store pass of conv_res2d_kernel)
+        launch_res2d<kModeFwd, true>(x, w, g, ep, st);
+        return launch_status();
+    }
     if ((ip == nullptr || atoi(ip) != 0) && pipe_eligible(ep, M, N, K, g.Ci, M, true)) {
         if (N > 64) {
             if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkInfer, true>(x, w, g, lat, M, N, K, ep, st);

@@ -23,10 +23,13 @@ constexpr int kR2HaloRows = 328;                 // ... as staged (41 passes of 
 constexpr int kR2HaloB = kR2HaloRows * kPRowB;   // 41 984 B
 constexpr int kR2WB = 9 * 64 * kPRowB;           // 73 728 B
 
-template <int MODE>
+// INFER (forward only; lp_conv_fwd_act, round 4): out = [relu](acc + bias) - the inference launch of these layers with the BatchNorm folded
+// into weights and bias (conv2 of a bottleneck has no residual branch); its own instantiation, the training kernel's code is untouched.
+template <int MODE, bool INFER = false>
 __global__ __launch_bounds__(512) void conv_res2d_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt,
                                                          unsigned x_bytes, unsigned w_bytes, int B, int H, int W, int ntiles, ConvEpilogue ep) {
     static_assert(MODE == kModeFwd || MODE == kModeDgrad, "forward or data gradient");
+    static_assert(!INFER || MODE == kModeFwd, "the inference store pass belongs to the forward kernel");
     constexpr bool kFwd = MODE == kModeFwd;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kR2WB + 2 * kR2HaloB];
     unsigned char* const wlds = smem;
@@ -214,6 +217,22 @@ __global__ __launch_bounds__(512) void conv_res2d_kernel(const unsigned short* _
             // lane (pixel fr, half fg) holds the channels 8 j + 4 fg + (0..3) of its wave's 32 in acc[mt][4 j .. 4 j + 3]
             constexpr int ROWB = 64 + 16;
             unsigned char* stg = stg_all + wave * (32 * ROWB);
+            if (INFER && ep.bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(ep.bias + wn * 32 + 8 * j + 4 * fg);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[mt][4 * j + e] += bv[e];
+                }
+            }
+            if (INFER && ep.relu_fwd) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mt][e] = fmaxf(acc[mt][e], 0.f);
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll

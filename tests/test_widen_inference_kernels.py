@@ -78,6 +78,31 @@ def test_conv_fwd_act_on_the_pipelined_kernel(case, kernel, monkeypatch):
         assert float(((got - want).abs() / (scale + 1e-3)).max()) <= 2.0 ** -7
 
 
+def test_conv_fwd_act_of_layer1s_3x3_layers_on_the_resident_filter_kernel(monkeypatch):
+    """round 4: the 64 -> 64 channel 3x3 layers (conv2 of layer1's blocks: no residual branch) take conv_res2d_kernel's inference store pass -
+    bias and ReLU on the accumulators, one rounding: bit-identical to conv_igemm_kernel<infer>; with a residual the launch stays on
+    conv_pipe_kernel"""
+    B, Hi, Wi = 2, 32, 16
+    gen = torch.Generator().manual_seed(41)
+    x = emu.to_bf16_bits(nhwc(torch.randn(B, 64, Hi, Wi, generator=gen)))
+    w = emu.to_bf16_bits(torch.randn(64, 9 * 64, generator=gen) / 24)
+    bias = torch.randn(64, generator=gen).numpy()
+    g = emu.geom(B, Hi, Wi, 64, 64, 3, 3, 1, 1)
+    for relu in (True, False):
+        got = emu.conv_fwd_act(x, w, g, bias=bias, relu=relu)
+        assert emu.lib().lp_conv_last_kernel() == 5          # LP_CONV_KERNEL_RES2D
+        monkeypatch.setenv("LP_INFER_PIPE", "0")
+        want = emu.conv_fwd_act(x, w, g, bias=bias, relu=relu)
+        assert emu.lib().lp_conv_last_kernel() == 0
+        monkeypatch.delenv("LP_INFER_PIPE")
+        np.testing.assert_array_equal(got, want)
+        if relu:
+            assert float(emu.from_bf16_bits(got).min()) == 0.0
+    res = emu.to_bf16_bits(torch.randn(B * Hi * Wi, 64, generator=gen))
+    emu.conv_fwd_act(x, w, g, bias=bias, residual_bits=res, relu=True)
+    assert emu.lib().lp_conv_last_kernel() in (1, 4)       # conv_pipe_kernel, plain or HALO form
+
+
 @pytest.mark.parametrize("nb,nh,T,ldp", [(2, 2, 77, 80), (1, 3, 130, 192), (1, 1, 64, 64), (1, 2, 5, 8)])
 def test_attention_forward_without_probabilities(nb, nh, T, ldp):
     """inference form (p = NULL): the same O as the training form bit for bit, nothing of size T x T written"""
