@@ -262,7 +262,7 @@ struct AttnBwdArgs {
 
 // (Round 3 also built this kernel WITHOUT the stored probabilities - rebuilt per tile as exp(scale * Q K^T - m) / l from per-query statistics
 // the forward pass kept: 8 more MFMAs + 32 exponentials per tile and wave in a kernel already at 256 VGPRs.  Forward 433 -> 361 us per layer,
-// this kernel 476 -> 571 us, C4 3790 -> 3745 frames/s in one call (profiles/r03x_vit_kernel_stats.txt): slower, so it left the tree in round 4;
+// this kernel 476 -> 571 us, C4 3790 -> 3745 frames/s in one call (profiles/archive/r03x_vit_kernel_stats.txt): slower, so it left the tree in round 4;
 // the source is kept in profiles/retired/r04_attn_with_lse_recompute.hip.txt.)
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short sDO[kBQ * kLDT];

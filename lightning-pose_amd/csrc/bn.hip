@@ -609,11 +609,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned c
 
 // ---- round 3: the two backward passes with the pooled gradient and the arg-max bytes staged in LDS ---------------------------------
 // bn_pool_bwd_reduce_kernel / _apply_kernel gather dy and the arg-max byte of up to 4 windows per input pixel straight from global memory:
-// nine dependent-address loads per 16 B of z, 2.0 / 3.1 TB/s at any grid size (profiles/r03ab_pool.txt).  Here a workgroup walks a band of
+// nine dependent-address loads per 16 B of z, 2.0 / 3.1 TB/s at any grid size (profiles/archive/r03ab_pool.txt).  Here a workgroup walks a band of
 // output rows of one image; per output row ho it handles the input rows 2 ho and 2 ho + 1, whose windows lie in the output rows ho and ho + 1:
 // those two rows of dy (96 x 128 B) and of arg-max bytes (96 x 64 B) sit in LDS (row ho + 1 is loaded while row ho is still there: each is
 // read from memory once per band), and the gather reads LDS.  z is fetched LP_POOL_ZU = 2 chunks ahead per thread: with 6 in flight the
-// kernel needed 195 VGPRs (2 waves per SIMD) and ran at 2.3 / 3.4 TB/s, with 2 it needs 115 and runs at 3.2 / 4.6 (profiles/r03ag_pool_zu.txt:
+// kernel needed 195 VGPRs (2 waves per SIMD) and ran at 2.3 / 3.4 TB/s, with 2 it needs 115 and runs at 3.2 / 4.6 (profiles/archive/r03ag_pool_zu.txt:
 // reduce 418 -> 260 us, apply 452 -> 314 us per 128 frames against the gather-from-memory kernels).  C = 64 only
 // (the stem); other shapes keep the kernels above.  APPLY = false: the two reductions; true: dz.
 constexpr int kPbW = 96;   // widest pooled row staged (Wo <= 96: 384-px frames)
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
 #pragma unroll
                         for (int i = 0; i < 8; ++i) g[i] = 0.f;
                         // the (<= 4) windows that contain this pixel (a loop over the valid ones: reading all four unconditionally was slower,
-                        // ~350 instructions per 16 B of z, profiles/r03ac_pool_v2.txt)
+                        // ~350 instructions per 16 B of z, profiles/archive/r03ac_pool_v2.txt)
                         const int hlo = ho, hhi = (r == 1 && ho + 1 < Ho) ? ho + 1 : ho;   // rows hi / 2 .. min(Ho - 1, (hi + 1) / 2)
                         const int wlo = wi >> 1, whi = ((wi + 1) >> 1) < Wo ? ((wi + 1) >> 1) : Wo - 1;
                         for (int hh = hlo; hh <= hhi; ++hh)
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
 }
 
 // output rows per workgroup: 6 -> 16 bands per 96-row map, 1024 / 2048 workgroups for 64 / 128 frames = whole rounds (3, 4, 8, 12 measured:
-// profiles/r03ad_pool_band.txt)
+// profiles/archive/r03ad_pool_band.txt)
 static int pool_v2_band() { return 6; }
 
 static bool pool_v2_ok(int C, int Hi, int Wi, int Ho, int Wo) {

@@ -1268,7 +1268,7 @@ static WgradPipePlan plan_wgrad_pipe(const ConvGeom& g, int split_hint, bool for
     p.tiles_a = (p.Ka + 255) / 256;
     if (!force && (long long)p.tiles_a * 256 * 8 > (long long)p.Ka * 9) return p;   // a ragged last a-tile may waste an eighth at most (3x3 of 64 channels: 576 -> 768 lost, measured)
     // HBM-bound shapes (few FLOPs per operand byte: the 1x1 layers of layer1 / layer2) gain nothing from the bigger tile and lose a few
-    // per cent to the 64-B request granularity its LDS swizzle forces on the loads (measured per layer, profiles/r03g_layer_table.txt)
+    // per cent to the 64-B request granularity its LDS swizzle forces on the loads (measured per layer, profiles/archive/r03g_layer_table.txt)
     if (!force && (long long)p.Ka * p.Cb < 120LL * (p.Ka + p.Cb)) return p;
     p.tiles_b = p.Cb / p.bn;
     const int tiles = p.tiles_a * p.tiles_b;

@@ -2,7 +2,7 @@
 //
 // Why a second kernel next to conv_igemm_kernel (conv.hip): that kernel fetches ONE K step ahead into registers, so every
 // K step of every tile waits a full (loaded) memory latency - the 1x1 layers ran at ~3 TB/s of a 6.3 TB/s part and their
-// data gradients spent 53 % of their wave cycles parked on memory (profiles/r02_pmc_mfma.json).  Here the operands go
+// data gradients spent 53 % of their wave cycles parked on memory (profiles/archive/r02_pmc_mfma.json).  Here the operands go
 // global -> LDS with `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write pass) into a ring of THREE stages:
 // while the MFMAs of K step g run, the loads of steps g+1 and g+2 are in flight (96 KB per CU; profiles/probe/glds_probe.hip
 // measures 6.0 TB/s read-only and 5.4-5.5 TB/s with an output stream for exactly this ring), and the ring never drains between
@@ -62,7 +62,7 @@ constexpr int kPRowB = 128;  // bytes per staged operand row (64 k x bf16)
 #define LP_WAIT_LGKM_TOUCH4(n, a, b, c, d) ((void)0)
 #endif
 
-// 16-B store (a non-temporal form was measured in round 3 and dropped: profiles/r03b_bench_ntstore_1.json.log)
+// 16-B store (a non-temporal form was measured in round 3 and dropped: profiles/archive/r03b_bench_ntstore_1.json.log)
 __device__ __forceinline__ void store8(unsigned short* p, u16x8 v) { *reinterpret_cast<u16x8*>(p) = v; }
 
 // EK = what the data gradient's store pass reads back (its own instantiation each, so the read-back registers of one form are not
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     // Swizzle key of a halo row (round 4).  A wave's 32-pixel fragment window crosses an image-row end every W pixels, where the padded
     // raster skips the two border columns (+3 instead of +1): keyed on the halo row itself - (row >> 1) & 7, conflict-free for CONSECUTIVE
     // rows - the ds_read_b128 lane groups {0-3, 12-15, 20-27} ... then meet 2-way bank conflicts after every jump (W = 24 / 12: one to three
-    // per window; SQ_LDS_BANK_CONFLICT was 8 - 10 % of the HALO launches' cycles, profiles/r03_pmc_mfma.json).  Keyed on
+    // per window; SQ_LDS_BANK_CONFLICT was 8 - 10 % of the HALO launches' cycles, profiles/archive/r03_pmc_mfma.json).  Keyed on
     // u = row - 2 x (padded image rows since the tile's first), u advances by exactly 1 from pixel to pixel across row ends, and row - u is
     // even, so (bank half, chunk position) = u mod 16 stays distinct over any 16 pixels in a row.  A tap (r, s) moves u by (r - 1) W + (s - 1).
     auto halo_setup = [&](int vt) {
@@ -307,12 +307,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     f32x16 acc[2][NT];
     // `spread`: issue the prepared step's loads between the k-slices (2 after the first slice's MFMAs have been queued, then 2, 1, 1)
     // `spread`: issue the prepared step's loads between the k-slices (2 after the first slice's MFMAs have been queued, then 2, 1, 1).
-    // (Measured and dropped, profiles/r03k_stagger.txt: letting the two waves of a SIMD do their per-step address arithmetic at different
+    // (Measured and dropped, profiles/archive/r03k_stagger.txt: letting the two waves of a SIMD do their per-step address arithmetic at different
     // points - one before slice 0, the other after slice 1 with its loads in slices 2 - 3 - made every forward layer 15 - 25 % slower.)
     // fragment sets in flight: the forward kernel reads TWO k-slices ahead of its MFMAs (3 register sets; 16 more VGPRs it has), the data
     // gradient - at the register cap because of its read-back batches - one slice ahead (2 sets)
 #ifndef LP_PIPE_FRAG_SETS
-#define LP_PIPE_FRAG_SETS 2   // (3 = two slices ahead: measured equal within noise, profiles/r03n_fragsets.txt, at 16 more VGPRs)
+#define LP_PIPE_FRAG_SETS 2   // (3 = two slices ahead: measured equal within noise, profiles/archive/r03n_fragsets.txt, at 16 more VGPRs)
 #endif
     constexpr int NS = (MODE == kModeFwd) ? LP_PIPE_FRAG_SETS : 2;
     // HALO: rows of the tile's pixels inside the halo image (per tile), the halo image the MFMAs read, its tap, and whether the
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
 
     // ---- forward store pass of the tile at (m0, n0): per wave, 2 chunks of 32 pixels through a private bf16 corner; lane (pixel fr,
     // half fg) holds for block nt the channels nt*32 + 8 j + 4 fg + (0..3) in acc[mt][nt][4 j .. 4 j + 3]
-    // (Measured and dropped, profiles/r03al_store_pass_cost.txt + r03am_lazy_layers.txt.  In the open this pass costs ~1600 cycles per wave
+    // (Measured and dropped, profiles/archive/r03al_store_pass_cost.txt + r03am_lazy_layers.txt.  In the open this pass costs ~1600 cycles per wave
     // and tile whatever K is: 45 % on top of a K = 256 tile (timing builds, hooks kept in profiles/retired/r04_conv_pipe_timing_hooks.txt: 7.32 ms of forward launches per step, 6.53
     // without the global stores, 7.08 without the sums, 5.74 without the pass).  Converting the accumulators at the end of a tile and running
     // the rest - a 2-KB corner per wave outside the ring, 16 units: write / read / store + sums twice per 16-pixel chunk - one unit after
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         for (int kt = 0; kt < KT; ++kt) {
             // this wave's loads of the current step have landed; the next step's (4 + NBL; HALO: its NBL weight pieces - the halo piece
             // issued before them is the oldest of that step and is waited for a step early, which costs nothing: it has 8 steps to land) stay in flight
-            // (Measured and dropped, profiles/r03p_vmcnt_layers.txt: right behind a tile boundary the needed loads are OLDER than the
+            // (Measured and dropped, profiles/archive/r03p_vmcnt_layers.txt: right behind a tile boundary the needed loads are OLDER than the
             // previous tile's output stores, so the count could leave those stores in flight instead of waiting for them to reach
             // memory - every layer came out 0 - 7 % SLOWER, forward and data gradient: the wait paces the workgroups' store bursts.)
             if (HALO && NBL == 2) LP_WAIT_VM(2);

@@ -3,7 +3,7 @@
 //
 // Why a third kernel: on this shape conv_pipe_kernel's K step is 8 MFMAs per wave, so its per-step cost (counted wait, barrier, address
 // arithmetic, the first fragments' LDS latency) and its per-tile store pass - a tile lasts 9 steps - are the time, not the operand stream
-// (profiles/r03q_halo_loop_experiments.txt: 253 us with the HALO form, 198 us with no loads at all, against a 52 us MFMA floor).  Here
+// (profiles/archive/r03q_halo_loop_experiments.txt: 253 us with the HALO form, 198 us with no loads at all, against a 52 us MFMA floor).  Here
 //   * the 9 x 64 x 64 filter (73.7 KB as 576 rows of 128 B) is loaded ONCE per workgroup and stays in LDS for the whole persistent walk;
 //   * a tile is a 16 x 16 block of one image, so its input neighbourhood is 18 x 18 pixels = 324 rows of 128 B (41 KB; a 256-pixel raster
 //     run of a 96-wide image needs 460) - two of them fit beside the filter (157.7 KB of the CU's 160), the next tile's neighbourhood

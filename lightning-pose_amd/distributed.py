@@ -39,7 +39,7 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
         if backend is None:
             backend = os.environ.get("LP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         # (no device_id=: binding the communicator eagerly was measured in loop-back at +1.8 ms per step - 56.8 vs 55.0 ms on the same box,
-        # profiles/r02_final_bench_loopback_rccl*.json.log; the device is already current, which is what RCCL's lazy initialisation uses)
+        # profiles/archive/r02_final_bench_loopback_rccl*.json.log; the device is already current, which is what RCCL's lazy initialisation uses)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -145,7 +145,7 @@ class _DecodePruneAuto:
 
     stats[..., 1] of lp_decode_fwd is sum exp(T (y - max y)) over the up-sampled map = the number of pixels that carry weight in the
     soft-argmax: ~2 - 10 on the peaked maps of a trained head (T = 1000), ~all 147 456 on the flat maps of an untrained one.  Pruning pays
-    (forward 1.4x, backward 1.8x, profiles/r02k_decode_microbench.jsonl) when most maps are peaked and costs when they are flat, and which
+    (forward 1.4x, backward 1.8x, profiles/archive/r02k_decode_microbench.jsonl) when most maps are peaked and costs when they are flat, and which
     regime a run is in changes once, early in training.  So every PERIOD-th call (and the FIRST-th) the fraction of peaked maps is reduced
     on the device and copied to pinned host memory WITHOUT a synchronisation; a later call picks the value up once its event has
     completed and flips the switch if needed.  LP_DECODE_PRUNE=0 / 1 pins the choice instead (read per call).

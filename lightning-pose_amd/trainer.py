@@ -71,7 +71,7 @@ class Trainer:
     def training_batch(self, model, batch: dict, batch_idx: int, last_in_epoch: bool = False) -> torch.Tensor:
         """One optimisation step; returns the (detached) loss.  Every kernel is enqueued from here; nothing in it makes the host wait for the
         device.  (Rounds 2 - 3 could also replay the step as one captured HIP graph: host 0.2 instead of 10 - 26 ms per step, but the replay
-        was ~3 ms SLOWER on the device than stream launches and the device bounds the step - measured in profiles/r02d_*, removed in round 4,
+        was ~3 ms SLOWER on the device than stream launches and the device bounds the step - measured in profiles/archive/r02d_*, removed in round 4,
         profiles/retired/r04_graph_step.py.txt.)"""
         return self._eager_batch(model, batch, batch_idx, last_in_epoch)
 

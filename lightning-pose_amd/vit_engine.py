@@ -435,7 +435,7 @@ class ViTEngine(Engine):
                 check(self._lib.lp_gelu_bwd(_p(t("h1")), _p(d_a1), d_a1.numel(), _p(d_h1), ops._stream()), "lp_gelu_bwd")
             d_y2 = self._linear_bwd(L["fc1"], t("y2"), d_h1, M, bias_done=fuse_bias)
             # (proj keeps the bias sums inside its weight-gradient launch: a 384 x 384 layer gains 5 us from the pipelined kernel, the
-            #  column sums cost the LayerNorm backward 40 - profiles/r03_final_vit_kernel_stats.txt)
+            #  column sums cost the LayerNorm backward 40 - profiles/archive/r03_final_vit_kernel_stats.txt)
             dx16 = self._ln_bwd(d_y2, t("x_mid"), t("m2"), t("r2"), L["ln2"], M, dx, want_bf16=True)
             # ---- attention branch: x_mid = x_in + proj(softmax(Q K^T / 8) V)
             dproj = dx16

@@ -3,9 +3,9 @@
 bytes = every tensor the launch reads or writes once (bf16 activations, 1-bit masks).
 
 Round 2 used it to A/B kernel variants behind LP_BN_VARIANT (1: deeper unroll, 2: non-temporal stores, 3: both; results in
-profiles/r02f_bn_microbench.jsonl): tensors of 900 MB stream at 4.4 - 4.7 TB/s (the practical mixed read/write HBM rate of this part), tensors
+profiles/archive/r02f_bn_microbench.jsonl): tensors of 900 MB stream at 4.4 - 4.7 TB/s (the practical mixed read/write HBM rate of this part), tensors
 that fit the 256 MB Infinity Cache at 5.9 - 6.4 TB/s in this loop only because the loop re-reads them.  Non-temporal stores gained 5 - 8 % here and
-NOTHING in the step (3541 vs 3553 frames/s, profiles/r02g_bench_*.json.log), so the variants were not kept; the library now ignores the variable."""
+NOTHING in the step (3541 vs 3553 frames/s, profiles/archive/r02g_bench_*.json.log), so the variants were not kept; the library now ignores the variable."""
 import ctypes as C
 import json
 import os

@@ -1,7 +1,7 @@
 """Where a step's wall time goes, from a rocprofv3 (rocpd SQLite) kernel trace: per step (one `conv_stem2d_kernel` each) the time some kernel runs,
 the time two or more run (side-stream weight gradients under the main stream), the idle time, and the idle gaps grouped by the kernels either side.
 
-    python profiles/gap_analysis.py /tmp/prof/x_results.db > profiles/r03_gap_analysis.txt
+    python profiles/gap_analysis.py /tmp/prof/x_results.db > profiles/archive/r03_gap_analysis.txt
 """
 import collections
 import sqlite3

@@ -1,6 +1,6 @@
 """The bf16-mixed POLICY's own gradients at a step fixture (reference arithmetic rounded where the product rounds, torch CPU, autograd rounding
 the gradients at the same places): how far are the policy's stem / head gradients and logged scalars from the fp32 fixture's?  This is the
-yardstick for the product's bf16-mixed deviations at BASELINE's real batch.      python profiles/policy_grad_full.py c2full > profiles/r03_policy_grad_c2full.json"""
+yardstick for the product's bf16-mixed deviations at BASELINE's real batch.      python profiles/policy_grad_full.py c2full > profiles/archive/r03_policy_grad_c2full.json"""
 import json
 import os
 import sys

@@ -4,7 +4,7 @@ The reference's own arithmetic (oracle.restated.OracleTracker: torch fp32 on the
 step fixture's frames four times - no rounding, trunk only, head only, both (= the policy the product implements) - and the quantities the
 losses see are compared with the un-rounded run: keypoints (frame px), confidences, heat-map peak height, heat-map MSE, temporal loss.
 
-    python profiles/rounding_ablation.py c2 [c1 c5 ...]  > profiles/r03_rounding_ablation.json        (build container: CPU only)
+    python profiles/rounding_ablation.py c2 [c1 c5 ...]  > profiles/archive/r03_rounding_ablation.json        (build container: CPU only)
 
 Round 4, the per-stage table: `--stages` runs one variant per STAGE of the trunk (only the stem's / layer1's / ... /
 layer4's rounding points on), one per KIND of rounding point across the trunk (weights / convolution outputs / inner activations / the

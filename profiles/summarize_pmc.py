@@ -1,6 +1,6 @@
 """HBM traffic of the MFMA convolution kernels from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; counters in KiB).
 
-    python profiles/summarize_pmc.py <fetch.db> <write.db> > profiles/r01_pmc_traffic.json
+    python profiles/summarize_pmc.py <fetch.db> <write.db> > profiles/archive/r01_pmc_traffic.json
 
 Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies a wide coalesced 16 B/lane stream
 at HALF its bytes, so reads are doubled; WRITE_SIZE matched the known output bytes of the conv micro-benchmark exactly

@@ -1,6 +1,6 @@
 """MFMA utilisation and issue-stall picture of the top kernels from one rocprofv3 PMC pass of SQ counters.
 
-    python profiles/summarize_pmc_sq.py <sq_results.db> > profiles/r02_pmc_mfma.json
+    python profiles/summarize_pmc_sq.py <sq_results.db> > profiles/archive/r02_pmc_mfma.json
 
 Units (/opt/skills/guides/MI355X_MICROARCH.md, "rocprofv3 PMC slots" and the s_memtime table): SQ_VALU_MFMA_BUSY_CYCLES counts cycles
 (32 per v_mfma_f32_32x32x16_bf16); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave; SQ_BUSY_CYCLES counts cycles the

@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 (rocpd SQLite) kernel trace into the per-kernel table `rocprofv3 --stats` prints.
 
-    python profiles/summarize_rocpd.py gpurun_out/prof_r1/r1_results.db > profiles/r01_kernel_stats.txt
+    python profiles/summarize_rocpd.py gpurun_out/prof_r1/r1_results.db > profiles/archive/r01_kernel_stats.txt
 """
 import sqlite3
 import sys

@@ -34,12 +34,12 @@ TOL = {"fp32": dict(rel=1e-4, kp_max=3e-3, kp_mean=1e-3, conf=1e-4, peak=3e-4, a
 # gradients are small signed sums: c1 0.17, c5 0.125, c5v4 0.10, c2 0.09, c4 0.009 on the device (r04e); until round 3 it also varied from
 # run to run - the BatchNorm sums went through fp32 atomics - between 0.05 and 0.19)
 # Full-batch fixtures (thousands of keypoints): the bulk is held to the bars above and the tail is bounded.  Measured on the device
-# (profiles/r03m_parity_dist.jsonl): c2full fp32 - keypoints mean 7e-5 px, 99.9 % within 1.9e-3 px, max 7e-3 px (2 - 3 of ~3000 keypoints, on
+# (profiles/archive/r03m_parity_dist.jsonl): c2full fp32 - keypoints mean 7e-5 px, 99.9 % within 1.9e-3 px, max 7e-3 px (2 - 3 of ~3000 keypoints, on
 # maps whose peak is < 0.05); c2full bf16-mixed - mean 0.17 / 0.11 px = the policy's own 0.18 / 0.11, 99 % within 0.9 px, and the same handful
 # of two-peak maps on which the reference's arithmetic under the policy jumps too (policy max 67 px, product 66 px on the same map).  Those few
 # jumps are what moves the temporal loss (a mean of frame-to-frame distances) by 1.7 % at full batch.
 # Run to run on the device (BatchNorm sums through fp32 atomics, in both executors) the 99.9th percentile of c2full fp32 was 1.9e-3, 3.1e-3 and
-# 4.8e-3 px (profiles/r03_flake4.log, r03m_parity_dist.jsonl) - the six worst of ~6000 coordinates, on maps whose peak is just above PEAK_MIN -
+# 4.8e-3 px (profiles/archive/r03_flake4.log, r03m_parity_dist.jsonl) - the six worst of ~6000 coordinates, on maps whose peak is just above PEAK_MIN -
 # so the bulk bar sits at the 99th percentile and the 99.9th is bounded separately (1.5e-2 px = 4e-5 of the frame).
 # s64 - the 64 x 64, K = 3 fixture small enough for the CPU-emulated kernels - is a WIRING test of the whole step, not a BASELINE config: 16 x 16
 # heat-maps whose head fits 10 frames almost exactly (heat-map loss 5.7e-5, RMSE 0.028 px), so the bf16-mixed path's absolute errors (RMSE
@@ -61,17 +61,17 @@ TAIL_BY_FIXTURE = {("c4full", "fp32"): dict(q=0.99, kp_max=1e-2, q_hi=(0.999, 4e
 SCALAR_REL = {"c2full": 2.5e-2}            # temporal / pca / total of the bf16-mixed path (default 1.2e-2): measured 1.27e-2 (temporal: the handful
                                            # of two-peak maps, see above; the policy oracle itself: 2.8e-2, profiles/r04_rounding_stages.json)
 # Parameter gradients at BASELINE's real batch under the bf16-mixed POLICY itself - the reference's arithmetic rounded where the product rounds,
-# torch autograd on the device (profiles/policy_grad_full.py -> profiles/r03_policy_grad_c2full.json): the stem's weight gradient (the end of a
+# torch autograd on the device (profiles/policy_grad_full.py -> profiles/archive/r03_policy_grad_c2full.json): the stem's weight gradient (the end of a
 # 53-layer bf16 backward chain summed over 7 M pixels x 192 frames) has cosine 0.888 against the fp32 fixture, the head's 0.90 - 0.94 (sums of
 # per-frame terms of a FITTED head, which nearly cancel), the temporal loss is 1.9 % off, the worst gradient-norm ratio 0.14.  The product
-# measured 0.853 - 0.870 (stem) and 0.877 - 0.897 (first head layer) on six boxes (profiles/r03n_step_parity.log, r03o, r03u): the same
+# measured 0.853 - 0.870 (stem) and 0.877 - 0.897 (first head layer) on six boxes (profiles/archive/r03n_step_parity.log, r03o, r03u): the same
 # noise.  So at the full batch each compared tensor's bar is the policy's own cosine less a margin, not the small fixtures' 0.9 / 0.97.
 import json as _json
 import os as _os
 
 
 def _policy_cos(name):
-    path = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "profiles", f"r03_policy_grad_{name}.json")
+    path = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "profiles", "archive", f"r03_policy_grad_{name}.json")
     if not _os.path.exists(path):
         return {}
     with open(path) as fh:
