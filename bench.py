@@ -432,7 +432,7 @@ def fit_line(args, dev, rank: int, world: int) -> dict:
     LabeledBatchProducer (bicubic resize, keypoint projection, heat-map targets, all on the device) -> the same step as the headline line.
     PCIe-inclusive by construction (56 MB of video frames + 31 MB of labeled images per step); the logged scalars reach the host every
     `log_every_n_steps` only.  Timed: one fit() of `steps` batches after a warm-up fit() of `warmup`."""
-    from lightning_pose_amd.data.producers import FrameWindowSource, LabeledBatchProducer, VideoFramePipeline
+    from lightning_pose_amd.data.producers import FrameWindowSource, HostStager, LabeledBatchProducer, VideoFramePipeline
     from lightning_pose_amd.trainer import Trainer
 
     Hs, Ws, K, size = 406, 396, args.keypoints, args.size
@@ -449,6 +449,7 @@ def fit_line(args, dev, rank: int, world: int) -> dict:
     src = FrameWindowSource(video, args.unlabeled, random_shuffle=False, pad_sequences=False, device=dev)
     pipe = VideoFramePipeline([size, size], imgaug="default")
     prod = LabeledBatchProducer(size, size, uniform_heatmaps=True)
+    stage, kp_dev = HostStager(dev), kp.to(dev)
 
     def batches(first: int, n: int):
         it = iter(src)
@@ -457,7 +458,7 @@ def fit_line(args, dev, rank: int, world: int) -> dict:
                 continue
             if i >= first + n:
                 break
-            labeled = prod(lab_u8.to(dev, non_blocking=True), kp.to(dev))
+            labeled = prod(stage(lab_u8), kp_dev)   # (HostStager: what HeatmapDataset.batch does with the images it loaded)
             yield {"labeled": labeled, "unlabeled": pipe(frames_u8)}
 
     trainer = Trainer(max_epochs=1, data_parallel=False, log_every_n_steps=50)

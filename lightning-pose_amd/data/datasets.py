@@ -24,7 +24,7 @@ import pandas as pd
 import torch
 
 from .datatypes import HeatmapLabeledBatchDict
-from .producers import LabeledBatchProducer
+from .producers import HostStager, LabeledBatchProducer
 
 
 @dataclass
@@ -108,6 +108,7 @@ class HeatmapDataset:
         self.producer = LabeledBatchProducer(image_resize_height, image_resize_width, downsample_factor=downsample_factor,
                                              uniform_heatmaps=uniform_heatmaps, hflip_swap_indices=None if swap is None else swap.tolist())
         self.device = torch.device(device) if device is not None else torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        self._stage = HostStager(self.device)
         self._rng = np.random.default_rng(0)
 
     @property
@@ -140,7 +141,7 @@ class HeatmapDataset:
     def batch(self, indices: Sequence[int], hflip: torch.Tensor | None = None) -> HeatmapLabeledBatchDict:
         """The labeled batch of the step for these examples; ``hflip`` (B,) overrides the random flip decisions of ``imgaug_hflip``."""
         idx = torch.as_tensor(list(indices), dtype=torch.long)
-        images = self.load_images(idx.tolist()).to(self.device, non_blocking=True)
+        images = self._stage(self.load_images(idx.tolist()))   # pinned staging + copy stream: overlaps the step that is running
         if hflip is None and self.imgaug_hflip:
             hflip = torch.from_numpy(self._rng.random(len(idx)) < 0.5)  # each sample flips with probability 0.5 (reference :275)
         return self.producer(images, self.keypoints[idx].to(self.device), idxs=idx, visibility=self.visibility[idx].to(self.device),
