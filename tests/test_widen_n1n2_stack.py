@@ -208,3 +208,23 @@ def test_frame_window_source_sequences_like_the_video_reader(stack_backend):
     assert tuple(out["frames"].shape) == (4, 3, 32, 32) and out["bbox"].cpu().tolist() == [[0.0, 0.0, 4.0, 6.0]] * 4
     with pytest.raises(ValueError):
         FrameWindowSource(torch.zeros(3, 4, 6, 3), 2, device=dev)  # not uint8
+
+
+def test_host_stager_copies_through_reused_pinned_buffers(stack_backend):
+    """HostStager (round 4): pageable host tensors of changing sizes go through two reusable pinned buffers on a copy stream and arrive
+    intact, in order, on the consumer's stream; pinned inputs and device tensors pass through"""
+    from lightning_pose_amd.data.producers import HostStager
+
+    dev = stack_backend
+    stage = HostStager(dev)
+    hosts = [_u8(20 + i, 2 + (i % 3), 40 + 8 * i, 56) for i in range(6)]
+    outs = [stage(h) for h in hosts]                 # six copies in flight over two buffers: reuse waits for the older copy
+    for h, o in zip(hosts, outs):
+        assert o.device.type == torch.device(dev).type and torch.equal(o.cpu(), h)
+    f = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    assert torch.equal(stage(f).cpu(), f)            # any dtype
+    if torch.device(dev).type == "cuda":
+        p = hosts[0].pin_memory()
+        assert torch.equal(stage(p).cpu(), hosts[0])
+        d = hosts[1].to(dev)
+        assert stage(d) is not None and torch.equal(stage(d).cpu(), hosts[1])
