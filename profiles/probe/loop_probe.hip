@@ -73,7 +73,11 @@ __global__ __launch_bounds__(512, 1) void loop_probe(const unsigned short* __res
     u32x4 stg[6] = {};                             // kLdStaged: one K step of operands on their way to LDS
     auto issue_staged = [&]() {                    // loads of the loader's current step -> registers
         const bool live = ld_tile < tiles;
-        const unsigned a_row0 = live ? (unsigned)((((blockIdx.x * tiles + ld_tile) / reuse) * 256) % x_rows) : 0u;
+        // reuse > 0: consecutive workgroups share rows - they sit on DIFFERENT XCDs, so the rows come through the fabric (MALL / HBM), not from a shared L2
+        // (found at the end of round 4: fat_tile_probe.hip); reuse < 0: -reuse workgroups of the SAME XCD (blockIdx % 8) share them
+        const unsigned grp = reuse > 0 ? (unsigned)((blockIdx.x * tiles + ld_tile) / reuse)
+                                       : (unsigned)((((blockIdx.x & 7) * 64 + (blockIdx.x >> 3) / (-reuse)) * tiles) + ld_tile);
+        const unsigned a_row0 = live ? (grp * 256u) % x_rows : 0u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (i * WAVES + wave) * 8 + lrow;
@@ -103,7 +107,11 @@ __global__ __launch_bounds__(512, 1) void loop_probe(const unsigned short* __res
         }
         unsigned char* dst = smem + st * kStep;
         const bool live = ld_tile < tiles;
-        const unsigned a_row0 = live ? (unsigned)((((blockIdx.x * tiles + ld_tile) / reuse) * 256) % x_rows) : 0u;
+        // reuse > 0: consecutive workgroups share rows - they sit on DIFFERENT XCDs, so the rows come through the fabric (MALL / HBM), not from a shared L2
+        // (found at the end of round 4: fat_tile_probe.hip); reuse < 0: -reuse workgroups of the SAME XCD (blockIdx % 8) share them
+        const unsigned grp = reuse > 0 ? (unsigned)((blockIdx.x * tiles + ld_tile) / reuse)
+                                       : (unsigned)((((blockIdx.x & 7) * 64 + (blockIdx.x >> 3) / (-reuse)) * tiles) + ld_tile);
+        const unsigned a_row0 = live ? (grp * 256u) % x_rows : 0u;
         if (LOADS != kLdB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -384,6 +392,20 @@ int main() {
                 printf("K %4d %-9s | no loads %6.2f (%4.0f TF) | direct-to-LDS %6.2f (%4.0f) | register-staged %6.2f (%4.0f) | with the store pass: direct %6.2f (%4.0f)  "
                        "staged %6.2f (%4.0f)\n", K, resident ? "resident" : "streamed", none, ft / none, dma, ft / dma, stg, ft / stg, dma_e, ft / dma_e, stg_e, ft / stg_e);
             }
+        }
+        return 0;
+    }
+    if (getenv("LOOP_PROBE_CALL_E") != nullptr) {   // today's shape with the pixel rows shared INSIDE an XCD (true L2 reuse), against fat_tile_probe's tables
+        const int Ke[4] = {256, 576, 1024, 2048};
+        for (int ki = 0; ki < 4; ++ki) {
+            const int K = Ke[ki];
+            const double ft = 2.0 * 256 * 128 * K * cus * 1e-6;
+            Args a{X, W, Y, sums, K, K >= 1024 ? 16 : 48, -8, (unsigned)(x_bytes / ((size_t)K * 2)), cus, 1, 0};
+            Args b = a;
+            b.reuse = 8;
+            const double full = run<1, true, kEpiNone, false>(a), epi = run<1, true, kEpiLds, false>(a), cross = run<1, true, kEpiNone, false>(b);
+            printf("K %4d | 8 waves x (64 x 64), rows shared inside an XCD (8 CUs): full %6.2f (%4.0f)  with the LDS-staged store pass %6.2f (%4.0f)  | shared across XCDs: full %6.2f (%4.0f)\n",
+                   K, full, ft / full, epi, ft / epi, cross, ft / cross);
         }
         return 0;
     }
