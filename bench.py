@@ -228,9 +228,9 @@ def hbm_rooflines(dev, size: int, K: int, frames: int, reps: int = 10) -> dict:
 
     cases = {
         "decode_fwd": (stack, lambda: lib.lp_decode_fwd(_p(heat), frames, K, h, h, 2, 1000.0, C.byref(tables), C.byref(fm.struct), _p(kp_aug),
-                                                        _p(kp_frame), _p(conf), _p(stats), st())),
+                                                        _p(kp_frame), _p(conf), _p(stats), 0, st())),
         "decode_bwd": (2 * stack, lambda: lib.lp_decode_bwd(_p(heat), frames, K, h, h, 2, 1000.0, C.byref(tables), C.byref(fm.struct), _p(stats),
-                                                            None, _p(g_frame), _p(g_heat), 0, st())),
+                                                            None, _p(g_frame), _p(g_heat), 0, 0, st())),
         "heatmap_gen": (stack, lambda: lib.lp_heatmap_gen(_p(kp), None, frames, K, size, size, h, h, 1.25, _p(out_hm), st())),
         "heatmap_mse_fwd": (2 * stack, lambda: lib.lp_heatmap_loss_fwd(_lib.HM_MSE, _p(targ), _p(heat), frames, K, h, h, _p(loss), _p(ws), st())),
         "heatmap_mse_bwd": (3 * stack, lambda: lib.lp_heatmap_loss_bwd(_lib.HM_MSE, _p(targ), _p(heat), frames, K, h, h, _p(ws), _p(go), _p(g_heat),

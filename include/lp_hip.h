@@ -13,7 +13,12 @@
  *   - `stream` is the hipStream_t the kernels are enqueued on (torch.cuda.current_stream().cuda_stream);
  *     calls only enqueue - no device synchronisation, no host read-back
  *   - return value: 0 = LP_OK, < 0 = argument / shape error (nothing was launched), > 0 = hipError_t
- *   - re-entrant and thread-safe (no mutable globals)
+ *   - re-entrant and thread-safe: no entry point keeps state between calls or reads the environment.  The only process-wide data is
+ *     the table of A/B switches (LP_CONV_PIPE, LP_CONV_HALO, LP_CONV_RES2D, LP_CONV_SPEC, LP_INFER_PIPE, LP_GEMM_PIPE, LP_WGRAD_PIPE,
+ *     LP_STEM_2D, LP_POOL_V2, LP_CONV_MAX_WGS), read from the environment ONCE when the library is loaded and immutable afterwards -
+ *     except through lp_config_reload_env(), a test / A-B hook that must not run concurrently with other calls
+ *   - limits: lp_bn_bwd_apply WITHOUT its terms_ws workspace covers C <= 2048 channels (the per-launch correction table then lives in
+ *     LDS; LP_ERR_UNSUPPORTED beyond); with the workspace any C that is a multiple of 8
  *   - heat-maps are fp32 NCHW (B, K, h, w); keypoints are fp32 (B, K, 2) = the reference's (B, 2K) row layout;
  *     backbone activations are bf16 NHWC; weights fp32 masters + bf16 GEMM copies
  */
@@ -28,6 +33,10 @@ extern "C" {
 #endif
 
 typedef void* lp_stream_t; /* hipStream_t */
+
+/* Re-read the LP_* switches from the environment into the library's switch table (done once, implicitly, at load).  For tests and A/B
+ * scripts that flip a switch inside one process; not to be called while another thread is inside an lp_* call. */
+int lp_config_reload_env(void);
 
 enum {
     LP_OK = 0,
@@ -70,21 +79,20 @@ typedef struct lp_frame_map {
 
 int lp_decode_window(int downsample_factor, int n);
 
-/* Which instantiation of the decode kernels runs: 1 = the exactly-pruned ones (terms below e^-50 of the largest are skipped: results equal
- * to the last bit or two, 1.4x / 1.8x faster on the peaked maps of a trained head, slower on flat maps), 0 = the plain ones, -1 = follow the
- * environment (LP_DECODE_PRUNE=1).  Process-wide; the product sets it from the decode's own sumexp output (ops.py).  Replaces nothing in the
- * reference (models/heads/heatmap.py:103-144 has one code path). */
-int lp_decode_set_prune(int mode);
+/* `prune` (lp_decode_fwd / lp_decode_bwd): which instantiation of the decode kernels runs - 1 = the exactly-pruned ones (terms below e^-50
+ * of the largest are skipped: results equal to the last bit or two, 1.4x / 1.8x faster on the peaked maps of a trained head, slower on flat
+ * maps), 0 = the plain ones.  An argument of the call since round 5 (no process state; the product chooses it per model from the decode's
+ * own sumexp output, ops.py).  Replaces nothing in the reference (models/heads/heatmap.py:103-144 has one code path). */
 
 /* heat (B,K,h,w) -> kp_aug (B,K,2) model px, kp_frame (B,K,2) frame px, conf (B,K), stats (B,K,4)={max,sumexp,ex,ey} */
 int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
                   const lp_decode_tables* tables, const lp_frame_map* frame_map, float* kp_aug, float* kp_frame, float* conf,
-                  float* stats, lp_stream_t stream);
+                  float* stats, int prune, lp_stream_t stream);
 
 /* g_heat (B,K,h,w) (+)= d loss / d heat given d loss / d kp_aug and/or d loss / d kp_frame (either may be NULL) */
 int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
                   const lp_decode_tables* tables, const lp_frame_map* frame_map, const float* stats, const float* g_kp_aug,
-                  const float* g_kp_frame, float* g_heat, int accumulate, lp_stream_t stream);
+                  const float* g_kp_frame, float* g_heat, int accumulate, int prune, lp_stream_t stream);
 
 /* data/utils.py:191-234 undo_affine_transform_batch + data/bboxes.py:222-288 model_to_frame_batch on their own
  * (target keypoints; backward = 1 applies the transposed Jacobian to a gradient). */
@@ -188,6 +196,8 @@ typedef struct lp_conv_geom {
 #define LP_CONV_KERNEL_WGRAD 2
 #define LP_CONV_KERNEL_WGRAD_PIPE 3
 #define LP_CONV_KERNEL_PIPE_HALO 4 /* conv_pipe_kernel<..., HALO>: 3x3 / stride 1, the input neighbourhood staged once (LP_CONV_HALO=0 disables) */
+#define LP_CONV_KERNEL_SPEC 6      /* conv_spec_kernel: the operand ring with producer / consumer wave roles and the store pass handed to the producers (LP_CONV_SPEC=0 disables) */
+#define LP_CONV_KERNEL_SPEC_HALO 7 /* ... its HALO form */
 #define LP_CONV_KERNEL_RES2D 5     /* conv_res2d_kernel: 3x3 / stride 1, 64 -> 64 channels, 16 x 16 tiles, filter resident in LDS (LP_CONV_RES2D=0 disables) */
 int lp_conv_last_kernel(void);
 
@@ -393,13 +403,16 @@ int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const flo
 /* dx = gamma * invstd * (dz - sum(dz)/N - xhat * sum(dz*xhat)/N) [, dres = dz].  `sums`: the totals the two correction terms use - the
  * buffer after the SyncBatchNorm all-reduce, with count = rows x world size - or NULL: no batch-statistics terms (eval-mode BatchNorm is a
  * fixed affine map).  `sums_local` (this rank's sums, before any exchange; may equal sums) + dbeta_acc / dgamma_acc (optional): the
- * BatchNorm's parameter gradients d beta += sum dz, d gamma += sum dz*xhat over the segments, added by one thread per channel. */
+ * BatchNorm's parameter gradients d beta += sum dz, d gamma += sum dz*xhat over the segments, added by one thread per channel.
+ * `terms_ws` (round 5): caller-owned scratch of segments x 2 x C floats, or NULL.  With it the call is two launches - a one-thread-per-value
+ * conversion of the fixed-point sums to sum / count (+ the parameter gradients), then the streaming kernel reading plain floats; without it
+ * one self-contained launch that converts the table into LDS per workgroup (C <= 2048 only; ~10 us slower per launch). */
 int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
                     const lp_fxsum* sums, float count, int M, int C, void* dx, void* dres, const lp_fxsum* sums_local, float* dbeta_acc,
-                    float* dgamma_acc, lp_stream_t stream);
+                    float* dgamma_acc, float* terms_ws, lp_stream_t stream);
 int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
                         const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
-                        const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream);
+                        const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws, lp_stream_t stream);
 /* 3x3 / stride 2 / pad 1; argmax_u8 (B,Ho,Wo,C) records the winning tap (first maximum, ATen tie rule) for the backward gather */
 int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream);
 int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);

@@ -61,9 +61,10 @@ _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 PROTOTYPES = {
     "lp_version": (_I, []),
     "lp_strerror": (C.c_char_p, [_I]),
+    "lp_config_reload_env": (_I, []),
     "lp_decode_window": (_I, [_I, _I]),
-    "lp_decode_fwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _P]),
-    "lp_decode_bwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _I, _P]),
+    "lp_decode_fwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _I, _P]),
+    "lp_decode_bwd": (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(DecodeTables), C.POINTER(FrameMap), _P, _P, _P, _P, _I, _I, _P]),
     "lp_frame_map_apply": (_I, [_P, _I, _I, C.POINTER(FrameMap), _I, _P, _P]),
     "lp_heatmap_gen": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "lp_heatmap_gen_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
@@ -95,7 +96,6 @@ PROTOTYPES = {
     "lp_attn_dscores": (_I, [_P, _I, _P, _I, _P, _P, _I, C.c_longlong, C.c_longlong, C.c_float, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_conv_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_last_kernel": (_I, []),
-    "lp_decode_set_prune": (_I, [_I]),
     "lp_stem_fwd_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, C.POINTER(BnFuse), _P]),
     "lp_conv_dgrad_bn": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, C.POINTER(BnFuse), _P]),
     "lp_bn_fold": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P]),
@@ -113,9 +113,9 @@ PROTOTYPES = {
     "lp_bn_finalize2": (_I, [_P, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "lp_bn_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
-    "lp_bn_bwd_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "lp_bn_bwd_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "lp_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _Z, _P]),
-    "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "lp_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "lp_maxpool_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_maxpool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "lp_bn_relu_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

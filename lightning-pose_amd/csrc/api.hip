@@ -1,7 +1,37 @@
 // Library-level entry points of liblp_hip.so.
 #include "lp_common.h"
 
-extern "C" int lp_version(void) { return 120; }  // 0.2.0: + two BatchNorm segments per launch (lp_bn_fuse.seg_images, lp_bn_finalize2), fp32 validation path (lp_f32_*)
+#include <stdlib.h>
+
+extern "C" int lp_version(void) { return 130; }  // 0.3.0: decode `prune` is a call argument, the LP_* switches are read once at load (lp_config_reload_env)
+
+namespace lp {
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e == nullptr || *e == 0) ? dflt : atoi(e);
+}
+static LpSwitches read_switches() {
+    LpSwitches s;
+    s.conv_pipe = env_int("LP_CONV_PIPE", 1);       // 0: every convolution on conv_igemm_kernel / conv_wgrad_kernel
+    s.conv_halo = env_int("LP_CONV_HALO", 1);       // 0: the 3x3 layers on the per-tap ring
+    s.conv_res2d = env_int("LP_CONV_RES2D", 1);     // 0: layer1's 64 -> 64 3x3 layers on the HALO form
+    s.conv_spec = env_int("LP_CONV_SPEC", 0);       // 1: producer / consumer wave-specialised launches where they apply (conv_spec.h)
+    s.infer_pipe = env_int("LP_INFER_PIPE", 1);     // 0: lp_conv_fwd_act on conv_igemm_kernel<infer>
+    s.gemm_pipe = env_int("LP_GEMM_PIPE", 1);       // 0: the Linear layers on conv_igemm_kernel
+    s.wgrad_pipe = env_int("LP_WGRAD_PIPE", 1);     // 0: weight gradients on conv_wgrad_kernel; 2: the pipelined kernel wherever it can run
+    s.stem_2d = env_int("LP_STEM_2D", 1);           // 0: the stem on conv_igemm_kernel<64, stem>
+    s.pool_v2 = env_int("LP_POOL_V2", 1);           // 0: the stem's pool backward on the first kernel
+    s.conv_max_wgs = env_int("LP_CONV_MAX_WGS", 0); // > 0: cap of the persistent grids (tests: several tiles per workgroup on small problems)
+    return s;
+}
+static LpSwitches g_switches = read_switches();     // (dynamic initialisation at library load)
+const LpSwitches& lp_switches() { return g_switches; }
+}  // namespace lp
+
+extern "C" int lp_config_reload_env(void) {
+    lp::g_switches = lp::read_switches();
+    return LP_OK;
+}
 
 extern "C" const char* lp_strerror(int code) {
     if (code == LP_OK) return "ok";

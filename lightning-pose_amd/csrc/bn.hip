@@ -273,13 +273,20 @@ __device__ __forceinline__ void bn_param_grads(const lp_fxsum* __restrict__ loca
 constexpr int kBnBwdMaxC = 2048;   // widest BatchNorm bn_bwd_apply_kernel takes (ResNet-50's layer4): 32 KB of LDS for its correction terms
 // (launch bounds: 5 waves per SIMD = 96 VGPRs, as before the fixed-point sums; the allocator spills two values, outside the chunk loop;
 // without the bound: 102 VGPRs = 4 waves, the same speed - profiles/r04o_*)
+// TERMS = true (round 5): the correction terms arrive as plain floats `terms` [segment][2][C] (bn_bwd_terms_kernel below converted them and
+// added the parameter gradients, one tiny launch in front of this one): no LDS table, no barrier, no 64-bit conversions in the streaming
+// kernel - its 1280 workgroups (ONE resident round: every one of them used to sit in that prologue at the same time, with HBM idle;
+// ~10 us of a 122 us launch, profiles/r04r_bn_bwd_prologue.txt) start streaming after one L2 round trip.  TERMS = false keeps the
+// self-contained form for callers without a workspace (lp_bn_bwd_apply(..., terms_ws = NULL)).
+template <bool TERMS>
 __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
                                                            const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const lp_fxsum* __restrict__ sums, float inv_count, size_t n_total, int C,
                                                            unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES,
                                                            size_t seg_chunk, float inv_count1, const lp_fxsum* __restrict__ local,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                           const float* __restrict__ terms) {
     // (segments as in bn_apply_kernel: mean / invstd rows of C, sums rows of 2 C, one 1 / count per segment)
     const int chunks = C >> 3;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -289,18 +296,20 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
     // The correction terms sum / count of the whole launch ([segment][2][C], C <= kBnBwdMaxC: host-checked) are converted from fixed point
     // ONCE per workgroup, a few per thread, into LDS.  Converted per lane (16 values per segment, four registers each while in flight) the
     // kernel needed 130 instead of 94 VGPRs = 3 instead of 5 waves per SIMD and the step lost 2.6 ms (profiles/r04m_*).  nullptr: zeros.
-    __shared__ float kterm[2 * 2 * kBnBwdMaxC];
-    bn_param_grads(local, nseg, C, dbeta, dgamma);
-    __builtin_amdgcn_sched_barrier(0);   // (keeps the parameter-gradient code's registers out of the walk's allocation)
+    __shared__ float kterm[TERMS ? 1 : 2 * 2 * kBnBwdMaxC];
+    if (!TERMS) {
+        bn_param_grads(local, nseg, C, dbeta, dgamma);
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the parameter-gradient code's registers out of the walk's allocation)
+    }
     // segment 0's per-channel terms are requested BEFORE the conversion and its barrier, so the workgroup waits one memory latency, not two
     float mu[8], is[8], ga[8], k0[8], k1[8];
+    if (!TERMS) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        mu[i] = mean[c + i];
-        is[i] = invstd[c + i];
-        ga[i] = gamma[c + i];
-    }
-    {
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = mean[c + i];
+            is[i] = invstd[c + i];
+            ga[i] = gamma[c + i];
+        }
         constexpr int UC = 8;   // conversions in flight per thread (C = 2048, two segments: 32 per thread = 4 round trips to L2)
         const int n = nseg * 2 * C;
         for (int e0 = threadIdx.x; e0 < n; e0 += 256 * UC) {
@@ -318,20 +327,21 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
                 if (e < n) kterm[e] = fx_value(&v) * (e < 2 * C ? inv_count : inv_count1);
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     for (int sg = 0; sg < nseg; ++sg) {
     const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
     size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
+    const float* kt = TERMS ? terms : kterm;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (sg > 0) {
+        if (TERMS || sg > 0) {
             mu[i] = mean[sg * C + c + i];
             is[i] = invstd[sg * C + c + i];
         }
         ga[i] = gamma[c + i] * is[i];
-        k0[i] = kterm[sg * 2 * C + c + i];
-        k1[i] = kterm[sg * 2 * C + C + c + i];
+        k0[i] = kt[sg * 2 * C + c + i];
+        k1[i] = kt[sg * 2 * C + C + c + i] * is[i];   // (xhat k1 = (x - mean) (invstd k1): one register array less in the walk)
     }
     constexpr int U = 2;
     for (; q < n_chunks; q += U * stride) {
@@ -356,14 +366,23 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float xh = (x[i] - mu[i]) * is[i];
-                o[i] = ga[i] * (dz[i] - k0[i] - xh * k1[i]);
+                o[i] = ga[i] * (dz[i] - k0[i] - (x[i] - mu[i]) * k1[i]);
             }
             *reinterpret_cast<u16x8*>(DX + (q + u * stride) * 8) = pack8(o);
             if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + (q + u * stride) * 8) = pack8(dz);
         }
     }
     }
+}
+
+// The launch in front of bn_bwd_apply_kernel<true>: terms[seg][2][C] = sum / count as floats (zeros without `sums`: eval-mode BatchNorm),
+// and the BatchNorm's parameter gradients (bn_param_grads) - one thread per value.
+__global__ __launch_bounds__(256) void bn_bwd_terms_kernel(const lp_fxsum* __restrict__ sums, float inv_count0, float inv_count1, int C, int nseg,
+                                                           float* __restrict__ terms, const lp_fxsum* __restrict__ local, float* __restrict__ dbeta,
+                                                           float* __restrict__ dgamma) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nseg * 2 * C) terms[e] = sums != nullptr ? fx_value(&sums[e]) * (e < 2 * C ? inv_count0 : inv_count1) : 0.f;
+    bn_param_grads(local, nseg, C, dbeta, dgamma);
 }
 
 // ---- 3x3 stride-2 pad-1 max-pool on NHWC bf16 --------------------------------------------------------------
@@ -750,8 +769,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_v2_kernel(const unsigned char
 static int pool_v2_band() { return 6; }
 
 static bool pool_v2_ok(int C, int Hi, int Wi, int Ho, int Wo) {
-    const char* e = getenv("LP_POOL_V2");
-    if (e != nullptr && atoi(e) == 0) return false;
+    if (lp_switches().pool_v2 == 0) return false;
     return C == 64 && Wo <= kPbW && Hi <= 2 * Ho && Wi <= 2 * Wo;
 }
 
@@ -964,30 +982,43 @@ extern "C" int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x
 
 static int bn_bwd_apply_impl(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
                              const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
-                             const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
+                             const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(dy && x && mean && invstd && gamma && dx && M > 0 && C > 0 && count0 > 0.f && count1 > 0.f && seg_rows >= 0 && seg_rows < M);
     LP_REQUIRE(sums_local != nullptr || (dbeta_acc == nullptr && dgamma_acc == nullptr));
-    if (C % 8 != 0 || C > kBnBwdMaxC) return LP_ERR_UNSUPPORTED;
+    if (C % 8 != 0 || (terms_ws == nullptr && C > kBnBwdMaxC)) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+    if (terms_ws != nullptr) {   // two launches: the conversion + parameter gradients (one thread per value), then the streaming kernel
+        const int nseg = seg_rows > 0 ? 2 : 1;
+        hipLaunchKernelGGL(bn_bwd_terms_kernel, dim3((nseg * 2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, 1.f / count0, 1.f / count1, C,
+                           nseg, terms_ws, sums_local, dbeta_acc, dgamma_acc);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+                           (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count0, n_chunks, C,
+                           (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1, sums_local, dbeta_acc, dgamma_acc,
+                           (const float*)terms_ws);
+        return launch_status();
+    }
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
                        (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count0, n_chunks, C,
-                       (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1, sums_local, dbeta_acc, dgamma_acc);
+                       (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1, sums_local, dbeta_acc, dgamma_acc,
+                       (const float*)nullptr);
     return launch_status();
 }
 
 extern "C" int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
                                const float* gamma, const lp_fxsum* sums, float count, int M, int C, void* dx, void* dres,
-                               const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
-    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count, count, M, C, 0, dx, dres, sums_local, dbeta_acc, dgamma_acc, stream);
+                               const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws, lp_stream_t stream) {
+    return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count, count, M, C, 0, dx, dres, sums_local, dbeta_acc, dgamma_acc, terms_ws,
+                             stream);
 }
 
 // two segments: mean / invstd (2, C), sums (2, 2, C), one row count per segment (times the world size under SyncBatchNorm)
 extern "C" int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
                                    const float* gamma, const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx,
-                                   void* dres, const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, lp_stream_t stream) {
+                                   void* dres, const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws,
+                                   lp_stream_t stream) {
     return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count0, count1, M, C, seg_rows, dx, dres, sums_local, dbeta_acc,
-                             dgamma_acc, stream);
+                             dgamma_acc, terms_ws, stream);
 }
 
 extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {

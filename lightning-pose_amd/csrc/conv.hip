@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 
 #include "conv_pipe.h"
 #include "conv_res2d.h"
+#include "conv_spec.h"
 
 namespace lp {
 
@@ -1073,10 +1074,8 @@ static thread_local int g_last_conv_kernel = LP_CONV_KERNEL_IGEMM;
 // stride walk keeps every workgroup on its XCD's tile range.  LP_CONV_MAX_WGS overrides the cap (tests use it to force several
 // tiles per workgroup on small problems).
 static int igemm_max_wgs() {
+    if (lp_switches().conv_max_wgs > 0) return lp_switches().conv_max_wgs;
     static int v = [] {
-        const char* e = getenv("LP_CONV_MAX_WGS");
-        const int n = e ? atoi(e) : 0;
-        if (n > 0) return n;
         int dev = 0, cus = 0;  // 2 workgroups per CU are resident (LDS-bound): 512 on a full MI355X, fewer on a partition
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
@@ -1110,16 +1109,11 @@ static int launch_igemm(const void* x, const void* w, const ConvGeom& g, const L
 }
 
 // Pipelined kernel (conv_pipe.h): one 512-thread workgroup per CU walks 256 x BN tiles.  LP_CONV_PIPE=0 sends everything to
-// conv_igemm_kernel instead (A/B runs, and the tests that compare the two kernels bit for bit); read per call.
-static bool conv_pipe_enabled() {
-    const char* e = getenv("LP_CONV_PIPE");
-    return e == nullptr || atoi(e) != 0;
-}
+// conv_igemm_kernel instead (A/B runs, and the tests that compare the two kernels bit for bit).
+static bool conv_pipe_enabled() { return lp_switches().conv_pipe != 0; }
 
 static int pipe_max_wgs() {
-    const char* e = getenv("LP_CONV_MAX_WGS");   // (tests: several tiles per workgroup on small problems; read per call)
-    const int n = e ? atoi(e) : 0;
-    if (n > 0) return n;
+    if (lp_switches().conv_max_wgs > 0) return lp_switches().conv_max_wgs;   // (tests: several tiles per workgroup on small problems)
     static int cus = [] {
         int dev = 0, c = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
@@ -1152,10 +1146,9 @@ static int pipe_dgrad_kind(const ConvEpilogue& ep) {
 
 // HALO form (conv_pipe.h): 3x3 / stride 1 / pad 1 with the tile's input neighbourhood staged once per 64-channel slice.  Eligible when the
 // neighbourhood of every 256-pixel tile (in padded raster coordinates) fits the kernel's halo image: `cap_rows` = 512 (BN = 64) or 384.
-// LP_CONV_HALO=0 keeps those layers on the per-tap ring (A/B runs, bit-identity tests); read per call.
+// LP_CONV_HALO=0 keeps those layers on the per-tap ring (A/B runs, bit-identity tests).
 static bool pipe_halo_ok(const ConvGeom& g, int M, int ck, int cap_rows) {
-    const char* e = getenv("LP_CONV_HALO");
-    if (e != nullptr && atoi(e) == 0) return false;
+    if (lp_switches().conv_halo == 0) return false;
     if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || g.Hi != g.Ho || g.Wi != g.Wo || ck % kBK != 0) return false;
     struct Memo { int B, H, W, cap; bool ok; };
     static thread_local Memo memo[8];
@@ -1177,10 +1170,9 @@ static bool pipe_halo_ok(const ConvGeom& g, int M, int ck, int cap_rows) {
 }
 
 // conv_res2d_kernel (conv_res2d.h): 3x3 / stride 1 / pad 1 with 64 channels in and out on 16 x 16 pixel tiles, the whole filter resident
-// in LDS.  LP_CONV_RES2D=0 leaves those layers to conv_pipe_kernel's HALO form (A/B runs, bit-identity tests); read per call.
+// in LDS.  LP_CONV_RES2D=0 leaves those layers to conv_pipe_kernel's HALO form (A/B runs, bit-identity tests).
 static bool res2d_ok(const ConvGeom& g, int ck, int N, const ConvEpilogue& ep) {
-    const char* e = getenv("LP_CONV_RES2D");
-    if (e != nullptr && atoi(e) == 0) return false;
+    if (lp_switches().conv_res2d == 0) return false;
     return g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.Hi == g.Ho && g.Wi == g.Wo && ck == 64 && N == 64 && g.Hi % 16 == 0 &&
            g.Wi % 16 == 0;
 }
@@ -1211,10 +1203,36 @@ static int launch_pipe(const void* x, const void* w, const ConvGeom& g, const La
     return grid;
 }
 
+// conv_spec_kernel (conv_spec.h): producer / consumer wave roles on the same ring, the store pass handed to the producers.  256 x 128 tiles,
+// no bias, at least `min_steps` K steps per tile (the handed-over store pass is spread over a tile's first 4 - 7 K steps).  LP_CONV_SPEC=0
+// keeps conv_pipe_kernel (A/B runs, bit-identity tests).
+static bool spec_ok(const ConvEpilogue& ep, int N, int K, int min_steps) {
+    return lp_switches().conv_spec != 0 && N % 128 == 0 && ep.bias == nullptr && K / kBK >= min_steps;
+}
+
+template <int MODE, int EK, bool HALO>
+static int launch_spec(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
+                        hipStream_t st) {
+    const int tm = (M + kPM - 1) / kPM, tn = N / 128, ntiles = tm * tn;
+    const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
+    const int ck = MODE == kModeDgrad ? g.Co : g.Ci;
+    const unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
+    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * ck);
+    g_last_conv_kernel = HALO ? LP_CONV_KERNEL_SPEC_HALO : LP_CONV_KERNEL_SPEC;
+    const HaloDivs hd{make_fastdiv(g.Hi), make_fastdiv(g.Wi + 2), make_fastdiv(g.Hi + 2)};
+    hipLaunchKernelGGL((conv_spec_kernel<MODE, EK, HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w,
+                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, hd);
+    return grid;
+}
+
 template <int BN>
 static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
                              const ConvEpilogue& ep, hipStream_t st) {
     if (kind == kEkZ && BN == 64 && ep.bias == nullptr && res2d_ok(g, g.Co, N, ep)) return launch_res2d<kModeDgrad>(x, w, g, ep, st);
+    if (kind == kEkZ && BN == 128 && spec_ok(ep, N, K, 7)) {
+        if (pipe_halo_ok(g, M, g.Co, 384)) return launch_spec<kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
+        return launch_spec<kModeDgrad, kEkZ, false>(x, w, g, lat, M, N, K, ep, st);
+    }
     if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) return launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkZ) return launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkAZB) return launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
@@ -1361,7 +1379,11 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     if (pipe_eligible(ep, M, N, K, g.Ci, split, true)) {
         if (N > 64) {
-            if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            const bool halo = pipe_halo_ok(g, M, g.Ci, 384);
+            if (spec_ok(ep, N, K, 4)) {
+                if (halo) launch_spec<kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+                else launch_spec<kModeFwd, kEkNone, false>(x, w, g, lat, M, N, K, ep, st);
+            } else if (halo) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
             else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         } else if (ep.bias == nullptr && res2d_ok(g, g.Ci, N, ep)) {
             launch_res2d<kModeFwd>(x, w, g, ep, st);
@@ -1399,13 +1421,13 @@ extern "C" int lp_conv_fwd_act(const void* x, const void* w, const lp_conv_geom*
     const Lattice lat{0, 1, g.Ho, 0, 1, g.Wo, 0, 1, g.R, 0, 1, g.S};
     hipStream_t st = (hipStream_t)stream;
     // the pipelined forward kernel with the residual and the ReLU in its store pass (LP_INFER_PIPE=0: A/B runs keep conv_igemm_kernel<infer>)
-    const char* ip = getenv("LP_INFER_PIPE");
-    if ((ip == nullptr || atoi(ip) != 0) && ep.addend == nullptr && res2d_ok(g, g.Ci, N, ep)) {
+    const bool ip = lp_switches().infer_pipe != 0;
+    if (ip && conv_pipe_enabled() && ep.addend == nullptr && res2d_ok(g, g.Ci, N, ep)) {   // (LP_CONV_PIPE=0 keeps these layers on conv_igemm_kernel too)
         // layer1's 64 -> 64 3x3 layers: 16 x 16 tiles, the filter resident in LDS (round 4: the inference store pass of conv_res2d_kernel)
         launch_res2d<kModeFwd, true>(x, w, g, ep, st);
         return launch_status();
     }
-    if ((ip == nullptr || atoi(ip) != 0) && pipe_eligible(ep, M, N, K, g.Ci, M, true)) {
+    if (ip && pipe_eligible(ep, M, N, K, g.Ci, M, true)) {
         if (N > 64) {
             if (pipe_halo_ok(g, M, g.Ci, 384)) launch_pipe<128, kModeFwd, kEkInfer, true>(x, w, g, lat, M, N, K, ep, st);
             else launch_pipe<128, kModeFwd, kEkInfer>(x, w, g, lat, M, N, K, ep, st);
@@ -1453,8 +1475,8 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     hipStream_t st = (hipStream_t)stream;
     const int nstore = ep.n_store;
     // a dense, unbatched product (every Linear layer of the ViT, forward and data gradient) is a 1x1 convolution: the pipelined kernel
-    const char* gpe = getenv("LP_GEMM_PIPE");   // (A/B: 0 keeps the Linear layers on conv_igemm_kernel; read per call)
-    if ((gpe == nullptr || atoi(gpe) != 0) && nb * nh == 1 && lda == K && ldb == K && ldc == N && pipe_eligible(ep, M, N, K, K, M, true)) {
+    // (LP_GEMM_PIPE=0, A/B: keeps the Linear layers on conv_igemm_kernel)
+    if (lp_switches().gemm_pipe != 0 && nb * nh == 1 && lda == K && ldb == K && ldc == N && pipe_eligible(ep, M, N, K, K, M, true)) {
         if (N > 64) launch_pipe<128, kModeFwd, kEkNone>(a, b, g, lat, M, N, K, ep, st);
         else launch_pipe<64, kModeFwd, kEkNone>(a, b, g, lat, M, N, K, ep, st);
         return launch_status();
@@ -1613,9 +1635,9 @@ static int conv_wgrad_impl(const void* x, const void* dy, const lp_conv_geom* ge
     LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
-    const char* wpe = getenv("LP_WGRAD_PIPE");   // (A/B: 0 keeps the weight gradients on conv_wgrad_kernel; 2 = wherever it can run)
-    if (!dbias && conv_pipe_enabled() && (wpe == nullptr || atoi(wpe) != 0)) {
-        const WgradPipePlan pp = plan_wgrad_pipe(g, split_hint, wpe != nullptr && atoi(wpe) == 2);
+    const int wpe = lp_switches().wgrad_pipe;   // (LP_WGRAD_PIPE, A/B: 0 keeps the weight gradients on conv_wgrad_kernel; 2 = wherever it can run)
+    if (!dbias && conv_pipe_enabled() && wpe != 0) {
+        const WgradPipePlan pp = plan_wgrad_pipe(g, split_hint, wpe == 2);
         if (pp.ok && workspace_bytes >= pp.ws_floats * sizeof(float)) {
             launch_wgrad_pipe(pp, x, dy, g, dw, ws, st);
             return launch_status();
@@ -1710,8 +1732,7 @@ static int stem_fwd_impl(const void* x4, const void* w, const lp_conv_geom* geom
     }
     // conv_stem2d_kernel (conv_res2d.h): 16 x 16 output tiles, filter resident in LDS.  LP_STEM_2D=0 (A/B runs, bit-identity tests) keeps
     // conv_igemm_kernel<64, stem>
-    const char* s2 = getenv("LP_STEM_2D");
-    if (conv_pipe_enabled() && (s2 == nullptr || atoi(s2) != 0) && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo) {
+    if (conv_pipe_enabled() && lp_switches().stem_2d != 0 && g.Ho % 16 == 0 && g.Wo % 16 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo) {
         const int ntiles = g.B * (g.Ho / 16) * (g.Wo / 16);
         const int grid = ntiles < 2 * pipe_max_wgs() ? ntiles : 2 * pipe_max_wgs();
         g_last_conv_kernel = LP_CONV_KERNEL_RES2D;

@@ -587,24 +587,11 @@ static int decode_bwd_threads(int h, int TY) {
     return waves * 64;
 }
 
-// LP_DECODE_PRUNE=1 selects the pruning instantiations (read per call: tests and profiles/decode_microbench.py A/B it).  Opt-in: on the
-// FLAT maps of an untrained network nothing can be skipped and the pruning state costs one resident workgroup per CU (fwd 94 vs 71 VGPRs),
-// on the PEAKED maps of a trained one it skips most of the work - see DESIGN.md section 4.2 for the measured numbers
 // Exact pruning of the T = 1000 soft-argmax (kernels above): pays on the peaked maps of a trained head (forward 1.4x, backward 1.8x),
-// costs on flat ones.  The host decides: lp_decode_set_prune(0 / 1) - the product's default is automatic (ops.py watches the decode's own
-// sum-of-exponentials output, a direct measure of how many pixels carry weight) - or, while nothing was set, LP_DECODE_PRUNE=1.
-static int g_decode_prune = -1;
-static int decode_prune() {
-    if (g_decode_prune >= 0) return g_decode_prune;
-    const char* e = getenv("LP_DECODE_PRUNE");
-    return e != nullptr && atoi(e) == 1;
-}
-
-extern "C" int lp_decode_set_prune(int mode) {
-    g_decode_prune = mode < 0 ? -1 : (mode != 0);
-    return LP_OK;
-}
-
+// costs on the FLAT maps of an untrained network, where nothing can be skipped and the pruning state costs one resident workgroup per CU
+// (fwd 94 vs 71 VGPRs) - DESIGN.md section 4.2 for the measured numbers.  The CALLER decides, per call: the `prune` argument of
+// lp_decode_fwd / lp_decode_bwd (round 5; until round 4 a process-wide switch, lp_decode_set_prune + LP_DECODE_PRUNE).  The product's
+// default is automatic: ops.py watches the decode's own sum-of-exponentials output, a direct measure of how many pixels carry weight.
 template <typename Kern>
 static void allow_large_lds(Kern kern, size_t bytes) {
     // opt in to > 64 KiB of dynamic LDS (gfx950 has 160 KiB per workgroup)
@@ -625,7 +612,7 @@ extern "C" int lp_decode_window(int downsample_factor, int n) {
 
 extern "C" int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
                              const lp_decode_tables* t, const lp_frame_map* f, float* kp_aug, float* kp_frame, float* conf,
-                             float* stats, lp_stream_t stream) {
+                             float* stats, int prune_mode, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(heat && t && f && kp_aug && kp_frame && conf && stats);
     LP_REQUIRE(B >= 0 && K > 0 && h > 0 && w > 0);
@@ -641,7 +628,7 @@ extern "C" int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B * K), block(decode_fwd_threads(w * R));
     const bool full = t->tx == kTXM;
-    const bool prune = decode_prune() && h <= kPruneMaxDim && w <= kPruneMaxDim;
+    const bool prune = prune_mode != 0 && h <= kPruneMaxDim && w <= kPruneMaxDim;
 #define LP_LAUNCH_FWD2(RR, TT, FF, PP)                                                                                      \
     allow_large_lds(decode_fwd_kernel<RR, TT, FF, PP>, smem + (PP ? sizeof(PruneState) : 0));                               \
     hipLaunchKernelGGL((decode_fwd_kernel<RR, TT, FF, PP>), grid, block, smem + (PP ? sizeof(PruneState) : 0), st, heat, K, h, w, \
@@ -668,7 +655,7 @@ extern "C" int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int 
 
 extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
                              const lp_decode_tables* t, const lp_frame_map* f, const float* stats, const float* g_aug,
-                             const float* g_frame, float* g_heat, int accumulate, lp_stream_t stream) {
+                             const float* g_frame, float* g_heat, int accumulate, int prune_mode, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(heat && t && f && stats && g_heat && (g_aug || g_frame));
     LP_REQUIRE(B >= 0 && K > 0 && h > 0 && w > 0);
@@ -686,7 +673,7 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(B * K), block(nthreads);
     const bool full = t->tx == kTXM;
-    const bool prune = decode_prune() && h <= kPruneMaxDim && w <= kPruneMaxDim;
+    const bool prune = prune_mode != 0 && h <= kPruneMaxDim && w <= kPruneMaxDim;
 #define LP_LAUNCH_BWD(RR, TT, NN, FF, PP)                                                                                   \
     allow_large_lds(decode_bwd_kernel<RR, TT, NN, FF, PP>, smem + (PP ? sizeof(PruneState) : 0));                           \
     hipLaunchKernelGGL((decode_bwd_kernel<RR, TT, NN, FF, PP>), grid, block, smem + (PP ? sizeof(PruneState) : 0), st, heat, K, h, w, \

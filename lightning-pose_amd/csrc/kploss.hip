@@ -59,57 +59,59 @@ __global__ __launch_bounds__(256) void temporal_kernel(const float* __restrict__
 // ---- PCA reprojection ---------------------------------------------------------------------------------
 // sample (s, j): x[2p], x[2p+1] = kp[s, idx[j*P + p]];  r = (x-mu) - V^T V (x-mu);  loss = mean relu(||r_p|| - eps).
 // singleview: rows = 1, P = selected keypoints;  multiview: rows = matched keypoints, P = views.
-__global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ kp, int S, int K, const int* __restrict__ idx, int rows,
-                                                  int P, const float* __restrict__ mean, const float* __restrict__ evecs, int ncomp,
-                                                  float eps, float* __restrict__ loss, float* __restrict__ grad) {
-    __shared__ float red[4];
-    const int D = 2 * P;
+// One WAVE per sample, one lane per point (P <= 64): the sample's coordinates, residual and gradient live in two registers per lane and a
+// projection coefficient is one wave reduction, so nothing is indexed dynamically (round 4's form - one THREAD per sample with three private
+// arrays of 128 floats - ran from 1552 B of scratch and took 104 us for < 20 KB of data).  16 waves walk the samples; the kept
+// eigenvectors are staged in LDS once.  The loss partials are added in a fixed order (lanes, then waves): bit-reproducible.
+constexpr int kPcaWaves = 16;
+__global__ __launch_bounds__(64 * kPcaWaves) void pca_kernel(const float* __restrict__ kp, int S, int K, const int* __restrict__ idx, int rows,
+                                                             int P, const float* __restrict__ mean, const float* __restrict__ evecs, int ncomp,
+                                                             float eps, float* __restrict__ loss, float* __restrict__ grad) {
+    HIP_DYNAMIC_SHARED(float, ev)   // [ncomp][2 P]
+    __shared__ float red[kPcaWaves];
+    const int D = 2 * P, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv_n = 1.f / (float)(S * rows * P);
-    for (int i = threadIdx.x; i < S * K * 2; i += 256) grad[i] = 0.f;
+    for (int i = tid; i < ncomp * D; i += 64 * kPcaWaves) ev[i] = evecs[i];
+    for (int i = tid; i < S * K * 2; i += 64 * kPcaWaves) grad[i] = 0.f;
     __syncthreads();
+    const bool act = lane < P;
+    const int lp = act ? lane : 0;
+    const float m0 = mean[2 * lp], m1 = mean[2 * lp + 1];
     float part = 0.f;
-    for (int smp = threadIdx.x; smp < S * rows; smp += 256) {
+    for (int smp = wave; smp < S * rows; smp += kPcaWaves) {   // (wave-uniform trip count: the reductions below involve all 64 lanes)
         const int s = smp / rows, j = smp - s * rows;
-        float xc[kMaxPcaDim], r[kMaxPcaDim], u[kMaxPcaDim];
-        for (int p = 0; p < P; ++p) {
-            const int kk = idx[j * P + p];
-            xc[2 * p] = kp[(s * K + kk) * 2] - mean[2 * p];
-            xc[2 * p + 1] = kp[(s * K + kk) * 2 + 1] - mean[2 * p + 1];
-        }
-        for (int d = 0; d < D; ++d) r[d] = xc[d];
+        const int kk = idx[j * P + lp];
+        const float x0 = act ? kp[(s * K + kk) * 2] - m0 : 0.f, x1 = act ? kp[(s * K + kk) * 2 + 1] - m1 : 0.f;
+        float r0 = x0, r1 = x1;
         for (int c = 0; c < ncomp; ++c) {
-            float dot = 0.f;
-            for (int d = 0; d < D; ++d) dot = fmaf(xc[d], evecs[c * D + d], dot);
-            for (int d = 0; d < D; ++d) r[d] = fmaf(-dot, evecs[c * D + d], r[d]);
+            const float e0 = act ? ev[c * D + 2 * lp] : 0.f, e1 = act ? ev[c * D + 2 * lp + 1] : 0.f;
+            const float dot = wave_sum(fmaf(x1, e1, x0 * e0));
+            r0 = fmaf(-dot, e0, r0);
+            r1 = fmaf(-dot, e1, r1);
         }
-        for (int p = 0; p < P; ++p) {
-            const float n = sqrtf(r[2 * p] * r[2 * p] + r[2 * p + 1] * r[2 * p + 1]);
-            const float v = n - eps;
-            if (v > 0.f) {
-                part += v;
-                u[2 * p] = r[2 * p] / n * inv_n;
-                u[2 * p + 1] = r[2 * p + 1] / n * inv_n;
-            } else {
-                u[2 * p] = 0.f;
-                u[2 * p + 1] = 0.f;
-            }
+        const float n = sqrtf(r0 * r0 + r1 * r1);
+        const float v = n - eps;
+        float u0 = 0.f, u1 = 0.f;
+        if (act && v > 0.f) {
+            part += v;
+            u0 = r0 / n * inv_n;
+            u1 = r1 / n * inv_n;
         }
         // dL/dx = (I - V^T V) u   (the projector is symmetric)
+        float g0 = u0, g1 = u1;
         for (int c = 0; c < ncomp; ++c) {
-            float dot = 0.f;
-            for (int d = 0; d < D; ++d) dot = fmaf(u[d], evecs[c * D + d], dot);
-            for (int d = 0; d < D; ++d) xc[d] = (c == 0 ? u[d] : xc[d]) - dot * evecs[c * D + d];
+            const float e0 = act ? ev[c * D + 2 * lp] : 0.f, e1 = act ? ev[c * D + 2 * lp + 1] : 0.f;
+            const float dot = wave_sum(fmaf(u1, e1, u0 * e0));
+            g0 = fmaf(-dot, e0, g0);
+            g1 = fmaf(-dot, e1, g1);
         }
-        if (ncomp == 0)
-            for (int d = 0; d < D; ++d) xc[d] = u[d];
-        for (int p = 0; p < P; ++p) {
-            const int kk = idx[j * P + p];
-            atomicAdd(&grad[(s * K + kk) * 2], xc[2 * p]);
-            atomicAdd(&grad[(s * K + kk) * 2 + 1], xc[2 * p + 1]);
+        if (act) {   // (an index may appear in several samples' rows: accumulate)
+            atomicAdd(&grad[(s * K + kk) * 2], g0);
+            atomicAdd(&grad[(s * K + kk) * 2 + 1], g1);
         }
     }
-    part = block_sum<4>(part, red);
-    if (threadIdx.x == 0) loss[0] = part * inv_n;
+    part = block_sum<kPcaWaves>(part, red);
+    if (tid == 0) loss[0] = part * inv_n;
 }
 
 // ---- RMSE diagnostic ------------------------------------------------------------------------------------
@@ -204,8 +206,11 @@ extern "C" int lp_pca_fwd_bwd(const float* kp, int S, int K, const int* index, i
     using namespace lp;
     LP_REQUIRE(kp && index && mean && kept_eigenvectors && loss && grad_unit && S > 0 && K > 0 && rows > 0 && points > 0);
     if (2 * points > kMaxPcaDim || ncomp > 2 * points || ncomp < 0) return LP_ERR_UNSUPPORTED;  // any number of kept components up to the dimension
-    hipLaunchKernelGGL(pca_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kp, S, K, index, rows, points, mean, kept_eigenvectors,
-                       ncomp, epsilon, loss, grad_unit);
+    const size_t smem = (size_t)(ncomp > 0 ? ncomp : 1) * 2 * points * sizeof(float);   // <= 64 KB (128 x 128 floats)
+    if (smem > 32 * 1024)   // (opt in to a large dynamic LDS window; gfx950 has 160 KB per workgroup)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pca_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(pca_kernel, dim3(1), dim3(64 * kPcaWaves), smem, (hipStream_t)stream, kp, S, K, index, rows, points, mean,
+                       kept_eigenvectors, ncomp, epsilon, loss, grad_unit);
     return launch_status();
 }
 

@@ -215,6 +215,15 @@ __device__ __forceinline__ void fx_add(lp_fxsum* p, float t) {
 __device__ __forceinline__ float fx_value(const lp_fxsum* p) { return (float)((double)p->hi * 0x1p-12 + (double)p->lo * 0x1p-60); }
 
 // ---- host-side launch epilogue ------------------------------------------------------------------
+// ---- the library's A/B switches (LP_CONV_PIPE, LP_CONV_HALO, ... - what each one selects is documented where it is used).  Read from the
+// environment ONCE, when the library is loaded (api.hip), into this table; the launch paths only read the table, so no entry point calls
+// getenv and the behaviour of a call does not depend on what the caller's environment holds at that moment.  lp_config_reload_env()
+// re-reads it (tests and A/B scripts that flip a switch inside one process).
+struct LpSwitches {
+    int conv_pipe, conv_halo, conv_res2d, conv_spec, infer_pipe, gemm_pipe, wgrad_pipe, stem_2d, pool_v2, conv_max_wgs;
+};
+const LpSwitches& lp_switches();
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LP_OK : (int)e;

@@ -794,8 +794,9 @@ class Engine:
         dres = torch.empty_like(z) if want_dres else None
         gam = _p(self.param_view(b, "weight"))
         counts = [float(n * rpi * world) for _, n in segs]
+        terms = torch.empty(len(segs) * 2 * Cn, device=z.device, dtype=torch.float32)   # sum / count as floats (written by the call's first launch)
         check(self._lib.lp_bn_bwd_apply_seg(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(total), counts[0], counts[-1], M, Cn,
-                                            seg * rpi, _p(dz), _p(dres), _p(local), _p(self.G[b.b_off:]), _p(self.G[b.g_off:]),
+                                            seg * rpi, _p(dz), _p(dres), _p(local), _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), _p(terms),
                                             ops._stream()), "lp_bn_bwd_apply_seg")
         return dz, dres
 

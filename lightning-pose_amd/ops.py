@@ -141,58 +141,51 @@ def _prune_env() -> str:
 
 
 class _DecodePruneAuto:
-    """Chooses between the plain and the exactly-pruned decode kernels (lp_decode_set_prune) from what the decode itself reports.
+    """Chooses between the plain and the exactly-pruned decode kernels (the `prune` argument of lp_decode_fwd / lp_decode_bwd) from what the
+    decode itself reports.
 
     stats[..., 1] of lp_decode_fwd is sum exp(T (y - max y)) over the up-sampled map = the number of pixels that carry weight in the
     soft-argmax: ~2 - 10 on the peaked maps of a trained head (T = 1000), ~all 147 456 on the flat maps of an untrained one.  Pruning pays
     (forward 1.4x, backward 1.8x, profiles/archive/r02k_decode_microbench.jsonl) when most maps are peaked and costs when they are flat, and which
     regime a run is in changes once, early in training.  So every PERIOD-th call (and the FIRST-th) the fraction of peaked maps is reduced
     on the device and copied to pinned host memory WITHOUT a synchronisation; a later call picks the value up once its event has
-    completed and flips the switch if needed.  LP_DECODE_PRUNE=0 / 1 pins the choice instead (read per call).
+    completed and flips the choice if needed.  LP_DECODE_PRUNE=0 / 1 pins the choice instead (read per call, here on the host: the
+    library itself holds no switch since round 5).
 
     One instance per OWNER (a tracker: HeatmapTracker._decode passes its own; stand-alone ops.decode calls share `_decode_prune_default`),
-    so one model's maps never steer another's kernels and a fresh model starts from the plain kernels (round 3 kept one process-wide
-    object: ADVICE r3).  The library's switch is process-wide, so every call states what its owner wants (`_lib_mode` caches what the
-    library was last given).  While the current stream is being captured into a HIP graph nothing here runs - no event query, no pinned
-    allocation, no copy, no counter: a replayed graph keeps the kernels it was captured with, and the eager steps around captures (the
-    warm-up steps, every re-capture at an epoch boundary) are where the choice is re-evaluated."""
+    so one model's maps never steer another's kernels and a fresh model starts from the plain kernels.  While the current stream is being
+    captured into a HIP graph nothing here runs - no event query, no pinned allocation, no copy, no counter: a replayed graph keeps the
+    kernels it was captured with, and the eager steps around captures are where the choice is re-evaluated."""
 
     PERIOD, FIRST, PEAKED_FRACTION_OF_PIXELS, PEAKED_MAPS = 32, 2, 0.01, 0.5
-    _lib_mode = -2   # what lp_decode_set_prune was last given by anyone (-2: nothing yet, -1: "follow the environment")
 
     def __init__(self) -> None:
         self.calls, self.pending, self.want = 0, None, 0   # want: this owner's current choice (0 plain, 1 pruned)
+        self.last = -2                                      # what the most recent decode call was given (-2: none yet)
 
     @property
     def state(self) -> int:
-        """what the library is set to right now (tests, bench): -1 environment, 0 plain, 1 pruned, -2 nothing set yet"""
-        return _DecodePruneAuto._lib_mode
-
-    @staticmethod
-    def _set(mode: int) -> None:
-        if mode != _DecodePruneAuto._lib_mode:
-            _lib.lib().lp_decode_set_prune(mode)
-            _DecodePruneAuto._lib_mode = mode
+        """the `prune` argument of this owner's most recent decode call (tests, bench): 0 plain, 1 pruned, -2 no call yet"""
+        return self.last
 
     @staticmethod
     def _capturing() -> bool:
         return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
-    def before(self) -> None:
+    def before(self) -> int:
+        """the `prune` argument for the call about to be made"""
         env = _prune_env()
-        if env != "auto":          # pinned by the environment: the library follows it
-            self._set(-1)
+        if env != "auto":          # pinned by the environment
             self.pending = None
-            return
-        if self._capturing():
-            self._set(self.want)   # (a host-side switch: harmless inside a capture)
-            return
-        if self.pending is not None:
+            self.last = int(env)
+            return self.last
+        if not self._capturing() and self.pending is not None:
             host, ev = self.pending
             if ev is None or ev.query():
                 self.want = 1 if float(host[0]) >= self.PEAKED_MAPS else 0
                 self.pending = None
-        self._set(self.want)
+        self.last = self.want
+        return self.last
 
     def after(self, stats: torch.Tensor, n_up: int) -> None:
         if _prune_env() != "auto" or self._capturing():
@@ -228,26 +221,26 @@ class _DecodeFn(torch.autograd.Function):
         kp_frame = torch.empty_like(kp_aug)
         conf = torch.empty(b, k, device=heat.device, dtype=torch.float32)
         stats = torch.empty(b, k, 4, device=heat.device, dtype=torch.float32)
-        prune.before()
+        mode = prune.before()
         check(_lib.lib().lp_decode_fwd(_p(heat), b, k, h, w, ds, float(temperature), C.byref(tables),
-                                       C.byref(frame_map.struct), _p(kp_aug), _p(kp_frame), _p(conf), _p(stats), _stream()),
+                                       C.byref(frame_map.struct), _p(kp_aug), _p(kp_frame), _p(conf), _p(stats), mode, _stream()),
               "lp_decode_fwd")
         prune.after(stats, h * w * (4 ** int(ds)))
         ctx.save_for_backward(heat, stats)
-        ctx.args = (ds, float(temperature), frame_map, tables, keep)
+        ctx.args = (ds, float(temperature), frame_map, tables, keep, mode)
         ctx.mark_non_differentiable(conf)
         return kp_aug.reshape(b, 2 * k), kp_frame.reshape(b, 2 * k), conf
 
     @staticmethod
     def backward(ctx, g_aug, g_frame, _g_conf):
         heat, stats = ctx.saved_tensors
-        ds, temperature, frame_map, tables, _keep = ctx.args
+        ds, temperature, frame_map, tables, _keep, mode = ctx.args   # (the backward runs the kernel family its forward ran)
         b, k, h, w = heat.shape
         ga = _f32c(g_aug) if g_aug is not None else None
         gf = _f32c(g_frame) if g_frame is not None else None
         g_heat = torch.empty_like(heat)
         check(_lib.lib().lp_decode_bwd(_p(heat), b, k, h, w, ds, temperature, C.byref(tables), C.byref(frame_map.struct),
-                                       _p(stats), _p(ga), _p(gf), _p(g_heat), 0, _stream()), "lp_decode_bwd")
+                                       _p(stats), _p(ga), _p(gf), _p(g_heat), 0, mode, _stream()), "lp_decode_bwd")
         return g_heat.to(ctx.in_dtype), None, None, None, None
 
 

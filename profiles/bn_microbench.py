@@ -53,7 +53,7 @@ for variant in (os.environ.get("LP_BN_VARIANTS", "0,1,2,3").split(",")):
         n = M * Cn * 2
         t_app = timeit(lambda: lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(gam), _p(bet), _p(res), 1, M, Cn, _p(y), _p(bits), st))
         t_app0 = timeit(lambda: lib.lp_bn_apply(_p(z), _p(mean), _p(invstd), _p(gam), _p(bet), None, 1, M, Cn, _p(y), None, st))
-        t_bwd = timeit(lambda: lib.lp_bn_bwd_apply(_p(res), None, _p(z), _p(mean), _p(invstd), _p(gam), _p(sums), float(M), M, Cn, _p(dz), None, st))
+        t_bwd = timeit(lambda: lib.lp_bn_bwd_apply(_p(res), None, _p(z), _p(mean), _p(invstd), _p(gam), _p(sums), float(M), M, Cn, _p(dz), None, None, None, None, _p(terms), st))
         print(json.dumps({"variant": variant, "shape": name, "M": M, "C": Cn,
                           "bn_apply+res+bits": {"us": round(t_app, 1), "TB/s": round((3 * n + n / 16) / t_app / 1e6, 2)},
                           "bn_apply": {"us": round(t_app0, 1), "TB/s": round(2 * n / t_app0 / 1e6, 2)},

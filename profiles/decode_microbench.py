@@ -46,12 +46,12 @@ def timeit(fn, reps=10):
 for name, hm in (("flat", flat), ("peaked", peak)):
     ref = None
     for prune in ("0", "1"):
-        os.environ["LP_DECODE_PRUNE"] = prune
+        pm = int(prune)   # (the `prune` argument of the two calls: a call argument since round 5)
         st = ops._stream()
         fwd = timeit(lambda: lib.lp_decode_fwd(_p(hm), frames, K, h, h, 2, 1000.0, C.byref(tables), C.byref(fm.struct), _p(kp_aug), _p(kp_frame),
-                                               _p(conf), _p(stats), st))
+                                               _p(conf), _p(stats), pm, st))
         bwd = timeit(lambda: lib.lp_decode_bwd(_p(hm), frames, K, h, h, 2, 1000.0, C.byref(tables), C.byref(fm.struct), _p(stats), None, _p(g_frame),
-                                               _p(g_heat), 0, st))
+                                               _p(g_heat), 0, pm, st))
         torch.cuda.synchronize()
         cur = (kp_aug.clone(), g_heat.clone())
         diff = None if ref is None else (float((cur[0] - ref[0]).abs().max()), float((cur[1] - ref[1]).abs().max() / ref[1].abs().max()))

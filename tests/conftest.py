@@ -31,6 +31,39 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: executes the reference's own modules (/root/reference, or oracle/_ref on the GPU box)")
 
 
+def reload_lp_switches() -> None:
+    """The kernel libraries read their LP_* A/B switches once, at load (lp_hip.h: lp_config_reload_env).  Tests flip them in-process with
+    monkeypatch.setenv / delenv: every library that is loaded right now (the product's, the emulated build) re-reads the environment."""
+    from lightning_pose_amd import _lib
+    from tests.hipemu import emu
+
+    for lib in (_lib._lib, emu._emu):
+        if lib is not None and hasattr(lib, "lp_config_reload_env"):
+            lib.lp_config_reload_env()
+
+
+@pytest.fixture(autouse=True)
+def _lp_switches_follow_the_environment(monkeypatch):
+    """start every test from the current environment, re-read after each LP_* edit, and once more after monkeypatch has undone them"""
+    set_, del_ = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        set_(name, value, *a, **k)
+        if str(name).startswith("LP_"):
+            reload_lp_switches()
+
+    def delenv(name, *a, **k):
+        del_(name, *a, **k)
+        if str(name).startswith("LP_"):
+            reload_lp_switches()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    reload_lp_switches()
+    yield
+    monkeypatch.undo()
+    reload_lp_switches()
+
+
 class Golden(dict):
     def t(self, key: str) -> torch.Tensor:
         return torch.from_numpy(np.asarray(self[key]))

@@ -111,7 +111,7 @@ def frame_map(transforms=None, tf_mode=_lib.TF_NONE, bbox=None, views=1, K=1, mo
     return fm, keep
 
 
-def decode_fwd(heat, ds, temperature=1000.0, fm=None):
+def decode_fwd(heat, ds, temperature=1000.0, fm=None, prune=0):
     heat = f32(heat)
     b, k, h, w = heat.shape
     tb = Tables(h, w, ds)
@@ -121,11 +121,11 @@ def decode_fwd(heat, ds, temperature=1000.0, fm=None):
     hb = Buf(heat)
     kp_aug, kp_frame, conf, stats = Z((b, k, 2)), Z((b, k, 2)), Z((b, k)), Z((b, k, 4))
     ok(lib().lp_decode_fwd(hb.p, b, k, h, w, ds, temperature, C.byref(tb.struct), C.byref(fm), kp_aug.p, kp_frame.p, conf.p, stats.p,
-                           stream()))
+                           int(prune), stream()))
     return kp_aug.np(), kp_frame.np(), conf.np(), stats.np()
 
 
-def decode_bwd(heat, ds, stats, g_aug=None, g_frame=None, temperature=1000.0, fm=None):
+def decode_bwd(heat, ds, stats, g_aug=None, g_frame=None, temperature=1000.0, fm=None, prune=0):
     heat = f32(heat)
     b, k, h, w = heat.shape
     tb = Tables(h, w, ds)
@@ -135,7 +135,7 @@ def decode_bwd(heat, ds, stats, g_aug=None, g_frame=None, temperature=1000.0, fm
     hb, sb, ga, gf = Buf(heat), Buf(f32(stats)), B(g_aug, np.float32), B(g_frame, np.float32)
     g_heat = Z(heat.shape)
     ok(lib().lp_decode_bwd(hb.p, b, k, h, w, ds, temperature, C.byref(tb.struct), C.byref(fm), sb.p, ptr(ga), ptr(gf), g_heat.p, 0,
-                           stream()))
+                           int(prune), stream()))
     return g_heat.np()
 
 
@@ -456,7 +456,7 @@ def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e
     return y.np(), mean.np(), invstd.np()
 
 
-def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False, eval_mode=False, acc0=None):
+def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False, eval_mode=False, acc0=None, terms_ws=True):
     """-> (dx bits, dres bits, dgamma, dbeta): lp_bn_bwd_reduce, then lp_bn_bwd_apply (which also adds the sums into d beta / d gamma,
     starting from ``acc0`` = (dbeta0, dgamma0) if given).  eval_mode: no batch-statistics terms (sums = NULL)."""
     db, yb, xb, mb, vb, gb = Buf(dy_bits), B(y_bits), Buf(x_bits), Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma))
@@ -466,8 +466,9 @@ def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=F
     ok(lib().lp_bn_bwd_reduce(db.p, ptr(yb), xb.p, mb.p, vb.p, M, Cn, sums.p, ws.p, ws.nbytes, stream()))
     dx = Z((M, Cn), np.uint16)
     dres = Z((M, Cn), np.uint16) if want_dres else None
+    tws = Z(2 * Cn) if terms_ws else None   # (the two-launch form the engine uses; None: the self-contained kernel)
     ok(lib().lp_bn_bwd_apply(db.p, ptr(yb), xb.p, mb.p, vb.p, gb.p, None if eval_mode else sums.p, float(M), M, Cn, dx.p, ptr(dres), sums.p,
-                             dbeta.p, dgamma.p, stream()))
+                             dbeta.p, dgamma.p, ptr(tws), stream()))
     return dx.np(), (dres.np() if dres is not None else None), dgamma.np(), dbeta.np()
 
 

@@ -111,7 +111,7 @@ def _peaked(g, b, k, h, w, sigma=1.25, amp=1.0):
 
 
 @pytest.mark.parametrize("ds,h,w", [(2, 24, 32), (2, 96, 96), (1, 16, 16), (3, 12, 12)])
-def test_exact_pruning_changes_nothing(kernel_backend, monkeypatch, ds, h, w):
+def test_exact_pruning_changes_nothing(kernel_backend, ds, h, w):
     """At T = 1000 every term more than 104 / T below the peak is exactly 0 in fp32: the kernels skip the row groups / column waves /
     strips whose bound says so (csrc/decode.hip, "exact pruning").  Peaked maps (a trained network's), incl. peaks on the border and a
     two-peak map: forward outputs and the backward gradient equal the unpruned kernels' to fp32 rounding."""
@@ -124,11 +124,9 @@ def test_exact_pruning_changes_nothing(kernel_backend, monkeypatch, ds, h, w):
     x[1, 2, h - 1, w // 2] = 0.2
     hm = x.numpy()
     res = {}
-    emu.lib().lp_decode_set_prune(-1)      # follow the environment (an earlier ops.decode in this process may have pinned the choice)
-    for flag in ("0", "1"):
-        monkeypatch.setenv("LP_DECODE_PRUNE", flag)
-        kp_aug, kp_frame, conf, stats = emu.decode_fwd(hm, ds)
-        g = emu.decode_bwd(hm, ds, stats, g_aug=np.ones((2, 5, 2), np.float32) * np.array([1.0, -0.5], np.float32))
+    for flag in ("0", "1"):            # the `prune` argument of lp_decode_fwd / lp_decode_bwd (a call argument since round 5: no process state)
+        kp_aug, kp_frame, conf, stats = emu.decode_fwd(hm, ds, prune=int(flag))
+        g = emu.decode_bwd(hm, ds, stats, g_aug=np.ones((2, 5, 2), np.float32) * np.array([1.0, -0.5], np.float32), prune=int(flag))
         res[flag] = (kp_aug, conf, stats, g)
     np.testing.assert_allclose(res["1"][0], res["0"][0], atol=2e-5, rtol=0)     # keypoints, px
     np.testing.assert_allclose(res["1"][1], res["0"][1], atol=1e-6, rtol=1e-5)  # confidences
@@ -149,7 +147,6 @@ def test_decode_pruning_is_chosen_from_the_maps(stack_backend, monkeypatch):
     dev = stack_backend
     monkeypatch.delenv("LP_DECODE_PRUNE", raising=False)
     auto = ops._DecodePruneAuto()                           # an owner's own chooser (a tracker holds one; ops.decode's default is shared)
-    ops._DecodePruneAuto._lib_mode = -2
     gen = torch.Generator().manual_seed(3)
     peaked = _peaked(gen, 2, 4, 24, 24).to(dev)
     flat = torch.softmax(torch.randn(2, 4, 24 * 24, generator=gen) * 0.1, -1).reshape(2, 4, 24, 24).to(dev)
@@ -175,10 +172,8 @@ def test_decode_pruning_is_chosen_from_the_maps(stack_backend, monkeypatch):
     assert auto.state == 0 and auto.want == 0
     monkeypatch.setenv("LP_DECODE_PRUNE", "1")
     ops.decode(flat, 2, 1000.0, fm, auto)
-    assert auto.state == -1                                 # the library follows the environment
+    assert auto.state == 1 and auto.want == 0               # pinned by the environment (the owner's own choice is kept for later)
     monkeypatch.setenv("LP_DECODE_PRUNE", "yes")
     with pytest.raises(ValueError):                         # auto / 0 / 1 only: a typo is an error, not a silent default
         ops.decode(flat, 2, 1000.0, fm, auto)
     monkeypatch.delenv("LP_DECODE_PRUNE")
-    emu.lib().lp_decode_set_prune(-1)
-    ops._DecodePruneAuto._lib_mode = -2

@@ -200,10 +200,12 @@ NORM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("with_ws", [True, False])
 @pytest.mark.parametrize("M,seg_rows,Cn", [(256, 128, 64), (300, 100, 24), (5000, 1800, 256), (96, 95, 8), (40, 24, 2048)])
-def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_rows, Cn):
+def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_rows, Cn, with_ws):
     """lp_bn_apply_seg / lp_bn_bwd_apply_seg == the one-segment entry points called once per segment, bit for bit (one launch walks both
-    segments, each with its own per-channel terms in registers)"""
+    segments, each with its own per-channel terms in registers).  with_ws: the two-launch form of the backward (terms_ws: the correction
+    terms converted by bn_bwd_terms_kernel, round 5) and the self-contained one (NULL) give the same bits."""
     gen = torch.Generator().manual_seed(M + Cn)
     bits16 = lambda t: emu.to_bf16_bits(t)  # noqa: E731
     x, res, dy = (bits16(torch.randn(M, Cn, generator=gen)) for _ in range(3))
@@ -216,12 +218,14 @@ def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_
     B = emu.Buf
     mb, ib, gb, bb, sb = B(mean), B(invstd), B(gamma), B(beta), B(emu.to_fx(sums))
     dbj, dgj, dbs, dgs = emu.Z(Cn), emu.Z(Cn), emu.Z(Cn), emu.Z(Cn)
+    ws = emu.Z(4 * Cn) if with_ws else None
+    wsp = ws.p if with_ws else None
     xb, rb, db = B(x), B(res), B(dy)
     nb = -(-M * Cn // 8)
     # joint launches
     y, bits, dx, dres = emu.Z((M, Cn), np.uint16), emu.Z(nb, np.uint8), emu.Z((M, Cn), np.uint16), emu.Z((M, Cn), np.uint16)
     emu.ok(lib.lp_bn_apply_seg(xb.p, mb.p, ib.p, gb.p, bb.p, rb.p, 1, M, Cn, seg_rows, y.p, bits.p if Cn % 8 == 0 and (seg_rows * Cn) % 8 == 0 else None, st))
-    emu.ok(lib.lp_bn_bwd_apply_seg(db.p, y.p, xb.p, mb.p, ib.p, gb.p, sb.p, counts[0], counts[1], M, Cn, seg_rows, dx.p, dres.p, sb.p, dbj.p, dgj.p, st))
+    emu.ok(lib.lp_bn_bwd_apply_seg(db.p, y.p, xb.p, mb.p, ib.p, gb.p, sb.p, counts[0], counts[1], M, Cn, seg_rows, dx.p, dres.p, sb.p, dbj.p, dgj.p, wsp, st))
     got = (y.np().copy(), dx.np().copy(), dres.np().copy())
     # one call per segment
     want = [np.zeros((M, Cn), np.uint16) for _ in range(3)]
@@ -230,7 +234,7 @@ def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_
         xs, rs, ds = B(x[r0:r0 + n]), B(res[r0:r0 + n]), B(dy[r0:r0 + n])
         ms, is_, ss = B(mean[si]), B(invstd[si]), B(emu.to_fx(sums[si]))
         emu.ok(lib.lp_bn_apply(xs.p, ms.p, is_.p, gb.p, bb.p, rs.p, 1, n, Cn, ys.p, None, st))
-        emu.ok(lib.lp_bn_bwd_apply(ds.p, ys.p, xs.p, ms.p, is_.p, gb.p, ss.p, counts[si], n, Cn, dxs.p, drs.p, ss.p, dbs.p, dgs.p, st))
+        emu.ok(lib.lp_bn_bwd_apply(ds.p, ys.p, xs.p, ms.p, is_.p, gb.p, ss.p, counts[si], n, Cn, dxs.p, drs.p, ss.p, dbs.p, dgs.p, None, st))   # (always the self-contained form: the reference bits)
         for dst, src in zip(want, (ys, dxs, drs)):
             dst[r0:r0 + n] = src.np()
     for a, b_ in zip(got, want):
@@ -243,9 +247,12 @@ def test_elementwise_batchnorm_kernels_with_two_segments(kernel_backend, M, seg_
 
 
 def test_bn_bwd_apply_refuses_more_channels_than_its_term_buffer_holds(kernel_backend):
-    """bn_bwd_apply_kernel stages the launch's correction terms in 32 KB of LDS: C <= 2048 (ResNet-50's widest BatchNorm); beyond -> LP_ERR_UNSUPPORTED"""
+    """WITHOUT its terms_ws workspace bn_bwd_apply_kernel stages the launch's correction terms in 32 KB of LDS: C <= 2048 (ResNet-50's widest
+    BatchNorm); beyond -> LP_ERR_UNSUPPORTED"""
     M, Cn = 8, 2056
     z16 = emu.Z((M, Cn), np.uint16)
     f = emu.Z(Cn)
     sums = emu.ZX((2, Cn))
-    assert emu.lib().lp_bn_bwd_apply(z16.p, None, z16.p, f.p, f.p, f.p, sums.p, float(M), M, Cn, z16.p, None, None, None, None, emu.stream()) == -2
+    assert emu.lib().lp_bn_bwd_apply(z16.p, None, z16.p, f.p, f.p, f.p, sums.p, float(M), M, Cn, z16.p, None, None, None, None, None, emu.stream()) == -2
+    ws = emu.Z(2 * Cn)   # ... with the caller's workspace for the terms there is no such limit
+    assert emu.lib().lp_bn_bwd_apply(z16.p, None, z16.p, f.p, f.p, f.p, sums.p, float(M), M, Cn, z16.p, None, None, None, None, ws.p, emu.stream()) == 0
