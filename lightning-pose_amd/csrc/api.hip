@@ -15,7 +15,7 @@ static LpSwitches read_switches() {
     s.conv_pipe = env_int("LP_CONV_PIPE", 1);       // 0: every convolution on conv_igemm_kernel / conv_wgrad_kernel
     s.conv_halo = env_int("LP_CONV_HALO", 1);       // 0: the 3x3 layers on the per-tap ring
     s.conv_res2d = env_int("LP_CONV_RES2D", 1);     // 0: layer1's 64 -> 64 3x3 layers on the HALO form
-    s.conv_spec = env_int("LP_CONV_SPEC", 0);       // 1: producer / consumer wave-specialised launches where they apply (conv_spec.h)
+    s.conv_spec = env_int("LP_CONV_SPEC", 0);       // 1: the forward convolutions on the producer / consumer wave-specialised kernel where it applies (conv_spec.h)
     s.infer_pipe = env_int("LP_INFER_PIPE", 1);     // 0: lp_conv_fwd_act on conv_igemm_kernel<infer>
     s.gemm_pipe = env_int("LP_GEMM_PIPE", 1);       // 0: the Linear layers on conv_igemm_kernel
     s.wgrad_pipe = env_int("LP_WGRAD_PIPE", 1);     // 0: weight gradients on conv_wgrad_kernel; 2: the pipelined kernel wherever it can run

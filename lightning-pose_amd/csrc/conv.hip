@@ -1203,25 +1203,26 @@ static int launch_pipe(const void* x, const void* w, const ConvGeom& g, const La
     return grid;
 }
 
-// conv_spec_kernel (conv_spec.h): producer / consumer wave roles on the same ring, the store pass handed to the producers.  256 x 128 tiles,
-// no bias, at least `min_steps` K steps per tile (the handed-over store pass is spread over a tile's first 4 - 7 K steps).  LP_CONV_SPEC=0
-// keeps conv_pipe_kernel (A/B runs, bit-identity tests).
-static bool spec_ok(const ConvEpilogue& ep, int N, int K, int min_steps) {
-    return lp_switches().conv_spec != 0 && N % 128 == 0 && ep.bias == nullptr && K / kBK >= min_steps;
+// conv_spec_kernel (conv_spec.h): producer / consumer wave roles on the same ring, the store pass handed to the producers.  Forward only,
+// 256 x 128 tiles, no bias, at least 4 K steps per tile (the handed-over store pass is spread over a tile's first 4 K steps).  LP_CONV_SPEC=1
+// selects it (default 0: measured correct and not faster than conv_pipe_kernel, profiles/r05_conv_spec_ab.txt).
+static bool spec_ok(const ConvEpilogue& ep, const Lattice& lat, const ConvGeom& g, int N, int K) {
+    const bool full = lat.h0 == 0 && lat.hstep == 1 && lat.w0 == 0 && lat.wstep == 1 && lat.r0 == 0 && lat.rstep == 1 && lat.nr == g.R &&
+                      lat.s0 == 0 && lat.sstep == 1 && lat.ns == g.S;
+    return lp_switches().conv_spec != 0 && full && N % 128 == 0 && ep.bias == nullptr && K / kBK >= 4;
 }
 
-template <int MODE, int EK, bool HALO>
+template <bool HALO>
 static int launch_spec(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
                         hipStream_t st) {
     const int tm = (M + kPM - 1) / kPM, tn = N / 128, ntiles = tm * tn;
     const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
-    const int ck = MODE == kModeDgrad ? g.Co : g.Ci;
-    const unsigned x_bytes = (unsigned)(2ull * (MODE == kModeDgrad ? (size_t)g.B * g.Ho * g.Wo * g.Co : (size_t)g.B * g.Hi * g.Wi * g.Ci));
-    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * ck);
+    const unsigned x_bytes = (unsigned)(2ull * (size_t)g.B * g.Hi * g.Wi * g.Ci);
+    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * g.Ci);
     g_last_conv_kernel = HALO ? LP_CONV_KERNEL_SPEC_HALO : LP_CONV_KERNEL_SPEC;
     const HaloDivs hd{make_fastdiv(g.Hi), make_fastdiv(g.Wi + 2), make_fastdiv(g.Hi + 2)};
-    hipLaunchKernelGGL((conv_spec_kernel<MODE, EK, HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w,
-                       x_bytes, w_bytes, g, lat, make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, hd);
+    hipLaunchKernelGGL((conv_spec_kernel<HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes, w_bytes, g,
+                       make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, hd);
     return grid;
 }
 
@@ -1229,10 +1230,6 @@ template <int BN>
 static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
                              const ConvEpilogue& ep, hipStream_t st) {
     if (kind == kEkZ && BN == 64 && ep.bias == nullptr && res2d_ok(g, g.Co, N, ep)) return launch_res2d<kModeDgrad>(x, w, g, ep, st);
-    if (kind == kEkZ && BN == 128 && spec_ok(ep, N, K, 7)) {
-        if (pipe_halo_ok(g, M, g.Co, 384)) return launch_spec<kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
-        return launch_spec<kModeDgrad, kEkZ, false>(x, w, g, lat, M, N, K, ep, st);
-    }
     if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) return launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkZ) return launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkAZB) return launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
@@ -1380,9 +1377,9 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     if (pipe_eligible(ep, M, N, K, g.Ci, split, true)) {
         if (N > 64) {
             const bool halo = pipe_halo_ok(g, M, g.Ci, 384);
-            if (spec_ok(ep, N, K, 4)) {
-                if (halo) launch_spec<kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
-                else launch_spec<kModeFwd, kEkNone, false>(x, w, g, lat, M, N, K, ep, st);
+            if (spec_ok(ep, lat, g, N, K)) {
+                if (halo) launch_spec<true>(x, w, g, lat, M, N, K, ep, st);
+                else launch_spec<false>(x, w, g, lat, M, N, K, ep, st);
             } else if (halo) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
             else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         } else if (ep.bias == nullptr && res2d_ok(g, g.Ci, N, ep)) {

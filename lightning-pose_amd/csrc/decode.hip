@@ -469,14 +469,31 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
             lx = wave_max(lx);
             if (prune && colb < cut) continue;
         }
-        for (int i = tid; i < h * LD; i += nthreads) zs[i] = 0.f;
+        {
+            int ti = tid;
+            if (NE <= 8 || R == 8) LP_OPAQUE(ti);   // (the fill's first address recomputed per strip where the allocation is at its cap: hoisted it
+                                                     //  is one more register alive through both phases; elsewhere the hint only perturbs the schedule)
+            for (int i = ti; i < h * LD; i += nthreads) zs[i] = 0.f;
+        }
         __syncthreads();  // (first trip: also the tile / table staging)
         const int c = c0 + lane;
         if (c < W && j0 < j1) {
-            float tx[kTXM];
-#pragma unroll
-            for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
+            // (the lane's 12 column taps are re-read - three 16-B loads from L1 - for each of the one or two window rows a row group adds,
+            //  instead of living in 12 registers beside the two windows and the NE gradient accumulators: with them the NE = 18
+            //  instantiations, capped at 128 registers for two workgroups per CU, spilled 15 - 48 registers)
+            const float* txg = tb.col_taps + (size_t)c * kTXM;
             const float* hcol = hs + tb.col_start[c];
+            auto zv = [&](int r) __attribute__((always_inline)) {
+                const float* tp = txg;
+                LP_OPAQUE(tp);
+                float tx[kTXM];
+#pragma unroll
+                for (int t4 = 0; t4 < kTXM / 4; ++t4) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(tp + 4 * t4);
+                    tx[4 * t4] = v4[0], tx[4 * t4 + 1] = v4[1], tx[4 * t4 + 2] = v4[2], tx[4 * t4 + 3] = v4[3];
+                }
+                return z_value<FULLTX>(hcol, r, w, tx, tb.TX);
+            };
             const float dxc = gxt * ((float)c - ex);
             float win[TY], acc[TY];
             int base = tb.row_base[j0];
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                         win[t] = win[t + 1];
                         acc[t] = acc[t + 1];
                     }
-                    if (have && !skip) win[TY - 1] = z_value<FULLTX>(hcol, nb + TY - 1, w, tx, tb.TX);
+                    if (have && !skip) win[TY - 1] = zv(nb + TY - 1);
                     acc[TY - 1] = 0.f;
                     base = nb;
                 }
@@ -503,11 +520,13 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 }
                 if (!have) {
 #pragma unroll
-                    for (int t = 0; t < TY; ++t) win[t] = z_value<FULLTX>(hcol, base + t, w, tx, tb.TX);
+                    for (int t = 0; t < TY; ++t) win[t] = zv(base + t);
                     have = true;
                 }
                 const float* taps = tb.row_taps + (size_t)j * R * TY;
-#pragma unroll
+                // (one output row at a time for the widest tables: unrolled, the R x TY taps of a row group - 88 scalars at ds = 3 - do not
+                //  fit the scalar file and come back as spilled VECTOR registers)
+#pragma unroll (R * TY <= 16 ? R : 1)
                 for (int rr = 0; rr < R; ++rr) {
                     float y = 0.f;
 #pragma unroll

@@ -387,9 +387,18 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
 #pragma unroll
     for (int k = 0; k < kSmK; ++k) dot[k] = 0.f;
     for (int i = tid; i < n; i += 1024) {
+        // (one walking pointer per tensor: indexed as p[k n + i] the unrolled loop keeps 2 x 32 map base addresses alive - more than the
+        //  scalar file holds - and the kernel, capped at 128 registers by its 1024 threads, spilled 38)
+        const float* pk = p + i;
+        const float* gk = g + i;
 #pragma unroll
-        for (int k = 0; k < kSmK; ++k)
-            if (k < K) dot[k] = fmaf(p[(size_t)k * n + i], g[(size_t)k * n + i], dot[k]);
+        for (int k = 0; k < kSmK; ++k) {
+            if (k < K) {
+                dot[k] = fmaf(*pk, *gk, dot[k]);
+                pk += n;
+                gk += n;
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < kSmK; ++k) {
@@ -408,12 +417,19 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
     unsigned short* dst = gin + (size_t)b * sb;
     const int chunks = (int)(si >> 3);
     for (int i = tid; i < n; i += 1024) {
+        const float* pk = p + i;
+        const float* gk = g + i;
         for (int c = 0; c < chunks; ++c) {
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = c * 8 + e;
-                o[e] = k < K ? p[(size_t)k * n + i] * (g[(size_t)k * n + i] - fin[k]) : 0.f;
+                o[e] = 0.f;
+                if (k < K) {
+                    o[e] = *pk * (*gk - fin[k]);
+                    pk += n;
+                    gk += n;
+                }
             }
             *reinterpret_cast<u16x8*>(dst + (size_t)i * si + c * 8) = pack_bf16x8(o);
         }

@@ -203,8 +203,19 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 // fp32 atomics' own rounding.  Costs what the atomics cost (two 8-byte ones per value instead of a 4-byte one + the d beta / d gamma one),
 // no workspace, no extra launch.  (The first form of round 4 - one row of partial sums per workgroup + an ordered reduction launch - was
 // bit-reproducible too and 1.4 % slower per step: ~110 more small launches on the critical path, profiles/r04i_bench_*.)
+// A NON-FINITE partial (a diverged run) must not turn into finite garbage - fmin / fmax drop a NaN, and the old fp32 atomics propagated it:
+// it POISONS the sum instead: `lo` is raised to 2^62 with an atomic max (idempotent, so any number of poisoned partials of this process
+// leaves it there; the finite partials that still arrive move it by < 2^59), and fx_value reads |lo| >= 2^61 as NaN - BatchNorm's moments,
+// running statistics and gradients then carry the NaN on, as the reference's do.  (Across ranks the words are SUMMED by SyncBatchNorm's
+// all-reduce: one to three poisoned ranks stay visible, four or eight identical poisons wrap around - the loss of every rank is NaN long
+// before that matters, since each rank's own forward sums are read back through this rank's activations.)
+constexpr long long kFxPoison = 1LL << 62;
 __device__ __forceinline__ void fx_add(lp_fxsum* p, float t) {
     double td = (double)t;
+    if (!(fabs(td) <= 0x1p127 * 2.0)) {   // NaN or +-inf
+        atomicMax(&p->lo, kFxPoison);
+        return;
+    }
     td = fmin(fmax(td, -0x1p49), 0x1p49);                         // (saturate: hi stays inside 2^61)
     const double h = rint(td * 0x1p12);
     const long long hi = (long long)h;
@@ -212,7 +223,11 @@ __device__ __forceinline__ void fx_add(lp_fxsum* p, float t) {
     atomicAdd(reinterpret_cast<unsigned long long*>(&p->hi), (unsigned long long)hi);
     atomicAdd(reinterpret_cast<unsigned long long*>(&p->lo), (unsigned long long)lo);
 }
-__device__ __forceinline__ float fx_value(const lp_fxsum* p) { return (float)((double)p->hi * 0x1p-12 + (double)p->lo * 0x1p-60); }
+__device__ __forceinline__ float fx_value(const lp_fxsum* p) {
+    const long long lo = p->lo;
+    if (lo >= (kFxPoison >> 1) || lo <= -(kFxPoison >> 1)) return __int_as_float(0x7fc00000);   // poisoned by a non-finite partial
+    return (float)((double)p->hi * 0x1p-12 + (double)lo * 0x1p-60);
+}
 
 // ---- host-side launch epilogue ------------------------------------------------------------------
 // ---- the library's A/B switches (LP_CONV_PIPE, LP_CONV_HALO, ... - what each one selects is documented where it is used).  Read from the

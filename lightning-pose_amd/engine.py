@@ -220,6 +220,9 @@ class Engine:
         # [segments][2][C] sums are all-gathered (over xGMI each rank writes its 4 - 16 KB straight into every peer's slot: one hop, no
         # ring) and added locally in RANK ORDER, so every rank holds the same bits whatever the collective's internal order
         self.sync_bn_gather = os.environ.get("LP_SYNCBN_GATHER", "0") == "1"
+        # lp_bn_bwd_apply in two launches (the correction terms converted by a one-thread-per-value kernel into a small workspace, round 5) or
+        # - LP_BN_BWD_TERMS=0, A/B runs - in the self-contained form that converts them per workgroup into LDS
+        self.bn_bwd_terms = os.environ.get("LP_BN_BWD_TERMS", "1") != "0"
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
@@ -794,7 +797,8 @@ class Engine:
         dres = torch.empty_like(z) if want_dres else None
         gam = _p(self.param_view(b, "weight"))
         counts = [float(n * rpi * world) for _, n in segs]
-        terms = torch.empty(len(segs) * 2 * Cn, device=z.device, dtype=torch.float32)   # sum / count as floats (written by the call's first launch)
+        # sum / count as floats (written by the call's first launch)
+        terms = torch.empty(len(segs) * 2 * Cn, device=z.device, dtype=torch.float32) if self.bn_bwd_terms else None
         check(self._lib.lp_bn_bwd_apply_seg(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(total), counts[0], counts[-1], M, Cn,
                                             seg * rpi, _p(dz), _p(dres), _p(local), _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), _p(terms),
                                             ops._stream()), "lp_bn_bwd_apply_seg")

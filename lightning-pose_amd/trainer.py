@@ -165,8 +165,13 @@ class Trainer:
             while nxt is not None:  # one batch of look-ahead: the last batch of the epoch closes a partial accumulation group
                 batch, nxt = nxt, next(it, None)
                 last = nxt is None or (self.limit_train_batches is not None and batch_idx + 1 >= self.limit_train_batches)
+                step_before = model.global_step
                 self.training_batch(model, batch, batch_idx, last_in_epoch=last)
-                if last or model.global_step % self.log_every_n_steps == 0:
+                # flush when an optimiser step HAPPENED in this batch and landed on a multiple of N (with accumulate_grad_batches > 1 the
+                # step counter stands still on the non-stepping micro-batches: testing only its value flushed - and synchronised - on every
+                # one of them while it sat on a multiple, and appended duplicate records), and at the end of the epoch
+                stepped = model.global_step != step_before
+                if last or (stepped and model.global_step % self.log_every_n_steps == 0):
                     self._flush_logged(model)
                 batch_idx += 1
                 if last:

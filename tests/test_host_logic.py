@@ -146,3 +146,50 @@ def test_loss_weight_and_log_names():
     assert float(t.weight) == pytest.approx(O.loss_weight(5.0))
     names = [d["name"] for d in t.log_loss(torch.tensor(1.0), "train")]
     assert names == ["train_temporal_loss", "temporal_weight"]
+
+
+def test_trainer_flushes_logged_scalars_once_per_logging_step_under_gradient_accumulation():
+    """with accumulate_grad_batches > 1 the step counter stands still on the non-stepping micro-batches; the flush (a host <->
+    device synchronisation) must happen when an optimiser step LANDED on a multiple of log_every_n_steps, not on every micro-batch while
+    the counter sits on one - and never twice for the same step."""
+    from lightning_pose_amd.trainer import Trainer
+
+    class Opt:
+        def zero_grad(self):
+            pass
+
+        def step(self):
+            pass
+
+    class Sched:
+        def step(self):
+            pass
+
+    class Module:
+        device = torch.device("cpu")
+        training = True
+
+        def __init__(self):
+            self.global_step, self.current_epoch, self.logged, self._opt = 0, 0, {}, Opt()
+            self.w = torch.zeros(1, requires_grad=True)
+
+        def train(self, mode=True):
+            self.training = mode
+
+        def optimizers(self):
+            return self._opt
+
+        def get_scheduler(self, opt):
+            return Sched()
+
+        def training_step(self, batch, batch_idx):
+            self.logged = {"total_loss": torch.tensor(float(batch_idx))}
+            return {"loss": (self.w * 0).sum()}
+
+    model = Module()
+    trainer = Trainer(max_epochs=1, data_parallel=False, accumulate_grad_batches=3, log_every_n_steps=2)
+    trainer.fit(model, [{} for _ in range(14)])   # 14 micro-batches: steps after batches 2, 5, 8, 11 and the trailing partial group (13)
+    assert model.global_step == 5
+    steps = [h["step"] for h in trainer.logged_history]
+    assert steps == [2.0, 4.0, 5.0], steps         # multiples of 2 as they are reached, + the end of the epoch; no duplicates, nothing at step 0
+    assert [h["total_loss"] for h in trainer.logged_history] == [5.0, 11.0, 13.0]

@@ -132,6 +132,30 @@ def test_fixed_point_sums_keep_small_and_large_terms(kernel_backend):
     assert np.array_equal(emu.bn_stats(xb, M, Cn, raw=True), words)
 
 
+def test_non_finite_partials_poison_the_fixed_point_sum(kernel_backend):
+    """a NaN / inf reaching a BatchNorm sum must stay visible (the fp32 atomics of rounds 2 - 3 propagated it; fmin / fmax in the
+    first fx_add turned it into -2^49): the sum is poisoned, the moments and the running statistics of THAT channel read NaN, the others
+    are untouched - through the stand-alone reduction and through a convolution's fused sums."""
+    M, Cn = 1024, 16
+    x = torch.randn(M, Cn, generator=torch.Generator().manual_seed(4))
+    x[17, 1] = float("nan")
+    x[500, 2] = float("inf")
+    run = [np.zeros(Cn, np.float32), np.ones(Cn, np.float32)]
+    _, mean, invstd = emu.bn_forward(emu.to_bf16_bits(x), M, Cn, np.ones(Cn, np.float32), np.zeros(Cn, np.float32), running=run)
+    bad = np.zeros(Cn, bool)
+    bad[[1, 2]] = True
+    assert np.isnan(mean[bad]).all() and np.isfinite(mean[~bad]).all() and np.isfinite(invstd[~bad]).all()
+    assert np.isnan(run[0][bad]).all() and np.isfinite(run[0][~bad]).all()
+    np.testing.assert_allclose(mean[~bad], emu.from_bf16_bits(emu.to_bf16_bits(x)).double().mean(0).numpy()[~bad], atol=1e-6)
+    # a convolution whose input holds a NaN: every output channel of that pixel is NaN, so every fused sum is poisoned
+    g = emu.geom(1, 16, 16, 64, 64, 1, 1, 1, 0)
+    xin = torch.randn(1, 16, 16, 64, generator=torch.Generator().manual_seed(5))
+    xin[0, 3, 3, 7] = float("nan")
+    w = emu.to_bf16_bits(torch.randn(64, 1, 1, 64, generator=torch.Generator().manual_seed(6)) / 8)
+    _, words = emu.conv_fwd_bn(emu.to_bf16_bits(xin), w, g, raw=True)
+    assert (np.abs(words[..., 1].astype(np.float64)) >= 2.0 ** 61).all()   # the `lo` words carry the poison
+
+
 def test_standalone_reductions_repeat_bit_for_bit(kernel_backend):
     """lp_bn_stats / lp_bn_bwd_reduce (fixed-point sums): same bits twice; lp_bn_bwd_apply adds the sums into d beta / d gamma on top of
     what is already there; sums = NULL (eval-mode BatchNorm) drops the batch-statistics terms: dx = dy * gamma * invstd"""
