@@ -383,6 +383,15 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // backward: d(loss)/d(heat) from d(loss)/d(kp_aug) (+ d(loss)/d(kp_frame) chained through the frame map)
 // ------------------------------------------------------------------------------------------------
+#ifndef LP_DEC_RR_FULL
+#define LP_DEC_RR_FULL 16   // (A/B builds) row-group tap tables up to this many scalars are walked fully unrolled ...
+#endif
+#ifndef LP_DEC_TX_REGS
+#define LP_DEC_TX_REGS 2   // column taps of a lane: 0 = re-read per use, 1 = in registers, 2 = in registers in the plain kernels only
+#endif
+#ifndef LP_DEC_RR_PART
+#define LP_DEC_RR_PART 2    // ... larger ones this many output rows at a time
+#endif
 constexpr int kBwdStrip = 64;          // output columns per strip = one wave of lanes; the block's waves split the rows
 constexpr int kBwdLd = kBwdStrip + 1;  // LDS row stride of the strip (odd: lanes that walk down a column hit distinct banks)
 
@@ -483,7 +492,16 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
             //  instantiations, capped at 128 registers for two workgroups per CU, spilled 15 - 48 registers)
             const float* txg = tb.col_taps + (size_t)c * kTXM;
             const float* hcol = hs + tb.col_start[c];
+            // the plain kernels keep the 12 taps in registers (with the row groups walked two output rows at a time they fit: 127 of 128); the
+            // pruning ones, which carry their bounds as well, re-read them per use (measured, profiles/r05d_decode_variants.txt)
+            constexpr bool kTxRegs = LP_DEC_TX_REGS == 1 || (LP_DEC_TX_REGS == 2 && !PRUNE && R == 4);   // (ds = 1 / 3 tables: the re-read form, one register short otherwise)
+            float txr[kTxRegs ? kTXM : 1];
+            if (kTxRegs) {
+#pragma unroll
+                for (int t = 0; t < (kTxRegs ? kTXM : 0); ++t) txr[kTxRegs ? t : 0] = txg[t];
+            }
             auto zv = [&](int r) __attribute__((always_inline)) {
+                if constexpr (kTxRegs) return z_value<FULLTX>(hcol, r, w, txr, tb.TX);
                 const float* tp = txg;
                 LP_OPAQUE(tp);
                 float tx[kTXM];
@@ -526,7 +544,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 const float* taps = tb.row_taps + (size_t)j * R * TY;
                 // (one output row at a time for the widest tables: unrolled, the R x TY taps of a row group - 88 scalars at ds = 3 - do not
                 //  fit the scalar file and come back as spilled VECTOR registers)
-#pragma unroll (R * TY <= 16 ? R : 1)
+#pragma unroll (R * TY <= LP_DEC_RR_FULL ? R : LP_DEC_RR_PART)
                 for (int rr = 0; rr < R; ++rr) {
                     float y = 0.f;
 #pragma unroll
