@@ -15,7 +15,7 @@
  *   - return value: 0 = LP_OK, < 0 = argument / shape error (nothing was launched), > 0 = hipError_t
  *   - re-entrant and thread-safe: no entry point keeps state between calls or reads the environment.  The only process-wide data is
  *     the table of A/B switches (LP_CONV_PIPE, LP_CONV_HALO, LP_CONV_RES2D, LP_CONV_SPEC, LP_INFER_PIPE, LP_GEMM_PIPE, LP_WGRAD_PIPE,
- *     LP_STEM_2D, LP_POOL_V2, LP_CONV_MAX_WGS), read from the environment ONCE when the library is loaded and immutable afterwards -
+ *     LP_STEM_2D, LP_POOL_V2, LP_CONV_MAX_WGS, LP_BN_BWD_WGS_PER_CU), read from the environment ONCE when the library is loaded and immutable afterwards -
  *     except through lp_config_reload_env(), a test / A-B hook that must not run concurrently with other calls
  *   - limits: lp_bn_bwd_apply WITHOUT its terms_ws workspace covers C <= 2048 channels (the per-launch correction table then lives in
  *     LDS; LP_ERR_UNSUPPORTED beyond); with the workspace any C that is a multiple of 8

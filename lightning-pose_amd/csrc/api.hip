@@ -21,6 +21,8 @@ static LpSwitches read_switches() {
     s.wgrad_pipe = env_int("LP_WGRAD_PIPE", 1);     // 0: weight gradients on conv_wgrad_kernel; 2: the pipelined kernel wherever it can run
     s.stem_2d = env_int("LP_STEM_2D", 1);           // 0: the stem on conv_igemm_kernel<64, stem>
     s.pool_v2 = env_int("LP_POOL_V2", 1);           // 0: the stem's pool backward on the first kernel
+    s.bn_bwd_wgs_per_cu = env_int("LP_BN_BWD_WGS_PER_CU", 5);   // 1 .. 5: workgroups per CU of the BatchNorm backward walk (5 = one resident round)
+    if (s.bn_bwd_wgs_per_cu < 1 || s.bn_bwd_wgs_per_cu > 5) s.bn_bwd_wgs_per_cu = 5;
     s.conv_max_wgs = env_int("LP_CONV_MAX_WGS", 0); // > 0: cap of the persistent grids (tests: several tiles per workgroup on small problems)
     return s;
 }

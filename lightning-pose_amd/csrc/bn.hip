@@ -824,12 +824,12 @@ static int colreduce_blocks(int M, int C) {
 
 // grid for the BatchNorm elementwise walks: the stride (grid * 256 lanes) must be a multiple of the row length in chunks so a
 // lane stays on one channel chunk; rows of C/8 chunks with C/8 a divisor of 256 (every ResNet width) need no adjustment
-static int bn_grid(size_t n_chunks, int chunks) {
+static int bn_grid(size_t n_chunks, int chunks, int per_cu = 5) {
     size_t blocks = (n_chunks + 255) / 256;
     // ONE resident round: bn_apply_kernel / bn_bwd_apply_kernel run 5 waves per SIMD = 5 workgroups per CU.  (Until round 4 the cap was
     // 2048 = 1.6 rounds, the second one 60 % full: 1280 gave bn_apply 110.7 -> 102.2 us and bn_bwd_apply 129.0 -> 121.8 us per launch,
     // 4260 -> 4324 frames/s over three A/B pairs; 1024 - four per CU - loses it again, 1536 gives half of it.  profiles/r04p_*, r04q_*)
-    if (blocks > 256 * 5) blocks = 256 * 5;
+    if (blocks > (size_t)256 * per_cu) blocks = (size_t)256 * per_cu;   // (per_cu < 5: LP_BN_BWD_WGS_PER_CU, A/B of the backward walk's share of a CU beside the weight-gradient stream)
     if (blocks < 1) blocks = 1;
     if (256 % chunks != 0) {  // make grid * 256 a multiple of `chunks`: round the grid up to a multiple of chunks / gcd(chunks, 256)
         int a = chunks, b = 256;
@@ -992,7 +992,7 @@ static int bn_bwd_apply_impl(const void* dy, const void* y_out, const void* x, c
         const int nseg = seg_rows > 0 ? 2 : 1;
         hipLaunchKernelGGL(bn_bwd_terms_kernel, dim3((nseg * 2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, 1.f / count0, 1.f / count1, C,
                            nseg, terms_ws, sums_local, dbeta_acc, dgamma_acc);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(n_chunks, C / 8, lp_switches().bn_bwd_wgs_per_cu)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy,
                            (const unsigned short*)y_out, (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count0, n_chunks, C,
                            (unsigned short*)dx, (unsigned short*)dres, (size_t)seg_rows * (C / 8), 1.f / count1, sums_local, dbeta_acc, dgamma_acc,
                            (const float*)terms_ws);

@@ -292,6 +292,7 @@ class Engine:
             check(fn(_p(x), _p(dy), C.byref(g), _p(dw), 0, _p(self._wgrad_ws), self._wgrad_ws.numel(), ops._stream()), what)
             return
         if self._side is None:
+            # (its priority was A/B'd in round 5 - higher than the main stream's, equal: no difference, profiles/r05f_overlap.txt)
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)          # dy (and the zeroed / partially accumulated G) are ready
