@@ -36,6 +36,9 @@ namespace lp {
 #ifndef LP_HALO_KEY_ROW
 #define LP_HALO_KEY_ROW 0   // (A/B builds: 1 = round 3's swizzle key of the HALO form, the halo row itself)
 #endif
+#ifndef LP_FWD_CORNER_PAD
+#define LP_FWD_CORNER_PAD 0
+#endif
 #ifndef LP_PIPE_SPREAD
 #define LP_PIPE_SPREAD 1   // (A/B builds: 0 issues a K step's loads in one burst after the barrier)
 #endif
@@ -450,8 +453,15 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     auto epilogue_fwd = [&](const int m0, const int n0, unsigned char* stg_all) {
         const int nbase = n0 + wn * (NT * 32);   // first channel of this wave
         constexpr bool infer = EK == kEkInfer;   // lp_conv_fwd_act: its own instantiations, so the training kernels' store pass carries none of it
-        constexpr int ROWB = NT * 64 + 16;       // bf16 chunk row + pad (16-B aligned)
+        // The wave's corner: 32 pixel rows of NT*64 B, UNPADDED, the 8-B slot s of row r at position s ^ key(r) (key = r & 15 for 128-B rows,
+        // (r >> 1) & 7 for 64-B rows): the 16 lanes of a ds_write_b64 group - 16 consecutive pixels, one slot - then hit 16 different slots,
+        // and the ds_read_b128 service groups of the read-back (4 rows x 4 chunks each) 16 different 16-bank ranges.  (Until round 5 the rows
+        // were padded to NT*64 + 16 B instead: conflict-free writes, but 2-way conflicts in the read-back - SQ_LDS_BANK_CONFLICT was 32 % of this
+        // kernel's busy cycles, 54 % on the K <= 128 launches where the store pass is most of the tile, profiles/r05_pmc_mfma_spec1.json.)
+        constexpr bool kPad = LP_FWD_CORNER_PAD != 0;   // (A/B builds: 1 = rounds 3 - 4's padded rows)
+        constexpr int ROWB = NT * 64 + (kPad ? 16 : 0);
         unsigned char* stg = stg_all + wave * (32 * ROWB);
+        const int wkey = kPad ? 0 : NT == 2 ? (fr & 15) : ((fr >> 1) & 7);
         u16x8 radd[2][32 / RP] = {};   // inference: this lane's pieces of the residual, all 8 requested before the conversion / staging work
         if (infer && ep.addend != nullptr) {
 #pragma unroll
@@ -485,13 +495,21 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
                     const u32x2_t p = {pack_bf16x2(acc[mt][nt][4 * j], acc[mt][nt][4 * j + 1]),
                                        pack_bf16x2(acc[mt][nt][4 * j + 2], acc[mt][nt][4 * j + 3])};
-                    *reinterpret_cast<u32x2_t*>(stg + fr * ROWB + (nt * 32 + 8 * j + 4 * fg) * 2) = p;
+                    *reinterpret_cast<u32x2_t*>(stg + fr * ROWB + ((((nt * 4 + j) * 2 + fg) ^ wkey) << 3)) = p;
                 }
             __builtin_amdgcn_wave_barrier();   // (lanes exchange through the wave's private corner: lock step on the device)
 #pragma unroll
             for (int ps = 0; ps < 32 / RP; ++ps) {
                 const int row = ps * RP + prow;
-                u16x8 w = *reinterpret_cast<const u16x8*>(stg + row * ROWB + pc * 16);
+                const int rkey = kPad ? 0 : NT == 2 ? (row & 15) : ((row >> 1) & 7);
+                u16x8 w;
+                {   // chunk pc = slots 2 pc, 2 pc + 1 -> positions (2 pc) ^ key and its neighbour: one aligned 16-B chunk, halves swapped for an odd key
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                    const u32x4_t q = *reinterpret_cast<const u32x4_t*>(stg + row * ROWB + ((pc ^ (rkey >> 1)) << 4));
+                    const bool sw = (rkey & 1) != 0;
+                    const u32x4_t o = {sw ? q[2] : q[0], sw ? q[3] : q[1], sw ? q[0] : q[2], sw ? q[1] : q[3]};
+                    w = __builtin_bit_cast(u16x8, o);
+                }
                 const int m = m0 + wm * 64 + mt * 32 + row;
                 if (m < M) {
                     const unsigned off = (unsigned)out_row(m, lat, div_img, div_row, full_h, full_w) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8);
@@ -559,7 +577,10 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         }
     };
     auto rb_process = [&](const ReadBack& rb, const int mt, unsigned char* stg_all, const int m0, const int n0) {
-        constexpr int ROWF = NT * 128 + 16;   // fp32 row of the wave's channels + pad
+        // fp32 row of the wave's channels + pad.  (The XOR-swizzled unpadded layout of the forward's corner was tried here too, round 5: the
+        // padded rows' read-back groups have 2-way conflicts - SQ_LDS_BANK_CONFLICT 9 - 16 % of these kernels' busy cycles - but the data gradients
+        // sit at the register cap, and the swizzle's address arithmetic made three of them spill: tests/test_kernel_resources.py.)
+        constexpr int ROWF = NT * 128 + 16;
         unsigned char* stg = stg_all + wave * (16 * ROWF);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
