@@ -36,6 +36,9 @@ namespace lp {
 #ifndef LP_HALO_KEY_ROW
 #define LP_HALO_KEY_ROW 0   // (A/B builds: 1 = round 3's swizzle key of the HALO form, the halo row itself)
 #endif
+#ifndef LP_HALO_STAGES
+#define LP_HALO_STAGES 3   // weight-ring stages of the HALO form (A/B builds: 4 = three K steps of weight loads in flight, 160 KB of LDS)
+#endif
 #ifndef LP_FWD_CORNER_PAD
 #define LP_FWD_CORNER_PAD 0
 #endif
@@ -103,8 +106,13 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     constexpr int kStageA = HALO ? 0 : kPM * kPRowB, kStageB = BN * kPRowB, kStage = kStageA + kStageB;
     constexpr int kHaloRows = BN == 64 ? 512 : 384;   // rows of a halo image (host-checked against the geometry: pipe_halo_rows)
     constexpr int kHaloB = kHaloRows * kPRowB, NA = kHaloRows / 64;   // bytes; direct-to-LDS loads per thread and halo image
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kStage + (HALO ? 2 * kHaloB : 0)];
-    unsigned char* const halo0 = smem + 3 * kStage;
+    // Ring depth.  Per-tap ring: 3 stages of 48 KB (two K steps of loads in flight) is what LDS holds.  HALO form: a stage is only the weights
+    // (16 / 8 KB), so FOUR stages would fit beside the two halo images (160 KB exactly), three K steps of weight loads in flight: measured in
+    // round 5 (-DLP_HALO_STAGES=4, profiles/r05h_halo_stages.txt) - no difference in any 3x3 layer, so their K step is not waiting for its weights.
+    constexpr int NST = HALO ? LP_HALO_STAGES : 3;
+    static_assert(NST == 3 || NST == 4, "ring depth");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * kStage + (HALO ? 2 * kHaloB : 0)];
+    unsigned char* const halo0 = smem + NST * kStage;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -660,12 +668,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         halo_advance();
     }
     setup(ld_vt);
-    load_step(0);
-    load_step(1);
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) load_step(st);
     int cur = 0;   // stage of the K step the MFMAs are about to consume
     ReadBack rb0, rb1;
     // LDS nobody else touches between a tile's last K step and the next tile's first barrier: the stage (HALO: the halo image) consumed last
-    auto free_lds = [&]() -> unsigned char* { return HALO ? halo0 + (mh_buf ^ 1) * kHaloB : smem + (cur == 0 ? 2 : cur - 1) * kStage; };
+    auto free_lds = [&]() -> unsigned char* { return HALO ? halo0 + (mh_buf ^ 1) * kHaloB : smem + (cur == 0 ? NST - 1 : cur - 1) * kStage; };
     for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
         const int tile = xcd_remap(vt, ntiles);
         const int tm_ = tile / tiles_n;
@@ -709,13 +717,16 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             // (Measured and dropped, profiles/archive/r03p_vmcnt_layers.txt: right behind a tile boundary the needed loads are OLDER than the
             // previous tile's output stores, so the count could leave those stores in flight instead of waiting for them to reach
             // memory - every layer came out 0 - 7 % SLOWER, forward and data gradient: the wait paces the workgroups' store bursts.)
-            if (HALO && NBL == 2) LP_WAIT_VM(2);
+            // (the count = the weight pieces of the NST - 2 younger steps; the halo pieces those steps may also have issued are left out: conservative)
+            if (HALO && NBL == 2 && NST == 4) LP_WAIT_VM(4);
+            else if (HALO && NST == 4) LP_WAIT_VM(2);
+            else if (HALO && NBL == 2) LP_WAIT_VM(2);
             else if (HALO) LP_WAIT_VM(1);
             else if (NBL == 2) LP_WAIT_VM(6);
             else LP_WAIT_VM(5);
             LP_RAW_BARRIER();              // ... everyone's have, and everyone is done reading the stage refilled next
             if (!kFwd && kt == KT - 1) rb_issue(rb0, 0, m0, n0);   // the first chunk's read-backs travel under the last K step
-            const int nxt = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
+            const int nxt = cur == 0 ? NST - 1 : cur - 1;   // (cur + NST - 1) % NST: the stage consumed at the previous step
             if (kSpread || HALO) {
                 prep_step(nxt);
                 mma_stage(cur, true);
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                 load_step(nxt);
                 mma_stage(cur, false);
             }
-            cur = cur == 2 ? 0 : cur + 1;
+            cur = cur == NST - 1 ? 0 : cur + 1;
             if (HALO && ++mh_tap == 9) {   // the slice is consumed: the MFMAs move to the other halo image, the loader to the one after it
                 mh_tap = 0;
                 mh_buf ^= 1;
