@@ -100,3 +100,40 @@ def test_error_code_mapping():
         _lib.check(0, "x")
     finally:
         L._lib = old
+
+
+def test_switches_are_read_at_load_not_per_call():
+    """lp_hip.h, round 5: no entry point reads the environment - the LP_* A/B switches live in a table filled ONCE when the library is loaded;
+    a later change of the environment has no effect until lp_config_reload_env() (the hook tests/conftest.py wires to monkeypatch.setenv).
+    Checked on the emulated build of the same sources (the product library cannot be loaded without a device runtime)."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from tests.hipemu import emu
+
+    lib = emu.emu_lib()
+    g = emu.geom(2, 16, 16, 256, 128, 1, 1, 1, 0)
+    gen = torch.Generator().manual_seed(0)
+    x = emu.to_bf16_bits(torch.randn(2, 16, 16, 256, generator=gen))
+    w = emu.to_bf16_bits(torch.randn(128, 1, 1, 256, generator=gen) / 16)
+    old = os.environ.get("LP_CONV_PIPE")
+    try:
+        os.environ.pop("LP_CONV_PIPE", None)
+        lib.lp_config_reload_env()
+        z_pipe, _ = emu.conv_fwd(x, w, g)
+        assert lib.lp_conv_last_kernel() == 1      # LP_CONV_KERNEL_PIPE
+        os.environ["LP_CONV_PIPE"] = "0"           # the environment changes ...
+        emu.conv_fwd(x, w, g)
+        assert lib.lp_conv_last_kernel() == 1      # ... the library does not look
+        lib.lp_config_reload_env()
+        z_igemm, _ = emu.conv_fwd(x, w, g)
+        assert lib.lp_conv_last_kernel() == 0      # LP_CONV_KERNEL_IGEMM
+        assert np.array_equal(z_pipe, z_igemm)
+    finally:
+        if old is None:
+            os.environ.pop("LP_CONV_PIPE", None)
+        else:
+            os.environ["LP_CONV_PIPE"] = old
+        lib.lp_config_reload_env()
