@@ -31,18 +31,6 @@ __device__ __forceinline__ u16x8 load_stream8(const unsigned short* p) {
 #endif
 }
 
-// 16-B store of a streamed result (A/B builds: -DLP_BN_NT_STORE=1 marks it non-temporal)
-#ifndef LP_BN_NT_STORE
-#define LP_BN_NT_STORE 0
-#endif
-__device__ __forceinline__ void store_stream8(unsigned short* p, u16x8 v) {
-#if defined(__HIP_DEVICE_COMPILE__) && LP_BN_NT_STORE
-    __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(p));
-#else
-    *reinterpret_cast<u16x8*>(p) = v;
-#endif
-}
-
 // ---- per-channel sums over rows: sums[0][c] += sum a, sums[1][c] += sum a*b -------------------------------------
 // MODE 0: plain statistics (sum x, sum x^2)
 // MODE 1: BN backward reductions: dz = relu-masked dy;  sum dz, sum dz * xhat
@@ -247,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
             }
-            store_stream8(Y + (q + u * stride) * 8, pack8(o));
+            *reinterpret_cast<u16x8*>(Y + (q + u * stride) * 8) = pack8(o);
             if (bits != nullptr) {  // 1-bit ReLU mask: o > 2^-134 is exactly "the stored bf16 is > 0"
                 unsigned m = 0;
 #pragma unroll
@@ -380,8 +368,8 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
             for (int i = 0; i < 8; ++i) {
                 o[i] = ga[i] * (dz[i] - k0[i] - (x[i] - mu[i]) * k1[i]);
             }
-            store_stream8(DX + (q + u * stride) * 8, pack8(o));
-            if (DRES != nullptr) store_stream8(DRES + (q + u * stride) * 8, pack8(dz));
+            *reinterpret_cast<u16x8*>(DX + (q + u * stride) * 8) = pack8(o);
+            if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + (q + u * stride) * 8) = pack8(dz);
         }
     }
     }
