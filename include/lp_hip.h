@@ -15,7 +15,7 @@
  *   - return value: 0 = LP_OK, < 0 = argument / shape error (nothing was launched), > 0 = hipError_t
  *   - re-entrant and thread-safe: no entry point keeps state between calls or reads the environment.  The only process-wide data is
  *     the table of A/B switches (LP_CONV_PIPE, LP_CONV_HALO, LP_CONV_RES2D, LP_CONV_SPEC, LP_INFER_PIPE, LP_GEMM_PIPE, LP_WGRAD_PIPE,
- *     LP_STEM_2D, LP_POOL_V2, LP_CONV_MAX_WGS, LP_BN_BWD_WGS_PER_CU), read from the environment ONCE when the library is loaded and immutable afterwards -
+ *     LP_STEM_2D, LP_STEM_WGRAD_NB, LP_POOL_V2, LP_CONV_MAX_WGS, LP_BN_BWD_WGS_PER_CU), read from the environment ONCE when the library is loaded and immutable afterwards -
  *     except through lp_config_reload_env(), a test / A-B hook that must not run concurrently with other calls
  *   - limits: lp_bn_bwd_apply WITHOUT its terms_ws workspace covers C <= 2048 channels (the per-launch correction table then lives in
  *     LDS; LP_ERR_UNSUPPORTED beyond); with the workspace any C that is a multiple of 8
@@ -198,6 +198,7 @@ typedef struct lp_conv_geom {
 #define LP_CONV_KERNEL_PIPE_HALO 4 /* conv_pipe_kernel<..., HALO>: 3x3 / stride 1, the input neighbourhood staged once (LP_CONV_HALO=0 disables) */
 #define LP_CONV_KERNEL_SPEC 6      /* conv_spec_kernel: the operand ring with producer / consumer wave roles and the store pass handed to the producers (LP_CONV_SPEC=0 disables) */
 #define LP_CONV_KERNEL_SPEC_HALO 7 /* ... its HALO form */
+#define LP_CONV_KERNEL_STEM_WGRAD_NB 8 /* stem_wgrad_nb_kernel: the stem's weight gradient from a staged input neighbourhood (LP_STEM_WGRAD_NB=0 disables) */
 #define LP_CONV_KERNEL_RES2D 5     /* conv_res2d_kernel: 3x3 / stride 1, 64 -> 64 channels, 16 x 16 tiles, filter resident in LDS (LP_CONV_RES2D=0 disables) */
 int lp_conv_last_kernel(void);
 

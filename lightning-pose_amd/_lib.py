@@ -52,6 +52,7 @@ class GemmBatch(C.Structure):
 
 HM_MSE, HM_KL, HM_JS = 0, 1, 2
 CONV_KERNEL_IGEMM, CONV_KERNEL_PIPE, CONV_KERNEL_WGRAD, CONV_KERNEL_WGRAD_PIPE, CONV_KERNEL_PIPE_HALO, CONV_KERNEL_RES2D = 0, 1, 2, 3, 4, 5   # lp_conv_last_kernel()
+CONV_KERNEL_SPEC, CONV_KERNEL_SPEC_HALO, CONV_KERNEL_STEM_WGRAD_NB = 6, 7, 8
 BORDER_RENORM, BORDER_CLAMP = 0, 1
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 

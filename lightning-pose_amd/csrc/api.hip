@@ -3,7 +3,7 @@
 
 #include <stdlib.h>
 
-extern "C" int lp_version(void) { return 130; }  // 0.3.0: decode `prune` is a call argument, the LP_* switches are read once at load (lp_config_reload_env)
+extern "C" int lp_version(void) { return 131; }  // 0.3.0: decode `prune` is a call argument, the LP_* switches are read once at load (lp_config_reload_env)
 
 namespace lp {
 static int env_int(const char* name, int dflt) {
@@ -20,6 +20,7 @@ static LpSwitches read_switches() {
     s.gemm_pipe = env_int("LP_GEMM_PIPE", 1);       // 0: the Linear layers on conv_igemm_kernel
     s.wgrad_pipe = env_int("LP_WGRAD_PIPE", 1);     // 0: weight gradients on conv_wgrad_kernel; 2: the pipelined kernel wherever it can run
     s.stem_2d = env_int("LP_STEM_2D", 1);           // 0: the stem on conv_igemm_kernel<64, stem>
+    s.stem_wgrad_nb = env_int("LP_STEM_WGRAD_NB", 1);   // 0: the stem's weight gradient on conv_wgrad_kernel<64, stem>
     s.pool_v2 = env_int("LP_POOL_V2", 1);           // 0: the stem's pool backward on the first kernel
     s.bn_bwd_wgs_per_cu = env_int("LP_BN_BWD_WGS_PER_CU", 5);   // 1 .. 5: workgroups per CU of the BatchNorm backward walk (5 = one resident round)
     if (s.bn_bwd_wgs_per_cu < 1 || s.bn_bwd_wgs_per_cu > 5) s.bn_bwd_wgs_per_cu = 5;

@@ -1236,6 +1236,10 @@ static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvG
     return launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
 }
 
+}  // namespace lp
+#include "conv_stem_wgrad.h"
+namespace lp {
+
 constexpr int kWgradWgs = 512;  // workgroups per weight-gradient launch (tiles x pixel slices)
 
 struct WgradPlan {
@@ -1603,6 +1607,25 @@ extern "C" int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_ge
     return conv_dgrad_impl(dy, wd, geom, nullptr, addend, relu_mask, dx_bf16, nullptr, geom->Ci, 0, 0, bn, stream);
 }
 
+// stem_wgrad_nb_kernel (conv_stem_wgrad.h): a K step is 64 consecutive pixels of one output row, byte offsets are 32-bit
+static bool stem_wgrad_nb_ok(const lp::ConvGeom& g) {
+    return lp::lp_switches().stem_wgrad_nb != 0 && g.Wo % 64 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo &&
+           128ull * g.B * g.Ho * g.Wo < (1ull << 32) && 8ull * g.B * g.Hi * g.Wi < (1ull << 32);
+}
+// one workgroup (all 256 gradient rows) per pixel slice, ~4 resident per CU (40 KB of LDS each); the workspace holds two 128-row j-tiles per slice
+static lp::WgradPlan plan_stem_wgrad_nb(int M, int split_hint) {
+    lp::WgradPlan p{};
+    const int ksteps = M / lp::kBK;
+    int split = split_hint > 0 ? split_hint : 1024;
+    if (split > ksteps) split = ksteps;
+    if (split < 1) split = 1;
+    p.per = ((ksteps + split - 1) / split) * lp::kBK;
+    p.split = (M + p.per - 1) / p.per;
+    p.tj = 2, p.tn = 1, p.wide = false;
+    p.ws_floats = (size_t)p.split * 2 * 4 * 2 * 16 * 64;
+    return p;
+}
+
 extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int split_hint) {
     using namespace lp;
     if (!geom_ok(geom)) return 0;
@@ -1610,6 +1633,10 @@ extern "C" size_t lp_conv_wgrad_workspace_bytes(const lp_conv_geom* geom, int sp
     const bool stem = (g.Ci == 4 && g.R == 7);
     const int Kw = stem ? 256 : g.R * g.S * g.Ci;
     size_t fl = plan_wgrad(g.B * g.Ho * g.Wo, Kw, g.Co, split_hint, kWgradWgs).ws_floats;
+    if (stem && stem_wgrad_nb_ok(g)) {
+        const size_t nb = plan_stem_wgrad_nb(g.B * g.Ho * g.Wo, split_hint).ws_floats;
+        if (nb > fl) fl = nb;
+    }
     if (!stem) {   // either kernel may take the launch (LP_CONV_PIPE): room for both plans
         const WgradPipePlan pp = plan_wgrad_pipe(g, split_hint, true);   // (the forced plan is the larger one)
         if (pp.ok && pp.ws_floats > fl) fl = pp.ws_floats;
@@ -1760,10 +1787,20 @@ extern "C" int lp_stem_wgrad(const void* x4, const void* dy, const lp_conv_geom*
     ConvGeom g = to_geom(geom);
     if (g.R != 7 || g.S != 7 || g.stride != 2 || g.pad != 3 || g.Ci != 4 || g.Co != 64) return LP_ERR_UNSUPPORTED;
     const int M = g.B * g.Ho * g.Wo, Kw = 256;
-    const WgradPlan p = plan_wgrad(M, Kw, 64, split_hint, kWgradWgs);
-    LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    if (stem_wgrad_nb_ok(g)) {   // one workgroup per pixel slice forms all 256 gradient rows from the staged input neighbourhood
+        const WgradPlan p = plan_stem_wgrad_nb(M, split_hint);
+        LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
+        g_last_conv_kernel = LP_CONV_KERNEL_STEM_WGRAD_NB;
+        hipLaunchKernelGGL(stem_wgrad_nb_kernel, dim3(p.split), dim3(256), 0, st, (const unsigned short*)x4, (const unsigned short*)dy,
+                           (unsigned)(8ull * g.B * g.Hi * g.Wi), (unsigned)(128ull * M), g, M, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws);
+        launch_wgrad_reduce<64>(ws, p.split, 2, 1, Kw, 64, dw, st);
+        return launch_status();
+    }
+    const WgradPlan p = plan_wgrad(M, Kw, 64, split_hint, kWgradWgs);
+    LP_REQUIRE(workspace_bytes >= p.ws_floats * sizeof(float));
+    g_last_conv_kernel = LP_CONV_KERNEL_WGRAD;
     hipLaunchKernelGGL((conv_wgrad_kernel<64, true>), dim3(p.tj * p.split), dim3(256), 0, st, (const unsigned short*)x4,
                        (const unsigned short*)dy, 0u, 0u, g, M, Kw, p.tj, 1, p.per, make_fastdiv(g.Ho * g.Wo), make_fastdiv(g.Wo), ws, TnExt{});
     launch_wgrad_reduce<64>(ws, p.split, p.tj, 1, Kw, 64, dw, st);

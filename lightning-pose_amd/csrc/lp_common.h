@@ -235,7 +235,7 @@ __device__ __forceinline__ float fx_value(const lp_fxsum* p) {
 // getenv and the behaviour of a call does not depend on what the caller's environment holds at that moment.  lp_config_reload_env()
 // re-reads it (tests and A/B scripts that flip a switch inside one process).
 struct LpSwitches {
-    int conv_pipe, conv_halo, conv_res2d, conv_spec, infer_pipe, gemm_pipe, wgrad_pipe, stem_2d, pool_v2, conv_max_wgs, bn_bwd_wgs_per_cu;
+    int conv_pipe, conv_halo, conv_res2d, conv_spec, infer_pipe, gemm_pipe, wgrad_pipe, stem_2d, stem_wgrad_nb, pool_v2, conv_max_wgs, bn_bwd_wgs_per_cu;
 };
 const LpSwitches& lp_switches();
 

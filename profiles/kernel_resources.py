@@ -17,7 +17,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
 # kernels launched by the bf16-mixed training step / inference at BASELINE's configs (demangled-name prefixes)
-HOT = ("lp::conv_pipe_kernel", "lp::conv_spec_kernel", "lp::conv_wgrad_pipe_kernel", "lp::conv_res2d_kernel", "lp::conv_stem2d_kernel", "lp::conv_wgrad_kernel",
+HOT = ("lp::conv_pipe_kernel", "lp::conv_spec_kernel", "lp::conv_wgrad_pipe_kernel", "lp::conv_res2d_kernel", "lp::conv_stem2d_kernel", "lp::conv_wgrad_kernel", "lp::stem_wgrad_nb_kernel",
        "lp::conv_igemm_kernel", "lp::bn_apply_kernel", "lp::bn_bwd_apply_kernel", "lp::bn_relu_maxpool_fwd_kernel", "lp::bn_pool_bwd_v2_kernel",
        "lp::colreduce_kernel", "lp::rows_reduce_kernel", "lp::decode_fwd_kernel", "lp::decode_bwd_kernel", "lp::heatmap_gen_kernel",
        "lp::hm_rowsq_kernel", "lp::hm_grad_kernel", "lp::softmax2d", "lp::adam_kernel", "lp::pca_kernel", "lp::temporal_kernel",

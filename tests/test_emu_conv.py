@@ -157,6 +157,35 @@ def test_stem_fwd_wgrad():
     assert not dw[:, 7].any() and not dw[:, :, 7].any() and not dw[..., 3].any()
 
 
+@pytest.mark.parametrize("B,H,W,split", [(1, 128, 128, 0), (2, 24, 256, 0), (1, 12, 128, 1), (3, 10, 128, 7)])
+def test_stem_wgrad_from_the_staged_neighbourhood(B, H, W, split, monkeypatch):
+    """stem_wgrad_nb_kernel (csrc/conv_stem_wgrad.h; output rows of 64 x n pixels) against autograd and against conv_wgrad_kernel<64, stem>
+    on the same operands: image borders on all four sides, several 64-pixel strips per output row, images / rows changing inside a slice,
+    one slice and ragged slice counts; the padding entries of the [64][8][8][4] layout stay zero."""
+    gen = torch.Generator().manual_seed(11 + B + H + W + split)
+    x = bf(torch.randn(B, 3, H, W, generator=gen))
+    w = bf(torch.randn(64, 3, 7, 7, generator=gen) / 12).requires_grad_(True)
+    y = F.conv2d(x, w, stride=2, padding=3)
+    dy = bf(torch.randn(y.shape, generator=gen))
+    y.backward(dy)
+    x4 = torch.zeros(B, H, W, 4)
+    x4[..., :3] = nhwc(x)
+    g = emu.geom(B, H, W, 4, 64, 7, 7, 2, 3)
+    xb, db = emu.to_bf16_bits(x4), emu.to_bf16_bits(nhwc(dy))
+    dw = torch.from_numpy(emu.stem_wgrad(xb, db, g, split)).reshape(64, 8, 8, 4)
+    assert emu.lib().lp_conv_last_kernel() == 8   # LP_CONV_KERNEL_STEM_WGRAD_NB
+    scale = float(w.grad.abs().max())
+    torch.testing.assert_close(dw[:, :7, :7, :3], w.grad.permute(0, 2, 3, 1), atol=2e-5 * scale * (B * H * W) ** 0.5, rtol=1e-4)
+    assert not dw[:, 7].any() and not dw[:, :, 7].any() and not dw[..., 3].any()
+    monkeypatch.setenv("LP_STEM_WGRAD_NB", "0")
+    old = torch.from_numpy(emu.stem_wgrad(xb, db, g, 0)).reshape(64, 8, 8, 4)
+    assert emu.lib().lp_conv_last_kernel() == 2   # LP_CONV_KERNEL_WGRAD
+    torch.testing.assert_close(dw, old, atol=2e-5 * scale * (B * H * W) ** 0.5, rtol=1e-4)
+    if split == 1:   # one slice each: the same pixels in the same order through the same MFMA - bit for bit
+        one = torch.from_numpy(emu.stem_wgrad(xb, db, g, 1)).reshape(64, 8, 8, 4)
+        assert torch.equal(dw, one)
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fused_batchnorm_reductions(case):
     """lp_conv_fwd_bn == lp_conv_fwd + lp_bn_stats;  lp_conv_dgrad_bn == lp_conv_dgrad(+mask) + lp_bn_bwd_reduce, for both mask
