@@ -1616,7 +1616,7 @@ static bool stem_wgrad_nb_ok(const lp::ConvGeom& g) {
 static lp::WgradPlan plan_stem_wgrad_nb(int M, int split_hint) {
     lp::WgradPlan p{};
     const int ksteps = M / lp::kBK;
-    int split = split_hint > 0 ? split_hint : 1024;
+    int split = split_hint > 0 ? split_hint : 768;   // (512 - 1024 slices measured equal within 4 %, more are slower: profiles/r05m_stem_wgrad_variants.txt)
     if (split > ksteps) split = ksteps;
     if (split < 1) split = 1;
     p.per = ((ksteps + split - 1) / split) * lp::kBK;

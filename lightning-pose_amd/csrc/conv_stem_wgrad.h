@@ -26,7 +26,10 @@ constexpr int kSnRows = 7, kSnChunks = 68, kSnRowB = kSnChunks * 16;   // neighb
 constexpr int kSnBytes = kSnRows * kSnRowB, kSnPieces = kSnRows * kSnChunks;
 constexpr int kSnLdb = 64 + 32;                                        // dy tile row pitch (elements), as conv_wgrad_kernel<64>
 
-__global__ __launch_bounds__(256) void stem_wgrad_nb_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
+#ifndef LP_STEM_NB_WGS
+#define LP_STEM_NB_WGS 2   // workgroups per CU the register budget allows (A/B builds: 3 caps the kernel at 168 registers)
+#endif
+__global__ __launch_bounds__(256, LP_STEM_NB_WGS) void stem_wgrad_nb_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY,
                                                             unsigned x_bytes, unsigned dy_bytes, ConvGeom g, int M, int m_per_split,
                                                             FastDiv div_hw, FastDiv div_wo, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) unsigned char sN[2][kSnBytes];

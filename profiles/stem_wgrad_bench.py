@@ -16,6 +16,7 @@ from lightning_pose_amd.ops import _p, _stream  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 HW = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+splits = [int(v) for v in os.environ.get("SPLITS", "0").split(",")]   # pixel slices of the new kernel (0 = the library's choice)
 dev = torch.device("cuda:0")
 lib = _lib.lib()
 g = _lib.ConvGeom(B, HW, HW, 4, HW // 2, HW // 2, 64, 7, 7, 2, 3)
@@ -25,10 +26,10 @@ dy = torch.randn(B, HW // 2, HW // 2, 64, device=dev).to(torch.bfloat16)
 nbytes = x4.numel() * 2 + dy.numel() * 2
 out = {}
 for rnd in range(3):
-    for mode in ("0", "1"):
+    for mode, split in [("0", 0)] + [("1", s_) for s_ in splits]:
         os.environ["LP_STEM_WGRAD_NB"] = mode
         lib.lp_config_reload_env()
-        nws = lib.lp_conv_wgrad_workspace_bytes(C.byref(g), 0)
+        nws = lib.lp_conv_wgrad_workspace_bytes(C.byref(g), split)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
         dw = torch.zeros(64, 256, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,13 +38,13 @@ for rnd in range(3):
                 e0.record()
             if it < 2:
                 dw.zero_()
-            assert lib.lp_stem_wgrad(_p(x4), _p(dy), C.byref(g), _p(dw), 0, _p(ws), nws, _stream()) == 0
+            assert lib.lp_stem_wgrad(_p(x4), _p(dy), C.byref(g), _p(dw), split, _p(ws), nws, _stream()) == 0
             if it == 0:
                 out[mode] = dw.clone()
         e1.record()
         torch.cuda.synchronize()
         us = 1000 * e0.elapsed_time(e1) / reps
-        print(f"round {rnd} LP_STEM_WGRAD_NB={mode} kernel id {lib.lp_conv_last_kernel()}: {us:8.1f} us per launch   {nbytes / us / 1e6:5.2f} TB/s of the {nbytes / 1e6:.0f} MB the operands hold", flush=True)
+        print(f"round {rnd} LP_STEM_WGRAD_NB={mode} split {split:4d} kernel id {lib.lp_conv_last_kernel()}: {us:8.1f} us per launch   {nbytes / us / 1e6:5.2f} TB/s of the {nbytes / 1e6:.0f} MB the operands hold", flush=True)
 a, b = out["0"], out["1"]
 print(f"max |old - new| = {float((a - b).abs().max()):.3e}   max |old| = {float(a.abs().max()):.3e}   padding entries zero: "
       f"{not bool(b.reshape(64, 8, 8, 4)[:, 7].any()) and not bool(b.reshape(64, 8, 8, 4)[:, :, 7].any())}")
