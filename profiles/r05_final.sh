@@ -24,5 +24,7 @@ python profiles/summarize_rocpd.py /tmp/r05_final_prof/dflt_results.db > gpurun_
 LP_WGRAD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r05_final_prof_serial -o serial -- python bench.py --no-cpu-baseline --no-profile --no-secondary --steps 8 --warmup 2 > gpurun_out/r05_final_prof_serial.log 2>&1
 python profiles/summarize_rocpd.py /tmp/r05_final_prof_serial/serial_results.db > gpurun_out/r05_final_kernel_stats_serial.txt 2>&1; head -12 gpurun_out/r05_final_kernel_stats_serial.txt | cut -c1-60,110-160
 python profiles/gap_analysis.py /tmp/r05_final_prof/dflt_results.db > gpurun_out/r05_final_gap_analysis.txt 2>&1; head -9 gpurun_out/r05_final_gap_analysis.txt
+python profiles/stream_tail.py /tmp/r05_final_prof/dflt_results.db > gpurun_out/r05_final_stream_tail.txt 2>&1; head -4 gpurun_out/r05_final_stream_tail.txt
+timeout 200 python profiles/stem_wgrad_bench.py > gpurun_out/r05_final_stem_wgrad.txt 2>&1; tail -3 gpurun_out/r05_final_stem_wgrad.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/r05_final_vit -o vit -- python bench.py --backbone vits_dino --no-cpu-baseline --no-profile --no-secondary --steps 6 --warmup 2 > gpurun_out/r05_final_vit_prof.log 2>&1
 python profiles/summarize_rocpd.py /tmp/r05_final_vit/vit_results.db > gpurun_out/r05_final_vit_kernel_stats.txt 2>&1; head -3 gpurun_out/r05_final_vit_kernel_stats.txt | cut -c1-60,110-160
