@@ -188,7 +188,6 @@ class Engine:
     # weight gradients on a side stream (measured on the ResNet step: +2 %; on the ViT step, whose main stream is already
     # MFMA-bound, -8 %, so ViTEngine turns it off)
     wgrad_side_stream = True
-    _wgrad_after_dgrad = False
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
         self.device = torch.device(device)
@@ -224,7 +223,6 @@ class Engine:
         # lp_bn_bwd_apply in two launches (the correction terms converted by a one-thread-per-value kernel into a small workspace, round 5) or
         # - LP_BN_BWD_TERMS=0, A/B runs - in the self-contained form that converts them per workgroup into LDS
         self.bn_bwd_terms = os.environ.get("LP_BN_BWD_TERMS", "1") != "0"
-        self._wgrad_after_dgrad = os.environ.get("LP_WGRAD_AFTER_DGRAD", "0") != "0"   # (A/B: order of a layer's two gradient launches)
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
@@ -815,13 +813,10 @@ class Engine:
         ``bn`` = (BNP, z, mean, invstd, sums): dx is the gradient of relu(BN(z) [+ residual]); the launch also leaves BatchNorm's
         two backward reductions in ``sums``.  Without ``relu_mask`` the ReLU mask is recomputed from z (no residual branch)."""
         g = self._geom(c, B, Hi, Wi)
-        wgrad = lambda: self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g),  # noqa: E731
-                                    lambda: self._wgrad(x, dz, g, self.G[c.w_off:]), self._bytes(c, g, wgrad=True))
-        # LP_WGRAD_AFTER_DGRAD=1 (A/B): enqueue the layer's weight gradient BEHIND its data gradient - the side stream then starts it when the
-        # data gradient (MFMA-bound, on the critical path) has finished, beside the HBM-bound BatchNorm kernels that follow it on the main stream
-        defer = need_dx and self._wgrad_after_dgrad
-        if not defer:
-            wgrad()
+        # (the weight gradient is enqueued BEFORE the layer's data gradient: the side stream starts it at once, beside the data gradient.  Enqueued
+        # behind it - so that it would run beside the HBM-bound BatchNorm kernels instead - the step was 1.3 % slower, profiles/r05o_wgrad_order_ab.txt)
+        self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g),
+                    lambda: self._wgrad(x, dz, g, self.G[c.w_off:]), self._bytes(c, g, wgrad=True))
         if not need_dx:
             return None
         st = ops._stream()
@@ -846,8 +841,6 @@ class Engine:
         extra = (dx_bytes if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
                 (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0)
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
-        if defer:
-            wgrad()
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05o: a layer's weight gradient enqueued behind its data gradient (LP_WGRAD_AFTER_DGRAD=1) against the default order, alternating processes
+# r05o: a layer's weight gradient enqueued behind its data gradient (LP_WGRAD_AFTER_DGRAD=1: an engine switch of commit 6b4136e..b1d58a4, removed after this measurement) against the default order, alternating processes
 mkdir -p gpurun_out
 for i in 1 2 3; do
   for m in 0 1; do
