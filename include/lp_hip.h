@@ -289,6 +289,12 @@ typedef struct lp_bn_fuse {
      * launch's rows per image must be a multiple of 128 (LP_ERR_UNSUPPORTED otherwise: run the segments as two calls).  0 = one segment. */
     int seg_images;
 } lp_bn_fuse;
+/* lp_conv_dgrad (bf16 result, no bias) with the ReLU mask read at 1 BIT per element - relu_bits[(row * Ci + c) / 8] bit c % 8, the bytes
+ * lp_bn_apply writes beside the activation - instead of from the bf16 activation itself (round 5: the two data gradients into a layer's first
+ * block's input read 1/16 of the mask bytes).  Results are identical to lp_conv_dgrad(relu_mask = that activation).
+ * Reference: autograd of relu(bn3(z) + identity) feeding conv1 / downsample under models/base.py:398. */
+int lp_conv_dgrad_bits(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_bits, void* dx_bf16,
+                       int skip_empty_classes, lp_stream_t stream);
 /* Inference (predict_step, models/heatmap_tracker.py:155-191; eval-mode nn.BatchNorm2d uses its running statistics): the BatchNorm
  * after a convolution is folded into it once per set of weights - lp_bn_fold: w_bf16[co][:] = bf16(w[co][:] * a[co]),
  * bias[co] = beta[co] - running_mean[co] * a[co], a = gamma / sqrt(running_var + eps) - and the layer becomes ONE launch,

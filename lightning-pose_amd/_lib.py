@@ -89,6 +89,7 @@ PROTOTYPES = {
     "lp_loss_combine_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "lp_conv_fwd": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _I, _P]),
     "lp_conv_dgrad": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "lp_conv_dgrad_bits": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _P]),
     "lp_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(GemmBatch), _P]),
     "lp_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P, _I, _P]),

@@ -1141,7 +1141,9 @@ static int pipe_dgrad_kind(const ConvEpilogue& ep) {
         if (!ep.mask_from_z && ep.addend && ep.relu_bits) return kEkAZB;
         return -1;
     }
-    return (ep.relu_bits == nullptr && ep.stats_sums == nullptr) ? kEkPlain : -1;
+    if (ep.stats_sums != nullptr) return -1;
+    if (ep.relu_bits != nullptr) return ep.relu_mask == nullptr ? kEkPB : -1;   // (one mask source per launch)
+    return kEkPlain;
 }
 
 // HALO form (conv_pipe.h): 3x3 / stride 1 / pad 1 with the tile's input neighbourhood staged once per 64-channel slice.  Eligible when the
@@ -1233,6 +1235,7 @@ static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvG
     if (kind == kEkZ && pipe_halo_ok(g, M, g.Co, BN == 64 ? 512 : 384)) return launch_pipe<BN, kModeDgrad, kEkZ, true>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkZ) return launch_pipe<BN, kModeDgrad, kEkZ>(x, w, g, lat, M, N, K, ep, st);
     if (kind == kEkAZB) return launch_pipe<BN, kModeDgrad, kEkAZB>(x, w, g, lat, M, N, K, ep, st);
+    if (kind == kEkPB) return launch_pipe<BN, kModeDgrad, kEkPB>(x, w, g, lat, M, N, K, ep, st);
     return launch_pipe<BN, kModeDgrad, kEkPlain>(x, w, g, lat, M, N, K, ep, st);
 }
 
@@ -1524,7 +1527,7 @@ extern "C" int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int 
 // dx[b][hi][wi][ci] = sum dy[b][ho][wo][co] * wd[ci][r][s][co] over taps with ho*st - pad + r == hi  (+ addend)
 static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* geom, const float* bias, const void* addend,
                            const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
-                           const lp_bn_fuse* bn, lp_stream_t stream) {
+                           const lp_bn_fuse* bn, lp_stream_t stream, const void* relu_bits = nullptr) {
     using namespace lp;
     LP_REQUIRE(dy && wd && geom_ok(geom) && (dx_bf16 || dx_f32) && ldo > 0);
     ConvGeom g = to_geom(geom);
@@ -1534,6 +1537,11 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
     const int N = g.Ci;
     ConvEpilogue ep{(unsigned short*)dx_bf16, dx_f32, ldo, n_store > 0 ? n_store : N, bias, (const unsigned short*)addend,
                     (const unsigned short*)relu_mask};
+    if (relu_bits != nullptr) {   // lp_conv_dgrad_bits: the ReLU mask at 1 bit per element of the dense bf16 result ([rows][N / 8] bytes)
+        LP_REQUIRE(bn == nullptr && relu_mask == nullptr && dx_bf16 && !dx_f32 && ldo == N && ep.n_store == N);
+        if (N % 8 != 0) return LP_ERR_UNSUPPORTED;
+        ep.relu_bits = (const unsigned char*)relu_bits;
+    }
     if (bn) {
         // the reductions cover every pixel exactly once, so no class may be skipped and the output must be the dense bf16 tensor
         LP_REQUIRE(bn->z && bn->mean && bn->invstd && bn->sums && dx_bf16 && !dx_f32 && !skip_empty_classes &&
@@ -1598,6 +1606,13 @@ extern "C" int lp_conv_dgrad(const void* dy, const void* wd, const lp_conv_geom*
                              const void* relu_mask, void* dx_bf16, float* dx_f32, int ldo, int n_store, int skip_empty_classes,
                              lp_stream_t stream) {
     return conv_dgrad_impl(dy, wd, geom, bias, addend, relu_mask, dx_bf16, dx_f32, ldo, n_store, skip_empty_classes, nullptr, stream);
+}
+
+// the same with the ReLU mask read at 1 bit per element (what lp_bn_apply writes beside the activation) instead of from the activation
+extern "C" int lp_conv_dgrad_bits(const void* dy, const void* wd, const lp_conv_geom* geom, const void* addend, const void* relu_bits,
+                                  void* dx_bf16, int skip_empty_classes, lp_stream_t stream) {
+    LP_REQUIRE(relu_bits && geom);
+    return conv_dgrad_impl(dy, wd, geom, nullptr, addend, nullptr, dx_bf16, nullptr, geom->Ci, 0, skip_empty_classes, nullptr, stream, relu_bits);
 }
 
 // data gradient + ReLU backward + the two reductions of the BatchNorm backward that consumes dx (sum dx, sum dx * xhat)

@@ -79,7 +79,9 @@ __device__ __forceinline__ void store8(unsigned short* p, u16x8 v) { *reinterpre
 //   kEkPlain no BatchNorm fused: optional addend, optional bf16 activation as the ReLU mask (conv1 / projection shortcut of the first
 //            block of a layer, whose input gradient has two writers)
 //   kEkInfer forward with + residual and ReLU in the store pass (inference, BatchNorm folded into weights and bias: lp_conv_fwd_act)
-enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4 };
+//   kEkPB    kEkPlain with the ReLU mask at 1 bit per element (lp_conv_dgrad_bits, round 5: the two writers of a layer's first block read
+//            57 MB of mask bits instead of re-reading the block input's 906 MB activation)
+enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4, kEkPB = 5 };
 
 // HALO (3x3, stride 1, pad 1 - conv2 of every identity-stride block, forward and data gradient): the pixel operand is not fetched per
 // filter tap.  The ring above re-reads every activation row 9 times from L2 (once per tap: 27.7 us per tap on layer1's 64-channel layers,
@@ -558,7 +560,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     // everything is applied before the single rounding to bf16, as in conv_igemm_kernel.
     constexpr int PH = 16 / RP;          // read-back passes per 16-pixel half
     constexpr int NPC = 2 * PH;          // pieces (8 channels of one row) per lane and 32-pixel chunk
-    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain), kLz = (EK != kEkNone && EK != kEkInfer), kLb = (EK == kEkAZB);
+    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain || EK == kEkPB), kLz = (EK != kEkNone && EK != kEkInfer && EK != kEkPB),
+                   kLb = (EK == kEkAZB || EK == kEkPB);
     // (kEkAZB - the hottest data gradient, at the register cap - does not keep the output offsets of its pieces: its launches cover the full
     //  pixel lattice (host-checked), so an offset is two multiply-adds away and is recomputed in rb_process: 8 VGPRs, the 7 it used to spill)
     constexpr bool kKeepOff = EK != kEkAZB;
@@ -578,10 +581,10 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             const unsigned off_p = rv ? (unsigned)(kKeepOff ? out_row(m, lat, div_img, div_row, full_h, full_w) : m) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8) : ~0u;
             if (kKeepOff) rb.off[kKeepOff ? p : 0] = off_p;
             const unsigned o = rv ? off_p : (unsigned)(nbase + pc * 8);   // (rows past M: any valid address, the result is not stored)
-            if (EK == kEkAZB || (EK == kEkPlain && ep.addend)) rb.la[kLa ? p : 0] = load8_stream(ep.addend + o);
-            if (bwd) rb.lz[p] = load8(ep.bn_z + o);
-            if (EK == kEkPlain && ep.relu_mask) rb.lz[p] = load8_stream(ep.relu_mask + o);
-            if (EK == kEkAZB) rb.lb[kLb ? p : 0] = ep.relu_bits[o >> 3];
+            if (EK == kEkAZB || ((EK == kEkPlain || EK == kEkPB) && ep.addend)) rb.la[kLa ? p : 0] = load8_stream(ep.addend + o);
+            if (bwd) rb.lz[kLz ? p : 0] = load8(ep.bn_z + o);
+            if (EK == kEkPlain && ep.relu_mask) rb.lz[kLz ? p : 0] = load8_stream(ep.relu_mask + o);
+            if (EK == kEkAZB || EK == kEkPB) rb.lb[kLb ? p : 0] = ep.relu_bits[o >> 3];
         }
     };
     auto rb_process = [&](const ReadBack& rb, const int mt, unsigned char* stg_all, const int m0, const int n0) {
@@ -621,14 +624,14 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                 }
                 if (off_p != ~0u) {
                     float v[8] = {lo_[ps][0], lo_[ps][1], lo_[ps][2], lo_[ps][3], hi_[ps][0], hi_[ps][1], hi_[ps][2], hi_[ps][3]};
-                    if (EK == kEkAZB || (EK == kEkPlain && ep.addend)) {
+                    if (EK == kEkAZB || ((EK == kEkPlain || EK == kEkPB) && ep.addend)) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += bf16_to_f32(rb.la[kLa ? p : 0][q]);
                     }
                     float zc[8];
                     if (bwd) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(rb.lz[p][q]) - mu[q];
+                        for (int q = 0; q < 8; ++q) zc[q] = bf16_to_f32(rb.lz[kLz ? p : 0][q]) - mu[q];
                         if (EK == kEkZ) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q)
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                     if (EK == kEkPlain && ep.relu_mask) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
-                            if (!bf16_positive(rb.lz[p][q])) v[q] = 0.f;
+                            if (!bf16_positive(rb.lz[kLz ? p : 0][q])) v[q] = 0.f;
                     }
-                    if (EK == kEkAZB) {
+                    if (EK == kEkAZB || EK == kEkPB) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
                             if (!((rb.lb[kLb ? p : 0] >> q) & 1u)) v[q] = 0.f;

@@ -188,6 +188,7 @@ class Engine:
     # weight gradients on a side stream (measured on the ResNet step: +2 %; on the ViT step, whose main stream is already
     # MFMA-bound, -8 %, so ViTEngine turns it off)
     wgrad_side_stream = True
+    dgrad_mask_bits = True
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
         self.device = torch.device(device)
@@ -223,6 +224,7 @@ class Engine:
         # lp_bn_bwd_apply in two launches (the correction terms converted by a one-thread-per-value kernel into a small workspace, round 5) or
         # - LP_BN_BWD_TERMS=0, A/B runs - in the self-contained form that converts them per workgroup into LDS
         self.bn_bwd_terms = os.environ.get("LP_BN_BWD_TERMS", "1") != "0"
+        self.dgrad_mask_bits = os.environ.get("LP_DGRAD_MASK_BITS", "1") != "0"   # (0: the two data gradients into a layer's first block read the bf16 activation as mask)
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
         self.profile: list | None = None  # bench.py: [(kernel tag, algorithmic flops, start event, end event)]
@@ -806,7 +808,7 @@ class Engine:
         return dz, dres
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
-                  relu_bits=None, seg: int = 0):
+                  relu_bits=None, seg: int = 0, mask_bits=None):
         """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
         ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
         for stride-2 layers only the pixels a filter tap reaches are touched.
@@ -832,6 +834,11 @@ class Engine:
             f = self._bn_fuse(sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None, relu_bits=relu_bits, seg=seg)
             run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
                                                            C.byref(f), st), "lp_conv_dgrad_bn")
+        elif mask_bits is not None and self.dgrad_mask_bits:
+            # the ReLU mask of x at 1 bit per element (written by lp_bn_apply beside x): 1/16 of the bytes the activation itself would cost
+            relu_mask = None
+            run = lambda: check(self._lib.lp_conv_dgrad_bits(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(mask_bits), _p(dx),  # noqa: E731
+                                                             skip, st), "lp_conv_dgrad_bits")
         else:
             run = lambda: check(self._lib.lp_conv_dgrad(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), None, _p(addend), _p(relu_mask),  # noqa: E731
                                                         _p(dx), None, c.Ci, 0, skip, st), "lp_conv_dgrad")
@@ -839,7 +846,8 @@ class Engine:
         # over the residual branch, the pre-normalisation tensor of the fused BatchNorm backward, the ReLU mask as activation or 1 bit each)
         dx_bytes = 2.0 * B * Hi * Wi * c.Ci
         extra = (dx_bytes if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
-                (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0)
+                (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0) + \
+                (dx_bytes / 16 if (bn is None and relu_mask is None and mask_bits is not None and self.dgrad_mask_bits) else 0.0)
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
         return dx
 
@@ -908,8 +916,9 @@ class Engine:
                 dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False, seg=seg)
                 # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
                 # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
-                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x)
-                self._conv_bwd(blk.down, x, dzd, B, hi, wi, True, relu_mask=mask_x, accumulate_into=d)
+                xbits = T.get(f"b{i - 1}.out_bits") if i > 0 else None   # x = the previous block's output: its 1-bit ReLU mask exists
+                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x, mask_bits=xbits)
+                self._conv_bwd(blk.down, x, dzd, B, hi, wi, True, relu_mask=mask_x, accumulate_into=d, mask_bits=xbits)
             elif i > 0:
                 prev, pk = plan.blocks[i - 1], f"b{i - 1}"
                 d_sums = new_sums(prev.bn3)

@@ -257,14 +257,33 @@ def conv_fwd(x_nhwc_bits, w_bits, g, bias=None, f32_out=False, ldo=None, n_store
     return ob.np(), (of.np() if of is not None else None)
 
 
-def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, ldo=None, n_store=0, mask_bits=None):
+def conv_dgrad(dy_bits, wd_bits, g, addend_bits=None, bias=None, f32_out=False, ldo=None, n_store=0, mask_bits=None, into=None):
+    """``into`` (bf16 bits of an existing gradient): accumulate in place (addend = output, skip_empty_classes = 1)"""
     M = g.B * g.Hi * g.Wi
     ldo = ldo or g.Ci
     db, wb, ab, bb, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(bias, np.float32), B(mask_bits)
+    if into is not None:
+        ob = Buf(into)
+        ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), None, ob.p, ptr(mb), ob.p, None, ldo, n_store, 1, stream()))
+        return ob.np(), None
     ob = Z((M, ldo), np.uint16)
     of = Z((M, ldo)) if f32_out else None
     ok(lib().lp_conv_dgrad(db.p, wb.p, C.byref(g), ptr(bb), ptr(ab), ptr(mb), ob.p, ptr(of), ldo, n_store, 0, stream()))
     return ob.np(), (of.np() if of is not None else None)
+
+
+def conv_dgrad_bits(dy_bits, wd_bits, g, relu_bits, addend_bits=None, into=None, skip=0):
+    """lp_conv_dgrad_bits: the ReLU mask at 1 bit per element; ``into`` (bf16 bits of an existing gradient) = accumulate in place, as the
+    projection shortcut's data gradient does (addend = output, skip_empty_classes)"""
+    M = g.B * g.Hi * g.Wi
+    db, wb, rb = Buf(dy_bits), Buf(wd_bits), Buf(relu_bits)
+    if into is not None:
+        ob = Buf(into)
+        ok(lib().lp_conv_dgrad_bits(db.p, wb.p, C.byref(g), ob.p, rb.p, ob.p, skip, stream()))
+    else:
+        ab, ob = B(addend_bits), Z((M, g.Ci), np.uint16)
+        ok(lib().lp_conv_dgrad_bits(db.p, wb.p, C.byref(g), ptr(ab), rb.p, ob.p, skip, stream()))
+    return ob.np()
 
 
 def ZX(shape):

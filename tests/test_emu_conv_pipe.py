@@ -58,6 +58,19 @@ def test_pipe_equals_igemm(case, wgs, monkeypatch):
     assert np.array_equal(d0, d1)
     (e0, _), (e1, _) = _both(monkeypatch, lambda: emu.conv_dgrad(dy, wd, g))
     assert np.array_equal(e0, e1)
+    # ... and the mask at 1 bit per element (lp_conv_dgrad_bits: kEkPB on conv_pipe_kernel, the relu_bits branch of conv_igemm_kernel): the
+    # same gradient as with the bf16 activation as mask; then the projection shortcut's form - accumulated in place into an existing
+    # gradient, only the pixels a filter tap reaches touched
+    b0, b1 = _both(monkeypatch, lambda: emu.conv_dgrad_bits(dy, wd, g, relu_bits, addend_bits=add))
+    assert np.array_equal(b0, d0) and np.array_equal(b1, d0)
+    assert st != 1 or emu.lib().lp_conv_last_kernel() == 1   # LP_CONV_KERNEL_PIPE (a strided launch ends on its last parity class's kernel)
+    (m0, _), _ = _both(monkeypatch, lambda: emu.conv_dgrad(dy, wd, g, mask_bits=a_bits))
+    n0, n1 = _both(monkeypatch, lambda: emu.conv_dgrad_bits(dy, wd, g, relu_bits))
+    assert np.array_equal(n0, m0) and np.array_equal(n1, m0)
+    acc0, acc1 = _both(monkeypatch, lambda: emu.conv_dgrad_bits(dy, wd, g, relu_bits, into=d0, skip=1))
+    (ref0, _), (ref1, _) = _both(monkeypatch, lambda: emu.conv_dgrad(dy, wd, g, mask_bits=a_bits, into=d0))
+    assert np.array_equal(ref0, ref1) and np.array_equal(acc0, ref0) and np.array_equal(acc1, ref0)
+    assert not np.array_equal(ref0, d0)   # (something was accumulated)
     for mask, bits in ((a_bits, None), (None, None), (None, relu_bits)):
         r0, r1 = _both(monkeypatch, lambda: emu.conv_dgrad_bn(dy, wd, g, zin_bits, mean, invstd, gamma.numpy(), beta.numpy(), addend_bits=add,
                                                            mask_bits=mask, relu_bits=bits))
