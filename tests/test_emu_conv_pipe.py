@@ -79,6 +79,20 @@ def test_pipe_equals_igemm(case, wgs, monkeypatch):
             np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)
 
 
+def test_dgrad_bits_refuses_what_it_cannot_do():
+    """lp_conv_dgrad_bits: a null mask is an argument error (lp_conv_dgrad is the call without a mask); the bits are indexed per 8 output
+    channels, so a channel count that is not a multiple of 8 is refused before anything is enqueued"""
+    import ctypes as C
+    g = emu.geom(1, 8, 8, 64, 64, 1, 1, 1, 0)
+    dy, wd = emu.Buf(emu.to_bf16_bits(torch.randn(64, 64))), emu.Buf(emu.to_bf16_bits(torch.randn(64, 64)))
+    out, bits = emu.Z((64, 64), np.uint16), emu.Z((64, 8), np.uint8)
+    lib = emu.lib()
+    assert lib.lp_conv_dgrad_bits(dy.p, wd.p, C.byref(g), None, None, out.p, 0, emu.stream()) == -1     # LP_ERR_ARGUMENT
+    assert lib.lp_conv_dgrad_bits(dy.p, wd.p, C.byref(g), None, bits.p, None, 0, emu.stream()) == -1
+    g4 = emu.geom(1, 8, 8, 4, 64, 1, 1, 1, 0)                                                                # 4 "input" channels
+    assert lib.lp_conv_dgrad_bits(dy.p, wd.p, C.byref(g4), None, bits.p, out.p, 0, emu.stream()) == -2  # LP_ERR_UNSUPPORTED
+
+
 def test_pipe_two_batchnorm_segments(monkeypatch):
     """Joint labeled + unlabeled pass: images [0, seg) and [seg, B) keep their own sums; the boundary sits on a 256-row tile."""
     gen = torch.Generator().manual_seed(5)
