@@ -404,6 +404,13 @@ int lp_bn_apply(const void* x, const float* mean, const float* invstd, const flo
  * [and of sums (2, 2, C), with count0], the other rows use row 1 [count1] */
 int lp_bn_apply_seg(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                     int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
+/* lp_bn_apply_seg whose residual is a PRE-normalisation tensor with its own BatchNorm (a block's projection shortcut, round 5): the shortcut is
+ * normalised in the same pass - rounded to bf16 as its own lp_bn_apply would have stored it - instead of being written and read back.
+ * Bit-identical to lp_bn_apply_seg(zd -> idt, no ReLU) followed by lp_bn_apply_seg(x, ..., residual = idt).
+ * Reference: torchvision Bottleneck.forward (out = relu(bn3(conv3(.)) + downsample(x))) under models/base.py:398. */
+int lp_bn_apply_seg_rbn(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* zd,
+                        const float* mean_d, const float* invstd_d, const float* gamma_d, const float* beta_d, int relu, int M, int C,
+                        int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
 /* sums (2,C) += [sum dz, sum dz*xhat], dz = dy masked by relu'(y_out) (y_out may be NULL) */
 int lp_bn_bwd_reduce(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, int M, int C,
                      lp_fxsum* sums, void* workspace, size_t workspace_bytes, lp_stream_t stream);
@@ -420,6 +427,17 @@ int lp_bn_bwd_apply(const void* dy, const void* y_out, const void* x, const floa
 int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
                         const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
                         const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws, lp_stream_t stream);
+/* lp_bn_bwd_apply_seg for a block output whose masked gradient ALSO feeds the block's projection-shortcut BatchNorm (round 5): the same walk reads
+ * that BatchNorm's pre-normalisation tensor zd and leaves its two backward reductions [sum dz, sum dz * xhat_d] per segment in sums_d
+ * ([segments][2][C], added into) - what lp_bn_bwd_reduce(dres, NULL, zd, mean_d, invstd_d, ...) computes from one more pass over the gradient.
+ * terms_ws is required; C / 8 must divide 256 (LP_ERR_UNSUPPORTED otherwise); workspace: lp_bn_bwd_ds_workspace_bytes(M, C).
+ * Reference: autograd of bn3(z3) + downsample-bn(zd) -> relu under models/base.py:398 (torchvision Bottleneck.forward). */
+size_t lp_bn_bwd_ds_workspace_bytes(int M, int C);
+int lp_bn_bwd_apply_seg_ds(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd, const float* gamma,
+                           const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows, void* dx, void* dres,
+                           const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws, const void* zd,
+                           const float* mean_d, const float* invstd_d, lp_fxsum* sums_d, void* workspace, size_t workspace_bytes,
+                           lp_stream_t stream);
 /* 3x3 / stride 2 / pad 1; argmax_u8 (B,Ho,Wo,C) records the winning tap (first maximum, ATen tie rule) for the backward gather */
 int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream);
 int lp_maxpool_bwd(const void* argmax_u8, const void* dy, int B, int Hi, int Wi, int C, void* dx, lp_stream_t stream);

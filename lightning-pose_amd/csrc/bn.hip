@@ -184,11 +184,18 @@ __global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, 
 // y = relu?( (x - mean) * invstd * gamma + beta (+ residual) )
 // The grid stride is a multiple of the row length (host guarantees it), so a lane keeps ONE channel chunk for its whole walk:
 // its 8 (mean, scale, shift) triples live in registers and the loop is nothing but 16-B streams, 4 chunks in flight per lane.
+// RBN = true (round 5, lp_bn_apply_seg_rbn): `residual` is the PRE-normalisation tensor of the block's projection shortcut and `rb` its
+// BatchNorm's terms - the shortcut is normalised here, rounded to bf16 exactly as its own lp_bn_apply pass stored it, and added; that pass (a
+// write and a read of a block-output-sized tensor) is gone.  Results bit-identical to lp_bn_apply(shortcut) -> lp_bn_apply(..., residual).
+struct BnResidualBn {
+    const float *mean, *invstd, *gamma, *beta;   // mean / invstd: [segments][C]
+};
+template <bool RBN>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_total, int C, unsigned short* __restrict__ Y,
-                                                       unsigned char* __restrict__ bits, size_t seg_chunk) {
+                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb) {
     // Two BatchNorm segments in one launch (seg_chunk > 0: chunks [0, seg_chunk) use mean / invstd row 0, the rest row 1; the boundary is
     // a whole number of rows): the walk runs once per segment with that segment's terms in registers; a lane keeps its channel chunk
     // because every start is congruent to its global index modulo the stride.
@@ -206,6 +213,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
         mu[i] = mean[sg * C + c + i];
         sc[i] = invstd[sg * C + c + i] * gamma[c + i];
         be[i] = beta[c + i];
+    }
+    float mud[RBN ? 8 : 1], scd[RBN ? 8 : 1], bed[RBN ? 8 : 1];
+    if (RBN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mud[RBN ? i : 0] = rb.mean[sg * C + c + i];
+            scd[RBN ? i : 0] = rb.invstd[sg * C + c + i] * rb.gamma[c + i];
+            bed[RBN ? i : 0] = rb.beta[c + i];
+        }
     }
     constexpr int U = 4;
     for (; q < n_chunks; q += U * stride) {
@@ -228,6 +244,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
             if (residual != nullptr) {
                 float r[8];
                 unpack8(rv[u], r);
+                if (RBN) {   // the shortcut's own lp_bn_apply (no ReLU), rounded to bf16 as that pass stored it
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) r[i] = bf16_to_f32(f32_to_bf16(fmaf(r[i] - mud[RBN ? i : 0], scd[RBN ? i : 0], bed[RBN ? i : 0])));
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += r[i];
             }
@@ -278,15 +298,28 @@ constexpr int kBnBwdMaxC = 2048;   // widest BatchNorm bn_bwd_apply_kernel takes
 // kernel - its 1280 workgroups (ONE resident round: every one of them used to sit in that prologue at the same time, with HBM idle;
 // ~10 us of a 122 us launch, profiles/r04r_bn_bwd_prologue.txt) start streaming after one L2 round trip.  TERMS = false keeps the
 // self-contained form for callers without a workspace (lp_bn_bwd_apply(..., terms_ws = NULL)).
-template <bool TERMS>
-__global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
+// DS = true (round 5, lp_bn_bwd_apply_seg_ds): the masked gradient this pass reads is ALSO the input of the block's projection-shortcut
+// BatchNorm backward, whose two reductions [sum dz, sum dz * xhat_d] used to cost a pass of their own over dz and that BatchNorm's
+// pre-normalisation tensor zd (lp_bn_bwd_reduce).  Here the walk reads zd as a fourth stream and leaves the workgroup's partial sums per segment
+// in its row of `ds_rows` ([segment][gridDim.x][2][C] fp32, colreduce_kernel's row format: rows_reduce_kernel adds them in a fixed order) -
+// dz is read once for both BatchNorms.  Its own instantiation (3 waves per SIMD: the accumulators and zd's constants are 40 more registers).
+#ifndef LP_BN_DS_WAVES
+#define LP_BN_DS_WAVES 3   // waves per SIMD of the DS instantiation: 133 registers, no scratch (4 = capped at 128, five spilled: the same speed, profiles/r05x_ds_waves.txt)
+#endif
+struct BnBwdDs {
+    const unsigned short* zd;          // [M][C] bf16
+    const float *mean_d, *invstd_d;    // [segments][C]
+    float* rows;                       // [segments][gridDim.x][2][C]
+};
+template <bool TERMS, bool DS = false>
+__global__ __launch_bounds__(256, DS ? LP_BN_DS_WAVES : 5) void bn_bwd_apply_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ Yout,
                                                            const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const lp_fxsum* __restrict__ sums, float inv_count, size_t n_total, int C,
                                                            unsigned short* __restrict__ DX, unsigned short* __restrict__ DRES,
                                                            size_t seg_chunk, float inv_count1, const lp_fxsum* __restrict__ local,
                                                            float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                           const float* __restrict__ terms) {
+                                                           const float* __restrict__ terms, BnBwdDs ds = BnBwdDs{}) {
     // (segments as in bn_apply_kernel: mean / invstd rows of C, sums rows of 2 C, one 1 / count per segment)
     const int chunks = C >> 3;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -297,6 +330,7 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
     // ONCE per workgroup, a few per thread, into LDS.  Converted per lane (16 values per segment, four registers each while in flight) the
     // kernel needed 130 instead of 94 VGPRs = 3 instead of 5 waves per SIMD and the step lost 2.6 ms (profiles/r04m_*).  nullptr: zeros.
     __shared__ float kterm[TERMS ? 1 : 2 * 2 * kBnBwdMaxC];
+    __shared__ float dsred[DS ? 2 : 1][DS ? 256 : 1][8];
     if (!TERMS) {
         bn_param_grads(local, nseg, C, dbeta, dgamma);
         __builtin_amdgcn_sched_barrier(0);   // (keeps the parameter-gradient code's registers out of the walk's allocation)
@@ -343,15 +377,25 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
         k0[i] = kt[sg * 2 * C + c + i];
         k1[i] = kt[sg * 2 * C + C + c + i] * is[i];   // (xhat k1 = (x - mean) (invstd k1): one register array less in the walk)
     }
+    float mud[DS ? 8 : 1], isd[DS ? 8 : 1], sd0[DS ? 8 : 1], sd1[DS ? 8 : 1];
+    if (DS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mud[DS ? i : 0] = ds.mean_d[sg * C + c + i];
+            isd[DS ? i : 0] = ds.invstd_d[sg * C + c + i];
+            sd0[DS ? i : 0] = sd1[DS ? i : 0] = 0.f;
+        }
+    }
     constexpr int U = 2;
     for (; q < n_chunks; q += U * stride) {
-        u16x8 dv[U], xv[U], yv[U];
+        u16x8 dv[U], xv[U], yv[U], zdv[DS ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (q + u * stride < n_chunks) {
                 dv[u] = load_stream8(DY + (q + u * stride) * 8);
                 xv[u] = load_stream8(X + (q + u * stride) * 8);
                 if (Yout != nullptr) yv[u] = *reinterpret_cast<const u16x8*>(Yout + (q + u * stride) * 8);
+                if (DS) zdv[DS ? u : 0] = load_stream8(ds.zd + (q + u * stride) * 8);
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -370,7 +414,38 @@ __global__ __launch_bounds__(256, 5) void bn_bwd_apply_kernel(const unsigned sho
             }
             *reinterpret_cast<u16x8*>(DX + (q + u * stride) * 8) = pack8(o);
             if (DRES != nullptr) *reinterpret_cast<u16x8*>(DRES + (q + u * stride) * 8) = pack8(dz);
+            if (DS) {   // colreduce_kernel<1>'s terms, on the values the pass already holds
+                float zd[8];
+                unpack8(zdv[DS ? u : 0], zd);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    sd0[DS ? i : 0] += dz[i];
+                    sd1[DS ? i : 0] = fmaf(dz[i], (zd[i] - mud[DS ? i : 0]) * isd[DS ? i : 0], sd1[DS ? i : 0]);
+                }
+            }
         }
+    }
+    if (DS) {   // the workgroup's partial sums of this segment -> its row (threads tid, tid + chunks, ... hold the same channels: 256 % chunks == 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dsred[0][threadIdx.x][i] = sd0[DS ? i : 0];
+            dsred[DS ? 1 : 0][threadIdx.x][i] = sd1[DS ? i : 0];
+        }
+        __syncthreads();
+        const int lanes_r = 256 / chunks;
+        float* const row = ds.rows + ((size_t)sg * gridDim.x + blockIdx.x) * 2 * C;
+        for (int pair = threadIdx.x; pair < chunks * 8; pair += 256) {
+            const int pc = pair >> 3, pi = pair & 7;
+            float t0 = 0.f, t1 = 0.f;
+            for (int r = 0; r < lanes_r; ++r) {
+                t0 += dsred[0][r * chunks + pc][pi];
+                t1 += dsred[DS ? 1 : 0][r * chunks + pc][pi];
+            }
+            // (thread tid holds chunk (blockIdx.x * 256 + tid) % chunks = tid % chunks)
+            row[pc * 8 + pi] = t0;
+            row[C + pc * 8 + pi] = t1;
+        }
+        __syncthreads();
     }
     }
 }
@@ -950,9 +1025,25 @@ static int bn_apply_impl(const void* x, const float* mean, const float* invstd, 
     LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0 && seg_rows >= 0 && seg_rows < M);
     if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
     const size_t n_chunks = (size_t)M * (C / 8);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
                        gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
-                       (size_t)seg_rows * (C / 8));
+                       (size_t)seg_rows * (C / 8), BnResidualBn{});
+    return launch_status();
+}
+
+// y = relu?( BatchNorm(x) + bf16( BatchNorm_d(zd) ) ): the block output of a layer's first block with its projection shortcut normalised in the
+// same pass (mean_d / invstd_d: (segments, C) like mean / invstd)
+extern "C" int lp_bn_apply_seg_rbn(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* zd,
+                                   const float* mean_d, const float* invstd_d, const float* gamma_d, const float* beta_d, int relu, int M, int C,
+                                   int seg_rows, void* y, void* relu_bits, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && mean && invstd && gamma && beta && zd && mean_d && invstd_d && gamma_d && beta_d && y && M > 0 && C > 0 && seg_rows >= 0 &&
+               seg_rows < M);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const size_t n_chunks = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
+                       gamma, beta, (const unsigned short*)zd, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
+                       (size_t)seg_rows * (C / 8), BnResidualBn{mean_d, invstd_d, gamma_d, beta_d});
     return launch_status();
 }
 
@@ -1019,6 +1110,41 @@ extern "C" int lp_bn_bwd_apply_seg(const void* dy, const void* y_out, const void
                                    lp_stream_t stream) {
     return bn_bwd_apply_impl(dy, y_out, x, mean, invstd, gamma, sums, count0, count1, M, C, seg_rows, dx, dres, sums_local, dbeta_acc,
                              dgamma_acc, terms_ws, stream);
+}
+
+// lp_bn_bwd_apply_seg that ALSO leaves the two backward reductions of a second BatchNorm fed by the same masked gradient (a block's projection
+// shortcut: zd, mean_d / invstd_d [segments][C]) in sums_d ([segments][2][C], added into: zero them first) - what lp_bn_bwd_reduce(dres, NULL, zd,
+// ...) per segment would compute from one more pass over the gradient.  Needs the terms workspace and C / 8 dividing 256.
+extern "C" size_t lp_bn_bwd_ds_workspace_bytes(int M, int C) {
+    if (M <= 0 || C <= 0 || C % 8 != 0) return 0;
+    return (size_t)2 * lp::bn_grid((size_t)M * (C / 8), C / 8, lp::lp_switches().bn_bwd_wgs_per_cu) * 2 * C * sizeof(float);
+}
+
+extern "C" int lp_bn_bwd_apply_seg_ds(const void* dy, const void* y_out, const void* x, const float* mean, const float* invstd,
+                                      const float* gamma, const lp_fxsum* sums, float count0, float count1, int M, int C, int seg_rows,
+                                      void* dx, void* dres, const lp_fxsum* sums_local, float* dbeta_acc, float* dgamma_acc, float* terms_ws,
+                                      const void* zd, const float* mean_d, const float* invstd_d, lp_fxsum* sums_d, void* workspace,
+                                      size_t workspace_bytes, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(dy && x && mean && invstd && gamma && dx && M > 0 && C > 0 && count0 > 0.f && count1 > 0.f && seg_rows >= 0 && seg_rows < M);
+    LP_REQUIRE(sums_local != nullptr || (dbeta_acc == nullptr && dgamma_acc == nullptr));
+    LP_REQUIRE(terms_ws && zd && mean_d && invstd_d && sums_d && workspace);
+    if (C % 8 != 0 || 256 % (C / 8) != 0) return LP_ERR_UNSUPPORTED;
+    const size_t n_chunks = (size_t)M * (C / 8);
+    const int nseg = seg_rows > 0 ? 2 : 1;
+    const int grid = bn_grid(n_chunks, C / 8, lp_switches().bn_bwd_wgs_per_cu);
+    LP_REQUIRE(workspace_bytes >= (size_t)nseg * grid * 2 * C * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_terms_kernel, dim3((nseg * 2 * C + 255) / 256), dim3(256), 0, st, sums, 1.f / count0, 1.f / count1, C, nseg, terms_ws,
+                       sums_local, dbeta_acc, dgamma_acc);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(grid), dim3(256), 0, st, (const unsigned short*)dy, (const unsigned short*)y_out,
+                       (const unsigned short*)x, mean, invstd, gamma, sums, 1.f / count0, n_chunks, C, (unsigned short*)dx, (unsigned short*)dres,
+                       (size_t)seg_rows * (C / 8), 1.f / count1, sums_local, dbeta_acc, dgamma_acc, (const float*)terms_ws,
+                       BnBwdDs{(const unsigned short*)zd, mean_d, invstd_d, (float*)workspace});
+    for (int sg = 0; sg < nseg; ++sg)
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace + (size_t)sg * grid * 2 * C, grid, C,
+                           sums_d + (size_t)sg * 2 * C);
+    return launch_status();
 }
 
 extern "C" int lp_maxpool_fwd(const void* x, int B, int Hi, int Wi, int C, void* y, void* argmax_u8, lp_stream_t stream) {

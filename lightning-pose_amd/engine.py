@@ -189,6 +189,8 @@ class Engine:
     # MFMA-bound, -8 %, so ViTEngine turns it off)
     wgrad_side_stream = True
     dgrad_mask_bits = True
+    bn_bwd_ds = True
+    bn_apply_rbn = True
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
         self.device = torch.device(device)
@@ -224,6 +226,8 @@ class Engine:
         # lp_bn_bwd_apply in two launches (the correction terms converted by a one-thread-per-value kernel into a small workspace, round 5) or
         # - LP_BN_BWD_TERMS=0, A/B runs - in the self-contained form that converts them per workgroup into LDS
         self.bn_bwd_terms = os.environ.get("LP_BN_BWD_TERMS", "1") != "0"
+        self.bn_apply_rbn = os.environ.get("LP_BN_APPLY_RBN", "1") != "0"   # (0: the projection shortcut normalised by a pass of its own, lp_bn_apply_seg)
+        self.bn_bwd_ds = os.environ.get("LP_BN_BWD_DS", "1") != "0"   # (0: the projection shortcut's BatchNorm reductions as a pass of their own, lp_bn_bwd_reduce)
         self.dgrad_mask_bits = os.environ.get("LP_DGRAD_MASK_BITS", "1") != "0"   # (0: the two data gradients into a layer's first block read the bf16 activation as mask)
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
@@ -525,8 +529,10 @@ class Engine:
         return mean, invstd
 
     def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
-                have_sums: bool = False, want_bits: bool = False, seg: int = 0):
-        """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass"""
+                have_sums: bool = False, want_bits: bool = False, seg: int = 0, residual_bn=None):
+        """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass.
+        ``residual_bn`` = (BNP, mean_d, invstd_d): ``residual`` is the PRE-normalisation tensor of the block's projection shortcut, normalised
+        inside this pass (lp_bn_apply_seg_rbn) instead of by a pass of its own that writes the normalised shortcut and this one reads back."""
         mean, invstd = self._bn_moments(b, z, M, training, sums, have_sums, seg)
         y = torch.empty_like(z)
         bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
@@ -534,8 +540,14 @@ class Engine:
         rpi = M // B
         gam, bet = _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias"))
         # both segments in ONE launch (the kernel walks each segment with that segment's terms in registers)
-        check(self._lib.lp_bn_apply_seg(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), int(relu), M, b.C,
-                                        (seg if training else 0) * rpi, _p(y), _p(bits), ops._stream()), "lp_bn_apply_seg")
+        if residual_bn is not None:
+            bd, md, vd = residual_bn
+            check(self._lib.lp_bn_apply_seg_rbn(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), _p(md), _p(vd), _p(self.param_view(bd, "weight")),
+                                                _p(self.param_view(bd, "bias")), int(relu), M, b.C, (seg if training else 0) * rpi, _p(y), _p(bits),
+                                                ops._stream()), "lp_bn_apply_seg_rbn")
+        else:
+            check(self._lib.lp_bn_apply_seg(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), int(relu), M, b.C,
+                                            (seg if training else 0) * rpi, _p(y), _p(bits), ops._stream()), "lp_bn_apply_seg")
         if want_bits:
             return y, mean, invstd, bits
         return y, mean, invstd
@@ -648,14 +660,18 @@ class Engine:
             check(self._lib.lp_images_to_nhwc4(_p(p_), p_.shape[0], H, W, _p(x4[i0:]), ops._stream()), "lp_images_to_nhwc4")
             i0 += p_.shape[0]
         T["x4"] = x4
-        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu, bits_key=None):
+        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu, bits_key=None, residual_bn=None, apply=True):
             """conv -> BatchNorm(+residual)(+ReLU); in training the statistics come out of the convolution's store pass.
             ``bits_key``: keep the output's 1-bit ReLU mask on the tape (block outputs: their backward reads it instead of the
-            activation itself)"""
+            activation itself).  ``apply=False``: convolution and moments only (the projection shortcut, normalised later inside the
+            block output's pass: ``residual_bn``) -> (z, None, mean, invstd, geometry)"""
             sums = next_sums(b)
             zz, gg = self._conv_fwd(c, xin, B, hh, ww, sums if training else None, seg=seg)
+            if not apply:
+                mm, vv = self._bn_moments(b, zz, B * gg.Ho * gg.Wo, training, sums, training, seg)
+                return zz, None, mm, vv, gg
             res = self._bn_fwd(b, zz, B * gg.Ho * gg.Wo, residual, relu, training, sums, have_sums=training,
-                               want_bits=bits_key is not None and training, seg=seg)
+                               want_bits=bits_key is not None and training, seg=seg, residual_bn=residual_bn)
             if len(res) == 4:
                 T[bits_key] = res[3]
             aa, mm, vv = res[:3]
@@ -685,12 +701,16 @@ class Engine:
             z1, a1, m1, v1, _ = conv_bn(blk.conv1, blk.bn1, x, h, w, None, True)
             z2, a2, m2, v2, g2 = conv_bn(blk.conv2, blk.bn2, a1, h, w, None, True)
             ho, wo = g2.Ho, g2.Wo
+            rbn = None
             if blk.down is not None:
-                zd, idt, md, vd, _ = conv_bn(blk.down, blk.dbn, x, h, w, None, False)
+                # the shortcut's BatchNorm is applied inside the block output's pass (its normalised tensor is never stored)
+                zd, idt, md, vd, _ = conv_bn(blk.down, blk.dbn, x, h, w, None, False, apply=not self.bn_apply_rbn)
                 T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"] = zd, md, vd
+                if self.bn_apply_rbn:
+                    idt, rbn = zd, (blk.dbn, md, vd)
             else:
                 idt = x
-            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits")
+            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits", residual_bn=rbn)
             for nm, val in (("z1", z1), ("a1", a1), ("m1", m1), ("v1", v1), ("z2", z2), ("a2", a2), ("m2", m2), ("v2", v2),
                             ("z3", z3), ("m3", m3), ("v3", v3), ("out", out)):
                 if val is not None:
@@ -771,9 +791,12 @@ class Engine:
         return self._head_forward(x, B, h, w, {})
 
     # ------------------------------------------------------------------------------------------------ backward
-    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None, seg: int = 0):
+    def _bn_bwd(self, b: BNP, dy, y_out, z, mean, invstd, M: int, want_dres: bool, sums: torch.Tensor | None = None, seg: int = 0, ds=None):
         """``sums``: the (segments,2,C) fixed-point reductions [sum dy, sum dy*xhat] when the dgrad that produced ``dy`` already made them.
-        The apply launch also adds THIS rank's sums into d beta / d gamma (they are the parameter gradients)."""
+        The apply launch also adds THIS rank's sums into d beta / d gamma (they are the parameter gradients).
+        ``ds`` = (zd, mean_d, invstd_d) of the block's projection-shortcut BatchNorm, which the same (masked) gradient feeds: the walk then
+        also leaves THAT BatchNorm's two reductions - returned as a third value, or None where the library declines (the caller then runs
+        lp_bn_bwd_reduce as before) - instead of a separate pass over the gradient (lp_bn_bwd_apply_seg_ds)."""
         B = z.shape[0]
         rpi = M // B
         segs = self._segments(B, seg)
@@ -802,10 +825,23 @@ class Engine:
         counts = [float(n * rpi * world) for _, n in segs]
         # sum / count as floats (written by the call's first launch)
         terms = torch.empty(len(segs) * 2 * Cn, device=z.device, dtype=torch.float32) if self.bn_bwd_terms else None
+        if ds is not None:
+            dsums = None
+            if self.bn_bwd_ds and terms is not None and 256 % (Cn // 8) == 0:
+                zd, md, vd = ds
+                dsums = self._zeros_fx(len(segs) * 2 * Cn)
+                need = int(self._lib.lp_bn_bwd_ds_workspace_bytes(M, Cn))
+                if getattr(self, "_ds_ws", None) is None or self._ds_ws.numel() < need:
+                    self._ds_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+                check(self._lib.lp_bn_bwd_apply_seg_ds(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(total), counts[0], counts[-1], M, Cn,
+                                                       seg * rpi, _p(dz), _p(dres), _p(local), _p(self.G[b.b_off:]), _p(self.G[b.g_off:]),
+                                                       _p(terms), _p(zd), _p(md), _p(vd), _p(dsums), _p(self._ds_ws), self._ds_ws.numel(),
+                                                       ops._stream()), "lp_bn_bwd_apply_seg_ds")
+                return dz, dres, dsums
         check(self._lib.lp_bn_bwd_apply_seg(_p(dy), _p(y_out), _p(z), _p(mean), _p(invstd), gam, _p(total), counts[0], counts[-1], M, Cn,
                                             seg * rpi, _p(dz), _p(dres), _p(local), _p(self.G[b.b_off:]), _p(self.G[b.g_off:]), _p(terms),
                                             ops._stream()), "lp_bn_bwd_apply_seg")
-        return dz, dres
+        return (dz, dres, None) if ds is not None else (dz, dres)
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
                   relu_bits=None, seg: int = 0, mask_bits=None):
@@ -897,8 +933,13 @@ class Engine:
             # pre-normalisation tensor, or read from the block output when there is a residual branch) and leaves
             # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head) and the inputs of the stride-2
             # blocks (two partial writers) still run lp_bn_bwd_reduce; the stem has its own fused pair (lp_bn_pool_bwd_*).
+            dbn_sums = None   # the projection shortcut's BatchNorm reductions, taken by bn3's backward walk over the same gradient where it can
             if last:
                 dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True, seg=seg)
+            elif blk.down is not None:
+                dz3, _, dbn_sums = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False, sums=d_sums, seg=seg,
+                                                ds=(T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"]))
+                dres = d
             else:
                 dz3, _ = self._bn_bwd(blk.bn3, d, None, T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, False, sums=d_sums, seg=seg)
                 dres = d
@@ -913,7 +954,7 @@ class Engine:
             mask_x = x if i > 0 else None  # block 0's input is the max-pool output: its ReLU is handled by the stem BN backward
             d_sums = None
             if blk.down is not None:
-                dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False, seg=seg)
+                dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False, sums=dbn_sums, seg=seg)
                 # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
                 # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
                 xbits = T.get(f"b{i - 1}.out_bits") if i > 0 else None   # x = the previous block's output: its 1-bit ReLU mask exists

@@ -28,7 +28,7 @@ ALLOWED_SCRATCH = (
     re.compile(r"lp::decode_bwd_kernel<\d+, \d+, 64, "),
     # the self-contained form of the BatchNorm backward (terms_ws = NULL: no caller in the product since round 5 - the engine passes the
     # workspace and runs bn_bwd_apply_kernel<true>, 86 registers, no scratch)
-    re.compile(r"lp::bn_bwd_apply_kernel<false>"),
+    re.compile(r"lp::bn_bwd_apply_kernel<false, false>"),
     # conv_igemm_kernel<128, data gradient>: not launched by any benchmarked step (kernel traces profiles/r04_final_*kernel_stats*.txt) - the
     # data gradients with more than 64 output channels run on conv_pipe_kernel; it remains the fallback for shapes that kernel declines
     re.compile(r"lp::conv_igemm_kernel<128, 1>"),

@@ -185,6 +185,86 @@ def test_standalone_reductions_repeat_bit_for_bit(kernel_backend):
     assert np.array_equal(ev[3].view(np.uint32), outs[0][3].view(np.uint32))                       # the parameter gradients do not change
 
 
+@pytest.mark.parametrize("Cn,seg", [(256, 0), (256, 3), (2048, 2), (512, 0)])
+def test_bn_backward_apply_also_reduces_for_the_projection_shortcut(kernel_backend, Cn, seg):
+    """lp_bn_bwd_apply_seg_ds == lp_bn_bwd_apply_seg (dx bit for bit, the same parameter gradients) + lp_bn_bwd_reduce of the masked gradient
+    against a second BatchNorm's tensor, per segment (sums equal up to the fp32 order of the partial sums), with and without the ReLU mask"""
+    import ctypes as C
+    gen = torch.Generator().manual_seed(Cn + seg)
+    rows_img, Bn = 40, 5
+    M = Bn * rows_img
+    dy = emu.to_bf16_bits(torch.randn(M, Cn, generator=gen))
+    x = emu.to_bf16_bits(torch.randn(M, Cn, generator=gen))
+    zd = emu.to_bf16_bits(torch.randn(M, Cn, generator=gen) * 1.5 + 0.2)
+    y = emu.to_bf16_bits(torch.randn(M, Cn, generator=gen))                # ~half of it <= 0: the mask
+    nseg = 2 if seg else 1
+    mean, invstd = np.random.default_rng(1).normal(size=(nseg, Cn)).astype(np.float32), (np.random.default_rng(2).random((nseg, Cn)) + 0.5).astype(np.float32)
+    mean_d, invstd_d = np.random.default_rng(3).normal(size=(nseg, Cn)).astype(np.float32), (np.random.default_rng(4).random((nseg, Cn)) + 0.5).astype(np.float32)
+    gamma = (np.random.default_rng(5).random(Cn) + 0.5).astype(np.float32)
+    lib = emu.lib()
+    for masked in (False, True):
+        db, xb, zb, yb = emu.Buf(dy), emu.Buf(x), emu.Buf(zd), (emu.Buf(y) if masked else None)
+        mb, vb, gb, mdb, vdb = (emu.Buf(v) for v in (mean, invstd, gamma, mean_d, invstd_d))
+        sums = emu.Buf(emu.to_fx(np.random.default_rng(6).normal(size=(nseg, 2, Cn)).astype(np.float32) * 3))
+        counts = (float(seg * rows_img), float((Bn - seg) * rows_img)) if seg else (float(M), float(M))
+        outs = []
+        for fused in (False, True):
+            dx, dres = emu.Z((M, Cn), np.uint16), emu.Z((M, Cn), np.uint16)
+            dbeta, dgamma, tws = emu.Z(Cn), emu.Z(Cn), emu.Z(nseg * 2 * Cn)
+            args = (db.p, emu.ptr(yb), xb.p, mb.p, vb.p, gb.p, sums.p, counts[0], counts[1], M, Cn, seg * rows_img, dx.p, dres.p, sums.p, dbeta.p,
+                    dgamma.p, tws.p)
+            sd = emu.ZX((nseg, 2, Cn))
+            if fused:
+                nws = lib.lp_bn_bwd_ds_workspace_bytes(M, Cn)
+                ws = emu.Z(nws, np.uint8)
+                emu.ok(lib.lp_bn_bwd_apply_seg_ds(*args, zb.p, mdb.p, vdb.p, sd.p, ws.p, nws, emu.stream()))
+            else:
+                emu.ok(lib.lp_bn_bwd_apply_seg(*args, emu.stream()))
+                dresb = emu.Buf(dres.np())
+                rws = emu._reduce_ws(M, Cn)
+                for si, (r0, r1) in enumerate([(0, seg * rows_img), (seg * rows_img, M)] if seg else [(0, M)]):
+                    part, zpart, m1, v1 = emu.Buf(dresb.np()[r0:r1]), emu.Buf(zd[r0:r1]), emu.Buf(mean_d[si]), emu.Buf(invstd_d[si])
+                    one = emu.ZX((2, Cn))
+                    emu.ok(lib.lp_bn_bwd_reduce(part.p, None, zpart.p, m1.p, v1.p, r1 - r0, Cn, one.p, rws.p, rws.nbytes, emu.stream()))
+                    outs.append(("ref", si, emu.fx(one.np())))   # (.np() synchronises: the argument buffers above stay alive until here)
+            outs.append(("dx", fused, dx.np(), dres.np(), dbeta.np(), dgamma.np(), emu.fx(sd.np())))
+        ref = {si: v for tag, si, v in [o for o in outs if o[0] == "ref"]}
+        plain, fusd = [o for o in outs if o[0] == "dx"]
+        assert np.array_equal(plain[2], fusd[2]) and np.array_equal(plain[3], fusd[3])
+        assert np.array_equal(plain[4], fusd[4]) and np.array_equal(plain[5], fusd[5])
+        for si in range(nseg):
+            np.testing.assert_allclose(fusd[6][si], ref[si], rtol=2e-5, atol=2e-4)
+        assert np.abs(fusd[6]).max() > 1
+
+
+@pytest.mark.parametrize("Cn,seg", [(256, 0), (64, 2), (2048, 3)])
+def test_bn_apply_normalises_the_projection_shortcut_in_the_same_pass(kernel_backend, Cn, seg):
+    """lp_bn_apply_seg_rbn == lp_bn_apply_seg(zd, no ReLU) -> lp_bn_apply_seg(z, residual = that), bit for bit: output and ReLU bits"""
+    gen = torch.Generator().manual_seed(3 * Cn + seg)
+    rows_img, Bn = 24, 5
+    M = Bn * rows_img
+    z = emu.to_bf16_bits(torch.randn(M, Cn, generator=gen) * 2)
+    zd = emu.to_bf16_bits(torch.randn(M, Cn, generator=gen) * 1.5 + 0.3)
+    nseg = 2 if seg else 1
+    rng = np.random.default_rng(Cn)
+    mean, mean_d = rng.normal(size=(nseg, Cn)).astype(np.float32), rng.normal(size=(nseg, Cn)).astype(np.float32)
+    invstd, invstd_d = (rng.random((nseg, Cn)) + 0.5).astype(np.float32), (rng.random((nseg, Cn)) + 0.5).astype(np.float32)
+    gamma, gamma_d = (rng.random(Cn) + 0.5).astype(np.float32), (rng.random(Cn) + 0.5).astype(np.float32)
+    beta, beta_d = rng.normal(size=Cn).astype(np.float32) * 0.3, rng.normal(size=Cn).astype(np.float32) * 0.3
+    lib = emu.lib()
+    zb, zdb = emu.Buf(z), emu.Buf(zd)
+    mb, vb, gb, bb, mdb, vdb, gdb, bdb = (emu.Buf(v) for v in (mean, invstd, gamma, beta, mean_d, invstd_d, gamma_d, beta_d))
+    for relu in (1, 0):
+        idt, y0, y1 = emu.Z((M, Cn), np.uint16), emu.Z((M, Cn), np.uint16), emu.Z((M, Cn), np.uint16)
+        b0, b1 = emu.Z(M * Cn // 8, np.uint8), emu.Z(M * Cn // 8, np.uint8)
+        emu.ok(lib.lp_bn_apply_seg(zdb.p, mdb.p, vdb.p, gdb.p, bdb.p, None, 0, M, Cn, seg * rows_img, idt.p, None, emu.stream()))
+        emu.ok(lib.lp_bn_apply_seg(zb.p, mb.p, vb.p, gb.p, bb.p, idt.p, relu, M, Cn, seg * rows_img, y0.p, b0.p, emu.stream()))
+        emu.ok(lib.lp_bn_apply_seg_rbn(zb.p, mb.p, vb.p, gb.p, bb.p, zdb.p, mdb.p, vdb.p, gdb.p, bdb.p, relu, M, Cn, seg * rows_img, y1.p, b1.p,
+                                       emu.stream()))
+        assert np.array_equal(y0.np(), y1.np()) and np.array_equal(b0.np(), b1.np())
+        assert y1.np().any()
+
+
 def test_segment_boundary_must_be_tile_aligned(kernel_backend):
     g = emu.geom(4, 6, 6, 64, 64, 1, 1, 1, 0)                    # 36 rows per image: 2 * 36 is not a multiple of 128
     x = emu.to_bf16_bits(torch.randn(4, 6, 6, 64))
