@@ -288,6 +288,10 @@ typedef struct lp_bn_fuse {
      * Then sums is (2 segments, 2, C), mean / invstd are (2, C).  seg_images times the
      * launch's rows per image must be a multiple of 128 (LP_ERR_UNSUPPORTED otherwise: run the segments as two calls).  0 = one segment. */
     int seg_images;
+    /* lp_conv_dgrad_bn only (stride 1, relu_bits given): `addend` is the data gradient of the block's stride-2 projection shortcut on ITS grid,
+     * [B][ceil(Hi / 2)][ceil(Wi / 2)][Ci] bf16, added at the pixels with even row and column only - the projection shortcut then needs no
+     * read-modify-write pass over dx and this launch, the last writer, can take the BatchNorm sums (round 5).  0 = a dense addend. */
+    int addend_half;
 } lp_bn_fuse;
 /* lp_conv_dgrad (bf16 result, no bias) with the ReLU mask read at 1 BIT per element - relu_bits[(row * Ci + c) / 8] bit c % 8, the bytes
  * lp_bn_apply writes beside the activation - instead of from the bf16 activation itself (round 5: the two data gradients into a layer's first

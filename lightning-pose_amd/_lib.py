@@ -34,7 +34,7 @@ class ConvGeom(C.Structure):
 
 class BnFuse(C.Structure):
     _fields_ = [("z", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("mask_from_z", C.c_int), ("relu_bits", C.c_void_p), ("sums", C.c_void_p), ("seg_images", C.c_int)]
+                ("mask_from_z", C.c_int), ("relu_bits", C.c_void_p), ("sums", C.c_void_p), ("seg_images", C.c_int), ("addend_half", C.c_int)]
 
 
 class FrameNorm(C.Structure):

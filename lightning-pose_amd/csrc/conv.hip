@@ -54,6 +54,9 @@ struct ConvEpilogue {
     const float* bn_gamma;         // [N]  } only for mask_from_z: the ReLU mask is recomputed as
     const float* bn_beta;          // [N]  } bf16(gamma * invstd * (z - mean) + beta) > 0 instead of reading the activation
     int mask_from_z;
+    // kEkAZB only (lp_bn_fuse.addend_half): `addend` is a [B][ceil(H / 2)][ceil(W / 2)][ldo] tensor - the data gradient of the block's stride-2
+    // projection shortcut on ITS grid - added at the pixels with even row and column only (a full-lattice launch: host-checked)
+    int addend_half;
     // kModeAttn (lp_attn_dscores): the store pass turns the accumulated dP = dO V^T into the score gradient
     // dS = attn_scale * P * (dP - D[row]) with P read at the output's own offsets and D = rowsum(dO * O) (GemmExt::d_*)
     const unsigned short* attn_p;
@@ -449,7 +452,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
                             ld_[i] = ep.attn_d[zd + (unsigned)(rv[i] ? m0 + r0 + (i0 + i) * RPP : 0) * gx.d_row];
                         }
                     }
-                    if (kReads && ep.addend) {
+                    if (kReads && ep.addend && ep.addend_half) {   // the addend on the half-resolution grid, at the even pixels only (full lattice: host-checked)
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) {
+                            const int mm = rv[i] ? m0 + r0 + (i0 + i) * RPP : 0;
+                            const int bi = fdiv(mm, div_img), rem = mm - bi * div_img.d;
+                            const int yy = fdiv(rem, div_row), xx = rem - yy * div_row.d;
+                            const bool on = rv[i] && !((yy | xx) & 1);
+                            const unsigned oa = (unsigned)((bi * ((full_h + 1) >> 1) + (yy >> 1)) * ((full_w + 1) >> 1) + (xx >> 1)) * (unsigned)ep.ldo + (unsigned)n;
+                            la[i] = on ? load8_stream(ep.addend + oa) : zero8();
+                        }
+                    } else if (kReads && ep.addend) {
 #pragma unroll
                         for (int i = 0; i < HB; ++i) la[i] = load8_stream(ep.addend + off[i]);
                     }
@@ -1556,6 +1569,8 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         ep.bn_beta = bn->beta;
         ep.mask_from_z = bn->mask_from_z;
         ep.relu_bits = (const unsigned char*)bn->relu_bits;
+        ep.addend_half = bn->addend_half;
+        LP_REQUIRE(!ep.addend_half || (addend && bn->relu_bits && g.stride == 1));
     }
     hipStream_t st = (hipStream_t)stream;
     int n_launches = 0;
@@ -1570,6 +1585,10 @@ static int conv_dgrad_impl(const void* dy, const void* wd, const lp_conv_geom* g
         }
         const int kind = pipe_dgrad_kind(ep);
         const bool full_lattice = lat.hstep == 1 && lat.wstep == 1;   // (kEkAZB recomputes its output offsets from the row index)
+        if (ep.addend_half && !full_lattice) {   // (stride 1: required above)
+            seg_ok = false;
+            return;
+        }
         if (kind >= 0 && (kind != kEkAZB || full_lattice) && pipe_eligible(ep, M, N, K, g.Co, seg_rows)) {
             if (N > 64) launch_pipe_dgrad<128>(kind, dy, wd, g, lat, M, N, K, ep, st);
             else launch_pipe_dgrad<64>(kind, dy, wd, g, lat, M, N, K, ep, st);

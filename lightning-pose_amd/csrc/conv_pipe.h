@@ -581,7 +581,16 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
             const unsigned off_p = rv ? (unsigned)(kKeepOff ? out_row(m, lat, div_img, div_row, full_h, full_w) : m) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8) : ~0u;
             if (kKeepOff) rb.off[kKeepOff ? p : 0] = off_p;
             const unsigned o = rv ? off_p : (unsigned)(nbase + pc * 8);   // (rows past M: any valid address, the result is not stored)
-            if (EK == kEkAZB || ((EK == kEkPlain || EK == kEkPB) && ep.addend)) rb.la[kLa ? p : 0] = load8_stream(ep.addend + o);
+            if (EK == kEkAZB && ep.addend_half) {
+                // the shortcut's gradient lives on the half-resolution grid: pixel (b, y, x) of this (full) lattice takes row (b, y / 2, x / 2) of
+                // it if y and x are both even, nothing otherwise
+                const int mm = rv ? m : 0;
+                const int bi = fdiv(mm, div_img), rem = mm - bi * div_img.d;
+                const int yy = fdiv(rem, div_row), xx = rem - yy * div_row.d;
+                const bool on = rv && !((yy | xx) & 1);
+                const unsigned oa = (unsigned)((bi * ((full_h + 1) >> 1) + (yy >> 1)) * ((full_w + 1) >> 1) + (xx >> 1)) * (unsigned)ep.ldo + (unsigned)(nbase + pc * 8);
+                rb.la[kLa ? p : 0] = on ? load8_stream(ep.addend + oa) : zero8();
+            } else if (EK == kEkAZB || ((EK == kEkPlain || EK == kEkPB) && ep.addend)) rb.la[kLa ? p : 0] = load8_stream(ep.addend + o);
             if (bwd) rb.lz[kLz ? p : 0] = load8(ep.bn_z + o);
             if (EK == kEkPlain && ep.relu_mask) rb.lz[kLz ? p : 0] = load8_stream(ep.relu_mask + o);
             if (EK == kEkAZB || EK == kEkPB) rb.lb[kLb ? p : 0] = ep.relu_bits[o >> 3];

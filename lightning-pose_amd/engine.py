@@ -191,6 +191,7 @@ class Engine:
     dgrad_mask_bits = True
     bn_bwd_ds = True
     bn_apply_rbn = True
+    dgrad_half_addend = True
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
         self.device = torch.device(device)
@@ -226,6 +227,7 @@ class Engine:
         # lp_bn_bwd_apply in two launches (the correction terms converted by a one-thread-per-value kernel into a small workspace, round 5) or
         # - LP_BN_BWD_TERMS=0, A/B runs - in the self-contained form that converts them per workgroup into LDS
         self.bn_bwd_terms = os.environ.get("LP_BN_BWD_TERMS", "1") != "0"
+        self.dgrad_half_addend = os.environ.get("LP_DGRAD_HALF_ADDEND", "1") != "0"   # (0: conv1 first, the shortcut accumulates in place, stand-alone reduction)
         self.bn_apply_rbn = os.environ.get("LP_BN_APPLY_RBN", "1") != "0"   # (0: the projection shortcut normalised by a pass of its own, lp_bn_apply_seg)
         self.bn_bwd_ds = os.environ.get("LP_BN_BWD_DS", "1") != "0"   # (0: the projection shortcut's BatchNorm reductions as a pass of their own, lp_bn_bwd_reduce)
         self.dgrad_mask_bits = os.environ.get("LP_DGRAD_MASK_BITS", "1") != "0"   # (0: the two data gradients into a layer's first block read the bf16 activation as mask)
@@ -433,10 +435,11 @@ class Engine:
         return self._red_ws
 
     def _bn_fuse(self, sums: torch.Tensor, b: BNP | None = None, z=None, mean=None, invstd=None, mask_from_z: bool = False,
-                 relu_bits=None, seg: int = 0) -> _lib.BnFuse:
+                 relu_bits=None, seg: int = 0, addend_half: bool = False) -> _lib.BnFuse:
         """lp_bn_fuse for one launch: ``sums`` alone = the forward form ([sum z, sum z^2] of the output); with ``b`` / ``z`` / ``mean`` /
         ``invstd`` the backward form ([sum dz, sum dz * xhat] of the gradient the launch produces)."""
         f = _lib.BnFuse()
+        f.addend_half = int(addend_half)
         f.sums = sums.data_ptr()
         f.seg_images = seg
         if b is not None:
@@ -844,7 +847,7 @@ class Engine:
         return (dz, dres, None) if ds is not None else (dz, dres)
 
     def _conv_bwd(self, c: ConvP, x, dz, B, Hi, Wi, need_dx: bool, addend=None, relu_mask=None, accumulate_into=None, bn=None,
-                  relu_bits=None, seg: int = 0, mask_bits=None):
+                  relu_bits=None, seg: int = 0, mask_bits=None, addend_half: bool = False):
         """wgrad into G, and (optionally) dx = dgrad(dz) + addend, zeroed where relu_mask <= 0 (fused ReLU backward).
         ``accumulate_into``: add the data gradient in place into an existing gradient tensor (which must already be masked);
         for stride-2 layers only the pixels a filter tap reaches are touched.
@@ -867,7 +870,8 @@ class Engine:
             b, z, mean, invstd, sums = bn
             if relu_bits is not None:
                 relu_mask = None  # the 1-bit form replaces the activation tensor as the mask source
-            f = self._bn_fuse(sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None, relu_bits=relu_bits, seg=seg)
+            f = self._bn_fuse(sums, b, z, mean, invstd, mask_from_z=relu_mask is None and relu_bits is None, relu_bits=relu_bits, seg=seg,
+                              addend_half=addend_half)
             run = lambda: check(self._lib.lp_conv_dgrad_bn(_p(dz), _p(self.Wd[c.wd_off:]), C.byref(g), _p(addend), _p(relu_mask), _p(dx),  # noqa: E731
                                                            C.byref(f), st), "lp_conv_dgrad_bn")
         elif mask_bits is not None and self.dgrad_mask_bits:
@@ -881,7 +885,7 @@ class Engine:
         # algorithmic bytes of the launch: the contraction's operands / result plus what its fused store pass reads back (the gradient arriving
         # over the residual branch, the pre-normalisation tensor of the fused BatchNorm backward, the ReLU mask as activation or 1 bit each)
         dx_bytes = 2.0 * B * Hi * Wi * c.Ci
-        extra = (dx_bytes if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
+        extra = ((dx_bytes / 4 if addend_half else dx_bytes) if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
                 (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0) + \
                 (dx_bytes / 16 if (bn is None and relu_mask is None and mask_bits is not None and self.dgrad_mask_bits) else 0.0)
         self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
@@ -931,8 +935,9 @@ class Engine:
             # ReLU backward AND the two reductions of the BatchNorm backward are fused into the dgrad that PRODUCES each
             # gradient: its store pass zeroes the gradient where the activation is <= 0 (mask recomputed from the saved
             # pre-normalisation tensor, or read from the block output when there is a residual branch) and leaves
-            # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head) and the inputs of the stride-2
-            # blocks (two partial writers) still run lp_bn_bwd_reduce; the stem has its own fused pair (lp_bn_pool_bwd_*).
+            # [sum dy, sum dy * xhat] per channel.  Only the trunk output (fed by the head) still runs lp_bn_bwd_reduce (the inputs of
+            # the stride-2 blocks, with their two writers, did until round 5: see the blk.down branch below); the stem has its own fused
+            # pair (lp_bn_pool_bwd_*).
             dbn_sums = None   # the projection shortcut's BatchNorm reductions, taken by bn3's backward walk over the same gradient where it can
             if last:
                 dz3, dres = self._bn_bwd(blk.bn3, d, T[f"{key}.out"], T[f"{key}.z3"], T[f"{key}.m3"], T[f"{key}.v3"], Mo, True, seg=seg)
@@ -955,11 +960,30 @@ class Engine:
             d_sums = None
             if blk.down is not None:
                 dzd, _ = self._bn_bwd(blk.dbn, dres, None, T[f"{key}.zd"], T[f"{key}.md"], T[f"{key}.vd"], Mo, False, sums=dbn_sums, seg=seg)
-                # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
-                # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
                 xbits = T.get(f"b{i - 1}.out_bits") if i > 0 else None   # x = the previous block's output: its 1-bit ReLU mask exists
-                d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x, mask_bits=xbits)
-                self._conv_bwd(blk.down, x, dzd, B, hi, wi, True, relu_mask=mask_x, accumulate_into=d, mask_bits=xbits)
+                if i > 0 and xbits is not None and self.dgrad_half_addend and blk.down.stride == 2 and blk.down.k == 1 and blk.conv1.stride == 1:
+                    # The shortcut's data gradient FIRST, on its own (half-resolution) grid - a plain 1x1 product, no read-modify-write of the
+                    # block input's gradient - then conv1's data gradient adds it at the even pixels as the LAST writer and so can take the
+                    # ReLU mask and the previous block's BatchNorm reductions in its store pass like every identity block's does: the
+                    # stand-alone reduction over the two-writer gradient (lp_bn_bwd_reduce, 2 passes over it) is gone.
+                    prev, pk = plan.blocks[i - 1], f"b{i - 1}"
+                    gd = self._geom(blk.down, B, hi, wi)
+                    self._timed(f"conv_wgrad_kernel<{128 if blk.down.Co > 64 else 64}>", self._flops(blk.down, gd),
+                                lambda: self._wgrad(x, dzd, gd, self.G[blk.down.w_off:]), self._bytes(blk.down, gd, wgrad=True))
+                    gh = _lib.ConvGeom(B, gd.Ho, gd.Wo, blk.down.Ci, gd.Ho, gd.Wo, blk.down.Co, 1, 1, 1, 0)   # the shortcut on its own grid: stride 1
+                    dd = torch.empty(B, gd.Ho, gd.Wo, blk.down.Ci, device=self.device, dtype=torch.bfloat16)
+                    self._timed(f"conv_igemm_kernel<{128 if blk.down.Ci > 64 else 64},dgrad>", self._flops(blk.down, gd),
+                                lambda: check(self._lib.lp_conv_dgrad(_p(dzd), _p(self.Wd[blk.down.wd_off:]), C.byref(gh), None, None, None, _p(dd), None,
+                                                                      blk.down.Ci, 0, 0, ops._stream()), "lp_conv_dgrad"),
+                                2.0 * B * gd.Ho * gd.Wo * (blk.down.Co + blk.down.Ci))
+                    d_sums = new_sums(prev.bn3)
+                    d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dd, addend_half=True,
+                                       bn=(prev.bn3, T[f"{pk}.z3"], T[f"{pk}.m3"], T[f"{pk}.v3"], d_sums), relu_bits=xbits, seg=seg)
+                else:
+                    # main path first, then the projection shortcut accumulates in place (no dense temporary; for the stride-2
+                    # shortcuts only every 4th pixel is touched); (a + b) * mask == (a * mask + b) * mask for a 0/1 mask
+                    d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, relu_mask=mask_x, mask_bits=xbits)
+                    self._conv_bwd(blk.down, x, dzd, B, hi, wi, True, relu_mask=mask_x, accumulate_into=d, mask_bits=xbits)
             elif i > 0:
                 prev, pk = plan.blocks[i - 1], f"b{i - 1}"
                 d_sums = new_sums(prev.bn3)

@@ -341,13 +341,14 @@ def stem_fwd_bn(x4_bits, w_bits, g, seg=0):
 
 
 def conv_dgrad_bn(dy_bits, wd_bits, g, z_bits, mean, invstd, gamma=None, beta=None, addend_bits=None, mask_bits=None, relu_bits=None, seg=0,
-                  rc=False, raw=False):
+                  rc=False, raw=False, addend_half=False):
     """-> (dx bits, sums (2,Ci), dbeta, dgamma); the ReLU mask comes from mask_bits (bf16 activation) or relu_bits (1 bit per
     element) if given, else is recomputed from z.  seg > 0: mean / invstd are (2, Ci), sums comes back (2, 2, Ci).  d beta / d gamma are
     the sums themselves added over the segments (the library adds them into the gradient buffer in lp_bn_bwd_apply: bn_backward)."""
     db, wb, ab, mb = Buf(dy_bits), Buf(wd_bits), B(addend_bits), B(mask_bits)
     ob = Z((g.B * g.Hi * g.Wi, g.Ci), np.uint16)
     f = _bn_fuse(g.Ci, z_bits, mean, invstd, gamma, beta, mask_from_z=mask_bits is None and relu_bits is None, relu_bits=relu_bits, seg=seg)
+    f.addend_half = int(addend_half)   # (the addend on the half-resolution grid, added at the even pixels: lp_bn_fuse.addend_half)
     code = lib().lp_conv_dgrad_bn(db.p, wb.p, C.byref(g), ptr(ab), ptr(mb), ob.p, C.byref(f), stream())
     if rc:
         return code

@@ -79,6 +79,46 @@ def test_pipe_equals_igemm(case, wgs, monkeypatch):
             np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,seg", [(2, 16, 16, 128, 64, 0), (3, 16, 16, 256, 128, 1), (1, 15, 17, 128, 64, 0)])
+def test_dgrad_takes_the_shortcut_gradient_from_its_own_grid(B, H, W, Ci, Co, seg, monkeypatch):
+    """lp_bn_fuse.addend_half: the addend of a 1x1 data gradient with fused BatchNorm sums (store-pass kind kEkAZB) is a tensor on the
+    half-resolution grid - the gradient of the block's stride-2 projection shortcut - added at the even pixels only.  Equal (as numbers) to the
+    same launch with that tensor scattered into a dense addend of zeros, sums included; odd sizes (the shortcut's grid is ceil(H / 2) x
+    ceil(W / 2)); two BatchNorm segments; both kernels."""
+    gen = torch.Generator().manual_seed(B + H + Ci)
+    g = emu.geom(B, H, W, Ci, Co, 1, 1, 1, 0)
+    M = B * H * W
+    Hh, Wh = (H + 1) // 2, (W + 1) // 2
+    dy = emu.to_bf16_bits(torch.randn(M, Co, generator=gen))
+    wd = emu.to_bf16_bits((torch.randn(Co, 1, 1, Ci, generator=gen) / Co ** 0.5).permute(3, 1, 2, 0))
+    half = emu.from_bf16_bits(emu.to_bf16_bits(torch.randn(B, Hh, Wh, Ci, generator=gen))).reshape(B, Hh, Wh, Ci)
+    dense = torch.zeros(B, H, W, Ci)
+    dense[:, ::2, ::2] = half
+    zin = emu.to_bf16_bits(torch.randn(M, Ci, generator=gen))
+    gamma, beta = torch.rand(Ci, generator=gen) + 0.5, torch.randn(Ci, generator=gen) * 0.3
+    if seg:
+        if (seg * H * W) % 256:
+            pytest.skip("segment boundary off the tile grid")
+        mean, invstd = np.random.default_rng(1).normal(size=(2, Ci)).astype(np.float32), (np.random.default_rng(2).random((2, Ci)) + 0.5).astype(np.float32)
+        _, _, _, relu_bits = emu.bn_forward(zin, M, Ci, gamma.numpy(), beta.numpy(), relu=True, want_bits=True)
+    else:
+        _, mean, invstd, relu_bits = emu.bn_forward(zin, M, Ci, gamma.numpy(), beta.numpy(), relu=True, want_bits=True)
+    monkeypatch.setenv("LP_CONV_PIPE", "1")
+    ref = emu.conv_dgrad_bn(dy, wd, g, zin, mean, invstd, addend_bits=emu.to_bf16_bits(dense.reshape(M, Ci)), relu_bits=relu_bits, seg=seg)
+    got = emu.conv_dgrad_bn(dy, wd, g, zin, mean, invstd, addend_bits=emu.to_bf16_bits(half.reshape(-1, Ci)), relu_bits=relu_bits, seg=seg,
+                            addend_half=True)
+    assert emu.lib().lp_conv_last_kernel() == 1
+    assert torch.equal(emu.from_bf16_bits(got[0]), emu.from_bf16_bits(ref[0]))
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-6, atol=1e-6)
+    assert emu.from_bf16_bits(got[0]).abs().max() > 0
+    monkeypatch.setenv("LP_CONV_PIPE", "0")   # the register-staged kernel (what shapes conv_pipe_kernel declines run on)
+    old = emu.conv_dgrad_bn(dy, wd, g, zin, mean, invstd, addend_bits=emu.to_bf16_bits(half.reshape(-1, Ci)), relu_bits=relu_bits, seg=seg,
+                            addend_half=True)
+    assert emu.lib().lp_conv_last_kernel() == 0
+    assert torch.equal(emu.from_bf16_bits(old[0]), emu.from_bf16_bits(ref[0]))
+    np.testing.assert_allclose(old[1], ref[1], rtol=1e-4, atol=1e-3)
+
+
 def test_dgrad_bits_refuses_what_it_cannot_do():
     """lp_conv_dgrad_bits: a null mask is an argument error (lp_conv_dgrad is the call without a mask); the bits are indexed per 8 output
     channels, so a channel count that is not a multiple of 8 is refused before anything is enqueued"""
