@@ -182,7 +182,7 @@ def pmc_traffic():
     import hashlib
     h = hashlib.sha256()
     try:
-        for name in ("conv.hip", "conv_pipe.h", "conv_res2d.h", "conv_spec.h", "conv_stem_wgrad.h", "lp_common.h"):   # (profiles/summarize_pmc.py: KERNEL_SOURCES)
+        for name in ("conv.hip", "conv_pipe.h", "conv_res2d.h", "conv_stem_wgrad.h", "lp_common.h"):   # (profiles/summarize_pmc.py: KERNEL_SOURCES)
             with open(os.path.join(ROOT, "lightning-pose_amd", "csrc", name), "rb") as fh:
                 h.update(fh.read())
     except OSError:

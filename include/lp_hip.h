@@ -14,7 +14,7 @@
  *     calls only enqueue - no device synchronisation, no host read-back
  *   - return value: 0 = LP_OK, < 0 = argument / shape error (nothing was launched), > 0 = hipError_t
  *   - re-entrant and thread-safe: no entry point keeps state between calls or reads the environment.  The only process-wide data is
- *     the table of A/B switches (LP_CONV_PIPE, LP_CONV_HALO, LP_CONV_RES2D, LP_CONV_SPEC, LP_INFER_PIPE, LP_GEMM_PIPE, LP_WGRAD_PIPE,
+ *     the table of A/B switches (LP_CONV_PIPE, LP_CONV_HALO, LP_CONV_RES2D, LP_INFER_PIPE, LP_GEMM_PIPE, LP_WGRAD_PIPE,
  *     LP_STEM_2D, LP_STEM_WGRAD_NB, LP_POOL_V2, LP_CONV_MAX_WGS, LP_BN_BWD_WGS_PER_CU), read from the environment ONCE when the library is loaded and immutable afterwards -
  *     except through lp_config_reload_env(), a test / A-B hook that must not run concurrently with other calls
  *   - limits: lp_bn_bwd_apply WITHOUT its terms_ws workspace covers C <= 2048 channels (the per-launch correction table then lives in
@@ -46,6 +46,11 @@ enum {
 
 enum { LP_TF_NONE = 0, LP_TF_SINGLE = 1, LP_TF_PER_FRAME = 2, LP_TF_PER_VIEW = 3 };
 
+/* ABI version of THIS header: bumped whenever the signature of an existing entry point changes (an argument inserted, a struct field added),
+ * not only when symbols come or go.  lp_version() returns the value the library was built with; a caller compares the two before its first
+ * call (lightning_pose_amd/_lib.py raises LpHipUnavailable on a mismatch) - a library built against an older header would otherwise take,
+ * e.g., the stream argument for an inserted flag without any error.  History: 131 = round 5 (decode `prune`, bn_bwd `terms_ws`), 140 = round 6. */
+#define LP_HIP_ABI_VERSION 140
 int lp_version(void);
 const char* lp_strerror(int code);
 
@@ -196,8 +201,7 @@ typedef struct lp_conv_geom {
 #define LP_CONV_KERNEL_WGRAD 2
 #define LP_CONV_KERNEL_WGRAD_PIPE 3
 #define LP_CONV_KERNEL_PIPE_HALO 4 /* conv_pipe_kernel<..., HALO>: 3x3 / stride 1, the input neighbourhood staged once (LP_CONV_HALO=0 disables) */
-#define LP_CONV_KERNEL_SPEC 6      /* conv_spec_kernel: the operand ring with producer / consumer wave roles and the store pass handed to the producers (LP_CONV_SPEC=0 disables) */
-#define LP_CONV_KERNEL_SPEC_HALO 7 /* ... its HALO form */
+/* (6, 7: round 5's producer / consumer kernel conv_spec_kernel - measured not faster, retired in round 6: profiles/retired/r05_conv_spec.h.txt) */
 #define LP_CONV_KERNEL_STEM_WGRAD_NB 8 /* stem_wgrad_nb_kernel: the stem's weight gradient from a staged input neighbourhood (LP_STEM_WGRAD_NB=0 disables) */
 #define LP_CONV_KERNEL_RES2D 5     /* conv_res2d_kernel: 3x3 / stride 1, 64 -> 64 channels, 16 x 16 tiles, filter resident in LDS (LP_CONV_RES2D=0 disables) */
 int lp_conv_last_kernel(void);

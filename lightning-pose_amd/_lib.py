@@ -52,9 +52,11 @@ class GemmBatch(C.Structure):
 
 HM_MSE, HM_KL, HM_JS = 0, 1, 2
 CONV_KERNEL_IGEMM, CONV_KERNEL_PIPE, CONV_KERNEL_WGRAD, CONV_KERNEL_WGRAD_PIPE, CONV_KERNEL_PIPE_HALO, CONV_KERNEL_RES2D = 0, 1, 2, 3, 4, 5   # lp_conv_last_kernel()
-CONV_KERNEL_SPEC, CONV_KERNEL_SPEC_HALO, CONV_KERNEL_STEM_WGRAD_NB = 6, 7, 8
+CONV_KERNEL_STEM_WGRAD_NB = 8
 BORDER_RENORM, BORDER_CLAMP = 0, 1
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
+
+ABI_VERSION = 140   # include/lp_hip.h: LP_HIP_ABI_VERSION - the header these PROTOTYPES were written against (tests/test_abi_and_failloud.py)
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
@@ -181,6 +183,10 @@ def declare(lib: C.CDLL) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    have = int(lib.lp_version())
+    if have != ABI_VERSION:   # same symbols, other signatures: a stale build would take e.g. the stream for an inserted argument
+        raise LpHipUnavailable(f"{getattr(lib, '_name', 'liblp_hip.so')} was built for ABI {have}, this package binds ABI {ABI_VERSION} "
+                               "(include/lp_hip.h: LP_HIP_ABI_VERSION) - rebuild it: python -c 'import __graft_entry__ as g; g.build()'")
     return lib
 
 

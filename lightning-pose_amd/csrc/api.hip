@@ -3,7 +3,9 @@
 
 #include <stdlib.h>
 
-extern "C" int lp_version(void) { return 131; }  // 0.3.0: decode `prune` is a call argument, the LP_* switches are read once at load (lp_config_reload_env)
+#include <atomic>
+
+extern "C" int lp_version(void) { return LP_HIP_ABI_VERSION; }   // (include/lp_hip.h: checked by every binding before its first call)
 
 namespace lp {
 static int env_int(const char* name, int dflt) {
@@ -15,7 +17,6 @@ static LpSwitches read_switches() {
     s.conv_pipe = env_int("LP_CONV_PIPE", 1);       // 0: every convolution on conv_igemm_kernel / conv_wgrad_kernel
     s.conv_halo = env_int("LP_CONV_HALO", 1);       // 0: the 3x3 layers on the per-tap ring
     s.conv_res2d = env_int("LP_CONV_RES2D", 1);     // 0: layer1's 64 -> 64 3x3 layers on the HALO form
-    s.conv_spec = env_int("LP_CONV_SPEC", 0);       // 1: the forward convolutions on the producer / consumer wave-specialised kernel where it applies (conv_spec.h)
     s.infer_pipe = env_int("LP_INFER_PIPE", 1);     // 0: lp_conv_fwd_act on conv_igemm_kernel<infer>
     s.gemm_pipe = env_int("LP_GEMM_PIPE", 1);       // 0: the Linear layers on conv_igemm_kernel
     s.wgrad_pipe = env_int("LP_WGRAD_PIPE", 1);     // 0: weight gradients on conv_wgrad_kernel; 2: the pipelined kernel wherever it can run
@@ -27,12 +28,15 @@ static LpSwitches read_switches() {
     s.conv_max_wgs = env_int("LP_CONV_MAX_WGS", 0); // > 0: cap of the persistent grids (tests: several tiles per workgroup on small problems)
     return s;
 }
-static LpSwitches g_switches = read_switches();     // (dynamic initialisation at library load)
-const LpSwitches& lp_switches() { return g_switches; }
+// The table is published through an atomic pointer: a call that reads it sees ONE consistent table, and lp_config_reload_env() swaps in a new
+// one (the old tables stay alive - a few dozen bytes per reload - so a reader that already holds one never sees it change or freed).  An entry
+// point may read the pointer more than once (workspace query + launch), so a reload must still not run concurrently with other calls (lp_hip.h).
+static std::atomic<const LpSwitches*> g_switches{new LpSwitches(read_switches())};     // (dynamic initialisation at library load)
+const LpSwitches& lp_switches() { return *g_switches.load(std::memory_order_acquire); }
 }  // namespace lp
 
 extern "C" int lp_config_reload_env(void) {
-    lp::g_switches = lp::read_switches();
+    lp::g_switches.store(new lp::LpSwitches(lp::read_switches()), std::memory_order_release);
     return LP_OK;
 }
 

@@ -170,7 +170,7 @@ __global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, 
         const SumT* sm = sums + (size_t)sg * 2 * C;
         const float mu = sum_value(&sm[c]) / count;
         float var = sum_value(&sm[C + c]) / count - mu * mu;
-        var = fmaxf(var, 0.f);
+        var = var < 0.f ? 0.f : var;   // (not fmaxf: a NaN - a poisoned sum - must reach invstd and the running variance too)
         mean[sg * C + c] = mu;
         invstd[sg * C + c] = 1.f / sqrtf(var + eps);
         if (running_mean != nullptr) {

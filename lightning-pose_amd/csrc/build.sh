@@ -15,7 +15,7 @@ if [ "$mode" = emu ]; then
   for s in "${SRCS[@]}"; do
     [ -f "$s" ] || continue
     o="$out/obj/${s%.hip}.o"
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || { [ "$s" = conv.hip ] && { [ conv_pipe.h -nt "$o" ] || [ conv_res2d.h -nt "$o" ] || [ conv_spec.h -nt "$o" ] || [ conv_stem_wgrad.h -nt "$o" ]; }; } || [ ../../include/lp_hip.h -nt "$o" ] || [ "$out/hip/hip_runtime.h" -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || { [ "$s" = conv.hip ] && { [ conv_pipe.h -nt "$o" ] || [ conv_res2d.h -nt "$o" ] || [ conv_stem_wgrad.h -nt "$o" ]; }; } || [ ../../include/lp_hip.h -nt "$o" ] || [ "$out/hip/hip_runtime.h" -nt "$o" ]; then
       "$ROCM/lib/llvm/bin/clang++" -x c++ -std=c++17 -O2 -fPIC -Wno-psabi -Wno-unused-value -I"$out" -c "$s" -o "$o" &
     fi
     objs+=("$o")
@@ -33,7 +33,7 @@ else
   for s in "${SRCS[@]}"; do
     [ -f "$s" ] || continue
     o="$od/${s%.hip}.o"
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || { [ "$s" = conv.hip ] && { [ conv_pipe.h -nt "$o" ] || [ conv_res2d.h -nt "$o" ] || [ conv_spec.h -nt "$o" ] || [ conv_stem_wgrad.h -nt "$o" ]; }; } || [ ../../include/lp_hip.h -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ lp_common.h -nt "$o" ] || { [ "$s" = conv.hip ] && { [ conv_pipe.h -nt "$o" ] || [ conv_res2d.h -nt "$o" ] || [ conv_stem_wgrad.h -nt "$o" ]; }; } || [ ../../include/lp_hip.h -nt "$o" ]; then
       "$ROCM/bin/hipcc" --offload-arch=gfx950 -O3 -std=c++17 -fPIC ${LP_BUILD_FLAGS:-} -c "$s" -o "$o" &
     fi
     objs+=("$o")

@@ -646,7 +646,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const unsigned short
 
 #include "conv_pipe.h"
 #include "conv_res2d.h"
-#include "conv_spec.h"
 
 namespace lp {
 
@@ -1218,29 +1217,6 @@ static int launch_pipe(const void* x, const void* w, const ConvGeom& g, const La
     return grid;
 }
 
-// conv_spec_kernel (conv_spec.h): producer / consumer wave roles on the same ring, the store pass handed to the producers.  Forward only,
-// 256 x 128 tiles, no bias, at least 4 K steps per tile (the handed-over store pass is spread over a tile's first 4 K steps).  LP_CONV_SPEC=1
-// selects it (default 0: measured correct and not faster than conv_pipe_kernel, profiles/r05_conv_spec_ab.txt).
-static bool spec_ok(const ConvEpilogue& ep, const Lattice& lat, const ConvGeom& g, int N, int K) {
-    const bool full = lat.h0 == 0 && lat.hstep == 1 && lat.w0 == 0 && lat.wstep == 1 && lat.r0 == 0 && lat.rstep == 1 && lat.nr == g.R &&
-                      lat.s0 == 0 && lat.sstep == 1 && lat.ns == g.S;
-    return lp_switches().conv_spec != 0 && full && N % 128 == 0 && ep.bias == nullptr && K / kBK >= 4;
-}
-
-template <bool HALO>
-static int launch_spec(const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K, const ConvEpilogue& ep,
-                        hipStream_t st) {
-    const int tm = (M + kPM - 1) / kPM, tn = N / 128, ntiles = tm * tn;
-    const int grid = ntiles < pipe_max_wgs() ? ntiles : pipe_max_wgs();
-    const unsigned x_bytes = (unsigned)(2ull * (size_t)g.B * g.Hi * g.Wi * g.Ci);
-    const unsigned w_bytes = (unsigned)(2ull * (size_t)N * g.R * g.S * g.Ci);
-    g_last_conv_kernel = HALO ? LP_CONV_KERNEL_SPEC_HALO : LP_CONV_KERNEL_SPEC;
-    const HaloDivs hd{make_fastdiv(g.Hi), make_fastdiv(g.Wi + 2), make_fastdiv(g.Hi + 2)};
-    hipLaunchKernelGGL((conv_spec_kernel<HALO>), dim3(grid), dim3(512), 0, st, (const unsigned short*)x, (const unsigned short*)w, x_bytes, w_bytes, g,
-                       make_fastdiv(lat.nh * lat.nw), make_fastdiv(lat.nw), M, N, K, tn, ntiles, ep, hd);
-    return grid;
-}
-
 template <int BN>
 static int launch_pipe_dgrad(int kind, const void* x, const void* w, const ConvGeom& g, const Lattice& lat, int M, int N, int K,
                              const ConvEpilogue& ep, hipStream_t st) {
@@ -1397,10 +1373,7 @@ static int conv_fwd_impl(const void* x, const void* w, const lp_conv_geom* geom,
     if (pipe_eligible(ep, M, N, K, g.Ci, split, true)) {
         if (N > 64) {
             const bool halo = pipe_halo_ok(g, M, g.Ci, 384);
-            if (spec_ok(ep, lat, g, N, K)) {
-                if (halo) launch_spec<true>(x, w, g, lat, M, N, K, ep, st);
-                else launch_spec<false>(x, w, g, lat, M, N, K, ep, st);
-            } else if (halo) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
+            if (halo) launch_pipe<128, kModeFwd, kEkNone, true>(x, w, g, lat, M, N, K, ep, st);
             else launch_pipe<128, kModeFwd, kEkNone>(x, w, g, lat, M, N, K, ep, st);
         } else if (ep.bias == nullptr && res2d_ok(g, g.Ci, N, ep)) {
             launch_res2d<kModeFwd>(x, w, g, ep, st);
@@ -1644,7 +1617,7 @@ extern "C" int lp_conv_dgrad_bn(const void* dy, const void* wd, const lp_conv_ge
 // stem_wgrad_nb_kernel (conv_stem_wgrad.h): a K step is 64 consecutive pixels of one output row, byte offsets are 32-bit
 static bool stem_wgrad_nb_ok(const lp::ConvGeom& g) {
     return lp::lp_switches().stem_wgrad_nb != 0 && g.Wo % 64 == 0 && g.Hi == 2 * g.Ho && g.Wi == 2 * g.Wo &&
-           128ull * g.B * g.Ho * g.Wo < (1ull << 32) && 8ull * g.B * g.Hi * g.Wi < (1ull << 32);
+           128ull * g.B * g.Ho * g.Wo < (1ull << 31) && 8ull * g.B * g.Hi * g.Wi < (1ull << 31);   // (the kernel forms these byte offsets in signed int)
 }
 // one workgroup (all 256 gradient rows) per pixel slice, ~4 resident per CU (40 KB of LDS each); the workspace holds two 128-row j-tiles per slice
 static lp::WgradPlan plan_stem_wgrad_nb(int M, int split_hint) {

@@ -204,12 +204,14 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 // no workspace, no extra launch.  (The first form of round 4 - one row of partial sums per workgroup + an ordered reduction launch - was
 // bit-reproducible too and 1.4 % slower per step: ~110 more small launches on the critical path, profiles/r04i_bench_*.)
 // A NON-FINITE partial (a diverged run) must not turn into finite garbage - fmin / fmax drop a NaN, and the old fp32 atomics propagated it:
-// it POISONS the sum instead: `lo` is raised to 2^62 with an atomic max (idempotent, so any number of poisoned partials of this process
-// leaves it there; the finite partials that still arrive move it by < 2^59), and fx_value reads |lo| >= 2^61 as NaN - BatchNorm's moments,
-// running statistics and gradients then carry the NaN on, as the reference's do.  (Across ranks the words are SUMMED by SyncBatchNorm's
-// all-reduce: one to three poisoned ranks stay visible, four or eight identical poisons wrap around - the loss of every rank is NaN long
-// before that matters, since each rank's own forward sums are read back through this rank's activations.)
-constexpr long long kFxPoison = 1LL << 62;
+// it POISONS the sum instead: `lo` is raised to kFxPoison = 5 * 2^60 with an atomic max (idempotent, so any number of poisoned partials of
+// this process leaves it there; the finite partials that still arrive move it by < 2^59), and fx_value reads |lo| >= 2^59 as NaN -
+// BatchNorm's moments, running statistics and gradients then carry the NaN on, as the reference's do.  Across ranks SyncBatchNorm SUMS the
+// words (all-reduce, or all-gather + add), modulo 2^64: k poisoned ranks leave k * 5 * 2^60 = (5 k mod 16) * 2^60, and 5 k is not a multiple
+// of 16 for k = 1 .. 15, so the summed word still lies outside (-2^59, 2^59) for every world size up to 15 ranks - one node has 8 - whatever
+// the number of ranks that diverged (round 5's 2^62 wrapped to 0 at exactly 4 and 8 poisoned ranks: tests/test_segmented_bn.py).
+constexpr long long kFxPoison = 5LL << 60;
+constexpr long long kFxPoisonSeen = 1LL << 59;
 __device__ __forceinline__ void fx_add(lp_fxsum* p, float t) {
     double td = (double)t;
     if (!(fabs(td) <= 0x1p127 * 2.0)) {   // NaN or +-inf
@@ -225,7 +227,7 @@ __device__ __forceinline__ void fx_add(lp_fxsum* p, float t) {
 }
 __device__ __forceinline__ float fx_value(const lp_fxsum* p) {
     const long long lo = p->lo;
-    if (lo >= (kFxPoison >> 1) || lo <= -(kFxPoison >> 1)) return __int_as_float(0x7fc00000);   // poisoned by a non-finite partial
+    if (lo >= kFxPoisonSeen || lo <= -kFxPoisonSeen) return __int_as_float(0x7fc00000);   // poisoned by a non-finite partial
     return (float)((double)p->hi * 0x1p-12 + (double)lo * 0x1p-60);
 }
 
@@ -235,7 +237,7 @@ __device__ __forceinline__ float fx_value(const lp_fxsum* p) {
 // getenv and the behaviour of a call does not depend on what the caller's environment holds at that moment.  lp_config_reload_env()
 // re-reads it (tests and A/B scripts that flip a switch inside one process).
 struct LpSwitches {
-    int conv_pipe, conv_halo, conv_res2d, conv_spec, infer_pipe, gemm_pipe, wgrad_pipe, stem_2d, stem_wgrad_nb, pool_v2, conv_max_wgs, bn_bwd_wgs_per_cu;
+    int conv_pipe, conv_halo, conv_res2d, infer_pipe, gemm_pipe, wgrad_pipe, stem_2d, stem_wgrad_nb, pool_v2, conv_max_wgs, bn_bwd_wgs_per_cu;
 };
 const LpSwitches& lp_switches();
 

@@ -13,7 +13,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("conv.hip", "conv_pipe.h", "conv_res2d.h", "conv_spec.h", "conv_stem_wgrad.h", "lp_common.h")   # what the measured kernels are compiled from (bench.py checks the same digest)
+KERNEL_SOURCES = ("conv.hip", "conv_pipe.h", "conv_res2d.h", "conv_stem_wgrad.h", "lp_common.h")   # what the measured kernels are compiled from (bench.py checks the same digest)
 
 
 def kernels_sha256():

@@ -457,6 +457,14 @@ def bn_stats(x_bits, M, Cn, raw=False):
     return sums.np() if raw else fx(sums.np())
 
 
+def bn_finalize_words(words: np.ndarray, count: float, eps=1e-5):
+    """lp_bn_finalize on given lp_fxsum words (2, Cn, 2) -> (mean, invstd): what a rank computes from a SyncBatchNorm message after the exchange"""
+    Cn = words.shape[1]
+    sums, mean, invstd = Buf(np.ascontiguousarray(words, np.int64)), Z(Cn), Z(Cn)
+    ok(lib().lp_bn_finalize(sums.p, float(count), Cn, eps, 0.1, mean.p, invstd.p, None, None, stream()))
+    return mean.np(), invstd.np()
+
+
 def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False):
     xb, rb = Buf(x_bits), B(residual_bits)
     sums, mean, invstd = ZX((2, Cn)), Z(Cn), Z(Cn)

@@ -70,6 +70,22 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
         _lib.lib()
 
 
+def test_abi_version_is_checked_not_only_the_symbol_names(monkeypatch):
+    """round 5 inserted arguments into existing entry points (decode `prune`, bn_bwd `terms_ws`) and nothing compared lp_version()
+    with what the binding expects - a stale library with all the symbols would have taken the stream for the new argument.  The header
+    carries LP_HIP_ABI_VERSION, lp_version() returns the value the library was built with, and `declare` refuses any other."""
+    from lightning_pose_amd import _lib
+    from tests.hipemu import emu
+
+    macro = int(re.search(r"#define\s+LP_HIP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert macro == _lib.ABI_VERSION
+    lib = emu.emu_lib()   # (the CPU build of the same sources: loadable here)
+    assert lib.lp_version() == macro
+    monkeypatch.setattr(_lib, "ABI_VERSION", macro + 1)
+    with pytest.raises(_lib.LpHipUnavailable, match="ABI"):
+        _lib.declare(lib)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "lightning-pose_amd")
     for dirpath, _, files in os.walk(pkg):

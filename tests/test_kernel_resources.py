@@ -29,5 +29,5 @@ def test_no_hot_kernel_uses_scratch():
     assert not bad, [(k["name"], k["scratch"], k["vgpr_spill"]) for k in bad]
     # one workgroup of 512 threads per CU: the pipelined convolutions may use the whole register file, not more
     for k in hot:
-        if k["name"].startswith(("lp::conv_pipe_kernel", "lp::conv_spec_kernel", "lp::conv_wgrad_pipe_kernel")):
+        if k["name"].startswith(("lp::conv_pipe_kernel", "lp::conv_wgrad_pipe_kernel")):
             assert k["vgpr"] + k["agpr"] <= 256 and k["lds"] <= 160 * 1024, k

@@ -156,6 +156,34 @@ def test_non_finite_partials_poison_the_fixed_point_sum(kernel_backend):
     assert (np.abs(words[..., 1].astype(np.float64)) >= 2.0 ** 61).all()   # the `lo` words carry the poison
 
 
+@pytest.mark.parametrize("world", [2, 4, 8, 15])
+def test_poison_survives_the_sum_over_ranks(kernel_backend, world):
+    """SyncBatchNorm ADDS the ranks' words modulo 2^64 (engine._sync_stats: all-reduce, or all-gather + torch.sum).  Round 5's
+    poison 2^62 wrapped to 0 at exactly 4 and 8 poisoned ranks - the moments read finite garbage.  With 5 * 2^60 the sum of any number of
+    poisoned ranks (1 .. world <= 15), next to the other ranks' finite words, still reads NaN in the poisoned channel and only there."""
+    M, Cn = 512, 16
+    gen = torch.Generator().manual_seed(40 + world)
+    clean = [torch.randn(M, Cn, generator=gen) for _ in range(world)]
+    finite = [emu.bn_stats(emu.to_bf16_bits(x), M, Cn, raw=True) for x in clean]
+    bad_x = []
+    for x in clean:
+        y = x.clone()
+        y[3, 5] = float("nan")
+        bad_x.append(y)
+    poisoned = [emu.bn_stats(emu.to_bf16_bits(x), M, Cn, raw=True) for x in bad_x]
+    want = np.mean([emu.from_bf16_bits(emu.to_bf16_bits(x)).double().mean(0).numpy() for x in clean], axis=0)
+    for k in range(1, world + 1):   # k ranks diverged, world - k did not
+        msg = np.zeros_like(finite[0])
+        with np.errstate(over="ignore"):
+            for r in range(world):
+                msg = msg + (poisoned[r] if r < k else finite[r])   # int64: wraps like the collective's SUM
+        mean, invstd = emu.bn_finalize_words(msg, M * world)
+        assert np.isnan(mean[5]) and np.isnan(invstd[5]), (world, k, msg[:, 5])
+        ok_ch = np.arange(Cn) != 5
+        assert np.isfinite(mean[ok_ch]).all() and np.isfinite(invstd[ok_ch]).all()
+        np.testing.assert_allclose(mean[ok_ch], want[ok_ch], atol=1e-6)
+
+
 def test_standalone_reductions_repeat_bit_for_bit(kernel_backend):
     """lp_bn_stats / lp_bn_bwd_reduce (fixed-point sums): same bits twice; lp_bn_bwd_apply adds the sums into d beta / d gamma on top of
     what is already there; sums = NULL (eval-mode BatchNorm) drops the batch-statistics terms: dx = dy * gamma * invstd"""
