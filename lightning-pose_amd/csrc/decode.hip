@@ -216,6 +216,8 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
 
+    const auto row_base = as_uniform(tb.row_base);   // (wave-uniform indices: scalar loads, lp_common.h: as_uniform)
+    const auto row_taps = as_uniform(tb.row_taps);
     const float* src = heat + (size_t)bk * h * w;
     for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
     __syncthreads();
@@ -237,11 +239,11 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
 #pragma unroll
             for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
             const float* hcol = hs + tb.col_start[c];
-            const int b0 = tb.row_base[jstar];
+            const int b0 = row_base[jstar];
             float wv[TY];
 #pragma unroll
             for (int t = 0; t < TY; ++t) wv[t] = z_value<FULLTX>(hcol, b0 + t, w, tx, tb.TX);
-            const float* taps = tb.row_taps + (size_t)jstar * R * TY;
+            const auto taps = row_taps + (size_t)jstar * R * TY;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 float y = 0.f;
@@ -283,10 +285,10 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
         }
         if (!wave_live) continue;  // (wave-uniform: every lane of the wave has the same colb)
         float win[TY];
-        int base = tb.row_base[0];
+        int base = row_base[0];
         bool have = false;         // is `win` the window of `base`?
         for (int j = 0; j < h; ++j) {
-            const int nb = tb.row_base[j];
+            const int nb = row_base[j];
             if (prune && ly * lx * ps.rwin[j] < cut) {  // the whole row group is below the cut for every column of the wave
                 have = false;
                 continue;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
                 win[TY - 1] = z_value<FULLTX>(hcol, nb + TY - 1, w, tx, tb.TX);
                 base = nb;
             }
-            const float* taps = tb.row_taps + (size_t)j * R * TY;
+            const auto taps = row_taps + (size_t)j * R * TY;
             float z[R];
             float gm = m;
 #pragma unroll
@@ -425,6 +427,10 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
     const int seg = (h + nwaves - 1) / nwaves;  // row groups per wave (host keeps it >= TY)
     const int j0 = wave * seg, j1 = min(h, j0 + seg);
 
+    // the row tables are indexed by the (wave-uniform) row-group counter: scalar loads (lp_common.h: as_uniform)
+    const auto row_base = as_uniform(tb.row_base);
+    const auto row_taps = as_uniform(tb.row_taps);
+
     const float* src = heat + (size_t)bk * h * w;
     for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
     for (int i = tid; i < w * tb.TC; i += nthreads) {
@@ -514,12 +520,12 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
             };
             const float dxc = gxt * ((float)c - ex);
             float win[TY], acc[TY];
-            int base = tb.row_base[j0];
+            int base = row_base[j0];
             bool have = false;  // is `win` the window of `base`? (acc always belongs to `base`)
 #pragma unroll
             for (int t = 0; t < TY; ++t) acc[t] = 0.f;
             for (int j = j0; j < j1; ++j) {
-                const int nb = tb.row_base[j];
+                const int nb = row_base[j];
                 const bool skip = prune && ly * lx * ps.rwin[j] < cut;  // wave-uniform: no row of this group reaches the cut
                 if (nb != base) {
                     atomicAdd(&zs[base * LD + lane], acc[0]);  // this segment is done with input row `base`
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                     for (int t = 0; t < TY; ++t) win[t] = zv(base + t);
                     have = true;
                 }
-                const float* taps = tb.row_taps + (size_t)j * R * TY;
+                const auto taps = row_taps + (size_t)j * R * TY;
                 // (one output row at a time for the widest tables: unrolled, the R x TY taps of a row group - 88 scalars at ds = 3 - do not
                 //  fit the scalar file and come back as spilled VECTOR registers)
 #pragma unroll (R * TY <= LP_DEC_RR_FULL ? R : LP_DEC_RR_PART)

@@ -152,6 +152,31 @@ __device__ __forceinline__ s16x4_t lds_read_tr16_async_off(const unsigned char* 
 #define LP_OPAQUE(x) asm volatile("" : "+r"(x))
 #endif
 
+// ---- read-only tables indexed by WAVE-UNIFORM values (tap tables walked by a row counter, per-launch parameter rows) ----------------
+// hipcc only emits scalar loads (s_load: one fetch per wave into SGPRs, far ahead of use, no vector-memory latency in the loop) for memory
+// it can prove nobody writes during the kernel.  Pointers that arrive inside a by-value struct carry no such promise, so a uniform
+// `taps[j * 9 + t]` becomes a per-lane global_load_dwordx4 of the same address in all 64 lanes followed by s_waitcnt vmcnt(0) - round 6 found
+// decode_bwd_kernel waiting three L1 round trips per row group that way.  A pointer in the CONSTANT address space (4
+// on amdgcn: the same memory as global, declared immutable for the kernel's lifetime) gets the scalar loads.
+#ifndef LP_UNIFORM_LOADS
+#define LP_UNIFORM_LOADS 1   // (A/B builds: 0 = plain pointers, the per-lane loads of rounds 1 - 5)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && LP_UNIFORM_LOADS
+template <typename T>
+using uniform_ptr = const __attribute__((address_space(4))) T*;
+template <typename T>
+__device__ __forceinline__ uniform_ptr<T> as_uniform(const T* p) {
+    return (uniform_ptr<T>)(unsigned long long)p;
+}
+#else
+template <typename T>
+using uniform_ptr = const T*;
+template <typename T>
+__host__ __device__ inline uniform_ptr<T> as_uniform(const T* p) {   // (hipcc's host pass and the CPU emulator build: a plain pointer)
+    return p;
+}
+#endif
+
 // ---- wave / block reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

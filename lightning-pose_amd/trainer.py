@@ -105,6 +105,8 @@ class Trainer:
                 model.global_step += 1
         elif self.dp is not None:
             self._sync_logged(model)
+        if count:   # Lightning's hook order: after the optimiser step of the batch (callbacks.Callback.on_train_batch_end(trainer, module, outputs, batch, idx))
+            self._hook("on_train_batch_end", model, {"loss": loss.detach()}, batch, batch_idx)
         if count and model.device.type == "cuda":
             ev = torch.cuda.Event()
             ev.record()
