@@ -22,12 +22,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.environ.get("LP_REFERENCE_SRC", "/root/reference")
 DST = os.path.join(HERE, "_ref")
 # what `ref_loader.load("models.heatmap_tracker")`, `load("losses.factory")`, `load("utils.pca")`, `load("data.utils")`, `load("data.bboxes")`
-# and `load("callbacks")` pull in (sys.modules after those loads), plus the ViT wrapper config C4 constructs
+# `load("callbacks")` and `load("models.factory")` (the reference's own get_model: tests/test_boundary_reference_factory.py) pull in (sys.modules after those loads), plus the ViT wrapper config C4 constructs
 FILES = [
     "callbacks.py",
     "data/bboxes.py", "data/datatypes.py", "data/heatmaps.py", "data/utils.py",
     "losses/factory.py", "losses/losses.py",
-    "models/base.py", "models/datatypes.py", "models/heatmap_tracker.py",
+    "models/base.py", "models/datatypes.py", "models/factory.py", "models/heatmap_tracker.py",
     "models/backbones/__init__.py", "models/backbones/factory.py", "models/backbones/vit.py",
     "models/heads/__init__.py", "models/heads/heatmap.py", "models/heads/heatmap_mhcrnn.py", "models/heads/regression.py",
     "utils/pca.py",
