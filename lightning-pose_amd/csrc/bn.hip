@@ -159,6 +159,24 @@ __device__ __forceinline__ float sum_value(const lp_fxsum* p) { return fx_value(
 
 // mean / invstd from [sum, sumsq]; running statistics updated with torch's momentum rule (unbiased variance)
 // `nseg` segments ([seg][2][C] sums -> [seg][C] moments), running statistics updated segment by segment in order
+// (one function for the stand-alone kernel and for bn_apply_kernel<.., FIN>: the same expressions, contracted the same way - the moments
+//  and running statistics of the two forms are the same bits, tests/test_segmented_bn.py)
+struct BnMoments {
+    float mu, var, invstd;
+};
+__device__ __forceinline__ BnMoments bn_moments(float s1, float s2, float count, float eps) {
+    BnMoments m;
+    m.mu = s1 / count;
+    float var = s2 / count - m.mu * m.mu;
+    m.var = var < 0.f ? 0.f : var;   // (not fmaxf: a NaN - a poisoned sum - must reach invstd and the running variance too)
+    m.invstd = 1.f / sqrtf(m.var + eps);
+    return m;
+}
+__device__ __forceinline__ void bn_running_update(const BnMoments& m, float count, float momentum, float* running_mean, float* running_var) {
+    const float unbiased = count > 1.f ? m.var * count / (count - 1.f) : m.var;
+    *running_mean = (1.f - momentum) * *running_mean + momentum * m.mu;
+    *running_var = (1.f - momentum) * *running_var + momentum * unbiased;
+}
 template <typename SumT>
 __global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, float count1, int nseg, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
@@ -168,16 +186,10 @@ __global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, 
     for (int sg = 0; sg < nseg; ++sg) {
         const float count = sg == 0 ? count0 : count1;
         const SumT* sm = sums + (size_t)sg * 2 * C;
-        const float mu = sum_value(&sm[c]) / count;
-        float var = sum_value(&sm[C + c]) / count - mu * mu;
-        var = var < 0.f ? 0.f : var;   // (not fmaxf: a NaN - a poisoned sum - must reach invstd and the running variance too)
-        mean[sg * C + c] = mu;
-        invstd[sg * C + c] = 1.f / sqrtf(var + eps);
-        if (running_mean != nullptr) {
-            const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-        }
+        const BnMoments m = bn_moments(sum_value(&sm[c]), sum_value(&sm[C + c]), count, eps);
+        mean[sg * C + c] = m.mu;
+        invstd[sg * C + c] = m.invstd;
+        if (running_mean != nullptr) bn_running_update(m, count, momentum, &running_mean[c], &running_var[c]);
     }
 }
 
@@ -190,12 +202,23 @@ __global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, 
 struct BnResidualBn {
     const float *mean, *invstd, *gamma, *beta;   // mean / invstd: [segments][C]
 };
-template <bool RBN>
+// FIN = true (round 6, lp_bn_apply_seg_fin): the launch takes the BatchNorm's fixed-point SUMS instead of finished moments.  Every lane converts
+// the 8 channels it walks (two 16-B words per value, once per segment - nothing against a 100-us stream), and the first C / 8 lanes of the grid
+// also store mean / invstd for the backward pass and apply the running-statistics updates, segment by segment in order: the stand-alone
+// lp_bn_finalize launch in front of every lp_bn_apply - 5 us of an idle device, 44 times per step - is gone.  Same bits as the two launches.
+struct BnFinalize {
+    const lp_fxsum* sums;            // [segments][2][C]
+    float count0, count1, eps, momentum;
+    float *mean_out, *invstd_out;    // [segments][C]
+    float *running_mean, *running_var;   // [C] or nullptr
+};
+template <bool RBN, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_total, int C, unsigned short* __restrict__ Y,
-                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb) {
+                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb,
+                                                       BnFinalize fin = BnFinalize{}) {
     // Two BatchNorm segments in one launch (seg_chunk > 0: chunks [0, seg_chunk) use mean / invstd row 0, the rest row 1; the boundary is
     // a whole number of rows): the walk runs once per segment with that segment's terms in registers; a lane keeps its channel chunk
     // because every start is congruent to its global index modulo the stride.
@@ -208,11 +231,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
     const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
     size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
     float mu[8], sc[8], be[8];
+    if (FIN) {
+        const float count = sg == 0 ? fin.count0 : fin.count1;
+        const lp_fxsum* sm = fin.sums + (size_t)sg * 2 * C;
+        const bool owner = q0 < (size_t)chunks;   // exactly one lane of the grid per channel chunk
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        mu[i] = mean[sg * C + c + i];
-        sc[i] = invstd[sg * C + c + i] * gamma[c + i];
-        be[i] = beta[c + i];
+        for (int i = 0; i < 8; ++i) {
+            const BnMoments m = bn_moments(fx_value(&sm[c + i]), fx_value(&sm[C + c + i]), count, fin.eps);
+            mu[i] = m.mu;
+            sc[i] = m.invstd * gamma[c + i];
+            be[i] = beta[c + i];
+            if (owner) {
+                fin.mean_out[sg * C + c + i] = m.mu;
+                fin.invstd_out[sg * C + c + i] = m.invstd;
+                if (fin.running_mean != nullptr) bn_running_update(m, count, fin.momentum, &fin.running_mean[c + i], &fin.running_var[c + i]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = mean[sg * C + c + i];
+            sc[i] = invstd[sg * C + c + i] * gamma[c + i];
+            be[i] = beta[c + i];
+        }
     }
     float mud[RBN ? 8 : 1], scd[RBN ? 8 : 1], bed[RBN ? 8 : 1];
     if (RBN) {
@@ -1028,6 +1069,26 @@ static int bn_apply_impl(const void* x, const float* mean, const float* invstd, 
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
                        gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
                        (size_t)seg_rows * (C / 8), BnResidualBn{});
+    return launch_status();
+}
+
+// lp_bn_finalize(2) + lp_bn_apply_seg in ONE launch (bn_apply_kernel<false, true>): sums (segments,2,C) fixed point -> mean_out / invstd_out
+// (segments,C) for the backward pass, running statistics updated segment by segment, y = relu?(BatchNorm(x) (+ residual)).  seg_rows = 0: one
+// segment (count1 unused).  Bit-identical to the two launches.
+extern "C" int lp_bn_apply_seg_fin(const void* x, const lp_fxsum* sums, float count0, float count1, float eps, float momentum, float* mean_out,
+                                   float* invstd_out, float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                   const void* residual, int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && sums && mean_out && invstd_out && gamma && beta && y && M > 0 && C > 0 && seg_rows >= 0 && seg_rows < M && count0 > 0.f &&
+               (seg_rows == 0 || count1 > 0.f) && (running_mean == nullptr) == (running_var == nullptr));
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const size_t n_chunks = (size_t)M * (C / 8);
+    const int grid = bn_grid(n_chunks, C / 8);
+    if ((size_t)grid * 256 < (size_t)(C / 8)) return LP_ERR_UNSUPPORTED;   // (every channel chunk needs its owner lane: tiny M with a wide C)
+    hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, nullptr, nullptr,
+                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
+                       (size_t)seg_rows * (C / 8), BnResidualBn{},
+                       BnFinalize{sums, count0, seg_rows > 0 ? count1 : count0, eps, momentum, mean_out, invstd_out, running_mean, running_var});
     return launch_status();
 }
 

@@ -394,6 +394,9 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
 #ifndef LP_DEC_RR_PART
 #define LP_DEC_RR_PART 2    // ... larger ones this many output rows at a time
 #endif
+#ifndef LP_DEC_PROBE
+#define LP_DEC_PROBE 0   // (timing builds only, profiles/r06b.sh: 1 = no strip product (phase B), 2 = no per-row arithmetic, 4 = no window values, 8 = no phase A)
+#endif
 constexpr int kBwdStrip = 64;          // output columns per strip = one wave of lanes; the block's waves split the rows
 constexpr int kBwdLd = kBwdStrip + 1;  // LDS row stride of the strip (odd: lanes that walk down a column hit distinct banks)
 
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
         }
         __syncthreads();  // (first trip: also the tile / table staging)
         const int c = c0 + lane;
-        if (c < W && j0 < j1) {
+        if (!(LP_DEC_PROBE & 8) && c < W && j0 < j1) {
             // (the lane's 12 column taps are re-read - three 16-B loads from L1 - for each of the one or two window rows a row group adds,
             //  instead of living in 12 registers beside the two windows and the NE gradient accumulators: with them the NE = 18
             //  instantiations, capped at 128 registers for two workgroups per CU, spilled 15 - 48 registers)
@@ -507,6 +510,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 for (int t = 0; t < (kTxRegs ? kTXM : 0); ++t) txr[kTxRegs ? t : 0] = txg[t];
             }
             auto zv = [&](int r) __attribute__((always_inline)) {
+                if constexpr ((LP_DEC_PROBE & 4) != 0) return hcol[r];
                 if constexpr (kTxRegs) return z_value<FULLTX>(hcol, r, w, txr, tb.TX);
                 const float* tp = txg;
                 LP_OPAQUE(tp);
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 // (one output row at a time for the widest tables: unrolled, the R x TY taps of a row group - 88 scalars at ds = 3 - do not
                 //  fit the scalar file and come back as spilled VECTOR registers)
 #pragma unroll (R * TY <= LP_DEC_RR_FULL ? R : LP_DEC_RR_PART)
-                for (int rr = 0; rr < R; ++rr) {
+                for (int rr = 0; rr < ((LP_DEC_PROBE & 2) ? 0 : R); ++rr) {
                     float y = 0.f;
 #pragma unroll
                     for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], win[t], y);
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
         __syncthreads();
         // dH[r][q] += sum_c Wst[r][c] * Ux[c][q]  over this strip's columns (columns past W hold zeros)
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
+        for (int i = 0; i < ((LP_DEC_PROBE & 1) ? 0 : NE); ++i) {
             int e = tid + i * nthreads;
             LP_OPAQUE(e);  // (q, r, cs) are recomputed per strip instead of living in registers per element
             if (e < h * w) {

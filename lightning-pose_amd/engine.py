@@ -191,6 +191,7 @@ class Engine:
     dgrad_mask_bits = True
     bn_bwd_ds = True
     bn_apply_rbn = True
+    bn_fin_fused = True
     dgrad_half_addend = True
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
@@ -230,6 +231,7 @@ class Engine:
         self.dgrad_half_addend = os.environ.get("LP_DGRAD_HALF_ADDEND", "1") != "0"   # (0: conv1 first, the shortcut accumulates in place, stand-alone reduction)
         self.bn_apply_rbn = os.environ.get("LP_BN_APPLY_RBN", "1") != "0"   # (0: the projection shortcut normalised by a pass of its own, lp_bn_apply_seg)
         self.bn_bwd_ds = os.environ.get("LP_BN_BWD_DS", "1") != "0"   # (0: the projection shortcut's BatchNorm reductions as a pass of their own, lp_bn_bwd_reduce)
+        self.bn_fin_fused = os.environ.get("LP_BN_FIN_FUSED", "1") != "0"   # (0: lp_bn_finalize as a launch of its own in front of every lp_bn_apply)
         self.dgrad_mask_bits = os.environ.get("LP_DGRAD_MASK_BITS", "1") != "0"   # (0: the two data gradients into a layer's first block read the bf16 activation as mask)
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
@@ -500,9 +502,11 @@ class Engine:
         else:
             dist.all_reduce(t, group=self.process_group)
 
-    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False, seg: int = 0):
+    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False, seg: int = 0,
+                    defer: bool = False):
         """-> (mean, invstd) of this pass, each (segments, C) flattened: batch statistics (running statistics updated, segment by
-        segment) in training, running statistics otherwise"""
+        segment) in training, running statistics otherwise.  ``defer`` (training): leave the finalisation to the caller's fused launch
+        (lp_bn_apply_seg_fin) -> (mean, invstd, counts) with mean / invstd still unwritten"""
         B = z.shape[0]
         rpi = M // B
         segs = self._segments(B, seg if training else 0)
@@ -519,6 +523,8 @@ class Engine:
                 self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
+            if defer:
+                return mean, invstd, counts
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
             if len(segs) == 1:
                 check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
@@ -536,14 +542,22 @@ class Engine:
         """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass.
         ``residual_bn`` = (BNP, mean_d, invstd_d): ``residual`` is the PRE-normalisation tensor of the block's projection shortcut, normalised
         inside this pass (lp_bn_apply_seg_rbn) instead of by a pass of its own that writes the normalised shortcut and this one reads back."""
-        mean, invstd = self._bn_moments(b, z, M, training, sums, have_sums, seg)
+        # training, no projection-shortcut BatchNorm riding along: finalise inside the apply launch (lp_bn_apply_seg_fin, round 6)
+        fused_fin = training and residual_bn is None and self.bn_fin_fused   # (grid x 256 lanes >= M x C / 8 >= C / 8: every channel chunk has its owner lane)
+        mom = self._bn_moments(b, z, M, training, sums, have_sums, seg, defer=fused_fin)
+        mean, invstd = mom[0], mom[1]
         y = torch.empty_like(z)
         bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
         B = z.shape[0]
         rpi = M // B
         gam, bet = _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias"))
         # both segments in ONE launch (the kernel walks each segment with that segment's terms in registers)
-        if residual_bn is not None:
+        if fused_fin:
+            counts = mom[2]
+            check(self._lib.lp_bn_apply_seg_fin(_p(z), _p(sums), counts[0], counts[-1], BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd),
+                                                _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")), gam, bet,
+                                                _p(residual), int(relu), M, b.C, seg * rpi, _p(y), _p(bits), ops._stream()), "lp_bn_apply_seg_fin")
+        elif residual_bn is not None:
             bd, md, vd = residual_bn
             check(self._lib.lp_bn_apply_seg_rbn(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), _p(md), _p(vd), _p(self.param_view(bd, "weight")),
                                                 _p(self.param_view(bd, "bias")), int(relu), M, b.C, (seg if training else 0) * rpi, _p(y), _p(bits),
