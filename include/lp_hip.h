@@ -89,7 +89,10 @@ int lp_decode_window(int downsample_factor, int n);
  * maps), 0 = the plain ones.  An argument of the call since round 5 (no process state; the product chooses it per model from the decode's
  * own sumexp output, ops.py).  Replaces nothing in the reference (models/heads/heatmap.py:103-144 has one code path). */
 
-/* heat (B,K,h,w) -> kp_aug (B,K,2) model px, kp_frame (B,K,2) frame px, conf (B,K), stats (B,K,4)={max,sumexp,ex,ey} */
+/* heat (B,K,h,w) -> kp_aug (B,K,2) model px, kp_frame (B,K,2) frame px, conf (B,K), stats (B,K,4) = {max, sumexp, E[x] - x0, E[y] - y0}: opaque
+ * to the caller except [1] (ops.py reads it as "how many pixels carry weight"); (x0, y0) = the up-sampled position of the tile's own maximum, which
+ * lp_decode_bwd re-derives from the same tile - the two moments are accumulated about that point (round 6: fp32 resolves offsets of a few pixels
+ * 100x finer than coordinates up to 384) */
 int lp_decode_fwd(const float* heat, int B, int K, int h, int w, int downsample_factor, float temperature,
                   const lp_decode_tables* tables, const lp_frame_map* frame_map, float* kp_aug, float* kp_frame, float* conf,
                   float* stats, int prune, lp_stream_t stream);

@@ -212,8 +212,10 @@ struct BnFinalize {
     float *mean_out, *invstd_out;    // [segments][C]
     float *running_mean, *running_var;   // [C] or nullptr
 };
-template <bool RBN, bool FIN = false>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
+// (launch bounds: the plain walk needs 5 waves per SIMD = at most 96 registers - its grid is ONE resident round of 5 workgroups per CU; the
+//  FIN form came out at 97 without the bound and the step lost 3.7 %, profiles/r06b_step_ab.txt)
+template <bool RBN, bool FIN = false, bool RES = true>
+__global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_total, int C, unsigned short* __restrict__ Y,
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                 fin.invstd_out[sg * C + c + i] = m.invstd;
                 if (fin.running_mean != nullptr) bn_running_update(m, count, fin.momentum, &fin.running_mean[c + i], &fin.running_var[c + i]);
             }
+            __builtin_amdgcn_sched_barrier(0);   // one channel at a time: hoisted together, the 8 channels' 64-bit words and fp64 temporaries cost 4 spilled registers
         }
     } else {
 #pragma unroll
@@ -266,14 +269,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
     }
     constexpr int U = 4;
     for (; q < n_chunks; q += U * stride) {
-        u16x8 xv[U], rv[U];
+        u16x8 xv[U], rv[RES ? U : 1];   // (RES = false: launches without a residual - bn1 / bn2 - do not carry its 16 registers)
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (q + u * stride < n_chunks) xv[u] = load_stream8(X + (q + u * stride) * 8);
-        if (residual != nullptr) {
+        if (RES && residual != nullptr) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (q + u * stride < n_chunks) rv[u] = *reinterpret_cast<const u16x8*>(residual + (q + u * stride) * 8);
+                if (q + u * stride < n_chunks) rv[RES ? u : 0] = *reinterpret_cast<const u16x8*>(residual + (q + u * stride) * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -282,9 +285,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
             unpack8(xv[u], x);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = fmaf(x[i] - mu[i], sc[i], be[i]);
-            if (residual != nullptr) {
+            if (RES && residual != nullptr) {
                 float r[8];
-                unpack8(rv[u], r);
+                unpack8(rv[RES ? u : 0], r);
                 if (RBN) {   // the shortcut's own lp_bn_apply (no ReLU), rounded to bf16 as that pass stored it
 #pragma unroll
                     for (int i = 0; i < 8; ++i) r[i] = bf16_to_f32(f32_to_bf16(fmaf(r[i] - mud[RBN ? i : 0], scd[RBN ? i : 0], bed[RBN ? i : 0])));
@@ -1085,10 +1088,18 @@ extern "C" int lp_bn_apply_seg_fin(const void* x, const lp_fxsum* sums, float co
     const size_t n_chunks = (size_t)M * (C / 8);
     const int grid = bn_grid(n_chunks, C / 8);
     if ((size_t)grid * 256 < (size_t)(C / 8)) return LP_ERR_UNSUPPORTED;   // (every channel chunk needs its owner lane: tiny M with a wide C)
-    hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, nullptr, nullptr,
-                       gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
-                       (size_t)seg_rows * (C / 8), BnResidualBn{},
-                       BnFinalize{sums, count0, seg_rows > 0 ? count1 : count0, eps, momentum, mean_out, invstd_out, running_mean, running_var});
+    const BnFinalize fin{sums, count0, seg_rows > 0 ? count1 : count0, eps, momentum, mean_out, invstd_out, running_mean, running_var};
+    if (residual != nullptr) {
+        // with a residual stream the walk is at its 96-register cap already (the fused form spilled 4 registers): the two kernels, same results
+        hipLaunchKernelGGL(bn_finalize_kernel<lp_fxsum>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, fin.count0, fin.count1,
+                           seg_rows > 0 ? 2 : 1, C, eps, momentum, mean_out, invstd_out, running_mean, running_var);
+        hipLaunchKernelGGL((bn_apply_kernel<false, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean_out,
+                           invstd_out, gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y,
+                           (unsigned char*)relu_bits, (size_t)seg_rows * (C / 8), BnResidualBn{}, BnFinalize{});
+    } else
+        hipLaunchKernelGGL((bn_apply_kernel<false, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, nullptr, nullptr,
+                           gamma, beta, nullptr, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
+                           (size_t)seg_rows * (C / 8), BnResidualBn{}, fin);
     return launch_status();
 }
 

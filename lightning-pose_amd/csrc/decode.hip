@@ -61,6 +61,43 @@ __device__ __forceinline__ void merge_softmax(float& m, float& s, float& sx, flo
     m = mm;
 }
 
+// Index of the tile's maximum (first one in row-major order), the same in every thread.  Round 6: the soft-argmax accumulates its two first
+// moments RELATIVE to this point - (x0, y0) = R * (column, row) + R / 2 in up-sampled pixels - instead of from the map's corner: the
+// expectation of a peaked map is then a sum of offsets of a few pixels (fp32 resolves 1e-7 px there) instead of coordinates up to 384 (3e-5),
+// and the backward pass's (c - E[x]) keeps the digits the old form lost - its gradient noise against exact arithmetic fell from 5e-5 to the
+// reference's own 5e-6 (tests/test_trajectory_vs_reference.py).  Forward and backward both derive the point from the tile itself, so the
+// `stats` they exchange carry only the small offsets.  `red` holds >= 2 * nwaves floats; order-independent (value, then lowest index).
+__device__ __forceinline__ int tile_argmax(const float* hs, int n, float* red) {
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += nthreads) {
+        const float v = hs[i];
+        if (v > bv) bv = v, bi = i;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = __shfl_xor(bv, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+    }
+    __syncthreads();   // (whatever used `red` before is done with it)
+    if (lane == 0) {
+        red[wave] = bv;
+        red[8 + wave] = __int_as_float(bi);
+    }
+    __syncthreads();
+    bv = red[0];
+    bi = __float_as_int(red[8]);
+    for (int i = 1; i < nwaves; ++i) {
+        const float ov = red[i];
+        const int oi = __float_as_int(red[8 + i]);
+        if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+    }
+    __syncthreads();   // (`red` is free again)
+    return __builtin_amdgcn_readfirstlane(bi == 0x7fffffff ? 0 : bi);   // (a tile of NaNs / -inf: any point will do, the outputs are NaN anyway; the same in every lane: a scalar)
+}
+
 // One element of Z = Hm * Ux^T for this lane's output column: `hcol` = tile + first input column of the lane's taps.
 template <bool FULLTX>
 __device__ __forceinline__ float z_value(const float* hcol, int r, int w, const float (&tx)[kTXM], int TX) {
@@ -221,6 +258,9 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     const float* src = heat + (size_t)bk * h * w;
     for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
     __syncthreads();
+    // the point the moments are taken about (tile_argmax): whole numbers, so (column - x0) and (row - y0) are exact
+    const int amax = tile_argmax(hs, h * w, red);
+    const float y0 = (float)((amax / w) * R + R / 2), x0 = (float)((amax % w) * R + R / 2);
 
     // ---- pruning set-up: bounds from the tile, and a LOWER bound of the final maximum from the row group at the tile's largest row
     float ly = 0.f, m_lb = -INFINITY;
@@ -269,7 +309,7 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int t = 0; t < kTXM; ++t) tx[t] = tb.col_taps[c * kTXM + t];
         const float* hcol = hs + tb.col_start[c];
-        const float xc = (float)c;
+        const float xc = (float)c - x0;
         float lx = 0.f;       // wave-wide bound factor of the columns: max over the wave of sum_t |tx|, and of their column maxima
         bool wave_live = true;
         if (prune) {
@@ -327,7 +367,7 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
                 const float e = __expf(z[rr] - gm);
                 s += e;
                 sx = fmaf(e, xc, sx);
-                sy = fmaf(e, (float)(j * R + rr), sy);
+                sy = fmaf(e, (float)(j * R + rr) - y0, sy);
             }
         }
     }
@@ -351,7 +391,8 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     sx = red[2];
     sy = red[3];
     for (int i = 1; i < nwaves; ++i) merge_softmax(m, s, sx, sy, red[i * 4 + 0], red[i * 4 + 1], red[i * 4 + 2], red[i * 4 + 3]);
-    const float ex = sx / s, ey = sy / s;
+    const float dex = sx / s, dey = sy / s;       // E[x] - x0, E[y] - y0
+    const float ex = x0 + dex, ey = y0 + dey;
 
     // confidence: softmax mass in the 5x5 window at trunc(ex, ey), zero outside the map
     float cpart = 0.f;
@@ -376,8 +417,8 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
             conf[bk] = cpart;
             stats[bk * 4 + 0] = m;
             stats[bk * 4 + 1] = s;
-            stats[bk * 4 + 2] = ex;
-            stats[bk * 4 + 3] = ey;
+            stats[bk * 4 + 2] = dex;   // (the offsets from the tile's own maximum: lp_decode_bwd rebuilds (x0, y0) from the tile)
+            stats[bk * 4 + 3] = dey;
         }
     }
 }
@@ -454,15 +495,16 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
         gy += ay;
     }
     const float m = stats[bk * 4 + 0], inv_s = 1.f / stats[bk * 4 + 1];
-    const float ex = stats[bk * 4 + 2], ey = stats[bk * 4 + 3];
+    const float dex = stats[bk * 4 + 2], dey = stats[bk * 4 + 3];   // E[x] - x0, E[y] - y0 (x0, y0: tile_argmax, below)
     const float gxt = gx * temperature, gyt = gy * temperature;
 
+    __syncthreads();  // the staged tile is complete
+    // (zs is not in use yet: scratch for the reduction)
+    const int amax = tile_argmax(hs, h * w, zs);
+    const float y0 = (float)((amax / w) * R + R / 2), x0 = (float)((amax % w) * R + R / 2);
     // pruning (see "exact pruning at high temperature"): here the exact maximum is known from the forward pass
     float ly = 0.f;
-    if (prune) {
-        __syncthreads();  // the staged tile is complete
-        ly = prune_setup<R, TY>(ps, hs, h, w, tb);
-    }
+    if (prune) ly = prune_setup<R, TY>(ps, hs, h, w, tb);
     const float cut = prune ? (m - kPruneMargin) / fmaxf(temperature, 1e-30f) : -INFINITY;
 
     // this thread's elements of dH: e = tid + i * nthreads -> (q, r) = (e / h, e % h): consecutive lanes walk down one input
@@ -487,20 +529,27 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
             lx = wave_max(lx);
             if (prune && colb < cut) continue;
         }
-        {
-            int ti = tid;
-            if (NE <= 8 || R == 8) LP_OPAQUE(ti);   // (the fill's first address recomputed per strip where the allocation is at its cap: hoisted it
-                                                     //  is one more register alive through both phases; elsewhere the hint only perturbs the schedule)
-            for (int i = ti; i < h * LD; i += nthreads) zs[i] = 0.f;
-        }
-        __syncthreads();  // (first trip: also the tile / table staging)
+        __syncthreads();  // (first trip: the tile / table staging; later trips: the previous strip's product is done reading zs)
+        // Who writes what into the strip (round 6: no LDS atomics).  A wave's row range overlaps only its neighbours' - by the TY - 1 rows of a
+        // window - so every strip element has one or two contributors.  The HIGHER wave of a shared row owns it: owners write with plain
+        // stores (the rows that leave a wave's window while it walks are never shared with the wave below it, and the rows it still holds
+        // at the end are stored there unless the wave below shares them); the guests - a wave's last rows, from the first row of the next
+        // wave on - are ADDED after a barrier, by then initialised.  Every element is written exactly once before it is read: no zero
+        // fill either.  (Rounds 1 - 5 zeroed the strip and let every wave ds_add_f32 into it: 21 LDS atomics per lane and strip at ~190 LDS
+        // cycles per wave instruction - the LDS was 96 % busy and 0.93 ms of the 1.45-ms launch remained with ALL arithmetic compiled out,
+        // profiles/r06b_decode_probe.txt, r06b_decode_pmc2.json.)
         const int c = c0 + lane;
-        if (!(LP_DEC_PROBE & 8) && c < W && j0 < j1) {
+        const bool live = c < W;                 // (lanes past the map's last column still write their zeros)
+        const int cc = live ? c : W - 1;
+        const int guest_from = j1 < h ? row_base[j1] : h;   // first row the wave below shares (wave-uniform); rows from here on are its to store
+        float acc[TY];
+        int base = row_base[j0 < h ? j0 : 0];
+        if (!(LP_DEC_PROBE & 8) && j0 < j1) {    // (wave-uniform)
             // (the lane's 12 column taps are re-read - three 16-B loads from L1 - for each of the one or two window rows a row group adds,
             //  instead of living in 12 registers beside the two windows and the NE gradient accumulators: with them the NE = 18
             //  instantiations, capped at 128 registers for two workgroups per CU, spilled 15 - 48 registers)
-            const float* txg = tb.col_taps + (size_t)c * kTXM;
-            const float* hcol = hs + tb.col_start[c];
+            const float* txg = tb.col_taps + (size_t)cc * kTXM;
+            const float* hcol = hs + tb.col_start[cc];
             // the plain kernels keep the 12 taps in registers (with the row groups walked two output rows at a time they fit: 127 of 128); the
             // pruning ones, which carry their bounds as well, re-read them per use (measured, profiles/r05d_decode_variants.txt)
             constexpr bool kTxRegs = LP_DEC_TX_REGS == 1 || (LP_DEC_TX_REGS == 2 && !PRUNE && R == 4);   // (ds = 1 / 3 tables: the re-read form, one register short otherwise)
@@ -522,9 +571,9 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 }
                 return z_value<FULLTX>(hcol, r, w, tx, tb.TX);
             };
-            const float dxc = gxt * ((float)c - ex);
-            float win[TY], acc[TY];
-            int base = row_base[j0];
+            const float dxc = live ? gxt * (((float)c - x0) - dex) : 0.f;
+            const float gyl = live ? gyt : 0.f;
+            float win[TY];
             bool have = false;  // is `win` the window of `base`? (acc always belongs to `base`)
 #pragma unroll
             for (int t = 0; t < TY; ++t) acc[t] = 0.f;
@@ -532,7 +581,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 const int nb = row_base[j];
                 const bool skip = prune && ly * lx * ps.rwin[j] < cut;  // wave-uniform: no row of this group reaches the cut
                 if (nb != base) {
-                    atomicAdd(&zs[base * LD + lane], acc[0]);  // this segment is done with input row `base`
+                    zs[base * LD + lane] = acc[0];  // this segment is done with input row `base` (base < guest_from: its owner)
 #pragma unroll
                     for (int t = 0; t < TY - 1; ++t) {
                         win[t] = win[t + 1];
@@ -560,13 +609,20 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
 #pragma unroll
                     for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], win[t], y);
                     const float p = __expf(y * temperature - m) * inv_s;
-                    const float g = p * (dxc + gyt * ((float)(j * R + rr) - ey));
+                    const float g = p * (dxc + gyl * (((float)(j * R + rr) - y0) - dey));
 #pragma unroll
                     for (int t = 0; t < TY; ++t) acc[t] = fmaf(taps[rr * TY + t], g, acc[t]);
                 }
             }
 #pragma unroll
-            for (int t = 0; t < TY; ++t) atomicAdd(&zs[(base + t) * LD + lane], acc[t]);
+            for (int t = 0; t < TY; ++t)   // the rows still in the window that nobody below shares: this wave's to store
+                if (base + t < guest_from) zs[(base + t) * LD + lane] = acc[t];
+        }
+        __syncthreads();   // every owner has stored
+        if (!(LP_DEC_PROBE & 8) && j0 < j1) {
+#pragma unroll
+            for (int t = 0; t < TY; ++t)   // ... and the shared ones are added to what the wave below stored
+                if (base + t >= guest_from) zs[(base + t) * LD + lane] += acc[t];
         }
         __syncthreads();
         // dH[r][q] += sum_c Wst[r][c] * Ux[c][q]  over this strip's columns (columns past W hold zeros)
@@ -727,13 +783,13 @@ extern "C" int lp_decode_bwd(const float* heat, int B, int K, int h, int w, int 
                        temperature, tb, fm, stats, g_aug, g_frame, g_heat, accumulate)
 #define LP_DISPATCH_NE2(RR, TT, PP)                                  \
     do {                                                             \
+        /* (rounds 1 - 5 also instantiated NE = 8 for maps of up to 64 x 64: the same 128-register cap and occupancy as NE = 18, whose ten */ \
+        /*  spare accumulators cost nothing - and in round 6's form the NE = 8 pruning kernels spilled 5 - 7 registers where NE = 18 has none) */ \
         if (full) {                                                  \
-            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, true, PP); }     \
-            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, true, PP); } \
+            if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, true, PP); }   \
             else { LP_LAUNCH_BWD(RR, TT, 64, true, PP); }            \
         } else {                                                     \
-            if (ne <= 8) { LP_LAUNCH_BWD(RR, TT, 8, false, PP); }    \
-            else if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, false, PP); } \
+            if (ne <= 18) { LP_LAUNCH_BWD(RR, TT, 18, false, PP); }  \
             else { LP_LAUNCH_BWD(RR, TT, 64, false, PP); }           \
         }                                                            \
     } while (0)
