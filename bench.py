@@ -604,7 +604,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
             tot_ms, tot_flops = 0.0, 0.0
             tot_bytes = 0.0
             tot_roof_ms = 0.0
-            for tag, flops, e0, e1, nbytes in prof:
+            for tag, flops, e0, e1, nbytes, *_layer in prof:
                 ms = e0.elapsed_time(e1)
                 # the launch's OWN roof: whichever of its algorithmic FLOPs at the dense bf16 MFMA peak and its algorithmic bytes at the
                 # HBM rate this part sustains (6.3 TB/s, MI355X_MICROARCH.md) takes longer
@@ -623,7 +623,7 @@ def train_line(args, dev, rank: int, world: int) -> dict:
             if dump:  # per-launch (tag, GFLOP, us) of the LAST timed step, for kernel tuning
                 per_step = len(prof) // prof_steps
                 with open(dump, "w") as fh:
-                    json.dump([[t, round(f / 1e9, 3), round(1000 * a.elapsed_time(b), 1), round(nb / 1e6, 2)] for t, f, a, b, nb in prof[-per_step:]], fh)
+                    json.dump([[t, round(f / 1e9, 3), round(1000 * a.elapsed_time(b), 1), round(nb / 1e6, 2), (ly[0] if ly else "")] for t, f, a, b, nb, *ly in prof[-per_step:]], fh)
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic() if (not is_vit and args.size == 384 and args.views == 1) else (None, None)
             out["roofline"] = {

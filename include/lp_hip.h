@@ -415,14 +415,6 @@ int lp_bn_apply(const void* x, const float* mean, const float* invstd, const flo
  * [and of sums (2, 2, C), with count0], the other rows use row 1 [count1] */
 int lp_bn_apply_seg(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                     int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
-/* lp_bn_finalize / lp_bn_finalize2 AND lp_bn_apply_seg in one launch (round 6): `sums` are the BatchNorm's fixed-point sums ((segments,2,C),
- * after any SyncBatchNorm exchange; count0 / count1 = rows per segment x world size); the launch stores mean_out / invstd_out (segments,C) for the
- * backward pass, applies the running-statistics updates (torch.nn.BatchNorm2d training forward: momentum rule, unbiased variance; NULL = none)
- * segment by segment in order, and normalises like lp_bn_apply_seg.  Bit-identical to the two launches; saves one dependent ~5-us launch per
- * BatchNorm (44 per ResNet-50 step).  seg_rows = 0: one segment (count1 unused). */
-int lp_bn_apply_seg_fin(const void* x, const lp_fxsum* sums, float count0, float count1, float eps, float momentum, float* mean_out,
-                        float* invstd_out, float* running_mean, float* running_var, const float* gamma, const float* beta, const void* residual,
-                        int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
 /* lp_bn_apply_seg whose residual is a PRE-normalisation tensor with its own BatchNorm (a block's projection shortcut, round 5): the shortcut is
  * normalised in the same pass - rounded to bf16 as its own lp_bn_apply would have stored it - instead of being written and read back.
  * Bit-identical to lp_bn_apply_seg(zd -> idt, no ReLU) followed by lp_bn_apply_seg(x, ..., residual = idt).

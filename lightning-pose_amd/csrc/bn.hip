@@ -159,8 +159,6 @@ __device__ __forceinline__ float sum_value(const lp_fxsum* p) { return fx_value(
 
 // mean / invstd from [sum, sumsq]; running statistics updated with torch's momentum rule (unbiased variance)
 // `nseg` segments ([seg][2][C] sums -> [seg][C] moments), running statistics updated segment by segment in order
-// (one function for the stand-alone kernel and for bn_apply_kernel<.., FIN>: the same expressions, contracted the same way - the moments
-//  and running statistics of the two forms are the same bits, tests/test_segmented_bn.py)
 struct BnMoments {
     float mu, var, invstd;
 };
@@ -202,25 +200,17 @@ __global__ void bn_finalize_kernel(const SumT* __restrict__ sums, float count0, 
 struct BnResidualBn {
     const float *mean, *invstd, *gamma, *beta;   // mean / invstd: [segments][C]
 };
-// FIN = true (round 6, lp_bn_apply_seg_fin): the launch takes the BatchNorm's fixed-point SUMS instead of finished moments.  Every lane converts
-// the 8 channels it walks (two 16-B words per value, once per segment - nothing against a 100-us stream), and the first C / 8 lanes of the grid
-// also store mean / invstd for the backward pass and apply the running-statistics updates, segment by segment in order: the stand-alone
-// lp_bn_finalize launch in front of every lp_bn_apply - 5 us of an idle device, 44 times per step - is gone.  Same bits as the two launches.
-struct BnFinalize {
-    const lp_fxsum* sums;            // [segments][2][C]
-    float count0, count1, eps, momentum;
-    float *mean_out, *invstd_out;    // [segments][C]
-    float *running_mean, *running_var;   // [C] or nullptr
-};
-// (launch bounds: the plain walk needs 5 waves per SIMD = at most 96 registers - its grid is ONE resident round of 5 workgroups per CU; the
-//  FIN form came out at 97 without the bound and the step lost 3.7 %, profiles/r06b_step_ab.txt)
-template <bool RBN, bool FIN = false, bool RES = true>
+// (launch bounds: the plain walk needs 5 waves per SIMD = at most 96 registers - its grid is ONE resident round of 5 workgroups per CU)
+// Round 6 measured folding lp_bn_finalize into this launch (every lane converting its 8 channels' fixed-point sums, the first C / 8 lanes
+// storing the moments and the running statistics): bit-identical and 2.4 % SLOWER per step (42.15 -> 43.12 ms, three alternating pairs) - the
+// 327 k lanes re-read 256 B of sums each where they read 64 B of finished moments, a third more load traffic than the launch's own stream;
+// retired with its measurement (profiles/retired/r06_bn_apply_fin.patch, profiles/r06b_step_ab.txt, r06c_step_ab.txt).
+template <bool RBN>
 __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_total, int C, unsigned short* __restrict__ Y,
-                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb,
-                                                       BnFinalize fin = BnFinalize{}) {
+                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb) {
     // Two BatchNorm segments in one launch (seg_chunk > 0: chunks [0, seg_chunk) use mean / invstd row 0, the rest row 1; the boundary is
     // a whole number of rows): the walk runs once per segment with that segment's terms in registers; a lane keeps its channel chunk
     // because every start is congruent to its global index modulo the stride.
@@ -233,30 +223,11 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
     const size_t lo = sg == 0 ? 0 : seg_chunk, n_chunks = (nseg == 2 && sg == 0) ? seg_chunk : n_total;
     size_t q = q0 >= lo ? q0 : q0 + (lo - q0 + stride - 1) / stride * stride;
     float mu[8], sc[8], be[8];
-    if (FIN) {
-        const float count = sg == 0 ? fin.count0 : fin.count1;
-        const lp_fxsum* sm = fin.sums + (size_t)sg * 2 * C;
-        const bool owner = q0 < (size_t)chunks;   // exactly one lane of the grid per channel chunk
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const BnMoments m = bn_moments(fx_value(&sm[c + i]), fx_value(&sm[C + c + i]), count, fin.eps);
-            mu[i] = m.mu;
-            sc[i] = m.invstd * gamma[c + i];
-            be[i] = beta[c + i];
-            if (owner) {
-                fin.mean_out[sg * C + c + i] = m.mu;
-                fin.invstd_out[sg * C + c + i] = m.invstd;
-                if (fin.running_mean != nullptr) bn_running_update(m, count, fin.momentum, &fin.running_mean[c + i], &fin.running_var[c + i]);
-            }
-            __builtin_amdgcn_sched_barrier(0);   // one channel at a time: hoisted together, the 8 channels' 64-bit words and fp64 temporaries cost 4 spilled registers
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            mu[i] = mean[sg * C + c + i];
-            sc[i] = invstd[sg * C + c + i] * gamma[c + i];
-            be[i] = beta[c + i];
-        }
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = mean[sg * C + c + i];
+        sc[i] = invstd[sg * C + c + i] * gamma[c + i];
+        be[i] = beta[c + i];
     }
     float mud[RBN ? 8 : 1], scd[RBN ? 8 : 1], bed[RBN ? 8 : 1];
     if (RBN) {
@@ -269,14 +240,14 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
     }
     constexpr int U = 4;
     for (; q < n_chunks; q += U * stride) {
-        u16x8 xv[U], rv[RES ? U : 1];   // (RES = false: launches without a residual - bn1 / bn2 - do not carry its 16 registers)
+        u16x8 xv[U], rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (q + u * stride < n_chunks) xv[u] = load_stream8(X + (q + u * stride) * 8);
-        if (RES && residual != nullptr) {
+        if (residual != nullptr) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (q + u * stride < n_chunks) rv[RES ? u : 0] = *reinterpret_cast<const u16x8*>(residual + (q + u * stride) * 8);
+                if (q + u * stride < n_chunks) rv[u] = *reinterpret_cast<const u16x8*>(residual + (q + u * stride) * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -285,9 +256,9 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
             unpack8(xv[u], x);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = fmaf(x[i] - mu[i], sc[i], be[i]);
-            if (RES && residual != nullptr) {
+            if (residual != nullptr) {
                 float r[8];
-                unpack8(rv[RES ? u : 0], r);
+                unpack8(rv[u], r);
                 if (RBN) {   // the shortcut's own lp_bn_apply (no ReLU), rounded to bf16 as that pass stored it
 #pragma unroll
                     for (int i = 0; i < 8; ++i) r[i] = bf16_to_f32(f32_to_bf16(fmaf(r[i] - mud[RBN ? i : 0], scd[RBN ? i : 0], bed[RBN ? i : 0])));
@@ -1072,34 +1043,6 @@ static int bn_apply_impl(const void* x, const float* mean, const float* invstd, 
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
                        gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
                        (size_t)seg_rows * (C / 8), BnResidualBn{});
-    return launch_status();
-}
-
-// lp_bn_finalize(2) + lp_bn_apply_seg in ONE launch (bn_apply_kernel<false, true>): sums (segments,2,C) fixed point -> mean_out / invstd_out
-// (segments,C) for the backward pass, running statistics updated segment by segment, y = relu?(BatchNorm(x) (+ residual)).  seg_rows = 0: one
-// segment (count1 unused).  Bit-identical to the two launches.
-extern "C" int lp_bn_apply_seg_fin(const void* x, const lp_fxsum* sums, float count0, float count1, float eps, float momentum, float* mean_out,
-                                   float* invstd_out, float* running_mean, float* running_var, const float* gamma, const float* beta,
-                                   const void* residual, int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream) {
-    using namespace lp;
-    LP_REQUIRE(x && sums && mean_out && invstd_out && gamma && beta && y && M > 0 && C > 0 && seg_rows >= 0 && seg_rows < M && count0 > 0.f &&
-               (seg_rows == 0 || count1 > 0.f) && (running_mean == nullptr) == (running_var == nullptr));
-    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
-    const size_t n_chunks = (size_t)M * (C / 8);
-    const int grid = bn_grid(n_chunks, C / 8);
-    if ((size_t)grid * 256 < (size_t)(C / 8)) return LP_ERR_UNSUPPORTED;   // (every channel chunk needs its owner lane: tiny M with a wide C)
-    const BnFinalize fin{sums, count0, seg_rows > 0 ? count1 : count0, eps, momentum, mean_out, invstd_out, running_mean, running_var};
-    if (residual != nullptr) {
-        // with a residual stream the walk is at its 96-register cap already (the fused form spilled 4 registers): the two kernels, same results
-        hipLaunchKernelGGL(bn_finalize_kernel<lp_fxsum>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, fin.count0, fin.count1,
-                           seg_rows > 0 ? 2 : 1, C, eps, momentum, mean_out, invstd_out, running_mean, running_var);
-        hipLaunchKernelGGL((bn_apply_kernel<false, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean_out,
-                           invstd_out, gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y,
-                           (unsigned char*)relu_bits, (size_t)seg_rows * (C / 8), BnResidualBn{}, BnFinalize{});
-    } else
-        hipLaunchKernelGGL((bn_apply_kernel<false, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, nullptr, nullptr,
-                           gamma, beta, nullptr, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
-                           (size_t)seg_rows * (C / 8), BnResidualBn{}, fin);
     return launch_status();
 }
 

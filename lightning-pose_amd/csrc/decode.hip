@@ -67,7 +67,11 @@ __device__ __forceinline__ void merge_softmax(float& m, float& s, float& sx, flo
 // and the backward pass's (c - E[x]) keeps the digits the old form lost - its gradient noise against exact arithmetic fell from 5e-5 to the
 // reference's own 5e-6 (tests/test_trajectory_vs_reference.py).  Forward and backward both derive the point from the tile itself, so the
 // `stats` they exchange carry only the small offsets.  `red` holds >= 2 * nwaves floats; order-independent (value, then lowest index).
+#ifndef LP_DEC_CENTER
+#define LP_DEC_CENTER 1   // (A/B builds: 0 = moments from the map's corner, rounds 1 - 5)
+#endif
 __device__ __forceinline__ int tile_argmax(const float* hs, int n, float* red) {
+    if (!LP_DEC_CENTER) return -1;
     const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     __syncthreads();
     // the point the moments are taken about (tile_argmax): whole numbers, so (column - x0) and (row - y0) are exact
     const int amax = tile_argmax(hs, h * w, red);
-    const float y0 = (float)((amax / w) * R + R / 2), x0 = (float)((amax % w) * R + R / 2);
+    const float y0 = amax < 0 ? 0.f : (float)((amax / w) * R + R / 2), x0 = amax < 0 ? 0.f : (float)((amax % w) * R + R / 2);
 
     // ---- pruning set-up: bounds from the tile, and a LOWER bound of the final maximum from the row group at the tile's largest row
     float ly = 0.f, m_lb = -INFINITY;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
     __syncthreads();  // the staged tile is complete
     // (zs is not in use yet: scratch for the reduction)
     const int amax = tile_argmax(hs, h * w, zs);
-    const float y0 = (float)((amax / w) * R + R / 2), x0 = (float)((amax % w) * R + R / 2);
+    const float y0 = amax < 0 ? 0.f : (float)((amax / w) * R + R / 2), x0 = amax < 0 ? 0.f : (float)((amax % w) * R + R / 2);
     // pruning (see "exact pruning at high temperature"): here the exact maximum is known from the forward pass
     float ly = 0.f;
     if (prune) ly = prune_setup<R, TY>(ps, hs, h, w, tb);

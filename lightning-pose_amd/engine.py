@@ -191,7 +191,6 @@ class Engine:
     dgrad_mask_bits = True
     bn_bwd_ds = True
     bn_apply_rbn = True
-    bn_fin_fused = True
     dgrad_half_addend = True
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
@@ -231,7 +230,6 @@ class Engine:
         self.dgrad_half_addend = os.environ.get("LP_DGRAD_HALF_ADDEND", "1") != "0"   # (0: conv1 first, the shortcut accumulates in place, stand-alone reduction)
         self.bn_apply_rbn = os.environ.get("LP_BN_APPLY_RBN", "1") != "0"   # (0: the projection shortcut normalised by a pass of its own, lp_bn_apply_seg)
         self.bn_bwd_ds = os.environ.get("LP_BN_BWD_DS", "1") != "0"   # (0: the projection shortcut's BatchNorm reductions as a pass of their own, lp_bn_bwd_reduce)
-        self.bn_fin_fused = os.environ.get("LP_BN_FIN_FUSED", "1") != "0"   # (0: lp_bn_finalize as a launch of its own in front of every lp_bn_apply)
         self.dgrad_mask_bits = os.environ.get("LP_DGRAD_MASK_BITS", "1") != "0"   # (0: the two data gradients into a layer's first block read the bf16 activation as mask)
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
@@ -259,9 +257,10 @@ class Engine:
         workgroups or ranks arrive in."""
         return self._zeros_f32(4 * n).view(torch.int64)
 
-    def _timed(self, tag: str, flops: float, fn, nbytes: float = 0.0):
+    def _timed(self, tag: str, flops: float, fn, nbytes: float = 0.0, layer: str = ""):
         """Run one kernel launch; when profiling is on, bracket it with HIP events on the launch stream.  ``nbytes``: the launch's
-        ALGORITHMIC bytes (operands read once + result written once), the denominator the measured HBM traffic is held against."""
+        ALGORITHMIC bytes (operands read once + result written once), the denominator the measured HBM traffic is held against.
+        ``layer``: the parameter name of the layer the launch belongs to (profiles/layer_table.py groups by it, not by launch order)."""
         if self.profile is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -278,7 +277,7 @@ class Engine:
                 tag = tag.replace("conv_igemm_kernel<64,", "conv_res2d_kernel<").replace("conv_igemm_kernel<64>", "conv_res2d_kernel<fwd>")
             elif k == _lib.CONV_KERNEL_WGRAD_PIPE:
                 tag = tag.replace("conv_wgrad_kernel", "conv_wgrad_pipe_kernel")
-        self.profile.append((tag, flops, e0, e1, nbytes))
+        self.profile.append((tag, flops, e0, e1, nbytes, layer))
         return out
 
     def _wgrad(self, x, dy, g, dw: torch.Tensor, stem: bool = False, dbias: torch.Tensor | None = None) -> None:
@@ -464,14 +463,14 @@ class Engine:
             else:
                 f = self._bn_fuse(sums, seg=seg)
                 run = lambda: check(self._lib.lp_stem_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_stem_fwd_bn")  # noqa: E731
-            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run, self._bytes(c, g))
+            self._timed("conv_igemm_kernel<64,stem>", self._flops(c, g), run, self._bytes(c, g), layer=c.name)
         else:
             if sums is None:
                 run = lambda: check(self._lib.lp_conv_fwd(_p(x), _p(w), C.byref(g), None, _p(out), None, c.Co, 0, st), "lp_conv_fwd")  # noqa: E731
             else:
                 f = self._bn_fuse(sums, seg=seg)
                 run = lambda: check(self._lib.lp_conv_fwd_bn(_p(x), _p(w), C.byref(g), _p(out), C.byref(f), st), "lp_conv_fwd_bn")  # noqa: E731
-            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run, self._bytes(c, g))
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},fwd>", self._flops(c, g), run, self._bytes(c, g), layer=c.name)
         return out, g
 
     @staticmethod
@@ -502,11 +501,9 @@ class Engine:
         else:
             dist.all_reduce(t, group=self.process_group)
 
-    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False, seg: int = 0,
-                    defer: bool = False):
+    def _bn_moments(self, b: BNP, z: torch.Tensor, M: int, training: bool, sums: torch.Tensor, have_sums: bool = False, seg: int = 0):
         """-> (mean, invstd) of this pass, each (segments, C) flattened: batch statistics (running statistics updated, segment by
-        segment) in training, running statistics otherwise.  ``defer`` (training): leave the finalisation to the caller's fused launch
-        (lp_bn_apply_seg_fin) -> (mean, invstd, counts) with mean / invstd still unwritten"""
+        segment) in training, running statistics otherwise"""
         B = z.shape[0]
         rpi = M // B
         segs = self._segments(B, seg if training else 0)
@@ -523,8 +520,6 @@ class Engine:
                 self._sync_stats(sums)
                 self.sync_bn_messages += 1
                 counts = [c_ * dist.get_world_size(self.process_group) for c_ in counts]
-            if defer:
-                return mean, invstd, counts
             rm, rv = _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var"))
             if len(segs) == 1:
                 check(self._lib.lp_bn_finalize(_p(sums), counts[0], b.C, BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd), rm, rv, ops._stream()),
@@ -542,22 +537,14 @@ class Engine:
         """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass.
         ``residual_bn`` = (BNP, mean_d, invstd_d): ``residual`` is the PRE-normalisation tensor of the block's projection shortcut, normalised
         inside this pass (lp_bn_apply_seg_rbn) instead of by a pass of its own that writes the normalised shortcut and this one reads back."""
-        # training, no projection-shortcut BatchNorm riding along: finalise inside the apply launch (lp_bn_apply_seg_fin, round 6)
-        fused_fin = training and residual_bn is None and self.bn_fin_fused   # (grid x 256 lanes >= M x C / 8 >= C / 8: every channel chunk has its owner lane)
-        mom = self._bn_moments(b, z, M, training, sums, have_sums, seg, defer=fused_fin)
-        mean, invstd = mom[0], mom[1]
+        mean, invstd = self._bn_moments(b, z, M, training, sums, have_sums, seg)
         y = torch.empty_like(z)
         bits = torch.empty(M * b.C // 8, device=self.device, dtype=torch.uint8) if want_bits else None
         B = z.shape[0]
         rpi = M // B
         gam, bet = _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias"))
         # both segments in ONE launch (the kernel walks each segment with that segment's terms in registers)
-        if fused_fin:
-            counts = mom[2]
-            check(self._lib.lp_bn_apply_seg_fin(_p(z), _p(sums), counts[0], counts[-1], BN_EPS, BN_MOMENTUM, _p(mean), _p(invstd),
-                                                _p(self.running_view(b, "running_mean")), _p(self.running_view(b, "running_var")), gam, bet,
-                                                _p(residual), int(relu), M, b.C, seg * rpi, _p(y), _p(bits), ops._stream()), "lp_bn_apply_seg_fin")
-        elif residual_bn is not None:
+        if residual_bn is not None:
             bd, md, vd = residual_bn
             check(self._lib.lp_bn_apply_seg_rbn(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), _p(md), _p(vd), _p(self.param_view(bd, "weight")),
                                                 _p(self.param_view(bd, "bias")), int(relu), M, b.C, (seg if training else 0) * rpi, _p(y), _p(bits),
@@ -796,7 +783,7 @@ class Engine:
             out = torch.empty(B, g_.Ho, g_.Wo, c.Co, device=self.device, dtype=torch.bfloat16)
             run = lambda: check(self._lib.lp_conv_fwd_act(_p(xin), _p(wf[c.w_off:]), C.byref(g_), _p(bf[b.b_off:]), _p(residual), int(relu),  # noqa: E731
                                                           _p(out), st), "lp_conv_fwd_act")
-            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},infer>", self._flops(c, g_), run, self._bytes(c, g_))
+            self._timed(f"conv_igemm_kernel<{128 if c.Co > 64 else 64},infer>", self._flops(c, g_), run, self._bytes(c, g_), layer=c.name)
             return out, g_
 
         for blk in plan.blocks:
@@ -871,7 +858,7 @@ class Engine:
         # (the weight gradient is enqueued BEFORE the layer's data gradient: the side stream starts it at once, beside the data gradient.  Enqueued
         # behind it - so that it would run beside the HBM-bound BatchNorm kernels instead - the step was 1.3 % slower, profiles/r05o_wgrad_order_ab.txt)
         self._timed(f"conv_wgrad_kernel<{128 if c.Co > 64 else 64}>", self._flops(c, g),
-                    lambda: self._wgrad(x, dz, g, self.G[c.w_off:]), self._bytes(c, g, wgrad=True))
+                    lambda: self._wgrad(x, dz, g, self.G[c.w_off:]), self._bytes(c, g, wgrad=True), layer=c.name)
         if not need_dx:
             return None
         st = ops._stream()
@@ -902,7 +889,7 @@ class Engine:
         extra = ((dx_bytes / 4 if addend_half else dx_bytes) if addend is not None else 0.0) + (dx_bytes if bn is not None else 0.0) + \
                 (dx_bytes if relu_mask is not None else 0.0) + (dx_bytes / 16 if (bn is not None and relu_bits is not None) else 0.0) + \
                 (dx_bytes / 16 if (bn is None and relu_mask is None and mask_bits is not None and self.dgrad_mask_bits) else 0.0)
-        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra)
+        self._timed(f"conv_igemm_kernel<{128 if c.Ci > 64 else 64},dgrad>", self._flops(c, g), run, self._bytes(c, g) + extra, layer=c.name)
         return dx
 
     def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> None:
@@ -983,13 +970,13 @@ class Engine:
                     prev, pk = plan.blocks[i - 1], f"b{i - 1}"
                     gd = self._geom(blk.down, B, hi, wi)
                     self._timed(f"conv_wgrad_kernel<{128 if blk.down.Co > 64 else 64}>", self._flops(blk.down, gd),
-                                lambda: self._wgrad(x, dzd, gd, self.G[blk.down.w_off:]), self._bytes(blk.down, gd, wgrad=True))
+                                lambda: self._wgrad(x, dzd, gd, self.G[blk.down.w_off:]), self._bytes(blk.down, gd, wgrad=True), layer=blk.down.name)
                     gh = _lib.ConvGeom(B, gd.Ho, gd.Wo, blk.down.Ci, gd.Ho, gd.Wo, blk.down.Co, 1, 1, 1, 0)   # the shortcut on its own grid: stride 1
                     dd = torch.empty(B, gd.Ho, gd.Wo, blk.down.Ci, device=self.device, dtype=torch.bfloat16)
                     self._timed(f"conv_igemm_kernel<{128 if blk.down.Ci > 64 else 64},dgrad>", self._flops(blk.down, gd),
                                 lambda: check(self._lib.lp_conv_dgrad(_p(dzd), _p(self.Wd[blk.down.wd_off:]), C.byref(gh), None, None, None, _p(dd), None,
                                                                       blk.down.Ci, 0, 0, ops._stream()), "lp_conv_dgrad"),
-                                2.0 * B * gd.Ho * gd.Wo * (blk.down.Co + blk.down.Ci))
+                                2.0 * B * gd.Ho * gd.Wo * (blk.down.Co + blk.down.Ci), layer=blk.down.name)
                     d_sums = new_sums(prev.bn3)
                     d = self._conv_bwd(blk.conv1, x, dz1, B, hi, wi, True, addend=dd, addend_half=True,
                                        bn=(prev.bn3, T[f"{pk}.z3"], T[f"{pk}.m3"], T[f"{pk}.v3"], d_sums), relu_bits=xbits, seg=seg)
@@ -1039,5 +1026,5 @@ class Engine:
                                                  _p(self.G[sb.b_off:]), _p(self.G[sb.g_off:]), ops._stream()), "lp_bn_pool_bwd_apply")
         g = self._geom(plan.stem, B, H, W)
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
-                    lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True), self._bytes(plan.stem, g, wgrad=True))
+                    lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True), self._bytes(plan.stem, g, wgrad=True), layer=plan.stem.name)
         self._join_side_stream()

@@ -484,34 +484,6 @@ def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e
     return y.np(), mean.np(), invstd.np()
 
 
-def bn_forward_fused(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e-5, momentum=0.1, running=None, want_bits=False, seg_rows=0):
-    """lp_bn_stats per segment, then lp_bn_apply_seg_fin (finalisation inside the apply launch) -> (y, mean, invstd[, bits]); ``running`` updated"""
-    xb, rb = Buf(x_bits), B(residual_bits)
-    nseg = 2 if seg_rows else 1
-    sums, mean, invstd = ZX((nseg, 2, Cn)), Z(nseg * Cn), Z(nseg * Cn)
-    bounds = [(0, M)] if not seg_rows else [(0, seg_rows), (seg_rows, M - seg_rows)]
-    x2 = np.ascontiguousarray(x_bits).reshape(M, Cn)
-    for si, (r0, n) in enumerate(bounds):
-        ws = _reduce_ws(n, Cn)
-        part, ssum = Buf(np.ascontiguousarray(x2[r0:r0 + n])), ZX((2, Cn))
-        ok(lib().lp_bn_stats(part.p, n, Cn, ssum.p, ws.p, ws.nbytes, stream()))
-        sums_np = sums.np()
-        sums_np[si] = ssum.np()
-        sums = Buf(sums_np)
-    rm = Buf(running[0]) if running is not None else None
-    rv = Buf(running[1]) if running is not None else None
-    y, gb, bb = Z((M, Cn), np.uint16), Buf(f32(gamma)), Buf(f32(beta))
-    bits = Z(M * Cn // 8, np.uint8) if want_bits else None
-    counts = [float(n) for _, n in bounds]
-    ok(lib().lp_bn_apply_seg_fin(xb.p, sums.p, counts[0], counts[-1], eps, momentum, mean.p, invstd.p, ptr(rm), ptr(rv), gb.p, bb.p, ptr(rb),
-                                 int(relu), M, Cn, seg_rows, y.p, ptr(bits), stream()))
-    if running is not None:
-        running[0][:] = rm.np()
-        running[1][:] = rv.np()
-    out = (y.np(), mean.np(), invstd.np())
-    return out + (bits.np(),) if want_bits else out
-
-
 def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False, eval_mode=False, acc0=None, terms_ws=True):
     """-> (dx bits, dres bits, dgamma, dbeta): lp_bn_bwd_reduce, then lp_bn_bwd_apply (which also adds the sums into d beta / d gamma,
     starting from ``acc0`` = (dbeta0, dgamma0) if given).  eval_mode: no batch-statistics terms (sums = NULL)."""

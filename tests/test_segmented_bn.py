@@ -156,29 +156,6 @@ def test_non_finite_partials_poison_the_fixed_point_sum(kernel_backend):
     assert (np.abs(words[..., 1].astype(np.float64)) >= 2.0 ** 61).all()   # the `lo` words carry the poison
 
 
-@pytest.mark.parametrize("M,Cn,seg", [(640, 64, 0), (1024, 16, 384), (4096, 256, 1024), (33, 8, 0), (256, 2048, 128)])
-def test_finalisation_inside_the_apply_launch(kernel_backend, M, Cn, seg):
-    """lp_bn_apply_seg_fin (round 6: the stand-alone lp_bn_finalize launch in front of every lp_bn_apply folded into it) against the two
-    launches: output, ReLU bits, mean / invstd and the running statistics (two segments: updated in order) - the same bits."""
-    gen = torch.Generator().manual_seed(M + Cn + seg)
-    x = torch.randn(M, Cn, generator=gen) * 1.7 + 0.3
-    res = torch.randn(M, Cn, generator=gen)
-    xb, rb = emu.to_bf16_bits(x), emu.to_bf16_bits(res)
-    gamma, beta = (torch.rand(Cn, generator=gen) + 0.5).numpy(), torch.randn(Cn, generator=gen).numpy()
-    run_a = [np.full(Cn, 0.25, np.float32), np.full(Cn, 2.0, np.float32)]
-    run_b = [r.copy() for r in run_a]
-    ya, ma, va, ba = emu.bn_forward_fused(xb, M, Cn, gamma, beta, residual_bits=rb, relu=True, running=run_a, want_bits=True, seg_rows=seg)
-    bounds = [(0, M)] if not seg else [(0, seg), (seg, M - seg)]
-    ys, ms, vs, bs = [], [], [], []
-    for r0, n in bounds:   # the reference's two forward calls: each segment normalised with its own statistics, running statistics in order
-        y, m, v, b = emu.bn_forward(xb.reshape(M, Cn)[r0:r0 + n], n, Cn, gamma, beta, residual_bits=rb.reshape(M, Cn)[r0:r0 + n], relu=True,
-                                    running=run_b, want_bits=True)
-        ys.append(y), ms.append(m), vs.append(v), bs.append(b)
-    assert np.array_equal(ya.reshape(M, Cn), np.concatenate(ys)) and np.array_equal(ba, np.concatenate(bs))
-    assert np.array_equal(ma.view(np.uint32), np.concatenate(ms).view(np.uint32)) and np.array_equal(va.view(np.uint32), np.concatenate(vs).view(np.uint32))
-    assert np.array_equal(run_a[0].view(np.uint32), run_b[0].view(np.uint32)) and np.array_equal(run_a[1].view(np.uint32), run_b[1].view(np.uint32))
-
-
 @pytest.mark.parametrize("world", [2, 4, 8, 15])
 def test_poison_survives_the_sum_over_ranks(kernel_backend, world):
     """SyncBatchNorm ADDS the ranks' words modulo 2^64 (engine._sync_stats: all-reduce, or all-gather + torch.sum).  Round 5's
