@@ -651,18 +651,26 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
         }
         __syncthreads();
     }
-    // transpose through LDS (the tile is dead) so the map leaves in full rows
+    // transpose through LDS (the tile AND the strip behind it are dead) so the map leaves in full rows.  Rows padded to an odd pitch: consecutive
+    // lanes hold consecutive rows r of one column, and with the tile's own pitch w (96 words: a multiple of the 32 banks) all 32 lanes of a
+    // ds_write group hit ONE bank (round 6: ~9 k LDS cycles per map); pitch w | 1 spreads them over 32 banks.  h * (w | 1) <= h * (w + 65) floats.
+    const int wp = w | 1;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = tid + i * nthreads;
         if (e < h * w) {
             const int q = (int)(((float)e + 0.5f) * inv_h), r = e - q * h;
-            hs[r * w + q] = dacc[i];
+            hs[r * wp + q] = dacc[i];
         }
     }
     __syncthreads();
     float* dst = g_heat + (size_t)bk * h * w;
-    for (int i = tid; i < h * w; i += nthreads) dst[i] = accumulate ? dst[i] + hs[i] : hs[i];
+    const float inv_w = 1.f / (float)w;
+    for (int i = tid; i < h * w; i += nthreads) {
+        const int r = (int)(((float)i + 0.5f) * inv_w);   // exact for i < 2^22
+        const float v = hs[r * wp + (i - r * w)];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
 }
 
 // standalone keypoint epilogue (targets, or callers that decode elsewhere): kp_out = frame_map(kp_in); inverse-transpose
