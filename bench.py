@@ -312,7 +312,9 @@ def cpu_baseline_reference(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, 
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": round((n_lab + n_unlab) / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "reference",
-            "sample": f"{len(times)} timed full steps (training_step + backward + Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, "
+            "sample": f"frames/s of a {n_lab + n_unlab}-frame step, NOT of the {64 + 128}-frame batch the GPU line times (per-frame extrapolation from batch "
+                      f"{n_lab + n_unlab}: the reference's 192-frame fp32 step needs more host memory and minutes per step): "
+                      f"{len(times)} timed full steps (training_step + backward + Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, "
                       f"fp32, median {med:.2f} s/step; the reference's own SemiSupervisedHeatmapTracker / LossFactory / losses (verbatim modules from "
                       f"{'/root/reference' if R.REFERENCE_ROOT.startswith('/root/reference') else 'oracle/_ref (oracle/make_ref.py)'}; kornia / "
                       "torchvision restated by oracle/thirdparty.py) with heatmap_mse + temporal + pca_singleview (unimodal_mse is not in the "
@@ -357,7 +359,8 @@ def cpu_baseline(size: int, K: int, n_lab: int = 4, n_unlab: int = 8, steps: int
     steps = len(times)
     med = sorted(times)[len(times) // 2]
     return {"value": round((n_lab + n_unlab) / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed full steps (fwd+bwd+Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, fp32, "
+            "sample": f"frames/s of a {n_lab + n_unlab}-frame step (per-frame extrapolation from batch {n_lab + n_unlab}, not the 192-frame batch of the GPU line): "
+                      f"{steps} timed full steps (fwd+bwd+Adam) of {n_lab} labeled + {n_unlab} unlabeled {size}x{size} frames, fp32, "
                       f"median {med:.2f} s/step; oracle/restated.py OracleTracker + training_step (kind 'port': the torch fp32 restatement "
                       "that tests/ pin against the verbatim reference, with the bench's four losses: heatmap_mse + temporal + pca_singleview + unimodal_mse)"}
 
