@@ -91,6 +91,18 @@ def axis_tables(n: int, ds: int) -> dict[str, np.ndarray | int]:
         row_taps[j] = u[j * r:(j + 1) * r, base:base + ty]
     steps = np.diff(row_base)
     assert row_base[0] == 0 and row_base[-1] == n - ty and set(steps.tolist()) <= {0, 1}, "kernel needs unit window steps"
+    # lp_decode_bwd splits the row groups over up to 8 waves (csrc/decode.hip: decode_bwd_threads); a wave's rows of the LDS strip overlap its
+    # neighbours'.  The strip accumulation (owner stores, then the guests add in two phases by wave parity) is race-free while no input row has
+    # more than three contributing waves - true for every n up to 256 at every downsample factor (two everywhere except n = 65, ds = 1)
+    waves = max(1, min(8, n // ty))
+    seg = -(-n // waves)
+    cover = np.zeros(n, dtype=np.int32)
+    for k in range(waves):
+        j0, j1 = k * seg, min(n, (k + 1) * seg)
+        if j0 < j1:
+            cover[row_base[j0]:row_base[j1 - 1] + ty] += 1
+    if cover.min() < 1 or cover.max() > 3:
+        raise NotImplementedError(f"decode tables for n = {n}, downsample_factor = {ds}: a strip row with {int(cover.max())} contributing waves")
 
     # per output column: start + COL_TAPS taps
     tx = min(COL_TAPS, n)

@@ -623,12 +623,19 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                 if (base + t < guest_from) zs[(base + t) * LD + lane] = acc[t];
         }
         __syncthreads();   // every owner has stored
-        if (!(LP_DEC_PROBE & 8) && j0 < j1) {
+        // ... and the shared rows are added to what their owner stored: even waves, then odd waves.  (Neighbours only share with each other for
+        // every map size the trackers produce; where the clamped windows at the map's edge make THREE consecutive waves meet in a row - h = 65 at
+        // downsample_factor 1 is the one case up to 256 - its two guests are neighbours, hence of different parity, hence in different phases.
+        // ops.py refuses a table whose rows have four contributors.)
 #pragma unroll
-            for (int t = 0; t < TY; ++t)   // ... and the shared ones are added to what the wave below stored
-                if (base + t >= guest_from) zs[(base + t) * LD + lane] += acc[t];
+        for (int phase = 0; phase < 2; ++phase) {
+            if (!(LP_DEC_PROBE & 8) && j0 < j1 && (wave & 1) == phase) {
+#pragma unroll
+                for (int t = 0; t < TY; ++t)
+                    if (base + t >= guest_from) zs[(base + t) * LD + lane] += acc[t];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // dH[r][q] += sum_c Wst[r][c] * Ux[c][q]  over this strip's columns (columns past W hold zeros)
 #pragma unroll
         for (int i = 0; i < ((LP_DEC_PROBE & 1) ? 0 : NE); ++i) {

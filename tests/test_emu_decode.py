@@ -82,6 +82,28 @@ def test_decode_bwd_matches_autograd(shape, ds):
     np.testing.assert_allclose(g_heat, ref, atol=2e-3 * scale, rtol=0)
 
 
+@pytest.mark.parametrize("shape,ds", [((1, 2, 65, 65), 1), ((1, 2, 64, 64), 2), ((1, 3, 48, 48), 2), ((2, 17, 96, 96), 2), ((1, 2, 40, 56), 3)])
+def test_decode_bwd_strip_without_atomics_vs_fp64_autograd(kernel_backend, shape, ds):
+    """Round 6: the backward's LDS strip is written by owner stores and guest adds instead of LDS atomics (csrc/decode.hip).  Maps tall enough
+    for several waves - 96 x 96 is BASELINE's; 65 x 65 at downsample_factor 1 is the one size up to 256 where THREE waves meet in a strip row
+    (_tables.axis_tables checks the bound) - against autograd in fp64 through the restated reference decode; with the moments taken about the
+    tile's maximum the kernel is closer to the exact gradient than torch's own fp32, and it repeats bit for bit."""
+    if kernel_backend == "emu" and shape[1] * shape[2] * shape[3] > 20000:
+        shape = (1, 2) + shape[2:]   # (the emulator runs work-items as fibers: two maps of the full size are enough there)
+    gen = torch.Generator().manual_seed(sum(shape) + ds)
+    b, k, h, w = shape
+    heat = torch.softmax(3 * torch.randn(b, k, h * w, generator=gen), -1).reshape(shape)
+    h64 = heat.double().requires_grad_(True)
+    kp, _ = O.soft_argmax(h64, ds, 1000.0)
+    gk = torch.randn(kp.shape, generator=gen)
+    (kp * gk.double()).sum().backward()
+    _, _, _, stats = emu.decode_fwd(heat.numpy(), ds)
+    outs = [emu.decode_bwd(heat.numpy(), ds, stats, g_aug=gk.reshape(b, k, 2).numpy()) for _ in range(2)]
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    ref = h64.grad.numpy()
+    assert np.abs(outs[0] - ref).max() <= 5e-5 * np.abs(ref).max(), np.abs(outs[0] - ref).max() / np.abs(ref).max()
+
+
 def test_decode_bwd_through_frame_map(golden):
     g = golden("geometry")
     gen = torch.Generator().manual_seed(8)
