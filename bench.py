@@ -174,7 +174,7 @@ def build_model(dev, K: int, size: int, torch_seed: int = 0, backbone: str = "re
 
 def pmc_traffic():
     """Average HBM bytes per convolution launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
-    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r05_final.sh -> profiles/r05_pmc_traffic.json
+    separate runs, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes; profiles/r06_final.sh -> profiles/r06_pmc_traffic.json
     via profiles/summarize_pmc.py).  The counters need rocprofv3 around the process, so this is the committed measurement of the same
     workload, not a live one (``algorithmic_bytes_per_launch`` next to it IS computed live) - and it is only reported when it was taken
     on THESE kernels: the file records a digest of the convolution sources, and a file whose digest differs from the tree's is refused
@@ -187,7 +187,7 @@ def pmc_traffic():
                 h.update(fh.read())
     except OSError:
         return None, "kernel sources not found"
-    name = "r05_pmc_traffic.json"
+    name = "r06_pmc_traffic.json"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as fh:
             rec = json.load(fh)

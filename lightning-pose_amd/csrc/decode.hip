@@ -65,40 +65,46 @@ __device__ __forceinline__ void merge_softmax(float& m, float& s, float& sx, flo
 // moments RELATIVE to this point - (x0, y0) = R * (column, row) + R / 2 in up-sampled pixels - instead of from the map's corner: the
 // expectation of a peaked map is then a sum of offsets of a few pixels (fp32 resolves 1e-7 px there) instead of coordinates up to 384 (3e-5),
 // and the backward pass's (c - E[x]) keeps the digits the old form lost - its gradient noise against exact arithmetic fell from 5e-5 to the
-// reference's own 5e-6 (tests/test_trajectory_vs_reference.py).  Forward and backward both derive the point from the tile itself, so the
-// `stats` they exchange carry only the small offsets.  `red` holds >= 2 * nwaves floats; order-independent (value, then lowest index).
+// reference's own 5e-6.  Forward and backward both derive the point from the tile itself, so the
+// `stats` they exchange carry only the small offsets.  Order-independent (value, then lowest index): both kernels find the same point.
 #ifndef LP_DEC_CENTER
 #define LP_DEC_CENTER 1   // (A/B builds: 0 = moments from the map's corner, rounds 1 - 5)
 #endif
-__device__ __forceinline__ int tile_argmax(const float* hs, int n, float* red) {
-    if (!LP_DEC_CENTER) return -1;
-    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+// The tile is staged into LDS and its maximum found in the SAME pass: every thread tracks the largest value it copied, the waves' candidates
+// meet in `am` (2 x 8 words of their own: nothing else ever touches them) across the barrier that publishes the tile anyway.  (The first
+// form of round 6 scanned the staged tile in a pass of its own between three more barriers: forward +13 %, profiles/r06d_decode_ab.txt.)
+// Call `tile_stage` in every thread, then a `__syncthreads()`, then `tile_argmax_read`.
+__device__ __forceinline__ void tile_stage(const float* __restrict__ src, float* hs, int n, float* am) {
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < n; i += nthreads) {
-        const float v = hs[i];
-        if (v > bv) bv = v, bi = i;
+        const float v = src[i];
+        hs[i] = v;
+        if (LP_DEC_CENTER && v > bv) bv = v, bi = i;
     }
+    if (!LP_DEC_CENTER) return;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const float ov = __shfl_xor(bv, d, 64);
         const int oi = __shfl_xor(bi, d, 64);
         if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
     }
-    __syncthreads();   // (whatever used `red` before is done with it)
     if (lane == 0) {
-        red[wave] = bv;
-        red[8 + wave] = __int_as_float(bi);
+        am[wave] = bv;
+        am[8 + wave] = __int_as_float(bi);
     }
-    __syncthreads();
-    bv = red[0];
-    bi = __float_as_int(red[8]);
+}
+__device__ __forceinline__ int tile_argmax_read(const float* am) {
+    if (!LP_DEC_CENTER) return -1;
+    const int nwaves = blockDim.x >> 6;
+    float bv = am[0];
+    int bi = __float_as_int(am[8]);
     for (int i = 1; i < nwaves; ++i) {
-        const float ov = red[i];
-        const int oi = __float_as_int(red[8 + i]);
+        const float ov = am[i];
+        const int oi = __float_as_int(am[8 + i]);
         if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
     }
-    __syncthreads();   // (`red` is free again)
     return __builtin_amdgcn_readfirstlane(bi == 0x7fffffff ? 0 : bi);   // (a tile of NaNs / -inf: any point will do, the outputs are NaN anyway; the same in every lane: a scalar)
 }
 
@@ -260,10 +266,11 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
     const auto row_base = as_uniform(tb.row_base);   // (wave-uniform indices: scalar loads, lp_common.h: as_uniform)
     const auto row_taps = as_uniform(tb.row_taps);
     const float* src = heat + (size_t)bk * h * w;
-    for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
+    __shared__ float am[16];
+    tile_stage(src, hs, h * w, am);
     __syncthreads();
-    // the point the moments are taken about (tile_argmax): whole numbers, so (column - x0) and (row - y0) are exact
-    const int amax = tile_argmax(hs, h * w, red);
+    // the point the moments are taken about (the tile's maximum): whole numbers, so (column - x0) and (row - y0) are exact
+    const int amax = tile_argmax_read(am);
     const float y0 = amax < 0 ? 0.f : (float)((amax / w) * R + R / 2), x0 = amax < 0 ? 0.f : (float)((amax % w) * R + R / 2);
 
     // ---- pruning set-up: bounds from the tile, and a LOWER bound of the final maximum from the row group at the tile's largest row
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
     const auto row_taps = as_uniform(tb.row_taps);
 
     const float* src = heat + (size_t)bk * h * w;
-    for (int i = tid; i < h * w; i += nthreads) hs[i] = src[i];
+    __shared__ float am[16];
+    tile_stage(src, hs, h * w, am);
     for (int i = tid; i < w * tb.TC; i += nthreads) {
         const int q = i / tb.TC;
         lt[q * TCP + (i - q * tb.TC)] = tb.colT_taps[i];
@@ -499,12 +507,11 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
         gy += ay;
     }
     const float m = stats[bk * 4 + 0], inv_s = 1.f / stats[bk * 4 + 1];
-    const float dex = stats[bk * 4 + 2], dey = stats[bk * 4 + 3];   // E[x] - x0, E[y] - y0 (x0, y0: tile_argmax, below)
+    const float dex = stats[bk * 4 + 2], dey = stats[bk * 4 + 3];   // E[x] - x0, E[y] - y0 (x0, y0: the tile's maximum, below)
     const float gxt = gx * temperature, gyt = gy * temperature;
 
     __syncthreads();  // the staged tile is complete
-    // (zs is not in use yet: scratch for the reduction)
-    const int amax = tile_argmax(hs, h * w, zs);
+    const int amax = tile_argmax_read(am);
     const float y0 = amax < 0 ? 0.f : (float)((amax / w) * R + R / 2), x0 = amax < 0 ? 0.f : (float)((amax % w) * R + R / 2);
     // pruning (see "exact pruning at high temperature"): here the exact maximum is known from the forward pass
     float ly = 0.f;
