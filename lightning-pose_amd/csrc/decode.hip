@@ -369,17 +369,20 @@ __global__ __launch_bounds__(512) void decode_fwd_kernel(const float* __restrict
             }
             if (!valid) continue;
             const float sc = (m == -INFINITY) ? 0.f : __expf(m - gm);
-            s *= sc;
-            sx *= sc;
-            sy *= sc;
             m = gm;
+            // the row group's R terms are summed first (their column is the lane's, their rows are j R + 0 .. R - 1): one update of each moment
+            // per row GROUP instead of per row - 10 vector operations where the per-row form took 16 (round 6: with the moments taken about
+            // (x0, y0) the per-row form cost the kernel 12 %, profiles/r06g_decode_ab.txt)
+            float es = 0.f, ew = 0.f;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 const float e = __expf(z[rr] - gm);
-                s += e;
-                sx = fmaf(e, xc, sx);
-                sy = fmaf(e, (float)(j * R + rr) - y0, sy);
+                es += e;
+                ew = fmaf(e, (float)rr, ew);
             }
+            s = fmaf(s, sc, es);
+            sx = fmaf(sx, sc, es * xc);
+            sy = fmaf(sy, sc, fmaf(es, (float)(j * R) - y0, ew));
         }
     }
 
@@ -612,6 +615,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                     have = true;
                 }
                 const auto taps = row_taps + (size_t)j * R * TY;
+                const float gj = fmaf(gyl, ((float)(j * R) - y0) - dey, dxc);   // T (gx (c - E[x]) + gy (row j R - E[y])): the row group's part, once
                 // (one output row at a time for the widest tables: unrolled, the R x TY taps of a row group - 88 scalars at ds = 3 - do not
                 //  fit the scalar file and come back as spilled VECTOR registers)
 #pragma unroll (R * TY <= LP_DEC_RR_FULL ? R : LP_DEC_RR_PART)
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
 #pragma unroll
                     for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], win[t], y);
                     const float p = __expf(y * temperature - m) * inv_s;
-                    const float g = p * (dxc + gyl * (((float)(j * R + rr) - y0) - dey));
+                    const float g = p * fmaf(gyl, (float)rr, gj);
 #pragma unroll
                     for (int t = 0; t < TY; ++t) acc[t] = fmaf(taps[rr * TY + t], g, acc[t]);
                 }
