@@ -415,6 +415,14 @@ int lp_bn_apply(const void* x, const float* mean, const float* invstd, const flo
  * [and of sums (2, 2, C), with count0], the other rows use row 1 [count1] */
 int lp_bn_apply_seg(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
                     int relu, int M, int C, int seg_rows, void* y, void* relu_bits, lp_stream_t stream);
+/* The block-output pass of the optional "fp32 residual stream" policy (round 6; LP_RESIDUAL_FP32=1 in the engine - not the benchmarked default):
+ * a block output o is kept as a bf16 pair, y = bf16(o) (what the convolutions read) and y_lo = bf16(o - y) (may be NULL: nobody adds this
+ * output as an identity shortcut), and the residual added here is `residual` + `residual_lo` (the previous block's pair; residual_lo may be
+ * NULL) or - `zd` given, residual / residual_lo NULL - the projection shortcut zd normalised in this pass and added unrounded.  Otherwise as
+ * lp_bn_apply_seg / lp_bn_apply_seg_rbn.  (The reference keeps fp32 activations throughout: train.py:411-428.) */
+int lp_bn_apply_seg_lo(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
+                       const void* residual_lo, const void* zd, const float* mean_d, const float* invstd_d, const float* gamma_d,
+                       const float* beta_d, int relu, int M, int C, int seg_rows, void* y, void* y_lo, void* relu_bits, lp_stream_t stream);
 /* lp_bn_apply_seg whose residual is a PRE-normalisation tensor with its own BatchNorm (a block's projection shortcut, round 5): the shortcut is
  * normalised in the same pass - rounded to bf16 as its own lp_bn_apply would have stored it - instead of being written and read back.
  * Bit-identical to lp_bn_apply_seg(zd -> idt, no ReLU) followed by lp_bn_apply_seg(x, ..., residual = idt).

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "lp_bn_finalize2": (_I, [_P, _F, _F, _I, _F, _F, _P, _P, _P, _P, _P]),
     "lp_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "lp_bn_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "lp_bn_apply_seg_lo": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "lp_bn_apply_seg_rbn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "lp_bn_bwd_apply_seg": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "lp_bn_bwd_ds_workspace_bytes": (_Z, [_I, _I]),

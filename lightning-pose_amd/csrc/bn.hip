@@ -205,12 +205,21 @@ struct BnResidualBn {
 // storing the moments and the running statistics): bit-identical and 2.4 % SLOWER per step (42.15 -> 43.12 ms, three alternating pairs) - the
 // 327 k lanes re-read 256 B of sums each where they read 64 B of finished moments, a third more load traffic than the launch's own stream;
 // retired with its measurement (profiles/retired/r06_bn_apply_fin.patch, profiles/r06b_step_ab.txt, r06c_step_ab.txt).
-template <bool RBN>
-__global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
+// LO = true (round 6, lp_bn_apply_seg_lo: the "fp32 residual stream" policy, LP_RESIDUAL_FP32=1 - NOT the benchmarked default): a block output
+// o is kept as a bf16 PAIR, hi = bf16(o) (what every convolution reads, as before) and lo = bf16(o - hi), and the next identity block adds
+// hi + lo (16 mantissa bits) instead of hi; a projection shortcut normalised in this pass (RBN) is added unrounded.  Own instantiations (4 waves
+// per SIMD: the second residual stream is 16 more registers), so the default walk is untouched.  What it buys and costs: DESIGN.md section 3.
+struct BnResidualLo {
+    const unsigned short* residual_lo;   // [M][C] bf16 or nullptr
+    unsigned short* y_lo;                // [M][C] bf16 or nullptr
+};
+template <bool RBN, bool LO = false>
+__global__ __launch_bounds__(256, (RBN || LO) ? 4 : 5) void bn_apply_kernel(const unsigned short* __restrict__ X, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const unsigned short* __restrict__ residual,
                                                        int relu, size_t n_total, int C, unsigned short* __restrict__ Y,
-                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb) {
+                                                       unsigned char* __restrict__ bits, size_t seg_chunk, BnResidualBn rb,
+                                                       BnResidualLo rl = BnResidualLo{}) {
     // Two BatchNorm segments in one launch (seg_chunk > 0: chunks [0, seg_chunk) use mean / invstd row 0, the rest row 1; the boundary is
     // a whole number of rows): the walk runs once per segment with that segment's terms in registers; a lane keeps its channel chunk
     // because every start is congruent to its global index modulo the stride.
@@ -240,7 +249,8 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
     }
     constexpr int U = 4;
     for (; q < n_chunks; q += U * stride) {
-        u16x8 xv[U], rv[U];
+        constexpr bool kRLo = LO && !RBN;   // (a projection shortcut has no lo word: it is added unrounded)
+        u16x8 xv[U], rv[U], rlv[kRLo ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (q + u * stride < n_chunks) xv[u] = load_stream8(X + (q + u * stride) * 8);
@@ -248,6 +258,11 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (q + u * stride < n_chunks) rv[u] = *reinterpret_cast<const u16x8*>(residual + (q + u * stride) * 8);
+        }
+        if (kRLo && rl.residual_lo != nullptr) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q + u * stride < n_chunks) rlv[kRLo ? u : 0] = load_stream8(rl.residual_lo + (q + u * stride) * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -259,9 +274,18 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
             if (residual != nullptr) {
                 float r[8];
                 unpack8(rv[u], r);
-                if (RBN) {   // the shortcut's own lp_bn_apply (no ReLU), rounded to bf16 as that pass stored it
+                if (RBN) {   // the shortcut's own lp_bn_apply (no ReLU), rounded to bf16 as that pass stored it (LO: added unrounded)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) r[i] = bf16_to_f32(f32_to_bf16(fmaf(r[i] - mud[RBN ? i : 0], scd[RBN ? i : 0], bed[RBN ? i : 0])));
+                    for (int i = 0; i < 8; ++i) {
+                        const float nd = fmaf(r[i] - mud[RBN ? i : 0], scd[RBN ? i : 0], bed[RBN ? i : 0]);
+                        r[i] = LO ? nd : bf16_to_f32(f32_to_bf16(nd));
+                    }
+                }
+                if (kRLo && rl.residual_lo != nullptr) {
+                    float rl8[8];
+                    unpack8(rlv[kRLo ? u : 0], rl8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) r[i] += rl8[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] += r[i];
@@ -270,7 +294,15 @@ __global__ __launch_bounds__(256, RBN ? 4 : 5) void bn_apply_kernel(const unsign
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], 0.f);
             }
-            *reinterpret_cast<u16x8*>(Y + (q + u * stride) * 8) = pack8(o);
+            const u16x8 hi8 = pack8(o);
+            *reinterpret_cast<u16x8*>(Y + (q + u * stride) * 8) = hi8;
+            if (LO && rl.y_lo != nullptr) {   // what bf16 dropped of this output, itself in bf16
+                float h8[8], l8[8];
+                unpack8(hi8, h8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) l8[i] = o[i] - h8[i];
+                *reinterpret_cast<u16x8*>(rl.y_lo + (q + u * stride) * 8) = pack8(l8);
+            }
             if (bits != nullptr) {  // 1-bit ReLU mask: o > 2^-134 is exactly "the stored bf16 is > 0"
                 unsigned m = 0;
 #pragma unroll
@@ -1059,6 +1091,31 @@ extern "C" int lp_bn_apply_seg_rbn(const void* x, const float* mean, const float
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean, invstd,
                        gamma, beta, (const unsigned short*)zd, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
                        (size_t)seg_rows * (C / 8), BnResidualBn{mean_d, invstd_d, gamma_d, beta_d});
+    return launch_status();
+}
+
+// The block-output pass of the "fp32 residual stream" policy (bn_apply_kernel<.., LO>): residual = hi [+ residual_lo], or - zd given - the
+// projection shortcut zd normalised here with (mean_d, invstd_d, gamma_d, beta_d) and added UNROUNDED; y = bf16 of the result, y_lo (optional)
+// = bf16(result - y).  Everything else as lp_bn_apply_seg / lp_bn_apply_seg_rbn.
+extern "C" int lp_bn_apply_seg_lo(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const void* residual,
+                                  const void* residual_lo, const void* zd, const float* mean_d, const float* invstd_d, const float* gamma_d,
+                                  const float* beta_d, int relu, int M, int C, int seg_rows, void* y, void* y_lo, void* relu_bits,
+                                  lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(x && mean && invstd && gamma && beta && y && M > 0 && C > 0 && seg_rows >= 0 && seg_rows < M);
+    LP_REQUIRE((zd == nullptr) || (mean_d && invstd_d && gamma_d && beta_d && residual == nullptr && residual_lo == nullptr));
+    LP_REQUIRE(residual_lo == nullptr || residual != nullptr);
+    if (C % 8 != 0) return LP_ERR_UNSUPPORTED;
+    const size_t n_chunks = (size_t)M * (C / 8);
+    const BnResidualLo rl{(const unsigned short*)residual_lo, (unsigned short*)y_lo};
+    if (zd != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean,
+                           invstd, gamma, beta, (const unsigned short*)zd, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
+                           (size_t)seg_rows * (C / 8), BnResidualBn{mean_d, invstd_d, gamma_d, beta_d}, rl);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(bn_grid(n_chunks, C / 8)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, mean,
+                           invstd, gamma, beta, (const unsigned short*)residual, relu, n_chunks, C, (unsigned short*)y, (unsigned char*)relu_bits,
+                           (size_t)seg_rows * (C / 8), BnResidualBn{}, rl);
     return launch_status();
 }
 

@@ -615,7 +615,10 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
                     have = true;
                 }
                 const auto taps = row_taps + (size_t)j * R * TY;
-                const float gj = fmaf(gyl, ((float)(j * R) - y0) - dey, dxc);   // T (gx (c - E[x]) + gy (row j R - E[y])): the row group's part, once
+                // T (gx (c - E[x]) + gy (row j R - E[y])): the row group's part, once.  (R = 2 - downsample_factor 1 - keeps the per-row form: with one
+                // more value alive across its row loop that instantiation spilled a register, tests/test_kernel_resources.py)
+                constexpr bool kGroupCoef = R != 2;
+                const float gj = kGroupCoef ? fmaf(gyl, ((float)(j * R) - y0) - dey, dxc) : 0.f;
                 // (one output row at a time for the widest tables: unrolled, the R x TY taps of a row group - 88 scalars at ds = 3 - do not
                 //  fit the scalar file and come back as spilled VECTOR registers)
 #pragma unroll (R * TY <= LP_DEC_RR_FULL ? R : LP_DEC_RR_PART)
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(512, (NE <= 18 ? 4 : 2)) void decode_bwd_kernel(con
 #pragma unroll
                     for (int t = 0; t < TY; ++t) y = fmaf(taps[rr * TY + t], win[t], y);
                     const float p = __expf(y * temperature - m) * inv_s;
-                    const float g = p * fmaf(gyl, (float)rr, gj);
+                    const float g = kGroupCoef ? p * fmaf(gyl, (float)rr, gj) : p * (dxc + gyl * (((float)(j * R + rr) - y0) - dey));
 #pragma unroll
                     for (int t = 0; t < TY; ++t) acc[t] = fmaf(taps[rr * TY + t], g, acc[t]);
                 }

@@ -191,6 +191,7 @@ class Engine:
     dgrad_mask_bits = True
     bn_bwd_ds = True
     bn_apply_rbn = True
+    residual_fp32 = False
     dgrad_half_addend = True
 
     def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
@@ -230,6 +231,9 @@ class Engine:
         self.dgrad_half_addend = os.environ.get("LP_DGRAD_HALF_ADDEND", "1") != "0"   # (0: conv1 first, the shortcut accumulates in place, stand-alone reduction)
         self.bn_apply_rbn = os.environ.get("LP_BN_APPLY_RBN", "1") != "0"   # (0: the projection shortcut normalised by a pass of its own, lp_bn_apply_seg)
         self.bn_bwd_ds = os.environ.get("LP_BN_BWD_DS", "1") != "0"   # (0: the projection shortcut's BatchNorm reductions as a pass of their own, lp_bn_bwd_reduce)
+        # The optional "fp32 residual stream" policy (round 6): block outputs that the next block adds as an identity shortcut
+        # are kept as a bf16 pair (hi + lo), a projection shortcut is added unrounded.  NOT the benchmarked default: +3.9 % of the step's HBM time.
+        self.residual_fp32 = os.environ.get("LP_RESIDUAL_FP32", "0") == "1"
         self.dgrad_mask_bits = os.environ.get("LP_DGRAD_MASK_BITS", "1") != "0"   # (0: the two data gradients into a layer's first block read the bf16 activation as mask)
         self._gather_buf: torch.Tensor | None = None
         self._lib = _lib.lib()
@@ -533,7 +537,7 @@ class Engine:
         return mean, invstd
 
     def _bn_fwd(self, b: BNP, z: torch.Tensor, M: int, residual: torch.Tensor | None, relu: bool, training: bool, sums: torch.Tensor,
-                have_sums: bool = False, want_bits: bool = False, seg: int = 0, residual_bn=None):
+                have_sums: bool = False, want_bits: bool = False, seg: int = 0, residual_bn=None, pair=None):
         """-> (y, mean, invstd[, relu_bits]); ``want_bits``: also the 1-bit ReLU mask (M*C/8 bytes) for the backward pass.
         ``residual_bn`` = (BNP, mean_d, invstd_d): ``residual`` is the PRE-normalisation tensor of the block's projection shortcut, normalised
         inside this pass (lp_bn_apply_seg_rbn) instead of by a pass of its own that writes the normalised shortcut and this one reads back."""
@@ -544,7 +548,20 @@ class Engine:
         rpi = M // B
         gam, bet = _p(self.param_view(b, "weight")), _p(self.param_view(b, "bias"))
         # both segments in ONE launch (the kernel walks each segment with that segment's terms in registers)
-        if residual_bn is not None:
+        if pair is not None:
+            # fp32-residual policy: ``pair`` = (residual_lo or None, y_lo or None): lp_bn_apply_seg_lo adds hi + lo (or the unrounded
+            # normalised shortcut) and leaves this output's own lo word for the next identity block
+            res_lo, y_lo = pair
+            if residual_bn is not None:
+                bd, md, vd = residual_bn
+                check(self._lib.lp_bn_apply_seg_lo(_p(z), _p(mean), _p(invstd), gam, bet, None, None, _p(residual), _p(md), _p(vd),
+                                                   _p(self.param_view(bd, "weight")), _p(self.param_view(bd, "bias")), int(relu), M, b.C,
+                                                   (seg if training else 0) * rpi, _p(y), _p(y_lo), _p(bits), ops._stream()), "lp_bn_apply_seg_lo")
+            else:
+                check(self._lib.lp_bn_apply_seg_lo(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), _p(res_lo), None, None, None, None, None,
+                                                   int(relu), M, b.C, (seg if training else 0) * rpi, _p(y), _p(y_lo), _p(bits), ops._stream()),
+                      "lp_bn_apply_seg_lo")
+        elif residual_bn is not None:
             bd, md, vd = residual_bn
             check(self._lib.lp_bn_apply_seg_rbn(_p(z), _p(mean), _p(invstd), gam, bet, _p(residual), _p(md), _p(vd), _p(self.param_view(bd, "weight")),
                                                 _p(self.param_view(bd, "bias")), int(relu), M, b.C, (seg if training else 0) * rpi, _p(y), _p(bits),
@@ -664,7 +681,7 @@ class Engine:
             check(self._lib.lp_images_to_nhwc4(_p(p_), p_.shape[0], H, W, _p(x4[i0:]), ops._stream()), "lp_images_to_nhwc4")
             i0 += p_.shape[0]
         T["x4"] = x4
-        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu, bits_key=None, residual_bn=None, apply=True):
+        def conv_bn(c: ConvP, b: BNP, xin, hh, ww, residual, relu, bits_key=None, residual_bn=None, apply=True, pair=None):
             """conv -> BatchNorm(+residual)(+ReLU); in training the statistics come out of the convolution's store pass.
             ``bits_key``: keep the output's 1-bit ReLU mask on the tape (block outputs: their backward reads it instead of the
             activation itself).  ``apply=False``: convolution and moments only (the projection shortcut, normalised later inside the
@@ -675,7 +692,7 @@ class Engine:
                 mm, vv = self._bn_moments(b, zz, B * gg.Ho * gg.Wo, training, sums, training, seg)
                 return zz, None, mm, vv, gg
             res = self._bn_fwd(b, zz, B * gg.Ho * gg.Wo, residual, relu, training, sums, have_sums=training,
-                               want_bits=bits_key is not None and training, seg=seg, residual_bn=residual_bn)
+                               want_bits=bits_key is not None and training, seg=seg, residual_bn=residual_bn, pair=pair)
             if len(res) == 4:
                 T[bits_key] = res[3]
             aa, mm, vv = res[:3]
@@ -698,6 +715,7 @@ class Engine:
         h, w = ph, pw
         tp.meta["stem_hw"] = (g.Ho, g.Wo)
 
+        x_lo = None   # fp32-residual policy: the lo word of x (the previous block's output), when the previous block left one
         for i, blk in enumerate(plan.blocks):
             key = f"b{i}"
             T[f"{key}.x"] = x
@@ -714,7 +732,16 @@ class Engine:
                     idt, rbn = zd, (blk.dbn, md, vd)
             else:
                 idt = x
-            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits", residual_bn=rbn)
+            pair = None
+            if self.residual_fp32 and (rbn is not None or blk.down is None):
+                # this output gets a lo word iff the NEXT block adds it as an identity shortcut (a layer's last block and the trunk's: nobody does)
+                nxt_identity = i + 1 < len(plan.blocks) and plan.blocks[i + 1].down is None
+                y_lo = torch.empty(B, ho, wo, blk.bn3.C, device=self.device, dtype=torch.bfloat16) if nxt_identity else None
+                pair = (x_lo if blk.down is None else None, y_lo)
+            z3, out, m3, v3, _ = conv_bn(blk.conv3, blk.bn3, a2, ho, wo, idt, True, bits_key=f"{key}.out_bits", residual_bn=rbn, pair=pair)
+            x_lo = pair[1] if pair is not None else None
+            if x_lo is not None:
+                T[f"{key}.out_lo"] = x_lo   # (not needed by the backward pass: kept for inspection, freed with the tape)
             for nm, val in (("z1", z1), ("a1", a1), ("m1", m1), ("v1", v1), ("z2", z2), ("a2", a2), ("m2", m2), ("v2", v2),
                             ("z3", z3), ("m3", m3), ("v3", v3), ("out", out)):
                 if val is not None:

@@ -123,6 +123,8 @@ class HeatmapTracker(BaseSupervisedTracker):
                     top, _, rest = k.partition(".")
                     if top in names and f"{names[top]}.{rest}" in init:
                         init[f"{names[top]}.{rest}"] = v
+        if kwargs.get("residual_fp32") is not None and hasattr(self.net, "residual_fp32"):
+            self.net.residual_fp32 = bool(kwargs["residual_fp32"])   # (optional policy; default: LP_RESIDUAL_FP32, off)
         self.net.load_state_dict(init, strict=False)
         self._bind_parameters()
         self._anchor = torch.zeros(1, device=device, requires_grad=True)

@@ -646,6 +646,22 @@ class _RoundGrad(torch.autograd.Function):
         return g.to(torch.bfloat16).float()
 
 
+class _PairRound(torch.autograd.Function):
+    """A block output kept as a bf16 PAIR (the "fp32 residual stream" policy, lp_bn_apply_seg_lo): -> (hi, hi + lo) with hi = bf16(y), lo =
+    bf16(y - hi).  The convolutions read hi, the next identity shortcut adds hi + lo.  Backward: the two gradients are summed and rounded to
+    bf16 once, as the product's data-gradient store pass does (and as `_q` does for the single-word policy)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        hi = y.to(torch.bfloat16).float()
+        lo = (y - hi).to(torch.bfloat16).float()
+        return hi, hi + lo
+
+    @staticmethod
+    def backward(ctx, g_hi, g_carried):
+        return (g_hi + g_carried).to(torch.bfloat16).float()
+
+
 def _bn_train(z: torch.Tensor, bn: nn.BatchNorm2d, residual: torch.Tensor | None, relu: bool, q=None) -> torch.Tensor:
     y = F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, training=True, momentum=bn.momentum, eps=bn.eps)
     if residual is not None:
@@ -663,7 +679,9 @@ def forward_bf16_policy(model: OracleTracker, images: torch.Tensor, rounding: tu
     policy the product implements; () = the fp32 reference itself.  Finer tags switch on parts of "trunk" only (the per-stage ablation,
     profiles/r04_rounding_stages.json): a STAGE - "stem", "layer1" .. "layer4" = every rounding point inside it - or a KIND across all
     stages - "trunk:w" weights, "trunk:z" convolution outputs (the pre-normalisation tensors), "trunk:a" the activations inside a block
-    (outputs of bn1 / bn2, the stem's pooled activation), "trunk:res" the residual stream (block outputs, shortcut projections)."""
+    (outputs of bn1 / bn2, the stem's pooled activation), "trunk:res" the residual stream (block outputs, shortcut projections).
+    "res32" (with "trunk" / "trunk:res" on): the OPTIONAL policy of round 6 (Engine.residual_fp32, LP_RESIDUAL_FP32=1) - a block output is a
+    bf16 pair, the identity shortcut of the next block adds hi + lo, a projection shortcut is added unrounded (`_PairRound`)."""
     ident = lambda t: t  # noqa: E731
 
     def qt(stage: str, kind: str):
@@ -675,18 +693,23 @@ def forward_bf16_policy(model: OracleTracker, images: torch.Tensor, rounding: tu
     x = qt("stem", "z")(F.conv2d(x, qt("stem", "w")(bb[0].weight), stride=2, padding=3))
     x = _bn_train(x, bb[1], None, True, q=qt("stem", "a"))
     x = F.max_pool2d(x, 3, 2, 1)
+    carried = None   # ("res32": the previous block's output as hi + lo)
     for li, layer in enumerate((bb[4], bb[5], bb[6], bb[7])):
         st = f"layer{li + 1}"
         qw, qz, qa, qr = qt(st, "w"), qt(st, "z"), qt(st, "a"), qt(st, "res")
+        pair = "res32" in rounding and qr is _q
         for blk in layer:
-            idt = x
+            idt = carried if (pair and carried is not None and blk.downsample is None) else x
             o = _bn_train(qz(F.conv2d(x, qw(blk.conv1.weight))), blk.bn1, None, True, q=qa)
             o = _bn_train(qz(F.conv2d(o, qw(blk.conv2.weight), stride=blk.stride, padding=1)), blk.bn2, None, True, q=qa)
             z3 = qz(F.conv2d(o, qw(blk.conv3.weight)))
             if blk.downsample is not None:
                 zd = qz(F.conv2d(x, qw(blk.downsample[0].weight), stride=blk.stride))
-                idt = _bn_train(zd, blk.downsample[1], None, False, q=qr)
-            x = _bn_train(z3, blk.bn3, idt, True, q=qr)
+                idt = _bn_train(zd, blk.downsample[1], None, False, q=ident if pair else qr)
+            if pair:
+                x, carried = _PairRound.apply(_bn_train(z3, blk.bn3, idt, True, q=ident))
+            else:
+                x = _bn_train(z3, blk.bn3, idt, True, q=qr)
     x = F.pixel_shuffle(x, 2)
     cts = [m for m in model.head.upsampling_layers if isinstance(m, nn.ConvTranspose2d)]
     for i, ct in enumerate(cts):

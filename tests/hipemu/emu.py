@@ -484,6 +484,19 @@ def bn_forward(x_bits, M, Cn, gamma, beta, residual_bits=None, relu=True, eps=1e
     return y.np(), mean.np(), invstd.np()
 
 
+def bn_apply_lo(x_bits, mean, invstd, gamma, beta, M, Cn, residual_bits=None, residual_lo_bits=None, zd_bits=None, dbn=None, relu=True, want_lo=True,
+                seg_rows=0):
+    """lp_bn_apply_seg_lo -> (y bits, y_lo bits or None, relu bits); ``dbn`` = (mean_d, invstd_d, gamma_d, beta_d) with ``zd_bits``"""
+    xb, rb, rlb, zb = Buf(x_bits), B(residual_bits), B(residual_lo_bits), B(zd_bits)
+    mb, vb, gb, bb = Buf(f32(mean)), Buf(f32(invstd)), Buf(f32(gamma)), Buf(f32(beta))
+    d = [Buf(f32(a)) for a in dbn] if dbn is not None else [None] * 4
+    y, ylo = Z((M, Cn), np.uint16), (Z((M, Cn), np.uint16) if want_lo else None)
+    bits = Z(M * Cn // 8, np.uint8)
+    ok(lib().lp_bn_apply_seg_lo(xb.p, mb.p, vb.p, gb.p, bb.p, ptr(rb), ptr(rlb), ptr(zb), ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), int(relu), M, Cn,
+                                seg_rows, y.p, ptr(ylo), bits.p, stream()))
+    return y.np(), (ylo.np() if ylo is not None else None), bits.np()
+
+
 def bn_backward(dy_bits, y_bits, x_bits, mean, invstd, gamma, M, Cn, want_dres=False, eval_mode=False, acc0=None, terms_ws=True):
     """-> (dx bits, dres bits, dgamma, dbeta): lp_bn_bwd_reduce, then lp_bn_bwd_apply (which also adds the sums into d beta / d gamma,
     starting from ``acc0`` = (dbeta0, dgamma0) if given).  eval_mode: no batch-statistics terms (sums = NULL)."""

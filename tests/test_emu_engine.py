@@ -156,3 +156,49 @@ def test_engine_forward_backward_blockwise(stack_backend, joint, monkeypatch):
     close("backbone.1.bias", G["backbone.1.bias"], bb[1].bias.grad)
     print("\nMARGINS lowest cos:", [(round(c, 5), n) for c, _, n in sorted(MARGINS)[:3]],
           "largest |ratio - 1|:", [(round(r, 4), n) for _, r, n in sorted(MARGINS, key=lambda m: -m[1])[:3]])
+
+
+def test_engine_residual_stream_as_bf16_pairs(stack_backend):
+    """Engine.residual_fp32 (LP_RESIDUAL_FP32=1; round 6, optional - DESIGN.md section 3): every block output that the next block adds as an
+    identity shortcut carries a lo word, out + out_lo reproduces relu(bn3(z3) + shortcut) in fp32 - with the shortcut = the previous pair, or the
+    projection's BatchNorm output UNROUNDED - and the hi word is its bf16 rounding; the backward pass runs on the same tape.  Block by block
+    from the engine's own tensors (see the module docstring)."""
+    dev = stack_backend
+    from lightning_pose_amd.engine import Engine
+    from lightning_pose_amd.models.backbones._init import seeded_state_dict
+
+    K, HW, B = 3, 64, 4
+    torch.manual_seed(7)
+    sd = seeded_state_dict(K, 2)
+    gen = torch.Generator().manual_seed(1)
+    eng = Engine(K, 2, dev)
+    eng.residual_fp32 = True
+    eng.load_state_dict(sd, strict=False)
+    ref = O.OracleTracker(K, 2, torch_seed=7)
+    ref.load_state_dict(sd, strict=False)
+    ref.train()
+    images = torch.randn(B, 3, HW, HW, generator=gen)
+    heat, tape = eng.forward(images.to(dev), True)
+    T = {k: v.cpu() for k, v in tape.t.items()}
+    bb = ref.backbone
+    blocks = [blk for layer in (bb[4], bb[5], bb[6], bb[7]) for blk in layer]
+    have_lo = [f"b{i}.out_lo" in T for i in range(16)]
+    assert have_lo == [i + 1 < 16 and blocks[i + 1].downsample is None for i in range(16)]   # exactly the outputs an identity block adds
+    with torch.no_grad():
+        for i, blk in enumerate(blocks):
+            key = f"b{i}"
+            z3 = nchw(T[key + ".z3"])
+            if blk.downsample is not None:
+                zd = nchw(T[key + ".zd"])
+                sh = F.batch_norm(zd, None, None, blk.downsample[1].weight, blk.downsample[1].bias, training=True, eps=1e-5)   # unrounded
+            else:
+                sh = nchw(T[key + ".x"]) + (nchw(T[f"b{i - 1}.out_lo"]) if have_lo[i - 1] else 0.0)
+            want = F.relu(F.batch_norm(z3, None, None, blk.bn3.weight, blk.bn3.bias, training=True, eps=1e-5) + sh)
+            hi = nchw(T[key + ".out"])
+            scale = float(want.abs().max())
+            assert float((hi - want).abs().max()) <= 2.0 ** -8 * scale + 1e-6, key
+            if have_lo[i]:
+                assert float((hi + nchw(T[key + ".out_lo"]) - want).abs().max()) <= 2.0 ** -15 * scale + 1e-6, key
+    eng.zero_grad()
+    eng.backward(tape, torch.randn(heat.shape, generator=gen).to(dev))
+    assert float(eng.G.abs().sum()) > 0 and bool(torch.isfinite(eng.G).all())

@@ -156,6 +156,58 @@ def test_non_finite_partials_poison_the_fixed_point_sum(kernel_backend):
     assert (np.abs(words[..., 1].astype(np.float64)) >= 2.0 ** 61).all()   # the `lo` words carry the poison
 
 
+@pytest.mark.parametrize("M,Cn,seg", [(640, 64, 0), (1024, 256, 384), (257, 16, 0)])
+def test_block_output_as_a_bf16_pair(kernel_backend, M, Cn, seg):
+    """lp_bn_apply_seg_lo (round 6: the optional "fp32 residual stream" policy).  y is what lp_bn_apply_seg would store when the residual it
+    adds is hi + lo; y + y_lo reproduces the fp32 result to 2^-17 of it; without the lo words in and out it IS lp_bn_apply_seg; with a
+    projection shortcut (zd) the shortcut is added unrounded."""
+    gen = torch.Generator().manual_seed(M + Cn)
+    x = torch.randn(M, Cn, generator=gen) * 1.5 + 0.2
+    res = torch.randn(M, Cn, generator=gen) * 2.0
+    xb = emu.to_bf16_bits(x)
+    rhi = emu.to_bf16_bits(res)
+    rlo = emu.to_bf16_bits(res - emu.from_bf16_bits(rhi))
+    gamma, beta = (torch.rand(Cn, generator=gen) + 0.5), torch.randn(Cn, generator=gen)
+    nseg = 2 if seg else 1
+    bounds = [(0, M)] if not seg else [(0, seg), (seg, M - seg)]
+    xf = emu.from_bf16_bits(xb).reshape(M, Cn)
+    mean = torch.cat([xf[r0:r0 + n].mean(0) for r0, n in bounds])
+    invstd = torch.cat([(xf[r0:r0 + n].var(0, unbiased=False) + 1e-5).rsqrt() for r0, n in bounds])
+    y, ylo, bits = emu.bn_apply_lo(xb, mean.numpy(), invstd.numpy(), gamma.numpy(), beta.numpy(), M, Cn, residual_bits=rhi, residual_lo_bits=rlo, seg_rows=seg)
+    want = torch.empty(M, Cn)
+    for si, (r0, n) in enumerate(bounds):
+        mu, iv = mean[si * Cn:(si + 1) * Cn], invstd[si * Cn:(si + 1) * Cn]
+        want[r0:r0 + n] = torch.relu((xf[r0:r0 + n] - mu) * (iv * gamma) + beta + (emu.from_bf16_bits(rhi) + emu.from_bf16_bits(rlo)).reshape(M, Cn)[r0:r0 + n])
+    got_hi, got = emu.from_bf16_bits(y).reshape(M, Cn), emu.from_bf16_bits(y).reshape(M, Cn) + emu.from_bf16_bits(ylo).reshape(M, Cn)
+    assert float((got_hi - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max()) + 1e-6       # hi alone: one bf16 rounding
+    assert float((got - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max()) + 1e-6         # the pair: 16 mantissa bits
+    assert np.array_equal(np.unpackbits(bits, bitorder="little").reshape(M, Cn).astype(bool), (got_hi > 0).numpy())
+    # no lo in, no lo out: lp_bn_apply_seg itself
+    y1, ylo1, b1 = emu.bn_apply_lo(xb, mean.numpy(), invstd.numpy(), gamma.numpy(), beta.numpy(), M, Cn, residual_bits=rhi, want_lo=False, seg_rows=seg)
+    yb = emu.Z((M, Cn), np.uint16)
+    bb = emu.Z(M * Cn // 8, np.uint8)
+    mb, vb, gb, beb = [emu.Buf(emu.f32(a)) for a in (mean.numpy(), invstd.numpy(), gamma.numpy(), beta.numpy())]
+    xbuf, rbuf = emu.Buf(xb), emu.Buf(rhi)
+    emu.ok(emu.lib().lp_bn_apply_seg(xbuf.p, mb.p, vb.p, gb.p, beb.p, rbuf.p, 1, M, Cn, seg, yb.p, bb.p, emu.stream()))
+    assert ylo1 is None and np.array_equal(y1, yb.np()) and np.array_equal(b1, bb.np())
+    # projection shortcut normalised in the pass and added UNROUNDED
+    zd = torch.randn(M, Cn, generator=gen) * 3.0
+    zb = emu.to_bf16_bits(zd)
+    zf = emu.from_bf16_bits(zb).reshape(M, Cn)
+    md = torch.cat([zf[r0:r0 + n].mean(0) for r0, n in bounds])
+    vd = torch.cat([(zf[r0:r0 + n].var(0, unbiased=False) + 1e-5).rsqrt() for r0, n in bounds])
+    gd, bd = (torch.rand(Cn, generator=gen) + 0.5), torch.randn(Cn, generator=gen)
+    y2, ylo2, _ = emu.bn_apply_lo(xb, mean.numpy(), invstd.numpy(), gamma.numpy(), beta.numpy(), M, Cn, zd_bits=zb, dbn=(md.numpy(), vd.numpy(), gd.numpy(), bd.numpy()),
+                                  seg_rows=seg)
+    want2 = torch.empty(M, Cn)
+    for si, (r0, n) in enumerate(bounds):
+        mu, iv = mean[si * Cn:(si + 1) * Cn], invstd[si * Cn:(si + 1) * Cn]
+        sh = (zf[r0:r0 + n] - md[si * Cn:(si + 1) * Cn]) * (vd[si * Cn:(si + 1) * Cn] * gd) + bd
+        want2[r0:r0 + n] = torch.relu((xf[r0:r0 + n] - mu) * (iv * gamma) + beta + sh)
+    got2 = emu.from_bf16_bits(y2).reshape(M, Cn) + emu.from_bf16_bits(ylo2).reshape(M, Cn)
+    assert float((got2 - want2).abs().max()) <= 2.0 ** -16 * float(want2.abs().max()) + 2e-6
+
+
 @pytest.mark.parametrize("world", [2, 4, 8, 15])
 def test_poison_survives_the_sum_over_ranks(kernel_backend, world):
     """SyncBatchNorm ADDS the ranks' words modulo 2^64 (engine._sync_stats: all-reduce, or all-gather + torch.sum).  Round 5's
