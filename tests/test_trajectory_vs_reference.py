@@ -231,6 +231,9 @@ NOISE_ONLY = ("head.upsampling_layers.2.bias",)   # gradient identically 0 in ex
 TOL_BF16 = dict(scalar=(0.25, 2e-3), state=(1.5, 0.5), m=(1.5, 0.8), v=(2.0, 0.9))
 
 
+_REFERENCE_RUNS: dict = {}
+
+
 def _run_reference_fp64(batches, init, K, HW):
     """the reference's own code in DOUBLE precision: the exact trajectory, to the 1e-4 this test resolves"""
     old = torch.get_default_dtype()
@@ -262,8 +265,11 @@ def test_trajectory_vs_reference(stack_backend, precision):
     K, HW = size["K"], size["HW"]
     batches = _batches(HW, K, size["Bl"], size["S"], STEPS_PER_EPOCH * EPOCHS)
     init, got, model = _run_product(batches, stack_backend, precision, K, HW)
-    ref32 = _run_reference(copy.deepcopy(batches), init, K, HW)
-    exact = _run_reference_fp64(batches, init, K, HW)
+    ck = (stack_backend.type, K, HW)
+    if ck not in _REFERENCE_RUNS:   # (the two precisions start from the same seeded state: the reference's two runs are shared)
+        _REFERENCE_RUNS[ck] = (init, _run_reference(copy.deepcopy(batches), init, K, HW), _run_reference_fp64(batches, init, K, HW))
+    init0, ref32, exact = _REFERENCE_RUNS[ck]
+    assert all(torch.equal(init[k], init0[k]) for k in init)
     assert len(got) == len(ref32) == len(exact) == STEPS_PER_EPOCH * EPOCHS
     # the schedule the verbatim callbacks produced on the reference side is the one this test means to exercise
     lrs = [w["lrs"] for w in ref32]
