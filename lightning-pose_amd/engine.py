@@ -51,7 +51,7 @@ class ConvP:
     Ci: int
     w_off: int = 0
     wd_off: int = 0
-    bias_off: int = -1   # convT only (padded to CPAD)
+    bias_off: int = -1   # convT only (padded to Ci)
 
     @property
     def numel(self) -> int:
@@ -94,19 +94,21 @@ class Plan:
     bns: list[BNP] = field(default_factory=list)
 
 
-def build_head(feat_channels: int, stride: int, num_keypoints: int, downsample_factor: int) -> list[ConvP]:
+def build_head(feat_channels: int, stride: int, num_keypoints: int, downsample_factor: int, int_channels: int | None = None) -> list[ConvP]:
     """PixelShuffle(2) + n x ConvTranspose2d(k3,s2,p1,op1) of HeatmapHead (reference models/heads/heatmap.py:20-71,186-196):
-    n = log2(stride) - downsample_factor - 1.  Each ConvTranspose2d(cin -> K) is stored as the mirrored convolution's weight
-    [Co = cin rounded up to 64][3][3][Ci = K padded to CPAD]."""
+    n = log2(stride) - downsample_factor - 1; every layer but the last has ``int_channels`` outputs (``deconv_out_channels``; default: the
+    keypoints).  Each ConvTranspose2d(cin -> cout) is stored as the mirrored convolution's weight
+    [Co = cin rounded up to 64][3][3][Ci = cout rounded up to 64 (CPAD for the keypoints)]."""
     n_layers = int(math.log2(stride)) - downsample_factor - 1
     if n_layers < 1:
         raise NotImplementedError(f"downsample_factor={downsample_factor} leaves no upsampling layer for a stride-{stride} backbone")
     head: list[ConvP] = []
     cin = feat_channels // 4
     for i in range(n_layers):
-        co_store = -(-cin // 64) * 64
-        head.append(ConvP(f"head.upsampling_layers.{i + 1}", "convT", cin, num_keypoints, 3, 2, 1, co_store, CPAD))
-        cin = num_keypoints
+        cout = num_keypoints if i == n_layers - 1 else (int_channels or num_keypoints)
+        co_store, ci_store = -(-cin // 64) * 64, -(-cout // 64) * 64
+        head.append(ConvP(f"head.upsampling_layers.{i + 1}", "convT", cin, cout, 3, 2, 1, co_store, ci_store))
+        cin = cout
     return head
 
 
@@ -147,7 +149,7 @@ def build_plan(num_keypoints: int, downsample_factor: int) -> Plan:
             wd += c.numel
         if c.kind == "convT":
             c.bias_off = off
-            off += CPAD
+            off += c.Ci
         plan.convs.append(c)
 
     def add_bn(b: BNP):
@@ -194,13 +196,15 @@ class Engine:
     residual_fp32 = False
     dgrad_half_addend = True
 
-    def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0"):
+    final_softmax = True   # (HeadEngine: HeatmapHead(final_softmax=False) leaves the last layer's output un-normalised)
+
+    def __init__(self, num_keypoints: int, downsample_factor: int = 2, device: torch.device | str = "cuda:0", plan: Plan | None = None):
         self.device = torch.device(device)
         ops.require_device_type(self.device)
         _lib.lib()  # fail loudly now if liblp_hip.so is missing
         self.K = num_keypoints
         self.ds = downsample_factor
-        self.plan = build_plan(num_keypoints, downsample_factor)
+        self.plan = build_plan(num_keypoints, downsample_factor) if plan is None else plan
         n = self.plan.n_total
         dev = self.device
         self.P = torch.zeros(n, device=dev, dtype=torch.float32)      # master parameters
@@ -590,20 +594,24 @@ class Engine:
         for li, c in enumerate(head):
             g = self._geom(c, B, h, w)
             last = li == len(head) - 1
-            bias = self.P[c.bias_off:c.bias_off + CPAD]
+            bias = self.P[c.bias_off:c.bias_off + c.Ci]
             wd = self.Wd[c.wd_off:]
             if last:
                 logits = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.float32)
                 check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, None, _p(logits), CPAD, self.K, 0, ops._stream()),
                       "lp_conv_dgrad(head)")
-            else:
-                nxt = torch.empty(B, 2 * h, 2 * w, CPAD, device=self.device, dtype=torch.bfloat16)
-                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, CPAD, CPAD, 0, ops._stream()),
+            else:   # (intermediate layer: c.Ci = its channels - deconv_out_channels, by default the keypoints - rounded up to 64, zeros behind them)
+                nxt = torch.empty(B, 2 * h, 2 * w, c.Ci, device=self.device, dtype=torch.bfloat16)
+                check(self._lib.lp_conv_dgrad(_p(cur), _p(wd), C.byref(g), _p(bias), None, None, _p(nxt), None, c.Ci, c.Ci, 0, ops._stream()),
                       "lp_conv_dgrad(head)")
                 cur = nxt
                 T[f"head.in{li + 1}"] = cur
             h, w = 2 * h, 2 * w
         n = h * w
+        if not self.final_softmax:   # HeatmapHead(final_softmax=False), reference :209-211: the last layer's output as it is, (B, K, h, w)
+            heat = logits[..., :self.K].permute(0, 3, 1, 2).contiguous()
+            T["heat"] = heat
+            return heat
         heat = torch.empty(B, self.K, h, w, device=self.device, dtype=torch.float32)
         check(self._lib.lp_softmax2d_fwd(_p(logits), n * CPAD, CPAD, 1, B, self.K, n, _p(heat), ops._stream()), "lp_softmax2d_fwd")
         T["heat"] = heat
@@ -617,17 +625,20 @@ class Engine:
         n = h * w
         g_heat = g_heat.to(torch.float32).contiguous()
         dcur = torch.zeros(B, h, w, CPAD, device=self.device, dtype=torch.bfloat16)
-        check(self._lib.lp_softmax2d_bwd(_p(heat), _p(g_heat), B, K, n, _p(dcur), n * CPAD, CPAD, 1, ops._stream()), "lp_softmax2d_bwd")
+        if self.final_softmax:
+            check(self._lib.lp_softmax2d_bwd(_p(heat), _p(g_heat), B, K, n, _p(dcur), n * CPAD, CPAD, 1, ops._stream()), "lp_softmax2d_bwd")
+        else:
+            dcur[..., :K] = g_heat.permute(0, 2, 3, 1)
         # last layer first.  ConvT backward-data is the mirrored conv's forward; its wgrad is lp_conv_wgrad.
         for li in range(len(head) - 1, -1, -1):
             c = head[li]
             hs, ws = h // 2, w // 2
             g = self._geom(c, B, hs, ws)
             x_small = T[f"head.in{li}"]
-            bsum = self._zeros_fx(2 * CPAD)
-            rws = self._reduce_ws(B * h * w, CPAD)
-            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, CPAD, _p(bsum), _p(rws), rws.numel(), ops._stream()), "lp_bn_stats(bias)")
-            check(self._lib.lp_fxsum_accumulate(_p(bsum), CPAD, _p(self.G[c.bias_off:]), ops._stream()), "lp_fxsum_accumulate")
+            bsum = self._zeros_fx(2 * c.Ci)
+            rws = self._reduce_ws(B * h * w, c.Ci)
+            check(self._lib.lp_bn_stats(_p(dcur), B * h * w, c.Ci, _p(bsum), _p(rws), rws.numel(), ops._stream()), "lp_bn_stats(bias)")
+            check(self._lib.lp_fxsum_accumulate(_p(bsum), c.Ci, _p(self.G[c.bias_off:]), ops._stream()), "lp_fxsum_accumulate")
             self._wgrad(dcur, x_small, g, self.G[c.w_off:])
             dx = torch.empty(B, hs, ws, c.Co, device=self.device, dtype=torch.bfloat16)
             check(self._lib.lp_conv_fwd(_p(dcur), _p(self.Wb[c.w_off:]), C.byref(g), None, _p(dx), None, c.Co, 0, ops._stream()),
@@ -930,7 +941,7 @@ class Engine:
         nseg = 2 if seg else 1
         # One zeroed arena for every reduction target of this pass: the sums of each BatchNorm backward (fused into a data gradient or
         # not), the head's bias sums, the stem's.
-        self._zero_arena = torch.zeros(4 * ((sum(2 * b.C for b in plan.bns) + 2 * plan.stem_bn.C) * nseg + 2 * CPAD * len(plan.head)) + 64,
+        self._zero_arena = torch.zeros(4 * ((sum(2 * b.C for b in plan.bns) + 2 * plan.stem_bn.C) * nseg + sum(2 * c.Ci for c in plan.head)) + 64,
                                        device=self.device, dtype=torch.float32)
         self._zero_off = 0
         try:
@@ -1055,3 +1066,55 @@ class Engine:
         self._timed("conv_wgrad_kernel<64,stem>", self._flops(plan.stem, g),
                     lambda: self._wgrad(T["x4"], dz, g, self.G[plan.stem.w_off:], stem=True), self._bytes(plan.stem, g, wgrad=True), layer=plan.stem.name)
         self._join_side_stream()
+
+
+class HeadEngine(Engine):
+    """The head alone, for a ``HeatmapHead`` used outside a tracker (reference models/heads/heatmap.py:147-212, as its own tests use it:
+    tests/models/heads/test_heatmap.py): PixelShuffle(2) + n ConvTranspose2d + optional spatial soft-max over its own flat buffers, with
+    every constructor option of the reference class (``deconv_out_channels``, ``final_softmax``).  Same kernels and tape as the head
+    of the full engines; features come and go as (B, C, h, w) fp32, the arithmetic is bf16-mixed like the trunk's."""
+
+    def __init__(self, in_channels: int, stride: int, num_keypoints: int, downsample_factor: int = 2, deconv_out_channels: int | None = None,
+                 final_softmax: bool = True, device: torch.device | str = "cuda:0"):
+        if num_keypoints > CPAD:
+            raise NotImplementedError(f"at most {CPAD} heat-map channels are supported, got {num_keypoints}")
+        if in_channels % 4:
+            raise ValueError(f"PixelShuffle(2) needs a multiple of 4 input channels, got {in_channels}")
+        head = build_head(in_channels, stride, num_keypoints, downsample_factor, deconv_out_channels)
+        plan = Plan(None, None, [], head)
+        off = wd = 0
+        for c in head:
+            c.w_off, c.wd_off = off, wd
+            off += c.numel
+            wd += c.numel
+            c.bias_off = off
+            off += c.Ci
+            plan.convs.append(c)
+        plan.n_backbone, plan.n_total, plan.n_wd, plan.n_running = 0, off, wd, 0
+        super().__init__(num_keypoints, downsample_factor, device, plan=plan)
+        self.in_channels = in_channels
+        self.final_softmax = bool(final_softmax)
+
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        sd: dict[str, torch.Tensor] = {}
+        for c in self.plan.head:
+            sd[f"{c.name}.weight"] = self.param_view(c)
+            sd[f"{c.name}.bias"] = self.param_view(c, "bias")
+        return sd
+
+    def forward(self, features: torch.Tensor, training: bool = True) -> tuple[torch.Tensor, Tape]:   # type: ignore[override]
+        ops.require_device(features)
+        if features.dim() != 4 or features.shape[1] != self.in_channels:
+            raise ValueError(f"features must be (B, {self.in_channels}, h, w), got {tuple(features.shape)}")
+        B, _, h, w = features.shape
+        x = features.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+        tp = Tape()
+        tp.meta.update(B=B, h=h, w=w)
+        heat = self._head_forward(x, B, h, w, tp.t)
+        return heat, tp
+
+    def backward(self, tp: Tape, g_heat: torch.Tensor, trace: dict | None = None) -> torch.Tensor:   # type: ignore[override]
+        """Parameter gradients accumulate into G; returns d loss / d features (B, C, h, w) fp32."""
+        d = self._head_backward(tp.t, tp.meta["B"], g_heat)
+        self._join_side_stream()
+        return d.permute(0, 3, 1, 2).to(torch.float32)

@@ -73,7 +73,7 @@ class HeatmapTracker(BaseSupervisedTracker):
         self.precision = {"32": "fp32", "32-true": "fp32", "fp32": "fp32"}.get(
             str(os.environ.get("LP_PRECISION") or kwargs.get("precision") or "bf16-mixed"), "bf16-mixed")
         self.head = HeatmapHead(backbone_arch=backbone, in_channels=self.num_fc_input_features, out_channels=num_keypoints,
-                                downsample_factor=downsample_factor)
+                                downsample_factor=downsample_factor, _bound=True)
         self.backbone = _Holder()
         checkpoint = kwargs.get("backbone_checkpoint")
         if backbone in VIT_CONFIGS:

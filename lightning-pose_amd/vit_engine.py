@@ -28,7 +28,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .engine import CPAD, ConvP, Engine, Tape, build_head
+from .engine import ConvP, Engine, Tape, build_head
 from .ops import _p
 
 LN_EPS = 1e-12  # ViTConfig.layer_norm_eps
@@ -113,7 +113,7 @@ class ViTPlan:
             c.wd_off = wd
             wd += c.numel
             c.bias_off = off
-            off += CPAD
+            off += c.Ci
             self.convs.append(c)
         self.n_total, self.n_wd = off, wd
         self.n_running = 0
