@@ -206,20 +206,21 @@ def test_pca_losses_with_the_reference_fit(dev, seed):
         if key == "kept_eigenvectors":     # principal axes are defined up to sign
             sgn = torch.sign((a * b).sum(1, keepdim=True))
             a = a * sgn
-        torch.testing.assert_close(a, b, atol=2e-3, rtol=1e-3)
-    assert float(prod.pca.parameters["epsilon"]) == pytest.approx(float(ref_pca.parameters["epsilon"]), rel=2e-3)
+        # both fits run in float64 numpy and hand over float32: the mean (values ~40) to a few ulp, the axes to the last bit or two
+        torch.testing.assert_close(a, b, atol=5e-5 if key == "mean" else 2e-6, rtol=0)
+    assert float(prod.pca.parameters["epsilon"]) == pytest.approx(float(ref_pca.parameters["epsilon"]), rel=5e-5)
     ref_loss = L.PCALoss.__new__(L.PCALoss)      # the reference class around the reference fit, without a data module
     L.Loss.__init__(ref_loss, epsilon=float(ref_pca.parameters["epsilon"]), log_weight=1.0)
     ref_loss.loss_name, ref_loss.pca, ref_loss.device = "pca_singleview", ref_pca, "cpu"
     a, b = kp.clone().requires_grad_(True), _d(kp, dev).requires_grad_(True)
     want, want_logs = ref_loss(keypoints_pred=a, stage="train")
     got, got_logs = prod(keypoints_pred=b, stage="train")
-    assert float(got.detach()) == pytest.approx(float(want.detach()), rel=5e-3, abs=1e-6)
+    assert float(got.detach()) == pytest.approx(float(want.detach()), rel=1e-4, abs=1e-6)   # (north_star's fp32 bar; measured 2e-6)
     assert _logs(got_logs).keys() == _logs(want_logs).keys()
     if float(want.detach()) > 0:
         want.backward()
         got.backward()
-        torch.testing.assert_close(b.grad.cpu(), a.grad, atol=5e-3 * float(a.grad.abs().max()), rtol=5e-2)
+        torch.testing.assert_close(b.grad.cpu(), a.grad, atol=1e-4 * float(a.grad.abs().max()), rtol=1e-3)   # (measured 5e-6)
 
 
 @pytest.mark.parametrize("K,H,W,ds,B", [(2, 96, 96, 3, 2), (5, 64, 96, 2, 3), (1, 96, 64, 2, 2), (3, 64, 64, 1, 2)])
