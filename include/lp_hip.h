@@ -50,7 +50,7 @@ enum { LP_TF_NONE = 0, LP_TF_SINGLE = 1, LP_TF_PER_FRAME = 2, LP_TF_PER_VIEW = 3
  * not only when symbols come or go.  lp_version() returns the value the library was built with; a caller compares the two before its first
  * call (lightning_pose_amd/_lib.py raises LpHipUnavailable on a mismatch) - a library built against an older header would otherwise take,
  * e.g., the stream argument for an inserted flag without any error.  History: 131 = round 5 (decode `prune`, bn_bwd `terms_ws`), 140 = round 6. */
-#define LP_HIP_ABI_VERSION 140
+#define LP_HIP_ABI_VERSION 141
 int lp_version(void);
 const char* lp_strerror(int code);
 
@@ -270,6 +270,15 @@ int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int ldv, const 
 typedef struct lp_fxsum {
     long long hi, lo;
 } lp_fxsum;
+/* The data gradient of a Linear layer that follows a GELU, leaving as the gradient of the GELU's INPUT (a ViT block's fc2 -> fc1's
+ * output; HF ViTIntermediate / ViTOutput, reference models/backbones/vit.py:29-49 through transformers' ViTLayer):
+ *   c[m][n] = bf16( bf16(sum_k a[m][k] * b[n][k]) * GELU'(u[m][n]) ),   a (M, K), b (N, K), u and c (M, N), all dense bf16;
+ * the inner rounding is the one lp_gemm_nt's output would have had, so the result equals lp_gemm_nt followed by lp_gelu_bwd bit for
+ * bit, without the activation gradient's write and read.  colsum (optional, (2, N) lp_fxsum, zeroed by the caller): row 0 receives the
+ * column sums of c - the bias gradient of the layer that produced u (lp_fxsum_accumulate turns them into fp32); row 1 is scratch.
+ * LP_ERR_UNSUPPORTED unless K % 64 == 0 and N % 128 == 0 (the pipelined kernel's shapes): the caller then runs the two-pass form. */
+int lp_gemm_nt_gelu_bwd(const void* a, const void* b, const void* u_bf16, void* c_bf16, int M, int N, int K, lp_fxsum* colsum,
+                        lp_stream_t stream);
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
  * for them (torch.nn.BatchNorm2d training forward / backward).  Every persistent workgroup adds the
  * column sums of the tiles it walked into `sums` (fixed point, integer atomics: see lp_fxsum).

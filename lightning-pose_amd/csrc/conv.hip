@@ -1476,6 +1476,22 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     return launch_status();
 }
 
+// lp_gemm_nt with GELU's backward in the store pass (conv_pipe.h: kEkGeluBwd)
+extern "C" int lp_gemm_nt_gelu_bwd(const void* a, const void* b, const void* u_bf16, void* c_bf16, int M, int N, int K, lp_fxsum* colsum,
+                                   lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(a && b && u_bf16 && c_bf16 && M > 0 && N > 0 && K > 0);
+    if ((long long)M * K >= (1LL << 31) || (long long)N * K >= (1LL << 31) || (long long)M * N >= (1LL << 32)) return LP_ERR_UNSUPPORTED;
+    ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
+    ConvEpilogue ep{(unsigned short*)c_bf16, nullptr, N, N, nullptr};
+    ep.addend = (const unsigned short*)u_bf16;
+    ep.stats_sums = colsum;
+    const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
+    if (N % 128 != 0 || !pipe_eligible(ep, M, N, K, K, M)) return LP_ERR_UNSUPPORTED;
+    launch_pipe<128, kModeFwd, kEkGeluBwd>(a, b, g, lat, M, N, K, ep, (hipStream_t)stream);
+    return launch_status();
+}
+
 // Attention backward, score gradient: dS[z] = scale * P[z] o (dO[z] V[z]^T - D[z] 1^T), D = rowsum(dO o O) (lp_attn_rowdot).  The
 // product is lp_gemm_nt's; the soft-max backward happens in its store pass, so dP is never written and P is read once here.
 extern "C" int lp_attn_dscores(const void* d_out, int ld_do, const void* v, int ldv, const void* p_bf16, const float* d_rows, int d_row_stride,

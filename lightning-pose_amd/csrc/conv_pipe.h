@@ -81,7 +81,10 @@ __device__ __forceinline__ void store8(unsigned short* p, u16x8 v) { *reinterpre
 //   kEkInfer forward with + residual and ReLU in the store pass (inference, BatchNorm folded into weights and bias: lp_conv_fwd_act)
 //   kEkPB    kEkPlain with the ReLU mask at 1 bit per element (lp_conv_dgrad_bits, round 5: the two writers of a layer's first block read
 //            57 MB of mask bits instead of re-reading the block input's 906 MB activation)
-enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4, kEkPB = 5 };
+//   kEkGeluBwd  forward-mode GEMM whose store pass multiplies the (bf16-rounded) product by GELU'(u), u read at the output's own offsets
+//            as `addend` (lp_gemm_nt_gelu_bwd, round 6: the data gradient of a ViT block's fc2 leaves as the gradient of fc1's OUTPUT - the
+//            stand-alone GELU backward's write and read of the activation gradient are gone; the column sums = fc1's bias gradient)
+enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4, kEkPB = 5, kEkGeluBwd = 6 };
 
 // HALO (3x3, stride 1, pad 1 - conv2 of every identity-stride block, forward and data gradient): the pixel operand is not fetched per
 // filter tap.  The ring above re-reads every activation row 9 times from L2 (once per tap: 27.7 us per tap on layer1's 64-channel layers,
@@ -101,7 +104,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
                                                         FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep,
                                                         HaloDivs hd) {
-    static_assert((MODE == kModeFwd && (EK == kEkNone || EK == kEkInfer)) || (MODE == kModeDgrad && EK != kEkNone && EK != kEkInfer),
+    static_assert((MODE == kModeFwd && (EK == kEkNone || EK == kEkInfer || EK == kEkGeluBwd)) ||
+                      (MODE == kModeDgrad && EK != kEkNone && EK != kEkInfer && EK != kEkGeluBwd),
                   "trunk convolutions only");
     constexpr int NT = BN / 64;                  // 32-channel MFMA blocks per wave along N (wave tile 64 pixels x NT*32 channels)
     constexpr int NBL = BN / 64;                 // weight rows each thread stages per K step
@@ -463,6 +467,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     auto epilogue_fwd = [&](const int m0, const int n0, unsigned char* stg_all) {
         const int nbase = n0 + wn * (NT * 32);   // first channel of this wave
         constexpr bool infer = EK == kEkInfer;   // lp_conv_fwd_act: its own instantiations, so the training kernels' store pass carries none of it
+        constexpr bool gelub = EK == kEkGeluBwd; // lp_gemm_nt_gelu_bwd: `addend` is u, the pre-activation the product's gradient passes through
         // The wave's corner: 32 pixel rows of NT*64 B, UNPADDED, the 8-B slot s of row r at position s ^ key(r) (key = r & 15 for 128-B rows,
         // (r >> 1) & 7 for 64-B rows): the 16 lanes of a ds_write_b64 group - 16 consecutive pixels, one slot - then hit 16 different slots,
         // and the ds_read_b128 service groups of the read-back (4 rows x 4 chunks each) 16 different 16-bank ranges.  (Until round 5 the rows
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
         unsigned char* stg = stg_all + wave * (32 * ROWB);
         const int wkey = kPad ? 0 : NT == 2 ? (fr & 15) : ((fr >> 1) & 7);
         u16x8 radd[2][32 / RP] = {};   // inference: this lane's pieces of the residual, all 8 requested before the conversion / staging work
-        if (infer && ep.addend != nullptr) {
+        if ((infer || gelub) && ep.addend != nullptr) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -537,6 +542,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                         }
                         w = pack_bf16x8(v);
                     }
+                    if (gelub) {   // d u = bf16(d a) * GELU'(u): the arithmetic of the stand-alone pass (vit.hip: gelu_bwd_kernel) on the value it would have read
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = bf16_to_f32(w[q]) * gelu_df(bf16_to_f32(radd[mt][ps][q]));
+                        w = pack_bf16x8(v);
+                    }
                     store8(ep.out_bf16 + off, w);
                     if (want_stats) {
 #pragma unroll
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     // everything is applied before the single rounding to bf16, as in conv_igemm_kernel.
     constexpr int PH = 16 / RP;          // read-back passes per 16-pixel half
     constexpr int NPC = 2 * PH;          // pieces (8 channels of one row) per lane and 32-pixel chunk
-    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain || EK == kEkPB), kLz = (EK != kEkNone && EK != kEkInfer && EK != kEkPB),
+    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain || EK == kEkPB), kLz = (EK != kEkNone && EK != kEkInfer && EK != kEkPB && EK != kEkGeluBwd),
                    kLb = (EK == kEkAZB || EK == kEkPB);
     // (kEkAZB - the hottest data gradient, at the register cap - does not keep the output offsets of its pieces: its launches cover the full
     //  pixel lattice (host-checked), so an offset is two multiply-adds away and is recomputed in rb_process: 8 VGPRs, the 7 it used to spill)

@@ -40,6 +40,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (un
 #endif
 
 // 8 floats -> 8 bf16 (16 B)
+// GELU (exact, erf: HF ViT's "gelu") and its derivative - vit.hip's stand-alone passes and the fused store pass of conv_pipe.h (kEkGeluBwd)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
 __device__ __forceinline__ u16x8 pack_bf16x8(const float (&f)[8]) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
     const u32x4_t p = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};

@@ -287,10 +287,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
 }
 
 // ---- GELU (exact, erf) on bf16 streams --------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_df(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
+// (gelu_f / gelu_df: lp_common.h - the Linear layers' store pass uses the same two functions, conv_pipe.h: kEkGeluBwd)
 
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const unsigned short* __restrict__ x, size_t n_chunks, unsigned short* __restrict__ y) {
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {

@@ -251,7 +251,8 @@ class ViTEngine(Engine):
             nbytes=2.0 * (M * l.K + M * l.N + l.N * l.K))
         return out
 
-    def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True, bias_done: bool = False):
+    def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True, bias_done: bool = False,
+                    gelu_of: tuple[torch.Tensor, torch.Tensor] | None = None):
         """bias / weight gradients into G; returns dX = dY W (bf16) if wanted.  ``bias_done``: the kernel that produced ``dy`` already left its
         column sums in G (lp_gelu_bwd_colsum / lp_layernorm_bwd_bf16_colsum), so the weight gradient runs without the bias pass - which lets the
         pipelined weight-gradient kernel take it."""
@@ -264,6 +265,23 @@ class ViTEngine(Engine):
         if not need_dx:
             return None
         dx = torch.empty(M, l.K, device=self.device, dtype=torch.bfloat16)
+        if gelu_of is not None:
+            # this layer's input is GELU(u): the data gradient leaves the store pass as the gradient of u (lp_gemm_nt_gelu_bwd), its column sums
+            # - the bias gradient of the layer that produced u - as fixed-point totals; a shape the pipelined kernel does not tile: two passes
+            u, dbias_u = gelu_of
+            sums = torch.zeros(4 * l.K, device=self.device, dtype=torch.int64)
+            rc = self._timed("lp_gemm_nt<linear dgrad+gelu>", 2.0 * M * l.N * l.K, lambda: self._lib.lp_gemm_nt_gelu_bwd(
+                _p(dy), _p(self.Wd[l.wd_off:]), _p(u), _p(dx), M, l.K, l.N, _p(sums), ops._stream()),
+                nbytes=2.0 * (2 * M * l.K + M * l.N + l.N * l.K))
+            if rc == 0:
+                check(self._lib.lp_fxsum_accumulate(_p(sums), l.K, _p(dbias_u), ops._stream()), "lp_fxsum_accumulate")
+                return dx
+            if rc != -2:   # (LP_ERR_UNSUPPORTED, include/lp_hip.h: a shape outside the pipelined tiles)
+                check(rc, "lp_gemm_nt_gelu_bwd")
+            d_a = torch.empty_like(dx)
+            self._gemm(_p(dy), l.N, _p(self.Wd[l.wd_off:]), l.N, M, l.K, l.N, d_a, l.K)
+            check(self._lib.lp_gelu_bwd_colsum(_p(u), _p(d_a), M, l.K, _p(dx), _p(dbias_u), ops._stream()), "lp_gelu_bwd_colsum")
+            return dx
         self._timed("lp_gemm_nt<linear dgrad>", 2.0 * M * l.N * l.K, lambda: self._gemm(_p(dy), l.N, _p(self.Wd[l.wd_off:]), l.N, M, l.K, l.N, dx, l.K),
                     nbytes=2.0 * (M * l.K + M * l.N + l.N * l.K))
         return dx
@@ -417,6 +435,7 @@ class ViTEngine(Engine):
         # every LayerNorm backward also leaves the updated stream gradient in bf16: it is the operand of the next Linear backward
         # ... and its column sums are the bias gradient of that layer (fc2 of the last block here), so no weight gradient needs a bias pass
         fuse_bias = os.environ.get("LP_VIT_BIAS_FUSED", "1") != "0"
+        fuse_gelu = os.environ.get("LP_VIT_GELU_FUSED", "1") != "0"   # (0: A/B runs - lp_gemm_nt, then lp_gelu_bwd_colsum)
         bsum = (lambda lin: self.G[lin.b_off:lin.b_off + lin.N]) if fuse_bias else (lambda lin: None)
         dx16 = self._ln_bwd(d_feat, T["x_last"], T["mf"], T["rf"], pl.lnf, M, dx, drop_T=Tn, want_bf16=True, colsum=bsum(pl.layers[-1]["fc2"]))
 
@@ -427,9 +446,15 @@ class ViTEngine(Engine):
                 trace[f"l{i}.dout"] = dx.clone()
             # ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             dmlp = dx16
-            d_a1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M, bias_done=fuse_bias)
-            d_h1 = torch.empty_like(d_a1)
-            if fuse_bias:
+            if fuse_bias and fuse_gelu:   # GELU's backward inside fc2's data gradient (round 6): d_a1 is never written
+                d_h1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M, bias_done=True, gelu_of=(t("h1"), bsum(L["fc1"])))
+                d_a1 = None
+            else:
+                d_a1 = self._linear_bwd(L["fc2"], t("a1"), dmlp, M, bias_done=fuse_bias)
+                d_h1 = torch.empty_like(d_a1)
+            if d_a1 is None:
+                pass
+            elif fuse_bias:
                 check(self._lib.lp_gelu_bwd_colsum(_p(t("h1")), _p(d_a1), M, pl.mlp, _p(d_h1), _p(bsum(L["fc1"])), ops._stream()), "lp_gelu_bwd_colsum")
             else:
                 check(self._lib.lp_gelu_bwd(_p(t("h1")), _p(d_a1), d_a1.numel(), _p(d_h1), ops._stream()), "lp_gelu_bwd")

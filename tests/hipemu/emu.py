@@ -372,6 +372,14 @@ def gemm_nt(a_bits, lda, b_bits, ldb, M, N, K, ldc, c_rows, n_store=0, bias=None
     return cf.np() if f32_out else cb.np()
 
 
+def gemm_nt_gelu_bwd(a_bits, b_bits, u_bits, M, N, K, colsum=True):
+    """lp_gemm_nt_gelu_bwd: (c bits (M, N), column sums of c as fp32 (N,) or None); raises Unsupported shapes as the library reports them"""
+    ab, bb, ub, cb = Buf(a_bits), Buf(b_bits), Buf(u_bits), Z((M, N), np.uint16)
+    sums = ZX((2, N)) if colsum else None
+    ok(lib().lp_gemm_nt_gelu_bwd(ab.p, bb.p, ub.p, cb.p, M, N, K, ptr(sums), stream()))
+    return cb.np(), (fx(sums.np())[0] if colsum else None)
+
+
 def gemm_tn(x_bits, ldx, y_bits, ldy, M, J, N, ldo, o_elems, batch=None):
     """out[z][j][n] = sum_m x[z][m][j] y[z][m][n]; batch = (nb, nh, x_b, x_h, y_b, y_h, o_b, o_h). Returns the flat bf16 output."""
     xb, yb, ob = Buf(x_bits), Buf(y_bits), Z(o_elems, np.uint16)

@@ -140,3 +140,38 @@ def test_vit_tracker_trains_through_the_reference_surface(stack_backend, monkeyp
         g["lr"] = 1e-3
     losses = [float(tr.training_batch(model, batch, i)) for i in range(5)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_gelu_backward_inside_fc2s_data_gradient_changes_no_bit(stack_backend, monkeypatch):
+    """round 6: fc2's data gradient leaves as the gradient of fc1's OUTPUT (lp_gemm_nt_gelu_bwd) - every gradient equals the two-pass form
+    (lp_gemm_nt, then lp_gelu_bwd_colsum) bit for bit, except fc1's bias gradient, whose column sums are now fixed-point totals"""
+    from lightning_pose_amd.vit_engine import ViTEngine
+
+    dev = stack_backend
+
+    def grads(fused: bool):
+        monkeypatch.setenv("LP_VIT_GELU_FUSED", "1" if fused else "0")
+        torch.manual_seed(3)
+        eng = ViTEngine(5, 2, dev, hidden=128, depth=2, heads=2, mlp=256, patch=16, pretrain_grid=3)
+        sd = {k: torch.randn_like(v) * (0.05 if v.dim() > 1 else 0.1) + (1.0 if "layernorm" in k and k.endswith("weight") else 0.0)
+              for k, v in eng.state_dict().items()}
+        eng.load_state_dict(sd)
+        x = torch.randn(2, 3, 64, 64, device=dev)
+        heat, tape = eng.forward(x, training=True)
+        eng.zero_grad()
+        eng.backward(tape, torch.randn(heat.shape, generator=torch.Generator().manual_seed(4)).to(dev) * heat)
+        return {k: v.detach().cpu().clone() for k, v in eng.grad_views().items()}
+
+    a, b = grads(True), grads(False)
+    assert a.keys() == b.keys()
+    exact = 0
+    for k in a:
+        if k.endswith("mlp.fc1.bias"):   # (a sum of ~1e-3-sized terms that nearly cancel: the two-pass form rounds its fp32 partial sums)
+            torch.testing.assert_close(a[k], b[k], atol=1e-2 * float(b[k].abs().max()), rtol=0)
+            assert float(b[k].abs().max()) > 0
+        elif a[k].dim() == 1:            # LayerNorm parameters, the other biases: fp32 atomics in arrival order - equal to their own run-to-run noise
+            torch.testing.assert_close(a[k], b[k], atol=1e-6 * float(b[k].abs().max()), rtol=0)
+        else:                            # every weight gradient (and so every tensor that flows through the backward pass)
+            assert torch.equal(a[k], b[k]), k
+            exact += 1
+    assert exact >= 10

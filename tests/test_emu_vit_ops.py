@@ -227,3 +227,21 @@ def test_attention_backward_kv_fused(nb, nh, T, ldp):
         torch.testing.assert_close(got, want, atol=2e-2 * want.abs().max().item(), rtol=2e-2, msg=lambda m, n=name: f"{n}: {m}")
 
 
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (577, 256, 192), (256, 384, 128)])
+def test_gemm_with_gelu_backward_in_the_store_pass(kernel_backend, M, N, K, monkeypatch):
+    """lp_gemm_nt_gelu_bwd = lp_gemm_nt followed by lp_gelu_bwd, bit for bit (the inner rounding is kept), and its column sums are the
+    bias gradient lp_gelu_bwd_colsum accumulates; several tiles per workgroup, a ragged last row tile"""
+    monkeypatch.setenv("LP_CONV_MAX_WGS", "2")
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=gen))
+    b = bf(torch.randn(N, K, generator=gen) * 0.2)
+    u = bf(torch.randn(M, N, generator=gen) * 1.5)
+    two_pass = emu.gelu(bits(u), emu.gemm_nt(bits(a).ravel(), K, bits(b).ravel(), K, M, N, K, N, M).reshape(M, N))
+    fused, colsum = emu.gemm_nt_gelu_bwd(bits(a), bits(b), bits(u), M, N, K)
+    assert np.array_equal(fused, two_pass)
+    want = unbits(fused).double().sum(0)
+    torch.testing.assert_close(torch.from_numpy(colsum).double(), want, atol=1e-4 * float(want.abs().max()) + 1e-5, rtol=1e-5)
+    with pytest.raises(Exception):   # a column count the pipelined kernel does not tile: reported, the caller keeps the two-pass form
+        emu.gemm_nt_gelu_bwd(bits(a), bits(b)[:64], bits(u)[:, :64].copy(), M, 64, K)
