@@ -50,7 +50,7 @@ enum { LP_TF_NONE = 0, LP_TF_SINGLE = 1, LP_TF_PER_FRAME = 2, LP_TF_PER_VIEW = 3
  * not only when symbols come or go.  lp_version() returns the value the library was built with; a caller compares the two before its first
  * call (lightning_pose_amd/_lib.py raises LpHipUnavailable on a mismatch) - a library built against an older header would otherwise take,
  * e.g., the stream argument for an inserted flag without any error.  History: 131 = round 5 (decode `prune`, bn_bwd `terms_ws`), 140 = round 6. */
-#define LP_HIP_ABI_VERSION 141
+#define LP_HIP_ABI_VERSION 142
 int lp_version(void);
 const char* lp_strerror(int code);
 
@@ -278,6 +278,10 @@ typedef struct lp_fxsum {
  * column sums of c - the bias gradient of the layer that produced u (lp_fxsum_accumulate turns them into fp32); row 1 is scratch.
  * LP_ERR_UNSUPPORTED unless K % 64 == 0 and N % 128 == 0 (the pipelined kernel's shapes): the caller then runs the two-pass form. */
 int lp_gemm_nt_gelu_bwd(const void* a, const void* b, const void* u_bf16, void* c_bf16, int M, int N, int K, lp_fxsum* colsum,
+                        lp_stream_t stream);
+/* ... and the forward side of the same pair: c = bf16(a b^T + bias) as lp_gemm_nt writes it, and act = bf16(GELU(c)) beside it (what
+ * lp_gelu_fwd would compute from c, bit for bit): fc1 of a ViT block leaves with its activation.  Same shape limits. */
+int lp_gemm_nt_gelu_fwd(const void* a, const void* b, const float* bias, void* c_bf16, void* act_bf16, int M, int N, int K,
                         lp_stream_t stream);
 /* BatchNorm reductions fused into the store pass of the convolution next to it, so the normalised tensor is not re-read
  * for them (torch.nn.BatchNorm2d training forward / backward).  Every persistent workgroup adds the

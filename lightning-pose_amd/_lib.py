@@ -56,7 +56,7 @@ CONV_KERNEL_STEM_WGRAD_NB = 8
 BORDER_RENORM, BORDER_CLAMP = 0, 1
 TF_NONE, TF_SINGLE, TF_PER_FRAME, TF_PER_VIEW = 0, 1, 2, 3
 
-ABI_VERSION = 141   # include/lp_hip.h: LP_HIP_ABI_VERSION - the header these PROTOTYPES were written against (tests/test_abi_and_failloud.py)
+ABI_VERSION = 142   # include/lp_hip.h: LP_HIP_ABI_VERSION - the header these PROTOTYPES were written against (tests/test_abi_and_failloud.py)
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
@@ -94,6 +94,7 @@ PROTOTYPES = {
     "lp_conv_dgrad_bits": (_I, [_P, _P, C.POINTER(ConvGeom), _P, _P, _P, _I, _P]),
     "lp_gemm_nt": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, C.POINTER(GemmBatch), _P]),
     "lp_gemm_nt_gelu_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "lp_gemm_nt_gelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "lp_gemm_tn": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, C.POINTER(GemmBatch), _P]),
     "lp_attn_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P, _I, _P]),
     "lp_attn_bwd_kv": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, C.c_float, _P, _P, _I, _I, _I, _P]),

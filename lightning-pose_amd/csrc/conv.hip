@@ -70,6 +70,8 @@ struct ConvEpilogue {
     // straddles the boundary (host-checked: seg_images * rows per image is a multiple of the 128-row tile).  Segment s uses
     // bn_mean / bn_invstd + s * N and adds into stats_sums + s * 2 * N; 0 = one segment
     int seg_images;
+    // kEkGeluFwd (lp_gemm_nt_gelu_fwd): GELU of the stored output, same offsets
+    unsigned short* out2_bf16;
 };
 
 // one workgroup's contribution to a fused BatchNorm sum (`idx` = 2 * segment offset + component * N + column)
@@ -1473,6 +1475,21 @@ extern "C" int lp_gemm_nt(const void* a, int lda, const void* b, int ldb, void* 
     }
     if (nstore > 64) launch_igemm<128, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
     else launch_igemm<64, kModeFwd>(a, b, g, lat, M, N, K, ep, st, &gx, nb * nh, (unsigned)(2 * a_elems), (unsigned)(2 * b_elems));
+    return launch_status();
+}
+
+// lp_gemm_nt (+ bias) that also writes GELU of its output (conv_pipe.h: kEkGeluFwd)
+extern "C" int lp_gemm_nt_gelu_fwd(const void* a, const void* b, const float* bias, void* c_bf16, void* act_bf16, int M, int N, int K,
+                                   lp_stream_t stream) {
+    using namespace lp;
+    LP_REQUIRE(a && b && c_bf16 && act_bf16 && M > 0 && N > 0 && K > 0);
+    if ((long long)M * K >= (1LL << 31) || (long long)N * K >= (1LL << 31) || (long long)M * N >= (1LL << 32)) return LP_ERR_UNSUPPORTED;
+    ConvGeom g{1, 1, M, K, 1, M, N, 1, 1, 1, 0};
+    ConvEpilogue ep{(unsigned short*)c_bf16, nullptr, N, N, bias};
+    ep.out2_bf16 = (unsigned short*)act_bf16;
+    const Lattice lat{0, 1, 1, 0, 1, M, 0, 1, 1, 0, 1, 1};
+    if (N % 128 != 0 || !pipe_eligible(ep, M, N, K, K, M, true)) return LP_ERR_UNSUPPORTED;
+    launch_pipe<128, kModeFwd, kEkGeluFwd>(a, b, g, lat, M, N, K, ep, (hipStream_t)stream);
     return launch_status();
 }
 

@@ -84,7 +84,9 @@ __device__ __forceinline__ void store8(unsigned short* p, u16x8 v) { *reinterpre
 //   kEkGeluBwd  forward-mode GEMM whose store pass multiplies the (bf16-rounded) product by GELU'(u), u read at the output's own offsets
 //            as `addend` (lp_gemm_nt_gelu_bwd, round 6: the data gradient of a ViT block's fc2 leaves as the gradient of fc1's OUTPUT - the
 //            stand-alone GELU backward's write and read of the activation gradient are gone; the column sums = fc1's bias gradient)
-enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4, kEkPB = 5, kEkGeluBwd = 6 };
+//   kEkGeluFwd  forward GEMM that also writes GELU of its (bias-added, bf16-rounded) output to ep.out2_bf16 (lp_gemm_nt_gelu_fwd: a ViT block's
+//            fc1 leaves with its activation; the stand-alone GELU pass's read of the pre-activation is gone)
+enum { kEkNone = 0, kEkZ = 1, kEkAZB = 2, kEkPlain = 3, kEkInfer = 4, kEkPB = 5, kEkGeluBwd = 6, kEkGeluFwd = 7 };
 
 // HALO (3x3, stride 1, pad 1 - conv2 of every identity-stride block, forward and data gradient): the pixel operand is not fetched per
 // filter tap.  The ring above re-reads every activation row 9 times from L2 (once per tap: 27.7 us per tap on layer1's 64-channel layers,
@@ -104,8 +106,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                                                         unsigned x_bytes, unsigned w_bytes, ConvGeom g, Lattice lat, FastDiv div_img,
                                                         FastDiv div_row, int M, int N, int K, int tiles_n, int ntiles, ConvEpilogue ep,
                                                         HaloDivs hd) {
-    static_assert((MODE == kModeFwd && (EK == kEkNone || EK == kEkInfer || EK == kEkGeluBwd)) ||
-                      (MODE == kModeDgrad && EK != kEkNone && EK != kEkInfer && EK != kEkGeluBwd),
+    static_assert((MODE == kModeFwd && (EK == kEkNone || EK == kEkInfer || EK == kEkGeluBwd || EK == kEkGeluFwd)) ||
+                      (MODE == kModeDgrad && EK != kEkNone && EK != kEkInfer && EK != kEkGeluBwd && EK != kEkGeluFwd),
                   "trunk convolutions only");
     constexpr int NT = BN / 64;                  // 32-channel MFMA blocks per wave along N (wave tile 64 pixels x NT*32 channels)
     constexpr int NBL = BN / 64;                 // weight rows each thread stages per K step
@@ -549,6 +551,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                         w = pack_bf16x8(v);
                     }
                     store8(ep.out_bf16 + off, w);
+                    if (EK == kEkGeluFwd) {   // the activation beside it: the arithmetic of vit.hip's gelu_fwd_kernel on the value just stored
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = gelu_f(bf16_to_f32(w[q]));
+                        store8(ep.out2_bf16 + off, pack_bf16x8(v));
+                    }
                     if (want_stats) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
     // everything is applied before the single rounding to bf16, as in conv_igemm_kernel.
     constexpr int PH = 16 / RP;          // read-back passes per 16-pixel half
     constexpr int NPC = 2 * PH;          // pieces (8 channels of one row) per lane and 32-pixel chunk
-    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain || EK == kEkPB), kLz = (EK != kEkNone && EK != kEkInfer && EK != kEkPB && EK != kEkGeluBwd),
+    constexpr bool kLa = (EK == kEkAZB || EK == kEkPlain || EK == kEkPB), kLz = (EK != kEkNone && EK != kEkInfer && EK != kEkPB && EK != kEkGeluBwd && EK != kEkGeluFwd),
                    kLb = (EK == kEkAZB || EK == kEkPB);
     // (kEkAZB - the hottest data gradient, at the register cap - does not keep the output offsets of its pieces: its launches cover the full
     //  pixel lattice (host-checked), so an offset is two multiply-adds away and is recomputed in rb_process: 8 VGPRs, the 7 it used to spill)

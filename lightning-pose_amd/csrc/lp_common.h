@@ -40,11 +40,36 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (un
 #endif
 
 // 8 floats -> 8 bf16 (16 B)
-// GELU (exact, erf: HF ViT's "gelu") and its derivative - vit.hip's stand-alone passes and the fused store pass of conv_pipe.h (kEkGeluBwd)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_df(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// GELU (exact form, x Phi(x): HF ViT's "gelu") and its derivative - vit.hip's stand-alone passes and the fused store passes of conv_pipe.h
+// (kEkGeluBwd / kEkGeluFwd).  Phi(-|x|) = erfc(|x| / sqrt 2) / 2 through the Chebyshev fit of Numerical Recipes' erfcc (fractional error
+// < 1.2e-7 everywhere, so the negative tail keeps its RELATIVE accuracy: 0.5 x (1 + erf) cancels there) - one reciprocal, one exponential and
+// ten FMAs instead of the device library's branching erff, which made the fused store pass cost as much as the pass it replaced (round 6,
+// profiles/r06j_vit_step_ab.txt).  Against fp64 on bf16 inputs the rounded results differ in no element of 4 M (torch's fp32 F.gelu: 0.4 %).
+__device__ __forceinline__ float fast_rcp(float d) {   // v_rcp_f32 (1 ulp)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(d);
+#else
+    return 1.0f / d;
+#endif
 }
+__device__ __forceinline__ float gelu_phi(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = fast_rcp(fmaf(0.5f, z, 1.f));
+    float p = 0.17087277f;
+    p = fmaf(p, t, -0.82215223f);
+    p = fmaf(p, t, 1.48851587f);
+    p = fmaf(p, t, -1.13520398f);
+    p = fmaf(p, t, 0.27886807f);
+    p = fmaf(p, t, -0.18628806f);
+    p = fmaf(p, t, 0.09678418f);
+    p = fmaf(p, t, 0.37409196f);
+    p = fmaf(p, t, 1.00002368f);
+    p = fmaf(p, t, -1.26551223f);
+    const float tail = 0.5f * t * __expf(fmaf(-z, z, p));   // Phi(-|x|)
+    return x < 0.f ? tail : 1.f - tail;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_phi(x); }
+__device__ __forceinline__ float gelu_df(float x) { return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), gelu_phi(x)); }
 
 __device__ __forceinline__ u16x8 pack_bf16x8(const float (&f)[8]) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;

@@ -251,6 +251,23 @@ class ViTEngine(Engine):
             nbytes=2.0 * (M * l.K + M * l.N + l.N * l.K))
         return out
 
+    def _linear_gelu(self, x: torch.Tensor, l: Lin, M: int) -> tuple[torch.Tensor, torch.Tensor]:
+        """(u, GELU(u)) for u = x W^T + b: one launch whose store pass writes both (lp_gemm_nt_gelu_fwd, round 6); LP_VIT_GELU_FUSED=0 or a
+        shape the pipelined kernel does not tile: the Linear layer, then lp_gelu_fwd"""
+        u = torch.empty(M, l.N, device=self.device, dtype=torch.bfloat16)
+        act = torch.empty_like(u)
+        if os.environ.get("LP_VIT_GELU_FUSED", "1") != "0":
+            rc = self._timed("lp_gemm_nt<linear fwd+gelu>", 2.0 * M * l.N * l.K, lambda: self._lib.lp_gemm_nt_gelu_fwd(
+                _p(x), _p(self.Wb[l.w_off:]), _p(self.P[l.b_off:l.b_off + l.N]), _p(u), _p(act), M, l.N, l.K, ops._stream()),
+                nbytes=2.0 * (M * l.K + 2 * M * l.N + l.N * l.K))
+            if rc == 0:
+                return u, act
+            if rc != -2:   # (LP_ERR_UNSUPPORTED)
+                check(rc, "lp_gemm_nt_gelu_fwd")
+        u = self._linear(x, l, M)
+        check(self._lib.lp_gelu_fwd(_p(u), u.numel(), _p(act), ops._stream()), "lp_gelu_fwd")
+        return u, act
+
     def _linear_bwd(self, l: Lin, x: torch.Tensor, dy: torch.Tensor, M: int, need_dx: bool = True, bias_done: bool = False,
                     gelu_of: tuple[torch.Tensor, torch.Tensor] | None = None):
         """bias / weight gradients into G; returns dX = dY W (bf16) if wanted.  ``bias_done``: the kernel that produced ``dy`` already left its
@@ -400,9 +417,7 @@ class ViTEngine(Engine):
             proj = self._linear(attn, L["proj"], M)
             x_in = x
             y2, m2, r2, x = self._ln(x, proj, L["ln2"], M)
-            h1 = self._linear(y2, L["fc1"], M)
-            a1 = torch.empty_like(h1)
-            check(self._lib.lp_gelu_fwd(_p(h1), h1.numel(), _p(a1), ops._stream()), "lp_gelu_fwd")
+            h1, a1 = self._linear_gelu(y2, L["fc1"], M)
             delta = self._linear(a1, L["fc2"], M)
             if keep:
                 for nm, v in (("x_in", x_in), ("m1", m1), ("r1", r1), ("y1", y1), ("qkv", qkv), ("P", S), ("attn", attn), ("x_mid", x),

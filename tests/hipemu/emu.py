@@ -372,6 +372,13 @@ def gemm_nt(a_bits, lda, b_bits, ldb, M, N, K, ldc, c_rows, n_store=0, bias=None
     return cf.np() if f32_out else cb.np()
 
 
+def gemm_nt_gelu_fwd(a_bits, b_bits, bias, M, N, K):
+    """lp_gemm_nt_gelu_fwd: (c bits, GELU(c) bits), both (M, N)"""
+    ab, bb, bi, cb, gb = Buf(a_bits), Buf(b_bits), B(bias, np.float32), Z((M, N), np.uint16), Z((M, N), np.uint16)
+    ok(lib().lp_gemm_nt_gelu_fwd(ab.p, bb.p, ptr(bi), cb.p, gb.p, M, N, K, stream()))
+    return cb.np(), gb.np()
+
+
 def gemm_nt_gelu_bwd(a_bits, b_bits, u_bits, M, N, K, colsum=True):
     """lp_gemm_nt_gelu_bwd: (c bits (M, N), column sums of c as fp32 (N,) or None); raises Unsupported shapes as the library reports them"""
     ab, bb, ub, cb = Buf(a_bits), Buf(b_bits), Buf(u_bits), Z((M, N), np.uint16)

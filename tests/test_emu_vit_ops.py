@@ -245,3 +245,32 @@ def test_gemm_with_gelu_backward_in_the_store_pass(kernel_backend, M, N, K, monk
     torch.testing.assert_close(torch.from_numpy(colsum).double(), want, atol=1e-4 * float(want.abs().max()) + 1e-5, rtol=1e-5)
     with pytest.raises(Exception):   # a column count the pipelined kernel does not tile: reported, the caller keeps the two-pass form
         emu.gemm_nt_gelu_bwd(bits(a), bits(b)[:64], bits(u)[:, :64].copy(), M, 64, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (577, 256, 192)])
+def test_gemm_that_also_writes_its_gelu(kernel_backend, M, N, K, monkeypatch):
+    """lp_gemm_nt_gelu_fwd = lp_gemm_nt (+ bias) and lp_gelu_fwd of its output, both bit for bit"""
+    monkeypatch.setenv("LP_CONV_MAX_WGS", "2")
+    gen = torch.Generator().manual_seed(M + N + K + 1)
+    a = bf(torch.randn(M, K, generator=gen))
+    b = bf(torch.randn(N, K, generator=gen) * 0.2)
+    bias = torch.randn(N, generator=gen) * 0.3
+    c0 = emu.gemm_nt(bits(a).ravel(), K, bits(b).ravel(), K, M, N, K, N, M, bias=bias.numpy()).reshape(M, N)
+    c, act = emu.gemm_nt_gelu_fwd(bits(a), bits(b), bias.numpy(), M, N, K)
+    assert np.array_equal(c, c0)
+    assert np.array_equal(act, emu.gelu(c0))
+    torch.testing.assert_close(unbits(act), bf(F.gelu(unbits(c0))), atol=1e-2, rtol=1e-2)
+
+
+def test_gelu_keeps_its_relative_accuracy_in_the_tails():
+    """gelu_phi (lp_common.h): x Phi(x) through an erfc fit with 1.2e-7 FRACTIONAL error - against fp64 the bf16 results agree everywhere,
+    also where 0.5 x (1 + erf) cancels (torch's own fp32 F.gelu differs from fp64 in ~0.4 % of bf16 results there)"""
+    gen = torch.Generator().manual_seed(9)
+    x = bf(torch.cat([torch.randn(200000, generator=gen) * 1.5, torch.linspace(-9, 9, 20000)]))
+    x = x[: x.numel() // 8 * 8]
+    exact = (x.double() * 0.5 * torch.erfc(-x.double() / 2 ** 0.5)).float()
+    got = unbits(emu.gelu(bits(x)))
+    assert float((got != bf(exact)).float().mean()) < 2e-4
+    dexact = (0.5 * torch.erfc(-x.double() / 2 ** 0.5) + x.double() * torch.exp(-0.5 * x.double() ** 2) / (2 * np.pi) ** 0.5).float()
+    one = bf(torch.ones_like(x))
+    assert float((unbits(emu.gelu(bits(x), bits(one))) != bf(dexact)).float().mean()) < 2e-4
