@@ -545,16 +545,18 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const unsigned short* __
                         w = pack_bf16x8(v);
                     }
                     if (gelub) {   // d u = bf16(d a) * GELU'(u): the arithmetic of the stand-alone pass (vit.hip: gelu_bwd_kernel) on the value it would have read
-                        float v[8];
+                        float v[8], u8[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = bf16_to_f32(w[q]) * gelu_df(bf16_to_f32(radd[mt][ps][q]));
+                        for (int q = 0; q < 8; ++q) v[q] = bf16_to_f32(w[q]), u8[q] = bf16_to_f32(radd[mt][ps][q]);
+                        gelu8_bwd(v, u8);
                         w = pack_bf16x8(v);
                     }
                     store8(ep.out_bf16 + off, w);
                     if (EK == kEkGeluFwd) {   // the activation beside it: the arithmetic of vit.hip's gelu_fwd_kernel on the value just stored
                         float v[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = gelu_f(bf16_to_f32(w[q]));
+                        for (int q = 0; q < 8; ++q) v[q] = bf16_to_f32(w[q]);
+                        gelu8(v);
                         store8(ep.out2_bf16 + off, pack_bf16x8(v));
                     }
                     if (want_stats) {

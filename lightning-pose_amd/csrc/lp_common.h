@@ -41,10 +41,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (un
 
 // 8 floats -> 8 bf16 (16 B)
 // GELU (exact form, x Phi(x): HF ViT's "gelu") and its derivative - vit.hip's stand-alone passes and the fused store passes of conv_pipe.h
-// (kEkGeluBwd / kEkGeluFwd).  Phi(-|x|) = erfc(|x| / sqrt 2) / 2 through the Chebyshev fit of Numerical Recipes' erfcc (fractional error
-// < 1.2e-7 everywhere, so the negative tail keeps its RELATIVE accuracy: 0.5 x (1 + erf) cancels there) - one reciprocal, one exponential and
-// ten FMAs instead of the device library's branching erff, which made the fused store pass cost as much as the pass it replaced (round 6,
-// profiles/r06j_vit_step_ab.txt).  Against fp64 on bf16 inputs the rounded results differ in no element of 4 M (torch's fp32 F.gelu: 0.4 %).
+// (kEkGeluFwd / kEkGeluBwd), eight values at a time in PAIRS: the arithmetic is v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per VALU slot), the
+// reciprocal and the exponentials are the only scalar-rate instructions.  Instead of the device library's branching erff - in a store pass
+// GELU's instructions are not hidden behind memory as they are in a streaming kernel (round 6, profiles/r06j/k/l_vit_step_ab.txt):
+//   forward   Phi(-|x|) = erfc(|x| / sqrt 2) / 2 = t exp(-z^2 + P9(t)) / 2, t = 1 / (1 + z / 2): the Chebyshev fit of Numerical Recipes' erfcc,
+//             FRACTIONAL error < 1.2e-7 everywhere, so the negative tail keeps its relative accuracy (0.5 x (1 + erf) cancels there): against
+//             fp64 on bf16 inputs the rounded results differ in no element of 4 M (torch's fp32 F.gelu: 0.4 %)
+//   backward  Phi(-|x|) = P5(t) E / 2, t = 1 / (1 + 0.3275911 z), E = exp(-x^2 / 2) (Abramowitz & Stegun 7.1.26, |error| < 1.5e-7 ABSOLUTE -
+//             enough for Phi + x phi, which is O(1) wherever it matters): ONE exponential serves both terms; 0.014 % of the bf16 results
+//             differ from fp64's by one place.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fast_rcp(float d) {   // v_rcp_f32 (1 ulp)
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rcpf(d);
@@ -52,24 +58,62 @@ __device__ __forceinline__ float fast_rcp(float d) {   // v_rcp_f32 (1 ulp)
     return 1.0f / d;
 #endif
 }
-__device__ __forceinline__ float gelu_phi(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = fast_rcp(fmaf(0.5f, z, 1.f));
-    float p = 0.17087277f;
-    p = fmaf(p, t, -0.82215223f);
-    p = fmaf(p, t, 1.48851587f);
-    p = fmaf(p, t, -1.13520398f);
-    p = fmaf(p, t, 0.27886807f);
-    p = fmaf(p, t, -0.18628806f);
-    p = fmaf(p, t, 0.09678418f);
-    p = fmaf(p, t, 0.37409196f);
-    p = fmaf(p, t, 1.00002368f);
-    p = fmaf(p, t, -1.26551223f);
-    const float tail = 0.5f * t * __expf(fmaf(-z, z, p));   // Phi(-|x|)
-    return x < 0.f ? tail : 1.f - tail;
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return f32x2_t{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};
+#endif
 }
-__device__ __forceinline__ float gelu_f(float x) { return x * gelu_phi(x); }
-__device__ __forceinline__ float gelu_df(float x) { return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), gelu_phi(x)); }
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, float c) { return fma2(a, b, f32x2_t{c, c}); }
+__device__ __forceinline__ f32x2_t gelu_f2(f32x2_t x) {
+    const f32x2_t z = f32x2_t{fabsf(x.x), fabsf(x.y)} * 0.70710678118654752f;
+    const f32x2_t d = fma2(z, f32x2_t{0.5f, 0.5f}, 1.f);
+    const f32x2_t t = {fast_rcp(d.x), fast_rcp(d.y)};
+    f32x2_t p = fma2(t, f32x2_t{0.17087277f, 0.17087277f}, -0.82215223f);
+    p = fma2(p, t, 1.48851587f);
+    p = fma2(p, t, -1.13520398f);
+    p = fma2(p, t, 0.27886807f);
+    p = fma2(p, t, -0.18628806f);
+    p = fma2(p, t, 0.09678418f);
+    p = fma2(p, t, 0.37409196f);
+    p = fma2(p, t, 1.00002368f);
+    p = fma2(p, t, -1.26551223f);
+    const f32x2_t a = fma2(-z, z, p);
+    const f32x2_t tail = t * 0.5f * f32x2_t{__expf(a.x), __expf(a.y)};   // Phi(-|x|)
+    const f32x2_t up = 1.f - tail;
+    return x * f32x2_t{x.x < 0.f ? tail.x : up.x, x.y < 0.f ? tail.y : up.y};
+}
+__device__ __forceinline__ f32x2_t gelu_df2(f32x2_t x) {
+    const f32x2_t z = f32x2_t{fabsf(x.x), fabsf(x.y)} * (0.3275911f * 0.70710678118654752f);
+    const f32x2_t d = z + 1.f;
+    const f32x2_t t = {fast_rcp(d.x), fast_rcp(d.y)};
+    const f32x2_t h = x * x * -0.5f;
+    const f32x2_t e = {__expf(h.x), __expf(h.y)};                            // exp(-x^2 / 2)
+    f32x2_t p = fma2(t, f32x2_t{1.061405429f, 1.061405429f}, -1.453152027f);
+    p = fma2(p, t, 1.421413741f);
+    p = fma2(p, t, -0.284496736f);
+    p = fma2(p, t, 0.254829592f);
+    const f32x2_t tail = p * t * 0.5f * e;                                   // Phi(-|x|)
+    const f32x2_t up = 1.f - tail;
+    const f32x2_t phi = {x.x < 0.f ? tail.x : up.x, x.y < 0.f ? tail.y : up.y};
+    return fma2(x * 0.3989422804014327f, e, phi);
+}
+// eight values at a time (every caller's unit: one 16-B piece of bf16)
+__device__ __forceinline__ void gelu8(float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_t g = gelu_f2(f32x2_t{v[i], v[i + 1]});
+        v[i] = g.x, v[i + 1] = g.y;
+    }
+}
+__device__ __forceinline__ void gelu8_bwd(float (&d)[8], const float (&u)[8]) {   // d *= GELU'(u)
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2_t g = f32x2_t{d[i], d[i + 1]} * gelu_df2(f32x2_t{u[i], u[i + 1]});
+        d[i] = g.x, d[i + 1] = g.y;
+    }
+}
 
 __device__ __forceinline__ u16x8 pack_bf16x8(const float (&f)[8]) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;

@@ -287,14 +287,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
 }
 
 // ---- GELU (exact, erf) on bf16 streams --------------------------------------------------------------------------------
-// (gelu_f / gelu_df: lp_common.h - the Linear layers' store pass uses the same two functions, conv_pipe.h: kEkGeluBwd)
+// (gelu8 / gelu8_bwd: lp_common.h - the Linear layers' store passes use the same two functions, conv_pipe.h: kEkGeluFwd / kEkGeluBwd)
 
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const unsigned short* __restrict__ x, size_t n_chunks, unsigned short* __restrict__ y) {
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += (size_t)gridDim.x * 256) {
         float v[8];
         unpack8v(*reinterpret_cast<const u16x8*>(x + q * 8), v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+        gelu8(v);
         *reinterpret_cast<u16x8*>(y + q * 8) = pack_bf16x8(v);
     }
 }
@@ -305,8 +304,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const unsigned short* __r
         float v[8], d[8];
         unpack8v(*reinterpret_cast<const u16x8*>(x + q * 8), v);
         unpack8v(*reinterpret_cast<const u16x8*>(dy + q * 8), d);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] *= gelu_df(v[i]);
+        gelu8_bwd(d, v);
         *reinterpret_cast<u16x8*>(dx + q * 8) = pack_bf16x8(d);
     }
 }
@@ -327,8 +325,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const unsigned sho
             float v[8], d[8];
             unpack8v(*reinterpret_cast<const u16x8*>(x + q * 8), v);
             unpack8v(*reinterpret_cast<const u16x8*>(dy + q * 8), d);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) d[i] *= gelu_df(v[i]);
+            gelu8_bwd(d, v);
             *reinterpret_cast<u16x8*>(dx + q * 8) = pack_bf16x8(d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += d[i];   // (fp32: the reference's bias gradient sums the unrounded dy)

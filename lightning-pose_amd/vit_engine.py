@@ -256,7 +256,7 @@ class ViTEngine(Engine):
         shape the pipelined kernel does not tile: the Linear layer, then lp_gelu_fwd"""
         u = torch.empty(M, l.N, device=self.device, dtype=torch.bfloat16)
         act = torch.empty_like(u)
-        if os.environ.get("LP_VIT_GELU_FUSED", "1") != "0":
+        if os.environ.get("LP_VIT_GELU_FUSED", "1") not in ("0", "bwd"):
             rc = self._timed("lp_gemm_nt<linear fwd+gelu>", 2.0 * M * l.N * l.K, lambda: self._lib.lp_gemm_nt_gelu_fwd(
                 _p(x), _p(self.Wb[l.w_off:]), _p(self.P[l.b_off:l.b_off + l.N]), _p(u), _p(act), M, l.N, l.K, ops._stream()),
                 nbytes=2.0 * (M * l.K + 2 * M * l.N + l.N * l.K))
