@@ -97,11 +97,13 @@ __global__ __launch_bounds__(256) void small_matmul_kernel(const float* __restri
     }
 }
 
-// ---- LayerNorm over D (one wave per row, D % 4 == 0, D <= 1024), optional residual add in front ---------------------------
+// ---- LayerNorm over D (D % 4 == 0, D <= 1024), optional residual add in front ---------------------------------------------------------
 // x_out = x (+ delta);  y = (x_out - mean) * rstd * gamma + beta.  `drop_T` > 0: rows with (row % drop_T) == 0 ([CLS]) are
 // not written to y and the others are compacted (the feature map the head consumes).
-// A lane owns float4 pieces (piece index lane + 64 * pass): 16-B accesses on the fp32 streams, 8-B on the bf16 ones.
-constexpr int kLnPass = 4;  // D <= 4 * 64 * 4 = 1024
+// HALF a wave per row (round 6): a lane owns float4 pieces (piece index hl + 32 * pass, hl = lane & 31) - 16-B accesses on the fp32 streams,
+// 8-B on the bf16 ones - so ViT-S's 384 columns are exactly 3 passes of 32 lanes (one wave per row covered them in 1.5 passes of 64: a quarter
+// of the lanes idle) and a wave has TWO rows' loads in flight before the first of its two dependent reductions.  NP = passes that cover D.
+constexpr int kLnMaxD = 1024;
 __device__ __forceinline__ void unpack4(const u16x4& v, float (&f)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = bf16_to_f32(v[i]);
@@ -111,23 +113,31 @@ __device__ __forceinline__ u16x4 pack4(const float (&f)[4]) {
     u16x4 v = {(unsigned short)(lo & 0xffffu), (unsigned short)(lo >> 16), (unsigned short)(hi & 0xffffu), (unsigned short)(hi >> 16)};
     return v;
 }
+__device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes of this lane's half
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
 
+template <int NP>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const unsigned short* __restrict__ delta,
                                                             float* __restrict__ x_out, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, int M, int D, int drop_T,
                                                             unsigned short* __restrict__ y, float* __restrict__ mean,
                                                             float* __restrict__ rstd) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
     const int pieces = D >> 2;
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        float v[kLnPass][4];
+    for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < M; row0 += gridDim.x * 8) {
+        const int row = row0 + half;
+        const bool live = row < M;
+        float v[NP][4];
         float s = 0.f;
 #pragma unroll
-        for (int p = 0; p < kLnPass; ++p) {
-            const int pc = lane + 64 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int pc = hl + 32 * p;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[p][e] = 0.f;
-            if (pc < pieces) {
+            if (live && pc < pieces) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + pc * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[p][e] = xv[e];
@@ -141,19 +151,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 for (int e = 0; e < 4; ++e) s += v[p][e];
             }
         }
-        const float mu = wave_sum(s) / (float)D;
+        const float mu = half_wave_sum(s) / (float)D;
         float ss = 0.f;
 #pragma unroll
-        for (int p = 0; p < kLnPass; ++p)
-            if (lane + 64 * p < pieces) {
+        for (int p = 0; p < NP; ++p)
+            if (hl + 32 * p < pieces) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = v[p][e] - mu;
                     ss = fmaf(d, d, ss);
                 }
             }
-        const float rs = 1.f / sqrtf(wave_sum(ss) / (float)D + eps);
-        if (lane == 0) {
+        const float rs = 1.f / sqrtf(half_wave_sum(ss) / (float)D + eps);
+        if (!live) continue;   // (after the shuffles: both halves of a wave take part in them)
+        if (hl == 0) {
             mean[row] = mu;
             rstd[row] = rs;
         }
@@ -165,8 +176,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             yrow = b * (drop_T - 1) + t - 1;
         }
 #pragma unroll
-        for (int p = 0; p < kLnPass; ++p) {
-            const int pc = lane + 64 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int pc = hl + 32 * p;
             if (pc < pieces) {
                 if (x_out != nullptr) {
                     const f32x4 o = {v[p][0], v[p][1], v[p][2], v[p][3]};
@@ -187,20 +198,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-workgroup partial d gamma / d beta -> atomics
 // COLSUM (round 3): also the column sums of the bf16 stream gradient it writes - that tensor is the dy of the NEXT Linear backward, and its
 // column sums are that layer's bias gradient: taken here, the weight gradient needs no bias pass and may run on the pipelined kernel.
-// NP = passes of 64 lanes x 4 columns that cover D (2 for ViT-S: the accumulators of unused passes would cost a wave of occupancy per SIMD)
+// Half a wave per row, as the forward kernel; NP = passes of 32 lanes x 4 columns that cover D (3 for ViT-S, 6 for ViT-B).
 template <bool COLSUM, int NP>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int M, int D, int drop_T,
                                                             float* __restrict__ dx, unsigned short* __restrict__ dx_bf16,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ colsum) {
-    __shared__ float red[COLSUM ? 3 : 2][4][256];  // [gamma|beta|column sum][wave][column of the current pass]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float red[COLSUM ? 3 : 2][8][128];  // [gamma|beta|column sum][wave, half][column of the current pass]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
     const int pieces = D >> 2;
     float ag[NP][4], ab[NP][4], gm[NP][4], ac[COLSUM ? NP : 1][4];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int pc = lane + 64 * p;
+        const int pc = hl + 32 * p;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             ag[p][e] = ab[p][e] = 0.f;
@@ -208,23 +219,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             gm[p][e] = pc < pieces ? gamma[pc * 4 + e] : 0.f;
         }
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < M; row0 += gridDim.x * 8) {
+        const int row = row0 + half;
+        const bool live = row < M;
         int yrow = row;
-        bool has = true;
-        if (drop_T > 0) {
+        bool has = live;
+        if (drop_T > 0 && live) {
             const int b = row / drop_T, t = row - b * drop_T;
             has = t > 0;
             yrow = b * (drop_T - 1) + t - 1;
         }
-        const float mu = mean[row], rs = rstd[row];
+        const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
         float g[NP][4], xh[NP][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int pc = lane + 64 * p;
+            const int pc = hl + 32 * p;
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[p][e] = xh[p][e] = 0.f;
-            if (pc < pieces) {
+            if (live && pc < pieces) {
                 float d[4] = {0.f, 0.f, 0.f, 0.f};
                 if (has) unpack4(*reinterpret_cast<const u16x4*>(dy + (size_t)yrow * D + pc * 4), d);
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * D + pc * 4);
@@ -239,11 +252,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
+        s1 = half_wave_sum(s1) / (float)D;
+        s2 = half_wave_sum(s2) / (float)D;
+        if (!live) continue;   // (after the shuffles)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int pc = lane + 64 * p;
+            const int pc = hl + 32 * p;
             if (pc < pieces) {
                 f32x4* dst = reinterpret_cast<f32x4*>(dx + (size_t)row * D + pc * 4);
                 f32x4 o = *dst;
@@ -262,26 +276,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             }
         }
     }
-    // column sums of this workgroup: 4 waves -> LDS -> one atomic per column, one 256-column pass at a time
+    // column sums of this workgroup: 4 waves x 2 halves -> LDS -> one atomic per column, one 128-column pass at a time
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (64 * p >= pieces) break;
+        if (32 * p >= pieces) break;
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            red[0][wave][lane * 4 + e] = ag[p][e];
-            red[1][wave][lane * 4 + e] = ab[p][e];
-            if (COLSUM) red[COLSUM ? 2 : 0][wave][lane * 4 + e] = ac[COLSUM ? p : 0][e];
+            red[0][wave * 2 + half][hl * 4 + e] = ag[p][e];
+            red[1][wave * 2 + half][hl * 4 + e] = ab[p][e];
+            if (COLSUM) red[COLSUM ? 2 : 0][wave * 2 + half][hl * 4 + e] = ac[COLSUM ? p : 0][e];
         }
         __syncthreads();
         const int cl = threadIdx.x;            // column within this pass
-        const int c = 256 * p + cl;
-        if (c < D) {
-            const float tg = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-            const float tb = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-            atomicAdd(&dgamma[c], tg);
-            atomicAdd(&dbeta[c], tb);
-            if (COLSUM) atomicAdd(&colsum[c], (red[COLSUM ? 2 : 0][0][cl] + red[COLSUM ? 2 : 0][1][cl]) + (red[COLSUM ? 2 : 0][2][cl] + red[COLSUM ? 2 : 0][3][cl]));
+        const int c = 128 * p + cl;
+        if (cl < 128 && c < D) {
+            auto total = [&](int k) {
+                return ((red[k][0][cl] + red[k][1][cl]) + (red[k][2][cl] + red[k][3][cl])) + ((red[k][4][cl] + red[k][5][cl]) + (red[k][6][cl] + red[k][7][cl]));
+            };
+            atomicAdd(&dgamma[c], total(0));
+            atomicAdd(&dbeta[c], total(1));
+            if (COLSUM) atomicAdd(&colsum[c], total(COLSUM ? 2 : 0));
         }
     }
 }
@@ -569,11 +584,21 @@ extern "C" int lp_layernorm_fwd(const float* x, const void* delta_bf16, float* x
                                 int M, int D, int drop_T, void* y_bf16, float* mean, float* rstd, lp_stream_t stream) {
     using namespace lp;
     LP_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd && M > 0 && D > 0 && drop_T >= 0 && (delta_bf16 == nullptr || x_out != nullptr));
-    if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
-    int blocks = (M + 3) / 4;
+    if (D > kLnMaxD || D % 4 != 0) return LP_ERR_UNSUPPORTED;
+    int blocks = (M + 7) / 8;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const unsigned short*)delta_bf16, x_out,
-                       gamma, beta, eps, M, D, drop_T, (unsigned short*)y_bf16, mean, rstd);
+#define LP_LN_FWD(NP_)                                                                                                                      \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<NP_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (const unsigned short*)delta_bf16, \
+                       x_out, gamma, beta, eps, M, D, drop_T, (unsigned short*)y_bf16, mean, rstd)
+    switch ((D + 127) / 128) {
+    case 1: LP_LN_FWD(1); break;
+    case 2: LP_LN_FWD(2); break;
+    case 3: LP_LN_FWD(3); break;
+    case 4: LP_LN_FWD(4); break;
+    case 5: case 6: LP_LN_FWD(6); break;
+    default: LP_LN_FWD(8); break;
+    }
+#undef LP_LN_FWD
     return launch_status();
 }
 
@@ -582,24 +607,27 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* 
                               float* colsum_acc = nullptr) {
     using namespace lp;
     LP_REQUIRE(dy_bf16 && x && mean && rstd && gamma && dx_acc && dgamma_acc && dbeta_acc && M > 0 && D > 0 && drop_T >= 0);
-    if (D > 256 * kLnPass || D % 4 != 0) return LP_ERR_UNSUPPORTED;
-    int blocks = (M + 3) / 4;
+    if (D > kLnMaxD || D % 4 != 0) return LP_ERR_UNSUPPORTED;
+    int blocks = (M + 7) / 8;
     if (blocks > 2048) blocks = 2048;  // 8 waves per SIMD; also bounds the d gamma / d beta atomics per column
 #define LP_LN_BWD(CS_, NP_)                                                                                                                   \
     hipLaunchKernelGGL((layernorm_bwd_kernel<CS_, NP_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dy_bf16, x, mean, \
                        rstd, gamma, M, D, drop_T, dx_acc, (unsigned short*)dx_bf16, dgamma_acc, dbeta_acc, colsum_acc)
-    const int np = (D + 255) / 256;
-    if (colsum_acc != nullptr) {
-        if (np == 1) LP_LN_BWD(true, 1);
-        else if (np == 2) LP_LN_BWD(true, 2);
-        else if (np == 3) LP_LN_BWD(true, 3);
-        else LP_LN_BWD(true, 4);
-    } else {
-        if (np == 1) LP_LN_BWD(false, 1);
-        else if (np == 2) LP_LN_BWD(false, 2);
-        else if (np == 3) LP_LN_BWD(false, 3);
-        else LP_LN_BWD(false, 4);
+#define LP_LN_BWD_NP(CS_)                        \
+    switch ((D + 127) / 128) {                   \
+    case 1: LP_LN_BWD(CS_, 1); break;            \
+    case 2: LP_LN_BWD(CS_, 2); break;            \
+    case 3: LP_LN_BWD(CS_, 3); break;            \
+    case 4: LP_LN_BWD(CS_, 4); break;            \
+    case 5: case 6: LP_LN_BWD(CS_, 6); break;    \
+    default: LP_LN_BWD(CS_, 8); break;           \
     }
+    if (colsum_acc != nullptr) {
+        LP_LN_BWD_NP(true)
+    } else {
+        LP_LN_BWD_NP(false)
+    }
+#undef LP_LN_BWD_NP
 #undef LP_LN_BWD
     return launch_status();
 }

@@ -43,7 +43,7 @@ def test_small_matmul_is_interpolation_and_adjoint():
     torch.testing.assert_close(torch.from_numpy(got), y0 + w.T @ g, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,D,drop_T", [(37, 384, 0), (3 * 5, 96, 5), (9, 1024, 0)])
+@pytest.mark.parametrize("M,D,drop_T", [(37, 384, 0), (3 * 5, 96, 5), (9, 1024, 0), (10, 768, 0), (7, 640, 0), (1, 128, 0), (4 * 7, 256, 7)])
 def test_layernorm_fwd_bwd(M, D, drop_T):
     gen = torch.Generator().manual_seed(M + D)
     x = (torch.randn(M, D, generator=gen) * 2 + 0.3)
