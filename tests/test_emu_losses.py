@@ -85,7 +85,7 @@ def test_unimodal_mse_matches_oracle():
     assert loss0 == 0.0 and not grad0.any()
 
 
-@pytest.mark.parametrize("b,k,n,c", [(2, 5, 48, 8), (2, 17, 2300, 64), (1, 5, 70, 6)])
+@pytest.mark.parametrize("b,k,n,c", [(2, 5, 48, 8), (2, 17, 2300, 64), (1, 5, 70, 6), (2, 17, 4101, 64), (1, 3, 9216, 8)])   # (n >= 4096: four workgroups share a frame)
 def test_softmax2d_fwd_bwd(b, k, n, c):
     """forward + backward; c % 8 == 0 takes the pixel-major backward (whole channel rows, pad channels zeroed by the kernel: the output
     buffer is pre-filled with garbage to prove it), c = 6 the per-map fallback (pad channels untouched: pre-filled with zeros)"""
@@ -102,7 +102,7 @@ def test_softmax2d_fwd_bwd(b, k, n, c):
     assert not gin[:, :, k:].any()
 
 
-@pytest.mark.parametrize("b,k,n,c", [(3, 17, 2500, 64), (2, 17, 300, 17), (1, 32, 1100, 32)])
+@pytest.mark.parametrize("b,k,n,c", [(3, 17, 2500, 64), (2, 17, 300, 17), (1, 32, 1100, 32), (2, 32, 4099, 32)])
 def test_softmax2d_pixel_major_and_fallback(b, k, n, c):
     """the head's layout (K logits of a pixel contiguous, padded to c): one 1024-lane workgroup per frame; c = 17 (rows not
     16-B readable) takes the per-map kernel"""
