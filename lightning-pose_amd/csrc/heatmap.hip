@@ -278,6 +278,10 @@ __global__ __launch_bounds__(256) void softmax2d_fwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = expf(src[(size_t)i * si] - mx) / s;
 }
 
+// (Measured and dropped, round 6: four workgroups per frame - each taking the (max, sum) pairs / the dots over the WHOLE maps and writing a
+// quarter of the pixels - because 192 frames leave a quarter of the CUs without a workgroup.  Slower both ways, 167 -> 391 us forward and
+// 333 -> 409 us backward: the first pass is the expensive one (two exponentials per logit), and it is the one the slices repeat;
+// profiles/r06o_softmax_kernels.txt, profiles/retired/r06_softmax_slices.patch.)
 // Same soft-max for pixel-major logits (sk == 1: the K logits of a pixel are contiguous, as the head's last layer writes them).
 // One 1024-lane workgroup per frame: every lane owns pixels i = lane, lane + 1024, ... and reads a pixel's K logits as 16-B
 // pieces (the per-map kernel above reads the same cache lines K times with a 4-B stride); pass 1 keeps K online (max, sum)
@@ -344,10 +348,7 @@ __global__ __launch_bounds__(1024) void softmax2d_pixmajor_kernel(const float* _
     }
     __syncthreads();
     float* dst = out + (size_t)b * K * n;
-    // gridDim.y workgroups share a frame (round 6): each merges the (max, sum) pairs of the WHOLE maps - the same values in the same order,
-    // the logits' re-reads are L2 hits - and writes its slice of the pixels
-    const int per = (n + (int)gridDim.y - 1) / (int)gridDim.y, i0 = (int)blockIdx.y * per, i1 = i0 + per < n ? i0 + per : n;
-    for (int i = i0 + tid; i < i1; i += 1024) {
+    for (int i = tid; i < n; i += 1024) {
         const f32x4* row = reinterpret_cast<const f32x4*>(src + (size_t)i * si);
 #pragma unroll
         for (int q = 0; q < kSmK / 4; ++q) {
@@ -419,10 +420,7 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
     __syncthreads();
     unsigned short* dst = gin + (size_t)b * sb;
     const int chunks = (int)(si >> 3);
-    // gridDim.y workgroups share a frame (round 6: 192 frames left a quarter of the CUs without a workgroup and the rest with one): each
-    // takes the dots over the WHOLE maps - the same sums in the same order, the re-reads are L2 hits - and writes its slice of the pixels
-    const int per = (n + (int)gridDim.y - 1) / (int)gridDim.y, i0 = (int)blockIdx.y * per, i1 = i0 + per < n ? i0 + per : n;
-    for (int i = i0 + tid; i < i1; i += 1024) {
+    for (int i = tid; i < n; i += 1024) {
         const float* pk = p + i;
         const float* gk = g + i;
         for (int c = 0; c < chunks; ++c) {
@@ -678,10 +676,6 @@ extern "C" int lp_unimodal_mse_bwd(const float* kp_aug, const float* pred, int S
     return launch_status();
 }
 
-// workgroups per frame of the pixel-major soft-max kernels: 4 when one per frame would leave CUs empty (192 frames on 256 CUs) and a frame's
-// maps are large enough to share
-static int softmax_slices(int B, int n) { return (B >= 1024 || n < 4096) ? 1 : 4; }
-
 extern "C" int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, long stride_k, int B, int K, int n, float* out,
                                 lp_stream_t stream) {
     using namespace lp;
@@ -689,8 +683,7 @@ extern "C" int lp_softmax2d_fwd(const float* in, long stride_b, long stride_i, l
     if (B == 0) return LP_OK;
     // pixel-major logits (the head's layout): one workgroup per frame reading whole pixels; needs 16-B readable rows
     if (stride_k == 1 && K <= kSmK && stride_i % 4 == 0 && stride_i >= ((K + 3) & ~3) && stride_b % 4 == 0 && ((uintptr_t)in & 15) == 0)
-        hipLaunchKernelGGL(softmax2d_pixmajor_kernel, dim3(B, softmax_slices(B, n)),
-                           dim3(1024), 0, (hipStream_t)stream, in, stride_b, stride_i, K, n, out);
+        hipLaunchKernelGGL(softmax2d_pixmajor_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, in, stride_b, stride_i, K, n, out);
     else
         hipLaunchKernelGGL(softmax2d_fwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, in, stride_b, stride_i, stride_k, K, n, out);
     return launch_status();
@@ -703,7 +696,7 @@ extern "C" int lp_softmax2d_bwd(const float* prob, const float* gprob, int B, in
     if (B == 0) return LP_OK;
     // pixel-major gradient rows (the head's layout): whole channel rows per pixel, pad channels [K, stride_i) written as zeros
     if (stride_k == 1 && K <= kSmK && stride_i % 8 == 0 && stride_i >= K && stride_b % 8 == 0 && ((uintptr_t)gin_bf16 & 15) == 0)
-        hipLaunchKernelGGL(softmax2d_bwd_pixmajor_kernel, dim3(B, softmax_slices(B, n)), dim3(1024), 0, (hipStream_t)stream, prob, gprob, K, n,
+        hipLaunchKernelGGL(softmax2d_bwd_pixmajor_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, prob, gprob, K, n,
                            (unsigned short*)gin_bf16, stride_b, stride_i);
     else
         hipLaunchKernelGGL(softmax2d_bwd_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, prob, gprob, K, n, (unsigned short*)gin_bf16,

@@ -85,7 +85,7 @@ def test_unimodal_mse_matches_oracle():
     assert loss0 == 0.0 and not grad0.any()
 
 
-@pytest.mark.parametrize("b,k,n,c", [(2, 5, 48, 8), (2, 17, 2300, 64), (1, 5, 70, 6), (2, 17, 4101, 64), (1, 3, 9216, 8)])   # (n >= 4096: four workgroups share a frame)
+@pytest.mark.parametrize("b,k,n,c", [(2, 5, 48, 8), (2, 17, 2300, 64), (1, 5, 70, 6), (2, 17, 4101, 64), (1, 3, 9216, 8)])
 def test_softmax2d_fwd_bwd(b, k, n, c):
     """forward + backward; c % 8 == 0 takes the pixel-major backward (whole channel rows, pad channels zeroed by the kernel: the output
     buffer is pre-filled with garbage to prove it), c = 6 the per-map fallback (pad channels untouched: pre-filled with zeros)"""
