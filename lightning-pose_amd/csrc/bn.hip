@@ -596,6 +596,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
 // written: the pooled value is max over the window of bf16(relu(bn(z))) - each tap rounded exactly as lp_bn_apply would have
 // stored it, so values AND arg-max ties equal the unfused lp_bn_apply -> lp_maxpool_fwd - and the backward kernels rebuild the
 // activation's gradient on the fly from the pooled gradient, the arg-max bytes and z (ReLU gate: o > 2^-134, see bn_apply_kernel).
+// (Measured and dropped, round 6 - this kernel runs at 2.8 - 3.0 TB/s of its bytes and neither memory latency nor L2 locality is why: requesting all
+// nine taps before the first is used (clamped addresses + validity flags instead of the border branches: 92 VGPRs) 137.4 -> 136.9 us at 64 frames,
+// 291 -> 294 at 128; an XCD-aware row order, so that the input row two neighbouring output rows share is fetched into one L2, 139.0 -> 136.9 and
+// 296 -> 303; the step unchanged both times (profiles/r06p_*, r06q_*, retired/r06_pool_fwd_*.patch).  What is left is its arithmetic: every input value
+// is normalised, rounded and compared in each of the 2.25 windows it belongs to, ~650 VALU instructions per 16 output bytes.)
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const unsigned short* __restrict__ Z, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, int B, int Hi, int Wi, int C, int Ho,
