@@ -434,7 +434,10 @@ def fit_line(args, dev, rank: int, world: int) -> dict:
     FrameWindowSource (pinned copy on a side stream, one window ahead) -> VideoFramePipeline (antialiased resize + normalise) /
     LabeledBatchProducer (bicubic resize, keypoint projection, heat-map targets, all on the device) -> the same step as the headline line.
     PCIe-inclusive by construction (56 MB of video frames + 31 MB of labeled images per step); the logged scalars reach the host every
-    `log_every_n_steps` only.  Timed: one fit() of `steps` batches after a warm-up fit() of `warmup`."""
+    `log_every_n_steps` only.  Timed: one fit() of `steps` batches after a warm-up fit() of `warmup`.  A fit() call itself costs ~10 ms
+    (loader set-up, the epoch-end record's synchronisation): 44.5 / 43.8 / 43.3 / 43.0 ms per step at 6 / 12 / 24 / 48 timed steps next to
+    41.6 for the resident batch on the same box (profiles/r06s_fit_steps.txt), i.e. +2.9 % per step in a long run; the default run's
+    secondary line times 24 steps (rounds 4 - 5 timed 6 and read -6 %)."""
     from lightning_pose_amd.data.producers import FrameWindowSource, HostStager, LabeledBatchProducer, VideoFramePipeline
     from lightning_pose_amd.trainer import Trainer
 
@@ -757,7 +760,7 @@ def main(argv: list[str] | None = None, device: torch.device | None = None) -> N
             sec = {}
             for tag, over in (("resnet50_256", dict(size=256)), ("resnet50_384_unfrozen_backbone", dict(unfrozen=True)),
                               ("resnet50_384_peaked_maps", dict(peaked=True, warmup=4, steps=5)),
-                              ("resnet50_384_trainer_fit", dict(fit=True, warmup=2, steps=6)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
+                              ("resnet50_384_trainer_fit", dict(fit=True, warmup=2, steps=24)), ("c4_vits_dino_384", dict(backbone="vits_dino")),
                               ("c5_multiview_4x256", dict(views=4, size=256, labeled=16, unlabeled=32)),
                               ("predict_resnet50_384", dict(predict=True)), ("predict_vits_dino_384", dict(predict=True, backbone="vits_dino")),
                               # the reference trains fp32 only (train.py:411-428): the same step at its precision, on the fp32 validation executor
