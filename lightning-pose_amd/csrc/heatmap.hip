@@ -301,10 +301,15 @@ __global__ __launch_bounds__(1024) void softmax2d_pixmajor_kernel(const float* _
     }
     for (int i = tid; i < n; i += 1024) {
         const f32x4* row = reinterpret_cast<const f32x4*>(src + (size_t)i * si);
+        // the pixel's pieces are all requested before the first is used (round 6: behind one `if (q < k4)` each they were k4 dependent memory
+        // latencies per pixel, with 16 waves per CU to hide them); a piece index past k4 reads piece k4 - 1 again and is dropped
+        f32x4 piece[kSmK / 4];
+#pragma unroll
+        for (int q = 0; q < kSmK / 4; ++q) piece[q] = row[q < k4 ? q : k4 - 1];
 #pragma unroll
         for (int q = 0; q < kSmK / 4; ++q) {
             if (q < k4) {
-                const f32x4 v = row[q];
+                const f32x4 v = piece[q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = q * 4 + e;
@@ -350,10 +355,13 @@ __global__ __launch_bounds__(1024) void softmax2d_pixmajor_kernel(const float* _
     float* dst = out + (size_t)b * K * n;
     for (int i = tid; i < n; i += 1024) {
         const f32x4* row = reinterpret_cast<const f32x4*>(src + (size_t)i * si);
+        f32x4 piece[kSmK / 4];
+#pragma unroll
+        for (int q = 0; q < kSmK / 4; ++q) piece[q] = row[q < k4 ? q : k4 - 1];
 #pragma unroll
         for (int q = 0; q < kSmK / 4; ++q) {
             if (q < k4) {
-                const f32x4 v = row[q];
+                const f32x4 v = piece[q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = q * 4 + e;
@@ -390,17 +398,30 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
     float dot[kSmK];
 #pragma unroll
     for (int k = 0; k < kSmK; ++k) dot[k] = 0.f;
+    // The maps are read EIGHT at a time, all sixteen loads requested before the first product (round 6).  With one `if (k < K)` around each
+    // pair of loads the compiler could not move a load above the branch in front of it, so a lane waited for memory K times per pixel with two
+    // loads in flight - and this kernel has 16 waves per CU to hide that with: 250 of its 350 us were this loop.  A map index past K reads map
+    // K - 1 again (a valid address) and its product is dropped.
     for (int i = tid; i < n; i += 1024) {
         // (one walking pointer per tensor: indexed as p[k n + i] the unrolled loop keeps 2 x 32 map base addresses alive - more than the
         //  scalar file holds - and the kernel, capped at 128 registers by its 1024 threads, spilled 38)
         const float* pk = p + i;
         const float* gk = g + i;
 #pragma unroll
-        for (int k = 0; k < kSmK; ++k) {
-            if (k < K) {
-                dot[k] = fmaf(*pk, *gk, dot[k]);
-                pk += n;
-                gk += n;
+        for (int k0 = 0; k0 < kSmK; k0 += 8) {
+            if (k0 < K) {   // (workgroup-uniform)
+                float pv[8], gv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const size_t o = (size_t)(k0 + e < K ? e : K - 1 - k0) * n;
+                    pv[e] = pk[o];
+                    gv[e] = gk[o];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + e < K) dot[k0 + e] = fmaf(pv[e], gv[e], dot[k0 + e]);
+                pk += (size_t)8 * n;
+                gk += (size_t)8 * n;
             }
         }
     }
@@ -425,15 +446,21 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
         const float* gk = g + i;
         for (int c = 0; c < chunks; ++c) {
             float o[8];
+            if (c * 8 < K) {   // (workgroup-uniform) the chunk's maps, all requested before the first is used; past K: map K - 1 again, dropped
+                float pv[8], gv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = c * 8 + e;
-                o[e] = 0.f;
-                if (k < K) {
-                    o[e] = *pk * (*gk - fin[k]);
-                    pk += n;
-                    gk += n;
+                for (int e = 0; e < 8; ++e) {
+                    const size_t off = (size_t)(c * 8 + e < K ? e : K - 1 - c * 8) * n;
+                    pv[e] = pk[off];
+                    gv[e] = gk[off];
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = c * 8 + e < K ? pv[e] * (gv[e] - fin[c * 8 + e]) : 0.f;
+                pk += (size_t)8 * n;
+                gk += (size_t)8 * n;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
             }
             *reinterpret_cast<u16x8*>(dst + (size_t)i * si + c * 8) = pack_bf16x8(o);
         }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# r06u: the head soft-max kernels with their loads batched (eight maps / all pieces of a pixel requested before the first is used) against rounds 3 - 5 (build/liblp_hip_smrot0.so):
+# kernel durations from serialised traces of the step, the step itself alternating; r06t was the same comparison for a rotated walk (no effect: not channel conflicts)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+(timeout 600 python -m pytest tests/test_emu_losses.py -q -m gpu -x -p no:cacheprovider -k softmax 2>&1 | tail -2) | tee gpurun_out/r06u_pytest.txt
+for lib in smrot0 new; do
+  if [ $lib = new ]; then unset LP_HIP_LIB; else export LP_HIP_LIB=$GRAFT_REPO_ROOT/build/liblp_hip_$lib.so; fi
+  rm -rf /tmp/r06u_prof
+  LP_WGRAD_SIDE_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/r06u_prof -o t -- python bench.py --steps 6 --warmup 2 --no-secondary --no-cpu-baseline --no-profile > /dev/null 2>&1
+  python profiles/summarize_rocpd.py $(ls /tmp/r06u_prof/*results.db /tmp/r06u_prof/*/*results.db 2>/dev/null | head -1) 2>&1 | grep -i "softmax2d" | cut -c1-70,100-170 | sed "s/^/$lib /" | tee -a gpurun_out/r06u_softmax_kernels.txt
+done
+for i in 1 2 3; do
+  for lib in smrot0 new; do
+    if [ $lib = new ]; then unset LP_HIP_LIB; else export LP_HIP_LIB=$GRAFT_REPO_ROOT/build/liblp_hip_$lib.so; fi
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('softmax_rot=$lib', d['value'], d['ms_per_step'])" | tee -a gpurun_out/r06u_step_ab.txt
+  done
+done
