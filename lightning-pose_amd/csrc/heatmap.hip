@@ -392,6 +392,8 @@ __global__ __launch_bounds__(256) void softmax2d_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, int K,
                                                                       int n, unsigned short* __restrict__ gin, long sb, long si) {
     __shared__ float red[16][kSmK], fin[kSmK];
+    // pass 2's staging rows: a wave's 64 pixels x 8 chunks of 16 B, pitch 144 B (round 6, below)
+    __shared__ __attribute__((aligned(16))) unsigned short stage[16][64][72];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = prob + (size_t)b * K * n;
     const float* g = gprob + (size_t)b * K * n;
@@ -441,9 +443,16 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
     __syncthreads();
     unsigned short* dst = gin + (size_t)b * sb;
     const int chunks = (int)(si >> 3);
-    for (int i = tid; i < n; i += 1024) {
-        const float* pk = p + i;
-        const float* gk = g + i;
+    // A lane owns a pixel, and a pixel's row is `chunks` x 16 B: stored straight from the lane, every store instruction touched 64 different
+    // 128-B lines with 16 B each - 178 of this kernel's 285 us were those stores (timing builds, profiles/r06v_softmax_probe.txt).  With the
+    // head's 64-channel rows (chunks == 8) a wave now stages its 64 pixels x 128 B in LDS and writes them back as eight fully coalesced 1-KB
+    // pieces (lane -> pixel lane / 8 of the piece, chunk lane % 8).
+    const bool via_lds = chunks == 8;
+    for (int i0 = wave * 64; i0 < n; i0 += 1024) {
+        const int i = i0 + lane;
+        const bool live = i < n;
+        const float* pk = p + (live ? i : n - 1);
+        const float* gk = g + (live ? i : n - 1);
         for (int c = 0; c < chunks; ++c) {
             float o[8];
             if (c * 8 < K) {   // (workgroup-uniform) the chunk's maps, all requested before the first is used; past K: map K - 1 again, dropped
@@ -462,7 +471,18 @@ __global__ __launch_bounds__(1024) void softmax2d_bwd_pixmajor_kernel(const floa
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = 0.f;
             }
-            *reinterpret_cast<u16x8*>(dst + (size_t)i * si + c * 8) = pack_bf16x8(o);
+            if (via_lds) *reinterpret_cast<u16x8*>(&stage[wave][lane][c * 8]) = pack_bf16x8(o);
+            else if (live) *reinterpret_cast<u16x8*>(dst + (size_t)i * si + c * 8) = pack_bf16x8(o);
+        }
+        if (via_lds) {
+            __builtin_amdgcn_wave_barrier();   // (lanes exchange through the wave's own rows: lock step on the device)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = j * 8 + (lane >> 3), ii = i0 + px;
+                const u16x8 v = *reinterpret_cast<const u16x8*>(&stage[wave][px][(lane & 7) * 8]);
+                if (ii < n) *reinterpret_cast<u16x8*>(dst + (size_t)ii * si + (lane & 7) * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
