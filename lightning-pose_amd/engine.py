@@ -624,7 +624,8 @@ class Engine:
         _, K, h, w = heat.shape
         n = h * w
         g_heat = g_heat.to(torch.float32).contiguous()
-        dcur = torch.zeros(B, h, w, CPAD, device=self.device, dtype=torch.bfloat16)
+        # (lp_softmax2d_bwd's pixel-major kernel - K <= 32 maps - writes every channel of a pixel's row, the pad channels as zeros: no fill needed)
+        dcur = (torch.empty if (self.final_softmax and K <= 32) else torch.zeros)(B, h, w, CPAD, device=self.device, dtype=torch.bfloat16)
         if self.final_softmax:
             check(self._lib.lp_softmax2d_bwd(_p(heat), _p(g_heat), B, K, n, _p(dcur), n * CPAD, CPAD, 1, ops._stream()), "lp_softmax2d_bwd")
         else:
