@@ -214,18 +214,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();  // sP, sK, sV are free again
     }
 
-    // O[q][h*64 + d]: reg e of block db is d = db*32 + (e&3) + 8*(e>>2) + 4*half -> 4 consecutive d per store
-    const int q = q0 + wave * 32 + col;
-    if (active && q < T) {
-        unsigned short* orow = a.out + ((size_t)b * T + q) * a.ldo + h * kAD;
+    // O[q][h*64 + d]: reg e of block db is d = db*32 + (e&3) + 8*(e>>2) + 4*half -> 4 consecutive d (8 B) per lane and piece.  A lane owns a
+    // query ROW, so written straight from the registers every store instruction touched 32 rows with 16 B each: 66 of the kernel's 407 us for
+    // a tensor a tenth of P's size (timing builds, profiles/r06x_attn_probe.txt).  The wave's 32 rows go through its own rows of sP (free
+    // since the last tile's closing barrier) and leave as 16-B pieces, 8 lanes per 128-B row (round 6).
+    if (active) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
                 const u32x2_t w = {pack_bf16x2(o[db][4 * g4], o[db][4 * g4 + 1]), pack_bf16x2(o[db][4 * g4 + 2], o[db][4 * g4 + 3])};
-                *reinterpret_cast<u32x2_t*>(orow + db * 32 + 8 * g4 + 4 * half) = w;
+                *reinterpret_cast<u32x2_t*>(&sP[(wave * 32 + col) * kLDP + db * 32 + 8 * g4 + 4 * half]) = w;
             }
+        __builtin_amdgcn_wave_barrier();   // (lanes exchange through the wave's own rows: lock step on the device)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = j * 8 + (lane >> 3), q = q0 + wave * 32 + row;
+            if (q < T)
+                *reinterpret_cast<u16x8*>(a.out + ((size_t)b * T + q) * a.ldo + h * kAD + (lane & 7) * 8) =
+                    *reinterpret_cast<const u16x8*>(&sP[(wave * 32 + row) * kLDP + (lane & 7) * 8]);
+        }
     }
 }
 
@@ -416,6 +425,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnBwdArgs a) {
         __syncthreads();  // the tiles are free for the next staging
     }
 
+    // dV / dK rows: a lane owns a KEY row (8-B pieces of it), so written straight from the registers every store instruction touches 32 rows
+    // with 16 B each - the forward kernel's O store in the same form cost a sixth of that kernel (profiles/r06x_attn_probe.txt).  With 16-B
+    // aligned rows the wave's 32 rows of each tensor go through its own slice of sP (free since the loop's closing barrier; pitch 72) and leave as
+    // 16-B pieces, 8 lanes per 128-B row (round 6); other pitches keep the direct form.
+    if (active && ((a.ld_dqkv | a.dk_off | a.dv_off) & 7) == 0) {
+        unsigned short* stg = sP + wave * (32 * 72);
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                    const f32x16& src = which == 0 ? dv[db] : dk[db];
+                    const u32x2_t w = {pack_bf16x2(src[4 * g4], src[4 * g4 + 1]), pack_bf16x2(src[4 * g4 + 2], src[4 * g4 + 3])};
+                    *reinterpret_cast<u32x2_t*>(&stg[col * 72 + db * 32 + 8 * g4 + 4 * half]) = w;
+                }
+            __builtin_amdgcn_wave_barrier();   // (lanes exchange through the wave's own rows: lock step on the device)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = j * 8 + (lane >> 3), kvr = kv0 + wave * 32 + r;
+                if (kvr < T)
+                    *reinterpret_cast<u16x8*>(a.dqkv + ((size_t)b * T + kvr) * a.ld_dqkv + h * kAD + (which == 0 ? a.dv_off : a.dk_off) + (lane & 7) * 8) =
+                        *reinterpret_cast<const u16x8*>(&stg[r * 72 + (lane & 7) * 8]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     const int kv = kv0 + wave * 32 + col;
     if (active && kv < T) {
         unsigned short* row = a.dqkv + ((size_t)b * T + kv) * a.ld_dqkv + h * kAD;
