@@ -26,6 +26,16 @@ constexpr int kLDK = kAD + 8;     // K tile pitch: 144 B, conflict-free 16-B fra
 constexpr int kLDV = kAD + 32;    // V tile pitch: +64 B so the 4 rows of a transpose read fall in distinct bank quarters
 constexpr int kLDP = kAK + 8;     // P staging pitch
 
+// 2^x as ONE instruction (v_exp_f32); the soft-max below works in base 2 - scores x (scale log2 e), maxima and sums in that unit - so an
+// exponential is a subtraction (or one FMA from the raw score) and a v_exp, not multiply + subtract + multiply + v_exp (round 6)
+__device__ __forceinline__ float exp2_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return exp2f(x);
+#endif
+}
+
 struct AttnArgs {
     const unsigned short* qkv;  // [B*T][ld] bf16 token rows; Q at column h*64, K at k_off + h*64, V at v_off + h*64
     int ld, k_off, v_off;
@@ -51,6 +61,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int b = z / a.nh, h = z - b * a.nh;
     const int T = a.T;
     const int q0 = qt * kAQ;
+    const float sc2 = a.scale * 1.4426950408889634f;   // scores in base-2 units
     const unsigned short* Qp = a.qkv + (size_t)b * T * a.ld + h * kAD;
     const unsigned short* Kp = Qp + a.k_off;
     const unsigned short* Vp = Qp + a.v_off;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kv = t * kAK + blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    s[blk][e] = kv < T ? s[blk][e] * a.scale : -INFINITY;
+                    s[blk][e] = kv < T ? s[blk][e] * sc2 : -INFINITY;
                     tmax = fmaxf(tmax, s[blk][e]);
                 }
             const float mn = fmaxf(m, tmax);
@@ -124,8 +135,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) sum += __expf(s[blk][e] - mn);
-                l = l * __expf(m - mn) + sum;
+                    for (int e = 0; e < 16; ++e) sum += exp2_fast(s[blk][e] - mn);
+                l = l * exp2_fast(m - mn) + sum;
                 m = mn;
             }
         }
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     {   // merge the two halves of each query (lanes l and l^32)
         const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
         const float mt = fmaxf(m, mo);
-        l = (m > -INFINITY ? l * __expf(m - mt) : 0.f) + (mo > -INFINITY ? lo * __expf(mo - mt) : 0.f);
+        l = (m > -INFINITY ? l * exp2_fast(m - mt) : 0.f) + (mo > -INFINITY ? lo * exp2_fast(mo - mt) : 0.f);
         m = mt;
     }
     const float inv_l = active ? 1.f / l : 0.f;
@@ -167,8 +178,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     const int kv = t * kAK + blk * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    const float p0 = kv < T ? __expf(s[blk][e] * a.scale - m) * inv_l : 0.f;
-                    const float p1 = kv + 1 < T ? __expf(s[blk][e + 1] * a.scale - m) * inv_l : 0.f;
+                    const float p0 = kv < T ? exp2_fast(fmaf(s[blk][e], sc2, -m)) * inv_l : 0.f;
+                    const float p1 = kv + 1 < T ? exp2_fast(fmaf(s[blk][e + 1], sc2, -m)) * inv_l : 0.f;
                     pk[blk][e >> 1] = pack_bf16x2(p0, p1);
                 }
             // O^T += V^T P^T: k-slab j contracts the 16 keys held in regs 8*(j&1) .. +7 of block j>>1 (both halves)
